@@ -1,0 +1,198 @@
+/*
+ * mhe.h - C ABI of the MI355X-native multi-hypothesis hot path (libmhe_hip.so).
+ *
+ * The reference (GloryyrolG/MHEntropy) has no FFI layer: its boundary for this
+ * path is the Python module API (hand/network.py, hand/flows.py,
+ * hand/ManoLayer.py, hand/criteria.py).  Each entry point below replaces the
+ * arithmetic of one group of those functions; the Python classes in
+ * mhentropy_amd/ keep the reference's names/signatures and call in here through
+ * ctypes.  Citations are reference file:line.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (hipMalloc'ed / torch CUDA tensor
+ *    storage) unless the name ends in _host; the caller owns all memory, nothing
+ *    is allocated or freed inside, workspaces are passed in;
+ *  - `stream` is a hipStream_t (pass torch's current stream); all work is
+ *    enqueued asynchronously on it, nothing synchronises;
+ *  - return 0 on success, non-zero on error (mhe_last_error() gives the text);
+ *    no C++ exception crosses the ABI;
+ *  - hypothesis rows are SAMPLE-MAJOR like the reference's feat.repeat(N,1)
+ *    (hand/network.py:734): row r = n*B + b, R = N*B rows;
+ *  - all matrices are dense row-major with the stated shapes.
+ */
+#ifndef MHE_H
+#define MHE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MHE_OK 0
+#define MHE_ERR_ARG 1
+#define MHE_ERR_LAUNCH 2
+
+enum { MHE_ACT_NONE = 0, MHE_ACT_RELU = 1 };
+enum { MHE_F32 = 0, MHE_BF16 = 1 };
+enum { MHE_FLOW_FORWARD = 0, MHE_FLOW_INVERSE = 1 };
+
+/* library ---------------------------------------------------------------- */
+int         mhe_abi_version(void);
+const char *mhe_last_error(void);
+
+/* dense layers ------------------------------------------------------------
+ * Y[M,N] = act(X[M,K] * W[N,K]^T + bias[N]); W is torch.nn.Linear's layout.
+ * Replaces: BasicEnc.l1 (hand/network.py:87,121), MHEnt.det_head
+ * (hand/network.py:380-383,747) and the per-image conditioning projections
+ * c0/c1 of every coupling net (hand/flows.py:108-109) - evaluated once per
+ * image instead of once per hypothesis row.  `bias` may be NULL.
+ * f32 in / f32 accumulate on v_mfma_f32_16x16x4_f32 (bit-level = fmaf chain). */
+int mhe_linear_f32(const float *X, const float *W, const float *bias, float *Y,
+                   int M, int N, int K, int act, void *stream);
+
+/* conditional RealNVP ----------------------------------------------------- */
+
+/* Geometry of the packed weight stream for one coupling network
+ * (dim -> hidden -> hidden -> dim, hand/flows.py:86-89). */
+size_t mhe_flow_packed_floats_per_net(int dim, int hidden);
+
+/* Pack one network's three Linear weights (torch layout, W0[hidden,dim],
+ * W1[hidden,hidden], W2[dim,hidden]; hand/flows.py:87-89) from HOST memory into
+ * the MFMA-fragment-ordered stream the coupling kernel consumes.  Pure data
+ * movement, done when weights change.  `out_host` holds
+ * mhe_flow_packed_floats_per_net() floats. */
+int mhe_flow_pack_net_host(const float *W0_host, const float *W1_host, const float *W2_host,
+                           int dim, int hidden, float *out_host);
+
+/* All couplings of RealNVP.forward_p (z -> x, hand/flows.py:210-217) or
+ * RealNVP.backward_p (x -> z, hand/flows.py:219-227) in one launch.
+ *   in, out      [R, dim]      flow variable before / after (may alias)
+ *   cond         [B, 2*ncoup, 2, hidden]  per image, per net (net index = 2*i for
+ *                s_i, 2*i+1 for t_i), per hidden layer j: c_j(feat) + c_j.bias +
+ *                l_j.bias (hand/flows.py:105-117) - produced with mhe_linear_f32
+ *   wstream      [2*ncoup] packed nets (mhe_flow_pack_net_host), same net order
+ *   bias2        [2*ncoup, dim]  l_2.bias of every net
+ *   mask         [ncoup, dim]    RealNVP.mask (hand/flows.py:153-155,188)
+ *   sum_s        [R]  out: sum_i sum_d s_i,d  (forward: log|det dx/dz|;
+ *                inverse: equals -log_det_J of hand/flows.py:226)
+ *   log_prob     [R]  out: log q(x) = logN(z;0,I) -+ sum_s, i.e. what
+ *                RealNVP.log_prob returns (hand/flows.py:314-320); in FORWARD
+ *                mode it is evaluated from the sampling pass itself (z = `in`),
+ *                SURVEY.md appendix A2(ii).  May be NULL.
+ * Row r uses image r % B (sample-major rows).  hidden must be a multiple of 64,
+ * dim <= 48. */
+int mhe_flow_couplings_f32(const float *in, float *out, const float *cond,
+                           const float *wstream, const float *bias2, const float *mask,
+                           float *sum_s, float *log_prob,
+                           int R, int B, int dim, int hidden, int ncoup, int direction,
+                           void *stream);
+
+/* MANO decode + likelihood ------------------------------------------------- */
+
+/* Number of floats of the packed MANO table blob (layout: mhentropy_amd/mano_pack.py). */
+size_t mhe_mano_table_floats(void);
+
+/* Fused loss-pass decoder: z assembly (hand/network.py:703-717), PCA pose +
+ * Rodrigues + kinematic chain + the 21 joints (hand/manopth/manolayer.py:131-273;
+ * only the 5 fingertip vertices are skinned), RHD reorder (hand/ManoLayer.py:54-56),
+ * root/bone normalisation (hand/utils.py:46-66), orthographic projection
+ * (hand/ManoLayer.py:150-165), visibility-masked Laplace log-likelihood and the
+ * soft box/ball priors (hand/network.py:155-165,233-258,640-662), parameter
+ * norms (hand/network.py:787-788).  One wavefront per hypothesis row.
+ *   th45   [R,45]   flow sample            det [B,16] = det_head output
+ *   crop_uv [B,42], vis [B,21]  targets (may be NULL when terms == NULL)
+ *   tables  packed blob
+ * outputs (each may be NULL):
+ *   z [R,61], xyz [R,63] normalised joints, uv [R,42],
+ *   terms [R,4] = log p(uv|z), log p(th3), log p(th45), log p(bt); log_p [R] their sum,
+ *   norms [R,2] = |theta|, |beta|,
+ *   joints_mm [R,63] the un-normalised `mano_joints` (mm, centred on joint 9, RHD order).
+ * inv_norm != 0 maps uv to pixels ((uv+1)/2*image_size) as MHEnt.sample does. */
+int mhe_mano_joints_f32(const float *th45, const float *det, const float *crop_uv, const float *vis,
+                        const float *tables,
+                        float *z, float *xyz, float *uv, float *terms, float *log_p, float *norms,
+                        float *joints_mm, int R, int B, float laplace_b, float th45_alpha, int inv_norm, float image_size,
+                        void *stream);
+
+/* Full 778-vertex linear-blend skinning for MHEnt.sample
+ * (hand/manopth/manolayer.py:181-246, hand/network.py:480): verts [R,778,3]
+ * normalised like xyz ((mesh - root)/bone), or with mm_mode != 0 the `mesh`
+ * output of ManoLayer.forward (mm, centred on joint 9).  z [R,61] as written by
+ * mhe_mano_joints_f32. */
+int mhe_mano_verts_f32(const float *z, const float *tables, float *verts, int R, int mm_mode, void *stream);
+
+/* ManoLayer.xyz_from_vertice (hand/ManoLayer.py:108-148) + RHD reorder (:54-56):
+ * verts [R,778,3] -> joints [R,21,3] (the wrapper's 'joints' output, unused by MHEnt). */
+int mhe_mano_regress_joints_f32(const float *verts, const float *tables, float *joints, int R, void *stream);
+
+/* mean over the N hypotheses of each image and the ELBO
+ * (hand/network.py:793,801-808): rows [N*B] -> [B].
+ *   q_log_p[b] = mean_n log_p_rows[n*B+b];  h[b] = mean_n -log_q_rows[n*B+b];
+ *   log_p[b] = h[b] + q_log_p[b] */
+int mhe_elbo_reduce_f32(const float *log_p_rows, const float *log_q_rows,
+                        float *q_log_p, float *h, float *log_p, int N, int B, void *stream);
+
+/* image encoder ------------------------------------------------------------
+ * NHWC convolution as an implicit GEMM on MFMA, replacing the torchvision
+ * ResNet trunk the reference builds (hand/network.py:54-61,110).
+ *   x   [B,H,W,Cin]      w [Cout,KH,KW,Cin] (packed from torch's [Cout,Cin,KH,KW])
+ *   y   [B,Ho,Wo,Cout]
+ *   in_scale/in_shift [Cin] (optional): the producer's BatchNorm folded to
+ *       relu(x*scale+shift) applied while loading (padding stays zero)
+ *   out_scale/out_shift [Cout] (optional, eval-mode BN), residual (optional,
+ *       [B,Ho,Wo,Cout]), relu flag: y = act(conv*scale+shift + residual)
+ *   stats [2,Cout] (optional): += per-channel sum and sum of squares of the raw
+ *       conv output (train-mode BatchNorm batch statistics); must be zeroed by
+ *       the caller.
+ * dtype is the storage type of x, w, y, residual (MHE_F32 or MHE_BF16);
+ * accumulation is always f32. */
+typedef struct mhe_conv_desc {
+    int B, H, W, Cin, Cout, KH, KW, stride, pad;
+    int dtype;
+    int relu_in;   /* apply relu after in_scale/in_shift */
+    int relu_out;
+} mhe_conv_desc;
+
+int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y,
+                    const float *in_scale, const float *in_shift,
+                    const float *out_scale, const float *out_shift, const void *residual,
+                    float *stats, void *stream);
+
+/* BatchNorm batch statistics -> affine (train mode), torch semantics
+ * (momentum 0.1, eps 1e-5, unbiased running_var):
+ *   mean = sum/n, var = sumsq/n - mean^2; scale = gamma/sqrt(var+eps);
+ *   shift = beta - mean*scale; running stats updated in place when non-NULL. */
+int mhe_bn_finalize(const float *stats, const float *gamma, const float *beta,
+                    float *running_mean, float *running_var, float *scale, float *shift,
+                    int C, float count, float momentum, float eps, void *stream);
+
+/* y = relu?(x*scale+shift (+ r*r_scale+r_shift | + r)) elementwise over NHWC
+ * [P,C]; the bottleneck tail bn3 + identity + relu (torchvision Bottleneck). */
+int mhe_bn_act_nhwc(const void *x, const float *scale, const float *shift,
+                    const void *res, const float *res_scale, const float *res_shift,
+                    void *y, long P, int C, int relu, int dtype, void *stream);
+
+/* 3x3/2 max pool with pad 1 over relu(x*scale+shift), NHWC (stem). */
+int mhe_maxpool3x3s2_nhwc(const void *x, const float *scale, const float *shift, void *y,
+                          int B, int H, int W, int C, int dtype, void *stream);
+
+/* global average pool NHWC [B,HW,C] -> f32 [B,C]. */
+int mhe_avgpool_nhwc(const void *x, float *y, int B, int HW, int C, int dtype, void *stream);
+
+/* NCHW f32 image -> NHWC (dtype), stem input layout change. */
+int mhe_nchw_to_nhwc(const float *x, void *y, int B, int C, int H, int W, int dtype, void *stream);
+
+/* evaluation metrics ---------------------------------------------------------
+ * MHEntLoss metrics (hand/criteria.py:91-168): xyz [N,B,63] normalised joints,
+ * uv [N,B,42] pixels, targets pose3d [B,63], scale [B], crop_uv [B,42], vis [B,21].
+ * out [14,B], rows: for sup in (3d,2d): sample, sample_std, vis, vis_std,
+ * vis_mean, invis, invis_std  (key eucLoss_{sup}_rgb_{row}). */
+int mhe_metrics_f32(const float *xyz, const float *uv, const float *pose3d, const float *scale,
+                    const float *crop_uv, const float *vis, float *out, int N, int B, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MHE_H */

@@ -1,0 +1,66 @@
+"""ctypes binding of libmhe_hip.so (the C ABI declared in include/mhe.h).
+
+There is NO fallback: if the shared library is missing or a symbol cannot be
+bound, importing the product path fails loudly."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmhe_hip.so")
+
+_p, _i, _f, _sz, _l = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_long
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in
+                ("B", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad", "dtype", "relu_in", "relu_out")]
+
+
+# name -> (restype, argtypes); must list every symbol of include/mhe.h
+SIGNATURES = {
+    "mhe_abi_version": (_i, []),
+    "mhe_last_error": (C.c_char_p, []),
+    "mhe_linear_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "mhe_flow_packed_floats_per_net": (_sz, [_i, _i]),
+    "mhe_flow_pack_net_host": (_i, [_p, _p, _p, _i, _i, _p]),
+    "mhe_flow_couplings_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "mhe_mano_table_floats": (_sz, []),
+    "mhe_mano_joints_f32": (_i, [_p] * 12 + [_i, _i, _f, _f, _i, _f, _p]),
+    "mhe_mano_verts_f32": (_i, [_p, _p, _p, _i, _i, _p]),
+    "mhe_mano_regress_joints_f32": (_i, [_p, _p, _p, _i, _p]),
+    "mhe_elbo_reduce_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
+    "mhe_conv2d_nhwc": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "mhe_bn_finalize": (_i, [_p] * 7 + [_i, _f, _f, _f, _p]),
+    "mhe_bn_act_nhwc": (_i, [_p] * 7 + [_l, _i, _i, _i, _p]),
+    "mhe_maxpool3x3s2_nhwc": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "mhe_avgpool_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "mhe_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "mhe_metrics_f32": (_i, [_p] * 7 + [_i, _i, _p]),
+}
+
+_lib = None
+
+
+class MheError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the bound library; raise if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MheError(
+                f"{LIB_PATH} is missing: build it with `python -m mhentropy_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the export is absent
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise MheError(f"{what} failed ({status}): {lib().mhe_last_error().decode()}")

@@ -1,0 +1,16 @@
+// Library-level entry points: ABI version and the thread-local error text.
+#include "common.h"
+#include <cstring>
+
+namespace mhe {
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace mhe
+
+extern "C" int mhe_abi_version(void) { return 1; }
+extern "C" const char *mhe_last_error(void) { return mhe::g_err; }

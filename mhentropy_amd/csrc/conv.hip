@@ -1,0 +1,480 @@
+// NHWC convolution / dense layer as an implicit GEMM on MFMA (f32 or bf16 storage,
+// f32 accumulate), with the BatchNorm affine + ReLU of the PRODUCER folded into the
+// operand load, the BatchNorm affine / residual / ReLU of THIS layer folded into the
+// epilogue, and the train-mode batch statistics accumulated from the accumulators.
+//
+// Replaces the torchvision ResNet trunk the reference instantiates
+// (hand/network.py:54-61,110) and, with KH=KW=1, the Linear layers
+// (hand/network.py:87,121,380-383; hand/flows.py:108-109).
+//
+// GEMM view: y^T[n][m] = sum_k w[n][k] * xcol[m][k],  m = output pixel, n = output
+// channel, k = (kh, kw, cin) with cin fastest (NHWC keeps a k-chunk contiguous).
+// Both operands are staged as rows of 128 bytes of K (32 f32 / 64 bf16) in LDS,
+// 16-byte chunks XOR-swizzled by row so the ds_read_b128 fragment reads are
+// conflict-free.  A 16x16 MFMA tile reads one 16-byte chunk per lane per operand:
+//   f32 : 4 x v_mfma_f32_16x16x4_f32   (lane group q <-> k = 4q+i)
+//   bf16: 1 x v_mfma_f32_16x16x32_bf16 (lane group q <-> k = 8q+j)
+// The accumulator holds y^T (row = channel 4q+r, column = pixel lane&15), so each
+// lane owns 4 consecutive channels of one pixel: the epilogue's per-channel
+// scale/shift are one float4 load and the store is one 16 B (f32) / 8 B (bf16) write.
+#include "common.h"
+
+namespace mhe { namespace conv {
+
+struct Params {
+    const void *x; const void *w; void *y;
+    const float *in_scale, *in_shift, *out_scale, *out_shift;
+    const void *residual;
+    float *stats;
+    int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, M, Kpad, relu_in, relu_out;
+};
+
+constexpr int BM = 128;
+
+template <typename T> struct El;
+template <> struct El<float> { static constexpr int CE = 4; };
+template <> struct El<u16>   { static constexpr int CE = 8; };
+
+__device__ __forceinline__ int swz(int row, int slot) { return row * 8 + (slot ^ ((row >> 1) & 7)); }
+
+// apply relu(v*scale+shift) to one 16-byte chunk of activations
+template <typename T>
+__device__ __forceinline__ uint4 in_transform(uint4 raw, const float *sc, const float *sh, int c, int relu) {
+    if constexpr (sizeof(T) == 4) {
+        const float4 s = *reinterpret_cast<const float4 *>(sc + c), t = *reinterpret_cast<const float4 *>(sh + c);
+        float4 v = __builtin_bit_cast(float4, raw);
+        v.x = fmaf(v.x, s.x, t.x); v.y = fmaf(v.y, s.y, t.y); v.z = fmaf(v.z, s.z, t.z); v.w = fmaf(v.w, s.w, t.w);
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        return __builtin_bit_cast(uint4, v);
+    } else {
+        unsigned in[4] = {raw.x, raw.y, raw.z, raw.w}, o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float lo = __uint_as_float(in[i] << 16), hi = __uint_as_float(in[i] & 0xffff0000u);
+            lo = fmaf(lo, sc[c + 2 * i], sh[c + 2 * i]);
+            hi = fmaf(hi, sc[c + 2 * i + 1], sh[c + 2 * i + 1]);
+            if (relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+            o[i] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+        }
+        return make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+template <typename T, int BN, bool FAST>
+__global__ __launch_bounds__(256) void conv_kernel(const Params p) {
+    constexpr int CE = El<T>::CE, BKE = 8 * CE;
+    constexpr int NJ_B = BN / 32;           // weight chunks per thread per stage
+    constexpr int NTW = BN / 32;            // 16-wide channel tiles per wave
+    __shared__ uint4 lds[2][(BM + BN) * 8];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int q = lane >> 4, l15 = lane & 15;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int s = tid & 7, rbase = tid >> 3;
+    const T *xg = reinterpret_cast<const T *>(p.x);
+    const T *wg = reinterpret_cast<const T *>(p.w);
+
+    // ---- per-thread activation rows (4 rows, same 16-byte slot)
+    int hi0[4], wi0[4];
+    size_t xb[4];
+    bool mv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + rbase + 32 * j;
+        mv[j] = m < p.M;
+        const int mm = mv[j] ? m : 0;
+        const int wo = mm % p.Wo, t = mm / p.Wo, ho = t % p.Ho, b = t / p.Ho;
+        hi0[j] = ho * p.stride - p.pad;
+        wi0[j] = wo * p.stride - p.pad;
+        xb[j] = (size_t)b * p.H * p.W;
+    }
+    const int ntaps = p.KH * p.KW;
+    const int nk = p.Kpad / BKE;
+
+    uint4 ra[4], rb[NJ_B];
+    auto load_stage = [&](int ks) {
+        const int kc = ks * BKE + s * CE;
+        int tap, c;
+        if constexpr (FAST) { tap = (ks * BKE) / p.Cin; c = kc - tap * p.Cin; }
+        else                { tap = kc / p.Cin; c = kc - tap * p.Cin; }
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        const bool tv = tap < ntaps;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int hi = hi0[j] + kh, wi = wi0[j] + kw;
+            const bool ok = tv && mv[j] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                v = *reinterpret_cast<const uint4 *>(xg + ((xb[j] + (size_t)hi * p.W + wi) * p.Cin + c));
+                if (p.in_scale) v = in_transform<T>(v, p.in_scale, p.in_shift, c, p.relu_in);
+            }
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < NJ_B; ++j) {
+            const int n = n0 + rbase + 32 * j;
+            rb[j] = n < p.Cout ? *reinterpret_cast<const uint4 *>(wg + (size_t)n * p.Kpad + kc) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds[buf][swz(rbase + 32 * j, s)] = ra[j];
+#pragma unroll
+        for (int j = 0; j < NJ_B; ++j) lds[buf][BM * 8 + swz(rbase + 32 * j, s)] = rb[j];
+    };
+
+    v4f acc[NTW][4];
+#pragma unroll
+    for (int a = 0; a < NTW; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    int cur = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+        const bool more = ks + 1 < nk;
+        if (more) load_stage(ks + 1);
+        const uint4 *LA = lds[cur], *LB = lds[cur] + BM * 8;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 fa[4], fb[NTW];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) fa[mt] = LA[swz(wr * 64 + mt * 16 + l15, kk * 4 + q)];
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) fb[nt] = LB[swz(wc * (BN / 2) + nt * 16 + l15, kk * 4 + q)];
+            if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) {
+                            const float wv = __uint_as_float(reinterpret_cast<const unsigned *>(&fb[nt])[i]);
+                            const float xv = __uint_as_float(reinterpret_cast<const unsigned *>(&fa[mt])[i]);
+                            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc[nt][mt], 0, 0, 0);
+                        }
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fb[nt]),
+                            __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fa[mt]), acc[nt][mt], 0, 0, 0);
+            }
+        }
+        if (more) store_stage(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: lane owns channels n..n+3 (n = 4q + 16nt) of pixel m = 16mt + l15
+    T *yg = reinterpret_cast<T *>(p.y);
+    const T *rg = reinterpret_cast<const T *>(p.residual);
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int n = n0 + wc * (BN / 2) + nt * 16 + 4 * q;
+        const bool nv = n < p.Cout;           // Cout is a multiple of 4 (checked on the host)
+        float4 osc = make_float4(1.f, 1.f, 1.f, 1.f), osh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (nv && p.out_scale) osc = *reinterpret_cast<const float4 *>(p.out_scale + n);
+        if (nv && p.out_shift) osh = *reinterpret_cast<const float4 *>(p.out_shift + n);
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = m0 + wr * 64 + mt * 16 + l15;
+            const bool ok = nv && m < p.M;
+            v4f v = acc[nt][mt];
+            if (p.stats && ok) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s1[r] += v[r]; s2[r] = fmaf(v[r], v[r], s2[r]); }
+            }
+            v[0] = fmaf(v[0], osc.x, osh.x); v[1] = fmaf(v[1], osc.y, osh.y);
+            v[2] = fmaf(v[2], osc.z, osh.z); v[3] = fmaf(v[3], osc.w, osh.w);
+            if (!ok) continue;
+            const size_t off = (size_t)m * p.Cout + n;
+            if constexpr (sizeof(T) == 4) {
+                if (rg) { const float4 rr = *reinterpret_cast<const float4 *>(rg + off); v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
+                if (p.relu_out) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                *reinterpret_cast<float4 *>(yg + off) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                if (rg) {
+                    const uint2 rr = *reinterpret_cast<const uint2 *>(rg + off);
+                    v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+                    v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+                }
+                if (p.relu_out) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                uint2 o;
+                o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                *reinterpret_cast<uint2 *>(yg + off) = o;
+            }
+        }
+        if (p.stats) {
+            // sum the 16 pixels held by the lanes of one q-group, one atomic per channel per wave
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s1[r] += __shfl_xor(s1[r], o, 64); s2[r] += __shfl_xor(s2[r], o, 64); }
+            }
+            if (l15 == 0 && nv) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { atomicAdd(p.stats + n + r, s1[r]); atomicAdd(p.stats + p.Cout + n + r, s2[r]); }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float *__restrict__ stats, const float *__restrict__ gamma,
+                                   const float *__restrict__ beta, float *__restrict__ rmean, float *__restrict__ rvar,
+                                   float *__restrict__ scale, float *__restrict__ shift, int C, float count, float momentum,
+                                   float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mean = stats[c] / count;
+    const float var = fmaxf(stats[C + c] / count - mean * mean, 0.f);      // biased, as F.batch_norm normalises with
+    const float sc = gamma[c] / sqrtf(var + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+    if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * var * (count / (count - 1.f));
+}
+
+template <typename T> __device__ __forceinline__ void load4(const T *p, float *v);
+template <> __device__ __forceinline__ void load4<float>(const float *p, float *v) {
+    const float4 t = *reinterpret_cast<const float4 *>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void load4<u16>(const u16 *p, float *v) {
+    const uint2 t = *reinterpret_cast<const uint2 *>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void store4(T *p, const float *v);
+template <> __device__ __forceinline__ void store4<float>(float *p, const float *v) {
+    *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store4<u16>(u16 *p, const float *v) {
+    uint2 o;
+    o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+    o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+    *reinterpret_cast<uint2 *>(p) = o;
+}
+
+// y = relu?(x*scale+shift + (res*rscale+rshift | res))   4 channels per thread
+template <typename T>
+__global__ void bn_act_kernel(const T *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift,
+                              const T *__restrict__ res, const float *__restrict__ rscale, const float *__restrict__ rshift,
+                              T *__restrict__ y, size_t n4, int C, int relu) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * 4;
+        const int c = (int)(e % C);
+        float v[4], r[4];
+        load4<T>(x + e, v);
+        const float4 s = *reinterpret_cast<const float4 *>(scale + c), t = *reinterpret_cast<const float4 *>(shift + c);
+        v[0] = fmaf(v[0], s.x, t.x); v[1] = fmaf(v[1], s.y, t.y); v[2] = fmaf(v[2], s.z, t.z); v[3] = fmaf(v[3], s.w, t.w);
+        if (res) {
+            load4<T>(res + e, r);
+            if (rscale) {
+                const float4 rs = *reinterpret_cast<const float4 *>(rscale + c), rt = *reinterpret_cast<const float4 *>(rshift + c);
+                r[0] = fmaf(r[0], rs.x, rt.x); r[1] = fmaf(r[1], rs.y, rt.y); r[2] = fmaf(r[2], rs.z, rt.z); r[3] = fmaf(r[3], rs.w, rt.w);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += r[k];
+        }
+        if (relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        store4<T>(y + e, v);
+    }
+}
+
+// 3x3 stride-2 pad-1 max pool over relu(x*scale+shift); 4 channels per thread
+template <typename T>
+__global__ void maxpool_kernel(const T *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift,
+                               T *__restrict__ y, int B, int H, int W, int C, int Ho, int Wo) {
+    const size_t n4 = (size_t)B * Ho * Wo * C / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * 4;
+        const int c = (int)(e % C);
+        size_t t = e / C;
+        const int wo = (int)(t % Wo); t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        float4 s = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (scale) { s = *reinterpret_cast<const float4 *>(scale + c); sh = *reinterpret_cast<const float4 *>(shift + c); }
+        float m[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const int hi = 2 * ho - 1 + dh, wi = 2 * wo - 1 + dw;
+                if ((unsigned)hi >= (unsigned)H || (unsigned)wi >= (unsigned)W) continue;
+                float v[4];
+                load4<T>(x + (((size_t)b * H + hi) * W + wi) * C + c, v);
+                v[0] = fmaf(v[0], s.x, sh.x); v[1] = fmaf(v[1], s.y, sh.y); v[2] = fmaf(v[2], s.z, sh.z); v[3] = fmaf(v[3], s.w, sh.w);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], v[k]);
+            }
+        if (scale) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], 0.f);       // relu commutes with max
+        }
+        store4<T>(y + e, m);
+    }
+}
+
+// global average pool: block = (image b, 64-channel group); 4 pixel groups x 64 channels
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_kernel(const T *__restrict__ x, float *__restrict__ y, int HW, int C) {
+    __shared__ float part[4][64];
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    float a = 0.f;
+    if (c < C)
+        for (int p = g; p < HW; p += 4) {
+            if constexpr (sizeof(T) == 4) a += x[((size_t)b * HW + p) * C + c];
+            else a += bf16_to_f32(x[((size_t)b * HW + p) * C + c]);
+        }
+    part[g][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (g == 0 && c < C) y[(size_t)b * C + c] = (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) / (float)HW;
+}
+
+// NCHW f32 -> NHWC with the channel dimension zero-padded to Cp
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float *__restrict__ x, T *__restrict__ y, int B, int C, int HW, int Cp) {
+    const size_t n = (size_t)B * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / HW, p = i % HW;
+        for (int c = 0; c < Cp; ++c) {
+            const float v = c < C ? x[(b * C + c) * HW + p] : 0.f;
+            if constexpr (sizeof(T) == 4) y[i * Cp + c] = v;
+            else y[i * Cp + c] = f32_to_bf16(v);
+        }
+    }
+}
+
+template <typename T>
+static int launch_conv(const Params &p, hipStream_t s) {
+    constexpr int BKE = 8 * El<T>::CE;
+    const bool fast = (p.Cin % BKE) == 0;
+    const int bn = p.Cout <= 64 ? 64 : 128;
+    dim3 grid((p.M + BM - 1) / BM, (p.Cout + bn - 1) / bn);
+    if (bn == 64) {
+        if (fast) hipLaunchKernelGGL((conv_kernel<T, 64, true>), grid, dim3(256), 0, s, p);
+        else      hipLaunchKernelGGL((conv_kernel<T, 64, false>), grid, dim3(256), 0, s, p);
+    } else {
+        if (fast) hipLaunchKernelGGL((conv_kernel<T, 128, true>), grid, dim3(256), 0, s, p);
+        else      hipLaunchKernelGGL((conv_kernel<T, 128, false>), grid, dim3(256), 0, s, p);
+    }
+    return check_launch("conv_kernel");
+}
+
+}}  // namespace mhe::conv
+
+using namespace mhe;
+
+static inline int elem_chunk(int dtype) { return dtype == MHE_F32 ? 4 : 8; }
+
+extern "C" int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
+                               const float *in_shift, const float *out_scale, const float *out_shift,
+                               const void *residual, float *stats, void *stream) {
+    MHE_REQUIRE(d && x && w && y, "mhe_conv2d_nhwc: null pointer");
+    MHE_REQUIRE(d->dtype == MHE_F32 || d->dtype == MHE_BF16, "mhe_conv2d_nhwc: dtype=%d", d->dtype);
+    const int ce = elem_chunk(d->dtype), bke = 8 * ce;
+    MHE_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0,
+                "mhe_conv2d_nhwc: bad geometry");
+    MHE_REQUIRE(d->Cin % ce == 0, "mhe_conv2d_nhwc: Cin=%d must be a multiple of %d (pad channels)", d->Cin, ce);
+    MHE_REQUIRE(d->Cout % 4 == 0, "mhe_conv2d_nhwc: Cout=%d must be a multiple of 4", d->Cout);
+    MHE_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "mhe_conv2d_nhwc: in_scale/in_shift must come together");
+    conv::Params p;
+    p.x = x; p.w = w; p.y = y; p.in_scale = in_scale; p.in_shift = in_shift; p.out_scale = out_scale;
+    p.out_shift = out_shift; p.residual = residual; p.stats = stats;
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
+    p.stride = d->stride; p.pad = d->pad;
+    p.Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
+    p.Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+    MHE_REQUIRE(p.Ho > 0 && p.Wo > 0, "mhe_conv2d_nhwc: empty output");
+    const long long M = (long long)p.B * p.Ho * p.Wo;
+    MHE_REQUIRE(M < (1ll << 31), "mhe_conv2d_nhwc: too many output pixels");
+    p.M = (int)M;
+    const int ktot = d->KH * d->KW * d->Cin;
+    p.Kpad = (ktot + bke - 1) / bke * bke;       // weight rows are zero-padded to this length by the packer
+    p.relu_in = d->relu_in; p.relu_out = d->relu_out;
+    if (d->dtype == MHE_F32) return conv::launch_conv<float>(p, (hipStream_t)stream);
+    return conv::launch_conv<u16>(p, (hipStream_t)stream);
+}
+
+extern "C" int mhe_linear_f32(const float *X, const float *W, const float *bias, float *Y, int M, int N, int K, int act,
+                              void *stream) {
+    MHE_REQUIRE(X && W && Y && M > 0 && N > 0 && K > 0, "mhe_linear_f32: bad arguments");
+    MHE_REQUIRE(K % 32 == 0, "mhe_linear_f32: K=%d must be a multiple of 32", K);
+    MHE_REQUIRE(N % 4 == 0, "mhe_linear_f32: N=%d must be a multiple of 4", N);
+    mhe_conv_desc d = {M, 1, 1, K, N, 1, 1, 1, 0, MHE_F32, 0, act == MHE_ACT_RELU};
+    return mhe_conv2d_nhwc(&d, X, W, Y, nullptr, nullptr, nullptr, bias, nullptr, nullptr, stream);
+}
+
+extern "C" int mhe_bn_finalize(const float *stats, const float *gamma, const float *beta, float *running_mean,
+                               float *running_var, float *scale, float *shift, int C, float count, float momentum,
+                               float eps, void *stream) {
+    MHE_REQUIRE(stats && gamma && beta && scale && shift && C > 0 && count > 1.f, "mhe_bn_finalize: bad arguments");
+    hipLaunchKernelGGL(conv::bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, gamma,
+                       beta, running_mean, running_var, scale, shift, C, count, momentum, eps);
+    return check_launch("bn_finalize_kernel");
+}
+
+static inline int ew_blocks(size_t n) { size_t b = (n + 255) / 256; return (int)(b < 4096 ? (b ? b : 1) : 4096); }
+
+extern "C" int mhe_bn_act_nhwc(const void *x, const float *scale, const float *shift, const void *res,
+                               const float *res_scale, const float *res_shift, void *y, long P, int C, int relu,
+                               int dtype, void *stream) {
+    MHE_REQUIRE(x && scale && shift && y && P > 0 && C > 0 && C % 4 == 0, "mhe_bn_act_nhwc: bad arguments");
+    const size_t n4 = (size_t)P * C / 4;
+    if (dtype == MHE_F32)
+        hipLaunchKernelGGL(conv::bn_act_kernel<float>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream,
+                           (const float *)x, scale, shift, (const float *)res, res_scale, res_shift, (float *)y, n4, C, relu);
+    else
+        hipLaunchKernelGGL(conv::bn_act_kernel<u16>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream,
+                           (const u16 *)x, scale, shift, (const u16 *)res, res_scale, res_shift, (u16 *)y, n4, C, relu);
+    return check_launch("bn_act_kernel");
+}
+
+extern "C" int mhe_maxpool3x3s2_nhwc(const void *x, const float *scale, const float *shift, void *y, int B, int H, int W,
+                                     int C, int dtype, void *stream) {
+    MHE_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C % 4 == 0, "mhe_maxpool3x3s2_nhwc: bad arguments");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const size_t n4 = (size_t)B * Ho * Wo * C / 4;
+    if (dtype == MHE_F32)
+        hipLaunchKernelGGL(conv::maxpool_kernel<float>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream,
+                           (const float *)x, scale, shift, (float *)y, B, H, W, C, Ho, Wo);
+    else
+        hipLaunchKernelGGL(conv::maxpool_kernel<u16>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream,
+                           (const u16 *)x, scale, shift, (u16 *)y, B, H, W, C, Ho, Wo);
+    return check_launch("maxpool_kernel");
+}
+
+extern "C" int mhe_avgpool_nhwc(const void *x, float *y, int B, int HW, int C, int dtype, void *stream) {
+    MHE_REQUIRE(x && y && B > 0 && HW > 0 && C > 0, "mhe_avgpool_nhwc: bad arguments");
+    dim3 grid((C + 63) / 64, B);
+    if (dtype == MHE_F32)
+        hipLaunchKernelGGL(conv::avgpool_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)x, y, HW, C);
+    else
+        hipLaunchKernelGGL(conv::avgpool_kernel<u16>, grid, dim3(256), 0, (hipStream_t)stream, (const u16 *)x, y, HW, C);
+    return check_launch("avgpool_kernel");
+}
+
+extern "C" int mhe_nchw_to_nhwc(const float *x, void *y, int B, int C, int H, int W, int dtype, void *stream) {
+    MHE_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0, "mhe_nchw_to_nhwc: bad arguments");
+    const int Cp = (C + elem_chunk(dtype) - 1) / elem_chunk(dtype) * elem_chunk(dtype);
+    const size_t n = (size_t)B * H * W;
+    if (dtype == MHE_F32)
+        hipLaunchKernelGGL(conv::nchw_to_nhwc_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x,
+                           (float *)y, B, C, H * W, Cp);
+    else
+        hipLaunchKernelGGL(conv::nchw_to_nhwc_kernel<u16>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x,
+                           (u16 *)y, B, C, H * W, Cp);
+    return check_launch("nchw_to_nhwc_kernel");
+}

@@ -1,0 +1,437 @@
+// MANO forward kinematics, fingertip / full linear-blend skinning, projection and
+// the per-hypothesis log-likelihood + priors, one 64-lane wavefront per hypothesis.
+//
+// Reference arithmetic being replaced (all fp32):
+//   hand/manopth/manolayer.py:131-273, rodrigues_layer.py:15-54, tensutils.py:6-22,
+//   hand/ManoLayer.py:45-60,150-165, hand/utils.py:46-66,
+//   hand/network.py:155-165,233-258,455-558,612-667,703-717,787-788.
+//
+// HBM view (loss pass): reads 180 B (th45) per row + per-image det/crop_uv/vis,
+// writes <= 0.6 KB per row; the 19.5 KB of joint-section tables live in LDS.
+#include "common.h"
+#include "mano_layout.h"
+
+namespace mhe { namespace mano {
+
+// MANO joint j -> index into the level-ordered transform list is already folded:
+// G[j] below IS the global transform of MANO joint j (manolayer.py:228 reorder).
+// final joint k (RHD order) <- pre-reorder index (16 chain joints then 5 tips):
+// pre[ JOINT_REORDER[ FREIHAND2RHD[k] ] ]   (manolayer.py:260, utils.py:15, ManoLayer.py:54-56)
+__device__ constexpr int kJointReorder[21] = {0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20};
+__device__ constexpr int kFreihand2Rhd[21] = {0, 4, 3, 2, 1, 8, 7, 6, 5, 12, 11, 10, 9, 16, 15, 14, 13, 20, 19, 18, 17};
+constexpr int kCenterPre = 4;     // kJointReorder[center_idx = 9]   (manolayer.py:262-266)
+constexpr int kRootIdx = 12;      // hand/network.py:477
+constexpr int kNormIdx = 11;      // hand/network.py:478
+
+// per-wave LDS scratch (floats)
+constexpr int S_POSE = 0;      // [48]
+constexpr int S_ROT = 48;      // [16][9]
+constexpr int S_JR = 192;      // [16][3]  rest joints
+constexpr int S_G = 240;       // [16][12] global transform: R(9), t(3)
+constexpr int S_GR = 432;      // [16][12] R(9), t - R*j_rest
+constexpr int S_TIPV = 624;    // [5][3]   posed tip vertices (rest frame)
+constexpr int S_PRE = 640;     // [21][3]  chain joints + skinned tips
+constexpr int S_J21 = 704;     // [21][3]  final joints, mm, centred
+constexpr int SCRATCH = 768;
+
+__device__ __forceinline__ float bcast(float v, int srclane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srclane));
+}
+
+struct RowOut {
+    float xyz;      // lane < 63: normalised joint coordinate (joint lane/3, comp lane%3)
+    float bone;     // |J11 - J12| in mm
+    float center_c; // lane%3 component of the centring joint (metres, pre-centre)
+    float root_c;   // lane%3 component of final joint 12 (mm, centred)
+};
+
+// Everything up to the 21 normalised joints for one hypothesis.  `th45` lane<45,
+// `det` lane<16 = [th3(3) bt(10) logs t(2)] (hand/network.py:370-372 order).
+// tb = joint section of the table blob in LDS; sc = this wave's scratch.
+__device__ __forceinline__ RowOut joint_pass(const float *tb, float *sc, int lane, float th45, float det) {
+    // -- PCA coefficients -> axis-angle (manolayer.py:131-143)
+    {
+        float acc = 0.f;
+        const int lc = lane < 45 ? lane : 44;
+#pragma unroll
+        for (int k = 0; k < 45; ++k) acc = fmaf(bcast(th45, k), tb[COMPS + k * 45 + lc], acc);
+        if (lane < 45) sc[S_POSE + 3 + lane] = tb[MEAN + lc] + acc;
+        if (lane < 3) sc[S_POSE + lane] = det;
+    }
+    wave_sync();
+    // -- Rodrigues through a unit quaternion, 16 joints on 16 lanes
+    //    (rodrigues_layer.py:43-54, :15-40)
+    if (lane < 16) {
+        const float ax = sc[S_POSE + 3 * lane], ay = sc[S_POSE + 3 * lane + 1], az = sc[S_POSE + 3 * lane + 2];
+        const float px = ax + 1e-8f, py = ay + 1e-8f, pz = az + 1e-8f;
+        const float angle = sqrtf(px * px + py * py + pz * pz);
+        const float nx = ax / angle, ny = ay / angle, nz = az / angle;
+        const float half = angle * 0.5f;
+        const float cs = cosf(half), sn = sinf(half);
+        float w = cs, x = sn * nx, y = sn * ny, z = sn * nz;
+        const float qn = sqrtf(w * w + x * x + y * y + z * z);
+        w /= qn; x /= qn; y /= qn; z /= qn;
+        const float w2 = w * w, x2 = x * x, y2 = y * y, z2 = z * z;
+        const float wx = w * x, wy = w * y, wz = w * z, xy = x * y, xz = x * z, yz = y * z;
+        float *r = sc + S_ROT + 9 * lane;
+        r[0] = w2 + x2 - y2 - z2; r[1] = 2 * xy - 2 * wz;    r[2] = 2 * wy + 2 * xz;
+        r[3] = 2 * wz + 2 * xy;   r[4] = w2 - x2 + y2 - z2;  r[5] = 2 * yz - 2 * wx;
+        r[6] = 2 * xz - 2 * wy;   r[7] = 2 * wx + 2 * yz;    r[8] = w2 - x2 - y2 + z2;
+    }
+    // -- rest joints: J_regressor @ (template + shapedirs beta) is affine in beta
+    //    (manolayer.py:181-184; SURVEY.md A2 iii)
+    if (lane < 48) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) a = fmaf(tb[JSD + lane * 10 + k], bcast(det, 3 + k), a);
+        sc[S_JR + lane] = tb[JT + lane] + a;
+    }
+    wave_sync();
+    // -- kinematic chain root -> 3 levels, one finger per lane (manolayer.py:193-229)
+    if (lane < 5) {
+        float PR[9], Pt[3];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) PR[e] = sc[S_ROT + e];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Pt[c] = sc[S_JR + c];
+        if (lane == 0) {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) { sc[S_G + e] = PR[e]; sc[S_GR + e] = PR[e]; }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                sc[S_G + 9 + c] = Pt[c];
+                sc[S_GR + 9 + c] = Pt[c] - (PR[3 * c] * Pt[0] + PR[3 * c + 1] * Pt[1] + PR[3 * c + 2] * Pt[2]);
+            }
+        }
+        int parent = 0;
+#pragma unroll
+        for (int lvl = 0; lvl < 3; ++lvl) {
+            const int j = 1 + 3 * lane + lvl;
+            float Rj[9], rel[3], jr[3], CR[9], Ct[3];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) Rj[e] = sc[S_ROT + 9 * j + e];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { jr[c] = sc[S_JR + 3 * j + c]; rel[c] = jr[c] - sc[S_JR + 3 * parent + c]; }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+                    CR[3 * a + b] = PR[3 * a] * Rj[b] + PR[3 * a + 1] * Rj[3 + b] + PR[3 * a + 2] * Rj[6 + b];
+                Ct[a] = PR[3 * a] * rel[0] + PR[3 * a + 1] * rel[1] + PR[3 * a + 2] * rel[2] + Pt[a];
+            }
+#pragma unroll
+            for (int e = 0; e < 9; ++e) { sc[S_G + 12 * j + e] = CR[e]; sc[S_GR + 12 * j + e] = CR[e]; PR[e] = CR[e]; }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                sc[S_G + 12 * j + 9 + c] = Ct[c];
+                // subtract the rest-pose joint (manolayer.py:231-234)
+                sc[S_GR + 12 * j + 9 + c] = Ct[c] - (CR[3 * c] * jr[0] + CR[3 * c + 1] * jr[1] + CR[3 * c + 2] * jr[2]);
+                Pt[c] = Ct[c];
+            }
+            parent = j;
+        }
+    }
+    // -- pose-corrective blend of the 5 fingertip vertices (manolayer.py:187-188),
+    //    135 terms split over 4 lane groups
+    {
+        const int q = lane >> 4, tc = lane & 15, tcc = tc < 15 ? tc : 14;
+        const int k0 = q * 34, k1 = (k0 + 34 < 135) ? k0 + 34 : 135;
+        float part = 0.f;
+        for (int k = k0; k < k1; ++k) {
+            const int e = k % 9;
+            const float pm = sc[S_ROT + 9 + k] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+            part = fmaf(tb[TIP_PD + tcc * 135 + k], pm, part);
+        }
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+        float shaped = 0.f;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) shaped = fmaf(tb[TIP_SD + tcc * 10 + k], bcast(det, 3 + k), shaped);
+        if (lane < 15) sc[S_TIPV + lane] = (shaped + tb[TIP_T + lane]) + part;
+    }
+    wave_sync();
+    // -- skin the tips: T = sum_j w_j Gr_j ; v' = T [v;1]   (manolayer.py:236-246)
+    if (lane < 15) {
+        const int tip = lane / 3, c = lane % 3;
+        float T0 = 0.f, T1 = 0.f, T2 = 0.f, T3 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float w = tb[TIP_W + tip * 16 + j];
+            const float *g = sc + S_GR + 12 * j;
+            T0 = fmaf(g[3 * c], w, T0); T1 = fmaf(g[3 * c + 1], w, T1); T2 = fmaf(g[3 * c + 2], w, T2);
+            T3 = fmaf(g[9 + c], w, T3);
+        }
+        const float *v = sc + S_TIPV + 3 * tip;
+        sc[S_PRE + 48 + lane] = T0 * v[0] + T1 * v[1] + T2 * v[2] + T3;
+    }
+    if (lane < 48) sc[S_PRE + lane] = sc[S_G + 12 * (lane / 3) + 9 + lane % 3];
+    wave_sync();
+    // -- reorder, centre on joint 9, metres -> mm (manolayer.py:260-273, ManoLayer.py:54-56)
+    RowOut o;
+    const int c3 = lane % 3;
+    const int k21 = lane < 63 ? lane / 3 : 20;
+    const int src = kJointReorder[kFreihand2Rhd[k21]];
+    o.center_c = sc[S_PRE + 3 * kCenterPre + c3];
+    const float J = (sc[S_PRE + 3 * src + c3] - o.center_c) * 1000.f;
+    if (lane < 63) sc[S_J21 + lane] = J;
+    wave_sync();
+    // -- root-relative, bone-length normalised (hand/utils.py:46-66)
+    o.root_c = sc[S_J21 + 3 * kRootIdx + c3];
+    const float d0 = sc[S_J21 + 3 * kNormIdx] - sc[S_J21 + 3 * kRootIdx];
+    const float d1 = sc[S_J21 + 3 * kNormIdx + 1] - sc[S_J21 + 3 * kRootIdx + 1];
+    const float d2 = sc[S_J21 + 3 * kNormIdx + 2] - sc[S_J21 + 3 * kRootIdx + 2];
+    o.bone = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+    o.xyz = (J - o.root_c) / o.bone;
+    return o;
+}
+
+__global__ __launch_bounds__(256) void mano_joints_kernel(
+    const float *__restrict__ th45_g, const float *__restrict__ det_g, const float *__restrict__ crop_uv,
+    const float *__restrict__ vis, const float *__restrict__ tables,
+    float *__restrict__ z_o, float *__restrict__ xyz_o, float *__restrict__ uv_o, float *__restrict__ terms_o,
+    float *__restrict__ logp_o, float *__restrict__ norms_o, float *__restrict__ jmm_o,
+    int R, int B, float lap_b, float th45_alpha, int inv_norm, float image_size) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *tb = smem;
+    for (int i = threadIdx.x; i < JOINT_FLOATS / 4; i += 256)
+        reinterpret_cast<float4 *>(tb)[i] = reinterpret_cast<const float4 *>(tables)[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *sc = smem + JOINT_FLOATS + wave * SCRATCH;
+    const float log2b = logf(2.f * lap_b);
+
+    for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
+        const int b = r % B;
+        const float th45 = lane < 45 ? th45_g[(size_t)r * 45 + lane] : 0.f;
+        const float det = lane < 16 ? det_g[b * 16 + lane] : 0.f;
+        const RowOut o = joint_pass(tb, sc, lane, th45, det);
+
+        if (xyz_o && lane < 63) xyz_o[(size_t)r * 63 + lane] = o.xyz;
+        if (jmm_o && lane < 63) jmm_o[(size_t)r * 63 + lane] = sc[S_J21 + lane];
+        // -- orthographic projection (hand/network.py:497-514, ManoLayer.py:150-165)
+        const float s_cam = expf(bcast(det, 13));
+        const float t_cam = (lane & 1) ? bcast(det, 15) : bcast(det, 14);
+        const int lu = lane < 42 ? lane : 41;
+        float uv = s_cam * __shfl(o.xyz, 3 * (lu >> 1) + (lu & 1), 64) + t_cam;
+        if (inv_norm) uv = (uv + 1.f) / 2.f * image_size;
+        if (uv_o && lane < 42) uv_o[(size_t)r * 42 + lane] = uv;
+
+        if (z_o) {      // z = [th3 th45 bt logs t]  (hand/network.py:703-717)
+            const float a = __shfl(th45, lane >= 3 ? lane - 3 : 0, 64);
+            const float d = __shfl(det, lane >= 45 ? lane - 45 : 0, 64);
+            if (lane < 61) z_o[(size_t)r * 61 + lane] = lane < 3 ? det : (lane < 48 ? a : d);
+        }
+        // |theta|, |beta|  (hand/network.py:787-788)
+        const float th_sq = wave_sum((lane < 45 ? th45 * th45 : 0.f) + (lane < 3 ? det * det : 0.f));
+        const float bt_sq = wave_sum((lane >= 3 && lane < 13) ? det * det : 0.f);
+        if (norms_o && lane == 0) { norms_o[(size_t)r * 2] = sqrtf(th_sq); norms_o[(size_t)r * 2 + 1] = sqrtf(bt_sq); }
+
+        if (terms_o || logp_o) {
+            // visibility-masked Laplace over the 42 projected coordinates (hand/network.py:255-257)
+            float lt = 0.f;
+            if (lane < 42) {
+                const float y = crop_uv[b * 42 + lane];
+                const float w = vis[b * 21 + (lane >> 1)];
+                const float e = -(fmaxf(fabsf(y - uv) - 1e-4f, 0.f) + 1e-4f) / lap_b - log2b;
+                lt = (w == 1.f) ? e : 0.f;
+            }
+            const float lp_uv = wave_sum(lt);
+            // soft box on th45 (+-2) and beta (+-0.03), soft ball on th3 (pi)  (hand/network.py:155-163,429-435)
+            float v45 = lane < 45 ? fmaxf(fabsf(th45) / 2.f - 1.f, 0.f) : 0.f;
+            const float lp_45 = -wave_sum(th45_alpha * v45 * v45);
+            float vbt = (lane >= 3 && lane < 13) ? fmaxf(fabsf(det) / 0.03f - 1.f, 0.f) : 0.f;
+            const float lp_bt = -wave_sum(50.f * vbt * vbt);
+            const float r3 = sqrtf(bcast(det, 0) * bcast(det, 0) + bcast(det, 1) * bcast(det, 1) + bcast(det, 2) * bcast(det, 2));
+            const float v3 = fmaxf(r3 / 3.14159265358979323846f - 1.f, 0.f);
+            const float lp_3 = -5.f * v3 * v3;
+            if (lane == 0) {
+                if (terms_o) {
+                    float4 t4 = make_float4(lp_uv, lp_3, lp_45, lp_bt);
+                    reinterpret_cast<float4 *>(terms_o)[r] = t4;
+                }
+                if (logp_o) logp_o[r] = ((lp_uv + lp_3) + lp_45) + lp_bt;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Full mesh: HB hypotheses per block; the blend-shape tables are read once per
+// block and reused from registers across the HB hypotheses, so L2 traffic is
+// 1.5 MB / HB per hypothesis instead of 1.5 MB.
+template <int HB>
+__global__ __launch_bounds__(256) void mano_verts_kernel(const float *__restrict__ z_g, const float *__restrict__ tables,
+                                                         float *__restrict__ verts_o, int R, int mm_mode) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *tb = smem;                               // joint section
+    float *scr = smem + JOINT_FLOATS;               // 4 wave scratches
+    float *pm = scr + 4 * SCRATCH;                  // [135][HB] pose map
+    float *bt = pm + 135 * HB;                      // [10][HB]
+    float *gr = bt + 10 * HB;                       // [16][12][HB]
+    float *nrm = gr + 192 * HB;                     // [8][HB]: center(3) root(3) bone
+    for (int i = threadIdx.x; i < JOINT_FLOATS / 4; i += 256)
+        reinterpret_cast<float4 *>(tb)[i] = reinterpret_cast<const float4 *>(tables)[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *sc = scr + wave * SCRATCH;
+    const int r0 = blockIdx.x * HB;
+    for (int h = wave; h < HB; h += 4) {
+        const int r = (r0 + h < R) ? r0 + h : R - 1;
+        const float *zr = z_g + (size_t)r * 61;
+        const float th45 = lane < 45 ? zr[3 + lane] : 0.f;
+        // det lane layout [th3 bt logs t] from z = [th3 th45 bt logs t]
+        const float det = lane < 3 ? zr[lane] : (lane < 16 ? zr[45 + lane] : 0.f);
+        const RowOut o = joint_pass(tb, sc, lane, th45, det);
+        for (int k = lane; k < 135; k += 64) {
+            const int e = k % 9;
+            pm[k * HB + h] = sc[S_ROT + 9 + k] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+        }
+        if (lane < 10) bt[lane * HB + h] = zr[48 + lane];
+        for (int k = lane; k < 192; k += 64) gr[k * HB + h] = sc[S_GR + k];
+        if (lane < 3) { nrm[lane * HB + h] = o.center_c; nrm[(3 + lane) * HB + h] = o.root_c; }
+        if (lane == 0) nrm[6 * HB + h] = o.bone;
+        wave_sync();
+    }
+    __syncthreads();
+    const float *Vt = tables + V_T, *Vsd = tables + V_SD, *Vpd = tables + V_PD, *Vw = tables + V_W;
+    for (int v = threadIdx.x; v < VP; v += 256) {
+        float acc[HB][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float t = Vt[c * VP + v];
+#pragma unroll
+            for (int h = 0; h < HB; ++h) acc[h][c] = t;
+        }
+        for (int k = 0; k < 10; ++k) {
+            const float s0 = Vsd[(k * 3 + 0) * VP + v], s1 = Vsd[(k * 3 + 1) * VP + v], s2 = Vsd[(k * 3 + 2) * VP + v];
+#pragma unroll
+            for (int h = 0; h < HB; ++h) {
+                const float bk = bt[k * HB + h];
+                acc[h][0] = fmaf(s0, bk, acc[h][0]); acc[h][1] = fmaf(s1, bk, acc[h][1]); acc[h][2] = fmaf(s2, bk, acc[h][2]);
+            }
+        }
+#pragma unroll 3
+        for (int k = 0; k < 135; ++k) {
+            const float p0 = Vpd[(k * 3 + 0) * VP + v], p1 = Vpd[(k * 3 + 1) * VP + v], p2 = Vpd[(k * 3 + 2) * VP + v];
+#pragma unroll
+            for (int h = 0; h < HB; ++h) {
+                const float m = pm[k * HB + h];
+                acc[h][0] = fmaf(p0, m, acc[h][0]); acc[h][1] = fmaf(p1, m, acc[h][1]); acc[h][2] = fmaf(p2, m, acc[h][2]);
+            }
+        }
+        float w[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) w[j] = Vw[j * VP + v];
+#pragma unroll
+        for (int h = 0; h < HB; ++h) {
+            float T[12];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+#pragma unroll
+                for (int e = 0; e < 12; ++e) T[e] = fmaf(gr[(j * 12 + e) * HB + h], w[j], T[e]);
+            const int r = r0 + h;
+            if (v < NV && r < R) {
+                const float bone = nrm[6 * HB + h];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float vp = T[3 * c] * acc[h][0] + T[3 * c + 1] * acc[h][1] + T[3 * c + 2] * acc[h][2] + T[9 + c];
+                    const float mesh = (vp - nrm[c * HB + h]) * 1000.f;            // manolayer.py:262-273
+                    verts_o[((size_t)r * NV + v) * 3 + c] = mm_mode ? mesh : (mesh - nrm[(3 + c) * HB + h]) / bone;   // network.py:480
+                }
+            }
+        }
+    }
+}
+
+
+// ManoLayer.xyz_from_vertice (hand/ManoLayer.py:141-148,108-139): 16 joints regressed
+// from the mesh + 5 tip vertices, FreiHand order, then the RHD reorder (:54-56).
+// One workgroup per hypothesis; wave w handles joints w, w+4, ...
+__device__ constexpr int kWrapJointMap[16] = {0, 5, 6, 7, 9, 10, 11, 17, 18, 19, 13, 14, 15, 1, 2, 3};   // mano id -> FreiHand id
+__device__ constexpr int kWrapTipVert[5] = {744, 320, 443, 555, 672};                                    // FreiHand ids 4,8,12,16,20
+__global__ __launch_bounds__(256) void regress_joints_kernel(const float *__restrict__ verts, const float *__restrict__ tables,
+                                                             float *__restrict__ joints, int R) {
+    __shared__ float kp[21 * 3];
+    const int r = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float *v = verts + (size_t)r * NV * 3;
+    for (int j = wave; j < 16; j += 4) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int i = lane; i < NV; i += 64) {
+            const float w = tables[V_JR + j * VP + i];
+            a0 = fmaf(v[3 * i], w, a0); a1 = fmaf(v[3 * i + 1], w, a1); a2 = fmaf(v[3 * i + 2], w, a2);
+        }
+        a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+        if (lane == 0) { float *o = kp + 3 * kWrapJointMap[j]; o[0] = a0; o[1] = a1; o[2] = a2; }
+    }
+    if (threadIdx.x < 15) kp[3 * (4 + 4 * (threadIdx.x / 3)) + threadIdx.x % 3] = v[3 * kWrapTipVert[threadIdx.x / 3] + threadIdx.x % 3];
+    __syncthreads();
+    if (threadIdx.x < 63) joints[(size_t)r * 63 + threadIdx.x] = kp[3 * kFreihand2Rhd[threadIdx.x / 3] + threadIdx.x % 3];
+}
+
+__global__ void elbo_reduce_kernel(const float *__restrict__ lp_rows, const float *__restrict__ lq_rows,
+                                   float *__restrict__ q_log_p, float *__restrict__ h_o, float *__restrict__ log_p,
+                                   int N, int B) {
+    // one wavefront per image: lanes stride over the N hypotheses, LDS-free wave reduce
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= B) return;
+    float a = 0.f, q = 0.f;
+    for (int n = lane; n < N; n += 64) {
+        a += lp_rows[(size_t)n * B + wave];
+        q += lq_rows ? -lq_rows[(size_t)n * B + wave] : 0.f;
+    }
+    a = wave_sum(a) / (float)N;
+    q = wave_sum(q) / (float)N;
+    if (lane == 0) {
+        if (q_log_p) q_log_p[wave] = a;
+        if (h_o) h_o[wave] = q;
+        if (log_p) log_p[wave] = q + a;
+    }
+}
+
+}}  // namespace mhe::mano
+
+using namespace mhe;
+
+extern "C" size_t mhe_mano_table_floats(void) { return mano::TOTAL_FLOATS; }
+
+extern "C" int mhe_mano_joints_f32(const float *th45, const float *det, const float *crop_uv, const float *vis,
+                                   const float *tables, float *z, float *xyz, float *uv, float *terms, float *log_p,
+                                   float *norms, float *joints_mm, int R, int B, float laplace_b, float th45_alpha,
+                                   int inv_norm, float image_size, void *stream) {
+    MHE_REQUIRE(th45 && det && tables, "mhe_mano_joints_f32: null input");
+    MHE_REQUIRE(R > 0 && B > 0 && R % B == 0, "mhe_mano_joints_f32: R=%d must be a positive multiple of B=%d", R, B);
+    MHE_REQUIRE(!(terms || log_p) || (crop_uv && vis), "mhe_mano_joints_f32: likelihood outputs need crop_uv and vis");
+    MHE_REQUIRE(laplace_b > 0.f, "mhe_mano_joints_f32: laplace_b must be > 0");
+    const int blocks = (R + 3) / 4 < 2048 ? (R + 3) / 4 : 2048;
+    const size_t lds = (mano::JOINT_FLOATS + 4 * mano::SCRATCH) * sizeof(float);
+    hipLaunchKernelGGL(mano::mano_joints_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, th45, det, crop_uv,
+                       vis, tables, z, xyz, uv, terms, log_p, norms, joints_mm, R, B, laplace_b, th45_alpha, inv_norm,
+                       image_size);
+    return check_launch("mano_joints_kernel");
+}
+
+extern "C" int mhe_mano_verts_f32(const float *z, const float *tables, float *verts, int R, int mm_mode, void *stream) {
+    MHE_REQUIRE(z && tables && verts, "mhe_mano_verts_f32: null pointer");
+    MHE_REQUIRE(R > 0, "mhe_mano_verts_f32: R=%d", R);
+    constexpr int HB = 8;
+    const size_t lds = (mano::JOINT_FLOATS + 4 * mano::SCRATCH + (135 + 10 + 192 + 8) * HB) * sizeof(float);
+    hipLaunchKernelGGL(mano::mano_verts_kernel<HB>, dim3((R + HB - 1) / HB), dim3(256), lds, (hipStream_t)stream, z,
+                       tables, verts, R, mm_mode);
+    return check_launch("mano_verts_kernel");
+}
+
+extern "C" int mhe_mano_regress_joints_f32(const float *verts, const float *tables, float *joints, int R, void *stream) {
+    MHE_REQUIRE(verts && tables && joints && R > 0, "mhe_mano_regress_joints_f32: bad arguments");
+    hipLaunchKernelGGL(mano::regress_joints_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, verts, tables, joints, R);
+    return check_launch("regress_joints_kernel");
+}
+
+extern "C" int mhe_elbo_reduce_f32(const float *log_p_rows, const float *log_q_rows, float *q_log_p, float *h,
+                                   float *log_p, int N, int B, void *stream) {
+    MHE_REQUIRE(log_p_rows && N > 0 && B > 0, "mhe_elbo_reduce_f32: bad arguments");
+    hipLaunchKernelGGL(mano::elbo_reduce_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, log_p_rows,
+                       log_q_rows, q_log_p, h, log_p, N, B);
+    return check_launch("elbo_reduce_kernel");
+}

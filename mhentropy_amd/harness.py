@@ -1,0 +1,28 @@
+"""Builders for the model exactly as the reference trainer assembles it
+(reference hand/CrossModalHand.py:55-86: special_cfg / common_cfg) with the shipped
+hyper-parameters of hand/configs/ho3d.yaml, plus the train-step plumbing the
+"img/s" metric wraps (hand/CrossModalHand.py:191-203,455-470)."""
+import torch
+
+from .network import MHEnt
+from .criteria import MHEntLoss
+
+
+def mhent_cfgs(backbone="resnet50", h_dims=(512, 512), num_steps=6, tables=None, compute_dtype=torch.float32):
+    special = dict(
+        q_z_giv_i_model="realnvp",                                              # ho3d.yaml:39
+        q_z_giv_i_cfg=dict(dim=45, tsfm_on=512, kemb=False, jointN=21, h_dims=list(h_dims), num_steps=num_steps),
+        ds="ho3d", image_size=[256, 256],
+        mano_cfg=dict(flat_hand_mean=False, ncomps=45, use_pca=True, tables=tables),
+        prior_cfg=dict(p_theta45_pth=None, th45_ref_alpha=50),                  # ho3d.yaml:40-41
+        data_prior_cfg=dict(b_2d=0.03, w_prior_2d=0),                           # ho3d.yaml:42,44
+        loss_cfg=dict(entropy=True, mode=False, w_reg_ds=0),
+        kld_w=1, kld_w_annealing=[1, 20 * 1200], T=1.0)
+    common = dict(n_latent=512, backbone=backbone, pretrained=False, conditional_p=False, K=21, D=3, feat_dim=None,
+                  sigma_act="exp", deterministic=False, input="image", compute_dtype=compute_dtype)
+    return special, common
+
+
+def build_mhent(**kw):
+    special, common = mhent_cfgs(**kw)
+    return MHEnt(special, **common)

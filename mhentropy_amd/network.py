@@ -1,0 +1,178 @@
+"""MHEnt - image encoder -> K pose/shape hypotheses with log-probability -> MANO
+joints -> entropy + 2D re-projection ELBO - with the reference's module API
+(reference hand/network.py: `BasicEnc` :27-140, `MHEnt` :309-887) on HIP kernels.
+
+Kept from the reference: constructor (`MHEnt(special_cfg, **common_cfg)`), child
+module names (feat_extractor, q_z_giv_i, mano_dec, det_head -> identical
+state_dict keys), `get_loss` / `log_prob` / `sample` / `training_step_start`
+signatures and the keys + shapes of the dicts they return.
+Extensions (all optional, defaults reproduce the reference):
+  * `N=` hypotheses per image for the loss (the reference hard-codes 10, :780),
+  * `noise=` host-supplied base noise for reproducible parity,
+  * `fused_entropy=True`: log q from the sampling pass instead of a second,
+    inverse pass through the flow (same value to fp32 round-off, SURVEY.md A2 ii);
+    set False to run the reference's two-pass form.
+Dead reference branches (ConditionalGlow - third-party nflows, absent; VAE prior;
+renderer; GT evidences) raise NotImplementedError.
+"""
+from typing import Union
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops, resnet
+from .ManoLayer import ManoLayer
+from .flows import RealNVP
+
+
+class BasicEnc(nn.Module):
+    """reference hand/network.py:27-140: ResNet trunk + two Linear heads; returns (z, mn, sd).
+    MHEnt consumes only `mn` (:779,862); l2 / exp / the epsilon draw are dead for it, so
+    by default they are skipped (`full_outputs=False` -> z = mn, sd = None)."""
+    def __init__(self, cfg=None, n_latent: Union[int, list] = 64, backbone="resnet18", pretrained=True,
+                 conditional_p=False, K=21, D=3, feat_dim=None, sigma_act="exp", deterministic=False,
+                 compute_dtype=torch.float32, **kwargs):
+        super().__init__()
+        if conditional_p:
+            raise NotImplementedError("conditional_p is deprecated in the reference (network.py:63)")
+        self.n_latent = [n_latent, n_latent] if isinstance(n_latent, int) else list(n_latent)
+        if backbone not in resnet.CFG:
+            raise NotImplementedError(backbone)
+        self.res = resnet.ResNetTrunk(backbone, compute_dtype=compute_dtype)      # random init: no network for pretrained weights
+        feat_dim = feat_dim or resnet.CFG[backbone][2]
+        self.l1 = nn.Sequential(nn.Linear(feat_dim, self.n_latent[0]))
+        self.l2 = nn.Sequential(nn.Linear(feat_dim, self.n_latent[1]))
+        self.sigma_act, self.deterministic = sigma_act, deterministic
+        self._feat = None
+
+    def forward(self, x, deterministic=False, p=None):
+        f = self.res(x)
+        self._feat = f
+        mn = ops.linear(f, self.l1[0].weight.detach(), self.l1[0].bias.detach())
+        return mn, mn, None
+
+
+class MHEnt(nn.Module):
+    def __init__(self, special_cfg, **common_cfg):
+        super().__init__()
+        self.integrated = True
+        if common_cfg["input"] != "image":
+            raise NotImplementedError
+        self.feat_extractor = BasicEnc(**common_cfg)
+        model = special_cfg["q_z_giv_i_model"]
+        if model != "realnvp":
+            raise NotImplementedError(
+                f"q_z_giv_i_model={model!r}: only the shipped RealNVP branch is built (ConditionalGlow is the "
+                "third-party nkolot/nflows class, absent from the reference tree; SURVEY.md section 8c)")
+        self.q_z_giv_i = RealNVP(**special_cfg["q_z_giv_i_cfg"])
+        self.ds = special_cfg["ds"]
+        if self.ds not in ("rhd", "ho3d"):
+            raise NotImplementedError(self.ds)
+        self.image_size = max(special_cfg["image_size"])
+        mano_cfg = special_cfg["mano_cfg"]
+        self.mano_dec = ManoLayer(skeidx="RHD", flat_hand_mean=mano_cfg["flat_hand_mean"], ncomps=mano_cfg["ncomps"],
+                                  use_pca=mano_cfg["use_pca"], output_size=self.image_size, mask_sz=64,
+                                  tables=mano_cfg.get("tables"),
+                                  **({"MANO_dir": mano_cfg["MANO_dir"]} if "MANO_dir" in mano_cfg else {}))
+        self.zdims = {"th3": 3, "th45": 45, "bt": 10, "logs": 1, "t": 2}
+        self.zdets = {"th3": True, "th45": False, "bt": True, "logs": True, "t": True}
+        self.z_dim = 45
+        feat_dim = 512
+        self.det_head = nn.Sequential(nn.Linear(feat_dim, feat_dim), nn.ReLU(inplace=True), nn.Linear(feat_dim, 16))
+        self.b_2d = float(special_cfg["data_prior_cfg"]["b_2d"])                   # network.py:392
+        prior_cfg = special_cfg["prior_cfg"]
+        if prior_cfg.get("p_theta45_pth"):
+            raise NotImplementedError("VAE4Pose prior is undefined in the reference (network.py:423)")
+        self.th45_ref_alpha = float(prior_cfg.get("th45_ref_alpha", 50.0))       # network.py:427
+        self.kld_w = self.kld_w_final = special_cfg.get("kld_w", 1.0)
+        self.kld_w_annealing = special_cfg["kld_w_annealing"]
+        self.T = special_cfg.get("T", 1.0)
+        if self.T != 1.0:
+            raise NotImplementedError("T != 1")
+        self.entropy = special_cfg["loss_cfg"]["entropy"]
+        self.best_mode = special_cfg["loss_cfg"]["mode"]
+        self._extra_ws = {"log_p_vis_giv_z": 1.0}
+        self.loss_N = 10                        # network.py:780
+        self.fused_entropy = True
+
+    # ---- pieces ---------------------------------------------------------------
+    def _det(self, feat):
+        """det_head (network.py:380-383) on the B image rows."""
+        h = ops.linear(feat, self.det_head[0].weight.detach(), self.det_head[0].bias.detach(), relu=True)
+        return ops.linear(h, self.det_head[2].weight.detach(), self.det_head[2].bias.detach())
+
+    def _noise(self, rows, temp, noise, device):
+        if noise is None:
+            noise = torch.randn(rows, 45, device=device, dtype=torch.float32)
+        noise = noise.reshape(rows, 45)
+        return (noise * temp).contiguous() if temp != 1.0 else noise.contiguous()
+
+    # ---- reference surface ------------------------------------------------------
+    def _reverse_kld(self, y, x, mods=None, return_dict=True, N=None, noise=None):
+        """reference hand/network.py:760-831."""
+        if mods is not None and list(mods) != ["uv"]:
+            raise NotImplementedError("only the weakly supervised 'uv' likelihood of the shipped config is built")
+        N = N or self.loss_N
+        _, feat, _ = self.feat_extractor(x)
+        B = feat.shape[0]
+        z0 = self._noise(N * B, 1.0, noise, feat.device)
+        if self.entropy and self.fused_entropy:
+            th45, log_q = self.q_z_giv_i.sample_with_log_prob(z0, feat)
+        else:
+            th45 = self.q_z_giv_i.forward_p(z0, cond=feat)
+            log_q = self.q_z_giv_i.log_prob(th45, logvar=feat) if self.entropy else None       # network.py:801
+        o = ops.mano_joints(th45, self._det(feat), self.mano_dec.table_blob(), y["crop_uv"].contiguous(),
+                            y["vis"].contiguous(), self.b_2d, self.th45_ref_alpha, want=("log_p", "norms"))
+        q_log_p, h, log_p = ops.elbo_reduce(o["log_p"], log_q, N, B)
+        out = {"th_norm": o["norms"][:, 0], "bt_norm": o["norms"][:, 1], "q_log_p_z_giv_y": q_log_p}
+        if self.entropy:
+            out["h_q_z_giv_i"] = h
+            out["log_p"] = log_p
+        else:
+            out["log_p"] = q_log_p
+        if not return_dict:
+            raise NotImplementedError
+        return out
+
+    def log_prob(self, y, x, div_type=0, mods=None, return_dict=True, **kw):
+        return self._reverse_kld(y, x, mods=mods, return_dict=return_dict, **kw)
+
+    def get_loss(self, x, y, div_type=0, mods=None, return_dict=True, **kw):
+        """reference hand/network.py:838-844."""
+        return self.log_prob(y, x, div_type=div_type, mods=mods, return_dict=return_dict, **kw)
+
+    def sample(self, x, N: Union[int, list] = 5, temp=0.5, mods=None, y=None, noise=None):
+        """reference hand/network.py:846-883 -> th_bt (N,B,58), logs_t (N,B,3), verts (N,B,2334),
+        xyz (N,B,63), uv (N,B,42) in pixels, faces."""
+        N_quant = N
+        if isinstance(N, (list, tuple)):
+            N, N_quant = N
+        if N_quant < N:
+            raise NotImplementedError("top-k hypothesis selection (network.py:866-871) is a later scope row")
+        out = {}
+        if y is not None and "image" in y:
+            out["image"] = y["image"]
+        _, feat, _ = self.feat_extractor(x)
+        B = feat.shape[0]
+        z0 = self._noise(N * B, temp, noise, feat.device)
+        th45 = self.q_z_giv_i.forward_p(z0, cond=feat)
+        mods = {"xyz", "uv", "verts"} if mods is None else set(mods)
+        blob = self.mano_dec.table_blob()
+        o = ops.mano_joints(th45, self._det(feat), blob, inv_norm=True, image_size=float(self.image_size),
+                            want=("z", "xyz", "uv"))
+        z = o["z"].view(N, B, 61)
+        out["th_bt"], out["logs_t"] = z[..., :58], z[..., -3:]
+        if "verts" in mods:
+            out["verts"] = ops.mano_verts(o["z"], blob).view(N, B, -1)
+            out["faces"] = self.mano_dec.mano_faces
+        if "xyz" in mods:
+            out["xyz"] = o["xyz"].view(N, B, -1)
+        if "uv" in mods:
+            out["uv"] = o["uv"].view(N, B, -1)
+        return out
+
+    def training_step_start(self, step):
+        """reference hand/network.py:885-887."""
+        kld_w_init, kld_w_steps = self.kld_w_annealing
+        self.kld_w = kld_w_init + (self.kld_w_final - kld_w_init) * min(1.0, step / kld_w_steps)

@@ -1,0 +1,213 @@
+"""Tensor-level wrappers over the C ABI (include/mhe.h).
+
+torch is plumbing here: it owns device memory and the HIP stream; every number is
+produced by the hand-written kernels in csrc/.  All functions require CUDA (HIP)
+tensors and raise on anything else - there is no CPU path in the product.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check
+
+F32, BF16 = 0, 1
+FLOW_FORWARD, FLOW_INVERSE = 0, 1
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _chk(t, dtype, name, shape=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.MheError(f"{name}: expected a CUDA/HIP tensor (the hot path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise _lib.MheError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.MheError(f"{name}: must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise _lib.MheError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+def dtype_code(dt):
+    return F32 if dt == torch.float32 else BF16
+
+
+def linear(x, w, bias=None, relu=False, out=None):
+    """act(x @ w.T + bias) in f32 (mhe_linear_f32)."""
+    M, K = x.shape
+    N = w.shape[0]
+    _chk(x, torch.float32, "linear.x"); _chk(w, torch.float32, "linear.w", (N, K))
+    if bias is not None:
+        _chk(bias, torch.float32, "linear.bias", (N,))
+    y = out if out is not None else torch.empty(M, N, device=x.device, dtype=torch.float32)
+    _chk(y, torch.float32, "linear.out", (M, N))
+    check(_lib.lib().mhe_linear_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), M, N, K, int(relu), _stream()), "mhe_linear_f32")
+    return y
+
+
+def flow_pack_net(w0, w1, w2):
+    """Host repack of one coupling network's weights (numpy float32) into the
+    fragment-ordered stream (mhe_flow_pack_net_host)."""
+    hidden, dim = w0.shape
+    L = _lib.lib()
+    n = L.mhe_flow_packed_floats_per_net(dim, hidden)
+    if n == 0:
+        raise _lib.MheError(f"flow_pack_net: unsupported geometry dim={dim} hidden={hidden}")
+    out = np.empty(n, np.float32)
+    w0, w1, w2 = (np.ascontiguousarray(a, np.float32) for a in (w0, w1, w2))
+    check(L.mhe_flow_pack_net_host(w0.ctypes.data_as(C.c_void_p), w1.ctypes.data_as(C.c_void_p),
+                                   w2.ctypes.data_as(C.c_void_p), dim, hidden, out.ctypes.data_as(C.c_void_p)),
+          "mhe_flow_pack_net_host")
+    return out
+
+
+def flow_couplings(x_in, cond, wstream, bias2, mask, B, hidden, direction, want_log_prob=True):
+    """All couplings in one launch; returns (out, sum_s, log_prob)."""
+    R, dim = x_in.shape
+    ncoup = mask.shape[0]
+    _chk(x_in, torch.float32, "flow.in")
+    _chk(cond, torch.float32, "flow.cond", (B, 2 * ncoup, 2, hidden))
+    _chk(wstream, torch.float32, "flow.wstream"); _chk(bias2, torch.float32, "flow.bias2", (2 * ncoup, dim))
+    _chk(mask, torch.float32, "flow.mask", (ncoup, dim))
+    out = torch.empty_like(x_in)
+    sum_s = torch.empty(R, device=x_in.device, dtype=torch.float32)
+    logp = torch.empty(R, device=x_in.device, dtype=torch.float32) if want_log_prob else None
+    check(_lib.lib().mhe_flow_couplings_f32(_ptr(x_in), _ptr(out), _ptr(cond), _ptr(wstream), _ptr(bias2), _ptr(mask),
+                                            _ptr(sum_s), _ptr(logp), R, B, dim, hidden, ncoup, direction, _stream()),
+          "mhe_flow_couplings_f32")
+    return out, sum_s, logp
+
+
+def mano_joints(th45, det, tables, crop_uv=None, vis=None, laplace_b=0.03, th45_alpha=50.0, inv_norm=False,
+                image_size=256.0, want=("z", "xyz", "uv", "terms", "log_p", "norms")):
+    """want may also include "joints_mm"."""
+    R, B = th45.shape[0], det.shape[0]
+    dev = th45.device
+    _chk(th45, torch.float32, "mano.th45", (R, 45)); _chk(det, torch.float32, "mano.det", (B, 16))
+    _chk(tables, torch.float32, "mano.tables")
+    if crop_uv is not None:
+        _chk(crop_uv, torch.float32, "mano.crop_uv", (B, 42)); _chk(vis, torch.float32, "mano.vis", (B, 21))
+    shapes = {"z": (R, 61), "xyz": (R, 63), "uv": (R, 42), "terms": (R, 4), "log_p": (R,), "norms": (R, 2),
+              "joints_mm": (R, 63)}
+    o = {k: (torch.empty(shapes[k], device=dev, dtype=torch.float32) if k in want else None) for k in shapes}
+    check(_lib.lib().mhe_mano_joints_f32(_ptr(th45), _ptr(det), _ptr(crop_uv), _ptr(vis), _ptr(tables),
+                                         _ptr(o["z"]), _ptr(o["xyz"]), _ptr(o["uv"]), _ptr(o["terms"]), _ptr(o["log_p"]),
+                                         _ptr(o["norms"]), _ptr(o["joints_mm"]), R, B, float(laplace_b), float(th45_alpha), int(inv_norm),
+                                         float(image_size), _stream()), "mhe_mano_joints_f32")
+    return o
+
+
+def mano_verts(z, tables, mm=False):
+    R = z.shape[0]
+    _chk(z, torch.float32, "mano_verts.z", (R, 61))
+    verts = torch.empty(R, 778, 3, device=z.device, dtype=torch.float32)
+    check(_lib.lib().mhe_mano_verts_f32(_ptr(z), _ptr(tables), _ptr(verts), R, int(mm), _stream()), "mhe_mano_verts_f32")
+    return verts
+
+
+def mano_regress_joints(verts, tables):
+    R = verts.shape[0]
+    _chk(verts, torch.float32, "regress.verts", (R, 778, 3))
+    j = torch.empty(R, 21, 3, device=verts.device, dtype=torch.float32)
+    check(_lib.lib().mhe_mano_regress_joints_f32(_ptr(verts), _ptr(tables), _ptr(j), R, _stream()), "mhe_mano_regress_joints_f32")
+    return j
+
+
+def elbo_reduce(log_p_rows, log_q_rows, N, B):
+    dev = log_p_rows.device
+    _chk(log_p_rows, torch.float32, "elbo.log_p_rows", (N * B,))
+    if log_q_rows is not None:
+        _chk(log_q_rows, torch.float32, "elbo.log_q_rows", (N * B,))
+    q, h, lp = (torch.empty(B, device=dev, dtype=torch.float32) for _ in range(3))
+    check(_lib.lib().mhe_elbo_reduce_f32(_ptr(log_p_rows), _ptr(log_q_rows), _ptr(q), _ptr(h), _ptr(lp), N, B, _stream()),
+          "mhe_elbo_reduce_f32")
+    return q, h, lp
+
+
+def metrics(xyz, uv, pose3d, scale, crop_uv, vis):
+    N, B = xyz.shape[:2]
+    _chk(xyz, torch.float32, "metrics.xyz", (N, B, 63)); _chk(uv, torch.float32, "metrics.uv", (N, B, 42))
+    _chk(pose3d, torch.float32, "metrics.pose3d", (B, 63)); _chk(scale, torch.float32, "metrics.scale", (B,))
+    _chk(crop_uv, torch.float32, "metrics.crop_uv", (B, 42)); _chk(vis, torch.float32, "metrics.vis", (B, 21))
+    out = torch.empty(14, B, device=xyz.device, dtype=torch.float32)
+    check(_lib.lib().mhe_metrics_f32(_ptr(xyz), _ptr(uv), _ptr(pose3d), _ptr(scale), _ptr(crop_uv), _ptr(vis), _ptr(out),
+                                     N, B, _stream()), "mhe_metrics_f32")
+    return out
+
+
+def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in=False, out_scale=None,
+                out_shift=None, residual=None, relu_out=False, stats=None, out=None):
+    """x [B,H,W,Cin], w packed [Cout, Kpad]; returns y [B,Ho,Wo,Cout] of x.dtype."""
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    dt = x.dtype
+    _chk(x, dt, "conv.x"); _chk(w, dt, "conv.w")
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    y = out if out is not None else torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=dt)
+    _chk(y, dt, "conv.y", (B, Ho, Wo, Cout))
+    for t, n, c in ((in_scale, "in_scale", Cin), (in_shift, "in_shift", Cin), (out_scale, "out_scale", Cout),
+                    (out_shift, "out_shift", Cout)):
+        if t is not None:
+            _chk(t, torch.float32, "conv." + n, (c,))
+    if residual is not None:
+        _chk(residual, dt, "conv.residual", (B, Ho, Wo, Cout))
+    if stats is not None:
+        _chk(stats, torch.float32, "conv.stats", (2, Cout))
+    d = ConvDesc(B, H, W, Cin, Cout, KH, KW, stride, pad, dtype_code(dt), int(relu_in), int(relu_out))
+    check(_lib.lib().mhe_conv2d_nhwc(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _ptr(in_scale), _ptr(in_shift),
+                                     _ptr(out_scale), _ptr(out_shift), _ptr(residual), _ptr(stats), _stream()),
+          "mhe_conv2d_nhwc")
+    return y
+
+
+def bn_finalize(stats, gamma, beta, running_mean, running_var, count, momentum=0.1, eps=1e-5):
+    Cn = gamma.shape[0]
+    scale = torch.empty(Cn, device=gamma.device, dtype=torch.float32)
+    shift = torch.empty_like(scale)
+    check(_lib.lib().mhe_bn_finalize(_ptr(stats), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                     _ptr(scale), _ptr(shift), Cn, float(count), float(momentum), float(eps), _stream()),
+          "mhe_bn_finalize")
+    return scale, shift
+
+
+def bn_act(x, scale, shift, res=None, res_scale=None, res_shift=None, relu=True, out=None):
+    Cn = x.shape[-1]
+    P = x.numel() // Cn
+    y = out if out is not None else torch.empty_like(x)
+    check(_lib.lib().mhe_bn_act_nhwc(_ptr(x), _ptr(scale), _ptr(shift), _ptr(res), _ptr(res_scale), _ptr(res_shift),
+                                     _ptr(y), P, Cn, int(relu), dtype_code(x.dtype), _stream()), "mhe_bn_act_nhwc")
+    return y
+
+
+def maxpool3x3s2(x, scale=None, shift=None):
+    B, H, W, Cn = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(B, Ho, Wo, Cn, device=x.device, dtype=x.dtype)
+    check(_lib.lib().mhe_maxpool3x3s2_nhwc(_ptr(x), _ptr(scale), _ptr(shift), _ptr(y), B, H, W, Cn, dtype_code(x.dtype),
+                                           _stream()), "mhe_maxpool3x3s2_nhwc")
+    return y
+
+
+def avgpool(x):
+    B, H, W, Cn = x.shape
+    y = torch.empty(B, Cn, device=x.device, dtype=torch.float32)
+    check(_lib.lib().mhe_avgpool_nhwc(_ptr(x), _ptr(y), B, H * W, Cn, dtype_code(x.dtype), _stream()), "mhe_avgpool_nhwc")
+    return y
+
+
+def nchw_to_nhwc(x, dtype=torch.float32):
+    B, Cn, H, W = x.shape
+    _chk(x, torch.float32, "nchw_to_nhwc.x")
+    ce = 4 if dtype == torch.float32 else 8
+    Cp = (Cn + ce - 1) // ce * ce
+    y = torch.empty(B, H, W, Cp, device=x.device, dtype=dtype)
+    check(_lib.lib().mhe_nchw_to_nhwc(_ptr(x), _ptr(y), B, Cn, H, W, dtype_code(dtype), _stream()), "mhe_nchw_to_nhwc")
+    return y

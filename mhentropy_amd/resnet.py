@@ -1,0 +1,146 @@
+"""ResNet-18/50 trunk driven through the HIP implicit-GEMM convolution.
+
+Stands where the reference uses torchvision (`models.resnet18/50`, then
+`res.fc = nn.Identity()`, reference hand/network.py:54-61).  Parameters and buffers
+carry torchvision's names (conv1, bn1, layer{1-4}.{i}.conv{1-3}/bn{1-3}/downsample.{0,1})
+so a state_dict saved by the reference loads unchanged; the nn.Conv2d /
+nn.BatchNorm2d objects are parameter holders only - their forward is never
+called.  Activations are NHWC; BatchNorm + ReLU of a producer is applied by the
+consumer while it loads its operand, the tail of each residual block is one
+fused elementwise pass.
+"""
+import torch
+from torch import nn
+
+from . import ops
+
+CFG = {
+    "resnet18": ("basic", (2, 2, 2, 2), 512),
+    "resnet50": ("bottleneck", (3, 4, 6, 3), 2048),
+}
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+def pack_conv_weight(w, dtype, cin_pad=None):
+    """torch [Cout,Cin,KH,KW] -> [Cout, Kpad] with k = (kh,kw,cin), cin fastest,
+    channels zero-padded to cin_pad and K to the kernel's 128-byte stage."""
+    Cout, Cin, KH, KW = w.shape
+    cin_pad = cin_pad or Cin
+    bke = 32 if dtype == torch.float32 else 64
+    wp = torch.zeros(Cout, KH, KW, cin_pad, dtype=torch.float32, device=w.device)
+    wp[..., :Cin] = w.detach().float().permute(0, 2, 3, 1)
+    k = KH * KW * cin_pad
+    kpad = (k + bke - 1) // bke * bke
+    out = torch.zeros(Cout, kpad, dtype=torch.float32, device=w.device)
+    out[:, :k] = wp.reshape(Cout, k)
+    return out.to(dtype).contiguous()
+
+
+class _Block(nn.Module):
+    def __init__(self, kind, inplanes, planes, stride):
+        super().__init__()
+        self.kind, self.stride = kind, stride
+        exp = 4 if kind == "bottleneck" else 1
+        if kind == "bottleneck":
+            self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False); self.bn1 = nn.BatchNorm2d(planes)
+            self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False); self.bn2 = nn.BatchNorm2d(planes)
+            self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False); self.bn3 = nn.BatchNorm2d(planes * 4)
+        else:
+            self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False); self.bn1 = nn.BatchNorm2d(planes)
+            self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False); self.bn2 = nn.BatchNorm2d(planes)
+        if stride != 1 or inplanes != planes * exp:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes * exp, 1, stride, bias=False),
+                                            nn.BatchNorm2d(planes * exp))
+        else:
+            self.downsample = None
+
+
+class ResNetTrunk(nn.Module):
+    def __init__(self, arch="resnet50", compute_dtype=torch.float32):
+        super().__init__()
+        kind, blocks, self.feat_dim = CFG[arch]
+        self.arch, self.kind = arch, kind
+        self.compute_dtype = compute_dtype
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        inplanes, exp = 64, (4 if kind == "bottleneck" else 1)
+        for li, (planes, nb) in enumerate(zip((64, 128, 256, 512), blocks)):
+            layer = []
+            for bi in range(nb):
+                layer.append(_Block(kind, inplanes, planes, 2 if (bi == 0 and li > 0) else 1))
+                inplanes = planes * exp
+            setattr(self, f"layer{li + 1}", nn.Sequential(*layer))
+        self.fc = nn.Identity()       # the reference overwrites fc with Identity (network.py:61)
+        self._wcache = {}
+
+    # -- packed-weight cache keyed on the parameter's version counter
+    def _w(self, conv, cin_pad=None):
+        p = conv.weight
+        key = (id(p), p._version, self.compute_dtype, p.device)
+        hit = self._wcache.get(id(p))
+        if hit is None or hit[0] != key:
+            hit = (key, pack_conv_weight(p, self.compute_dtype, cin_pad))
+            self._wcache[id(p)] = hit
+        return hit[1]
+
+    def _conv_bn(self, x, conv, bn, stats_pool, in_aff=None, stride=1, pad=0, k=1, cin_pad=None):
+        """raw conv output + this layer's BatchNorm folded to (scale, shift)."""
+        w = self._w(conv, cin_pad)
+        isc, ish = in_aff if in_aff is not None else (None, None)
+        if self.training:
+            st = stats_pool.take(conv.out_channels)
+            y = ops.conv2d_nhwc(x, w, k, k, stride, pad, in_scale=isc, in_shift=ish, relu_in=in_aff is not None, stats=st)
+            count = y.numel() // y.shape[-1]
+            aff = ops.bn_finalize(st, bn.weight, bn.bias, bn.running_mean, bn.running_var, count, BN_MOMENTUM, BN_EPS)
+            bn.num_batches_tracked += 1
+        else:
+            y = ops.conv2d_nhwc(x, w, k, k, stride, pad, in_scale=isc, in_shift=ish, relu_in=in_aff is not None)
+            sc = bn.weight.detach() / torch.sqrt(bn.running_var + BN_EPS)
+            aff = (sc.contiguous(), (bn.bias.detach() - bn.running_mean * sc).contiguous())
+        return y, aff
+
+    def forward(self, x):
+        """x (B,3,H,W) float32 NCHW -> (B, feat_dim) float32."""
+        dt = self.compute_dtype
+        pool = _StatsPool(x.device)
+        a = ops.nchw_to_nhwc(x.contiguous(), dt)
+        y, aff = self._conv_bn(a, self.conv1, self.bn1, pool, None, 2, 3, 7, cin_pad=a.shape[-1])
+        a = ops.maxpool3x3s2(y, aff[0], aff[1])
+        for li in range(4):
+            for blk in getattr(self, f"layer{li + 1}"):
+                if blk.kind == "bottleneck":
+                    y1, a1 = self._conv_bn(a, blk.conv1, blk.bn1, pool)
+                    y2, a2 = self._conv_bn(y1, blk.conv2, blk.bn2, pool, a1, blk.stride, 1, 3)
+                    yl, al = self._conv_bn(y2, blk.conv3, blk.bn3, pool, a2)
+                else:
+                    y1, a1 = self._conv_bn(a, blk.conv1, blk.bn1, pool, None, blk.stride, 1, 3)
+                    yl, al = self._conv_bn(y1, blk.conv2, blk.bn2, pool, a1, 1, 1, 3)
+                if blk.downsample is not None:
+                    yd, ad = self._conv_bn(a, blk.downsample[0], blk.downsample[1], pool, None, blk.stride, 0, 1)
+                    a = ops.bn_act(yl, al[0], al[1], yd, ad[0], ad[1], relu=True)
+                else:
+                    a = ops.bn_act(yl, al[0], al[1], a, relu=True)
+        return self.fc(ops.avgpool(a))
+
+
+class _StatsPool:
+    """one zeroed arena for all per-channel (sum, sum^2) accumulators of a forward"""
+    def __init__(self, device, floats=2 * 32768):
+        self.buf = torch.zeros(floats, device=device, dtype=torch.float32)
+        self.off = 0
+
+    def take(self, C):
+        if self.off + 2 * C > self.buf.numel():
+            self.buf = torch.zeros_like(self.buf)
+            self.off = 0
+        v = self.buf[self.off:self.off + 2 * C].view(2, C)
+        self.off += 2 * C
+        return v
+
+
+def resnet18(pretrained=False, **kw):
+    return ResNetTrunk("resnet18", **kw)
+
+
+def resnet50(pretrained=False, **kw):
+    return ResNetTrunk("resnet50", **kw)

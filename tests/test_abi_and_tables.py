@@ -1,0 +1,102 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mhe.h declares;
+host-side packing/layout constants agree with the kernels; the index tables baked
+into the kernels equal the reference's gathers (bit-exact integer work)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from mhentropy_amd import _lib, mano_pack, synth
+from oracle import mano_ref
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "mhe.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mhe_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    syms = _header_symbols()
+    assert len(syms) >= 18
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/mhe.h but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
+    assert set(_lib.SIGNATURES) == set(syms)
+    assert L.mhe_abi_version() == 1
+
+
+def test_layout_constants_agree():
+    L = _lib.lib()
+    assert L.mhe_mano_table_floats() == mano_pack.TOTAL_FLOATS
+    hdr = open(os.path.join(ROOT, "mhentropy_amd", "csrc", "mano_layout.h")).read()
+    for name in ("COMPS", "MEAN", "JT", "JSD", "TIP_T", "TIP_SD", "TIP_PD", "TIP_W", "JOINT_FLOATS", "VP", "NV"):
+        v = int(re.search(rf"constexpr int {name} = (\d+);", hdr).group(1))
+        assert v == getattr(mano_pack, name), name
+    # stage geometry of the packed flow stream: 78 stages of 16 KiB for the shipped width
+    assert L.mhe_flow_packed_floats_per_net(45, 512) == 78 * 4096
+    assert L.mhe_flow_packed_floats_per_net(45, 64) == 3 * 4096
+    assert L.mhe_flow_packed_floats_per_net(45, 100) == 0 and L.mhe_flow_packed_floats_per_net(49, 64) == 0
+
+
+def _c_array(src, name):
+    m = re.search(rf"{name}\[\d+\] = \{{([^}}]*)\}}", src)
+    return [int(v) for v in m.group(1).split(",")]
+
+
+def test_index_tables_are_the_references():
+    src = open(os.path.join(ROOT, "mhentropy_amd", "csrc", "mano.hip")).read()
+    assert _c_array(src, "kJointReorder") == list(mano_ref.JOINT_REORDER)
+    assert _c_array(src, "kFreihand2Rhd") == list(mano_ref.FREIHAND2RHD)
+    assert tuple(mano_pack.TIP_VERTS_RIGHT) == mano_ref.TIP_VERTS_RIGHT
+    # centring joint: index 9 of the reordered list (manolayer.py:262-266)
+    assert int(re.search(r"kCenterPre = (\d+);", src).group(1)) == mano_ref.JOINT_REORDER[9]
+    # wrapper re-regression map and tip vertices (ManoLayer.py:112-126)
+    jm = _c_array(src, "kWrapJointMap")
+    assert {i: v for i, v in enumerate(jm)} == mano_ref.WRAPPER_JOINT_MAP
+    assert _c_array(src, "kWrapTipVert") == [mano_ref.WRAPPER_TIP_VERTS[k] for k in (4, 8, 12, 16, 20)]
+
+
+def test_flow_pack_roundtrip():
+    """every weight appears exactly once in the packed stream at the documented position"""
+    from mhentropy_amd import ops
+    rng = np.random.default_rng(0)
+    h, d = 64, 45
+    w0, w1, w2 = rng.normal(size=(h, d)), rng.normal(size=(h, h)), rng.normal(size=(d, h))
+    p = ops.flow_pack_net(w0.astype(np.float32), w1.astype(np.float32), w2.astype(np.float32))
+    assert p.shape == (3 * 4096,)
+    nz = p[p != 0]
+    assert nz.size == w0.size + w1.size + w2.size
+    assert np.isclose(np.sort(nz), np.sort(np.concatenate([w0.ravel(), w1.ravel(), w2.ravel()]).astype(np.float32))).all()
+    # block (To,Tk) of layer 0 lives at block f = Tk*NT + To; lane 16q+n holds W[16To+n][16Tk+4q+i]
+    NT, To, Tk, q, n, i = 4, 2, 1, 3, 5, 2
+    assert p[(Tk * NT + To) * 256 + (16 * q + n) * 4 + i] == np.float32(w0[16 * To + n, 16 * Tk + 4 * q + i])
+
+
+def test_state_dict_keys_match_reference_layout():
+    """key names a reference checkpoint (ent_ho3d.pth) carries for encoderRGB"""
+    from mhentropy_amd import harness
+    model = harness.build_mhent(backbone="resnet18", h_dims=(64, 64), num_steps=2, tables=synth.mano_tables(0))
+    keys = set(model.state_dict().keys())
+    for k in ("feat_extractor.res.conv1.weight", "feat_extractor.res.bn1.running_mean",
+              "feat_extractor.res.layer2.0.downsample.0.weight", "feat_extractor.res.layer4.1.bn2.num_batches_tracked",
+              "feat_extractor.l1.0.weight", "feat_extractor.l2.0.bias", "q_z_giv_i.mask", "q_z_giv_i.s.0.l.0.weight",
+              "q_z_giv_i.t.3.c.1.bias", "det_head.0.weight", "det_head.2.bias", "mano_dec.mano_layer.th_posedirs",
+              "mano_dec.mano_layer.th_selected_comps", "mano_dec.mano_layer.th_faces"):
+        assert k in keys, k
+    sd = {"q_z_giv_i." + k: torch.as_tensor(v) for k, v in synth.flow_state(1, 45, 512, (64, 64), 2).items()}
+    sd.update({k: torch.as_tensor(v) for k, v in synth.head_state(1, 512, 512, 16).items()})
+    sd.update({"feat_extractor.res." + k: torch.as_tensor(v) for k, v in synth.resnet_state(1, "resnet18").items()})
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected
+    assert all(k.startswith("mano_dec.") for k in missing)
+
+
+def test_product_refuses_cpu_tensors():
+    from mhentropy_amd import ops
+    with pytest.raises(_lib.MheError):
+        ops.linear(torch.zeros(4, 32), torch.zeros(8, 32))

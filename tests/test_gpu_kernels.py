@@ -1,0 +1,183 @@
+"""GPU parity: each C-ABI kernel against the oracle / golden vectors.
+Tolerances: 1e-4 relative to the tensor's scale for fp32 (BASELINE.json north_star);
+index gathers are checked bit-exactly in test_index_tables.py."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, assert_close
+from mhentropy_amd import synth, mano_pack
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def _dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def _mano_blob(seed=0):
+    t = synth.mano_tables(seed)
+    return _dev(mano_pack.pack_tables(t["shapedirs"], t["posedirs"], t["v_template"], t["J_regressor"], t["weights"],
+                                      t["hands_components"][:45], t["hands_mean"]))
+
+
+def _flow_device_state(sd, dim, hidden, steps):
+    """numpy state_dict -> (wstream, bias2, mask, Wc, bc) device tensors as the kernels want them."""
+    from mhentropy_amd import ops
+    ncoup = 2 * steps
+    packs, b2, wc, bc = [], [], [], []
+    for i in range(ncoup):
+        for net in ("s", "t"):
+            p = f"{net}.{i}."
+            packs.append(ops.flow_pack_net(sd[p + "l.0.weight"], sd[p + "l.1.weight"], sd[p + "l.2.weight"]))
+            b2.append(sd[p + "l.2.bias"])
+            for j in range(2):
+                wc.append(sd[p + f"c.{j}.weight"])
+                bc.append(sd[p + f"c.{j}.bias"] + sd[p + f"l.{j}.bias"])
+    return (_dev(np.concatenate(packs)), _dev(np.stack(b2)), _dev(sd["mask"]), _dev(np.concatenate(wc)),
+            _dev(np.concatenate(bc)))
+
+
+@pytest.mark.parametrize("tag", ["small", "shipped"])
+def test_flow_couplings_match_reference_vectors(gpu_lib, tag):
+    from mhentropy_amd import ops
+    g = load_golden(f"flow_{tag}")
+    h, steps, cd = int(g["h"]), int(g["steps"]), int(g["cond_dim"])
+    sd = synth.flow_state(int(g["seed"]), 45, cd, (h, h), steps)
+    wstream, b2, mask, Wc, bc = _flow_device_state(sd, 45, h, steps)
+    feat = _dev(g["feat"])
+    R = feat.shape[0]
+    cond = ops.linear(feat, Wc, bc).view(R, 4 * steps, 2, h)
+    x, sum_s, logq = ops.flow_couplings(_dev(g["z0"]), cond, wstream, b2, mask, R, h, ops.FLOW_FORWARD)
+    assert_close(x.cpu(), g["x"], RTOL, what="forward_p")
+    assert_close(logq.cpu(), g["log_prob"], RTOL, what="log q from the sampling pass")
+    zb, sum_s2, lp = ops.flow_couplings(_dev(g["x"]), cond, wstream, b2, mask, R, h, ops.FLOW_INVERSE)
+    assert_close(zb.cpu(), g["z_back"], RTOL, what="backward_p z")
+    assert_close(-sum_s2.cpu(), g["log_det"], RTOL, what="log_det")
+    assert_close(lp.cpu(), g["log_prob"], RTOL, what="log_prob")
+
+
+def test_flow_shared_conditioning_rows(gpu_lib):
+    """B images x N hypotheses with per-image conditioning == per-row conditioning (feat.repeat)."""
+    from mhentropy_amd import ops
+    from oracle import flows_ref
+    h, steps, B, N = 64, 2, 3, 10
+    sd = synth.flow_state(5, 45, 512, (h, h), steps)
+    wstream, b2, mask, Wc, bc = _flow_device_state(sd, 45, h, steps)
+    rng = np.random.default_rng(1)
+    feat = rng.normal(0, 1, (B, 512)).astype(np.float32)
+    z0 = rng.normal(0, 1, (N * B, 45)).astype(np.float32)
+    cond = ops.linear(_dev(feat), Wc, bc).view(B, 4 * steps, 2, h)
+    x, _, logq = ops.flow_couplings(_dev(z0), cond, wstream, b2, mask, B, h, ops.FLOW_FORWARD)
+    sdt = {k: torch.as_tensor(v) for k, v in sd.items()}
+    with torch.no_grad():
+        xr = flows_ref.forward_p(sdt, torch.as_tensor(z0), torch.as_tensor(feat).repeat(N, 1))
+        lq = flows_ref.log_prob(sdt, xr, torch.as_tensor(feat).repeat(N, 1))
+    assert_close(x.cpu(), xr, RTOL, what="x")
+    assert_close(logq.cpu(), lq, RTOL, what="log q")
+
+
+def test_mano_joints_and_verts_match_reference_vectors(gpu_lib):
+    from mhentropy_amd import ops
+    g = load_golden("mano")
+    blob = _mano_blob(int(g["table_seed"]))
+    theta, beta = g["theta"], g["beta"]
+    R = theta.shape[0]
+    det = np.zeros((R, 16), np.float32)
+    det[:, :3], det[:, 3:13] = theta[:, :3], beta
+    o = ops.mano_joints(_dev(theta[:, 3:]), _dev(det), blob, want=("z", "xyz"))
+    tj = torch.as_tensor(g["mano_joints"])
+    rel = tj - tj[:, 12:13]
+    bone = rel[:, 11].norm(dim=-1)
+    assert_close(o["xyz"].cpu().view(R, 21, 3), rel / bone[:, None, None], RTOL, what="xyz")
+    verts = ops.mano_verts(o["z"], blob)
+    assert_close(verts.cpu(), (torch.as_tensor(g["mesh"]) - tj[:, 12:13]) / bone[:, None, None], RTOL, what="verts")
+
+
+@pytest.mark.parametrize("tag", ["small", "shipped"])
+def test_loss_rows_match_reference_vectors(gpu_lib, tag):
+    from mhentropy_amd import ops
+    g = load_golden(f"mhent_{tag}")
+    B, N = int(g["B"]), int(g["N_loss"])
+    blob = _mano_blob(0)
+    z = g["z_loss"]
+    det = np.concatenate([z[:B, :3], z[:B, 48:61]], 1)
+    o = ops.mano_joints(_dev(z[:, 3:48]), _dev(det), blob, _dev(g["y_crop_uv"]), _dev(g["y_vis"]))
+    assert_close(o["z"].cpu(), z, 0.0, what="z assembly (pure copy)")
+    for i, k in enumerate(("log_p_uv_giv_z", "log_p_th3", "log_p_th45", "log_p_bt")):
+        assert_close(o["terms"][:, i].cpu(), g["terms_" + k], RTOL, 1e-6, what=k)
+    assert_close(o["norms"][:, 0].cpu(), np.tile(g["loss_th_norm"], 1), RTOL, what="th_norm")
+    assert_close(o["norms"][:, 1].cpu(), g["loss_bt_norm"], RTOL, what="bt_norm")
+    q, h, lp = ops.elbo_reduce(o["log_p"], _dev(g["log_q_loss"]), N, B)
+    assert_close(q.cpu(), g["loss_q_log_p_z_giv_y"], RTOL, what="q_log_p_z_giv_y")
+    assert_close(h.cpu(), g["loss_h_q_z_giv_i"], RTOL, what="h_q_z_giv_i")
+    assert_close(lp.cpu(), g["loss_log_p"], RTOL, what="log_p")
+
+
+def test_linear_matches_torch(gpu_lib):
+    from mhentropy_amd import ops
+    rng = np.random.default_rng(3)
+    for M, N, K, relu in ((5, 16, 512, False), (64, 512, 2048, False), (130, 512, 512, True), (3, 196, 64, False)):
+        x = rng.normal(0, 1, (M, K)).astype(np.float32)
+        w = rng.normal(0, 0.05, (N, K)).astype(np.float32)
+        b = rng.normal(0, 1, (N,)).astype(np.float32)
+        y = ops.linear(_dev(x), _dev(w), _dev(b), relu=relu)
+        ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+        if relu:
+            ref = np.maximum(ref, 0)
+        assert_close(y.cpu(), ref, 2e-6, what=f"linear {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [
+    # B, H, W, Cin, Cout, K, stride, pad
+    (2, 16, 16, 64, 64, 1, 1, 0), (2, 16, 16, 64, 128, 3, 1, 1), (2, 17, 15, 64, 256, 3, 2, 1),
+    (1, 32, 32, 3, 64, 7, 2, 3), (3, 8, 8, 128, 64, 1, 2, 0), (1, 9, 9, 256, 512, 3, 1, 1)])
+def test_conv_matches_torch(gpu_lib, dtype, cfg):
+    from mhentropy_amd import ops, resnet
+    B, H, W, Cin, Cout, K, stride, pad = cfg
+    rng = np.random.default_rng(7)
+    x = rng.normal(0, 1, (B, Cin, H, W)).astype(np.float32)
+    w = rng.normal(0, (2.0 / (Cin * K * K)) ** 0.5, (Cout, Cin, K, K)).astype(np.float32)
+    osc = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    osh = rng.normal(0, 0.1, Cout).astype(np.float32)
+    xt, wt = torch.as_tensor(x), torch.as_tensor(w)
+    if dtype == torch.bfloat16:       # same quantised operands on both sides, f32 accumulate
+        xt, wt = xt.bfloat16().float(), wt.bfloat16().float()
+    ref = torch.nn.functional.conv2d(xt.double(), wt.double(), None, stride, pad)
+    xd = ops.nchw_to_nhwc(_dev(x), dtype)
+    wd = resnet.pack_conv_weight(torch.as_tensor(w), dtype, xd.shape[-1]).cuda()
+    stats = torch.zeros(2, Cout, device="cuda")
+    y = ops.conv2d_nhwc(xd, wd, K, K, stride, pad, stats=stats)
+    tol = 2e-6 if dtype == torch.float32 else 6e-3        # bf16: output rounding 2^-9
+    assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, tol, what="raw conv")
+    n = ref.numel() / Cout
+    assert_close(stats[0].cpu() / n, ref.mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean")
+    assert_close(stats[1].cpu() / n, (ref ** 2).mean((0, 2, 3)), 1e-5, what="batch E[x^2]")
+    # fused eval-mode epilogue: relu(conv*scale+shift + residual)
+    res = rng.normal(0, 1, tuple(ref.shape)).astype(np.float32)
+    rd = torch.as_tensor(res).permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    y2 = ops.conv2d_nhwc(xd, wd, K, K, stride, pad, out_scale=_dev(osc), out_shift=_dev(osh), residual=rd, relu_out=True)
+    ref2 = torch.relu(ref * torch.as_tensor(osc).view(1, -1, 1, 1) + torch.as_tensor(osh).view(1, -1, 1, 1)
+                      + rd.float().cpu().permute(0, 3, 1, 2))
+    assert_close(y2.float().cpu().permute(0, 3, 1, 2), ref2, tol, what="fused epilogue")
+    # fused producer BN+ReLU on the operand load (padding must stay zero)
+    isc = rng.uniform(0.5, 1.5, xd.shape[-1]).astype(np.float32)
+    ish = rng.normal(0, 0.3, xd.shape[-1]).astype(np.float32)
+    y3 = ops.conv2d_nhwc(xd, wd, K, K, stride, pad, in_scale=_dev(isc), in_shift=_dev(ish), relu_in=True)
+    xin = torch.relu(xt * torch.as_tensor(isc[:Cin]).view(1, -1, 1, 1) + torch.as_tensor(ish[:Cin]).view(1, -1, 1, 1))
+    if dtype == torch.bfloat16:
+        xin = xin.bfloat16().float()
+    ref3 = torch.nn.functional.conv2d(xin.double(), wt.double(), None, stride, pad)
+    assert_close(y3.float().cpu().permute(0, 3, 1, 2), ref3, tol, what="fused input transform")
+
+
+def test_metrics_match_reference_vectors(gpu_lib):
+    from mhentropy_amd import ops, criteria
+    for tag in ("small", "shipped"):
+        g = load_golden(f"mhent_{tag}")
+        out = ops.metrics(_dev(g["sample_xyz"]), _dev(g["sample_uv"]), _dev(g["y_pose3d"]), _dev(g["y_scale"]),
+                          _dev(g["y_crop_uv"]), _dev(g["y_vis"]))
+        for i, k in enumerate(criteria.METRIC_KEYS):
+            assert_close(out[i].cpu(), g["metric_" + k], RTOL, what=k)

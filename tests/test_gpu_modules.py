@@ -1,0 +1,140 @@
+"""GPU parity at the reference's own module boundary: MHEnt.get_loss / sample,
+MHEntLoss, ManoLayer.forward, RealNVP.log_prob/sample and the ResNet trunk,
+against the golden vectors captured from the reference and against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, assert_close
+from mhentropy_amd import synth
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4          # BASELINE.json north_star: 1e-4 relative, fp32
+
+
+def _t(d, dev="cuda"):
+    return {k: torch.as_tensor(v).to(dev) for k, v in d.items()}
+
+
+def _model_from_golden(g, backbone="resnet50"):
+    from mhentropy_amd import harness
+    seed, h, steps = int(g["seed"]), int(g["h"]), int(g["steps"])
+    model = harness.build_mhent(backbone=backbone, h_dims=(h, h), num_steps=steps, tables=synth.mano_tables(0))
+    sd = {"q_z_giv_i." + k: torch.as_tensor(v) for k, v in synth.flow_state(seed, 45, 512, (h, h), steps).items()}
+    sd.update({k: torch.as_tensor(v) for k, v in synth.head_state(seed, 2048, 512, 16).items()})
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected
+    model = model.cuda()
+    trunk = torch.as_tensor(g["trunk"]).cuda()
+    model.feat_extractor.res.forward = lambda x: trunk        # the fixture pins everything after the trunk
+    return model
+
+
+@pytest.mark.parametrize("tag", ["small", "shipped"])
+@pytest.mark.parametrize("fused", [True, False])
+def test_get_loss_matches_reference_vectors(gpu_lib, tag, fused):
+    g = load_golden(f"mhent_{tag}")
+    model = _model_from_golden(g)
+    model.fused_entropy = fused
+    B = int(g["B"])
+    y = _t({k[2:]: v for k, v in g.items() if k.startswith("y_")})
+    x = torch.zeros(B, 3, 8, 8, device="cuda")
+    out = model.get_loss(x, y, mods=["uv"], noise=torch.as_tensor(g["z0_loss"]).cuda())
+    assert set(out) == {"th_norm", "bt_norm", "log_p", "q_log_p_z_giv_y", "h_q_z_giv_i"}
+    for k in out:
+        assert_close(out[k].cpu(), g["loss_" + k], RTOL, what=k)
+
+
+@pytest.mark.parametrize("tag,N", [("small", 4), ("shipped", 16)])
+def test_other_hypothesis_counts(gpu_lib, tag, N):
+    g = load_golden(f"mhent_{tag}")
+    model = _model_from_golden(g)
+    B = int(g["B"])
+    feat = torch.as_tensor(g["feat"]).cuda()
+    z0 = torch.as_tensor(g[f"z0_N{N}"]).cuda()
+    th45, lq = model.q_z_giv_i.sample_with_log_prob(z0, feat)
+    assert_close(th45.cpu(), g[f"z_N{N}"][:, 3:48], RTOL, what="th45")
+    assert_close(lq.cpu(), g[f"logq_N{N}"], RTOL, what="log q (fused)")
+    assert_close(model.q_z_giv_i.log_prob(th45, logvar=feat).cpu(), g[f"logq_N{N}"], RTOL, what="log q (inverse pass)")
+    from mhentropy_amd import ops
+    o = ops.mano_joints(th45, model._det(feat), model.mano_dec.table_blob(), torch.as_tensor(g["y_crop_uv"]).cuda(),
+                        torch.as_tensor(g["y_vis"]).cuda(), want=("log_p", "z"))
+    assert_close(o["z"].cpu(), g[f"z_N{N}"], RTOL, what="z")
+    assert_close(o["log_p"].cpu(), g[f"logp_rows_N{N}"], RTOL, what="log_p rows")
+
+
+@pytest.mark.parametrize("tag", ["small", "shipped"])
+def test_sample_and_criterion_match_reference_vectors(gpu_lib, tag):
+    from mhentropy_amd.criteria import MHEntLoss
+    g = load_golden(f"mhent_{tag}")
+    model = _model_from_golden(g)
+    B = int(g["B"])
+    y = _t({k[2:]: v for k, v in g.items() if k.startswith("y_")})
+    x = torch.zeros(B, 3, 8, 8, device="cuda")
+    s = model.sample(x, N=[4, 4], temp=0.8, mods={"uv", "xyz", "verts"}, y=y,
+                     noise=torch.as_tensor(g["z0_sample"]).cuda() / 0.8)
+    for k in ("th_bt", "logs_t", "verts", "xyz", "uv"):
+        assert tuple(s[k].shape) == g["sample_" + k].shape, k
+        assert_close(s[k].cpu(), g["sample_" + k], RTOL, what="sample." + k)
+    assert torch.equal(s["faces"].cpu(), torch.as_tensor(synth.mano_tables(0)["faces"]))
+    out = {"log_p": torch.as_tensor(g["loss_log_p"]).cuda(), "xyz": s["xyz"], "uv": s["uv"], "verts": s["verts"]}
+    total, losses, metrics = MHEntLoss()(out, y)
+    assert_close(total.cpu(), g["criterion_total"], RTOL, what="total")
+    assert set(losses) == {"neg_log_p"}
+    assert len(metrics) == 14
+    for k, v in metrics.items():
+        assert_close(v.cpu(), g["metric_" + k], 5e-4, what=k)      # metrics amplify the 1e-4 of xyz/uv through std/min
+
+
+def test_mano_layer_forward_matches_reference_vectors(gpu_lib):
+    from mhentropy_amd.ManoLayer import ManoLayer
+    g = load_golden("mano")
+    layer = ManoLayer(skeidx="RHD", flat_hand_mean=False, ncomps=45, use_pca=True, tables=synth.mano_tables(0)).cuda()
+    out = layer(beta=torch.as_tensor(g["beta"]).cuda(), theta=torch.as_tensor(g["theta"]).cuda())
+    for k in ("mesh", "mano_joints", "joints"):
+        assert_close(out[k].cpu(), g[k], RTOL, what=k)
+
+
+@pytest.mark.parametrize("arch,B,S", [("resnet18", 4, 64), ("resnet50", 4, 64)])
+@pytest.mark.parametrize("training", [True, False])
+def test_resnet_trunk_matches_oracle(gpu_lib, arch, B, S, training):
+    from mhentropy_amd import resnet
+    from oracle import resnet_ref
+    sdn = synth.resnet_state(3, arch)
+    x, _ = synth.batch(3, B, image_size=S)
+    trunk = resnet.ResNetTrunk(arch)
+    trunk.load_state_dict({k: torch.as_tensor(v) for k, v in sdn.items()})
+    trunk = trunk.cuda().train(training)
+    f = trunk(torch.as_tensor(x).cuda())
+    stats = {}
+    with torch.no_grad():
+        ref = resnet_ref.forward({k: torch.as_tensor(v) for k, v in sdn.items()}, torch.as_tensor(x), arch, training, stats)
+    assert_close(f.cpu(), ref, RTOL, what="pooled feature")
+    if training:      # running statistics updated like torch's BatchNorm
+        mean, var, rm, rv = stats["layer1.0.bn1"]
+        assert_close(trunk.layer1[0].bn1.running_mean.cpu(), rm, RTOL, 1e-6, what="running_mean")
+        assert_close(trunk.layer1[0].bn1.running_var.cpu(), rv, RTOL, what="running_var")
+        assert int(trunk.bn1.num_batches_tracked) == 1
+
+
+def test_full_path_end_to_end_vs_oracle(gpu_lib):
+    """config C0 (BASELINE.json configs[0]): ResNet-18, 2-block small flow, K=4, B=2, 256x256."""
+    from mhentropy_amd import harness
+    from oracle import network_ref, mano_ref
+    B, N, h, steps = 2, 4, 64, 2
+    sdn = {"q_z_giv_i." + k: v for k, v in synth.flow_state(31, 45, 512, (h, h), steps).items()}
+    sdn.update(synth.head_state(31, 512, 512, 16))
+    sdn.update({"feat_extractor.res." + k: v for k, v in synth.resnet_state(31, "resnet18").items()})
+    x, yn = synth.batch(31, B, image_size=256)
+    z0 = synth.noise(31, N * B)
+    model = harness.build_mhent(backbone="resnet18", h_dims=(h, h), num_steps=steps, tables=synth.mano_tables(0))
+    missing, unexpected = model.load_state_dict({k: torch.as_tensor(v) for k, v in sdn.items()}, strict=False)
+    assert not unexpected and all(k.startswith("mano_dec.") for k in missing)
+    model = model.cuda().train()
+    out = model.get_loss(torch.as_tensor(x).cuda(), _t(yn), mods=["uv"], N=N, noise=torch.as_tensor(z0).cuda())
+    sd = {k: torch.as_tensor(v) for k, v in sdn.items()}
+    tb = mano_ref.tables_from_numpy(synth.mano_tables(0))
+    with torch.no_grad():
+        ref = network_ref.get_loss(sd, tb, torch.as_tensor(x), _t(yn, "cpu"), torch.as_tensor(z0), N, "resnet18", True)
+    for k in ("th_norm", "bt_norm", "q_log_p_z_giv_y", "h_q_z_giv_i", "log_p"):
+        assert_close(out[k].cpu(), ref[k], 2e-4, what=k)       # 18 BN layers of round-off in front of the 1e-4 path
