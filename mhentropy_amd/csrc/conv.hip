@@ -25,7 +25,7 @@ struct Params {
     const void *x; const void *w; void *y;
     const float *in_scale, *in_shift, *out_scale, *out_shift;
     const void *residual;
-    float *stats;
+    double *stats;
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, M, Kpad, relu_in, relu_out;
 };
 
@@ -221,21 +221,23 @@ __global__ __launch_bounds__(256) void conv_kernel(const Params p) {
             }
             if (l15 == 0 && nv) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { atomicAdd(p.stats + n + r, s1[r]); atomicAdd(p.stats + p.Cout + n + r, s2[r]); }
+                for (int r = 0; r < 4; ++r) { atomicAdd(p.stats + n + r, (double)s1[r]); atomicAdd(p.stats + p.Cout + n + r, (double)s2[r]); }
             }
         }
     }
 }
 
 // ---------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const float *__restrict__ stats, const float *__restrict__ gamma,
+__global__ void bn_finalize_kernel(const double *__restrict__ stats, const float *__restrict__ gamma,
                                    const float *__restrict__ beta, float *__restrict__ rmean, float *__restrict__ rvar,
                                    float *__restrict__ scale, float *__restrict__ shift, int C, float count, float momentum,
                                    float eps) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const float mean = stats[c] / count;
-    const float var = fmaxf(stats[C + c] / count - mean * mean, 0.f);      // biased, as F.batch_norm normalises with
+    // the accumulators are f64 (f32 per-wave partials), so E[x^2]-E[x]^2 keeps fp32-level accuracy
+    const double dmean = stats[c] / (double)count;
+    const double dvar = fmax(stats[C + c] / (double)count - dmean * dmean, 0.0);   // biased, as F.batch_norm normalises with
+    const float mean = (float)dmean, var = (float)dvar;
     const float sc = gamma[c] / sqrtf(var + eps);
     scale[c] = sc;
     shift[c] = beta[c] - mean * sc;
@@ -381,7 +383,7 @@ static inline int elem_chunk(int dtype) { return dtype == MHE_F32 ? 4 : 8; }
 
 extern "C" int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
                                const float *in_shift, const float *out_scale, const float *out_shift,
-                               const void *residual, float *stats, void *stream) {
+                               const void *residual, double *stats, void *stream) {
     MHE_REQUIRE(d && x && w && y, "mhe_conv2d_nhwc: null pointer");
     MHE_REQUIRE(d->dtype == MHE_F32 || d->dtype == MHE_BF16, "mhe_conv2d_nhwc: dtype=%d", d->dtype);
     const int ce = elem_chunk(d->dtype), bke = 8 * ce;
@@ -417,7 +419,7 @@ extern "C" int mhe_linear_f32(const float *X, const float *W, const float *bias,
     return mhe_conv2d_nhwc(&d, X, W, Y, nullptr, nullptr, nullptr, bias, nullptr, nullptr, stream);
 }
 
-extern "C" int mhe_bn_finalize(const float *stats, const float *gamma, const float *beta, float *running_mean,
+extern "C" int mhe_bn_finalize(const double *stats, const float *gamma, const float *beta, float *running_mean,
                                float *running_var, float *scale, float *shift, int C, float count, float momentum,
                                float eps, void *stream) {
     MHE_REQUIRE(stats && gamma && beta && scale && shift && C > 0 && count > 1.f, "mhe_bn_finalize: bad arguments");

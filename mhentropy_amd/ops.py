@@ -160,7 +160,7 @@ def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in
     if residual is not None:
         _chk(residual, dt, "conv.residual", (B, Ho, Wo, Cout))
     if stats is not None:
-        _chk(stats, torch.float32, "conv.stats", (2, Cout))
+        _chk(stats, torch.float64, "conv.stats", (2, Cout))
     d = ConvDesc(B, H, W, Cin, Cout, KH, KW, stride, pad, dtype_code(dt), int(relu_in), int(relu_out))
     check(_lib.lib().mhe_conv2d_nhwc(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _ptr(in_scale), _ptr(in_shift),
                                      _ptr(out_scale), _ptr(out_shift), _ptr(residual), _ptr(stats), _stream()),

@@ -126,7 +126,7 @@ class ResNetTrunk(nn.Module):
 class _StatsPool:
     """one zeroed arena for all per-channel (sum, sum^2) accumulators of a forward"""
     def __init__(self, device, floats=2 * 32768):
-        self.buf = torch.zeros(floats, device=device, dtype=torch.float32)
+        self.buf = torch.zeros(floats, device=device, dtype=torch.float64)
         self.off = 0
 
     def take(self, C):

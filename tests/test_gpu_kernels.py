@@ -148,7 +148,7 @@ def test_conv_matches_torch(gpu_lib, dtype, cfg):
     ref = torch.nn.functional.conv2d(xt.double(), wt.double(), None, stride, pad)
     xd = ops.nchw_to_nhwc(_dev(x), dtype)
     wd = resnet.pack_conv_weight(torch.as_tensor(w), dtype, xd.shape[-1]).cuda()
-    stats = torch.zeros(2, Cout, device="cuda")
+    stats = torch.zeros(2, Cout, device="cuda", dtype=torch.float64)
     y = ops.conv2d_nhwc(xd, wd, K, K, stride, pad, stats=stats)
     tol = 2e-6 if dtype == torch.float32 else 6e-3        # bf16: output rounding 2^-9
     assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, tol, what="raw conv")
