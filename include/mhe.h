@@ -143,9 +143,10 @@ int mhe_elbo_reduce_f32(const float *log_p_rows, const float *log_q_rows,
  *       relu(x*scale+shift) applied while loading (padding stays zero)
  *   out_scale/out_shift [Cout] (optional, eval-mode BN), residual (optional,
  *       [B,Ho,Wo,Cout]), relu flag: y = act(conv*scale+shift + residual)
- *   stats [2,Cout] f64 (optional): += per-channel sum and sum of squares of the
- *       raw conv output (train-mode BatchNorm batch statistics; f32 per-wave
- *       partials, f64 atomics); must be zeroed by the caller.
+ *   stats [S,2,Cout] f32 (optional), S = mhe_conv_stat_shards(): per-channel sum and
+ *       sum of squares of the raw conv output (train-mode BatchNorm batch
+ *       statistics).  Each workgroup reduces its tile in LDS and adds one value
+ *       per channel into shard (workgroup % S); must be zeroed by the caller.
  * dtype is the storage type of x, w, y, residual (MHE_F32 or MHE_BF16);
  * accumulation is always f32. */
 typedef struct mhe_conv_desc {
@@ -158,13 +159,15 @@ typedef struct mhe_conv_desc {
 int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y,
                     const float *in_scale, const float *in_shift,
                     const float *out_scale, const float *out_shift, const void *residual,
-                    double *stats, void *stream);
+                    float *stats, void *stream);
+int mhe_conv_stat_shards(void);
 
-/* BatchNorm batch statistics -> affine (train mode), torch semantics
+/* BatchNorm batch statistics (the sharded accumulators of mhe_conv2d_nhwc, summed in f64)
+ * -> affine (train mode), torch semantics
  * (momentum 0.1, eps 1e-5, unbiased running_var):
  *   mean = sum/n, var = sumsq/n - mean^2; scale = gamma/sqrt(var+eps);
  *   shift = beta - mean*scale; running stats updated in place when non-NULL. */
-int mhe_bn_finalize(const double *stats, const float *gamma, const float *beta,
+int mhe_bn_finalize(const float *stats, const float *gamma, const float *beta,
                     float *running_mean, float *running_var, float *scale, float *shift,
                     int C, float count, float momentum, float eps, void *stream);
 

@@ -25,11 +25,13 @@ struct Params {
     const void *x; const void *w; void *y;
     const float *in_scale, *in_shift, *out_scale, *out_shift;
     const void *residual;
-    double *stats;
+    float *stats;          // [NSH][2][Cout] sharded accumulators
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, M, Kpad, relu_in, relu_out;
 };
 
 constexpr int BM = 128;
+constexpr int NSH = 64;          // statistic shards: block b adds into shard b % NSH
+constexpr int MAXC = 2048;       // largest Cin whose BatchNorm affine is staged in LDS
 
 template <typename T> struct El;
 template <> struct El<float> { static constexpr int CE = 4; };
@@ -37,7 +39,7 @@ template <> struct El<u16>   { static constexpr int CE = 8; };
 
 __device__ __forceinline__ int swz(int row, int slot) { return row * 8 + (slot ^ ((row >> 1) & 7)); }
 
-// apply relu(v*scale+shift) to one 16-byte chunk of activations
+// apply relu(v*scale+shift) to one 16-byte chunk of activations; sc/sh point into LDS
 template <typename T>
 __device__ __forceinline__ uint4 in_transform(uint4 raw, const float *sc, const float *sh, int c, int relu) {
     if constexpr (sizeof(T) == 4) {
@@ -47,12 +49,16 @@ __device__ __forceinline__ uint4 in_transform(uint4 raw, const float *sc, const 
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         return __builtin_bit_cast(uint4, v);
     } else {
+        const float4 s0 = *reinterpret_cast<const float4 *>(sc + c), s1 = *reinterpret_cast<const float4 *>(sc + c + 4);
+        const float4 t0 = *reinterpret_cast<const float4 *>(sh + c), t1 = *reinterpret_cast<const float4 *>(sh + c + 4);
+        const float ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float tt[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
         unsigned in[4] = {raw.x, raw.y, raw.z, raw.w}, o[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float lo = __uint_as_float(in[i] << 16), hi = __uint_as_float(in[i] & 0xffff0000u);
-            lo = fmaf(lo, sc[c + 2 * i], sh[c + 2 * i]);
-            hi = fmaf(hi, sc[c + 2 * i + 1], sh[c + 2 * i + 1]);
+            lo = fmaf(lo, ss[2 * i], tt[2 * i]);
+            hi = fmaf(hi, ss[2 * i + 1], tt[2 * i + 1]);
             if (relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
             o[i] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
         }
@@ -66,6 +72,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const Params p) {
     constexpr int NJ_B = BN / 32;           // weight chunks per thread per stage
     constexpr int NTW = BN / 32;            // 16-wide channel tiles per wave
     __shared__ uint4 lds[2][(BM + BN) * 8];
+    __shared__ __attribute__((aligned(16))) float aff[2][MAXC];     // producer BatchNorm scale / shift
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int q = lane >> 4, l15 = lane & 15;
@@ -89,6 +96,10 @@ __global__ __launch_bounds__(256) void conv_kernel(const Params p) {
         wi0[j] = wo * p.stride - p.pad;
         xb[j] = (size_t)b * p.H * p.W;
     }
+    if (p.in_scale) {
+        for (int i = tid; i < p.Cin; i += 256) { aff[0][i] = p.in_scale[i]; aff[1][i] = p.in_shift[i]; }
+        __syncthreads();
+    }
     const int ntaps = p.KH * p.KW;
     const int nk = p.Kpad / BKE;
 
@@ -107,7 +118,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const Params p) {
             uint4 v = make_uint4(0, 0, 0, 0);
             if (ok) {
                 v = *reinterpret_cast<const uint4 *>(xg + ((xb[j] + (size_t)hi * p.W + wi) * p.Cin + c));
-                if (p.in_scale) v = in_transform<T>(v, p.in_scale, p.in_shift, c, p.relu_in);
+                if (p.in_scale) v = in_transform<T>(v, aff[0], aff[1], c, p.relu_in);
             }
             ra[j] = v;
         }
@@ -213,30 +224,54 @@ __global__ __launch_bounds__(256) void conv_kernel(const Params p) {
             }
         }
         if (p.stats) {
-            // sum the 16 pixels held by the lanes of one q-group, one atomic per channel per wave
+            // per-thread partials -> LDS [wave][value][lane]; the tile buffers are free after the main loop
+            float *red = reinterpret_cast<float *>(lds);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { s1[r] += __shfl_xor(s1[r], o, 64); s2[r] += __shfl_xor(s2[r], o, 64); }
+                red[(wave * (8 * NTW) + nt * 4 + r) * 64 + lane] = s1[r];
+                red[(wave * (8 * NTW) + 4 * NTW + nt * 4 + r) * 64 + lane] = s2[r];
             }
-            if (l15 == 0 && nv) {
+        }
+    }
+    if (p.stats) {
+        // one thread per (statistic, channel of the tile): sum the 2 pixel-waves x 16 lanes that hold it,
+        // then ONE coalesced f32 atomic per thread into this block's shard (no same-address pile-up)
+        __syncthreads();
+        const float *red = reinterpret_cast<const float *>(lds);
+        if (tid < 2 * BN) {
+            const int stat = tid / BN, ch = tid % BN;
+            const int wcc = ch / (BN / 2), cc = ch % (BN / 2), nt = cc >> 4, qq = (cc >> 2) & 3, r = cc & 3;
+            const int v = stat * 4 * NTW + nt * 4 + r;
+            float sum = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { atomicAdd(p.stats + n + r, (double)s1[r]); atomicAdd(p.stats + p.Cout + n + r, (double)s2[r]); }
+            for (int w2 = 0; w2 < 2; ++w2) {
+                const float *src = red + ((w2 * 2 + wcc) * (8 * NTW) + v) * 64 + qq * 16;
+#pragma unroll
+                for (int l = 0; l < 16; ++l) sum += src[l];
             }
+            const int n = n0 + ch;
+            if (n < p.Cout) atomicAdd(p.stats + ((size_t)(blockIdx.x % NSH) * 2 + stat) * p.Cout + n, sum);
         }
     }
 }
 
 // ---------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const double *__restrict__ stats, const float *__restrict__ gamma,
+__global__ void bn_finalize_kernel(const float *__restrict__ stats, const float *__restrict__ gamma,
                                    const float *__restrict__ beta, float *__restrict__ rmean, float *__restrict__ rvar,
                                    float *__restrict__ scale, float *__restrict__ shift, int C, float count, float momentum,
                                    float eps) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    // the accumulators are f64 (f32 per-wave partials), so E[x^2]-E[x]^2 keeps fp32-level accuracy
-    const double dmean = stats[c] / (double)count;
-    const double dvar = fmax(stats[C + c] / (double)count - dmean * dmean, 0.0);   // biased, as F.batch_norm normalises with
+    // shard sums are f32 (each shard holds <= M/(128*NSH) block partials); combine them in f64 so that
+    // E[x^2] - E[x]^2 keeps fp32-level accuracy
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll 8
+    for (int sh = 0; sh < NSH; ++sh) {
+        s1 += (double)stats[((size_t)sh * 2) * C + c];
+        s2 += (double)stats[((size_t)sh * 2 + 1) * C + c];
+    }
+    const double dmean = s1 / (double)count;
+    const double dvar = fmax(s2 / (double)count - dmean * dmean, 0.0);   // biased, as F.batch_norm normalises with
     const float mean = (float)dmean, var = (float)dvar;
     const float sc = gamma[c] / sqrtf(var + eps);
     scale[c] = sc;
@@ -383,7 +418,7 @@ static inline int elem_chunk(int dtype) { return dtype == MHE_F32 ? 4 : 8; }
 
 extern "C" int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
                                const float *in_shift, const float *out_scale, const float *out_shift,
-                               const void *residual, double *stats, void *stream) {
+                               const void *residual, float *stats, void *stream) {
     MHE_REQUIRE(d && x && w && y, "mhe_conv2d_nhwc: null pointer");
     MHE_REQUIRE(d->dtype == MHE_F32 || d->dtype == MHE_BF16, "mhe_conv2d_nhwc: dtype=%d", d->dtype);
     const int ce = elem_chunk(d->dtype), bke = 8 * ce;
@@ -392,6 +427,7 @@ extern "C" int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void
     MHE_REQUIRE(d->Cin % ce == 0, "mhe_conv2d_nhwc: Cin=%d must be a multiple of %d (pad channels)", d->Cin, ce);
     MHE_REQUIRE(d->Cout % 4 == 0, "mhe_conv2d_nhwc: Cout=%d must be a multiple of 4", d->Cout);
     MHE_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "mhe_conv2d_nhwc: in_scale/in_shift must come together");
+    MHE_REQUIRE(!in_scale || d->Cin <= conv::MAXC, "mhe_conv2d_nhwc: fused input affine supports Cin <= %d", conv::MAXC);
     conv::Params p;
     p.x = x; p.w = w; p.y = y; p.in_scale = in_scale; p.in_shift = in_shift; p.out_scale = out_scale;
     p.out_shift = out_shift; p.residual = residual; p.stats = stats;
@@ -410,6 +446,8 @@ extern "C" int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void
     return conv::launch_conv<u16>(p, (hipStream_t)stream);
 }
 
+extern "C" int mhe_conv_stat_shards(void) { return conv::NSH; }
+
 extern "C" int mhe_linear_f32(const float *X, const float *W, const float *bias, float *Y, int M, int N, int K, int act,
                               void *stream) {
     MHE_REQUIRE(X && W && Y && M > 0 && N > 0 && K > 0, "mhe_linear_f32: bad arguments");
@@ -419,7 +457,7 @@ extern "C" int mhe_linear_f32(const float *X, const float *W, const float *bias,
     return mhe_conv2d_nhwc(&d, X, W, Y, nullptr, nullptr, nullptr, bias, nullptr, nullptr, stream);
 }
 
-extern "C" int mhe_bn_finalize(const double *stats, const float *gamma, const float *beta, float *running_mean,
+extern "C" int mhe_bn_finalize(const float *stats, const float *gamma, const float *beta, float *running_mean,
                                float *running_var, float *scale, float *shift, int C, float count, float momentum,
                                float eps, void *stream) {
     MHE_REQUIRE(stats && gamma && beta && scale && shift && C > 0 && count > 1.f, "mhe_bn_finalize: bad arguments");

@@ -15,6 +15,11 @@ from ._lib import ConvDesc, check
 F32, BF16 = 0, 1
 FLOW_FORWARD, FLOW_INVERSE = 0, 1
 
+# bench.py instrumentation: when TIMING is set every conv launch is bracketed by
+# HIP events on the launch stream and logged as (kernel name, algorithmic flops, ev0, ev1)
+TIMING = False
+KERNEL_TIMES = []
+
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -34,6 +39,10 @@ def _chk(t, dtype, name, shape=None):
     if shape is not None and tuple(t.shape) != tuple(shape):
         raise _lib.MheError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
     return t
+
+
+def stat_shards():
+    return _lib.lib().mhe_conv_stat_shards()
 
 
 def dtype_code(dt):
@@ -160,11 +169,20 @@ def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in
     if residual is not None:
         _chk(residual, dt, "conv.residual", (B, Ho, Wo, Cout))
     if stats is not None:
-        _chk(stats, torch.float64, "conv.stats", (2, Cout))
+        _chk(stats, torch.float32, "conv.stats", (stat_shards(), 2, Cout))
     d = ConvDesc(B, H, W, Cin, Cout, KH, KW, stride, pad, dtype_code(dt), int(relu_in), int(relu_out))
+    if TIMING:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     check(_lib.lib().mhe_conv2d_nhwc(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _ptr(in_scale), _ptr(in_shift),
                                      _ptr(out_scale), _ptr(out_shift), _ptr(residual), _ptr(stats), _stream()),
           "mhe_conv2d_nhwc")
+    if TIMING:
+        ev1.record()
+        bke = 32 if dt == torch.float32 else 64
+        name = "conv_kernel<%s,%d,%s>" % ("float" if dt == torch.float32 else "bf16", 64 if Cout <= 64 else 128,
+                                          "true" if Cin % bke == 0 else "false")
+        KERNEL_TIMES.append((name, 2.0 * B * Ho * Wo * Cout * KH * KW * Cin, ev0, ev1))
     return y
 
 

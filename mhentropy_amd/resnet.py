@@ -124,17 +124,19 @@ class ResNetTrunk(nn.Module):
 
 
 class _StatsPool:
-    """one zeroed arena for all per-channel (sum, sum^2) accumulators of a forward"""
-    def __init__(self, device, floats=2 * 32768):
-        self.buf = torch.zeros(floats, device=device, dtype=torch.float64)
+    """one zeroed arena for all sharded per-channel (sum, sum^2) accumulators of a forward"""
+    def __init__(self, device, channels=32768):
+        self.S = ops.stat_shards()
+        self.buf = torch.zeros(self.S * 2 * channels, device=device, dtype=torch.float32)
         self.off = 0
 
     def take(self, C):
-        if self.off + 2 * C > self.buf.numel():
+        n = self.S * 2 * C
+        if self.off + n > self.buf.numel():
             self.buf = torch.zeros_like(self.buf)
             self.off = 0
-        v = self.buf[self.off:self.off + 2 * C].view(2, C)
-        self.off += 2 * C
+        v = self.buf[self.off:self.off + n].view(self.S, 2, C)
+        self.off += n
         return v
 
 

@@ -148,13 +148,14 @@ def test_conv_matches_torch(gpu_lib, dtype, cfg):
     ref = torch.nn.functional.conv2d(xt.double(), wt.double(), None, stride, pad)
     xd = ops.nchw_to_nhwc(_dev(x), dtype)
     wd = resnet.pack_conv_weight(torch.as_tensor(w), dtype, xd.shape[-1]).cuda()
-    stats = torch.zeros(2, Cout, device="cuda", dtype=torch.float64)
+    stats = torch.zeros(ops.stat_shards(), 2, Cout, device="cuda")
     y = ops.conv2d_nhwc(xd, wd, K, K, stride, pad, stats=stats)
     tol = 2e-6 if dtype == torch.float32 else 6e-3        # bf16: output rounding 2^-9
     assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, tol, what="raw conv")
     n = ref.numel() / Cout
-    assert_close(stats[0].cpu() / n, ref.mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean")
-    assert_close(stats[1].cpu() / n, (ref ** 2).mean((0, 2, 3)), 1e-5, what="batch E[x^2]")
+    st = stats.double().sum(0).cpu()
+    assert_close(st[0] / n, ref.mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean")
+    assert_close(st[1] / n, (ref ** 2).mean((0, 2, 3)), 1e-5, what="batch E[x^2]")
     # fused eval-mode epilogue: relu(conv*scale+shift + residual)
     res = rng.normal(0, 1, tuple(ref.shape)).astype(np.float32)
     rd = torch.as_tensor(res).permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
