@@ -59,7 +59,7 @@ def cpu_baseline(cfg, sd, seed, budget_s=20.0):
     # the GPU box exposes every host CPU but a 1-GPU job owns a 16-core share: oversubscribing stalls torch's pool
     ncores = min(len(os.sched_getaffinity(0)), os.cpu_count() or 1, 16)
     torch.set_num_threads(ncores)
-    Bs, K = min(cfg["B"], 4), cfg["K"]
+    Bs, K = min(cfg["B"], 64), cfg["K"]
     sdt = {k: torch.as_tensor(v) for k, v in sd.items()}
     tb = mano_ref.tables_from_numpy(synth.mano_tables(0))
     x, yn = synth.batch(seed + 1, Bs, image_size=256)
