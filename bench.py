@@ -93,20 +93,12 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from mhentropy_amd import dist as mdist
+    rank, local_rank, world, dist = mdist.init("nccl")
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+                         "python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if world == 1:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
@@ -132,22 +124,14 @@ def main():
         log(f"warm-up step {i} done")
     ops.KERNEL_TIMES.clear()
     ops.TIMING = True               # HIP events around every conv launch (same stream), read after the region
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    last = {}
+
+    def timed_step():
+        last["out"] = step()
+    dt = mdist.timed_region(timed_step, args.steps, dist, dev)          # barrier+sync | K steps | sync+barrier, MAX over ranks
+    out = last["out"]
     ops.TIMING = False
     log(f"timed region: {dt * 1e3 / args.steps:.2f} ms/step")
-    if dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     assert torch.isfinite(out["log_p"]).all(), "non-finite loss"
 
     if rank == 0:

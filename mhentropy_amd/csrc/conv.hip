@@ -182,62 +182,34 @@ __global__ __launch_bounds__(256) void conv_kernel(const Params p) {
         cur ^= 1;
     }
 
-    // ---- epilogue: lane owns channels n..n+3 (n = 4q + 16nt) of pixel m = 16mt + l15
-    T *yg = reinterpret_cast<T *>(p.y);
-    const T *rg = reinterpret_cast<const T *>(p.residual);
+    // ---- epilogue.  The accumulator holds y^T: lane (l15, q) owns channels 4q..4q+3 of tile nt
+    // for pixel 16mt + l15.  (1) batch statistics: per-thread partials -> LDS -> one thread per
+    // (statistic, channel) -> ONE coalesced f32 atomic per thread into this block's shard.
+    // (2) the tile is transposed through LDS (16-byte chunks XOR-swizzled by row) so that global
+    // stores are whole 16-byte pieces of contiguous channel rows instead of 8-byte row-strided ones.
+    constexpr int CPR = BN * (int)sizeof(T) / 16;          // 16-byte chunks per output row
+    constexpr int CMASK = (CPR - 1) & 15;
+    constexpr int EPC = 16 / (int)sizeof(T);               // elements per chunk
+    if (p.stats) {
+        float *red = reinterpret_cast<float *>(lds);
 #pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-        const int n = n0 + wc * (BN / 2) + nt * 16 + 4 * q;
-        const bool nv = n < p.Cout;           // Cout is a multiple of 4 (checked on the host)
-        float4 osc = make_float4(1.f, 1.f, 1.f, 1.f), osh = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (nv && p.out_scale) osc = *reinterpret_cast<const float4 *>(p.out_scale + n);
-        if (nv && p.out_shift) osh = *reinterpret_cast<const float4 *>(p.out_shift + n);
-        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NTW; ++nt) {
+            const bool nv = n0 + wc * (BN / 2) + nt * 16 + 4 * q < p.Cout;
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int m = m0 + wr * 64 + mt * 16 + l15;
-            const bool ok = nv && m < p.M;
-            v4f v = acc[nt][mt];
-            if (p.stats && ok) {
+            for (int mt = 0; mt < 4; ++mt) {
+                if (nv && m0 + wr * 64 + mt * 16 + l15 < p.M) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { s1[r] += v[r]; s2[r] = fmaf(v[r], v[r], s2[r]); }
-            }
-            v[0] = fmaf(v[0], osc.x, osh.x); v[1] = fmaf(v[1], osc.y, osh.y);
-            v[2] = fmaf(v[2], osc.z, osh.z); v[3] = fmaf(v[3], osc.w, osh.w);
-            if (!ok) continue;
-            const size_t off = (size_t)m * p.Cout + n;
-            if constexpr (sizeof(T) == 4) {
-                if (rg) { const float4 rr = *reinterpret_cast<const float4 *>(rg + off); v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
-                if (p.relu_out) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                *reinterpret_cast<float4 *>(yg + off) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                if (rg) {
-                    const uint2 rr = *reinterpret_cast<const uint2 *>(rg + off);
-                    v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-                    v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+                    for (int r = 0; r < 4; ++r) { const float v = acc[nt][mt][r]; s1[r] += v; s2[r] = fmaf(v, v, s2[r]); }
                 }
-                if (p.relu_out) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                uint2 o;
-                o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-                o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-                *reinterpret_cast<uint2 *>(yg + off) = o;
             }
-        }
-        if (p.stats) {
-            // per-thread partials -> LDS [wave][value][lane]; the tile buffers are free after the main loop
-            float *red = reinterpret_cast<float *>(lds);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 red[(wave * (8 * NTW) + nt * 4 + r) * 64 + lane] = s1[r];
                 red[(wave * (8 * NTW) + 4 * NTW + nt * 4 + r) * 64 + lane] = s2[r];
             }
         }
-    }
-    if (p.stats) {
-        // one thread per (statistic, channel of the tile): sum the 2 pixel-waves x 16 lanes that hold it,
-        // then ONE coalesced f32 atomic per thread into this block's shard (no same-address pile-up)
         __syncthreads();
-        const float *red = reinterpret_cast<const float *>(lds);
         if (tid < 2 * BN) {
             const int stat = tid / BN, ch = tid % BN;
             const int wcc = ch / (BN / 2), cc = ch % (BN / 2), nt = cc >> 4, qq = (cc >> 2) & 3, r = cc & 3;
@@ -251,6 +223,77 @@ __global__ __launch_bounds__(256) void conv_kernel(const Params p) {
             }
             const int n = n0 + ch;
             if (n < p.Cout) atomicAdd(p.stats + ((size_t)(blockIdx.x % NSH) * 2 + stat) * p.Cout + n, sum);
+        }
+        __syncthreads();
+    }
+    {
+        unsigned char *ot = reinterpret_cast<unsigned char *>(lds);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int row = wr * 64 + mt * 16 + l15;
+                const int e0 = wc * (BN / 2) + nt * 16 + 4 * q;             // first of 4 channels within the tile
+                const int boff = e0 * (int)sizeof(T);
+                const int chunk = (boff >> 4) ^ (row & CMASK);
+                unsigned char *dst = ot + ((size_t)row * CPR + chunk) * 16 + (boff & 15);
+                const v4f v = acc[nt][mt];
+                if constexpr (sizeof(T) == 4) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    uint2 o;
+                    o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                    o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                    *reinterpret_cast<uint2 *>(dst) = o;
+                }
+            }
+        __syncthreads();
+        T *yg = reinterpret_cast<T *>(p.y);
+        const T *rg = reinterpret_cast<const T *>(p.residual);
+        const bool plain = !p.out_scale && !p.out_shift && !rg && !p.relu_out;
+#pragma unroll
+        for (int j = 0; j < BM * CPR / 256; ++j) {
+            const int id = tid + 256 * j;
+            const int row = id / CPR, c = id % CPR;
+            const int m = m0 + row, n = n0 + c * EPC;
+            if (m >= p.M || n >= p.Cout) continue;
+            uint4 raw = *reinterpret_cast<const uint4 *>(ot + ((size_t)row * CPR + (c ^ (row & CMASK))) * 16);
+            const size_t off = (size_t)m * p.Cout + n;
+            if (!plain) {
+                float v[EPC];
+                if constexpr (sizeof(T) == 4) { v[0] = __uint_as_float(raw.x); v[1] = __uint_as_float(raw.y); v[2] = __uint_as_float(raw.z); v[3] = __uint_as_float(raw.w); }
+                else {
+                    const unsigned in[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(in[i] << 16); v[2 * i + 1] = __uint_as_float(in[i] & 0xffff0000u); }
+                }
+#pragma unroll
+                for (int i = 0; i < EPC; ++i) {
+                    const float sc = p.out_scale ? p.out_scale[n + i] : 1.f, sh = p.out_shift ? p.out_shift[n + i] : 0.f;
+                    v[i] = fmaf(v[i], sc, sh);
+                }
+                if (rg) {
+                    const uint4 rr = *reinterpret_cast<const uint4 *>(rg + off);
+                    if constexpr (sizeof(T) == 4) { v[0] += __uint_as_float(rr.x); v[1] += __uint_as_float(rr.y); v[2] += __uint_as_float(rr.z); v[3] += __uint_as_float(rr.w); }
+                    else {
+                        const unsigned in[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { v[2 * i] += __uint_as_float(in[i] << 16); v[2 * i + 1] += __uint_as_float(in[i] & 0xffff0000u); }
+                    }
+                }
+                if (p.relu_out) {
+#pragma unroll
+                    for (int i = 0; i < EPC; ++i) v[i] = fmaxf(v[i], 0.f);
+                }
+                if constexpr (sizeof(T) == 4) raw = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+                else {
+                    unsigned o[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (unsigned)f32_to_bf16(v[2 * i]) | ((unsigned)f32_to_bf16(v[2 * i + 1]) << 16);
+                    raw = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+            }
+            *reinterpret_cast<uint4 *>(yg + off) = raw;
         }
     }
 }
@@ -425,7 +468,7 @@ extern "C" int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void
     MHE_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0,
                 "mhe_conv2d_nhwc: bad geometry");
     MHE_REQUIRE(d->Cin % ce == 0, "mhe_conv2d_nhwc: Cin=%d must be a multiple of %d (pad channels)", d->Cin, ce);
-    MHE_REQUIRE(d->Cout % 4 == 0, "mhe_conv2d_nhwc: Cout=%d must be a multiple of 4", d->Cout);
+    MHE_REQUIRE(d->Cout % ce == 0, "mhe_conv2d_nhwc: Cout=%d must be a multiple of %d", d->Cout, ce);
     MHE_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "mhe_conv2d_nhwc: in_scale/in_shift must come together");
     MHE_REQUIRE(!in_scale || d->Cin <= conv::MAXC, "mhe_conv2d_nhwc: fused input affine supports Cin <= %d", conv::MAXC);
     conv::Params p;

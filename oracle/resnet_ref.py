@@ -37,6 +37,50 @@ def _bn(sd, name, x, training, stats_out=None):
     return F.batch_norm(x, rm, rv, sd[name + ".weight"], sd[name + ".bias"], False, BN_MOMENTUM, BN_EPS)
 
 
+def _q(t):
+    """round to bf16 and back: a storage point of the bf16 performance mode"""
+    return t.bfloat16().float()
+
+
+def forward_bf16_storage(sd, x, arch="resnet50", training=True):
+    """The same network with every stored tensor (input, weights, raw conv outputs, activations) rounded
+    to bf16 and all arithmetic in f32 - the rounding points of the product's bf16 encoder mode
+    (mhentropy_amd/resnet.py): statistics from the f32 conv result, BN+ReLU evaluated in f32 on the
+    bf16-stored conv output and stored as bf16."""
+    kind, blocks, _ = CFG[arch]
+
+    def conv_bn(inp, cname, bname, stride=1, pad=0, relu=True, res=None):
+        y = F.conv2d(inp, _q(sd[cname + ".weight"]), None, stride, pad)
+        if training:
+            mean, var = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
+        else:
+            mean, var = sd[bname + ".running_mean"], sd[bname + ".running_var"]
+        sc = sd[bname + ".weight"] / torch.sqrt(var + BN_EPS)
+        sh = sd[bname + ".bias"] - mean * sc
+        return _q(y), sc.view(1, -1, 1, 1), sh.view(1, -1, 1, 1)
+
+    y, sc, sh = conv_bn(_q(x), "conv1", "bn1", 2, 3)
+    a = _q(F.max_pool2d(F.relu(y * sc + sh), 3, 2, 1))
+    for li, nb in enumerate(blocks):
+        for bi in range(nb):
+            stride = 2 if (bi == 0 and li > 0) else 1
+            p = f"layer{li + 1}.{bi}"
+            if kind == "bottleneck":
+                y, sc, sh = conv_bn(a, p + ".conv1", p + ".bn1")
+                y, sc, sh = conv_bn(_q(F.relu(y * sc + sh)), p + ".conv2", p + ".bn2", stride, 1)
+                y, sc, sh = conv_bn(_q(F.relu(y * sc + sh)), p + ".conv3", p + ".bn3")
+            else:
+                y, sc, sh = conv_bn(a, p + ".conv1", p + ".bn1", stride, 1)
+                y, sc, sh = conv_bn(_q(F.relu(y * sc + sh)), p + ".conv2", p + ".bn2", 1, 1)
+            if (p + ".downsample.0.weight") in sd:
+                yd, scd, shd = conv_bn(a, p + ".downsample.0", p + ".downsample.1", stride)
+                idt = yd * scd + shd
+            else:
+                idt = a
+            a = _q(F.relu(y * sc + sh + idt))
+    return torch.flatten(F.adaptive_avg_pool2d(a, 1), 1)
+
+
 def forward(sd, x, arch="resnet50", training=True, stats_out=None, taps=None):
     """x (B,3,H,W) -> pooled feature (B,512|2048).  `taps` (dict) collects named
     intermediate activations for layer-by-layer parity tests."""

@@ -1,0 +1,56 @@
+"""CPU, world_size 2 over gloo: the multi-process bookkeeping bench.py relies on (rank shards that
+tile the global batch, barrier-bracketed max-over-ranks timing, scalar averaging)."""
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+from mhentropy_amd import dist as mdist
+
+WORKER = r'''
+import os, sys, time, json
+sys.path.insert(0, os.environ["MHE_ROOT"])
+import torch
+from mhentropy_amd import dist as mdist, synth
+rank, local_rank, world, dist = mdist.init("gloo")
+assert world == 2 and dist is not None
+lo, hi = mdist.shard_range(7, rank, world)
+x, y = synth.batch(100 + rank, hi - lo, image_size=8)            # rank-private synthetic shard
+calls = []
+def step():
+    calls.append(1); time.sleep(0.02 * (rank + 1))                # rank 1 is slower
+dt = mdist.timed_region(step, 3, dist, sync=lambda: None)
+avg = mdist.reduce_mean_scalars({"loss": float(rank), "n": float(hi - lo)}, dist)
+print(json.dumps({"rank": rank, "lo": lo, "hi": hi, "dt": dt, "calls": len(calls), "avg": avg,
+                  "sum_x": float(x.sum())}), flush=True)
+dist.destroy_process_group()
+'''
+
+
+def test_shard_ranges_tile_the_batch():
+    for gb in (1, 7, 256, 2048):
+        for world in (1, 2, 3, 8):
+            spans = [mdist.shard_range(gb, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == gb
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_ranks_over_gloo(tmp_path):
+    import json
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MHE_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29611", str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    recs = sorted((json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")), key=lambda r: r["rank"])
+    assert len(recs) == 2
+    assert (recs[0]["lo"], recs[0]["hi"], recs[1]["lo"], recs[1]["hi"]) == (0, 4, 4, 7)
+    assert recs[0]["calls"] == recs[1]["calls"] == 3                       # exactly K timed steps per rank
+    assert abs(recs[0]["dt"] - recs[1]["dt"]) < 1e-9                       # everyone reports the max over ranks
+    assert recs[0]["dt"] >= 3 * 0.04 - 1e-3                                # ... which is the slow rank's time
+    assert recs[0]["avg"] == recs[1]["avg"] == {"loss": 0.5, "n": 3.5}
+    assert recs[0]["sum_x"] != recs[1]["sum_x"]                            # different shards

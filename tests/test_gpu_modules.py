@@ -117,6 +117,31 @@ def test_resnet_trunk_matches_oracle(gpu_lib, arch, B, S, training):
         assert int(trunk.bn1.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+@pytest.mark.parametrize("bn_apply", ["pass", "load"])
+def test_resnet_trunk_bf16_storage_mode(gpu_lib, arch, bn_apply):
+    """bf16 is a performance mode: compared with the oracle that rounds at the same storage points
+    (f32 accumulate everywhere).  bf16 has 8 significant bits, so one flipped rounding is 4e-3 relative;
+    after up to 53 conv+BN layers the pooled feature agrees to a few 1e-2 of its scale."""
+    from mhentropy_amd import resnet
+    from oracle import resnet_ref
+    B, S = 4, 64
+    sdn = synth.resnet_state(4, arch)
+    x, _ = synth.batch(4, B, image_size=S)
+    trunk = resnet.ResNetTrunk(arch, compute_dtype=torch.bfloat16)
+    trunk.bn_apply = bn_apply
+    trunk.load_state_dict({k: torch.as_tensor(v) for k, v in sdn.items()})
+    trunk = trunk.cuda().train()
+    f = trunk(torch.as_tensor(x).cuda())
+    with torch.no_grad():
+        ref = resnet_ref.forward_bf16_storage({k: torch.as_tensor(v) for k, v in sdn.items()}, torch.as_tensor(x), arch, True)
+        ref32 = resnet_ref.forward({k: torch.as_tensor(v) for k, v in sdn.items()}, torch.as_tensor(x), arch, True)
+    err = (f.cpu() - ref).abs().max().item() / ref.abs().max().item()
+    err32 = (ref32 - ref).abs().max().item() / ref.abs().max().item()      # what bf16 storage itself costs
+    assert err < 4e-2, (err, err32)
+    assert (f.cpu() - ref).abs().mean().item() / ref.abs().mean().item() < 1e-2
+
+
 def test_full_path_end_to_end_vs_oracle(gpu_lib):
     """config C0 (BASELINE.json configs[0]): ResNet-18, 2-block small flow, K=4, B=2, 256x256."""
     from mhentropy_amd import harness
