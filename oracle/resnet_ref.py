@@ -42,7 +42,7 @@ def _q(t):
     return t.bfloat16().float()
 
 
-def forward_bf16_storage(sd, x, arch="resnet50", training=True):
+def forward_bf16_storage(sd, x, arch="resnet50", training=True, taps=None):
     """The same network with every stored tensor (input, weights, raw conv outputs, activations) rounded
     to bf16 and all arithmetic in f32 - the rounding points of the product's bf16 encoder mode
     (mhentropy_amd/resnet.py): statistics from the f32 conv result, BN+ReLU evaluated in f32 on the
@@ -78,6 +78,8 @@ def forward_bf16_storage(sd, x, arch="resnet50", training=True):
             else:
                 idt = a
             a = _q(F.relu(y * sc + sh + idt))
+            if taps is not None:
+                taps[p] = a
     return torch.flatten(F.adaptive_avg_pool2d(a, 1), 1)
 
 

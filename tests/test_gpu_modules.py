@@ -119,27 +119,43 @@ def test_resnet_trunk_matches_oracle(gpu_lib, arch, B, S, training):
 
 @pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
 @pytest.mark.parametrize("bn_apply", ["pass", "load"])
-def test_resnet_trunk_bf16_storage_mode(gpu_lib, arch, bn_apply):
-    """bf16 is a performance mode: compared with the oracle that rounds at the same storage points
-    (f32 accumulate everywhere).  bf16 has 8 significant bits, so one flipped rounding is 4e-3 relative;
-    after up to 53 conv+BN layers the pooled feature agrees to a few 1e-2 of its scale."""
-    from mhentropy_amd import resnet
+def test_resnet_trunk_bf16_storage_mode(gpu_lib, arch, bn_apply, monkeypatch):
+    """bf16 is a performance mode, checked against the oracle that rounds at the same storage points
+    (f32 accumulate everywhere).  Two roundings of values that differ by 1e-6 disagree by a full bf16 ulp
+    (4e-3) on a few elements, and after a handful of layers on all of them, so agreement is asserted
+    tightly on the first residual block (where the implementations are still in lock-step), and on the
+    pooled feature within the band by which bf16 storage itself moves the f32 result."""
+    from mhentropy_amd import resnet, ops
     from oracle import resnet_ref
-    B, S = 4, 64
+    B, S = 8, 128        # >= 128 samples per channel in every BatchNorm
     sdn = synth.resnet_state(4, arch)
+    sd = {k: torch.as_tensor(v) for k, v in sdn.items()}
     x, _ = synth.batch(4, B, image_size=S)
     trunk = resnet.ResNetTrunk(arch, compute_dtype=torch.bfloat16)
     trunk.bn_apply = bn_apply
-    trunk.load_state_dict({k: torch.as_tensor(v) for k, v in sdn.items()})
+    trunk.load_state_dict(sd)
     trunk = trunk.cuda().train()
-    f = trunk(torch.as_tensor(x).cuda())
+    taps, orig = [], ops.bn_act
+
+    def spy(x_, scale, shift, res=None, *a, **k):
+        y = orig(x_, scale, shift, res, *a, **k)
+        if res is not None:                      # the tail of a residual block
+            taps.append(y.float().cpu().permute(0, 3, 1, 2).clone())
+        return y
+    monkeypatch.setattr(ops, "bn_act", spy)
+    f = trunk(torch.as_tensor(x).cuda()).cpu()
+    ref_taps = {}
     with torch.no_grad():
-        ref = resnet_ref.forward_bf16_storage({k: torch.as_tensor(v) for k, v in sdn.items()}, torch.as_tensor(x), arch, True)
-        ref32 = resnet_ref.forward({k: torch.as_tensor(v) for k, v in sdn.items()}, torch.as_tensor(x), arch, True)
-    err = (f.cpu() - ref).abs().max().item() / ref.abs().max().item()
-    err32 = (ref32 - ref).abs().max().item() / ref.abs().max().item()      # what bf16 storage itself costs
-    assert err < 4e-2, (err, err32)
-    assert (f.cpu() - ref).abs().mean().item() / ref.abs().mean().item() < 1e-2
+        ref = resnet_ref.forward_bf16_storage(sd, torch.as_tensor(x), arch, True, taps=ref_taps)
+        ref32 = resnet_ref.forward(sd, torch.as_tensor(x), arch, True)
+    first = ref_taps["layer1.0"]
+    e0 = (taps[0] - first).abs().mean().item() / first.abs().mean().item()
+    err = (f - ref).abs().mean().item() / ref.abs().mean().item()
+    err32 = (ref32 - ref).abs().mean().item() / ref.abs().mean().item()
+    print(f"bf16 trunk {arch}/{bn_apply}: first block mean-rel {e0:.2e}; pooled feature mean-rel {err:.2e} "
+          f"(bf16-storage oracle vs f32 oracle: {err32:.2e})")
+    assert e0 < 1e-3, e0
+    assert err < max(1e-2, 1.5 * err32), (err, err32)
 
 
 def test_full_path_end_to_end_vs_oracle(gpu_lib):
