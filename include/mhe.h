@@ -89,6 +89,21 @@ int mhe_flow_couplings_f32(const float *in, float *out, const float *cond,
                            int R, int B, int dim, int hidden, int ncoup, int direction,
                            void *stream);
 
+/* bf16-operand variant (bf16 x bf16 products, f32 accumulate, hidden activations rounded to bf16
+ * between layers; flow variable, s, t, exp and log-det in f32): same contract as
+ * mhe_flow_couplings_f32 with `wstream` = 2*ncoup nets packed by mhe_flow_pack_net_bf16_host and
+ * `bias2` zero-padded to [2*ncoup, 64] (uniform scalar loads, no bounds test in the kernel).
+ * v_mfma_f32_32x32x16_bf16, 32 rows per wave, weights DMA'd (global_load_lds) into an LDS ring.
+ * hidden in {128, 256, 512}, dim <= 48. */
+size_t mhe_flow_packed_bytes_per_net_bf16(int dim, int hidden);
+int mhe_flow_pack_net_bf16_host(const float *W0_host, const float *W1_host, const float *W2_host,
+                                int dim, int hidden, void *out_host);
+int mhe_flow_couplings_bf16(const float *in, float *out, const float *cond,
+                            const void *wstream, const float *bias2, const float *mask,
+                            float *sum_s, float *log_prob,
+                            int R, int B, int dim, int hidden, int ncoup, int direction,
+                            void *stream);
+
 /* MANO decode + likelihood ------------------------------------------------- */
 
 /* Number of floats of the packed MANO table blob (layout: mhentropy_amd/mano_pack.py). */

@@ -49,22 +49,31 @@ class RealNVP(nn.Module):
         self.s = nn.ModuleList([nets(dim, cond_dim=tsfm_on, h_dims=h_dims) for _ in range(len(mask))])
         self.scale = 1.0
         self._pack = None
+        # operand dtype of the coupling MLPs: float32 (parity mode) or bfloat16 (performance mode, f32 accumulate)
+        self.compute_dtype = torch.float32
 
     # ---- device-side packed parameters, rebuilt when any weight changes ------
     def _packed(self):
-        ver = tuple(p._version for p in self.parameters()) + (str(self.mask.device),)
+        bf16 = self.compute_dtype == torch.bfloat16 and self.hidden % 128 == 0
+        ver = tuple(p._version for p in self.parameters()) + (str(self.mask.device), bf16)
         if self._pack is None or self._pack[0] != ver:
             dev = self.mask.device
             packs, b2, wc, bc = [], [], [], []
             for i in range(len(self.mask)):
                 for net in (self.s[i], self.t[i]):
                     w = [l.weight.detach().cpu().numpy() for l in net.l]
-                    packs.append(ops.flow_pack_net(w[0], w[1], w[2]))
+                    packs.append((ops.flow_pack_net_bf16 if bf16 else ops.flow_pack_net)(w[0], w[1], w[2]))
                     b2.append(net.l[2].bias.detach())
                     for j in range(2):
                         wc.append(net.c[j].weight.detach())
                         bc.append(net.c[j].bias.detach() + net.l[j].bias.detach())
-            self._pack = (ver, torch.from_numpy(np.concatenate(packs)).to(dev), torch.stack(b2).contiguous(),
+            stream = np.concatenate(packs)
+            if bf16:
+                stream = stream.view(np.int16)
+            b2 = torch.stack(b2)
+            if bf16:                      # the bf16 kernel wants l2.bias zero-padded to 64 per net
+                b2 = torch.nn.functional.pad(b2, (0, 64 - b2.shape[1]))
+            self._pack = (ver, torch.from_numpy(stream).to(dev), b2.contiguous(),
                           torch.cat(wc).contiguous(), torch.cat(bc).contiguous())
         return self._pack[1:]
 

@@ -78,20 +78,37 @@ def flow_pack_net(w0, w1, w2):
     return out
 
 
+def flow_pack_net_bf16(w0, w1, w2):
+    """Host repack of one coupling network into the bf16 fragment stream (mhe_flow_pack_net_bf16_host)."""
+    hidden, dim = w0.shape
+    L = _lib.lib()
+    n = L.mhe_flow_packed_bytes_per_net_bf16(dim, hidden)
+    if n == 0:
+        raise _lib.MheError(f"flow_pack_net_bf16: unsupported geometry dim={dim} hidden={hidden}")
+    out = np.empty(n // 2, np.uint16)
+    w0, w1, w2 = (np.ascontiguousarray(a, np.float32) for a in (w0, w1, w2))
+    check(L.mhe_flow_pack_net_bf16_host(w0.ctypes.data_as(C.c_void_p), w1.ctypes.data_as(C.c_void_p),
+                                        w2.ctypes.data_as(C.c_void_p), dim, hidden, out.ctypes.data_as(C.c_void_p)),
+          "mhe_flow_pack_net_bf16_host")
+    return out
+
+
 def flow_couplings(x_in, cond, wstream, bias2, mask, B, hidden, direction, want_log_prob=True):
-    """All couplings in one launch; returns (out, sum_s, log_prob)."""
+    """All couplings in one launch; returns (out, sum_s, log_prob).  The dtype of `wstream` selects the
+    kernel: float32 stream -> f32 MFMA, int16/bf16 stream -> bf16 MFMA."""
     R, dim = x_in.shape
     ncoup = mask.shape[0]
     _chk(x_in, torch.float32, "flow.in")
     _chk(cond, torch.float32, "flow.cond", (B, 2 * ncoup, 2, hidden))
-    _chk(wstream, torch.float32, "flow.wstream"); _chk(bias2, torch.float32, "flow.bias2", (2 * ncoup, dim))
+    bf16 = wstream.dtype != torch.float32
+    _chk(wstream, wstream.dtype, "flow.wstream"); _chk(bias2, torch.float32, "flow.bias2", (2 * ncoup, 64 if bf16 else dim))
     _chk(mask, torch.float32, "flow.mask", (ncoup, dim))
     out = torch.empty_like(x_in)
     sum_s = torch.empty(R, device=x_in.device, dtype=torch.float32)
     logp = torch.empty(R, device=x_in.device, dtype=torch.float32) if want_log_prob else None
-    check(_lib.lib().mhe_flow_couplings_f32(_ptr(x_in), _ptr(out), _ptr(cond), _ptr(wstream), _ptr(bias2), _ptr(mask),
-                                            _ptr(sum_s), _ptr(logp), R, B, dim, hidden, ncoup, direction, _stream()),
-          "mhe_flow_couplings_f32")
+    fn = _lib.lib().mhe_flow_couplings_bf16 if bf16 else _lib.lib().mhe_flow_couplings_f32
+    check(fn(_ptr(x_in), _ptr(out), _ptr(cond), _ptr(wstream), _ptr(bias2), _ptr(mask), _ptr(sum_s), _ptr(logp), R, B, dim,
+             hidden, ncoup, direction, _stream()), "mhe_flow_couplings_bf16" if bf16 else "mhe_flow_couplings_f32")
     return out, sum_s, logp
 
 

@@ -91,3 +91,34 @@ def sample(sd, z0, feat):
     """reference flows.py:333-359 with the prior draw `z0` supplied by the caller
     (already multiplied by temp); scale=1."""
     return forward_p(sd, z0, feat)
+
+
+def _q(t):
+    return t.bfloat16().float()
+
+
+def coupling_net_bf16(sd, net, i, x, cond):
+    """coupling_net with the rounding points of the product's bf16 performance mode
+    (csrc/flow_bf16.hip): operands of every product rounded to bf16 (inputs, weights, hidden
+    activations after leaky_relu), accumulation, biases, conditioning and activations in f32."""
+    p = f"{net}.{i}."
+    h = F.linear(_q(x), _q(sd[p + "l.0.weight"])) + (F.linear(cond, sd[p + "c.0.weight"], sd[p + "c.0.bias"]) + sd[p + "l.0.bias"])
+    h = _q(F.leaky_relu(h))
+    h = F.linear(h, _q(sd[p + "l.1.weight"])) + (F.linear(cond, sd[p + "c.1.weight"], sd[p + "c.1.bias"]) + sd[p + "l.1.bias"])
+    h = _q(F.leaky_relu(h))
+    o = F.linear(h, _q(sd[p + "l.2.weight"])) + sd[p + "l.2.bias"]
+    return torch.tanh(o) if net == "s" else o
+
+
+def forward_p_logdet_bf16(sd, z, cond):
+    mask = sd["mask"]
+    x = z
+    tot = z.new_zeros(z.shape[0])
+    for i in range(mask.shape[0]):
+        m = mask[i]
+        x_ = x * m
+        s = coupling_net_bf16(sd, "s", i, x_, cond) * (1 - m)
+        t = coupling_net_bf16(sd, "t", i, x_, cond) * (1 - m)
+        x = x_ + (1 - m) * (x * torch.exp(s) + t)
+        tot = tot + s.sum(1)
+    return x, tot

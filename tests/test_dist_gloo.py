@@ -21,8 +21,8 @@ def step():
     calls.append(1); time.sleep(0.02 * (rank + 1))                # rank 1 is slower
 dt = mdist.timed_region(step, 3, dist, sync=lambda: None)
 avg = mdist.reduce_mean_scalars({"loss": float(rank), "n": float(hi - lo)}, dist)
-print(json.dumps({"rank": rank, "lo": lo, "hi": hi, "dt": dt, "calls": len(calls), "avg": avg,
-                  "sum_x": float(x.sum())}), flush=True)
+with open(os.path.join(os.environ["MHE_OUT"], f"rank{rank}.json"), "w") as fh:
+    json.dump({"rank": rank, "lo": lo, "hi": hi, "dt": dt, "calls": len(calls), "avg": avg, "sum_x": float(x.sum())}, fh)
 dist.destroy_process_group()
 '''
 
@@ -41,13 +41,12 @@ def test_two_ranks_over_gloo(tmp_path):
     import json
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MHE_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    env = dict(os.environ, MHE_ROOT=ROOT, MHE_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29611", str(script)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
-    recs = sorted((json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")), key=lambda r: r["rank"])
-    assert len(recs) == 2
+    recs = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
     assert (recs[0]["lo"], recs[0]["hi"], recs[1]["lo"], recs[1]["hi"]) == (0, 4, 4, 7)
     assert recs[0]["calls"] == recs[1]["calls"] == 3                       # exactly K timed steps per rank
     assert abs(recs[0]["dt"] - recs[1]["dt"]) < 1e-9                       # everyone reports the max over ranks

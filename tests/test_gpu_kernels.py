@@ -78,6 +78,45 @@ def test_flow_shared_conditioning_rows(gpu_lib):
     assert_close(logq.cpu(), lq, RTOL, what="log q")
 
 
+@pytest.mark.parametrize("h,steps,B,N", [(128, 2, 3, 10), (512, 6, 2, 40), (512, 6, 3, 64), (256, 3, 5, 32)])
+def test_flow_bf16_mode_vs_bf16_rounding_oracle(gpu_lib, h, steps, B, N):
+    """bf16 performance mode: against the oracle with the same rounding points.  A flipped bf16
+    rounding of one hidden unit moves an output by ~1e-3 of its scale, so the tolerance is 1e-2.
+    Invertibility (x -> z -> x) holds to the same level only: the inverse pass sees the pass-through
+    half of the variable reconstructed to f32 round-off, and its rounding to bf16 (the nets' operand)
+    can flip for an isolated row."""
+    from mhentropy_amd import ops
+    from oracle import flows_ref
+    sd = synth.flow_state(9, 45, 512, (h, h), steps)
+    ncoup = 2 * steps
+    packs, b2, wc, bc = [], [], [], []
+    for i in range(ncoup):
+        for net in ("s", "t"):
+            p = f"{net}.{i}."
+            packs.append(ops.flow_pack_net_bf16(sd[p + "l.0.weight"], sd[p + "l.1.weight"], sd[p + "l.2.weight"]))
+            b2.append(sd[p + "l.2.bias"])
+            for j in range(2):
+                wc.append(sd[p + f"c.{j}.weight"]); bc.append(sd[p + f"c.{j}.bias"] + sd[p + f"l.{j}.bias"])
+    wstream = _dev(np.concatenate(packs).view(np.int16))
+    rng = np.random.default_rng(2)
+    feat = rng.normal(0, 1, (B, 512)).astype(np.float32)
+    z0 = rng.normal(0, 1, (N * B, 45)).astype(np.float32)
+    cond = ops.linear(_dev(feat), _dev(np.concatenate(wc)), _dev(np.concatenate(bc))).view(B, 2 * ncoup, 2, h)
+    b2d = _dev(np.pad(np.stack(b2), ((0, 0), (0, 64 - 45))))
+    x, sum_s, logq = ops.flow_couplings(_dev(z0), cond, wstream, b2d, _dev(sd["mask"]), B, h, ops.FLOW_FORWARD)
+    sdt = {k: torch.as_tensor(v) for k, v in sd.items()}
+    with torch.no_grad():
+        xr, tot = flows_ref.forward_p_logdet_bf16(sdt, torch.as_tensor(z0), torch.as_tensor(feat).repeat(N, 1))
+    assert_close(x.cpu(), xr, 1e-2, what="x (bf16 mode)")
+    assert_close(sum_s.cpu(), tot, 1e-2, 1e-2, what="sum s (bf16 mode)")
+    assert_close(logq.cpu(), flows_ref.std_normal_logprob(torch.as_tensor(z0)) - tot, 1e-2, what="log q (bf16 mode)")
+    zb, sum_s2, _ = ops.flow_couplings(x, cond, wstream, b2d, _dev(sd["mask"]), B, h, ops.FLOW_INVERSE)
+    assert_close(zb.cpu(), z0, 1e-2, what="inverse(forward(z)) == z")
+    assert_close(sum_s2.cpu(), sum_s.cpu(), 1e-2, 1e-2, what="same log-det both ways")
+    x2, _, _ = ops.flow_couplings(_dev(z0), cond, wstream, b2d, _dev(sd["mask"]), B, h, ops.FLOW_FORWARD)
+    assert torch.equal(x, x2), "the kernel must be run-to-run deterministic (no race in the DMA ring)"
+
+
 def test_mano_joints_and_verts_match_reference_vectors(gpu_lib):
     from mhentropy_amd import ops
     g = load_golden("mano")
