@@ -177,6 +177,16 @@ int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *
                     float *stats, void *stream);
 int mhe_conv_stat_shards(void);
 
+/* 1x1 stride-1 convolution whose operand is the TAIL of the previous residual block evaluated while
+ * loading (torchvision Bottleneck: out = relu(bn3(conv3) + identity)):
+ *     a = relu(x*in_scale+in_shift + (x2*x2_scale+x2_shift | x2)),   y = conv1x1(a)
+ * x = raw conv3 output, x2 = identity (x2_scale/x2_shift NULL) or the raw downsample conv output with its
+ * BatchNorm affine.  a_out (optional, same shape as x) receives `a` once - the next identity.  Saves one
+ * full read of the block output compared with mhe_bn_act_nhwc followed by mhe_conv2d_nhwc. */
+int mhe_conv1x1_residual_in_nhwc(const mhe_conv_desc *d, const void *x, const void *x2, const void *w, void *y,
+                                 const float *in_scale, const float *in_shift, const float *x2_scale,
+                                 const float *x2_shift, void *a_out, float *stats, void *stream);
+
 /* BatchNorm batch statistics (the sharded accumulators of mhe_conv2d_nhwc, summed in f64)
  * -> affine (train mode), torch semantics
  * (momentum 0.1, eps 1e-5, unbiased running_var):

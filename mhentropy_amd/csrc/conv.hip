@@ -26,6 +26,9 @@ struct Params {
     const float *in_scale, *in_shift, *out_scale, *out_shift;
     const void *residual;
     float *stats;          // [NSH][2][Cout] sharded accumulators
+    // dual-input prologue (1x1, stride 1): operand = relu(x*in_scale+in_shift + (x2*x2_scale+x2_shift | x2)),
+    // i.e. the tail of the previous residual block evaluated on load; a_out (optional) receives it once
+    const void *x2; const float *x2_scale, *x2_shift; void *a_out;
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, M, Kpad, relu_in, relu_out;
 };
 
@@ -39,40 +42,76 @@ template <> struct El<u16>   { static constexpr int CE = 8; };
 
 __device__ __forceinline__ int swz(int row, int slot) { return row * 8 + (slot ^ ((row >> 1) & 7)); }
 
-// apply relu(v*scale+shift) to one 16-byte chunk of activations; sc/sh point into LDS
-template <typename T>
-__device__ __forceinline__ uint4 in_transform(uint4 raw, const float *sc, const float *sh, int c, int relu) {
-    if constexpr (sizeof(T) == 4) {
-        const float4 s = *reinterpret_cast<const float4 *>(sc + c), t = *reinterpret_cast<const float4 *>(sh + c);
-        float4 v = __builtin_bit_cast(float4, raw);
-        v.x = fmaf(v.x, s.x, t.x); v.y = fmaf(v.y, s.y, t.y); v.z = fmaf(v.z, s.z, t.z); v.w = fmaf(v.w, s.w, t.w);
-        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        return __builtin_bit_cast(uint4, v);
-    } else {
-        const float4 s0 = *reinterpret_cast<const float4 *>(sc + c), s1 = *reinterpret_cast<const float4 *>(sc + c + 4);
-        const float4 t0 = *reinterpret_cast<const float4 *>(sh + c), t1 = *reinterpret_cast<const float4 *>(sh + c + 4);
-        const float ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        const float tt[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-        unsigned in[4] = {raw.x, raw.y, raw.z, raw.w}, o[4];
+// one 16-byte chunk of activations -> floats and back
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void unpack(uint4 r, float *v) {
+        v[0] = __uint_as_float(r.x); v[1] = __uint_as_float(r.y); v[2] = __uint_as_float(r.z); v[3] = __uint_as_float(r.w);
+    }
+    static __device__ __forceinline__ uint4 pack(const float *v) {
+        return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+    }
+};
+template <> struct Chunk<u16> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void unpack(uint4 r, float *v) {
+        const unsigned in[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float lo = __uint_as_float(in[i] << 16), hi = __uint_as_float(in[i] & 0xffff0000u);
-            lo = fmaf(lo, ss[2 * i], tt[2 * i]);
-            hi = fmaf(hi, ss[2 * i + 1], tt[2 * i + 1]);
-            if (relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-            o[i] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
-        }
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(in[i] << 16); v[2 * i + 1] = __uint_as_float(in[i] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ uint4 pack(const float *v) {
+        unsigned o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (unsigned)f32_to_bf16(v[2 * i]) | ((unsigned)f32_to_bf16(v[2 * i + 1]) << 16);
         return make_uint4(o[0], o[1], o[2], o[3]);
     }
+};
+
+// relu?(x*scale+shift [+ x2*scale2+shift2 | + x2]); sc/sh point into LDS, sc2/sh2 (optional) into global memory
+template <typename T>
+__device__ __forceinline__ uint4 in_transform(uint4 raw, const float *sc, const float *sh, int c, int relu,
+                                              bool dual, uint4 raw2, const float *sc2, const float *sh2) {
+    constexpr int N = Chunk<T>::N;
+    float v[N], ss[N], tt[N];
+    Chunk<T>::unpack(raw, v);
+#pragma unroll
+    for (int i = 0; i < N; i += 4) {
+        const float4 a = *reinterpret_cast<const float4 *>(sc + c + i), b = *reinterpret_cast<const float4 *>(sh + c + i);
+        ss[i] = a.x; ss[i + 1] = a.y; ss[i + 2] = a.z; ss[i + 3] = a.w;
+        tt[i] = b.x; tt[i + 1] = b.y; tt[i + 2] = b.z; tt[i + 3] = b.w;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = fmaf(v[i], ss[i], tt[i]);
+    if (dual) {
+        float w[N];
+        Chunk<T>::unpack(raw2, w);
+        if (sc2) {
+#pragma unroll
+            for (int i = 0; i < N; i += 4) {
+                const float4 a = *reinterpret_cast<const float4 *>(sc2 + c + i), b = *reinterpret_cast<const float4 *>(sh2 + c + i);
+                w[i] = fmaf(w[i], a.x, b.x); w[i + 1] = fmaf(w[i + 1], a.y, b.y);
+                w[i + 2] = fmaf(w[i + 2], a.z, b.z); w[i + 3] = fmaf(w[i + 3], a.w, b.w);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] += w[i];
+    }
+    if (relu) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = fmaxf(v[i], 0.f);
+    }
+    return Chunk<T>::pack(v);
 }
 
-template <typename T, int BN, bool FAST>
+// MODE 0: plain operand load; 1: producer BatchNorm(+ReLU) applied to the operand; 2: residual-tail (dual input)
+template <typename T, int BN, bool FAST, int MODE>
 __global__ __launch_bounds__(256) void conv_kernel(const Params p) {
     constexpr int CE = El<T>::CE, BKE = 8 * CE;
     constexpr int NJ_B = BN / 32;           // weight chunks per thread per stage
     constexpr int NTW = BN / 32;            // 16-wide channel tiles per wave
     __shared__ uint4 lds[2][(BM + BN) * 8];
-    __shared__ __attribute__((aligned(16))) float aff[2][MAXC];     // producer BatchNorm scale / shift
+    __shared__ __attribute__((aligned(16))) float aff[2][MODE ? MAXC : 4];     // producer BatchNorm scale / shift
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int q = lane >> 4, l15 = lane & 15;
@@ -96,14 +135,21 @@ __global__ __launch_bounds__(256) void conv_kernel(const Params p) {
         wi0[j] = wo * p.stride - p.pad;
         xb[j] = (size_t)b * p.H * p.W;
     }
-    if (p.in_scale) {
+    if constexpr (MODE != 0) {
         for (int i = tid; i < p.Cin; i += 256) { aff[0][i] = p.in_scale[i]; aff[1][i] = p.in_shift[i]; }
         __syncthreads();
     }
     const int ntaps = p.KH * p.KW;
     const int nk = p.Kpad / BKE;
 
-    uint4 ra[4], rb[NJ_B];
+    // Loads are only ISSUED in load_stage; the producer's BatchNorm (+ residual tail) is applied in
+    // store_stage, one K-stage of MFMAs later, so the transform never waits on a load it has just issued.
+    constexpr bool dual = MODE == 2;
+    uint4 ra[4], ra2[dual ? 4 : 1], rb[NJ_B];
+    size_t aoff[dual ? 4 : 1];
+    int c_ld = 0;
+    unsigned okbits = 0;
+    const T *x2g = reinterpret_cast<const T *>(p.x2);
     auto load_stage = [&](int ks) {
         const int kc = ks * BKE + s * CE;
         int tap, c;
@@ -111,14 +157,19 @@ __global__ __launch_bounds__(256) void conv_kernel(const Params p) {
         else                { tap = kc / p.Cin; c = kc - tap * p.Cin; }
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
         const bool tv = tap < ntaps;
+        c_ld = c;
+        okbits = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int hi = hi0[j] + kh, wi = wi0[j] + kw;
             const bool ok = tv && mv[j] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
             uint4 v = make_uint4(0, 0, 0, 0);
+            if constexpr (dual) ra2[j] = v;
             if (ok) {
-                v = *reinterpret_cast<const uint4 *>(xg + ((xb[j] + (size_t)hi * p.W + wi) * p.Cin + c));
-                if (p.in_scale) v = in_transform<T>(v, aff[0], aff[1], c, p.relu_in);
+                const size_t off = (xb[j] + (size_t)hi * p.W + wi) * p.Cin + c;
+                v = *reinterpret_cast<const uint4 *>(xg + off);
+                if constexpr (dual) { ra2[j] = *reinterpret_cast<const uint4 *>(x2g + off); aoff[j] = off; }
+                if constexpr (MODE != 0) okbits |= 1u << j;
             }
             ra[j] = v;
         }
@@ -130,7 +181,18 @@ __global__ __launch_bounds__(256) void conv_kernel(const Params p) {
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) lds[buf][swz(rbase + 32 * j, s)] = ra[j];
+        for (int j = 0; j < 4; ++j) {
+            uint4 v = ra[j];
+            if constexpr (MODE != 0) {
+                if ((okbits >> j) & 1u) {          // padding stays zero
+                    v = in_transform<T>(v, aff[0], aff[1], c_ld, p.relu_in, dual, ra2[dual ? j : 0], p.x2_scale, p.x2_shift);
+                    if constexpr (dual) {
+                        if (p.a_out && blockIdx.y == 0) *reinterpret_cast<uint4 *>(reinterpret_cast<T *>(p.a_out) + aoff[j]) = v;
+                    }
+                }
+            }
+            lds[buf][swz(rbase + 32 * j, s)] = v;
+        }
 #pragma unroll
         for (int j = 0; j < NJ_B; ++j) lds[buf][BM * 8 + swz(rbase + 32 * j, s)] = rb[j];
     };
@@ -437,18 +499,28 @@ __global__ void nchw_to_nhwc_kernel(const float *__restrict__ x, T *__restrict__
     }
 }
 
+template <typename T, int BN, bool FAST>
+static void launch_mode(const Params &p, dim3 grid, hipStream_t s) {
+    if (p.x2) {
+        if constexpr (FAST) hipLaunchKernelGGL((conv_kernel<T, BN, true, 2>), grid, dim3(256), 0, s, p);
+    } else if (p.in_scale) {
+        hipLaunchKernelGGL((conv_kernel<T, BN, FAST, 1>), grid, dim3(256), 0, s, p);
+    } else {
+        hipLaunchKernelGGL((conv_kernel<T, BN, FAST, 0>), grid, dim3(256), 0, s, p);
+    }
+}
+
 template <typename T>
 static int launch_conv(const Params &p, hipStream_t s) {
     constexpr int BKE = 8 * El<T>::CE;
     const bool fast = (p.Cin % BKE) == 0;
     const int bn = p.Cout <= 64 ? 64 : 128;
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + bn - 1) / bn);
+    if (p.x2 && !fast) { set_error("residual-tail prologue needs Cin %% %d == 0", BKE); return MHE_ERR_ARG; }
     if (bn == 64) {
-        if (fast) hipLaunchKernelGGL((conv_kernel<T, 64, true>), grid, dim3(256), 0, s, p);
-        else      hipLaunchKernelGGL((conv_kernel<T, 64, false>), grid, dim3(256), 0, s, p);
+        if (fast) launch_mode<T, 64, true>(p, grid, s); else launch_mode<T, 64, false>(p, grid, s);
     } else {
-        if (fast) hipLaunchKernelGGL((conv_kernel<T, 128, true>), grid, dim3(256), 0, s, p);
-        else      hipLaunchKernelGGL((conv_kernel<T, 128, false>), grid, dim3(256), 0, s, p);
+        if (fast) launch_mode<T, 128, true>(p, grid, s); else launch_mode<T, 128, false>(p, grid, s);
     }
     return check_launch("conv_kernel");
 }
@@ -459,9 +531,29 @@ using namespace mhe;
 
 static inline int elem_chunk(int dtype) { return dtype == MHE_F32 ? 4 : 8; }
 
+static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
+                      const float *in_shift, const float *out_scale, const float *out_shift, const void *residual,
+                      float *stats, const void *x2, const float *x2_scale, const float *x2_shift, void *a_out, void *stream);
+
 extern "C" int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
                                const float *in_shift, const float *out_scale, const float *out_shift,
                                const void *residual, float *stats, void *stream) {
+    return conv_entry(d, x, w, y, in_scale, in_shift, out_scale, out_shift, residual, stats, nullptr, nullptr, nullptr,
+                      nullptr, stream);
+}
+
+extern "C" int mhe_conv1x1_residual_in_nhwc(const mhe_conv_desc *d, const void *x, const void *x2, const void *w, void *y,
+                                            const float *in_scale, const float *in_shift, const float *x2_scale,
+                                            const float *x2_shift, void *a_out, float *stats, void *stream) {
+    MHE_REQUIRE(d && x2 && in_scale && in_shift, "mhe_conv1x1_residual_in_nhwc: x2, in_scale and in_shift are required");
+    MHE_REQUIRE(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0, "mhe_conv1x1_residual_in_nhwc: 1x1 stride-1 only");
+    MHE_REQUIRE((x2_scale == nullptr) == (x2_shift == nullptr), "mhe_conv1x1_residual_in_nhwc: x2_scale/x2_shift must come together");
+    return conv_entry(d, x, w, y, in_scale, in_shift, nullptr, nullptr, nullptr, stats, x2, x2_scale, x2_shift, a_out, stream);
+}
+
+static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
+                      const float *in_shift, const float *out_scale, const float *out_shift, const void *residual,
+                      float *stats, const void *x2, const float *x2_scale, const float *x2_shift, void *a_out, void *stream) {
     MHE_REQUIRE(d && x && w && y, "mhe_conv2d_nhwc: null pointer");
     MHE_REQUIRE(d->dtype == MHE_F32 || d->dtype == MHE_BF16, "mhe_conv2d_nhwc: dtype=%d", d->dtype);
     const int ce = elem_chunk(d->dtype), bke = 8 * ce;
@@ -474,6 +566,7 @@ extern "C" int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void
     conv::Params p;
     p.x = x; p.w = w; p.y = y; p.in_scale = in_scale; p.in_shift = in_shift; p.out_scale = out_scale;
     p.out_shift = out_shift; p.residual = residual; p.stats = stats;
+    p.x2 = x2; p.x2_scale = x2_scale; p.x2_shift = x2_shift; p.a_out = a_out;
     p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
     p.stride = d->stride; p.pad = d->pad;
     p.Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;

@@ -197,9 +197,37 @@ def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in
     if TIMING:
         ev1.record()
         bke = 32 if dt == torch.float32 else 64
-        name = "conv_kernel<%s,%d,%s>" % ("float" if dt == torch.float32 else "bf16", 64 if Cout <= 64 else 128,
-                                          "true" if Cin % bke == 0 else "false")
+        name = "conv_kernel<%s,%d,%s,%d>" % ("float" if dt == torch.float32 else "bf16", 64 if Cout <= 64 else 128,
+                                             "true" if Cin % bke == 0 else "false", 1 if in_scale is not None else 0)
         KERNEL_TIMES.append((name, 2.0 * B * Ho * Wo * Cout * KH * KW * Cin, ev0, ev1))
+    return y
+
+
+def conv1x1_residual_in(x, x2, w, in_scale, in_shift, x2_scale=None, x2_shift=None, a_out=None, stats=None):
+    """y = conv1x1(relu(x*in_scale+in_shift + (x2*x2_scale+x2_shift | x2))); optionally writes that operand to a_out."""
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    dt = x.dtype
+    _chk(x, dt, "conv_res.x"); _chk(x2, dt, "conv_res.x2", x.shape); _chk(w, dt, "conv_res.w")
+    _chk(in_scale, torch.float32, "conv_res.in_scale", (Cin,)); _chk(in_shift, torch.float32, "conv_res.in_shift", (Cin,))
+    if x2_scale is not None:
+        _chk(x2_scale, torch.float32, "conv_res.x2_scale", (Cin,)); _chk(x2_shift, torch.float32, "conv_res.x2_shift", (Cin,))
+    if a_out is not None:
+        _chk(a_out, dt, "conv_res.a_out", x.shape)
+    if stats is not None:
+        _chk(stats, torch.float32, "conv_res.stats", (stat_shards(), 2, Cout))
+    y = torch.empty(B, H, W, Cout, device=x.device, dtype=dt)
+    d = ConvDesc(B, H, W, Cin, Cout, 1, 1, 1, 0, dtype_code(dt), 1, 0)
+    if TIMING:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(_lib.lib().mhe_conv1x1_residual_in_nhwc(C.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(y), _ptr(in_scale), _ptr(in_shift),
+                                                  _ptr(x2_scale), _ptr(x2_shift), _ptr(a_out), _ptr(stats), _stream()),
+          "mhe_conv1x1_residual_in_nhwc")
+    if TIMING:
+        ev1.record()
+        KERNEL_TIMES.append(("conv_kernel<%s,%d,true,2>" % ("float" if dt == torch.float32 else "bf16", 64 if Cout <= 64 else 128),
+                             2.0 * B * H * W * Cout * Cin, ev0, ev1))
     return y
 
 

@@ -78,6 +78,8 @@ class ResNetTrunk(nn.Module):
         # cheaper in both dtypes (bf16 15.2 -> 13.6 ms, f32 38.9 -> 35.7 ms per C2 step); "load" stays selectable.
         import os
         self.bn_apply = os.environ.get("MHE_BN_APPLY", "pass")
+        # evaluate relu(bn3(conv3) + identity) inside the next block's conv1 (one read of the block output saved)
+        self.fuse_tail = os.environ.get("MHE_FUSE_TAIL", "1") == "1"
 
     # -- packed-weight cache keyed on the parameter's version counter
     def _w(self, conv, cin_pad=None):
@@ -89,6 +91,16 @@ class ResNetTrunk(nn.Module):
             self._wcache[id(p)] = hit
         return hit[1]
 
+    def _bn_affine(self, y, bn, st):
+        """this layer's BatchNorm folded to (scale, shift): batch statistics in training, running ones in eval"""
+        if self.training:
+            count = y.numel() // y.shape[-1]
+            aff = ops.bn_finalize(st, bn.weight, bn.bias, bn.running_mean, bn.running_var, count, BN_MOMENTUM, BN_EPS)
+            bn.num_batches_tracked += 1
+            return aff
+        sc = bn.weight.detach() / torch.sqrt(bn.running_var + BN_EPS)
+        return sc.contiguous(), (bn.bias.detach() - bn.running_mean * sc).contiguous()
+
     def _conv_bn(self, x, conv, bn, stats_pool, in_aff=None, stride=1, pad=0, k=1, cin_pad=None):
         """raw conv output + this layer's BatchNorm folded to (scale, shift)."""
         w = self._w(conv, cin_pad)
@@ -96,17 +108,9 @@ class ResNetTrunk(nn.Module):
             x = ops.bn_act(x, in_aff[0], in_aff[1], relu=True, out=x)
             in_aff = None
         isc, ish = in_aff if in_aff is not None else (None, None)
-        if self.training:
-            st = stats_pool.take(conv.out_channels)
-            y = ops.conv2d_nhwc(x, w, k, k, stride, pad, in_scale=isc, in_shift=ish, relu_in=in_aff is not None, stats=st)
-            count = y.numel() // y.shape[-1]
-            aff = ops.bn_finalize(st, bn.weight, bn.bias, bn.running_mean, bn.running_var, count, BN_MOMENTUM, BN_EPS)
-            bn.num_batches_tracked += 1
-        else:
-            y = ops.conv2d_nhwc(x, w, k, k, stride, pad, in_scale=isc, in_shift=ish, relu_in=in_aff is not None)
-            sc = bn.weight.detach() / torch.sqrt(bn.running_var + BN_EPS)
-            aff = (sc.contiguous(), (bn.bias.detach() - bn.running_mean * sc).contiguous())
-        return y, aff
+        st = stats_pool.take(conv.out_channels) if self.training else None
+        y = ops.conv2d_nhwc(x, w, k, k, stride, pad, in_scale=isc, in_shift=ish, relu_in=in_aff is not None, stats=st)
+        return y, self._bn_affine(y, bn, st)
 
     def forward(self, x):
         """x (B,3,H,W) float32 NCHW -> (B, feat_dim) float32."""
@@ -115,20 +119,39 @@ class ResNetTrunk(nn.Module):
         a = ops.nchw_to_nhwc(x.contiguous(), dt)
         y, aff = self._conv_bn(a, self.conv1, self.bn1, pool, None, 2, 3, 7, cin_pad=a.shape[-1])
         a = ops.maxpool3x3s2(y, aff[0], aff[1])
-        for li in range(4):
-            for blk in getattr(self, f"layer{li + 1}"):
-                if blk.kind == "bottleneck":
+        blocks = [blk for li in range(4) for blk in getattr(self, f"layer{li + 1}")]
+        pending = None          # (raw conv3 output, bn3 affine, identity tensor, identity affine | None): an unevaluated block tail
+        for bi, blk in enumerate(blocks):
+            if blk.kind == "bottleneck":
+                if pending is not None:
+                    # the previous block's relu(bn3(y3) + identity) is evaluated inside this conv1's operand load,
+                    # which also writes it out once as this block's identity
+                    yl_p, al_p, idt_p, idaff_p = pending
+                    a = torch.empty_like(yl_p)
+                    st = pool.take(blk.conv1.out_channels) if self.training else None
+                    y1 = ops.conv1x1_residual_in(yl_p, idt_p, self._w(blk.conv1), al_p[0], al_p[1],
+                                                 None if idaff_p is None else idaff_p[0],
+                                                 None if idaff_p is None else idaff_p[1], a_out=a, stats=st)
+                    a1 = self._bn_affine(y1, blk.bn1, st)
+                    pending = None
+                else:
                     y1, a1 = self._conv_bn(a, blk.conv1, blk.bn1, pool)
-                    y2, a2 = self._conv_bn(y1, blk.conv2, blk.bn2, pool, a1, blk.stride, 1, 3)
-                    yl, al = self._conv_bn(y2, blk.conv3, blk.bn3, pool, a2)
-                else:
-                    y1, a1 = self._conv_bn(a, blk.conv1, blk.bn1, pool, None, blk.stride, 1, 3)
-                    yl, al = self._conv_bn(y1, blk.conv2, blk.bn2, pool, a1, 1, 1, 3)
-                if blk.downsample is not None:
-                    yd, ad = self._conv_bn(a, blk.downsample[0], blk.downsample[1], pool, None, blk.stride, 0, 1)
-                    a = ops.bn_act(yl, al[0], al[1], yd, ad[0], ad[1], relu=True)
-                else:
-                    a = ops.bn_act(yl, al[0], al[1], a, relu=True)
+                y2, a2 = self._conv_bn(y1, blk.conv2, blk.bn2, pool, a1, blk.stride, 1, 3)
+                yl, al = self._conv_bn(y2, blk.conv3, blk.bn3, pool, a2)
+            else:
+                y1, a1 = self._conv_bn(a, blk.conv1, blk.bn1, pool, None, blk.stride, 1, 3)
+                yl, al = self._conv_bn(y1, blk.conv2, blk.bn2, pool, a1, 1, 1, 3)
+            if blk.downsample is not None:
+                idt, idaff = self._conv_bn(a, blk.downsample[0], blk.downsample[1], pool, None, blk.stride, 0, 1)
+            else:
+                idt, idaff = a, None
+            nxt = blocks[bi + 1] if bi + 1 < len(blocks) else None
+            if self.fuse_tail and nxt is not None and nxt.kind == "bottleneck":
+                pending = (yl, al, idt, idaff)
+            elif idaff is not None:
+                a = ops.bn_act(yl, al[0], al[1], idt, idaff[0], idaff[1], relu=True)
+            else:
+                a = ops.bn_act(yl, al[0], al[1], idt, relu=True)
         return self.fc(ops.avgpool(a))
 
 

@@ -97,12 +97,15 @@ def test_mano_layer_forward_matches_reference_vectors(gpu_lib):
 
 @pytest.mark.parametrize("arch,B,S", [("resnet18", 4, 64), ("resnet50", 4, 64)])
 @pytest.mark.parametrize("training", [True, False])
-def test_resnet_trunk_matches_oracle(gpu_lib, arch, B, S, training):
+@pytest.mark.parametrize("mode", ["pass+fused-tail", "load+fused-tail", "pass", "load"])
+def test_resnet_trunk_matches_oracle(gpu_lib, arch, B, S, training, mode):
     from mhentropy_amd import resnet
     from oracle import resnet_ref
     sdn = synth.resnet_state(3, arch)
     x, _ = synth.batch(3, B, image_size=S)
     trunk = resnet.ResNetTrunk(arch)
+    trunk.bn_apply = mode.split("+")[0]
+    trunk.fuse_tail = mode.endswith("fused-tail")
     trunk.load_state_dict({k: torch.as_tensor(v) for k, v in sdn.items()})
     trunk = trunk.cuda().train(training)
     f = trunk(torch.as_tensor(x).cuda())
@@ -136,6 +139,8 @@ def test_resnet_trunk_bf16_storage_mode(gpu_lib, arch, bn_apply, monkeypatch):
     trunk.load_state_dict(sd)
     trunk = trunk.cuda().train()
     taps, orig = [], ops.bn_act
+
+    trunk.fuse_tail = False                      # the spy below needs every block tail materialised by bn_act
 
     def spy(x_, scale, shift, res=None, *a, **k):
         y = orig(x_, scale, shift, res, *a, **k)
