@@ -165,8 +165,17 @@ def main():
             name, (fl, sec, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
             ach = fl / sec / 1e12
             steps_timed = min(args.steps, 3)
+            # HBM bytes per launch of that kernel from the committed PMC passes (tools/pmc_traffic.py), if profiled
+            traffic = None
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+                key = ("mhe::conv::" + name).replace("bf16", "unsigned short").replace("true", "true").replace(",", ", ")
+                traffic = pmc.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                pass
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK[args.dtype] / 1e12,
-                    "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK[args.dtype], 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK[args.dtype], 4), "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
                     "launches_per_step": cnt // steps_timed, "avg_launch_us": round(sec / cnt * 1e6, 2),
                     "share_of_step": round(sec / steps_timed / (dt / args.steps), 3)}
         cpu = None if args.no_cpu_baseline else cpu_baseline(cfg, sd, args.seed)
