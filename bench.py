@@ -169,8 +169,7 @@ def main():
             traffic = None
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-                key = ("mhe::conv::" + name).replace("bf16", "unsigned short").replace("true", "true").replace(",", ", ")
-                traffic = pmc.get(key, {}).get("hbm_bytes_per_launch")
+                traffic = pmc.get(name, {}).get("hbm_bytes_per_launch")
             except Exception:
                 pass
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK[args.dtype] / 1e12,

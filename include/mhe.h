@@ -176,6 +176,8 @@ int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *
                     const float *out_scale, const float *out_shift, const void *residual,
                     float *stats, void *stream);
 int mhe_conv_stat_shards(void);
+/* tile the launcher picks for a geometry: 0 = 128x64, 1 = 128x128 (4 waves), 2 = 256x256 (8 waves, bf16) */
+int mhe_conv_tile(const mhe_conv_desc *d);
 
 /* 1x1 stride-1 convolution whose operand is the TAIL of the previous residual block evaluated while
  * loading (torchvision Bottleneck: out = relu(bn3(conv3) + identity)):

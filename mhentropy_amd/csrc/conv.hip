@@ -18,6 +18,7 @@
 // lane owns 4 consecutive channels of one pixel: the epilogue's per-channel
 // scale/shift are one float4 load and the store is one 16 B (f32) / 8 B (bf16) write.
 #include "common.h"
+#include <cstdlib>
 
 namespace mhe { namespace conv {
 
@@ -32,7 +33,6 @@ struct Params {
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, M, Kpad, relu_in, relu_out;
 };
 
-constexpr int BM = 128;
 constexpr int NSH = 64;          // statistic shards: block b adds into shard b % NSH
 constexpr int MAXC = 2048;       // largest Cin whose BatchNorm affine is staged in LDS
 
@@ -105,29 +105,34 @@ __device__ __forceinline__ uint4 in_transform(uint4 raw, const float *sc, const 
 }
 
 // MODE 0: plain operand load; 1: producer BatchNorm(+ReLU) applied to the operand; 2: residual-tail (dual input)
-template <typename T, int BN, bool FAST, int MODE>
-__global__ __launch_bounds__(256) void conv_kernel(const Params p) {
+// Tile BM x BN computed by WM x WN wavefronts (64 * WM * WN threads); each wave owns (BM/WM) x (BN/WN).
+// Shipped shapes: 128x64 and 128x128 on 2x2 waves (2 workgroups per CU), 256x256 on 2x4 waves (one per CU,
+// half the L2->LDS bytes per MAC of 128x128 - the 128-tiles measure L2-fill-bound at ~11 TB/s).
+template <typename T, int BM, int BN, int WM, int WN, bool FAST, int MODE>
+__global__ __launch_bounds__(64 * WM * WN) void conv_kernel(const Params p) {
+    constexpr int NTH = 64 * WM * WN;
     constexpr int CE = El<T>::CE, BKE = 8 * CE;
-    constexpr int NJ_B = BN / 32;           // weight chunks per thread per stage
-    constexpr int NTW = BN / 32;            // 16-wide channel tiles per wave
+    constexpr int RSTEP = NTH / 8;                  // rows covered by one pass of the thread block
+    constexpr int NJ_A = BM / RSTEP, NJ_B = BN / RSTEP;
+    constexpr int MTW = BM / WM / 16, NTW = BN / WN / 16;     // 16x16 tiles per wave
     __shared__ uint4 lds[2][(BM + BN) * 8];
     __shared__ __attribute__((aligned(16))) float aff[2][MODE ? MAXC : 4];     // producer BatchNorm scale / shift
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int q = lane >> 4, l15 = lane & 15;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WN, wc = wave % WN;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int s = tid & 7, rbase = tid >> 3;
     const T *xg = reinterpret_cast<const T *>(p.x);
     const T *wg = reinterpret_cast<const T *>(p.w);
 
-    // ---- per-thread activation rows (4 rows, same 16-byte slot)
-    int hi0[4], wi0[4];
-    size_t xb[4];
-    bool mv[4];
+    // ---- per-thread activation rows (NJ_A rows, same 16-byte slot)
+    int hi0[NJ_A], wi0[NJ_A];
+    size_t xb[NJ_A];
+    bool mv[NJ_A];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + rbase + 32 * j;
+    for (int j = 0; j < NJ_A; ++j) {
+        const int m = m0 + rbase + RSTEP * j;
         mv[j] = m < p.M;
         const int mm = mv[j] ? m : 0;
         const int wo = mm % p.Wo, t = mm / p.Wo, ho = t % p.Ho, b = t / p.Ho;
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const Params p) {
         xb[j] = (size_t)b * p.H * p.W;
     }
     if constexpr (MODE != 0) {
-        for (int i = tid; i < p.Cin; i += 256) { aff[0][i] = p.in_scale[i]; aff[1][i] = p.in_shift[i]; }
+        for (int i = tid; i < p.Cin; i += NTH) { aff[0][i] = p.in_scale[i]; aff[1][i] = p.in_shift[i]; }
         __syncthreads();
     }
     const int ntaps = p.KH * p.KW;
@@ -145,8 +150,8 @@ __global__ __launch_bounds__(256) void conv_kernel(const Params p) {
     // Loads are only ISSUED in load_stage; the producer's BatchNorm (+ residual tail) is applied in
     // store_stage, one K-stage of MFMAs later, so the transform never waits on a load it has just issued.
     constexpr bool dual = MODE == 2;
-    uint4 ra[4], ra2[dual ? 4 : 1], rb[NJ_B];
-    size_t aoff[dual ? 4 : 1];
+    uint4 ra[NJ_A], ra2[dual ? NJ_A : 1], rb[NJ_B];
+    size_t aoff[dual ? NJ_A : 1];
     int c_ld = 0;
     unsigned okbits = 0;
     const T *x2g = reinterpret_cast<const T *>(p.x2);
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const Params p) {
         c_ld = c;
         okbits = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ_A; ++j) {
             const int hi = hi0[j] + kh, wi = wi0[j] + kw;
             const bool ok = tv && mv[j] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
             uint4 v = make_uint4(0, 0, 0, 0);
@@ -175,13 +180,13 @@ __global__ __launch_bounds__(256) void conv_kernel(const Params p) {
         }
 #pragma unroll
         for (int j = 0; j < NJ_B; ++j) {
-            const int n = n0 + rbase + 32 * j;
+            const int n = n0 + rbase + RSTEP * j;
             rb[j] = n < p.Cout ? *reinterpret_cast<const uint4 *>(wg + (size_t)n * p.Kpad + kc) : make_uint4(0, 0, 0, 0);
         }
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ_A; ++j) {
             uint4 v = ra[j];
             if constexpr (MODE != 0) {
                 if ((okbits >> j) & 1u) {          // padding stays zero
@@ -191,17 +196,17 @@ __global__ __launch_bounds__(256) void conv_kernel(const Params p) {
                     }
                 }
             }
-            lds[buf][swz(rbase + 32 * j, s)] = v;
+            lds[buf][swz(rbase + RSTEP * j, s)] = v;
         }
 #pragma unroll
-        for (int j = 0; j < NJ_B; ++j) lds[buf][BM * 8 + swz(rbase + 32 * j, s)] = rb[j];
+        for (int j = 0; j < NJ_B; ++j) lds[buf][BM * 8 + swz(rbase + RSTEP * j, s)] = rb[j];
     };
 
-    v4f acc[NTW][4];
+    v4f acc[NTW][MTW];
 #pragma unroll
     for (int a = 0; a < NTW; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < MTW; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
 
     load_stage(0);
     store_stage(0);
@@ -213,18 +218,18 @@ __global__ __launch_bounds__(256) void conv_kernel(const Params p) {
         const uint4 *LA = lds[cur], *LB = lds[cur] + BM * 8;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            uint4 fa[4], fb[NTW];
+            uint4 fa[MTW], fb[NTW];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) fa[mt] = LA[swz(wr * 64 + mt * 16 + l15, kk * 4 + q)];
+            for (int mt = 0; mt < MTW; ++mt) fa[mt] = LA[swz(wr * (BM / WM) + mt * 16 + l15, kk * 4 + q)];
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) fb[nt] = LB[swz(wc * (BN / 2) + nt * 16 + l15, kk * 4 + q)];
+            for (int nt = 0; nt < NTW; ++nt) fb[nt] = LB[swz(wc * (BN / WN) + nt * 16 + l15, kk * 4 + q)];
             if constexpr (sizeof(T) == 4) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-                        for (int mt = 0; mt < 4; ++mt) {
+                        for (int mt = 0; mt < MTW; ++mt) {
                             const float wv = __uint_as_float(reinterpret_cast<const unsigned *>(&fb[nt])[i]);
                             const float xv = __uint_as_float(reinterpret_cast<const unsigned *>(&fa[mt])[i]);
                             acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc[nt][mt], 0, 0, 0);
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const Params p) {
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
+                    for (int mt = 0; mt < MTW; ++mt)
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fb[nt]),
                             __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fa[mt]), acc[nt][mt], 0, 0, 0);
@@ -252,34 +257,37 @@ __global__ __launch_bounds__(256) void conv_kernel(const Params p) {
     constexpr int CPR = BN * (int)sizeof(T) / 16;          // 16-byte chunks per output row
     constexpr int CMASK = (CPR - 1) & 15;
     constexpr int EPC = 16 / (int)sizeof(T);               // elements per chunk
+    constexpr int NV = 8 * NTW;                            // partial values per thread: 2 stats x NTW tiles x 4 channels
+    static_assert((size_t)BM * BN * sizeof(T) <= sizeof(lds), "output tile must fit the staging buffers");
+    static_assert((size_t)WM * WN * NV * 64 * 4 <= sizeof(lds), "statistics partials must fit the staging buffers");
     if (p.stats) {
-        float *red = reinterpret_cast<float *>(lds);
+        float *red = reinterpret_cast<float *>(lds);       // [waves][NV][64 lanes]
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
-            const bool nv = n0 + wc * (BN / 2) + nt * 16 + 4 * q < p.Cout;
+            const bool nv = n0 + wc * (BN / WN) + nt * 16 + 4 * q < p.Cout;
             float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                if (nv && m0 + wr * 64 + mt * 16 + l15 < p.M) {
+            for (int mt = 0; mt < MTW; ++mt) {
+                if (nv && m0 + wr * (BM / WM) + mt * 16 + l15 < p.M) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { const float v = acc[nt][mt][r]; s1[r] += v; s2[r] = fmaf(v, v, s2[r]); }
                 }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                red[(wave * (8 * NTW) + nt * 4 + r) * 64 + lane] = s1[r];
-                red[(wave * (8 * NTW) + 4 * NTW + nt * 4 + r) * 64 + lane] = s2[r];
+                red[(wave * NV + nt * 4 + r) * 64 + lane] = s1[r];
+                red[(wave * NV + 4 * NTW + nt * 4 + r) * 64 + lane] = s2[r];
             }
         }
         __syncthreads();
-        if (tid < 2 * BN) {
-            const int stat = tid / BN, ch = tid % BN;
-            const int wcc = ch / (BN / 2), cc = ch % (BN / 2), nt = cc >> 4, qq = (cc >> 2) & 3, r = cc & 3;
+        for (int t = tid; t < 2 * BN; t += NTH) {
+            const int stat = t / BN, ch = t % BN;
+            const int wcc = ch / (BN / WN), cc = ch % (BN / WN), nt = cc >> 4, qq = (cc >> 2) & 3, r = cc & 3;
             const int v = stat * 4 * NTW + nt * 4 + r;
             float sum = 0.f;
 #pragma unroll
-            for (int w2 = 0; w2 < 2; ++w2) {
-                const float *src = red + ((w2 * 2 + wcc) * (8 * NTW) + v) * 64 + qq * 16;
+            for (int w2 = 0; w2 < WM; ++w2) {
+                const float *src = red + ((w2 * WN + wcc) * NV + v) * 64 + qq * 16;
 #pragma unroll
                 for (int l = 0; l < 16; ++l) sum += src[l];
             }
@@ -293,9 +301,9 @@ __global__ __launch_bounds__(256) void conv_kernel(const Params p) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int row = wr * 64 + mt * 16 + l15;
-                const int e0 = wc * (BN / 2) + nt * 16 + 4 * q;             // first of 4 channels within the tile
+            for (int mt = 0; mt < MTW; ++mt) {
+                const int row = wr * (BM / WM) + mt * 16 + l15;
+                const int e0 = wc * (BN / WN) + nt * 16 + 4 * q;             // first of 4 channels within the tile
                 const int boff = e0 * (int)sizeof(T);
                 const int chunk = (boff >> 4) ^ (row & CMASK);
                 unsigned char *dst = ot + ((size_t)row * CPR + chunk) * 16 + (boff & 15);
@@ -314,8 +322,8 @@ __global__ __launch_bounds__(256) void conv_kernel(const Params p) {
         const T *rg = reinterpret_cast<const T *>(p.residual);
         const bool plain = !p.out_scale && !p.out_shift && !rg && !p.relu_out;
 #pragma unroll
-        for (int j = 0; j < BM * CPR / 256; ++j) {
-            const int id = tid + 256 * j;
+        for (int j = 0; j < BM * CPR / NTH; ++j) {
+            const int id = tid + NTH * j;
             const int row = id / CPR, c = id % CPR;
             const int m = m0 + row, n = n0 + c * EPC;
             if (m >= p.M || n >= p.Cout) continue;
@@ -323,37 +331,23 @@ __global__ __launch_bounds__(256) void conv_kernel(const Params p) {
             const size_t off = (size_t)m * p.Cout + n;
             if (!plain) {
                 float v[EPC];
-                if constexpr (sizeof(T) == 4) { v[0] = __uint_as_float(raw.x); v[1] = __uint_as_float(raw.y); v[2] = __uint_as_float(raw.z); v[3] = __uint_as_float(raw.w); }
-                else {
-                    const unsigned in[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(in[i] << 16); v[2 * i + 1] = __uint_as_float(in[i] & 0xffff0000u); }
-                }
+                Chunk<T>::unpack(raw, v);
 #pragma unroll
                 for (int i = 0; i < EPC; ++i) {
                     const float sc = p.out_scale ? p.out_scale[n + i] : 1.f, sh = p.out_shift ? p.out_shift[n + i] : 0.f;
                     v[i] = fmaf(v[i], sc, sh);
                 }
                 if (rg) {
-                    const uint4 rr = *reinterpret_cast<const uint4 *>(rg + off);
-                    if constexpr (sizeof(T) == 4) { v[0] += __uint_as_float(rr.x); v[1] += __uint_as_float(rr.y); v[2] += __uint_as_float(rr.z); v[3] += __uint_as_float(rr.w); }
-                    else {
-                        const unsigned in[4] = {rr.x, rr.y, rr.z, rr.w};
+                    float r2[EPC];
+                    Chunk<T>::unpack(*reinterpret_cast<const uint4 *>(rg + off), r2);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) { v[2 * i] += __uint_as_float(in[i] << 16); v[2 * i + 1] += __uint_as_float(in[i] & 0xffff0000u); }
-                    }
+                    for (int i = 0; i < EPC; ++i) v[i] += r2[i];
                 }
                 if (p.relu_out) {
 #pragma unroll
                     for (int i = 0; i < EPC; ++i) v[i] = fmaxf(v[i], 0.f);
                 }
-                if constexpr (sizeof(T) == 4) raw = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
-                else {
-                    unsigned o[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = (unsigned)f32_to_bf16(v[2 * i]) | ((unsigned)f32_to_bf16(v[2 * i + 1]) << 16);
-                    raw = make_uint4(o[0], o[1], o[2], o[3]);
-                }
+                raw = Chunk<T>::pack(v);
             }
             *reinterpret_cast<uint4 *>(yg + off) = raw;
         }
@@ -499,28 +493,39 @@ __global__ void nchw_to_nhwc_kernel(const float *__restrict__ x, T *__restrict__
     }
 }
 
-template <typename T, int BN, bool FAST>
-static void launch_mode(const Params &p, dim3 grid, hipStream_t s) {
+template <typename T, int BM, int BN, int WM, int WN, bool FAST>
+static void launch_mode(const Params &p, hipStream_t s) {
+    const dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN), block(64 * WM * WN);
     if (p.x2) {
-        if constexpr (FAST) hipLaunchKernelGGL((conv_kernel<T, BN, true, 2>), grid, dim3(256), 0, s, p);
+        if constexpr (FAST) hipLaunchKernelGGL((conv_kernel<T, BM, BN, WM, WN, true, 2>), grid, block, 0, s, p);
     } else if (p.in_scale) {
-        hipLaunchKernelGGL((conv_kernel<T, BN, FAST, 1>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_kernel<T, BM, BN, WM, WN, FAST, 1>), grid, block, 0, s, p);
     } else {
-        hipLaunchKernelGGL((conv_kernel<T, BN, FAST, 0>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_kernel<T, BM, BN, WM, WN, FAST, 0>), grid, block, 0, s, p);
     }
+}
+
+// tile choice: 0 = 128x64, 1 = 128x128, 2 = 256x256 (FAST only; needs >= ~3/4 of the CUs' worth of tiles)
+static int choose_tile(const Params &p, bool fast, bool bf16) {
+    static const int force = getenv("MHE_CONV_TILE") ? atoi(getenv("MHE_CONV_TILE")) : -1;    // tuning knob
+    if (force >= 0 && (force < 2 || (fast && bf16))) return force;
+    if (p.Cout <= 64) return 0;
+    if (fast && bf16 && p.Cout >= 256) {      // (an f32 256x256 output tile would not fit the LDS staging buffers)
+        const long tiles = (long)((p.M + 255) / 256) * ((p.Cout + 255) / 256);
+        if (tiles >= 192) return 2;
+    }
+    return 1;
 }
 
 template <typename T>
 static int launch_conv(const Params &p, hipStream_t s) {
     constexpr int BKE = 8 * El<T>::CE;
     const bool fast = (p.Cin % BKE) == 0;
-    const int bn = p.Cout <= 64 ? 64 : 128;
-    dim3 grid((p.M + BM - 1) / BM, (p.Cout + bn - 1) / bn);
     if (p.x2 && !fast) { set_error("residual-tail prologue needs Cin %% %d == 0", BKE); return MHE_ERR_ARG; }
-    if (bn == 64) {
-        if (fast) launch_mode<T, 64, true>(p, grid, s); else launch_mode<T, 64, false>(p, grid, s);
-    } else {
-        if (fast) launch_mode<T, 128, true>(p, grid, s); else launch_mode<T, 128, false>(p, grid, s);
+    switch (choose_tile(p, fast, sizeof(T) == 2)) {
+        case 0: if (fast) launch_mode<T, 128, 64, 2, 2, true>(p, s); else launch_mode<T, 128, 64, 2, 2, false>(p, s); break;
+        case 2: if constexpr (sizeof(T) == 2) launch_mode<T, 256, 256, 2, 4, true>(p, s); break;
+        default: if (fast) launch_mode<T, 128, 128, 2, 2, true>(p, s); else launch_mode<T, 128, 128, 2, 2, false>(p, s); break;
     }
     return check_launch("conv_kernel");
 }
@@ -583,6 +588,17 @@ static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void
 }
 
 extern "C" int mhe_conv_stat_shards(void) { return conv::NSH; }
+
+// which tile the launcher picks for a geometry: 0 = 128x64, 1 = 128x128 (4 waves), 2 = 256x256 (8 waves)
+extern "C" int mhe_conv_tile(const mhe_conv_desc *d) {
+    if (!d) return -1;
+    conv::Params p{};
+    p.Cin = d->Cin; p.Cout = d->Cout;
+    const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+    p.M = d->B * Ho * Wo;
+    const int bke = d->dtype == MHE_F32 ? 32 : 64;
+    return conv::choose_tile(p, d->Cin % bke == 0, d->dtype == MHE_BF16);
+}
 
 extern "C" int mhe_linear_f32(const float *X, const float *W, const float *bias, float *Y, int M, int N, int K, int act,
                               void *stream) {

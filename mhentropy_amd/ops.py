@@ -45,6 +45,17 @@ def stat_shards():
     return _lib.lib().mhe_conv_stat_shards()
 
 
+_TILES = {0: "128, 64, 2, 2", 1: "128, 128, 2, 2", 2: "256, 256, 2, 4"}
+
+
+def _conv_kernel_name(d, dt, mode):
+    """the template instantiation the launcher will pick, spelled as rocprofv3 prints it"""
+    bke = 32 if dt == torch.float32 else 64
+    return "mhe::conv::conv_kernel<%s, %s, %s, %d>" % ("float" if dt == torch.float32 else "unsigned short",
+                                                      _TILES[_lib.lib().mhe_conv_tile(C.byref(d))],
+                                                      "true" if d.Cin % bke == 0 else "false", mode)
+
+
 def dtype_code(dt):
     return F32 if dt == torch.float32 else BF16
 
@@ -196,10 +207,8 @@ def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in
           "mhe_conv2d_nhwc")
     if TIMING:
         ev1.record()
-        bke = 32 if dt == torch.float32 else 64
-        name = "conv_kernel<%s,%d,%s,%d>" % ("float" if dt == torch.float32 else "bf16", 64 if Cout <= 64 else 128,
-                                             "true" if Cin % bke == 0 else "false", 1 if in_scale is not None else 0)
-        KERNEL_TIMES.append((name, 2.0 * B * Ho * Wo * Cout * KH * KW * Cin, ev0, ev1))
+        KERNEL_TIMES.append((_conv_kernel_name(d, dt, 1 if in_scale is not None else 0),
+                             2.0 * B * Ho * Wo * Cout * KH * KW * Cin, ev0, ev1))
     return y
 
 
@@ -226,8 +235,7 @@ def conv1x1_residual_in(x, x2, w, in_scale, in_shift, x2_scale=None, x2_shift=No
           "mhe_conv1x1_residual_in_nhwc")
     if TIMING:
         ev1.record()
-        KERNEL_TIMES.append(("conv_kernel<%s,%d,true,2>" % ("float" if dt == torch.float32 else "bf16", 64 if Cout <= 64 else 128),
-                             2.0 * B * H * W * Cout * Cin, ev0, ev1))
+        KERNEL_TIMES.append((_conv_kernel_name(d, dt, 2), 2.0 * B * H * W * Cout * Cin, ev0, ev1))
     return y
 
 

@@ -96,7 +96,7 @@ class ResNetTrunk(nn.Module):
         if self.training:
             count = y.numel() // y.shape[-1]
             aff = ops.bn_finalize(st, bn.weight, bn.bias, bn.running_mean, bn.running_var, count, BN_MOMENTUM, BN_EPS)
-            bn.num_batches_tracked += 1
+            self._bn_touched.append(bn.num_batches_tracked)
             return aff
         sc = bn.weight.detach() / torch.sqrt(bn.running_var + BN_EPS)
         return sc.contiguous(), (bn.bias.detach() - bn.running_mean * sc).contiguous()
@@ -116,6 +116,7 @@ class ResNetTrunk(nn.Module):
         """x (B,3,H,W) float32 NCHW -> (B, feat_dim) float32."""
         dt = self.compute_dtype
         pool = _StatsPool(x.device)
+        self._bn_touched = []
         a = ops.nchw_to_nhwc(x.contiguous(), dt)
         y, aff = self._conv_bn(a, self.conv1, self.bn1, pool, None, 2, 3, 7, cin_pad=a.shape[-1])
         a = ops.maxpool3x3s2(y, aff[0], aff[1])
@@ -152,6 +153,8 @@ class ResNetTrunk(nn.Module):
                 a = ops.bn_act(yl, al[0], al[1], idt, idaff[0], idaff[1], relu=True)
             else:
                 a = ops.bn_act(yl, al[0], al[1], idt, relu=True)
+        if self._bn_touched:
+            torch._foreach_add_(self._bn_touched, 1)      # one multi-tensor launch instead of one per BatchNorm
         return self.fc(ops.avgpool(a))
 
 
