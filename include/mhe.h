@@ -189,6 +189,14 @@ int mhe_conv1x1_residual_in_nhwc(const mhe_conv_desc *d, const void *x, const vo
                                  const float *in_scale, const float *in_shift, const float *x2_scale,
                                  const float *x2_shift, void *a_out, float *stats, void *stream);
 
+/* ResNet stem: 7x7 stride-2 pad-3 convolution 3 -> 64 (torchvision `conv1`, reference hand/network.py:54-61)
+ * read straight from the NCHW f32 image x [B,3,H,W]; w [64][192] with k = 24*kh + 3*kw + c (each kh row of
+ * 21 taps zero-padded to 24, then to 192; mhentropy_amd/resnet.py:pack_stem_weight); y [B,Ho,Wo,64] raw
+ * conv output (dtype);
+ * stats [S,2,64] as in mhe_conv2d_nhwc (optional). */
+int mhe_stem_conv7x7s2(const float *x_nchw, const void *w, void *y, float *stats, int B, int H, int W, int dtype,
+                       void *stream);
+
 /* BatchNorm batch statistics (the sharded accumulators of mhe_conv2d_nhwc, summed in f64)
  * -> affine (train mode), torch semantics
  * (momentum 0.1, eps 1e-5, unbiased running_var):

@@ -104,6 +104,123 @@ __device__ __forceinline__ uint4 in_transform(uint4 raw, const float *sc, const 
     return Chunk<T>::pack(v);
 }
 
+// ---- epilogue shared by the conv kernels.  The accumulator holds y^T: lane (l15, q) owns channels
+// 4q..4q+3 of tile nt for tile row 16mt + l15; pix(row) maps a tile row to the global output pixel
+// index (or -1 when the row is outside the image / batch).
+template <typename T, int BM, int BN, int WM, int WN, typename LdsT, typename AccT, typename PixF>
+__device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, int m0, int n0, PixF pix) {
+    constexpr int NTH = 64 * WM * WN;
+    constexpr int MTW = BM / WM / 16, NTW = BN / WN / 16;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int q = lane >> 4, l15 = lane & 15;
+    const int wr = wave / WN, wc = wave % WN;
+    (void)m0;
+    // ---- epilogue.  The accumulator holds y^T: lane (l15, q) owns channels 4q..4q+3 of tile nt
+    // for pixel 16mt + l15.  (1) batch statistics: per-thread partials -> LDS -> one thread per
+    // (statistic, channel) -> ONE coalesced f32 atomic per thread into this block's shard.
+    // (2) the tile is transposed through LDS (16-byte chunks XOR-swizzled by row) so that global
+    // stores are whole 16-byte pieces of contiguous channel rows instead of 8-byte row-strided ones.
+    constexpr int CPR = BN * (int)sizeof(T) / 16;          // 16-byte chunks per output row
+    constexpr int CMASK = (CPR - 1) & 15;
+    constexpr int EPC = 16 / (int)sizeof(T);               // elements per chunk
+    constexpr int NV = 8 * NTW;                            // partial values per thread: 2 stats x NTW tiles x 4 channels
+    static_assert((size_t)BM * BN * sizeof(T) <= sizeof(lds), "output tile must fit the staging buffers");
+    static_assert((size_t)WM * WN * NV * 64 * 4 <= sizeof(lds), "statistics partials must fit the staging buffers");
+    if (p.stats) {
+        float *red = reinterpret_cast<float *>(lds);       // [waves][NV][64 lanes]
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const bool nv = n0 + wc * (BN / WN) + nt * 16 + 4 * q < p.Cout;
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+                if (nv && pix(wr * (BM / WM) + mt * 16 + l15) >= 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float v = acc[nt][mt][r]; s1[r] += v; s2[r] = fmaf(v, v, s2[r]); }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                red[(wave * NV + nt * 4 + r) * 64 + lane] = s1[r];
+                red[(wave * NV + 4 * NTW + nt * 4 + r) * 64 + lane] = s2[r];
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < 2 * BN; t += NTH) {
+            const int stat = t / BN, ch = t % BN;
+            const int wcc = ch / (BN / WN), cc = ch % (BN / WN), nt = cc >> 4, qq = (cc >> 2) & 3, r = cc & 3;
+            const int v = stat * 4 * NTW + nt * 4 + r;
+            float sum = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < WM; ++w2) {
+                const float *src = red + ((w2 * WN + wcc) * NV + v) * 64 + qq * 16;
+#pragma unroll
+                for (int l = 0; l < 16; ++l) sum += src[l];
+            }
+            const int n = n0 + ch;
+            if (n < p.Cout) atomicAdd(p.stats + ((size_t)(blockIdx.x % NSH) * 2 + stat) * p.Cout + n, sum);
+        }
+        __syncthreads();
+    }
+    {
+        unsigned char *ot = reinterpret_cast<unsigned char *>(lds);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+                const int row = wr * (BM / WM) + mt * 16 + l15;
+                const int e0 = wc * (BN / WN) + nt * 16 + 4 * q;             // first of 4 channels within the tile
+                const int boff = e0 * (int)sizeof(T);
+                const int chunk = (boff >> 4) ^ (row & CMASK);
+                unsigned char *dst = ot + ((size_t)row * CPR + chunk) * 16 + (boff & 15);
+                const v4f v = acc[nt][mt];
+                if constexpr (sizeof(T) == 4) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    uint2 o;
+                    o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                    o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                    *reinterpret_cast<uint2 *>(dst) = o;
+                }
+            }
+        __syncthreads();
+        T *yg = reinterpret_cast<T *>(p.y);
+        const T *rg = reinterpret_cast<const T *>(p.residual);
+        const bool plain = !p.out_scale && !p.out_shift && !rg && !p.relu_out;
+#pragma unroll
+        for (int j = 0; j < BM * CPR / NTH; ++j) {
+            const int id = tid + NTH * j;
+            const int row = id / CPR, c = id % CPR;
+            const long m = pix(row);
+            const int n = n0 + c * EPC;
+            if (m < 0 || n >= p.Cout) continue;
+            uint4 raw = *reinterpret_cast<const uint4 *>(ot + ((size_t)row * CPR + (c ^ (row & CMASK))) * 16);
+            const size_t off = (size_t)m * p.Cout + n;
+            if (!plain) {
+                float v[EPC];
+                Chunk<T>::unpack(raw, v);
+#pragma unroll
+                for (int i = 0; i < EPC; ++i) {
+                    const float sc = p.out_scale ? p.out_scale[n + i] : 1.f, sh = p.out_shift ? p.out_shift[n + i] : 0.f;
+                    v[i] = fmaf(v[i], sc, sh);
+                }
+                if (rg) {
+                    float r2[EPC];
+                    Chunk<T>::unpack(*reinterpret_cast<const uint4 *>(rg + off), r2);
+#pragma unroll
+                    for (int i = 0; i < EPC; ++i) v[i] += r2[i];
+                }
+                if (p.relu_out) {
+#pragma unroll
+                    for (int i = 0; i < EPC; ++i) v[i] = fmaxf(v[i], 0.f);
+                }
+                raw = Chunk<T>::pack(v);
+            }
+            *reinterpret_cast<uint4 *>(yg + off) = raw;
+        }
+    }
+}
+
 // MODE 0: plain operand load; 1: producer BatchNorm(+ReLU) applied to the operand; 2: residual-tail (dual input)
 // Tile BM x BN computed by WM x WN wavefronts (64 * WM * WN threads); each wave owns (BM/WM) x (BN/WN).
 // Shipped shapes: 128x64 and 128x128 on 2x2 waves (2 workgroups per CU), 256x256 on 2x4 waves (one per CU,
@@ -249,109 +366,123 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_kernel(const Params p) {
         cur ^= 1;
     }
 
-    // ---- epilogue.  The accumulator holds y^T: lane (l15, q) owns channels 4q..4q+3 of tile nt
-    // for pixel 16mt + l15.  (1) batch statistics: per-thread partials -> LDS -> one thread per
-    // (statistic, channel) -> ONE coalesced f32 atomic per thread into this block's shard.
-    // (2) the tile is transposed through LDS (16-byte chunks XOR-swizzled by row) so that global
-    // stores are whole 16-byte pieces of contiguous channel rows instead of 8-byte row-strided ones.
-    constexpr int CPR = BN * (int)sizeof(T) / 16;          // 16-byte chunks per output row
-    constexpr int CMASK = (CPR - 1) & 15;
-    constexpr int EPC = 16 / (int)sizeof(T);               // elements per chunk
-    constexpr int NV = 8 * NTW;                            // partial values per thread: 2 stats x NTW tiles x 4 channels
-    static_assert((size_t)BM * BN * sizeof(T) <= sizeof(lds), "output tile must fit the staging buffers");
-    static_assert((size_t)WM * WN * NV * 64 * 4 <= sizeof(lds), "statistics partials must fit the staging buffers");
-    if (p.stats) {
-        float *red = reinterpret_cast<float *>(lds);       // [waves][NV][64 lanes]
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const bool nv = n0 + wc * (BN / WN) + nt * 16 + 4 * q < p.Cout;
-            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) {
-                if (nv && m0 + wr * (BM / WM) + mt * 16 + l15 < p.M) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { const float v = acc[nt][mt][r]; s1[r] += v; s2[r] = fmaf(v, v, s2[r]); }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                red[(wave * NV + nt * 4 + r) * 64 + lane] = s1[r];
-                red[(wave * NV + 4 * NTW + nt * 4 + r) * 64 + lane] = s2[r];
-            }
-        }
-        __syncthreads();
-        for (int t = tid; t < 2 * BN; t += NTH) {
-            const int stat = t / BN, ch = t % BN;
-            const int wcc = ch / (BN / WN), cc = ch % (BN / WN), nt = cc >> 4, qq = (cc >> 2) & 3, r = cc & 3;
-            const int v = stat * 4 * NTW + nt * 4 + r;
-            float sum = 0.f;
-#pragma unroll
-            for (int w2 = 0; w2 < WM; ++w2) {
-                const float *src = red + ((w2 * WN + wcc) * NV + v) * 64 + qq * 16;
-#pragma unroll
-                for (int l = 0; l < 16; ++l) sum += src[l];
-            }
-            const int n = n0 + ch;
-            if (n < p.Cout) atomicAdd(p.stats + ((size_t)(blockIdx.x % NSH) * 2 + stat) * p.Cout + n, sum);
-        }
-        __syncthreads();
-    }
+    epilogue<T, BM, BN, WM, WN>(p, acc, lds, m0, n0, [&](int row) { const int m = m0 + row; return m < p.M ? (long)m : -1l; });
+}
+
+// ---------------------------------------------------------------------------
+// Stem: 7x7 stride-2 pad-3 convolution 3 -> 64 read straight from the NCHW f32 image (no layout-change
+// pass, no channel padding, every input element fetched from HBM once per 8x16 output tile).
+// K is ordered (kh, kw, c) with every kh row padded from 21 to 24: k = 24*kh + 3*kw + c.  With the input
+// patch stored channel-interleaved in LDS ([row][3*col + c]) the 24 k-values of one (pixel, kh) are 24
+// CONSECUTIVE patch elements, so MFMA operand fragments are read directly from the patch (4-byte aligned
+// 16-byte pieces) - no im2col buffer is ever built.  k-slots 21..23 of a row read the next pixels' data
+// against zero weights.  Algorithmic HBM bytes: 12 B/pixel in, 128 (bf16) | 256 (f32) B/pixel out.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ x, const Params p, int tiles_x, int tiles_y) {
+    constexpr int CE = El<T>::CE;                       // k per 16-byte chunk
+    constexpr int KP = 192, NCH = KP / CE, CPK = 24 / CE;     // chunks in all, chunks per kh row
+    constexpr int TH = 8, TW = 16, PH = 2 * TH + 5, PW = 2 * TW + 5;
+    constexpr int PSI = 3 * PW + 1;                     // 112 elements per interleaved patch row
+    constexpr int PROWS = PH + 3;                       // rows 21..23 are zero: k-slots of the K padding (kh = 7) land there
+    constexpr int BM = 128, BN = 64, WM = 2, WN = 2, MTW = 4, NTW = 2;
+    constexpr int NST = NCH / 8;
+    __shared__ uint4 lds[NST * BN * 8 > BM * BN * (int)sizeof(T) / 16 ? NST * BN * 8 : BM * BN * (int)sizeof(T) / 16];
+    __shared__ __attribute__((aligned(16))) T patch[PROWS * PSI];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int q = lane >> 4, l15 = lane & 15, wr = wave / WN, wc = wave % WN;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const T *wg = reinterpret_cast<const T *>(p.w);
+
+    // every global load is issued (clamped address, no branch) before the first LDS store
+    const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
     {
-        unsigned char *ot = reinterpret_cast<unsigned char *>(lds);
+        constexpr int NP = (3 * PH * PW + 255) / 256, NWL = BN * NCH / 256;
+        float pv[NP];
+        uint4 wv[NWL];
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
+        for (int j = 0; j < NP; ++j) {
+            const int i = tid + 256 * j, ic = i < 3 * PH * PW ? i : 0;
+            const int c = ic / (PH * PW), r = (ic / PW) % PH, col = ic % PW;
+            const int iy = iy0 + r, ix = ix0 + col;
+            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const float v = x[(((size_t)b * 3 + c) * p.H + (ok ? iy : 0)) * p.W + (ok ? ix : 0)];
+            pv[j] = ok ? v : 0.f;
+        }
 #pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) {
-                const int row = wr * (BM / WM) + mt * 16 + l15;
-                const int e0 = wc * (BN / WN) + nt * 16 + 4 * q;             // first of 4 channels within the tile
-                const int boff = e0 * (int)sizeof(T);
-                const int chunk = (boff >> 4) ^ (row & CMASK);
-                unsigned char *dst = ot + ((size_t)row * CPR + chunk) * 16 + (boff & 15);
-                const v4f v = acc[nt][mt];
-                if constexpr (sizeof(T) == 4) {
-                    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    uint2 o;
-                    o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-                    o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-                    *reinterpret_cast<uint2 *>(dst) = o;
-                }
+        for (int j = 0; j < NWL; ++j) {
+            const int i = tid + 256 * j, n = i / NCH, ch = i % NCH;
+            wv[j] = *reinterpret_cast<const uint4 *>(wg + (size_t)n * KP + ch * CE);
+        }
+        for (int i = tid; i < (PROWS - PH) * PSI + PH; i += 256) {      // zero rows + the pad column of real rows
+            const int idx = i < (PROWS - PH) * PSI ? PH * PSI + i : (i - (PROWS - PH) * PSI) * PSI + 3 * PW;
+            if constexpr (sizeof(T) == 4) patch[idx] = 0.f; else patch[idx] = 0;
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int i = tid + 256 * j;
+            if (i < 3 * PH * PW) {
+                const int c = i / (PH * PW), r = (i / PW) % PH, col = i % PW;
+                if constexpr (sizeof(T) == 4) patch[r * PSI + 3 * col + c] = pv[j]; else patch[r * PSI + 3 * col + c] = f32_to_bf16(pv[j]);
             }
-        __syncthreads();
-        T *yg = reinterpret_cast<T *>(p.y);
-        const T *rg = reinterpret_cast<const T *>(p.residual);
-        const bool plain = !p.out_scale && !p.out_shift && !rg && !p.relu_out;
+        }
 #pragma unroll
-        for (int j = 0; j < BM * CPR / NTH; ++j) {
-            const int id = tid + NTH * j;
-            const int row = id / CPR, c = id % CPR;
-            const int m = m0 + row, n = n0 + c * EPC;
-            if (m >= p.M || n >= p.Cout) continue;
-            uint4 raw = *reinterpret_cast<const uint4 *>(ot + ((size_t)row * CPR + (c ^ (row & CMASK))) * 16);
-            const size_t off = (size_t)m * p.Cout + n;
-            if (!plain) {
-                float v[EPC];
-                Chunk<T>::unpack(raw, v);
-#pragma unroll
-                for (int i = 0; i < EPC; ++i) {
-                    const float sc = p.out_scale ? p.out_scale[n + i] : 1.f, sh = p.out_shift ? p.out_shift[n + i] : 0.f;
-                    v[i] = fmaf(v[i], sc, sh);
-                }
-                if (rg) {
-                    float r2[EPC];
-                    Chunk<T>::unpack(*reinterpret_cast<const uint4 *>(rg + off), r2);
-#pragma unroll
-                    for (int i = 0; i < EPC; ++i) v[i] += r2[i];
-                }
-                if (p.relu_out) {
-#pragma unroll
-                    for (int i = 0; i < EPC; ++i) v[i] = fmaxf(v[i], 0.f);
-                }
-                raw = Chunk<T>::pack(v);
-            }
-            *reinterpret_cast<uint4 *>(yg + off) = raw;
+        for (int j = 0; j < NWL; ++j) {
+            const int i = tid + 256 * j, n = i / NCH, ch = i % NCH;
+            lds[(ch >> 3) * BN * 8 + swz(n, ch & 7)] = wv[j];
         }
     }
+    __syncthreads();
+
+    v4f acc[NTW][MTW];
+#pragma unroll
+    for (int a = 0; a < NTW; ++a)
+#pragma unroll
+        for (int c = 0; c < MTW; ++c) acc[a][c] = v4f{0.f, 0.f, 0.f, 0.f};
+    const unsigned *pw = reinterpret_cast<const unsigned *>(patch);
+#pragma unroll
+    for (int ks = 0; ks < NCH / 4; ++ks) {              // 4 chunks (one per lane group q) per step
+        const int chunk = 4 * ks + q, kh = chunk / CPK, jj = chunk - kh * CPK;
+        uint4 fa[MTW], fb[NTW];
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+            // tile row 16*(4wr+mt) + l15  <->  pixel (dy = 4wr+mt, dx = l15)
+            const int e = (2 * (4 * wr + mt) + kh) * PSI + 6 * l15 + CE * jj;       // first element; byte offset is 4-aligned
+            const unsigned *src = pw + e * (int)sizeof(T) / 4;
+            fa[mt] = make_uint4(src[0], src[1], src[2], src[3]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) fb[nt] = lds[(chunk >> 3) * BN * 8 + swz(wc * 32 + nt * 16 + l15, chunk & 7)];
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) {
+                        const float wv = __uint_as_float(reinterpret_cast<const unsigned *>(&fb[nt])[i]);
+                        const float xv = __uint_as_float(reinterpret_cast<const unsigned *>(&fa[mt])[i]);
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc[nt][mt], 0, 0, 0);
+                    }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fb[nt]),
+                        __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fa[mt]), acc[nt][mt], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    epilogue<T, BM, BN, WM, WN>(p, acc, lds, 0, 0, [&](int row) {
+        const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
+        return (oy < p.Ho && ox < p.Wo) ? ((long)b * p.Ho + oy) * p.Wo + ox : -1l;
+    });
 }
 
 // ---------------------------------------------------------------------------
@@ -525,6 +656,8 @@ static int launch_conv(const Params &p, hipStream_t s) {
     switch (choose_tile(p, fast, sizeof(T) == 2)) {
         case 0: if (fast) launch_mode<T, 128, 64, 2, 2, true>(p, s); else launch_mode<T, 128, 64, 2, 2, false>(p, s); break;
         case 2: if constexpr (sizeof(T) == 2) launch_mode<T, 256, 256, 2, 4, true>(p, s); break;
+        case 3: if constexpr (sizeof(T) == 2) launch_mode<T, 256, 128, 4, 2, true>(p, s); break;
+        case 4: if constexpr (sizeof(T) == 2) launch_mode<T, 256, 64, 4, 2, true>(p, s); break;
         default: if (fast) launch_mode<T, 128, 128, 2, 2, true>(p, s); else launch_mode<T, 128, 128, 2, 2, false>(p, s); break;
     }
     return check_launch("conv_kernel");
@@ -598,6 +731,23 @@ extern "C" int mhe_conv_tile(const mhe_conv_desc *d) {
     p.M = d->B * Ho * Wo;
     const int bke = d->dtype == MHE_F32 ? 32 : 64;
     return conv::choose_tile(p, d->Cin % bke == 0, d->dtype == MHE_BF16);
+}
+
+extern "C" int mhe_stem_conv7x7s2(const float *x_nchw, const void *w, void *y, float *stats, int B, int H, int W, int dtype,
+                                  void *stream) {
+    MHE_REQUIRE(x_nchw && w && y, "mhe_stem_conv7x7s2: null pointer");
+    MHE_REQUIRE(B > 0 && H > 0 && W > 0, "mhe_stem_conv7x7s2: bad geometry");
+    MHE_REQUIRE(dtype == MHE_F32 || dtype == MHE_BF16, "mhe_stem_conv7x7s2: dtype=%d", dtype);
+    conv::Params p{};
+    p.w = w; p.y = y; p.stats = stats;
+    p.B = B; p.H = H; p.W = W; p.Cin = 3; p.Cout = 64; p.KH = p.KW = 7; p.stride = 2; p.pad = 3;
+    p.Ho = (H + 6 - 7) / 2 + 1; p.Wo = (W + 6 - 7) / 2 + 1;
+    p.M = B * p.Ho * p.Wo;
+    const int tx = (p.Wo + 15) / 16, ty = (p.Ho + 7) / 8;
+    const dim3 grid((unsigned)(tx * ty * B));
+    if (dtype == MHE_F32) hipLaunchKernelGGL(conv::stem_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x_nchw, p, tx, ty);
+    else hipLaunchKernelGGL(conv::stem_kernel<u16>, grid, dim3(256), 0, (hipStream_t)stream, x_nchw, p, tx, ty);
+    return check_launch("stem_kernel");
 }
 
 extern "C" int mhe_linear_f32(const float *X, const float *W, const float *bias, float *Y, int M, int N, int K, int act,

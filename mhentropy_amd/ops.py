@@ -45,7 +45,7 @@ def stat_shards():
     return _lib.lib().mhe_conv_stat_shards()
 
 
-_TILES = {0: "128, 64, 2, 2", 1: "128, 128, 2, 2", 2: "256, 256, 2, 4"}
+_TILES = {0: "128, 64, 2, 2", 1: "128, 128, 2, 2", 2: "256, 256, 2, 4", 3: "256, 128, 4, 2", 4: "256, 64, 4, 2"}
 
 
 def _conv_kernel_name(d, dt, mode):
@@ -236,6 +236,28 @@ def conv1x1_residual_in(x, x2, w, in_scale, in_shift, x2_scale=None, x2_shift=No
     if TIMING:
         ev1.record()
         KERNEL_TIMES.append((_conv_kernel_name(d, dt, 2), 2.0 * B * H * W * Cout * Cin, ev0, ev1))
+    return y
+
+
+def stem_conv7x7s2(x, w, dtype, stats=None):
+    """x [B,3,H,W] f32 NCHW, w packed [64, Kpad] (dtype) -> raw conv1 output [B,Ho,Wo,64] NHWC (dtype)."""
+    B, Cn, H, W = x.shape
+    _chk(x, torch.float32, "stem.x"); _chk(w, dtype, "stem.w", (64, 192))
+    if Cn != 3:
+        raise _lib.MheError("stem.x: expected 3 input channels")
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(B, Ho, Wo, 64, device=x.device, dtype=dtype)
+    if stats is not None:
+        _chk(stats, torch.float32, "stem.stats", (stat_shards(), 2, 64))
+    if TIMING:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(_lib.lib().mhe_stem_conv7x7s2(_ptr(x), _ptr(w), _ptr(y), _ptr(stats), B, H, W, dtype_code(dtype), _stream()),
+          "mhe_stem_conv7x7s2")
+    if TIMING:
+        ev1.record()
+        KERNEL_TIMES.append(("mhe::conv::stem_kernel<%s>" % ("float" if dtype == torch.float32 else "unsigned short"),
+                             2.0 * B * Ho * Wo * 64 * 147, ev0, ev1))
     return y
 
 

@@ -36,6 +36,13 @@ def pack_conv_weight(w, dtype, cin_pad=None):
     return out.to(dtype).contiguous()
 
 
+def pack_stem_weight(w, dtype):
+    """torch [64,3,7,7] -> [64,192] for the fused stem kernel: k = 24*kh + 3*kw + c (zero-padded)."""
+    wp = torch.zeros(64, 8, 24, dtype=torch.float32, device=w.device)
+    wp[:, :7, :21] = w.detach().float().permute(0, 2, 3, 1).reshape(64, 7, 21)
+    return wp.reshape(64, 192).to(dtype).contiguous()
+
+
 class _Block(nn.Module):
     def __init__(self, kind, inplanes, planes, stride):
         super().__init__()
@@ -82,12 +89,12 @@ class ResNetTrunk(nn.Module):
         self.fuse_tail = os.environ.get("MHE_FUSE_TAIL", "1") == "1"
 
     # -- packed-weight cache keyed on the parameter's version counter
-    def _w(self, conv, cin_pad=None):
+    def _w(self, conv, cin_pad=None, stem=False):
         p = conv.weight
         key = (id(p), p._version, self.compute_dtype, p.device)
         hit = self._wcache.get(id(p))
         if hit is None or hit[0] != key:
-            hit = (key, pack_conv_weight(p, self.compute_dtype, cin_pad))
+            hit = (key, pack_stem_weight(p, self.compute_dtype) if stem else pack_conv_weight(p, self.compute_dtype, cin_pad))
             self._wcache[id(p)] = hit
         return hit[1]
 
@@ -117,8 +124,9 @@ class ResNetTrunk(nn.Module):
         dt = self.compute_dtype
         pool = _StatsPool(x.device)
         self._bn_touched = []
-        a = ops.nchw_to_nhwc(x.contiguous(), dt)
-        y, aff = self._conv_bn(a, self.conv1, self.bn1, pool, None, 2, 3, 7, cin_pad=a.shape[-1])
+        st = pool.take(64) if self.training else None
+        y = ops.stem_conv7x7s2(x.contiguous(), self._w(self.conv1, stem=True), dt, stats=st)      # reads the NCHW image directly
+        aff = self._bn_affine(y, self.bn1, st)
         a = ops.maxpool3x3s2(y, aff[0], aff[1])
         blocks = [blk for li in range(4) for blk in getattr(self, f"layer{li + 1}")]
         pending = None          # (raw conv3 output, bn3 affine, identity tensor, identity affine | None): an unevaluated block tail

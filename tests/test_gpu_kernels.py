@@ -213,6 +213,29 @@ def test_conv_matches_torch(gpu_lib, dtype, cfg):
     assert_close(y3.float().cpu().permute(0, 3, 1, 2), ref3, tol, what="fused input transform")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (1, 50, 38), (3, 16, 32)])
+def test_stem_conv_matches_torch(gpu_lib, dtype, B, H, W):
+    """fused stem (NCHW f32 in, im2col in LDS) against conv2d on the same (bf16-rounded) operands,
+    including image sizes that are not a multiple of the 8x16 output tile"""
+    from mhentropy_amd import ops, resnet
+    rng = np.random.default_rng(11)
+    x = rng.normal(0, 1, (B, 3, H, W)).astype(np.float32)
+    w = rng.normal(0, (2.0 / 147) ** 0.5, (64, 3, 7, 7)).astype(np.float32)
+    xt, wt = torch.as_tensor(x), torch.as_tensor(w)
+    if dtype == torch.bfloat16:
+        xt, wt = xt.bfloat16().float(), wt.bfloat16().float()
+    ref = torch.nn.functional.conv2d(xt.double(), wt.double(), None, 2, 3)
+    stats = torch.zeros(ops.stat_shards(), 2, 64, device="cuda")
+    y = ops.stem_conv7x7s2(_dev(x), resnet.pack_stem_weight(torch.as_tensor(w), dtype).cuda(), dtype, stats=stats)
+    tol = 2e-6 if dtype == torch.float32 else 6e-3
+    assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, tol, what="stem conv")
+    n = ref.numel() / 64
+    st = stats.double().sum(0).cpu()
+    assert_close(st[0] / n, ref.mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean")
+    assert_close(st[1] / n, (ref ** 2).mean((0, 2, 3)), 1e-5, what="batch E[x^2]")
+
+
 def test_metrics_match_reference_vectors(gpu_lib):
     from mhentropy_amd import ops, criteria
     for tag in ("small", "shipped"):
