@@ -51,6 +51,10 @@ const char *mhe_last_error(void);
  * f32 in / f32 accumulate on v_mfma_f32_16x16x4_f32 (bit-level = fmaf chain). */
 int mhe_linear_f32(const float *X, const float *W, const float *bias, float *Y,
                    int M, int N, int K, int act, void *stream);
+/* the M <= 256, K % 64 == 0 specialisation mhe_linear_f32 dispatches to (one workgroup per 16 output
+ * columns, K split over its 4 waves): the shapes of the per-image heads. */
+int mhe_linear_skinny_f32(const float *X, const float *W, const float *bias, float *Y,
+                          int M, int N, int K, int act, void *stream);
 
 /* conditional RealNVP ----------------------------------------------------- */
 

@@ -21,6 +21,7 @@ SIGNATURES = {
     "mhe_abi_version": (_i, []),
     "mhe_last_error": (C.c_char_p, []),
     "mhe_linear_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "mhe_linear_skinny_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mhe_flow_packed_floats_per_net": (_sz, [_i, _i]),
     "mhe_flow_pack_net_host": (_i, [_p, _p, _p, _i, _i, _p]),
     "mhe_flow_couplings_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),

@@ -750,11 +750,15 @@ extern "C" int mhe_stem_conv7x7s2(const float *x_nchw, const void *w, void *y, f
     return check_launch("stem_kernel");
 }
 
+extern "C" int mhe_linear_skinny_f32(const float *X, const float *W, const float *bias, float *Y, int M, int N, int K,
+                                     int act, void *stream);
+
 extern "C" int mhe_linear_f32(const float *X, const float *W, const float *bias, float *Y, int M, int N, int K, int act,
                               void *stream) {
     MHE_REQUIRE(X && W && Y && M > 0 && N > 0 && K > 0, "mhe_linear_f32: bad arguments");
     MHE_REQUIRE(K % 32 == 0, "mhe_linear_f32: K=%d must be a multiple of 32", K);
     MHE_REQUIRE(N % 4 == 0, "mhe_linear_f32: N=%d must be a multiple of 4", N);
+    if (M <= 256 && K % 64 == 0) return mhe_linear_skinny_f32(X, W, bias, Y, M, N, K, act, stream);
     mhe_conv_desc d = {M, 1, 1, K, N, 1, 1, 1, 0, MHE_F32, 0, act == MHE_ACT_RELU};
     return mhe_conv2d_nhwc(&d, X, W, Y, nullptr, nullptr, nullptr, bias, nullptr, nullptr, stream);
 }
@@ -819,4 +823,80 @@ extern "C" int mhe_nchw_to_nhwc(const float *x, void *y, int B, int C, int H, in
         hipLaunchKernelGGL(conv::nchw_to_nhwc_kernel<u16>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x,
                            (u16 *)y, B, C, H * W, Cp);
     return check_launch("nchw_to_nhwc_kernel");
+}
+
+// ---------------------------------------------------------------------------
+// Skinny dense layer for the per-image heads (M = batch <= a few hundred rows):
+//   Y[M,N] = act(X[M,K] W[N,K]^T + bias),  f32, exact fmaf chains on v_mfma_f32_16x16x4_f32.
+// The 128x128-tile kernel gives these shapes 8-16 workgroups walking K serially (165 us for
+// l1: 256x512x2048); here a workgroup owns 16 output columns x all rows (grid = N/16), its 4 waves
+// split K and reduce through LDS, operands go straight from L2 into fragments (W is streamed once,
+// X - at most a few MB - is L2-resident).
+namespace mhe { namespace conv {
+template <int MT>      // row tiles of 16 held per wave (M <= 16*MT)
+__global__ __launch_bounds__(256) void skinny_linear_kernel(const float *__restrict__ X, const float *__restrict__ W,
+                                                            const float *__restrict__ bias, float *__restrict__ Y,
+                                                            int M, int N, int K, int relu) {
+    __shared__ v4f red[3][MT][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, l15 = lane & 15;
+    const int n0 = blockIdx.x * 16;
+    const int kq = K / 4;                    // each wave reduces a quarter of K (K % 64 == 0)
+    const int kbeg = wave * kq, kend = kbeg + kq;
+    v4f acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+    const int n = n0 + l15;
+    const float *wrow = W + (size_t)(n < N ? n : N - 1) * K + 4 * q;
+    for (int k = kbeg; k < kend; k += 16) {
+        const float4 wv = *reinterpret_cast<const float4 *>(wrow + k);
+        float4 xv[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int m = 16 * t + l15;
+            xv[t] = *reinterpret_cast<const float4 *>(X + (size_t)(m < M ? m : M - 1) * K + k + 4 * q);
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv[t].x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv[t].y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv[t].z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv[t].w, acc[t], 0, 0, 0);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) red[wave - 1][t][lane] = acc[t];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // D layout: row (channel) 4q + r, column (batch row) l15
+        const int nb = n0 + 4 * q;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias && nb < N) bv = *reinterpret_cast<const float4 *>(bias + nb);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            v4f v = acc[t];
+#pragma unroll
+            for (int w2 = 0; w2 < 3; ++w2) { const v4f o = red[w2][t][lane]; v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
+            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+            if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            const int m = 16 * t + l15;
+            if (m < M && nb < N) *reinterpret_cast<float4 *>(Y + (size_t)m * N + nb) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+}}  // namespace mhe::conv
+
+extern "C" int mhe_linear_skinny_f32(const float *X, const float *W, const float *bias, float *Y, int M, int N, int K,
+                                     int act, void *stream) {
+    using namespace mhe;
+    MHE_REQUIRE(X && W && Y && M > 0 && M <= 256 && N > 0 && N % 4 == 0 && K > 0 && K % 64 == 0,
+                "mhe_linear_skinny_f32: need M <= 256, N %% 4 == 0, K %% 64 == 0 (M=%d N=%d K=%d)", M, N, K);
+    const dim3 grid((N + 15) / 16), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const int relu = act == MHE_ACT_RELU;
+    if (M <= 64) hipLaunchKernelGGL(conv::skinny_linear_kernel<4>, grid, block, 0, s, X, W, bias, Y, M, N, K, relu);
+    else if (M <= 128) hipLaunchKernelGGL(conv::skinny_linear_kernel<8>, grid, block, 0, s, X, W, bias, Y, M, N, K, relu);
+    else hipLaunchKernelGGL(conv::skinny_linear_kernel<16>, grid, block, 0, s, X, W, bias, Y, M, N, K, relu);
+    return check_launch("skinny_linear_kernel");
 }

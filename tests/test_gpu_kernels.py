@@ -157,7 +157,8 @@ def test_loss_rows_match_reference_vectors(gpu_lib, tag):
 def test_linear_matches_torch(gpu_lib):
     from mhentropy_amd import ops
     rng = np.random.default_rng(3)
-    for M, N, K, relu in ((5, 16, 512, False), (64, 512, 2048, False), (130, 512, 512, True), (3, 196, 64, False)):
+    for M, N, K, relu in ((5, 16, 512, False), (64, 512, 2048, False), (130, 512, 512, True), (3, 196, 64, False),
+                          (256, 512, 2048, False), (256, 1024, 512, True), (300, 64, 96, False), (17, 20, 32, True)):
         x = rng.normal(0, 1, (M, K)).astype(np.float32)
         w = rng.normal(0, 0.05, (N, K)).astype(np.float32)
         b = rng.normal(0, 1, (N,)).astype(np.float32)
