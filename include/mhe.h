@@ -234,6 +234,12 @@ int mhe_nchw_to_nhwc(const float *x, void *y, int B, int C, int H, int W, int dt
 int mhe_metrics_f32(const float *xyz, const float *uv, const float *pose3d, const float *scale,
                     const float *crop_uv, const float *vis, float *out, int N, int B, void *stream);
 
+/* Top-Q hypothesis selection of MHEnt.sample (hand/network.py:866-871): per image b keep the Q rows of
+ * highest score[n*B+b] in descending order and gather them: idx_out [Q,B] (hypothesis index n),
+ * rows_out [Q*B, D] sample-major.  rows [N*B, D] is the flow sample th45. */
+int mhe_topk_gather_f32(const float *score, const float *rows, int *idx_out, float *rows_out,
+                        int N, int B, int Q, int D, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,7 @@ SIGNATURES = {
     "mhe_maxpool3x3s2_nhwc": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mhe_avgpool_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mhe_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "mhe_topk_gather_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mhe_metrics_f32": (_i, [_p] * 7 + [_i, _i, _p]),
 }
 

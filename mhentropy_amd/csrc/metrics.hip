@@ -120,3 +120,42 @@ extern "C" int mhe_metrics_f32(const float *xyz, const float *uv, const float *p
                        scale, crop_uv, vis, out, N, B);
     return check_launch("metrics_kernel");
 }
+
+// ---------------------------------------------------------------------------
+// Top-Q hypothesis selection of MHEnt.sample (hand/network.py:866-871): per image keep the Q hypotheses
+// of highest log q, in descending order (torch.topk semantics), and gather their flow samples.
+// One wavefront per image; rank by counting (N is a few hundred at most).
+namespace mhe { namespace metrics {
+__global__ __launch_bounds__(256) void topk_gather_kernel(const float *__restrict__ score, const float *__restrict__ rows,
+                                                          int *__restrict__ idx_out, float *__restrict__ rows_out,
+                                                          int N, int B, int Q, int D) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    for (int n = lane; n < N; n += 64) {
+        const float v = score[(size_t)n * B + b];
+        int rank = 0;
+        for (int m = 0; m < N; ++m) {
+            const float u = score[(size_t)m * B + b];
+            rank += (u > v || (u == v && m < n)) ? 1 : 0;
+        }
+        if (rank < Q) idx_out[(size_t)rank * B + b] = n;
+    }
+    wave_sync();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);              // this wave's index stores are visible to its own later loads
+    for (int r = 0; r < Q; ++r) {
+        const int n = idx_out[(size_t)r * B + b];
+        for (int d = lane; d < D; d += 64) rows_out[((size_t)r * B + b) * D + d] = rows[((size_t)n * B + b) * D + d];
+    }
+}
+}}  // namespace mhe::metrics
+
+extern "C" int mhe_topk_gather_f32(const float *score, const float *rows, int *idx_out, float *rows_out, int N, int B,
+                                   int Q, int D, void *stream) {
+    using namespace mhe;
+    MHE_REQUIRE(score && rows && idx_out && rows_out, "mhe_topk_gather_f32: null pointer");
+    MHE_REQUIRE(N > 0 && B > 0 && Q > 0 && Q <= N && D > 0, "mhe_topk_gather_f32: need 0 < Q <= N (N=%d Q=%d)", N, Q);
+    hipLaunchKernelGGL(metrics::topk_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, score, rows,
+                       idx_out, rows_out, N, B, Q, D);
+    return check_launch("topk_gather_kernel");
+}

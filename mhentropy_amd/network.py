@@ -148,15 +148,18 @@ class MHEnt(nn.Module):
         N_quant = N
         if isinstance(N, (list, tuple)):
             N, N_quant = N
-        if N_quant < N:
-            raise NotImplementedError("top-k hypothesis selection (network.py:866-871) is a later scope row")
         out = {}
         if y is not None and "image" in y:
             out["image"] = y["image"]
         _, feat, _ = self.feat_extractor(x)
         B = feat.shape[0]
         z0 = self._noise(N * B, temp, noise, feat.device)
-        th45 = self.q_z_giv_i.forward_p(z0, cond=feat)
+        if N_quant < N:        # keep the N_quant most likely hypotheses per image (network.py:866-871); log q comes
+            th45, log_q = self.q_z_giv_i.sample_with_log_prob(z0, feat)      # from the sampling pass itself
+            _, th45 = ops.topk_gather(log_q, th45, N, B, N_quant)
+            N = N_quant
+        else:
+            th45 = self.q_z_giv_i.forward_p(z0, cond=feat)
         mods = {"xyz", "uv", "verts"} if mods is None else set(mods)
         blob = self.mano_dec.table_blob()
         o = ops.mano_joints(th45, self._det(feat), blob, inv_norm=True, image_size=float(self.image_size),

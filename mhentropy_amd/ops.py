@@ -169,6 +169,17 @@ def elbo_reduce(log_p_rows, log_q_rows, N, B):
     return q, h, lp
 
 
+def topk_gather(score, rows, N, B, Q):
+    """per image the Q rows of highest score, descending (torch.topk order): returns (idx [Q,B] int32, rows [Q*B,D])"""
+    D = rows.shape[1]
+    _chk(score, torch.float32, "topk.score", (N * B,)); _chk(rows, torch.float32, "topk.rows", (N * B, D))
+    idx = torch.empty(Q, B, device=rows.device, dtype=torch.int32)
+    out = torch.empty(Q * B, D, device=rows.device, dtype=torch.float32)
+    check(_lib.lib().mhe_topk_gather_f32(_ptr(score), _ptr(rows), _ptr(idx), _ptr(out), N, B, Q, D, _stream()),
+          "mhe_topk_gather_f32")
+    return idx, out
+
+
 def metrics(xyz, uv, pose3d, scale, crop_uv, vis):
     N, B = xyz.shape[:2]
     _chk(xyz, torch.float32, "metrics.xyz", (N, B, 63)); _chk(uv, torch.float32, "metrics.uv", (N, B, 42))

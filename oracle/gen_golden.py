@@ -273,6 +273,18 @@ def gen_mhent(network, criteria, tables, tag, seed, h, steps, B, Ns):
     gold["z0_sample"] = z0s.numpy()
     gold.update({"sample_" + k: sref[k].numpy() for k in ("th_bt", "logs_t", "verts", "xyz", "uv")})
 
+    # ---- sample() with top-k hypothesis selection (network.py:866-871): keep the N_quant most likely of N
+    Nt, Qt = 6, 3
+    z0t = torch.as_tensor(synth.noise(seed + 700, Nt * B)) * 0.8
+    model.q_z_giv_i.prior = _FixedPrior(real_prior, z0t / 0.8)
+    with torch.no_grad():
+        tref = model.sample(x_dummy, N=[Nt, Qt], temp=0.8, mods={"uv", "xyz", "verts"}, y=y)
+        tk = network_ref.sample(sd, tb, feat, z0t, Nt, N_quant=Qt)
+    for k in ("th_bt", "logs_t", "verts", "xyz", "uv"):
+        _close("sample_topk." + k, tk[k], tref[k], 5e-5, 5e-4)
+    gold["z0_topk"] = z0t.numpy()
+    gold.update({"topk_" + k: tref[k].numpy() for k in ("th_bt", "logs_t", "verts", "xyz", "uv")})
+
     # ---- criterion + metrics (criteria.py:47-173)
     crit = criteria.MHEntLoss()
     o = {"log_p": ref["log_p"].detach(), "xyz": sref["xyz"], "uv": sref["uv"], "verts": sref["verts"]}

@@ -111,11 +111,16 @@ def get_loss(sd, tb, x, y, z0, N, arch="resnet50", training=True):
     return reverse_kld(sd, tb, feat, y, z0, N)
 
 
-def sample(sd, tb, feat, z0, N, image_size=256):
-    """MHEnt.sample, network.py:846-883 with N_quant == N (shipped use,
-    CrossModalHand.py:357-361) and mods {'uv','xyz','verts'}; z0 already times temp."""
+def sample(sd, tb, feat, z0, N, image_size=256, N_quant=None):
+    """MHEnt.sample, network.py:846-883 with mods {'uv','xyz','verts'}; z0 already times temp.
+    N_quant < N keeps, per image, the N_quant hypotheses of highest log q (network.py:866-871)."""
     B = feat.shape[0]
     z = sample_q(sd, feat, z0, N).reshape(N, B, -1)
+    if N_quant is not None and N_quant < N:
+        log_q = flows_ref.log_prob(sub(sd, "q_z_giv_i."), z.flatten(0, 1)[:, 3:48], feat.repeat(N, 1)).reshape(N, -1)
+        idx = torch.topk(log_q, N_quant, dim=0)[1]
+        z = torch.gather(z, 0, idx[..., None].repeat(1, 1, z.shape[-1]))
+        N = N_quant
     out = {"th_bt": z[..., :58], "logs_t": z[..., -3:]}
     dec = decode(tb, z.reshape(N * B, -1), image_size, inv_norm=True)
     for k in ("verts", "xyz", "uv"):

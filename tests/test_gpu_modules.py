@@ -86,6 +86,20 @@ def test_sample_and_criterion_match_reference_vectors(gpu_lib, tag):
         assert_close(v.cpu(), g["metric_" + k], 5e-4, what=k)      # metrics amplify the 1e-4 of xyz/uv through std/min
 
 
+@pytest.mark.parametrize("tag", ["small", "shipped"])
+def test_sample_topk_matches_reference_vectors(gpu_lib, tag):
+    """MHEnt.sample(N=[6,3]): the 3 most likely of 6 hypotheses per image (hand/network.py:866-871)"""
+    g = load_golden(f"mhent_{tag}")
+    model = _model_from_golden(g)
+    B = int(g["B"])
+    y = _t({k[2:]: v for k, v in g.items() if k.startswith("y_")})
+    s = model.sample(torch.zeros(B, 3, 8, 8, device="cuda"), N=[6, 3], temp=0.8, mods={"uv", "xyz", "verts"}, y=y,
+                     noise=torch.as_tensor(g["z0_topk"]).cuda() / 0.8)
+    for k in ("th_bt", "logs_t", "verts", "xyz", "uv"):
+        assert tuple(s[k].shape) == g["topk_" + k].shape, k
+        assert_close(s[k].cpu(), g["topk_" + k], RTOL, what="topk." + k)
+
+
 def test_mano_layer_forward_matches_reference_vectors(gpu_lib):
     from mhentropy_amd.ManoLayer import ManoLayer
     g = load_golden("mano")

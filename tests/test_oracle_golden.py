@@ -79,6 +79,10 @@ def test_mhent_oracle_matches_reference_vectors(tag):
         s = network_ref.sample(sd, tb, feat, torch.as_tensor(g["z0_sample"]), 4)
     for k in ("th_bt", "logs_t", "verts", "xyz", "uv"):
         assert_close(s[k], g["sample_" + k], 1e-6, what="sample." + k)
+    with torch.no_grad():
+        tk = network_ref.sample(sd, tb, feat, torch.as_tensor(g["z0_topk"]), 6, N_quant=3)
+    for k in ("th_bt", "logs_t", "verts", "xyz", "uv"):
+        assert_close(tk[k], g["topk_" + k], 1e-6, what="topk." + k)
     o = {"log_p": torch.as_tensor(g["loss_log_p"]), "xyz": torch.as_tensor(g["sample_xyz"]),
          "uv": torch.as_tensor(g["sample_uv"])}
     tot, _, met = criteria_ref.mhent_loss(o, y)
