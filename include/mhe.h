@@ -156,7 +156,8 @@ int mhe_elbo_reduce_f32(const float *log_p_rows, const float *log_q_rows,
 /* image encoder ------------------------------------------------------------
  * NHWC convolution as an implicit GEMM on MFMA, replacing the torchvision
  * ResNet trunk the reference builds (hand/network.py:54-61,110).
- *   x   [B,H,W,Cin]      w [Cout,KH,KW,Cin] (packed from torch's [Cout,Cin,KH,KW])
+ *   x   [B,H,W,Cin]      w [Cout,KH,KW,Cin] (packed from torch's [Cout,Cin,KH,KW], K zero-padded to the
+ *       128-byte stage; mhentropy_amd/resnet.py:pack_conv_weight)
  *   y   [B,Ho,Wo,Cout]
  *   in_scale/in_shift [Cin] (optional): the producer's BatchNorm folded to
  *       relu(x*scale+shift) applied while loading (padding stays zero)
