@@ -139,8 +139,11 @@ int mhe_mano_joints_f32(const float *th45, const float *det, const float *crop_u
  * (hand/manopth/manolayer.py:181-246, hand/network.py:480): verts [R,778,3]
  * normalised like xyz ((mesh - root)/bone), or with mm_mode != 0 the `mesh`
  * output of ManoLayer.forward (mm, centred on joint 9).  z [R,61] as written by
- * mhe_mano_joints_f32. */
-int mhe_mano_verts_f32(const float *z, const float *tables, float *verts, int R, int mm_mode, void *stream);
+ * mhe_mano_joints_f32.  Two launches (per-hypothesis pose pass, per-vertex skinning pass) that hand
+ * over through `workspace` (mhe_mano_verts_workspace_floats(R) floats, caller-owned). */
+size_t mhe_mano_verts_workspace_floats(int R);
+int mhe_mano_verts_f32(const float *z, const float *tables, float *verts, float *workspace, int R, int mm_mode,
+                       void *stream);
 
 /* ManoLayer.xyz_from_vertice (hand/ManoLayer.py:108-148) + RHD reorder (:54-56):
  * verts [R,778,3] -> joints [R,21,3] (the wrapper's 'joints' output, unused by MHEnt). */

@@ -256,95 +256,106 @@ __global__ __launch_bounds__(256) void mano_joints_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// Full mesh: HB hypotheses per block; the blend-shape tables are read once per
-// block and reused from registers across the HB hypotheses, so L2 traffic is
-// 1.5 MB / HB per hypothesis instead of 1.5 MB.
-template <int HB>
-__global__ __launch_bounds__(256) void mano_verts_kernel(const float *__restrict__ z_g, const float *__restrict__ tables,
-                                                         float *__restrict__ verts_o, int R, int mm_mode) {
+// Full mesh in two launches.
+//  (1) mano_pose_kernel: one wavefront per hypothesis runs joint_pass and leaves what skinning needs in a
+//      352-float workspace row: pose map (135), beta (10), the 16 skinning transforms (192), centre/root/bone (7).
+//  (2) mano_skin_kernel: one thread per vertex, HB hypotheses per workgroup.  Every per-hypothesis quantity
+//      is wave-uniform, so it is read with SCALAR loads and enters the FMAs as an SGPR operand; the blend-shape
+//      tables (vertex-fastest, coalesced) are fetched once per workgroup and reused from registers across
+//      the HB hypotheses (1.5 MB / HB of L2 traffic per hypothesis).  No LDS at all in this kernel: the first
+//      version kept the per-hypothesis values in LDS and was LDS-issue bound (1536 broadcast reads per vertex).
+constexpr int WS_PM = 0, WS_BT = 135, WS_GR = 145, WS_NRM = 337, WS_STRIDE = 352;
+
+__global__ __launch_bounds__(256) void mano_pose_kernel(const float *__restrict__ z_g, const float *__restrict__ tables,
+                                                        float *__restrict__ ws, int R) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *tb = smem;                               // joint section
-    float *scr = smem + JOINT_FLOATS;               // 4 wave scratches
-    float *pm = scr + 4 * SCRATCH;                  // [135][HB] pose map
-    float *bt = pm + 135 * HB;                      // [10][HB]
-    float *gr = bt + 10 * HB;                       // [16][12][HB]
-    float *nrm = gr + 192 * HB;                     // [8][HB]: center(3) root(3) bone
+    float *tb = smem;
     for (int i = threadIdx.x; i < JOINT_FLOATS / 4; i += 256)
         reinterpret_cast<float4 *>(tb)[i] = reinterpret_cast<const float4 *>(tables)[i];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float *sc = scr + wave * SCRATCH;
-    const int r0 = blockIdx.x * HB;
-    for (int h = wave; h < HB; h += 4) {
-        const int r = (r0 + h < R) ? r0 + h : R - 1;
+    float *sc = smem + JOINT_FLOATS + wave * SCRATCH;
+    for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
         const float *zr = z_g + (size_t)r * 61;
         const float th45 = lane < 45 ? zr[3 + lane] : 0.f;
         // det lane layout [th3 bt logs t] from z = [th3 th45 bt logs t]
         const float det = lane < 3 ? zr[lane] : (lane < 16 ? zr[45 + lane] : 0.f);
         const RowOut o = joint_pass(tb, sc, lane, th45, det);
+        float *w = ws + (size_t)r * WS_STRIDE;
         for (int k = lane; k < 135; k += 64) {
             const int e = k % 9;
-            pm[k * HB + h] = sc[S_ROT + 9 + k] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+            w[WS_PM + k] = sc[S_ROT + 9 + k] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
         }
-        if (lane < 10) bt[lane * HB + h] = zr[48 + lane];
-        for (int k = lane; k < 192; k += 64) gr[k * HB + h] = sc[S_GR + k];
-        if (lane < 3) { nrm[lane * HB + h] = o.center_c; nrm[(3 + lane) * HB + h] = o.root_c; }
-        if (lane == 0) nrm[6 * HB + h] = o.bone;
+        if (lane < 10) w[WS_BT + lane] = zr[48 + lane];
+        for (int k = lane; k < 192; k += 64) w[WS_GR + k] = sc[S_GR + k];
+        if (lane < 3) { w[WS_NRM + lane] = o.center_c; w[WS_NRM + 3 + lane] = o.root_c; }
+        if (lane == 0) w[WS_NRM + 6] = o.bone;
         wave_sync();
     }
-    __syncthreads();
+}
+
+template <int HB>
+__global__ __launch_bounds__(256) void mano_skin_kernel(const float *__restrict__ ws, const float *__restrict__ tables,
+                                                        float *__restrict__ verts_o, int R, int mm_mode) {
+    const int v = blockIdx.x * 256 + threadIdx.x;            // vertex (VP = 832 padded: 4 vertex groups, last partial)
+    const int r0 = blockIdx.y * HB;
+    const int vc = v < VP ? v : VP - 1;
     const float *Vt = tables + V_T, *Vsd = tables + V_SD, *Vpd = tables + V_PD, *Vw = tables + V_W;
-    for (int v = threadIdx.x; v < VP; v += 256) {
-        float acc[HB][3];
+    // wave-uniform row pointers (rows past R are clamped; their results are not stored)
+    const float *wrow[HB];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float t = Vt[c * VP + v];
+    for (int h = 0; h < HB; ++h) wrow[h] = ws + (size_t)(r0 + h < R ? r0 + h : R - 1) * WS_STRIDE;
+    float acc[HB][3];
 #pragma unroll
-            for (int h = 0; h < HB; ++h) acc[h][c] = t;
-        }
-        for (int k = 0; k < 10; ++k) {
-            const float s0 = Vsd[(k * 3 + 0) * VP + v], s1 = Vsd[(k * 3 + 1) * VP + v], s2 = Vsd[(k * 3 + 2) * VP + v];
+    for (int c = 0; c < 3; ++c) {
+        const float t = Vt[c * VP + vc];
 #pragma unroll
-            for (int h = 0; h < HB; ++h) {
-                const float bk = bt[k * HB + h];
-                acc[h][0] = fmaf(s0, bk, acc[h][0]); acc[h][1] = fmaf(s1, bk, acc[h][1]); acc[h][2] = fmaf(s2, bk, acc[h][2]);
-            }
-        }
-#pragma unroll 3
-        for (int k = 0; k < 135; ++k) {
-            const float p0 = Vpd[(k * 3 + 0) * VP + v], p1 = Vpd[(k * 3 + 1) * VP + v], p2 = Vpd[(k * 3 + 2) * VP + v];
-#pragma unroll
-            for (int h = 0; h < HB; ++h) {
-                const float m = pm[k * HB + h];
-                acc[h][0] = fmaf(p0, m, acc[h][0]); acc[h][1] = fmaf(p1, m, acc[h][1]); acc[h][2] = fmaf(p2, m, acc[h][2]);
-            }
-        }
-        float w[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) w[j] = Vw[j * VP + v];
+        for (int h = 0; h < HB; ++h) acc[h][c] = t;
+    }
+    // shape blend (manolayer.py:181-183) then pose-corrective blend (:187-188)
+#pragma unroll 2
+    for (int k = 0; k < 10; ++k) {
+        const float s0 = Vsd[(k * 3 + 0) * VP + vc], s1 = Vsd[(k * 3 + 1) * VP + vc], s2 = Vsd[(k * 3 + 2) * VP + vc];
 #pragma unroll
         for (int h = 0; h < HB; ++h) {
-            float T[12];
+            const float bk = wrow[h][WS_BT + k];
+            acc[h][0] = fmaf(s0, bk, acc[h][0]); acc[h][1] = fmaf(s1, bk, acc[h][1]); acc[h][2] = fmaf(s2, bk, acc[h][2]);
+        }
+    }
+#pragma unroll 5
+    for (int k = 0; k < 135; ++k) {
+        const float p0 = Vpd[(k * 3 + 0) * VP + vc], p1 = Vpd[(k * 3 + 1) * VP + vc], p2 = Vpd[(k * 3 + 2) * VP + vc];
 #pragma unroll
-            for (int e = 0; e < 12; ++e) T[e] = 0.f;
+        for (int h = 0; h < HB; ++h) {
+            const float m = wrow[h][WS_PM + k];
+            acc[h][0] = fmaf(p0, m, acc[h][0]); acc[h][1] = fmaf(p1, m, acc[h][1]); acc[h][2] = fmaf(p2, m, acc[h][2]);
+        }
+    }
+    float w[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
+    for (int j = 0; j < 16; ++j) w[j] = Vw[j * VP + vc];
 #pragma unroll
-                for (int e = 0; e < 12; ++e) T[e] = fmaf(gr[(j * 12 + e) * HB + h], w[j], T[e]);
-            const int r = r0 + h;
-            if (v < NV && r < R) {
-                const float bone = nrm[6 * HB + h];
+    for (int h = 0; h < HB; ++h) {
+        // T = sum_j w_j Gr_j ; v' = T [v;1]   (manolayer.py:236-246)
+        float T[12];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float vp = T[3 * c] * acc[h][0] + T[3 * c + 1] * acc[h][1] + T[3 * c + 2] * acc[h][2] + T[9 + c];
-                    const float mesh = (vp - nrm[c * HB + h]) * 1000.f;            // manolayer.py:262-273
-                    verts_o[((size_t)r * NV + v) * 3 + c] = mm_mode ? mesh : (mesh - nrm[(3 + c) * HB + h]) / bone;   // network.py:480
-                }
+        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+#pragma unroll
+            for (int e = 0; e < 12; ++e) T[e] = fmaf(wrow[h][WS_GR + j * 12 + e], w[j], T[e]);
+        const int r = r0 + h;
+        if (v < NV && r < R) {
+            const float bone = wrow[h][WS_NRM + 6];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float vp = T[3 * c] * acc[h][0] + T[3 * c + 1] * acc[h][1] + T[3 * c + 2] * acc[h][2] + T[9 + c];
+                const float mesh = (vp - wrow[h][WS_NRM + c]) * 1000.f;            // manolayer.py:262-273
+                verts_o[((size_t)r * NV + v) * 3 + c] = mm_mode ? mesh : (mesh - wrow[h][WS_NRM + 3 + c]) / bone;   // network.py:480
             }
         }
     }
 }
-
 
 // ManoLayer.xyz_from_vertice (hand/ManoLayer.py:141-148,108-139): 16 joints regressed
 // from the mesh + 5 tip vertices, FreiHand order, then the RHD reorder (:54-56).
@@ -412,14 +423,20 @@ extern "C" int mhe_mano_joints_f32(const float *th45, const float *det, const fl
     return check_launch("mano_joints_kernel");
 }
 
-extern "C" int mhe_mano_verts_f32(const float *z, const float *tables, float *verts, int R, int mm_mode, void *stream) {
-    MHE_REQUIRE(z && tables && verts, "mhe_mano_verts_f32: null pointer");
+extern "C" size_t mhe_mano_verts_workspace_floats(int R) { return R > 0 ? (size_t)R * mano::WS_STRIDE : 0; }
+
+extern "C" int mhe_mano_verts_f32(const float *z, const float *tables, float *verts, float *workspace, int R, int mm_mode,
+                                  void *stream) {
+    MHE_REQUIRE(z && tables && verts && workspace, "mhe_mano_verts_f32: null pointer");
     MHE_REQUIRE(R > 0, "mhe_mano_verts_f32: R=%d", R);
-    constexpr int HB = 8;
-    const size_t lds = (mano::JOINT_FLOATS + 4 * mano::SCRATCH + (135 + 10 + 192 + 8) * HB) * sizeof(float);
-    hipLaunchKernelGGL(mano::mano_verts_kernel<HB>, dim3((R + HB - 1) / HB), dim3(256), lds, (hipStream_t)stream, z,
-                       tables, verts, R, mm_mode);
-    return check_launch("mano_verts_kernel");
+    constexpr int HB = 16;
+    const size_t lds = (mano::JOINT_FLOATS + 4 * mano::SCRATCH) * sizeof(float);
+    const int pb = (R + 3) / 4 < 2048 ? (R + 3) / 4 : 2048;
+    hipLaunchKernelGGL(mano::mano_pose_kernel, dim3(pb), dim3(256), lds, (hipStream_t)stream, z, tables, workspace, R);
+    if (int rc = check_launch("mano_pose_kernel")) return rc;
+    hipLaunchKernelGGL(mano::mano_skin_kernel<HB>, dim3((mano::VP + 255) / 256, (R + HB - 1) / HB), dim3(256), 0,
+                       (hipStream_t)stream, workspace, tables, verts, R, mm_mode);
+    return check_launch("mano_skin_kernel");
 }
 
 extern "C" int mhe_mano_regress_joints_f32(const float *verts, const float *tables, float *joints, int R, void *stream) {

@@ -146,7 +146,8 @@ def mano_verts(z, tables, mm=False):
     R = z.shape[0]
     _chk(z, torch.float32, "mano_verts.z", (R, 61))
     verts = torch.empty(R, 778, 3, device=z.device, dtype=torch.float32)
-    check(_lib.lib().mhe_mano_verts_f32(_ptr(z), _ptr(tables), _ptr(verts), R, int(mm), _stream()), "mhe_mano_verts_f32")
+    ws = torch.empty(_lib.lib().mhe_mano_verts_workspace_floats(R), device=z.device, dtype=torch.float32)
+    check(_lib.lib().mhe_mano_verts_f32(_ptr(z), _ptr(tables), _ptr(verts), _ptr(ws), R, int(mm), _stream()), "mhe_mano_verts_f32")
     return verts
 
 
