@@ -88,11 +88,14 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
+                    help="default: the dtype BASELINE.json's configs name for the workload (c2: bf16; c0, c1: f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured HIP graph (1) or launch eagerly (0)")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
+    if args.dtype is None:
+        args.dtype = "bf16" if args.workload == "c2" else "f32"
 
     from mhentropy_amd import dist as mdist
     rank, local_rank, world, dist = mdist.init("nccl")

@@ -145,6 +145,18 @@ size_t mhe_mano_verts_workspace_floats(int R);
 int mhe_mano_verts_f32(const float *z, const float *tables, float *verts, float *workspace, int R, int mm_mode,
                        void *stream);
 
+/* ---- train step (hand/CrossModalHand.py:455-470: zero_grad; loss.backward(); clip; Adam) -------------
+ * The reference differentiates the path with autograd; here every stage has a hand-written reverse
+ * kernel.  Reverse of mhe_mano_joints_f32's log_p output: row r = n*B + b receives
+ * d loss / d log_p[r] = g_log_p[b] * row_weight (row_weight = 1/N for the mean over hypotheses,
+ * hand/network.py:793), and the kernel returns d/d th45 [R,45] and d/d det per ROW [R,16]
+ * (sum over n with mhe_sum_over_hypotheses_f32 to get the per-image det-head gradient). */
+int mhe_mano_joints_bwd_f32(const float *th45, const float *det, const float *crop_uv, const float *vis,
+                            const float *tables, const float *g_log_p, float *g_th45, float *g_det_rows,
+                            int R, int B, float laplace_b, float th45_alpha, float row_weight, void *stream);
+/* out[b][c] (+)= sum_n rows[(n*B + b)][c] : the adjoint of `.repeat(N,1)` (hand/network.py:734,747). */
+int mhe_sum_over_hypotheses_f32(const float *rows, float *out, int N, int B, int C, int accumulate, void *stream);
+
 /* ManoLayer.xyz_from_vertice (hand/ManoLayer.py:108-148) + RHD reorder (:54-56):
  * verts [R,778,3] -> joints [R,21,3] (the wrapper's 'joints' output, unused by MHEnt). */
 int mhe_mano_regress_joints_f32(const float *verts, const float *tables, float *joints, int R, void *stream);

@@ -32,6 +32,8 @@ SIGNATURES = {
     "mhe_mano_joints_f32": (_i, [_p] * 12 + [_i, _i, _f, _f, _i, _f, _p]),
     "mhe_mano_verts_workspace_floats": (_sz, [_i]),
     "mhe_mano_verts_f32": (_i, [_p, _p, _p, _p, _i, _i, _p]),
+    "mhe_mano_joints_bwd_f32": (_i, [_p] * 8 + [_i, _i, _f, _f, _f, _p]),
+    "mhe_sum_over_hypotheses_f32": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mhe_mano_regress_joints_f32": (_i, [_p, _p, _p, _i, _p]),
     "mhe_elbo_reduce_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
     "mhe_conv2d_nhwc": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -142,6 +142,31 @@ def mano_joints(th45, det, tables, crop_uv=None, vis=None, laplace_b=0.03, th45_
     return o
 
 
+def mano_joints_bwd(th45, det, tables, crop_uv, vis, g_log_p, N, laplace_b=0.03, th45_alpha=50.0):
+    """reverse of mano_joints' log_p: (d/d th45 [R,45], d/d det [B,16]) for d loss/d log_p[n*B+b] = g_log_p[b]/N"""
+    R, B = th45.shape[0], det.shape[0]
+    _chk(th45, torch.float32, "mano_bwd.th45", (R, 45)); _chk(det, torch.float32, "mano_bwd.det", (B, 16))
+    _chk(crop_uv, torch.float32, "mano_bwd.crop_uv", (B, 42)); _chk(vis, torch.float32, "mano_bwd.vis", (B, 21))
+    _chk(g_log_p, torch.float32, "mano_bwd.g_log_p", (B,))
+    g_th45 = torch.empty(R, 45, device=th45.device, dtype=torch.float32)
+    g_rows = torch.empty(R, 16, device=th45.device, dtype=torch.float32)
+    check(_lib.lib().mhe_mano_joints_bwd_f32(_ptr(th45), _ptr(det), _ptr(crop_uv), _ptr(vis), _ptr(tables), _ptr(g_log_p),
+                                             _ptr(g_th45), _ptr(g_rows), R, B, float(laplace_b), float(th45_alpha), 1.0 / N,
+                                             _stream()), "mhe_mano_joints_bwd_f32")
+    return g_th45, sum_over_hypotheses(g_rows, N, B)
+
+
+def sum_over_hypotheses(rows, N, B, out=None):
+    """out[b] (+)= sum_n rows[n*B + b]; accumulates when `out` is given"""
+    C = rows.shape[1]
+    _chk(rows, torch.float32, "sum_over_hypotheses.rows", (N * B, C))
+    acc = out is not None
+    if out is None:
+        out = torch.empty(B, C, device=rows.device, dtype=torch.float32)
+    check(_lib.lib().mhe_sum_over_hypotheses_f32(_ptr(rows), _ptr(out), N, B, C, int(acc), _stream()), "mhe_sum_over_hypotheses_f32")
+    return out
+
+
 def mano_verts(z, tables, mm=False):
     R = z.shape[0]
     _chk(z, torch.float32, "mano_verts.z", (R, 61))
