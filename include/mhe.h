@@ -145,18 +145,6 @@ size_t mhe_mano_verts_workspace_floats(int R);
 int mhe_mano_verts_f32(const float *z, const float *tables, float *verts, float *workspace, int R, int mm_mode,
                        void *stream);
 
-/* ---- train step (hand/CrossModalHand.py:455-470: zero_grad; loss.backward(); clip; Adam) -------------
- * The reference differentiates the path with autograd; here every stage has a hand-written reverse
- * kernel.  Reverse of mhe_mano_joints_f32's log_p output: row r = n*B + b receives
- * d loss / d log_p[r] = g_log_p[b] * row_weight (row_weight = 1/N for the mean over hypotheses,
- * hand/network.py:793), and the kernel returns d/d th45 [R,45] and d/d det per ROW [R,16]
- * (sum over n with mhe_sum_over_hypotheses_f32 to get the per-image det-head gradient). */
-int mhe_mano_joints_bwd_f32(const float *th45, const float *det, const float *crop_uv, const float *vis,
-                            const float *tables, const float *g_log_p, float *g_th45, float *g_det_rows,
-                            int R, int B, float laplace_b, float th45_alpha, float row_weight, void *stream);
-/* out[b][c] (+)= sum_n rows[(n*B + b)][c] : the adjoint of `.repeat(N,1)` (hand/network.py:734,747). */
-int mhe_sum_over_hypotheses_f32(const float *rows, float *out, int N, int B, int C, int accumulate, void *stream);
-
 /* ManoLayer.xyz_from_vertice (hand/ManoLayer.py:108-148) + RHD reorder (:54-56):
  * verts [R,778,3] -> joints [R,21,3] (the wrapper's 'joints' output, unused by MHEnt). */
 int mhe_mano_regress_joints_f32(const float *verts, const float *tables, float *joints, int R, void *stream);
@@ -255,6 +243,70 @@ int mhe_metrics_f32(const float *xyz, const float *uv, const float *pose3d, cons
  * rows_out [Q*B, D] sample-major.  rows [N*B, D] is the flow sample th45. */
 int mhe_topk_gather_f32(const float *score, const float *rows, int *idx_out, float *rows_out,
                         int N, int B, int Q, int D, void *stream);
+
+/* ---- train step (hand/CrossModalHand.py:455-470: zero_grad; loss.backward(); clip; Adam) -------------
+ * The reference differentiates the path with autograd; here every stage has a hand-written reverse
+ * kernel.  Reverse of mhe_mano_joints_f32's log_p output: row r = n*B + b receives
+ * d loss / d log_p[r] = g_log_p[b] * row_weight (row_weight = 1/N for the mean over hypotheses,
+ * hand/network.py:793), and the kernel returns d/d th45 [R,45] and d/d det per ROW [R,16]
+ * (sum over n with mhe_sum_over_hypotheses_f32 to get the per-image det-head gradient). */
+int mhe_mano_joints_bwd_f32(const float *th45, const float *det, const float *crop_uv, const float *vis,
+                            const float *tables, const float *g_log_p, float *g_th45, float *g_det_rows,
+                            int R, int B, float laplace_b, float th45_alpha, float row_weight, void *stream);
+/* out[b][c] (+)= sum_n rows[(n*B + b)][c] : the adjoint of `.repeat(N,1)` (hand/network.py:734,747). */
+int mhe_sum_over_hypotheses_f32(const float *rows, float *out, int N, int B, int C, int accumulate, void *stream);
+
+/* dW[Cout][KH*KW*Cin] += gy^T (*) x : weight gradient of mhe_conv2d_nhwc (x [B,H,W,Cin], gy [B,Ho,Wo,Cout]
+ * of d->dtype storage, dW f32 with row pitch ldw >= KH*KW*Cin, 0 = dense).  The caller zeroes dW; partial sums of the
+ * pixel-range split are added with f32 atomics.  With H = W = KH = KW = 1 it is the weight gradient of a dense
+ * layer, dW[N][K] += gy[R,N]^T x[R,K] (torch.nn.Linear layout).  Cin, Cout multiples of 4. */
+int mhe_conv_wgrad_nhwc(const mhe_conv_desc *d, const void *x, const void *gy, float *dw, int ldw, void *stream);
+/* out[c] += sum_r rows[r][c] (bias gradients; caller zeroes out). */
+int mhe_colsum_f32(const float *rows, float *out, long R, int C, void *stream);
+/* dst[i] = (idx[i] < 0 ? 0 : src[idx[i]]) + (idx2 != NULL && idx2[i] >= 0 ? src[idx2[i]] : 0) ; dst f32 or bf16.  Every weight re-layout of a train step (forward
+ * operand packs, transposed / tap-flipped operands of the data-gradient convolutions, un-packing of weight
+ * gradients into the flat gradient buffer) is one gather over an index table built once on the host. */
+int mhe_gather_f32(const float *src, const int *idx, const int *idx2, void *dst, size_t n, int dst_dtype, void *stream);
+
+/* Elementwise stages of the RealNVP reverse pass (hand/flows.py:97-122,210-217), f32, flow variable padded
+ * to 64 columns where it is a GEMM operand; see csrc/flow_bwd.hip for the formulas. */
+int mhe_flow_mask_pad_f32(const float *x, const float *mask, float *xp, long R, int dim, void *stream);
+int mhe_flow_cond_lrelu_f32(float *P, const float *cond, long cond_stride, long R, int B, int H, void *stream);
+int mhe_flow_lrelu_bwd_f32(float *G, const float *Hact, long n, void *stream);
+int mhe_flow_couple_bwd_f32(const float *x_out, const float *Os, const float *Ot, const float *mask,
+                            const float *g_out, const float *g_log_p, float q_weight, float *x_in, float *GOs,
+                            float *GOt, float *g_part, long R, int B, int dim, void *stream);
+int mhe_flow_couple_accum_f32(const float *g_part, const float *GXs, const float *GXt, const float *mask,
+                              float *g_in, long R, int dim, void *stream);
+
+/* Train-mode BatchNorm(+ReLU) reverse over NHWC activations of storage `dtype` (F.batch_norm backward):
+ *   g' = g [a > 0] (a = the unit's post-activation output, NULL = no ReLU);  xhat = (y - mean) invstd
+ *   reduce:   stats[shard][0][c] += sum g',  stats[shard][1][c] += sum g' xhat   (mhe_conv_stat_shards() shards, zeroed by caller)
+ *   finalize: dbeta, dgamma and coef [3,C] with  gy = coef0 g' + coef1 y + coef2  (= gamma invstd (g' - dbeta/M - xhat dgamma/M))
+ *   apply:    gy (and optionally g' itself, the identity branch's gradient of a residual block)
+ * mhe_bn_mean_invstd recovers mean / invstd [2,C] from the forward's statistic shards. */
+int mhe_bn_mean_invstd(const float *stats, float *mean_invstd, int C, float count, float eps, void *stream);
+int mhe_bn_bwd_reduce_nhwc(const void *g, const void *a, const void *y, const float *mean_invstd, float *stats,
+                           long P, int C, int dtype, void *stream);
+int mhe_bn_bwd_finalize(const float *stats, const float *gamma, const float *mean_invstd, float *dgamma,
+                        float *dbeta, float *coef, int C, float count, void *stream);
+int mhe_bn_bwd_apply_nhwc(const void *g, const void *a, const void *y, const float *coef, void *gy, void *g_masked,
+                          long P, int C, int dtype, void *stream);
+/* 3x3/s2/p1 max pool recording the winning tap (first maximum, as torch), and its reverse gather. */
+int mhe_maxpool3x3s2_idx_nhwc(const void *x, void *y, unsigned char *idx, int B, int H, int W, int C, int dtype, void *stream);
+int mhe_maxpool3x3s2_bwd_nhwc(const void *gy, const unsigned char *idx, void *gx, int B, int H, int W, int C, int dtype, void *stream);
+/* gx[b,p,c] = g[b,c] / HW. */
+int mhe_avgpool_bwd_nhwc(const float *g, void *gx, int B, int HW, int C, int dtype, void *stream);
+/* out[b,2i,2j,c] = g[b,i,j,c] (+ base), 0 (+ base) elsewhere; out is [B,H,W,C], g is [B,ceil(H/2),ceil(W/2),C]:
+ * data gradient of stride-2 sampling (zero-dilated operand of a 3x3 data-gradient conv, or 1x1 downsample). */
+int mhe_upsample2_nhwc(const void *g, const void *base, void *out, int B, int H, int W, int C, int dtype, void *stream);
+/* Optimizer tail (hand/CrossModalHand.py:201,463-470): out[0] += |g|^2; tick: step += 1, sqnorm = 0;
+ * adam: clip_grad_norm_(max_norm) (max_norm <= 0: none) folded into torch.optim.Adam's default update,
+ * g pre-multiplied by grad_scale (1/world after a sum all-reduce).  step/sqnorm live in device memory. */
+int mhe_sqnorm_f32(const float *g, size_t n, float *out, void *stream);
+int mhe_train_tick(int *step, float *sqnorm, void *stream);
+int mhe_adam_step_f32(float *p, const float *g, float *m, float *v, size_t n, const float *sqnorm, const int *step,
+                      float lr, float beta1, float beta2, float eps, float max_norm, float grad_scale, void *stream);
 
 #ifdef __cplusplus
 }

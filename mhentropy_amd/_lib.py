@@ -34,6 +34,25 @@ SIGNATURES = {
     "mhe_mano_verts_f32": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "mhe_mano_joints_bwd_f32": (_i, [_p] * 8 + [_i, _i, _f, _f, _f, _p]),
     "mhe_sum_over_hypotheses_f32": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "mhe_conv_wgrad_nhwc": (_i, [_p, _p, _p, _p, _i, _p]),
+    "mhe_colsum_f32": (_i, [_p, _p, _l, _i, _p]),
+    "mhe_gather_f32": (_i, [_p, _p, _p, _p, _sz, _i, _p]),
+    "mhe_flow_mask_pad_f32": (_i, [_p, _p, _p, _l, _i, _p]),
+    "mhe_flow_cond_lrelu_f32": (_i, [_p, _p, _l, _l, _i, _i, _p]),
+    "mhe_flow_lrelu_bwd_f32": (_i, [_p, _p, _l, _p]),
+    "mhe_flow_couple_bwd_f32": (_i, [_p] * 6 + [_f] + [_p] * 4 + [_l, _i, _i, _p]),
+    "mhe_flow_couple_accum_f32": (_i, [_p] * 5 + [_l, _i, _p]),
+    "mhe_bn_mean_invstd": (_i, [_p, _p, _i, _f, _f, _p]),
+    "mhe_bn_bwd_reduce_nhwc": (_i, [_p] * 5 + [_l, _i, _i, _p]),
+    "mhe_bn_bwd_finalize": (_i, [_p] * 6 + [_i, _f, _p]),
+    "mhe_bn_bwd_apply_nhwc": (_i, [_p] * 6 + [_l, _i, _i, _p]),
+    "mhe_maxpool3x3s2_idx_nhwc": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "mhe_maxpool3x3s2_bwd_nhwc": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "mhe_avgpool_bwd_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "mhe_upsample2_nhwc": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "mhe_sqnorm_f32": (_i, [_p, _sz, _p, _p]),
+    "mhe_train_tick": (_i, [_p, _p, _p]),
+    "mhe_adam_step_f32": (_i, [_p] * 4 + [_sz, _p, _p] + [_f] * 6 + [_p]),
     "mhe_mano_regress_joints_f32": (_i, [_p, _p, _p, _i, _p]),
     "mhe_elbo_reduce_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
     "mhe_conv2d_nhwc": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

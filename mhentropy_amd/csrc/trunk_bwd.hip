@@ -1,0 +1,412 @@
+// Reverse kernels of the ResNet trunk's non-convolution stages (train-mode BatchNorm + ReLU, max / average
+// pooling, stride-2 scatter) and the optimizer tail of the train step (gradient norm, clip + Adam).
+// Reference: torchvision ResNet differentiated by autograd in hand/CrossModalHand.py:455-470
+// (`total_loss.backward(); clip_grad_norm_(encoderRGB.parameters(), 1.); optimizer.step()` with
+// torch.optim.Adam defaults, :201).  Activations NHWC of storage type T (f32 or bf16), statistics f32/f64.
+//
+// All of these are HBM-bound elementwise / reduction passes; algorithmic bytes are the tensors they name.
+#include "common.h"
+
+namespace mhe { namespace tb {
+constexpr int NSH = 64;       // statistic shards, as the forward's (conv.hip)
+
+template <typename T> __device__ __forceinline__ void load4(const T *p, float *v);
+template <> __device__ __forceinline__ void load4<float>(const float *p, float *v) {
+    const float4 t = *reinterpret_cast<const float4 *>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void load4<u16>(const u16 *p, float *v) {
+    const uint2 t = *reinterpret_cast<const uint2 *>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void store4(T *p, const float *v);
+template <> __device__ __forceinline__ void store4<float>(float *p, const float *v) {
+    *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store4<u16>(u16 *p, const float *v) {
+    uint2 o;
+    o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+    o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+    *reinterpret_cast<uint2 *>(p) = o;
+}
+
+// Per-channel sums of g' = g [a > 0] and g' * xhat, xhat = (y - mean) invstd, over a slab of pixels per block.
+// Threads: (C/4 channel quads, capped at 256) x row lanes; LDS reduce over row lanes; one sharded atomic per value.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict__ g, const T *__restrict__ a,
+                                                            const T *__restrict__ y, const float *__restrict__ mean_invstd,
+                                                            float *__restrict__ stats, long P, int C, long rows_per_block) {
+    __shared__ float red[256 * 8];
+    const int Q = C / 4;
+    const int qpb = Q < 256 ? Q : 256;          // quads handled at once
+    const int rl_n = 256 / qpb;                  // row lanes
+    const int tid = threadIdx.x;
+    const int ql = tid % qpb, rl = tid / qpb;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = r0 + rows_per_block < P ? r0 + rows_per_block : P;
+    float *sh = stats + (size_t)(blockIdx.x % NSH) * 2 * C;
+    for (int q0 = 0; q0 < Q; q0 += qpb) {
+        const int q = q0 + ql;
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (rl < rl_n && q < Q) {
+            const int c = q * 4;
+            const float4 mu = *reinterpret_cast<const float4 *>(mean_invstd + c);
+            const float4 is = *reinterpret_cast<const float4 *>(mean_invstd + C + c);
+            const float m[4] = {mu.x, mu.y, mu.z, mu.w}, iv[4] = {is.x, is.y, is.z, is.w};
+            for (long r = r0 + rl; r < r1; r += rl_n) {
+                float gv[4], yv[4], av[4];
+                load4<T>(g + r * C + c, gv);
+                load4<T>(y + r * C + c, yv);
+                if (a) load4<T>(a + r * C + c, av);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float gg = (!a || av[k] > 0.f) ? gv[k] : 0.f;
+                    s1[k] += gg;
+                    s2[k] = fmaf(gg, (yv[k] - m[k]) * iv[k], s2[k]);
+                }
+            }
+        }
+        if (rl_n > 1) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { red[tid * 8 + k] = s1[k]; red[tid * 8 + 4 + k] = s2[k]; }
+            __syncthreads();
+            if (rl == 0) {
+                for (int o = 1; o < rl_n; ++o)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { s1[k] += red[(o * qpb + ql) * 8 + k]; s2[k] += red[(o * qpb + ql) * 8 + 4 + k]; }
+            }
+        }
+        if (rl == 0 && q < Q) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { atomicAdd(sh + q * 4 + k, s1[k]); atomicAdd(sh + C + q * 4 + k, s2[k]); }
+        }
+    }
+}
+
+// dbeta = sum g', dgamma = sum g' xhat; coefficients of gy = k2 g' + k1 y + k0 with
+//   gy = gamma invstd (g' - dbeta/M - xhat dgamma/M)       (F.batch_norm backward, training mode)
+__global__ void bn_bwd_finalize_kernel(const float *__restrict__ stats, const float *__restrict__ gamma,
+                                       const float *__restrict__ mean_invstd, float *__restrict__ dgamma,
+                                       float *__restrict__ dbeta, float *__restrict__ coef, int C, float count) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll 8
+    for (int sh = 0; sh < NSH; ++sh) {
+        s1 += (double)stats[((size_t)sh * 2) * C + c];
+        s2 += (double)stats[((size_t)sh * 2 + 1) * C + c];
+    }
+    const float db = (float)s1, dg = (float)s2;
+    dbeta[c] = db;
+    dgamma[c] = dg;
+    const float mean = mean_invstd[c], invstd = mean_invstd[C + c];
+    const float k2 = gamma[c] * invstd;
+    const float k1 = -k2 * invstd * dg / count;
+    coef[c] = k2;
+    coef[C + c] = k1;
+    coef[2 * C + c] = -k2 * db / count - k1 * mean;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__ g, const T *__restrict__ a,
+                                                           const T *__restrict__ y, const float *__restrict__ coef,
+                                                           T *__restrict__ gy, T *__restrict__ g_masked, size_t n4, int C) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const size_t e = i * 4;
+        const int c = (int)(e % C);
+        float gv[4], yv[4], av[4], o[4];
+        load4<T>(g + e, gv);
+        load4<T>(y + e, yv);
+        if (a) {
+            load4<T>(a + e, av);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gv[k] = av[k] > 0.f ? gv[k] : 0.f;
+        }
+        const float4 k2 = *reinterpret_cast<const float4 *>(coef + c), k1 = *reinterpret_cast<const float4 *>(coef + C + c),
+                     k0 = *reinterpret_cast<const float4 *>(coef + 2 * C + c);
+        o[0] = fmaf(k2.x, gv[0], fmaf(k1.x, yv[0], k0.x)); o[1] = fmaf(k2.y, gv[1], fmaf(k1.y, yv[1], k0.y));
+        o[2] = fmaf(k2.z, gv[2], fmaf(k1.z, yv[2], k0.z)); o[3] = fmaf(k2.w, gv[3], fmaf(k1.w, yv[3], k0.w));
+        store4<T>(gy + e, o);
+        if (g_masked) store4<T>(g_masked + e, gv);
+    }
+}
+
+// mean / invstd of the batch statistics the forward accumulated (same shards, same f64 combine as bn_finalize)
+__global__ void bn_mean_invstd_kernel(const float *__restrict__ stats, float *__restrict__ mean_invstd, int C, float count, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll 8
+    for (int sh = 0; sh < NSH; ++sh) {
+        s1 += (double)stats[((size_t)sh * 2) * C + c];
+        s2 += (double)stats[((size_t)sh * 2 + 1) * C + c];
+    }
+    const double dmean = s1 / (double)count;
+    const double dvar = fmax(s2 / (double)count - dmean * dmean, 0.0);
+    mean_invstd[c] = (float)dmean;
+    mean_invstd[C + c] = 1.f / sqrtf((float)dvar + eps);
+}
+
+// 3x3 stride-2 pad-1 max pool that also records which of the 9 taps won (first maximum in scan order, as
+// torch's max_pool2d does) so that the reverse pass is a gather
+template <typename T>
+__global__ void maxpool_idx_kernel(const T *__restrict__ x, T *__restrict__ y, unsigned char *__restrict__ idx, int B, int H,
+                                   int W, int C, int Ho, int Wo) {
+    const size_t n4 = (size_t)B * Ho * Wo * C / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * 4;
+        const int c = (int)(e % C);
+        size_t t = e / C;
+        const int wo = (int)(t % Wo); t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        float m[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+        unsigned am[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const int hi = 2 * ho - 1 + dh, wi = 2 * wo - 1 + dw;
+                if ((unsigned)hi >= (unsigned)H || (unsigned)wi >= (unsigned)W) continue;
+                float v[4];
+                load4<T>(x + (((size_t)b * H + hi) * W + wi) * C + c, v);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (v[k] > m[k]) { m[k] = v[k]; am[k] = dh * 3 + dw; }
+            }
+        store4<T>(y + e, m);
+        *reinterpret_cast<unsigned *>(idx + e) = am[0] | (am[1] << 8) | (am[2] << 16) | (am[3] << 24);
+    }
+}
+
+// gx[b,h,w,c] = sum over the (at most 4) windows containing (h,w) whose recorded winner is (h,w)
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T *__restrict__ gy, const unsigned char *__restrict__ idx, T *__restrict__ gx, int B,
+                                   int H, int W, int C, int Ho, int Wo) {
+    const size_t n4 = (size_t)B * H * W * C / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * 4;
+        const int c = (int)(e % C);
+        size_t t = e / C;
+        const int w = (int)(t % W); t /= W;
+        const int h = (int)(t % H);
+        const int b = (int)(t / H);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int ho = h / 2; ho <= (h + 1) / 2; ++ho) {
+            if (ho >= Ho) continue;
+            const int dh = h - (2 * ho - 1);
+            for (int wo = w / 2; wo <= (w + 1) / 2; ++wo) {
+                if (wo >= Wo) continue;
+                const unsigned tap = dh * 3 + (w - (2 * wo - 1));
+                const size_t o = (((size_t)b * Ho + ho) * Wo + wo) * C + c;
+                const unsigned am = *reinterpret_cast<const unsigned *>(idx + o);
+                float gv[4];
+                load4<T>(gy + o, gv);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (((am >> (8 * k)) & 0xffu) == tap) acc[k] += gv[k];
+            }
+        }
+        store4<T>(gx + e, acc);
+    }
+}
+
+// gx[b,p,c] = g[b,c] / HW  (global average pool)
+template <typename T>
+__global__ void avgpool_bwd_kernel(const float *__restrict__ g, T *__restrict__ gx, int HW, int C, size_t n4) {
+    const float inv = 1.f / (float)HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * 4;
+        const int c = (int)(e % C);
+        const size_t b = e / ((size_t)HW * C);
+        const float4 v = *reinterpret_cast<const float4 *>(g + b * C + c);
+        const float o[4] = {v.x * inv, v.y * inv, v.z * inv, v.w * inv};
+        store4<T>(gx + e, o);
+    }
+}
+
+// out[b, 2ho, 2wo, c] = g[b, ho, wo, c] (+ base), everything else 0 (+ base): the data gradient of a stride-2
+// sampling, either as the zero-dilated operand of a 3x3 data-gradient convolution or added to `base`
+template <typename T>
+__global__ void upsample2_kernel(const T *__restrict__ g, const T *__restrict__ base, T *__restrict__ out, int B, int H, int W,
+                                 int C, int Ho, int Wo) {
+    const size_t n4 = (size_t)B * H * W * C / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * 4;
+        const int c = (int)(e % C);
+        size_t t = e / C;
+        const int w = (int)(t % W); t /= W;
+        const int h = (int)(t % H);
+        const int b = (int)(t / H);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (base) load4<T>(base + e, v);
+        if (!(h & 1) && !(w & 1) && (h >> 1) < Ho && (w >> 1) < Wo) {
+            float gv[4];
+            load4<T>(g + (((size_t)b * Ho + (h >> 1)) * Wo + (w >> 1)) * C + c, gv);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += gv[k];
+        }
+        store4<T>(out + e, v);
+    }
+}
+
+// sum of squares of the flat gradient buffer -> out[0] (f32 atomics of per-block f64-free partials)
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float *__restrict__ g, size_t n, float *__restrict__ out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc = fmaf(g[i], g[i], acc);
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+// clip_grad_norm_(max_norm) folded into torch.optim.Adam's update (defaults: no weight decay, no amsgrad):
+//   coef = min(1, max_norm / (|g| + 1e-6));  g *= coef * grad_scale;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+//   p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// t is read from device memory (state[0], advanced by the caller's tick kernel) so a captured graph stays valid.
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                   float *__restrict__ v, size_t n, const float *__restrict__ sqnorm,
+                                                   const int *__restrict__ step, float lr, float b1, float b2, float eps,
+                                                   float max_norm, float grad_scale) {
+    const float t = (float)step[0];
+    const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));
+    float coef = grad_scale;
+    if (max_norm > 0.f) {
+        const float nrm = sqrtf(sqnorm[0]) * grad_scale;
+        const float cc = max_norm / (nrm + 1e-6f);
+        coef *= cc < 1.f ? cc : 1.f;
+    }
+    const float step_size = lr / bc1;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gg = g[i] * coef;
+        const float mm = b1 * m[i] + (1.f - b1) * gg;
+        const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+        m[i] = mm; v[i] = vv;
+        p[i] -= step_size * mm / (sqrtf(vv) / bc2s + eps);
+    }
+}
+
+__global__ void tick_kernel(int *step, float *sqnorm) { step[0] += 1; sqnorm[0] = 0.f; }
+}}  // namespace mhe::tb
+
+using namespace mhe;
+static inline unsigned ewg(size_t n) { size_t b = (n + 255) / 256; return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
+#define DISPATCH_T(dtype, KERNEL, grid, ...)                                                                           \
+    do {                                                                                                                \
+        if ((dtype) == MHE_F32) hipLaunchKernelGGL(KERNEL<float>, grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL(KERNEL<u16>, grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);                      \
+    } while (0)
+
+extern "C" int mhe_bn_mean_invstd(const float *stats, float *mean_invstd, int C, float count, float eps, void *stream) {
+    MHE_REQUIRE(stats && mean_invstd && C > 0 && count > 0.f, "mhe_bn_mean_invstd: bad arguments");
+    hipLaunchKernelGGL(tb::bn_mean_invstd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, mean_invstd, C, count, eps);
+    return check_launch("bn_mean_invstd_kernel");
+}
+
+extern "C" int mhe_bn_bwd_reduce_nhwc(const void *g, const void *a, const void *y, const float *mean_invstd, float *stats,
+                                      long P, int C, int dtype, void *stream) {
+    MHE_REQUIRE(g && y && mean_invstd && stats && P > 0 && C > 0 && C % 4 == 0, "mhe_bn_bwd_reduce_nhwc: bad arguments");
+    long blocks = P / 64;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    const long rpb = (P + blocks - 1) / blocks;
+    blocks = (P + rpb - 1) / rpb;
+    if (dtype == MHE_F32)
+        hipLaunchKernelGGL(tb::bn_bwd_reduce_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float *)g,
+                           (const float *)a, (const float *)y, mean_invstd, stats, P, C, rpb);
+    else
+        hipLaunchKernelGGL(tb::bn_bwd_reduce_kernel<u16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const u16 *)g,
+                           (const u16 *)a, (const u16 *)y, mean_invstd, stats, P, C, rpb);
+    return check_launch("bn_bwd_reduce_kernel");
+}
+
+extern "C" int mhe_bn_bwd_finalize(const float *stats, const float *gamma, const float *mean_invstd, float *dgamma,
+                                   float *dbeta, float *coef, int C, float count, void *stream) {
+    MHE_REQUIRE(stats && gamma && mean_invstd && dgamma && dbeta && coef && C > 0 && count > 0.f, "mhe_bn_bwd_finalize: bad arguments");
+    hipLaunchKernelGGL(tb::bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, gamma,
+                       mean_invstd, dgamma, dbeta, coef, C, count);
+    return check_launch("bn_bwd_finalize_kernel");
+}
+
+extern "C" int mhe_bn_bwd_apply_nhwc(const void *g, const void *a, const void *y, const float *coef, void *gy, void *g_masked,
+                                     long P, int C, int dtype, void *stream) {
+    MHE_REQUIRE(g && y && coef && gy && P > 0 && C > 0 && C % 4 == 0, "mhe_bn_bwd_apply_nhwc: bad arguments");
+    const size_t n4 = (size_t)P * C / 4;
+    if (dtype == MHE_F32)
+        hipLaunchKernelGGL(tb::bn_bwd_apply_kernel<float>, dim3(ewg(n4)), dim3(256), 0, (hipStream_t)stream, (const float *)g,
+                           (const float *)a, (const float *)y, coef, (float *)gy, (float *)g_masked, n4, C);
+    else
+        hipLaunchKernelGGL(tb::bn_bwd_apply_kernel<u16>, dim3(ewg(n4)), dim3(256), 0, (hipStream_t)stream, (const u16 *)g,
+                           (const u16 *)a, (const u16 *)y, coef, (u16 *)gy, (u16 *)g_masked, n4, C);
+    return check_launch("bn_bwd_apply_kernel");
+}
+
+extern "C" int mhe_maxpool3x3s2_idx_nhwc(const void *x, void *y, unsigned char *idx, int B, int H, int W, int C, int dtype, void *stream) {
+    MHE_REQUIRE(x && y && idx && B > 0 && H > 0 && W > 0 && C % 4 == 0, "mhe_maxpool3x3s2_idx_nhwc: bad arguments");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const size_t n4 = (size_t)B * Ho * Wo * C / 4;
+    if (dtype == MHE_F32)
+        hipLaunchKernelGGL(tb::maxpool_idx_kernel<float>, dim3(ewg(n4)), dim3(256), 0, (hipStream_t)stream, (const float *)x, (float *)y, idx, B, H, W, C, Ho, Wo);
+    else
+        hipLaunchKernelGGL(tb::maxpool_idx_kernel<u16>, dim3(ewg(n4)), dim3(256), 0, (hipStream_t)stream, (const u16 *)x, (u16 *)y, idx, B, H, W, C, Ho, Wo);
+    return check_launch("maxpool_idx_kernel");
+}
+
+extern "C" int mhe_maxpool3x3s2_bwd_nhwc(const void *gy, const unsigned char *idx, void *gx, int B, int H, int W, int C, int dtype, void *stream) {
+    MHE_REQUIRE(gy && idx && gx && B > 0 && H > 0 && W > 0 && C % 4 == 0, "mhe_maxpool3x3s2_bwd_nhwc: bad arguments");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const size_t n4 = (size_t)B * H * W * C / 4;
+    if (dtype == MHE_F32)
+        hipLaunchKernelGGL(tb::maxpool_bwd_kernel<float>, dim3(ewg(n4)), dim3(256), 0, (hipStream_t)stream, (const float *)gy, idx, (float *)gx, B, H, W, C, Ho, Wo);
+    else
+        hipLaunchKernelGGL(tb::maxpool_bwd_kernel<u16>, dim3(ewg(n4)), dim3(256), 0, (hipStream_t)stream, (const u16 *)gy, idx, (u16 *)gx, B, H, W, C, Ho, Wo);
+    return check_launch("maxpool_bwd_kernel");
+}
+
+extern "C" int mhe_avgpool_bwd_nhwc(const float *g, void *gx, int B, int HW, int C, int dtype, void *stream) {
+    MHE_REQUIRE(g && gx && B > 0 && HW > 0 && C > 0 && C % 4 == 0, "mhe_avgpool_bwd_nhwc: bad arguments");
+    const size_t n4 = (size_t)B * HW * C / 4;
+    if (dtype == MHE_F32)
+        hipLaunchKernelGGL(tb::avgpool_bwd_kernel<float>, dim3(ewg(n4)), dim3(256), 0, (hipStream_t)stream, g, (float *)gx, HW, C, n4);
+    else
+        hipLaunchKernelGGL(tb::avgpool_bwd_kernel<u16>, dim3(ewg(n4)), dim3(256), 0, (hipStream_t)stream, g, (u16 *)gx, HW, C, n4);
+    return check_launch("avgpool_bwd_kernel");
+}
+
+extern "C" int mhe_upsample2_nhwc(const void *g, const void *base, void *out, int B, int H, int W, int C, int dtype, void *stream) {
+    MHE_REQUIRE(g && out && B > 0 && H > 0 && W > 0 && C % 4 == 0, "mhe_upsample2_nhwc: bad arguments");
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const size_t n4 = (size_t)B * H * W * C / 4;
+    if (dtype == MHE_F32)
+        hipLaunchKernelGGL(tb::upsample2_kernel<float>, dim3(ewg(n4)), dim3(256), 0, (hipStream_t)stream, (const float *)g, (const float *)base, (float *)out, B, H, W, C, Ho, Wo);
+    else
+        hipLaunchKernelGGL(tb::upsample2_kernel<u16>, dim3(ewg(n4)), dim3(256), 0, (hipStream_t)stream, (const u16 *)g, (const u16 *)base, (u16 *)out, B, H, W, C, Ho, Wo);
+    return check_launch("upsample2_kernel");
+}
+
+extern "C" int mhe_sqnorm_f32(const float *g, size_t n, float *out, void *stream) {
+    MHE_REQUIRE(g && out && n > 0, "mhe_sqnorm_f32: bad arguments");
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(tb::sqnorm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
+    return check_launch("sqnorm_kernel");
+}
+
+extern "C" int mhe_train_tick(int *step, float *sqnorm, void *stream) {
+    MHE_REQUIRE(step && sqnorm, "mhe_train_tick: null pointer");
+    hipLaunchKernelGGL(tb::tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, sqnorm);
+    return check_launch("tick_kernel");
+}
+
+extern "C" int mhe_adam_step_f32(float *p, const float *g, float *m, float *v, size_t n, const float *sqnorm, const int *step,
+                                 float lr, float beta1, float beta2, float eps, float max_norm, float grad_scale, void *stream) {
+    MHE_REQUIRE(p && g && m && v && step && n > 0, "mhe_adam_step_f32: bad arguments");
+    MHE_REQUIRE(max_norm <= 0.f || sqnorm, "mhe_adam_step_f32: clipping needs the squared gradient norm");
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(tb::adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sqnorm, step, lr,
+                       beta1, beta2, eps, max_norm, grad_scale);
+    return check_launch("adam_kernel");
+}

@@ -1,0 +1,246 @@
+// Weight gradients: dW[co][kh][kw][ci] += sum_{b,ho,wo} gy[b,ho,wo,co] * x[b, ho*s+kh-p, wo*s+kw-p, ci]
+// for NHWC convolutions, and with H = W = KH = KW = 1 the weight gradient of a dense layer
+// (dW[N][K] += gy[R][N]^T x[R][K]).  Stands where autograd's conv/addmm backward runs in the
+// reference's train step (hand/CrossModalHand.py:455-470).
+//
+// GEMM view: M = Cout, N = KH*KW*Cin (tap-major, channel fastest = the forward's packed weight order),
+// reduction over pixels.  Both operands are read as they lie in HBM ([pixel][channel], channel
+// contiguous, 8/16-byte loads); a stage of BK = 16 pixels is staged in LDS as f32 [pixel][channel] rows,
+// which IS the [k][m] / [k][n] image v_mfma_f32_16x16x4_f32 wants (lane = 16*k + m reads one dword,
+// conflict-free with a 16-dword row pad).  f32 accumulate of f32 or bf16 operands; the pixel range is
+// split over gridDim.z and partial tiles are added to dW with f32 atomics (dW zeroed by the caller).
+// Roofline: MFMA f32 (157 TFLOP/s); algorithmic bytes per launch = |x| + |gy| + 4|dW|.
+#include "common.h"
+#include "../../include/mhe.h"
+
+namespace mhe { namespace wgrad {
+
+struct Params {
+    const void *x, *gy;
+    float *dw;
+    int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
+    int ldw;             // row pitch of dW (floats)
+    int N;               // KH*KW*Cin
+    long P;              // B*Ho*Wo
+    int chunk;           // pixels per gridDim.z slice (multiple of BK)
+};
+
+constexpr int BK = 16;
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+    static __device__ __forceinline__ v4f load(const float *p) { return *reinterpret_cast<const v4f *>(p); }
+};
+template <> struct Vec4<u16> {
+    static __device__ __forceinline__ v4f load(const u16 *p) {
+        const uint2 r = *reinterpret_cast<const uint2 *>(p);
+        v4f o;
+        o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xffff0000u);
+        o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xffff0000u);
+        return o;
+    }
+};
+
+// BM x BN output tile, 4 waves as 2 x 2, each wave (BM/2) x (BN/2) = TM x TN MFMA tiles of 16 x 16.
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void wgrad_kernel(const Params p) {
+    constexpr int LDA = BM + 16, LDB = BN + 16;
+    constexpr int TM = BM / 32, TN = BN / 32;
+    constexpr int A4 = BK * BM / 4 / 256, B4 = BK * BN / 4 / 256;       // vec4 loads per thread per stage
+    static_assert(A4 >= 1 && B4 >= 1, "tile too small for 256 threads");
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const long k_begin = (long)blockIdx.z * p.chunk;
+    const long k_end = k_begin + p.chunk < p.P ? k_begin + p.chunk : p.P;
+    const T *x = reinterpret_cast<const T *>(p.x), *gy = reinterpret_cast<const T *>(p.gy);
+
+    // per-thread fixed columns: A (gy) channel quad, B (x) column quad -> (tap, ci)
+    int a_m[A4], a_k[A4], b_k[B4], b_ci[B4], b_dh[B4], b_dw[B4];
+    bool a_ok[A4], b_ok[B4];
+#pragma unroll
+    for (int i = 0; i < A4; ++i) {
+        const int f = tid + 256 * i;
+        a_m[i] = (f % (BM / 4)) * 4; a_k[i] = f / (BM / 4);
+        a_ok[i] = m0 + a_m[i] < p.Cout;
+    }
+#pragma unroll
+    for (int i = 0; i < B4; ++i) {
+        const int f = tid + 256 * i;
+        const int n = n0 + (f % (BN / 4)) * 4;
+        b_k[i] = f / (BN / 4);
+        b_ok[i] = n < p.N;
+        const int tap = b_ok[i] ? n / p.Cin : 0;
+        b_ci[i] = b_ok[i] ? n % p.Cin : 0;
+        b_dh[i] = tap / p.KW - p.pad; b_dw[i] = tap % p.KW - p.pad;
+    }
+    v4f ra[A4], rb[B4];
+    auto fetch = [&](long k0) {
+#pragma unroll
+        for (int i = 0; i < A4; ++i) {
+            const long pix = k0 + a_k[i];
+            ra[i] = (a_ok[i] && pix < k_end) ? Vec4<T>::load(gy + pix * p.Cout + m0 + a_m[i]) : v4f{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < B4; ++i) {
+            const long pix = k0 + b_k[i];
+            v4f v = {0.f, 0.f, 0.f, 0.f};
+            if (b_ok[i] && pix < k_end) {
+                const int wo = (int)(pix % p.Wo);
+                const long t = pix / p.Wo;
+                const int ho = (int)(t % p.Ho), b = (int)(t / p.Ho);
+                const int hi = ho * p.stride + b_dh[i], wi = wo * p.stride + b_dw[i];
+                if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.W)
+                    v = Vec4<T>::load(x + (((long)b * p.H + hi) * p.W + wi) * p.Cin + b_ci[i]);
+            }
+            rb[i] = v;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A4; ++i) *reinterpret_cast<v4f *>(&As[buf][a_k[i] * LDA + a_m[i]]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B4; ++i) *reinterpret_cast<v4f *>(&Bs[buf][b_k[i] * LDB + (tid + 256 * i) % (BN / 4) * 4]) = rb[i];
+    };
+
+    v4f acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    const int fk = lane >> 4, fc = lane & 15;
+    int buf = 0;
+    if (k_begin < k_end) {
+        fetch(k_begin);
+        stash(0);
+    }
+    __syncthreads();
+    for (long k0 = k_begin; k0 < k_end; k0 += BK) {
+        const bool more = k0 + BK < k_end;
+        if (more) fetch(k0 + BK);
+        const float *a = As[buf] + wm * (BM / 2) + fc, *b = Bs[buf] + wn * (BN / 2) + fc;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4) {
+            float fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = a[(kk + fk) * LDA + 16 * i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = b[(kk + fk) * LDB + 16 * j];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // D: column = lane & 15, rows 4*(lane >> 4) + r
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / 2) + 16 * j + fc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * (BM / 2) + 16 * i + 4 * fk + r;
+                if (m < p.Cout && n < p.N) atomicAdd(p.dw + (size_t)m * p.ldw + n, acc[i][j][r]);
+            }
+        }
+}
+
+// out[c] += sum_r in[r][c]  (bias gradients); one block per 64-row slab x 256 columns
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ in, float *__restrict__ out, long R, int C,
+                                                     int rows_per_block) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+    float acc = 0.f;
+    for (long r = r0; r < r1; ++r) acc += in[r * C + c];
+    atomicAdd(out + c, acc);
+}
+
+// dst[i] = (idx[i] < 0 ? 0 : src[idx[i]]) + (idx2 && idx2[i] >= 0 ? src[idx2[i]] : 0)  (f32 source; f32 or bf16 destination): every weight re-layout of the
+// train step (forward packs, transposed / flipped dgrad operands, gradient un-packing) is one such gather
+// over a table built once on the host.
+template <typename TO>
+__global__ __launch_bounds__(256) void gather_kernel(const float *__restrict__ src, const int *__restrict__ idx,
+                                                     const int *__restrict__ idx2, TO *__restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int j = idx[i];
+        float v = j < 0 ? 0.f : src[j];
+        if (idx2) {
+            const int j2 = idx2[i];
+            if (j2 >= 0) v += src[j2];
+        }
+        if constexpr (sizeof(TO) == 4) dst[i] = v;
+        else dst[i] = f32_to_bf16(v);
+    }
+}
+}}  // namespace mhe::wgrad
+
+using namespace mhe;
+
+extern "C" int mhe_conv_wgrad_nhwc(const mhe_conv_desc *d, const void *x, const void *gy, float *dw, int ldw, void *stream) {
+    MHE_REQUIRE(d && x && gy && dw, "mhe_conv_wgrad_nhwc: null pointer");
+    MHE_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0,
+                "mhe_conv_wgrad_nhwc: bad geometry");
+    MHE_REQUIRE(d->Cin % 4 == 0 && d->Cout % 4 == 0, "mhe_conv_wgrad_nhwc: Cin=%d and Cout=%d must be multiples of 4", d->Cin, d->Cout);
+    MHE_REQUIRE(d->dtype == MHE_F32 || d->dtype == MHE_BF16, "mhe_conv_wgrad_nhwc: dtype=%d", d->dtype);
+    wgrad::Params p;
+    p.x = x; p.gy = gy; p.dw = dw;
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
+    p.stride = d->stride; p.pad = d->pad;
+    p.Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
+    p.Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+    MHE_REQUIRE(p.Ho > 0 && p.Wo > 0, "mhe_conv_wgrad_nhwc: empty output");
+    p.N = d->KH * d->KW * d->Cin;
+    p.ldw = ldw > 0 ? ldw : p.N;
+    MHE_REQUIRE(p.ldw >= p.N, "mhe_conv_wgrad_nhwc: ldw=%d < KH*KW*Cin=%d", ldw, p.N);
+    p.P = (long)d->B * p.Ho * p.Wo;
+    const bool small = d->Cout <= 64;
+    const int BM = small ? 64 : 128, BN = 128;
+    const int gx = (p.N + BN - 1) / BN, gyy = (d->Cout + BM - 1) / BM;
+    // split the pixel range so that the launch has ~2048 workgroups, at least 64 pixels each
+    long want = 2048 / ((long)gx * gyy);
+    if (want < 1) want = 1;
+    long chunk = (p.P + want - 1) / want;
+    if (chunk < 64) chunk = 64;
+    chunk = (chunk + wgrad::BK - 1) / wgrad::BK * wgrad::BK;
+    p.chunk = (int)chunk;
+    const int gz = (int)((p.P + chunk - 1) / chunk);
+    const dim3 grid(gx, gyy, gz), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == MHE_F32) {
+        if (small) hipLaunchKernelGGL((wgrad::wgrad_kernel<float, 64, 128>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((wgrad::wgrad_kernel<float, 128, 128>), grid, block, 0, s, p);
+    } else {
+        if (small) hipLaunchKernelGGL((wgrad::wgrad_kernel<u16, 64, 128>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((wgrad::wgrad_kernel<u16, 128, 128>), grid, block, 0, s, p);
+    }
+    return check_launch("wgrad_kernel");
+}
+
+extern "C" int mhe_colsum_f32(const float *rows, float *out, long R, int C, void *stream) {
+    MHE_REQUIRE(rows && out && R > 0 && C > 0, "mhe_colsum_f32: bad arguments");
+    const int rpb = 64;
+    hipLaunchKernelGGL(wgrad::colsum_kernel, dim3((C + 255) / 256, (unsigned)((R + rpb - 1) / rpb)), dim3(256), 0,
+                       (hipStream_t)stream, rows, out, R, C, rpb);
+    return check_launch("colsum_kernel");
+}
+
+extern "C" int mhe_gather_f32(const float *src, const int *idx, const int *idx2, void *dst, size_t n, int dst_dtype, void *stream) {
+    MHE_REQUIRE(src && idx && dst && n > 0, "mhe_gather_f32: bad arguments");
+    MHE_REQUIRE(dst_dtype == MHE_F32 || dst_dtype == MHE_BF16, "mhe_gather_f32: dst_dtype=%d", dst_dtype);
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (dst_dtype == MHE_F32)
+        hipLaunchKernelGGL(wgrad::gather_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, idx, idx2, (float *)dst, n);
+    else
+        hipLaunchKernelGGL(wgrad::gather_kernel<u16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, idx, idx2, (u16 *)dst, n);
+    return check_launch("gather_kernel");
+}

@@ -341,3 +341,166 @@ def nchw_to_nhwc(x, dtype=torch.float32):
     y = torch.empty(B, H, W, Cp, device=x.device, dtype=dtype)
     check(_lib.lib().mhe_nchw_to_nhwc(_ptr(x), _ptr(y), B, Cn, H, W, dtype_code(dtype), _stream()), "mhe_nchw_to_nhwc")
     return y
+
+
+# ---- train-step (reverse) kernels ---------------------------------------------------------------------
+def conv_wgrad(x, gy, KH, KW, stride, pad, dw, ldw=0):
+    """dw[Cout, KH*KW*Cin] (f32, pre-zeroed or accumulating) += gy^T (*) x ; x [B,H,W,Cin], gy [B,Ho,Wo,Cout]."""
+    B, H, W, Cin = x.shape
+    Cout = gy.shape[-1]
+    dt = x.dtype
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    _chk(x, dt, "wgrad.x"); _chk(gy, dt, "wgrad.gy", (B, Ho, Wo, Cout)); _chk(dw, torch.float32, "wgrad.dw")
+    if dw.numel() < (Cout - 1) * (ldw or KH * KW * Cin) + KH * KW * Cin:
+        raise ValueError(f"wgrad.dw: {dw.numel()} floats cannot hold [{Cout}, {KH * KW * Cin}] at pitch {ldw or KH * KW * Cin}")
+    d = ConvDesc(B, H, W, Cin, Cout, KH, KW, stride, pad, dtype_code(dt), 0, 0)
+    check(_lib.lib().mhe_conv_wgrad_nhwc(C.byref(d), _ptr(x), _ptr(gy), _ptr(dw), int(ldw), _stream()), "mhe_conv_wgrad_nhwc")
+    return dw
+
+
+def linear_wgrad(x, gy, dw):
+    """dw[N,K] += gy[R,N]^T x[R,K] (torch.nn.Linear weight layout), f32."""
+    R, K = x.shape
+    return conv_wgrad(x.view(R, 1, 1, K), gy.view(R, 1, 1, gy.shape[1]), 1, 1, 1, 0, dw)
+
+
+def colsum(rows, out):
+    """out[c] += sum_r rows[r][c]"""
+    R, Cc = rows.shape
+    _chk(rows, torch.float32, "colsum.rows"); _chk(out, torch.float32, "colsum.out", (Cc,))
+    check(_lib.lib().mhe_colsum_f32(_ptr(rows), _ptr(out), R, Cc, _stream()), "mhe_colsum_f32")
+    return out
+
+
+def gather(src, idx, dst, idx2=None):
+    """dst[i] = src[idx[i]] (+ src[idx2[i]]), negative index = 0 ; src f32 flat, idx int32, dst f32 or bf16 of idx.numel() elements"""
+    _chk(src, torch.float32, "gather.src"); _chk(idx, torch.int32, "gather.idx")
+    if idx2 is not None:
+        _chk(idx2, torch.int32, "gather.idx2", idx.shape)
+    if dst.numel() != idx.numel() or dst.dtype not in (torch.float32, torch.bfloat16) or not dst.is_contiguous():
+        raise ValueError("gather.dst: contiguous f32/bf16 tensor with idx.numel() elements expected")
+    check(_lib.lib().mhe_gather_f32(_ptr(src), _ptr(idx), _ptr(idx2), _ptr(dst), idx.numel(), dtype_code(dst.dtype), _stream()), "mhe_gather_f32")
+    return dst
+
+
+def flow_mask_pad(x, mask_row, out):
+    R, dim = x.shape
+    _chk(x, torch.float32, "mask_pad.x"); _chk(mask_row, torch.float32, "mask_pad.mask", (dim,)); _chk(out, torch.float32, "mask_pad.out", (R, 64))
+    check(_lib.lib().mhe_flow_mask_pad_f32(_ptr(x), _ptr(mask_row), _ptr(out), R, dim, _stream()), "mhe_flow_mask_pad_f32")
+    return out
+
+
+def flow_cond_lrelu(P, cond_slice, cond_stride, B):
+    """P[r] = leaky_relu(P[r] + cond_slice[(r % B) * cond_stride : +H]) in place; cond_slice = view starting at the net/layer's column"""
+    R, H = P.shape
+    _chk(P, torch.float32, "cond_lrelu.P")
+    check(_lib.lib().mhe_flow_cond_lrelu_f32(_ptr(P), cond_slice.data_ptr(), int(cond_stride), R, B, H, _stream()), "mhe_flow_cond_lrelu_f32")
+    return P
+
+
+def flow_lrelu_bwd(G, Hact):
+    _chk(G, torch.float32, "lrelu_bwd.G"); _chk(Hact, torch.float32, "lrelu_bwd.H", G.shape)
+    check(_lib.lib().mhe_flow_lrelu_bwd_f32(_ptr(G), _ptr(Hact), G.numel(), _stream()), "mhe_flow_lrelu_bwd_f32")
+    return G
+
+
+def flow_couple_bwd(x_out, Os, Ot, mask_row, g_out, g_log_p, q_weight, B, x_in, GOs, GOt, g_part):
+    R, dim = x_out.shape
+    for t, n, s in ((x_out, "x_out", (R, dim)), (Os, "Os", (R, 64)), (Ot, "Ot", (R, 64)), (g_out, "g_out", (R, dim)),
+                    (x_in, "x_in", (R, dim)), (GOs, "GOs", (R, 64)), (GOt, "GOt", (R, 64)), (g_part, "g_part", (R, dim))):
+        _chk(t, torch.float32, "couple_bwd." + n, s)
+    check(_lib.lib().mhe_flow_couple_bwd_f32(_ptr(x_out), _ptr(Os), _ptr(Ot), _ptr(mask_row), _ptr(g_out), _ptr(g_log_p),
+                                             float(q_weight), _ptr(x_in), _ptr(GOs), _ptr(GOt), _ptr(g_part), R, B, dim, _stream()),
+          "mhe_flow_couple_bwd_f32")
+
+
+def flow_couple_accum(g_part, GXs, GXt, mask_row, g_in):
+    R, dim = g_part.shape
+    check(_lib.lib().mhe_flow_couple_accum_f32(_ptr(g_part), _ptr(GXs), _ptr(GXt), _ptr(mask_row), _ptr(g_in), R, dim, _stream()),
+          "mhe_flow_couple_accum_f32")
+    return g_in
+
+
+def bn_mean_invstd(stats, count, eps=1e-5):
+    Cc = stats.shape[-1]
+    mi = torch.empty(2, Cc, device=stats.device, dtype=torch.float32)
+    check(_lib.lib().mhe_bn_mean_invstd(_ptr(stats), _ptr(mi), Cc, float(count), float(eps), _stream()), "mhe_bn_mean_invstd")
+    return mi
+
+
+def bn_backward(g, a, y, mean_invstd, gamma, stats, dgamma, dbeta, want_masked=False, out=None):
+    """train-mode BatchNorm(+ReLU) reverse: returns gy (and g [a>0] when want_masked); writes dgamma / dbeta."""
+    Cc = y.shape[-1]
+    P = y.numel() // Cc
+    dt = y.dtype
+    _chk(g, dt, "bn_bwd.g", y.shape); _chk(y, dt, "bn_bwd.y")
+    if a is not None:
+        _chk(a, dt, "bn_bwd.a", y.shape)
+    _chk(stats, torch.float32, "bn_bwd.stats", (stat_shards(), 2, Cc)); _chk(mean_invstd, torch.float32, "bn_bwd.mean_invstd", (2, Cc))
+    _chk(gamma, torch.float32, "bn_bwd.gamma", (Cc,)); _chk(dgamma, torch.float32, "bn_bwd.dgamma", (Cc,)); _chk(dbeta, torch.float32, "bn_bwd.dbeta", (Cc,))
+    L = _lib.lib()
+    check(L.mhe_bn_bwd_reduce_nhwc(_ptr(g), _ptr(a), _ptr(y), _ptr(mean_invstd), _ptr(stats), P, Cc, dtype_code(dt), _stream()), "mhe_bn_bwd_reduce_nhwc")
+    coef = torch.empty(3, Cc, device=y.device, dtype=torch.float32)
+    check(L.mhe_bn_bwd_finalize(_ptr(stats), _ptr(gamma), _ptr(mean_invstd), _ptr(dgamma), _ptr(dbeta), _ptr(coef), Cc, float(P), _stream()), "mhe_bn_bwd_finalize")
+    gy = out if out is not None else torch.empty_like(y)
+    gm = torch.empty_like(y) if want_masked else None
+    check(L.mhe_bn_bwd_apply_nhwc(_ptr(g), _ptr(a), _ptr(y), _ptr(coef), _ptr(gy), _ptr(gm), P, Cc, dtype_code(dt), _stream()), "mhe_bn_bwd_apply_nhwc")
+    return (gy, gm) if want_masked else gy
+
+
+def maxpool3x3s2_idx(x):
+    B, H, W, Cc = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(B, Ho, Wo, Cc, device=x.device, dtype=x.dtype)
+    idx = torch.empty(B, Ho, Wo, Cc, device=x.device, dtype=torch.uint8)
+    _chk(x, x.dtype, "maxpool_idx.x")
+    check(_lib.lib().mhe_maxpool3x3s2_idx_nhwc(_ptr(x), _ptr(y), _ptr(idx), B, H, W, Cc, dtype_code(x.dtype), _stream()), "mhe_maxpool3x3s2_idx_nhwc")
+    return y, idx
+
+
+def maxpool3x3s2_bwd(gy, idx, H, W):
+    B, Ho, Wo, Cc = gy.shape
+    _chk(gy, gy.dtype, "maxpool_bwd.gy"); _chk(idx, torch.uint8, "maxpool_bwd.idx", gy.shape)
+    gx = torch.empty(B, H, W, Cc, device=gy.device, dtype=gy.dtype)
+    check(_lib.lib().mhe_maxpool3x3s2_bwd_nhwc(_ptr(gy), _ptr(idx), _ptr(gx), B, H, W, Cc, dtype_code(gy.dtype), _stream()), "mhe_maxpool3x3s2_bwd_nhwc")
+    return gx
+
+
+def avgpool_bwd(g, HW, dtype):
+    B, Cc = g.shape
+    _chk(g, torch.float32, "avgpool_bwd.g")
+    gx = torch.empty(B, HW, Cc, device=g.device, dtype=dtype)
+    check(_lib.lib().mhe_avgpool_bwd_nhwc(_ptr(g), _ptr(gx), B, HW, Cc, dtype_code(dtype), _stream()), "mhe_avgpool_bwd_nhwc")
+    return gx
+
+
+def upsample2(g, H, W, base=None):
+    """out[b,2i,2j] = g[b,i,j] (+ base), zero (+ base) elsewhere; out [B,H,W,C]"""
+    B, Ho, Wo, Cc = g.shape
+    if (Ho, Wo) != ((H + 1) // 2, (W + 1) // 2):
+        raise ValueError(f"upsample2: g {tuple(g.shape)} does not match output {H}x{W}")
+    _chk(g, g.dtype, "upsample2.g")
+    if base is not None:
+        _chk(base, g.dtype, "upsample2.base", (B, H, W, Cc))
+    out = torch.empty(B, H, W, Cc, device=g.device, dtype=g.dtype)
+    check(_lib.lib().mhe_upsample2_nhwc(_ptr(g), _ptr(base), _ptr(out), B, H, W, Cc, dtype_code(g.dtype), _stream()), "mhe_upsample2_nhwc")
+    return out
+
+
+def sqnorm(g, out):
+    _chk(g, torch.float32, "sqnorm.g"); _chk(out, torch.float32, "sqnorm.out", (1,))
+    check(_lib.lib().mhe_sqnorm_f32(_ptr(g), g.numel(), _ptr(out), _stream()), "mhe_sqnorm_f32")
+    return out
+
+
+def train_tick(step, sq):
+    _chk(step, torch.int32, "tick.step", (1,)); _chk(sq, torch.float32, "tick.sqnorm", (1,))
+    check(_lib.lib().mhe_train_tick(_ptr(step), _ptr(sq), _stream()), "mhe_train_tick")
+
+
+def adam_step(p, g, m, v, sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, max_norm=1.0, grad_scale=1.0):
+    n = p.numel()
+    for t, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, torch.float32, "adam." + nm, (n,))
+    check(_lib.lib().mhe_adam_step_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, _ptr(sq), _ptr(step), float(lr), float(beta1), float(beta2),
+                                       float(eps), float(max_norm), float(grad_scale), _stream()), "mhe_adam_step_f32")

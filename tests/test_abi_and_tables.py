@@ -49,7 +49,7 @@ def _c_array(src, name):
 
 
 def test_index_tables_are_the_references():
-    src = open(os.path.join(ROOT, "mhentropy_amd", "csrc", "mano.hip")).read()
+    src = "".join(open(os.path.join(ROOT, "mhentropy_amd", "csrc", f)).read() for f in ("mano_joint_pass.h", "mano.hip"))
     assert _c_array(src, "kJointReorder") == list(mano_ref.JOINT_REORDER)
     assert _c_array(src, "kFreihand2Rhd") == list(mano_ref.FREIHAND2RHD)
     assert tuple(mano_pack.TIP_VERTS_RIGHT) == mano_ref.TIP_VERTS_RIGHT
