@@ -253,8 +253,10 @@ int mhe_topk_gather_f32(const float *score, const float *rows, int *idx_out, flo
 int mhe_mano_joints_bwd_f32(const float *th45, const float *det, const float *crop_uv, const float *vis,
                             const float *tables, const float *g_log_p, float *g_th45, float *g_det_rows,
                             int R, int B, float laplace_b, float th45_alpha, float row_weight, void *stream);
-/* out[b][c] (+)= sum_n rows[(n*B + b)][c] : the adjoint of `.repeat(N,1)` (hand/network.py:734,747). */
-int mhe_sum_over_hypotheses_f32(const float *rows, float *out, int N, int B, int C, int accumulate, void *stream);
+/* out[b*out_stride + c] (+)= sum_n rows[(n*B + b)][c] : the adjoint of `.repeat(N,1)` (hand/network.py:734,747);
+ * out_stride <= 0 means C (dense). */
+int mhe_sum_over_hypotheses_f32(const float *rows, float *out, int N, int B, int C, int accumulate, long out_stride,
+                                void *stream);
 
 /* dW[Cout][KH*KW*Cin] += gy^T (*) x : weight gradient of mhe_conv2d_nhwc (x [B,H,W,Cin], gy [B,Ho,Wo,Cout]
  * of d->dtype storage, dW f32 with row pitch ldw >= KH*KW*Cin, 0 = dense).  The caller zeroes dW; partial sums of the
@@ -272,7 +274,8 @@ int mhe_gather_f32(const float *src, const int *idx, const int *idx2, void *dst,
  * to 64 columns where it is a GEMM operand; see csrc/flow_bwd.hip for the formulas. */
 int mhe_flow_mask_pad_f32(const float *x, const float *mask, float *xp, long R, int dim, void *stream);
 int mhe_flow_cond_lrelu_f32(float *P, const float *cond, long cond_stride, long R, int B, int H, void *stream);
-int mhe_flow_lrelu_bwd_f32(float *G, const float *Hact, long n, void *stream);
+int mhe_flow_lrelu_bwd_f32(float *G, const float *Hact, long n, float slope, void *stream);
+int mhe_add_f32(const float *a, const float *b, float *out, long n, void *stream);
 int mhe_flow_couple_bwd_f32(const float *x_out, const float *Os, const float *Ot, const float *mask,
                             const float *g_out, const float *g_log_p, float q_weight, float *x_in, float *GOs,
                             float *GOt, float *g_part, long R, int B, int dim, void *stream);

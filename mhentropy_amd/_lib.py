@@ -33,13 +33,14 @@ SIGNATURES = {
     "mhe_mano_verts_workspace_floats": (_sz, [_i]),
     "mhe_mano_verts_f32": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "mhe_mano_joints_bwd_f32": (_i, [_p] * 8 + [_i, _i, _f, _f, _f, _p]),
-    "mhe_sum_over_hypotheses_f32": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "mhe_sum_over_hypotheses_f32": (_i, [_p, _p, _i, _i, _i, _i, _l, _p]),
     "mhe_conv_wgrad_nhwc": (_i, [_p, _p, _p, _p, _i, _p]),
     "mhe_colsum_f32": (_i, [_p, _p, _l, _i, _p]),
     "mhe_gather_f32": (_i, [_p, _p, _p, _p, _sz, _i, _p]),
     "mhe_flow_mask_pad_f32": (_i, [_p, _p, _p, _l, _i, _p]),
     "mhe_flow_cond_lrelu_f32": (_i, [_p, _p, _l, _l, _i, _i, _p]),
-    "mhe_flow_lrelu_bwd_f32": (_i, [_p, _p, _l, _p]),
+    "mhe_flow_lrelu_bwd_f32": (_i, [_p, _p, _l, _f, _p]),
+    "mhe_add_f32": (_i, [_p, _p, _p, _l, _p]),
     "mhe_flow_couple_bwd_f32": (_i, [_p] * 6 + [_f] + [_p] * 4 + [_l, _i, _i, _p]),
     "mhe_flow_couple_accum_f32": (_i, [_p] * 5 + [_l, _i, _p]),
     "mhe_bn_mean_invstd": (_i, [_p, _p, _i, _f, _f, _p]),

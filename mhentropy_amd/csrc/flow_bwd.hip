@@ -38,15 +38,19 @@ __global__ __launch_bounds__(256) void cond_lrelu_kernel(float *__restrict__ P, 
     }
 }
 
-// G[r][c] *= (H[r][c] > 0 ? 1 : 0.01)
-__global__ __launch_bounds__(256) void lrelu_bwd_kernel(float *__restrict__ G, const float *__restrict__ Hact, long n4) {
+// G[r][c] *= (H[r][c] > 0 ? 1 : slope)   (slope 0.01: leaky_relu of the coupling nets; 0: the det head's ReLU)
+__global__ __launch_bounds__(256) void lrelu_bwd_kernel(float *__restrict__ G, const float *__restrict__ Hact, long n4, float slope) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         v4f g = *reinterpret_cast<v4f *>(G + i * 4);
         const v4f h = *reinterpret_cast<const v4f *>(Hact + i * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) g[e] = h[e] > 0.f ? g[e] : 0.01f * g[e];
+        for (int e = 0; e < 4; ++e) g[e] = h[e] > 0.f ? g[e] : slope * g[e];
         *reinterpret_cast<v4f *>(G + i * 4) = g;
     }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = a[i] + b[i];
 }
 
 // One coupling, reverse: from its output x_out and the nets' raw outputs Os, Ot (bias included, 64-wide)
@@ -109,9 +113,15 @@ extern "C" int mhe_flow_cond_lrelu_f32(float *P, const float *cond, long cond_st
     return check_launch("cond_lrelu_kernel");
 }
 
-extern "C" int mhe_flow_lrelu_bwd_f32(float *G, const float *Hact, long n, void *stream) {
+extern "C" int mhe_add_f32(const float *a, const float *b, float *out, long n, void *stream) {
+    MHE_REQUIRE(a && b && out && n > 0, "mhe_add_f32: bad arguments");
+    hipLaunchKernelGGL(flowbwd::add_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    return check_launch("add_kernel");
+}
+
+extern "C" int mhe_flow_lrelu_bwd_f32(float *G, const float *Hact, long n, float slope, void *stream) {
     MHE_REQUIRE(G && Hact && n > 0 && n % 4 == 0, "mhe_flow_lrelu_bwd_f32: bad arguments");
-    hipLaunchKernelGGL(flowbwd::lrelu_bwd_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, G, Hact, n / 4);
+    hipLaunchKernelGGL(flowbwd::lrelu_bwd_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, G, Hact, n / 4, slope);
     return check_launch("lrelu_bwd_kernel");
 }
 

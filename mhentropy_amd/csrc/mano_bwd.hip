@@ -243,12 +243,13 @@ __global__ __launch_bounds__(256) void mano_joints_bwd_kernel(
 
 // out[b][c] = sum_n in[(n*B + b)][c]: per-image totals of per-hypothesis rows (det head and conditioning gradients)
 __global__ __launch_bounds__(256) void sum_over_hypotheses_kernel(const float *__restrict__ in, float *__restrict__ out,
-                                                                  int N, int B, int C, int accumulate) {
+                                                                  int N, int B, int C, int accumulate, long out_stride) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)B * C) return;
     float acc = 0.f;
     for (int n = 0; n < N; ++n) acc += in[(size_t)n * B * C + i];
-    out[i] = accumulate ? out[i] + acc : acc;
+    float *o = out + (i / C) * out_stride + i % C;
+    *o = accumulate ? *o + acc : acc;
 }
 }}  // namespace mhe::mano
 
@@ -267,10 +268,13 @@ extern "C" int mhe_mano_joints_bwd_f32(const float *th45, const float *det, cons
     return check_launch("mano_joints_bwd_kernel");
 }
 
-extern "C" int mhe_sum_over_hypotheses_f32(const float *rows, float *out, int N, int B, int C, int accumulate, void *stream) {
+extern "C" int mhe_sum_over_hypotheses_f32(const float *rows, float *out, int N, int B, int C, int accumulate, long out_stride,
+                                           void *stream) {
     MHE_REQUIRE(rows && out && N > 0 && B > 0 && C > 0, "mhe_sum_over_hypotheses_f32: bad arguments");
+    if (out_stride <= 0) out_stride = C;
+    MHE_REQUIRE(out_stride >= C, "mhe_sum_over_hypotheses_f32: out_stride=%ld < C=%d", out_stride, C);
     const size_t n = (size_t)B * C;
     hipLaunchKernelGGL(mano::sum_over_hypotheses_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       rows, out, N, B, C, accumulate);
+                       rows, out, N, B, C, accumulate, out_stride);
     return check_launch("sum_over_hypotheses_kernel");
 }

@@ -156,14 +156,14 @@ def mano_joints_bwd(th45, det, tables, crop_uv, vis, g_log_p, N, laplace_b=0.03,
     return g_th45, sum_over_hypotheses(g_rows, N, B)
 
 
-def sum_over_hypotheses(rows, N, B, out=None):
-    """out[b] (+)= sum_n rows[n*B + b]; accumulates when `out` is given"""
-    C = rows.shape[1]
-    _chk(rows, torch.float32, "sum_over_hypotheses.rows", (N * B, C))
-    acc = out is not None
+def sum_over_hypotheses(rows, N, B, out=None, accumulate=False, out_stride=0):
+    """out[b] (+)= sum_n rows[n*B + b]; `out` may be a view into a wider [B, out_stride] matrix"""
+    Cc = rows.shape[1]
+    _chk(rows, torch.float32, "sum_over_hypotheses.rows", (N * B, Cc))
     if out is None:
-        out = torch.empty(B, C, device=rows.device, dtype=torch.float32)
-    check(_lib.lib().mhe_sum_over_hypotheses_f32(_ptr(rows), _ptr(out), N, B, C, int(acc), _stream()), "mhe_sum_over_hypotheses_f32")
+        out = torch.empty(B, Cc, device=rows.device, dtype=torch.float32)
+    check(_lib.lib().mhe_sum_over_hypotheses_f32(_ptr(rows), C.c_void_p(out.data_ptr()), N, B, Cc, int(accumulate), int(out_stride), _stream()),
+          "mhe_sum_over_hypotheses_f32")
     return out
 
 
@@ -398,10 +398,17 @@ def flow_cond_lrelu(P, cond_slice, cond_stride, B):
     return P
 
 
-def flow_lrelu_bwd(G, Hact):
+def flow_lrelu_bwd(G, Hact, slope=0.01):
     _chk(G, torch.float32, "lrelu_bwd.G"); _chk(Hact, torch.float32, "lrelu_bwd.H", G.shape)
-    check(_lib.lib().mhe_flow_lrelu_bwd_f32(_ptr(G), _ptr(Hact), G.numel(), _stream()), "mhe_flow_lrelu_bwd_f32")
+    check(_lib.lib().mhe_flow_lrelu_bwd_f32(_ptr(G), _ptr(Hact), G.numel(), float(slope), _stream()), "mhe_flow_lrelu_bwd_f32")
     return G
+
+
+def add(a, b, out=None):
+    _chk(a, torch.float32, "add.a"); _chk(b, torch.float32, "add.b", a.shape)
+    out = a if out is None else out
+    check(_lib.lib().mhe_add_f32(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()), "mhe_add_f32")
+    return out
 
 
 def flow_couple_bwd(x_out, Os, Ot, mask_row, g_out, g_log_p, q_weight, B, x_in, GOs, GOt, g_part):

@@ -1,0 +1,519 @@
+"""The reference's train step on HIP kernels, with an explicit reverse pass.
+
+Reference (hand/CrossModalHand.py:455-470, optimizer :191-203):
+    output = model(image, target); total_loss, losses, metrics = criterion(output, target)
+    optimizer.zero_grad(); total_loss.backward()
+    clip_grad_norm_(encoderRGB.parameters(), 1.);  optimizer.step()        # torch.optim.Adam(lr)
+with total_loss = mean_b(-log_p[b]) (hand/criteria.py:55,173).
+
+There is no autograd graph here: `TrainStep` runs the forward of MHEnt.get_loss stage by stage keeping
+what the reverse pass needs (raw convolution outputs, post-activation tensors, BatchNorm batch
+statistics, the flow sample), then walks the stages backwards through hand-written reverse kernels:
+    loss -> MANO likelihood (mhe_mano_joints_bwd_f32) -> RealNVP couplings (re-evaluated layer by layer,
+    csrc/flow_bwd.hip + mhe_conv_wgrad_nhwc) -> conditioning / det-head / l1 dense layers -> ResNet trunk
+    (data gradients through the forward implicit-GEMM kernel on transposed, tap-flipped weights; weight
+    gradients through mhe_conv_wgrad_nhwc; train-mode BatchNorm reverse) -> clip + Adam (one fused pass).
+
+Memory plan (sized for 288 GB HBM): all parameters live in ONE flat f32 buffer (the nn.Parameters of the
+model are views into it, so state_dict / eval paths are unchanged), with flat gradient and Adam moment
+buffers of the same length - one RCCL all-reduce, one optimizer launch.  Every derived operand
+layout (packed forward weights, dgrad operands, padded/transposed dense weights) is refreshed once per step
+by a gather over an index table built once on the host; weight gradients land in a raw arena in whatever
+layout their kernel produces and one final gather maps them onto the flat gradient buffer.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops, resnet
+from .resnet import BN_EPS, BN_MOMENTUM
+
+
+def _ceil(a, b):
+    return (a + b - 1) // b * b
+
+
+def dgrad_operand_index(idx):
+    """index table of the data-gradient convolution's weight operand from the index tensor of a torch conv
+    weight [Cout,Cin,KH,KW]:  W'[ci][kh'][kw'][co] = W[co][ci][KH-1-kh'][KW-1-kw'], rows = Cin, k = (kh',kw',co)"""
+    Cout, Cin, KH, KW = idx.shape
+    return idx.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, KH * KW * Cout)
+
+
+def conv_dgrad(gy, w_dg, k, stride, pad, H, W, residual=None):
+    """gradient of a k x k / stride / pad convolution w.r.t. its [B,H,W,Cin] input (+ residual), through the
+    FORWARD implicit-GEMM kernel: stride 1 is a convolution of gy with the transposed, tap-flipped weights at
+    padding k-1-pad; a stride-2 3x3 runs the same on the zero-dilated gy; a stride-2 1x1 is computed on the
+    coarse grid and scattered to the even positions."""
+    if stride == 1:
+        return ops.conv2d_nhwc(gy, w_dg, k, k, 1, k - 1 - pad, residual=residual)
+    if stride != 2 or k not in (1, 3):
+        raise NotImplementedError(f"conv_dgrad: k={k} stride={stride}")
+    if k == 3:
+        return ops.conv2d_nhwc(ops.upsample2(gy, H, W), w_dg, 3, 3, 1, 1, residual=residual)
+    half = ops.conv2d_nhwc(gy, w_dg, 1, 1, 1, 0)
+    return ops.upsample2(half, H, W, base=residual)
+
+
+class _Unit:
+    """one convolution + BatchNorm of the trunk"""
+    def __init__(self, conv, bn, k, stride, pad):
+        self.conv, self.bn, self.k, self.stride, self.pad = conv, bn, k, stride, pad
+        self.cin, self.cout = conv.in_channels, conv.out_channels
+
+
+class TrainStep:
+    def __init__(self, model, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, dist=None):
+        self.model, self.lr, self.betas, self.eps, self.max_norm, self.dist = model, lr, betas, eps, max_norm, dist
+        self.world = dist.get_world_size() if dist is not None else 1
+        trunk = model.feat_extractor.res
+        self.trunk = trunk
+        self.T = trunk.compute_dtype
+        self.dev = next(model.parameters()).device
+        if self.dev.type != "cuda":
+            raise RuntimeError("TrainStep needs the model on a HIP device (there is no CPU path)")
+        self._flatten_params()
+        self._src_tabs = []        # (dst tensor, idx, idx2) gathers from the flat parameters, run once per step
+        self._raw_n = 0
+        self._unpack = torch.full((self.n_params,), -1, dtype=torch.int64)
+        self._build_trunk()
+        self._build_heads()
+        self._build_flow()
+        self.raw = torch.zeros(self._raw_n, device=self.dev, dtype=torch.float32)
+        for u in self._raw_views:
+            u()
+        self._unpack_idx = self._unpack.to(torch.int32).to(self.dev)
+        self._src_tabs = [(d, i.to(torch.int32).to(self.dev).contiguous(), None if j is None else j.to(torch.int32).to(self.dev).contiguous())
+                          for d, i, j in self._src_tabs]
+        self.step_t = torch.zeros(1, device=self.dev, dtype=torch.int32)
+        self.sq = torch.zeros(1, device=self.dev, dtype=torch.float32)
+        self._ws = {}
+        self.g_logp_scale = 1.0
+
+    # ------------------------------------------------------------------ parameter arena
+    def _flatten_params(self):
+        ps = list(self.model.parameters())
+        self.off, n = {}, 0
+        for p in ps:
+            self.off[id(p)] = n
+            n += _ceil(p.numel(), 4)            # 16-byte aligned segments
+        self.n_params = n
+        self.P = torch.zeros(n, device=self.dev, dtype=torch.float32)
+        for p in ps:
+            o = self.off[id(p)]
+            self.P[o:o + p.numel()].copy_(p.data.reshape(-1).float())
+            p.data = self.P[o:o + p.numel()].view(p.shape)
+        self.G = torch.zeros_like(self.P)
+        self.M = torch.zeros_like(self.P)
+        self.V = torch.zeros_like(self.P)
+
+    def _pidx(self, p):
+        """int64 index tensor shaped like p holding each element's position in the flat buffer"""
+        o = self.off[id(p)]
+        return torch.arange(o, o + p.numel(), dtype=torch.int64).view(p.shape)
+
+    def grad_of(self, p):
+        o = self.off[id(p)]
+        return self.G[o:o + p.numel()].view(p.shape)
+
+    def _derived(self, idx, dtype, idx2=None):
+        """a tensor refreshed every step as P[idx] (+ P[idx2]); idx int64 with -1 = 0"""
+        dst = torch.zeros(idx.shape, device=self.dev, dtype=dtype)
+        self._src_tabs.append((dst, idx.reshape(-1), None if idx2 is None else idx2.reshape(-1)))
+        return dst
+
+    def _raw_slot(self, shape):
+        """reserve a raw-gradient slot; returns (offset, getter) - the view exists once the arena is allocated"""
+        n = int(np.prod(shape))
+        o = self._raw_n
+        self._raw_n += _ceil(n, 4)
+        return o
+
+    def _raw(self, o, shape):
+        return self.raw[o:o + int(np.prod(shape))].view(shape)
+
+    def _map_grad(self, p, raw_index):
+        """raw_index: int64 tensor shaped like p giving the raw-arena position of each element's gradient"""
+        o = self.off[id(p)]
+        self._unpack[o:o + p.numel()] = raw_index.reshape(-1)
+
+    # ------------------------------------------------------------------ trunk tables
+    def _build_trunk(self):
+        t, T = self.trunk, self.T
+        bke = 32 if T == torch.float32 else 64
+        self._raw_views = []
+        self.units = []
+
+        def add(conv, bn, k, stride, pad, stem=False):
+            u = _Unit(conv, bn, k, stride, pad)
+            w = conv.weight
+            Cout, Cin, KH, KW = w.shape
+            idx = self._pidx(w)
+            if stem:
+                wp = torch.full((64, 8, 24), -1, dtype=torch.int64)
+                wp[:, :7, :21] = idx.permute(0, 2, 3, 1).reshape(64, 7, 21)
+                u.w_fwd = self._derived(wp.reshape(64, 192), T)
+                u.cin_w = 4 if T == torch.float32 else 8              # channel padding of the NHWC image copy
+            else:
+                kk = KH * KW * Cin
+                f = torch.full((Cout, _ceil(kk, bke)), -1, dtype=torch.int64)
+                f[:, :kk] = idx.permute(0, 2, 3, 1).reshape(Cout, kk)
+                u.w_fwd = self._derived(f, T)
+                # data-gradient operand: W'[ci][kh'][kw'][co] = W[co][ci][KH-1-kh'][KW-1-kw']
+                kd = KH * KW * Cout
+                d = torch.full((Cin, _ceil(kd, bke)), -1, dtype=torch.int64)
+                d[:, :kd] = dgrad_operand_index(idx)
+                u.w_dg = self._derived(d, T)
+                u.cin_w = Cin
+            # raw weight gradient [Cout][KH*KW*cin_w]
+            u.raw_w = self._raw_slot((Cout, KH * KW * u.cin_w))
+            r = torch.arange(Cout * KH * KW * u.cin_w, dtype=torch.int64).view(Cout, KH, KW, u.cin_w)[..., :Cin] + u.raw_w
+            self._map_grad(w, r.permute(0, 3, 1, 2))
+            u.raw_g = self._raw_slot((Cout,)); u.raw_b = self._raw_slot((Cout,))
+            self._map_grad(bn.weight, torch.arange(Cout) + u.raw_g)
+            self._map_grad(bn.bias, torch.arange(Cout) + u.raw_b)
+
+            def views(u=u, shape=(Cout, KH * KW * u.cin_w)):
+                u.dw = self._raw(u.raw_w, shape); u.dgamma = self._raw(u.raw_g, (u.cout,)); u.dbeta = self._raw(u.raw_b, (u.cout,))
+            self._raw_views.append(views)
+            self.units.append(u)
+            return u
+
+        self.stem = add(t.conv1, t.bn1, 7, 2, 3, stem=True)
+        self.blocks = []
+        for li in range(4):
+            for blk in getattr(t, f"layer{li + 1}"):
+                b = {"kind": blk.kind, "stride": blk.stride}
+                if blk.kind == "bottleneck":
+                    b["u"] = [add(blk.conv1, blk.bn1, 1, 1, 0), add(blk.conv2, blk.bn2, 3, blk.stride, 1), add(blk.conv3, blk.bn3, 1, 1, 0)]
+                else:
+                    b["u"] = [add(blk.conv1, blk.bn1, 3, blk.stride, 1), add(blk.conv2, blk.bn2, 3, 1, 1)]
+                b["ud"] = add(blk.downsample[0], blk.downsample[1], 1, blk.stride, 0) if blk.downsample is not None else None
+                self.blocks.append(b)
+
+    # ------------------------------------------------------------------ dense heads
+    def _dense(self, lin, n_pad=None, k_pad=None, want_T=True):
+        """tables of one nn.Linear: optional padded copy, transposed (padded) copy for the data gradient,
+        raw slots for dW [Npad, Kpad] and db [Npad]"""
+        N, K = lin.weight.shape
+        Np, Kp = n_pad or N, k_pad or K
+        wi = torch.full((Np, Kp), -1, dtype=torch.int64)
+        wi[:N, :K] = self._pidx(lin.weight)
+        d = {"N": N, "K": K, "Np": Np, "Kp": Kp}
+        d["w"] = lin.weight.data if (Np, Kp) == (N, K) else self._derived(wi, torch.float32)
+        bi = torch.full((Np,), -1, dtype=torch.int64)
+        bi[:N] = self._pidx(lin.bias)
+        d["b"] = lin.bias.data if Np == N else self._derived(bi, torch.float32)
+        if want_T:
+            d["wT"] = self._derived(wi.t().contiguous(), torch.float32)
+        d["raw_w"], d["raw_b"] = self._raw_slot((Np, Kp)), self._raw_slot((Np,))
+        self._map_grad(lin.weight, (torch.arange(Np * Kp, dtype=torch.int64).view(Np, Kp) + d["raw_w"])[:N, :K])
+        self._map_grad(lin.bias, torch.arange(N, dtype=torch.int64) + d["raw_b"])
+
+        def views(d=d):
+            d["dw"] = self._raw(d["raw_w"], (d["Np"], d["Kp"])); d["db"] = self._raw(d["raw_b"], (d["Np"],))
+        self._raw_views.append(views)
+        return d
+
+    def _build_heads(self):
+        m = self.model
+        self.l1 = self._dense(m.feat_extractor.l1[0])
+        self.d0 = self._dense(m.det_head[0])
+        self.d2 = self._dense(m.det_head[2], n_pad=32)            # 16 outputs padded to the GEMM's K granule for the data gradient
+        # feat_extractor.l2 is dead for MHEnt (hand/network.py:779): its gradient stays zero (-1 in the unpack table)
+
+    # ------------------------------------------------------------------ flow tables
+    def _flow_stream_table(self, flow, bf16):
+        """gather table of ONE net's fragment-ordered weight stream, as local indices into [W0 | W1 | W2]
+        (obtained by running the host packer on index-valued weights)"""
+        dim, h = flow.dim, flow.hidden
+        n0, n1, n2 = h * dim, h * h, dim * h
+        loc = np.arange(n0 + n1 + n2, dtype=np.int64)
+        parts = lambda a: (a[:n0].reshape(h, dim), a[n0:n0 + n1].reshape(h, h), a[n0 + n1:].reshape(dim, h))
+        if not bf16:
+            w = parts((loc + 1).astype(np.float32))               # < 2^24: exact in f32
+            return ops.flow_pack_net(*w).astype(np.int64) - 1
+        out, pad = None, None
+        for dig in range(3):                                        # base-128 digits (+1) are exact in bf16
+            w = parts((((loc >> (7 * dig)) & 127) + 1).astype(np.float32))
+            s = ops.flow_pack_net_bf16(*w)
+            v = (s.astype(np.uint32) << 16).view(np.float32).astype(np.int64)
+            if dig == 0:
+                pad, out = v == 0, np.zeros_like(v)
+            out += (np.maximum(v, 1) - 1) << (7 * dig)
+        out[pad] = -1
+        return out
+
+    def _build_flow(self):
+        fl = self.model.q_z_giv_i
+        self.flow = fl
+        dim, h, ncoup = fl.dim, fl.hidden, len(fl.mask)
+        bf16 = fl.compute_dtype == torch.bfloat16 and h % 128 == 0
+        self.flow_bf16 = bf16
+        loc = torch.from_numpy(self._flow_stream_table(fl, bf16))
+        n0, n1 = h * dim, h * h
+        streams, b2, wc, bc1, bc2, nets = [], [], [], [], [], []
+        self.fnets = []
+        for i in range(ncoup):
+            for net in (fl.s[i], fl.t[i]):
+                o0, o1, o2 = (self.off[id(net.l[j].weight)] for j in range(3))
+                g = torch.where(loc < 0, loc, torch.where(loc < n0, loc + o0, torch.where(loc < n0 + n1, loc - n0 + o1, loc - n0 - n1 + o2)))
+                streams.append(g)
+                bi = torch.full((64 if bf16 else dim,), -1, dtype=torch.int64)
+                bi[:dim] = self._pidx(net.l[2].bias)
+                b2.append(bi)
+                for j in range(2):
+                    wc.append(self._pidx(net.c[j].weight))
+                    bc1.append(self._pidx(net.c[j].bias)); bc2.append(self._pidx(net.l[j].bias))
+                d = {"net": net}
+                # reverse-pass operands (f32): padded W0 [h,64], W1 [h,h] (the parameter itself), padded W2 [64,h] + transposes
+                w0i = torch.full((h, 64), -1, dtype=torch.int64); w0i[:, :dim] = self._pidx(net.l[0].weight)
+                w2i = torch.full((64, h), -1, dtype=torch.int64); w2i[:dim] = self._pidx(net.l[2].weight)
+                b2i = torch.full((64,), -1, dtype=torch.int64); b2i[:dim] = self._pidx(net.l[2].bias)
+                d["w0"], d["w0T"] = self._derived(w0i, torch.float32), self._derived(w0i.t().contiguous(), torch.float32)
+                d["w1"], d["w1T"] = net.l[1].weight.data, self._derived(self._pidx(net.l[1].weight).t().contiguous(), torch.float32)
+                d["w2"], d["w2T"] = self._derived(w2i, torch.float32), self._derived(w2i.t().contiguous(), torch.float32)
+                d["b2"] = self._derived(b2i, torch.float32)
+                d["r0"], d["r1"], d["r2"], d["rb2"] = (self._raw_slot(s) for s in ((h, 64), (h, h), (64, h), (64,)))
+                self._map_grad(net.l[0].weight, (torch.arange(h * 64, dtype=torch.int64).view(h, 64) + d["r0"])[:, :dim])
+                self._map_grad(net.l[1].weight, torch.arange(h * h, dtype=torch.int64).view(h, h) + d["r1"])
+                self._map_grad(net.l[2].weight, (torch.arange(64 * h, dtype=torch.int64).view(64, h) + d["r2"])[:dim])
+                self._map_grad(net.l[2].bias, torch.arange(dim, dtype=torch.int64) + d["rb2"])
+                self.fnets.append(d)
+        self.f_stream = self._derived(torch.cat(streams), torch.bfloat16 if bf16 else torch.float32)
+        self.f_b2 = self._derived(torch.stack(b2), torch.float32)
+        self.f_wc = self._derived(torch.cat(wc), torch.float32)                       # [2*ncoup*2*h, 512]
+        self.f_bc = self._derived(torch.cat(bc1), torch.float32, torch.cat(bc2))       # c_j.bias + l_j.bias
+        self.f_wcT = self._derived(torch.cat(wc).t().contiguous(), torch.float32)     # [512, slots*h]
+        slots = 4 * ncoup
+        self.f_slots = slots
+        raw_wc, raw_bc = self._raw_slot((slots * h, fl.tsfm_on)), self._raw_slot((slots * h,))
+        k = 0
+        for i in range(ncoup):
+            for net in (fl.s[i], fl.t[i]):
+                for j in range(2):
+                    self._map_grad(net.c[j].weight, torch.arange(h * fl.tsfm_on, dtype=torch.int64).view(h, fl.tsfm_on) + raw_wc + k * h * fl.tsfm_on)
+                    bidx = torch.arange(h, dtype=torch.int64) + raw_bc + k * h
+                    self._map_grad(net.c[j].bias, bidx); self._map_grad(net.l[j].bias, bidx)
+                    k += 1
+
+        def views():
+            self.dwc = self._raw(raw_wc, (slots * h, fl.tsfm_on)); self.dbc = self._raw(raw_bc, (slots * h,))
+            for d in self.fnets:
+                d["dw0"], d["dw1"], d["dw2"], d["db2"] = (self._raw(d[k_], s) for k_, s in (("r0", (h, 64)), ("r1", (h, h)), ("r2", (64, h)), ("rb2", (64,))))
+        self._raw_views.append(views)
+
+    # ------------------------------------------------------------------ per-step plumbing
+    def repack(self):
+        for dst, idx, idx2 in self._src_tabs:
+            ops.gather(self.P, idx, dst.view(-1), idx2)
+
+    def _buf(self, name, shape, dtype=torch.float32):
+        key = (name, tuple(shape), dtype)
+        b = self._ws.get(key)
+        if b is None:
+            b = self._ws[key] = torch.empty(shape, device=self.dev, dtype=dtype)
+        return b
+
+    # ------------------------------------------------------------------ trunk forward / backward
+    def _unit_fwd(self, u, x, pool):
+        st = pool.take(u.cout)
+        y = ops.conv2d_nhwc(x, u.w_fwd, u.k, u.k, u.stride, u.pad, stats=st)
+        return self._bn_tape(u, x, y, st)
+
+    def _bn_tape(self, u, x, y, st):
+        count = y.numel() // u.cout
+        bn = u.bn
+        u.scale, u.shift = ops.bn_finalize(st, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, count, BN_MOMENTUM, BN_EPS)
+        u.mi = ops.bn_mean_invstd(st, count, BN_EPS)
+        u.x, u.y = x, y
+        self._bn_touched.append(bn.num_batches_tracked)
+        return y
+
+    def _trunk_forward(self, x):
+        T = self.T
+        pool = resnet._StatsPool(self.dev, channels=65536)
+        self._bn_touched = []
+        u = self.stem
+        self.x_nhwc = ops.nchw_to_nhwc(x, T)
+        st = pool.take(64)
+        y0 = ops.stem_conv7x7s2(x, u.w_fwd, T, stats=st)
+        self._bn_tape(u, self.x_nhwc, y0, st)
+        self.r0 = ops.bn_act(y0, u.scale, u.shift, relu=True)
+        a, self.pool_idx = ops.maxpool3x3s2_idx(self.r0)
+        for b in self.blocks:
+            b["a"] = a
+            us = b["u"]
+            h = a
+            b["acts"] = []
+            for u in us[:-1]:
+                y = self._unit_fwd(u, h, pool)
+                h = ops.bn_act(y, u.scale, u.shift, relu=True)
+                b["acts"].append(h)
+            ul = us[-1]
+            yl = self._unit_fwd(ul, h, pool)
+            if b["ud"] is not None:
+                ud = b["ud"]
+                yd = self._unit_fwd(ud, a, pool)
+                a = ops.bn_act(yl, ul.scale, ul.shift, yd, ud.scale, ud.shift, relu=True)
+            else:
+                a = ops.bn_act(yl, ul.scale, ul.shift, a, relu=True)
+            b["out"] = a
+        torch._foreach_add_(self._bn_touched, 1)
+        self.a_last = a
+        return ops.avgpool(a)
+
+    def _bn_bwd(self, u, g, a, pool, want_masked=False):
+        return ops.bn_backward(g, a, u.y, u.mi, u.bn.weight.data, pool.take(u.cout), u.dgamma, u.dbeta, want_masked=want_masked)
+
+    def _wgrad(self, u, gy):
+        ops.conv_wgrad(u.x, gy, u.k, u.k, u.stride, u.pad, u.dw)
+
+    def _dgrad(self, u, gy, residual=None):
+        """gradient w.r.t. the unit's input (+ residual)"""
+        return conv_dgrad(gy, u.w_dg, u.k, u.stride, u.pad, u.x.shape[1], u.x.shape[2], residual)
+
+    def _trunk_backward(self, g_f):
+        pool = resnet._StatsPool(self.dev, channels=65536)
+        B, Hh, Ww, Cc = self.a_last.shape
+        g = ops.avgpool_bwd(g_f, Hh * Ww, self.T).view(B, Hh, Ww, Cc)
+        for b in reversed(self.blocks):
+            us, ud = b["u"], b["ud"]
+            ul = us[-1]
+            if ud is not None:
+                gy = self._bn_bwd(ul, g, b["out"], pool)
+                gyd = self._bn_bwd(ud, g, b["out"], pool)
+                self._wgrad(ud, gyd)
+                skip = self._dgrad(ud, gyd)
+            else:
+                gy, skip = self._bn_bwd(ul, g, b["out"], pool, want_masked=True)
+            for j in range(len(us) - 1, 0, -1):
+                u = us[j]
+                self._wgrad(u, gy)
+                ga = self._dgrad(u, gy)
+                gy = self._bn_bwd(us[j - 1], ga, b["acts"][j - 1], pool)
+            self._wgrad(us[0], gy)
+            g = self._dgrad(us[0], gy, residual=skip)
+        u = self.stem
+        g_r0 = ops.maxpool3x3s2_bwd(g, self.pool_idx, self.r0.shape[1], self.r0.shape[2])
+        gy0 = self._bn_bwd(u, g_r0, self.r0, pool)
+        ops.conv_wgrad(self.x_nhwc, gy0, 7, 7, 2, 3, u.dw)
+
+    # ------------------------------------------------------------------ flow reverse
+    def _flow_backward(self, x_out, cond, g_x, g_logp, N, B):
+        fl = self.flow
+        h, dim, ncoup = fl.hidden, fl.dim, len(fl.mask)
+        R = x_out.shape[0]
+        cstride = self.f_slots * h
+        XP = self._buf("XP", (R, 64))
+        Hb = [[self._buf(f"H{n}{j}", (R, h)) for j in range(2)] for n in range(2)]
+        O = [self._buf(f"O{n}", (R, 64)) for n in range(2)]
+        GO = [self._buf(f"GO{n}", (R, 64)) for n in range(2)]
+        GX = [self._buf(f"GX{n}", (R, 64)) for n in range(2)]
+        G2, G1 = self._buf("G2", (R, h)), self._buf("G1", (R, h))
+        xa, xb = self._buf("xa", (R, dim)), self._buf("xb", (R, dim))
+        ga, gb = self._buf("ga", (R, dim)), self._buf("gb", (R, dim))
+        gpart = self._buf("gpart", (R, dim))
+        Gc = self._buf("Gcond", (B, cstride))                     # gradient of the conditioning table, all nets / layers
+        cflat = cond.view(B, cstride)
+        x_cur, g_cur = x_out, g_x
+        for i in range(ncoup - 1, -1, -1):
+            m = fl.mask[i]
+            ops.flow_mask_pad(x_cur, m, XP)
+            for n in range(2):
+                d, slot = self.fnets[2 * i + n], (2 * i + n) * 2
+                ops.linear(XP, d["w0"], out=Hb[n][0])
+                ops.flow_cond_lrelu(Hb[n][0], cflat[:, slot * h:], cstride, B)
+                ops.linear(Hb[n][0], d["w1"], out=Hb[n][1])
+                ops.flow_cond_lrelu(Hb[n][1], cflat[:, (slot + 1) * h:], cstride, B)
+                ops.linear(Hb[n][1], d["w2"], d["b2"], out=O[n])
+            x_in, g_in = (xa, ga) if x_cur is not xa else (xb, gb)
+            ops.flow_couple_bwd(x_cur, O[0], O[1], m, g_cur, g_logp, -1.0 / N if g_logp is not None else 0.0, B, x_in, GO[0], GO[1], gpart)
+            for n in range(2):
+                d, slot = self.fnets[2 * i + n], (2 * i + n) * 2
+                ops.linear_wgrad(Hb[n][1], GO[n], d["dw2"]); ops.colsum(GO[n], d["db2"])
+                ops.linear(GO[n], d["w2T"], out=G2); ops.flow_lrelu_bwd(G2, Hb[n][1])
+                ops.linear_wgrad(Hb[n][0], G2, d["dw1"])
+                ops.sum_over_hypotheses(G2, N, B, out=Gc[:, (slot + 1) * h:], out_stride=Gc.shape[1])
+                ops.linear(G2, d["w1T"], out=G1); ops.flow_lrelu_bwd(G1, Hb[n][0])
+                ops.linear_wgrad(XP, G1, d["dw0"])
+                ops.sum_over_hypotheses(G1, N, B, out=Gc[:, slot * h:], out_stride=Gc.shape[1])
+                ops.linear(G1, d["w0T"], out=GX[n])
+            ops.flow_couple_accum(gpart, GX[0], GX[1], m, g_in)
+            x_cur, g_cur = x_in, g_in
+        self.z0_recovered = x_cur
+        return Gc
+
+    # ------------------------------------------------------------------ the step
+    def forward_backward(self, x, y, noise=None, N=None):
+        """forward of MHEnt.get_loss + full reverse pass; fills self.G.  Returns the get_loss dict + 'total'."""
+        m = self.model
+        N = N or m.loss_N
+        B = x.shape[0]
+        self.repack()
+        self.raw.zero_()
+        # ---- forward (hand/network.py:760-831)
+        f = self._trunk_forward(x.contiguous())
+        feat = ops.linear(f, self.l1["w"], self.l1["b"])
+        hd = ops.linear(feat, self.d0["w"], self.d0["b"], relu=True)
+        det = ops.linear(hd, self.d2["w"], self.d2["b"])[:, :16].contiguous()
+        fl = self.flow
+        h, ncoup = fl.hidden, len(fl.mask)
+        cond = ops.linear(feat, self.f_wc, self.f_bc).view(B, 2 * ncoup, 2, h)
+        z0 = m._noise(N * B, 1.0, noise, self.dev)
+        th45, _, log_q = ops.flow_couplings(z0, cond, self.f_stream, self.f_b2, fl.mask, B, h, ops.FLOW_FORWARD)
+        blob = m.mano_dec.table_blob()
+        cu, vis = y["crop_uv"].contiguous(), y["vis"].contiguous()
+        o = ops.mano_joints(th45, det, blob, cu, vis, m.b_2d, m.th45_ref_alpha, want=("log_p", "norms"))
+        q_log_p, hq, log_p = ops.elbo_reduce(o["log_p"], log_q if m.entropy else None, N, B)
+        out = {"th_norm": o["norms"][:, 0], "bt_norm": o["norms"][:, 1], "q_log_p_z_giv_y": q_log_p,
+               "log_p": log_p if m.entropy else q_log_p}
+        if m.entropy:
+            out["h_q_z_giv_i"] = hq
+        # ---- reverse: total = mean_b(-log_p[b])  (hand/criteria.py:55,173)
+        g_logp = self._buf("g_logp", (B,))
+        g_logp.fill_(-1.0 / B)
+        g45, gdet_rows = self._mano_bwd(th45, det, blob, cu, vis, g_logp, N)
+        Gc = self._flow_backward(th45, cond, g45, g_logp if m.entropy else None, N, B)
+        # det head: gdet [B,16] -> padded [B,32]
+        gdet = self._buf("gdet", (B, 32)); gdet.zero_()
+        ops.sum_over_hypotheses(gdet_rows, N, B, out=gdet, out_stride=32)
+        ops.linear_wgrad(hd, gdet, self.d2["dw"]); ops.colsum(gdet, self.d2["db"])
+        ghd = ops.linear(gdet, self.d2["wT"]); ops.flow_lrelu_bwd(ghd, hd, slope=0.0)
+        ops.linear_wgrad(feat, ghd, self.d0["dw"]); ops.colsum(ghd, self.d0["db"])
+        # conditioning projections of all nets in one pass
+        ops.linear_wgrad(feat, Gc, self.dwc); ops.colsum(Gc, self.dbc)
+        g_feat = ops.linear(Gc, self.f_wcT)
+        ops.add(g_feat, ops.linear(ghd, self.d0["wT"]))
+        ops.linear_wgrad(f, g_feat, self.l1["dw"]); ops.colsum(g_feat, self.l1["db"])
+        g_f = ops.linear(g_feat, self.l1["wT"])
+        self._trunk_backward(g_f)
+        ops.gather(self.raw, self._unpack_idx, self.G)
+        out["total"] = -log_p.mean() if m.entropy else -q_log_p.mean()
+        self.tape = {"feat": feat, "det": det, "th45": th45, "g_feat": g_feat, "g_th45": g45}
+        return out
+
+    def _mano_bwd(self, th45, det, blob, cu, vis, g_logp, N):
+        R, B = th45.shape[0], det.shape[0]
+        g45 = self._buf("g45", (R, 45)); rows = self._buf("gdet_rows", (R, 16))
+        from . import _lib
+        ops.check(_lib.lib().mhe_mano_joints_bwd_f32(ops._ptr(th45), ops._ptr(det), ops._ptr(cu), ops._ptr(vis), ops._ptr(blob), ops._ptr(g_logp),
+                                                     ops._ptr(g45), ops._ptr(rows), R, B, float(self.model.b_2d), float(self.model.th45_ref_alpha),
+                                                     1.0 / N, ops._stream()), "mhe_mano_joints_bwd_f32")
+        return g45, rows
+
+    def optimizer_step(self):
+        """all-reduce (sum) over ranks, clip_grad_norm_(max_norm) and Adam in one fused pass"""
+        if self.dist is not None and self.world > 1:
+            self.dist.all_reduce(self.G)
+        ops.train_tick(self.step_t, self.sq)
+        if self.max_norm and self.max_norm > 0:
+            ops.sqnorm(self.G, self.sq)
+        ops.adam_step(self.P, self.G, self.M, self.V, self.sq, self.step_t, self.lr, self.betas[0], self.betas[1], self.eps,
+                      self.max_norm or 0.0, 1.0 / self.world)
+
+    def step(self, x, y, noise=None, N=None):
+        out = self.forward_backward(x, y, noise=noise, N=N)
+        self.optimizer_step()
+        return out
