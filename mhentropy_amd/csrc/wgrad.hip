@@ -12,6 +12,7 @@
 // Roofline: MFMA f32 (157 TFLOP/s); algorithmic bytes per launch = |x| + |gy| + 4|dW|.
 #include "common.h"
 #include "../../include/mhe.h"
+#include <cstdlib>
 
 namespace mhe { namespace wgrad {
 
@@ -152,6 +153,131 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const Params p) {
         }
 }
 
+// ---------------------------------------------------------------------------
+// bf16 operands on v_mfma_f32_32x32x16_bf16.  The reduction index (pixels) is the ROW index of both operands
+// as they lie in HBM, while the MFMA wants 8 consecutive k per lane: the stage is stored in LDS exactly as
+// loaded ([pixel][channel] bf16 rows, 16-byte chunks) and read back with the gfx950 transposing LDS read
+// ds_read_b64_tr_b16 (a 4-pixel x 16-channel block per 16-lane group, delivered channel-major), two reads per
+// operand fragment.  Row pitch = tile bytes + 64: the four 64-byte row segments a 32-lane half touches land in
+// four different 64-byte bank groups (pitch = 64 or 192 mod 256) -> conflict-free transposed reads.
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
+typedef __attribute__((address_space(3))) v4s lds_v4s;
+
+template <int BM, int BN, int WM, int WN>      // WM x WN waves, wave tile (BM/WM) x (BN/WN) of 32x32 MFMA tiles
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const Params p) {
+    constexpr int BKB = 32;                                   // pixels per stage
+    constexpr int LDA = BM * 2 + 64, LDB = BN * 2 + 64;       // row pitch in bytes
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int CA = BM / 8, CB = BN / 8;                   // 16-byte chunks per row
+    constexpr int A4 = BKB * CA / 256, B4 = BKB * CB / 256;
+    static_assert(WM * WN == 4 && A4 >= 1 && B4 >= 1 && 256 % CA == 0 && 256 % CB == 0, "tile");
+    static_assert((LDA % 256 == 64 || LDA % 256 == 192) && (LDB % 256 == 64 || LDB % 256 == 192), "pitch");
+    __shared__ __attribute__((aligned(16))) char As[2][BKB * LDA];
+    __shared__ __attribute__((aligned(16))) char Bs[2][BKB * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const long k_begin = (long)blockIdx.z * p.chunk;
+    const long k_end = k_begin + p.chunk < p.P ? k_begin + p.chunk : p.P;
+    const u16 *x = reinterpret_cast<const u16 *>(p.x), *gy = reinterpret_cast<const u16 *>(p.gy);
+
+    const int a_c = (tid % CA) * 8, a_r = tid / CA;            // this thread's chunk column / first row (rows step 256/CA)
+    const int b_c = (tid % CB) * 8, b_r = tid / CB;
+    const bool a_ok = m0 + a_c < p.Cout;
+    const int nb = n0 + b_c;
+    const bool b_ok = nb < p.N;
+    const int tap = b_ok ? nb / p.Cin : 0, b_ci = b_ok ? nb % p.Cin : 0;
+    const int b_dh = tap / p.KW - p.pad, b_dw = tap % p.KW - p.pad;
+    uint4 ra[A4], rb[B4];
+    auto fetch = [&](long k0) {
+#pragma unroll
+        for (int i = 0; i < A4; ++i) {
+            const long pix = k0 + a_r + i * (256 / CA);
+            ra[i] = (a_ok && pix < k_end) ? *reinterpret_cast<const uint4 *>(gy + pix * p.Cout + m0 + a_c) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B4; ++i) {
+            const long pix = k0 + b_r + i * (256 / CB);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (b_ok && pix < k_end) {
+                const int wo = (int)(pix % p.Wo);
+                const long t = pix / p.Wo;
+                const int ho = (int)(t % p.Ho), b = (int)(t / p.Ho);
+                const int hi = ho * p.stride + b_dh, wi = wo * p.stride + b_dw;
+                if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.W)
+                    v = *reinterpret_cast<const uint4 *>(x + (((long)b * p.H + hi) * p.W + wi) * p.Cin + b_ci);
+            }
+            rb[i] = v;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A4; ++i) *reinterpret_cast<uint4 *>(&As[buf][(a_r + i * (256 / CA)) * LDA + a_c * 2]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B4; ++i) *reinterpret_cast<uint4 *>(&Bs[buf][(b_r + i * (256 / CB)) * LDB + b_c * 2]) = rb[i];
+    };
+    v16f acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposed-read lane geometry: 16-lane group g = lane>>4 reads pixels 8*(g>>1) + {0..3 | 4..7}, channels 16*(g&1)..+15;
+    // lane 4q+p of the group addresses row q, channel quad p
+    const int g = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
+    const int fr = 8 * (g >> 1) + q, fcol = 16 * (g & 1) + 4 * pq;
+    const int a_off = fr * LDA + (wm * (BM / WM) + fcol) * 2;
+    const int b_off = fr * LDB + (wn * (BN / WN) + fcol) * 2;
+
+    int buf = 0;
+    if (k_begin < k_end) { fetch(k_begin); stash(0); }
+    __syncthreads();
+    for (long k0 = k_begin; k0 < k_end; k0 += BKB) {
+        const bool more = k0 + BKB < k_end;
+        if (more) fetch(k0 + BKB);
+        const char *a = As[buf] + a_off, *b = Bs[buf] + b_off;
+#pragma unroll
+        for (int kk = 0; kk < BKB; kk += 16) {
+            v8s fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(a + kk * LDA + i * 64));
+                const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(a + (kk + 4) * LDA + i * 64));
+                fa[i] = v8s{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(b + kk * LDB + j * 64));
+                const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(b + (kk + 4) * LDB + j * 64));
+                fb[j] = v8s{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, fa[i]), __builtin_bit_cast(bf8, fb[j]), acc[i][j], 0, 0, 0);
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // D (32x32): column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / WN) + 32 * j + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.Cout && n < p.N) atomicAdd(p.dw + (size_t)m * p.ldw + n, acc[i][j][r]);
+            }
+        }
+}
+
 // out[c] += sum_r in[r][c]  (bias gradients); one block per 64-row slab x 256 columns
 __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ in, float *__restrict__ out, long R, int C,
                                                      int rows_per_block) {
@@ -210,7 +336,7 @@ extern "C" int mhe_conv_wgrad_nhwc(const mhe_conv_desc *d, const void *x, const 
     if (want < 1) want = 1;
     long chunk = (p.P + want - 1) / want;
     if (chunk < 64) chunk = 64;
-    chunk = (chunk + wgrad::BK - 1) / wgrad::BK * wgrad::BK;
+    chunk = (chunk + 31) / 32 * 32;
     p.chunk = (int)chunk;
     const int gz = (int)((p.P + chunk - 1) / chunk);
     const dim3 grid(gx, gyy, gz), block(256);
@@ -218,6 +344,9 @@ extern "C" int mhe_conv_wgrad_nhwc(const mhe_conv_desc *d, const void *x, const 
     if (d->dtype == MHE_F32) {
         if (small) hipLaunchKernelGGL((wgrad::wgrad_kernel<float, 64, 128>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((wgrad::wgrad_kernel<float, 128, 128>), grid, block, 0, s, p);
+    } else if (d->Cin % 8 == 0 && d->Cout % 8 == 0 && !getenv("MHE_WGRAD_F32MFMA")) {
+        if (small) hipLaunchKernelGGL((wgrad::wgrad_bf16_kernel<64, 128, 1, 4>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((wgrad::wgrad_bf16_kernel<128, 128, 2, 2>), grid, block, 0, s, p);
     } else {
         if (small) hipLaunchKernelGGL((wgrad::wgrad_kernel<u16, 64, 128>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((wgrad::wgrad_kernel<u16, 128, 128>), grid, block, 0, s, p);

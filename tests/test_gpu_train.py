@@ -211,3 +211,37 @@ def test_clip_adam_matches_torch(gpu_lib):
         assert abs(sq.item() ** 0.5 - gr.norm().item()) < 1e-3 * gr.norm().item()
     assert_close(P.cpu(), ref.detach(), 1e-6, what="parameters after 3 clipped Adam steps")
     assert (P.cpu() - p0).abs().max() > 1e-4
+
+
+def test_full_step_matches_oracle_clip_adam(gpu_lib):
+    """TrainStep.step (forward, reverse, clip_grad_norm_(1.0), Adam lr 2e-4) against the oracle's train step
+    (hand/CrossModalHand.py:455-470).  Adam's first update is lr * g / (|g| + eps): elements whose gradient is
+    ~0 may take either sign, so the bound is on the bulk of the elements."""
+    from mhentropy_amd.train import TrainStep
+    from oracle import train_ref, mano_ref
+    B, N = 2, 4
+    model, sd = _model_and_state("resnet18", 64, 2)
+    tb = mano_ref.tables_from_numpy(synth.mano_tables(0))
+    xn, yn = synth.batch(7, B, image_size=96)
+    z0 = torch.as_tensor(synth.noise(7, N * B))
+    x, y = torch.as_tensor(xn), {k: torch.as_tensor(v) for k, v in yn.items()}
+    _, _, grads, buffers = train_ref.loss_and_grads(sd, tb, x, y, z0, N, arch="resnet18")
+    params = {k: v for k, v in sd.items() if k in grads}
+    new, norm = train_ref.clip_and_adam(params, grads, {})
+    ts = TrainStep(model)
+    ts.step(x.cuda(), {k: v.cuda() for k, v in y.items()}, noise=z0.cuda(), N=N)
+    assert abs(ts.sq.item() ** 0.5 - norm.item()) < 2e-3 * norm.item(), (ts.sq.item() ** 0.5, norm.item())
+    tot = off = 0
+    for name, p in model.named_parameters():
+        if name in new and grads[name].abs().max() > 0:
+            d = (p.detach().cpu() - new[name]).abs()
+            sig = grads[name].abs() > 1e-4 * grads[name].abs().max()         # elements with a meaningful gradient
+            tot += int(sig.sum()); off += int((d[sig] > 2e-5).sum())
+            assert (p.detach().cpu() - sd[name]).abs().max() > 1e-5, name + " did not move"
+    assert off < 2e-3 * tot, (off, tot)
+    # BatchNorm running statistics advanced (their values are pinned by test_gpu_modules' trunk tests)
+    for k in ("feat_extractor.res.bn1.running_mean", "feat_extractor.res.layer4.1.bn2.running_var"):
+        assert (dict(model.named_buffers())[k].cpu() - sd[k]).abs().max() > 1e-6, k
+    assert int(model.feat_extractor.res.bn1.num_batches_tracked) == 1
+    # dead head: no gradient, no movement
+    assert (model.feat_extractor.l2[0].weight.detach().cpu() == sd["feat_extractor.l2.0.weight"]).all()
