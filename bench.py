@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
                     help="default: the dtype BASELINE.json's configs name for the workload (c2: bf16; c0, c1: f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=5,
+                    help="also time this many full train steps (forward + reverse + all-reduce + clip + Adam) for the metric's "
+                         "'img/s train step' part; 0 skips it")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured HIP graph (1) or launch eagerly (0)")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
@@ -154,8 +157,31 @@ def main():
             last["out"] = step()
     dt = mdist.timed_region(run, args.steps, dist, dev)          # barrier+sync | K steps | sync+barrier, MAX over ranks
     out = last["out"]
+    loss_out = {k: v.clone() for k, v in out.items()}
     log(f"timed region: {dt * 1e3 / args.steps:.2f} ms/step")
-    assert torch.isfinite(out["log_p"]).all(), "non-finite loss"
+    assert torch.isfinite(loss_out["log_p"]).all(), "non-finite loss"
+
+    # ---- second part of BASELINE.json's metric: img/s of a full train step (hand/CrossModalHand.py:455-470) on the
+    # same model, inputs and hypotheses; every rank takes part (gradient all-reduce over RCCL when N > 1)
+    train = None
+    if args.train_steps > 0:
+        from mhentropy_amd.train import TrainStep
+        del last, run
+        if args.graph:
+            del graph
+        ts = TrainStep(model, dist=dist)
+        tstep = lambda: ts.step(x, y, noise=noise, N=K)
+        for i in range(2):
+            tout = tstep()
+            torch.cuda.synchronize()
+            log(f"train warm-up step {i} done (loss {float(tout['total']):.3f})")
+        dtt = mdist.timed_region(tstep, args.train_steps, dist, dev)
+        assert torch.isfinite(tout["log_p"]).all(), "non-finite loss in the train step"
+        train = {"img_per_s": round(world * B * args.train_steps / dtt, 1), "ms_per_step": round(dtt / args.train_steps * 1e3, 3),
+                 "steps": args.train_steps, "launch": "eager", "params": int(ts.n_params),
+                 "includes": "forward + hand-written reverse pass + %sclip_grad_norm_(1.0) + Adam(lr 2e-4)"
+                             % ("RCCL all-reduce of the flat f32 gradient + " if world > 1 else "")}
+        log(f"train step: {train['ms_per_step']} ms/step, {train['img_per_s']} img/s")
 
     if rank == 0:
         # ---- roofline of the dominant kernel (the MFMA implicit-GEMM conv instance with the most time)
@@ -192,7 +218,7 @@ def main():
                        "images_per_gpu": B, "hypotheses_per_image": K, "global_batch": world * B,
                        "launch": "hip-graph replay" if args.graph else "eager",
                        "img_per_s": round(world * B * args.steps / dt, 1)},
-            "roofline": roof, "cpu_baseline": cpu,
+            "train_step": train, "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if dist:

@@ -65,3 +65,18 @@ def reduce_mean_scalars(values, dist=None, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     t /= dist.get_world_size()
     return {k: float(v) for k, v in zip(keys, t.tolist())}
+
+
+def allreduce_gradients(flat, dist=None, bucket_elems=16 << 20):
+    """The train step's ONE exchange: sum the flat gradient buffer over ranks, in place,
+    as a few large buckets issued back to back (64 MB of f32 each: large enough to run every xGMI link at its
+    ring bandwidth, small enough that a later bucket's reduce-scatter overlaps an earlier one's all-gather).
+    The mean (DDP semantics) is taken by the optimizer kernel's grad_scale = 1/world."""
+    if dist is None or dist.get_world_size() == 1:
+        return flat
+    works = []
+    for lo in range(0, flat.numel(), bucket_elems):
+        works.append(dist.all_reduce(flat[lo:lo + bucket_elems], op=dist.ReduceOp.SUM, async_op=True))
+    for w in works:
+        w.wait()
+    return flat

@@ -506,7 +506,8 @@ class TrainStep:
     def optimizer_step(self):
         """all-reduce (sum) over ranks, clip_grad_norm_(max_norm) and Adam in one fused pass"""
         if self.dist is not None and self.world > 1:
-            self.dist.all_reduce(self.G)
+            from . import dist as mdist
+            mdist.allreduce_gradients(self.G, self.dist)
         ops.train_tick(self.step_t, self.sq)
         if self.max_norm and self.max_norm > 0:
             ops.sqnorm(self.G, self.sq)

@@ -21,6 +21,9 @@ def step():
     calls.append(1); time.sleep(0.02 * (rank + 1))                # rank 1 is slower
 dt = mdist.timed_region(step, 3, dist, sync=lambda: None)
 avg = mdist.reduce_mean_scalars({"loss": float(rank), "n": float(hi - lo)}, dist)
+g = torch.arange(1000, dtype=torch.float32) * (rank + 1)          # the train step's flat gradient exchange, 4 buckets
+mdist.allreduce_gradients(g, dist, bucket_elems=300)
+assert torch.equal(g, torch.arange(1000, dtype=torch.float32) * 3), "bucketed gradient all-reduce"
 with open(os.path.join(os.environ["MHE_OUT"], f"rank{rank}.json"), "w") as fh:
     json.dump({"rank": rank, "lo": lo, "hi": hi, "dt": dt, "calls": len(calls), "avg": avg, "sum_x": float(x.sum())}, fh)
 dist.destroy_process_group()
