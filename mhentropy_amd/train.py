@@ -513,6 +513,10 @@ class TrainStep:
             ops.sqnorm(self.G, self.sq)
         ops.adam_step(self.P, self.G, self.M, self.V, self.sq, self.step_t, self.lr, self.betas[0], self.betas[1], self.eps,
                       self.max_norm or 0.0, 1.0 / self.world)
+        # the kernels wrote the parameters behind torch's version counters: drop the modules' packed-weight caches
+        # so that eval()/sample() on the same model see the new weights
+        self.flow._pack = None
+        self.trunk._wcache.clear()
 
     def step(self, x, y, noise=None, N=None):
         out = self.forward_backward(x, y, noise=noise, N=N)
