@@ -276,6 +276,11 @@ int mhe_flow_mask_pad_f32(const float *x, const float *mask, float *xp, long R, 
 int mhe_flow_cond_lrelu_f32(float *P, const float *cond, long cond_stride, long R, int B, int H, void *stream);
 int mhe_flow_lrelu_bwd_f32(float *G, const float *Hact, long n, float slope, void *stream);
 int mhe_add_f32(const float *a, const float *b, float *out, long n, void *stream);
+/* mixed-precision forms (bf16 performance mode): input f32 or bf16, output f32 and / or bf16 (either may be NULL) */
+int mhe_flow_cond_lrelu_mixed(const void *pre, int pre_dtype, const float *cond, long cond_stride, float *out_f32,
+                              void *out_bf16, long R, int B, int H, void *stream);
+int mhe_flow_lrelu_bwd_mixed(const void *g, int g_dtype, const void *h, int h_dtype, float *out_f32, void *out_bf16,
+                             long n, float slope, void *stream);
 int mhe_flow_couple_bwd_f32(const float *x_out, const float *Os, const float *Ot, const float *mask,
                             const float *g_out, const float *g_log_p, float q_weight, float *x_in, float *GOs,
                             float *GOt, float *g_part, long R, int B, int dim, void *stream);

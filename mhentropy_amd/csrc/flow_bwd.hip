@@ -53,6 +53,61 @@ __global__ __launch_bounds__(256) void add_kernel(const float *__restrict__ a, c
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = a[i] + b[i];
 }
 
+
+// Mixed-precision forms for the bf16 performance mode: the three hidden x hidden products of each net (forward l1, its
+// data gradient and its weight gradient: 85 % of the reverse pass's FLOP) run on bf16 MFMA, so their operands
+// are kept as bf16 copies while everything that feeds an exp/tanh or a per-image reduction stays f32.
+template <typename T> __device__ __forceinline__ v4f ld4(const T *p);
+template <> __device__ __forceinline__ v4f ld4<float>(const float *p) { return *reinterpret_cast<const v4f *>(p); }
+template <> __device__ __forceinline__ v4f ld4<u16>(const u16 *p) {
+    const uint2 r = *reinterpret_cast<const uint2 *>(p);
+    v4f o;
+    o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xffff0000u);
+    o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xffff0000u);
+    return o;
+}
+__device__ __forceinline__ void st4b(u16 *p, const v4f &v) {
+    uint2 o;
+    o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+    o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+    *reinterpret_cast<uint2 *>(p) = o;
+}
+
+// out = leaky_relu(pre + cond[r % B]) written as f32 and / or bf16
+template <typename TI>
+__global__ __launch_bounds__(256) void cond_lrelu_mixed_kernel(const TI *__restrict__ pre, const float *__restrict__ cond,
+                                                               long cond_stride, float *__restrict__ out_f, u16 *__restrict__ out_b,
+                                                               long R, int B, int H) {
+    const long n4 = R * H / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long r = i / (H / 4);
+        const int c = (int)(i % (H / 4)) * 4;
+        v4f v = ld4<TI>(pre + i * 4);
+        const v4f b = *reinterpret_cast<const v4f *>(cond + (r % B) * cond_stride + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = v[e] + b[e];
+            v[e] = t > 0.f ? t : 0.01f * t;
+        }
+        if (out_f) *reinterpret_cast<v4f *>(out_f + i * 4) = v;
+        if (out_b) st4b(out_b + i * 4, v);
+    }
+}
+
+// out = g * (h > 0 ? 1 : slope) written as f32 and / or bf16
+template <typename TG, typename TH>
+__global__ __launch_bounds__(256) void lrelu_bwd_mixed_kernel(const TG *__restrict__ g, const TH *__restrict__ h,
+                                                              float *__restrict__ out_f, u16 *__restrict__ out_b, long n4, float slope) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        v4f gv = ld4<TG>(g + i * 4);
+        const v4f hv = ld4<TH>(h + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gv[e] = hv[e] > 0.f ? gv[e] : slope * gv[e];
+        if (out_f) *reinterpret_cast<v4f *>(out_f + i * 4) = gv;
+        if (out_b) st4b(out_b + i * 4, gv);
+    }
+}
+
 // One coupling, reverse: from its output x_out and the nets' raw outputs Os, Ot (bias included, 64-wide)
 //   s = tanh(Os)(1-m), t = Ot(1-m), x_in = m x_out + (1-m)(x_out - t) e^{-s}          (hand/flows.py:213-216)
 // and the adjoints of x_out (g_out) and of log q (a_q per row; log q = logN(z0) - sum s):
@@ -141,4 +196,34 @@ extern "C" int mhe_flow_couple_accum_f32(const float *g_part, const float *GXs, 
     hipLaunchKernelGGL(flowbwd::couple_accum_kernel, dim3((unsigned)((R * dim + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        g_part, GXs, GXt, mask, g_in, R, dim);
     return check_launch("couple_accum_kernel");
+}
+
+extern "C" int mhe_flow_cond_lrelu_mixed(const void *pre, int pre_dtype, const float *cond, long cond_stride, float *out_f32,
+                                         void *out_bf16, long R, int B, int H, void *stream) {
+    MHE_REQUIRE(pre && cond && (out_f32 || out_bf16) && R > 0 && B > 0 && H > 0 && H % 4 == 0 && cond_stride % 4 == 0,
+                "mhe_flow_cond_lrelu_mixed: bad arguments");
+    if (pre_dtype == MHE_F32)
+        hipLaunchKernelGGL(flowbwd::cond_lrelu_mixed_kernel<float>, dim3(ew_grid(R * H / 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const float *)pre, cond, cond_stride, out_f32, (u16 *)out_bf16, R, B, H);
+    else
+        hipLaunchKernelGGL(flowbwd::cond_lrelu_mixed_kernel<u16>, dim3(ew_grid(R * H / 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const u16 *)pre, cond, cond_stride, out_f32, (u16 *)out_bf16, R, B, H);
+    return check_launch("cond_lrelu_mixed_kernel");
+}
+
+extern "C" int mhe_flow_lrelu_bwd_mixed(const void *g, int g_dtype, const void *h, int h_dtype, float *out_f32, void *out_bf16,
+                                        long n, float slope, void *stream) {
+    MHE_REQUIRE(g && h && (out_f32 || out_bf16) && n > 0 && n % 4 == 0, "mhe_flow_lrelu_bwd_mixed: bad arguments");
+    const dim3 grid(ew_grid(n / 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    u16 *ob = (u16 *)out_bf16;
+    if (g_dtype == MHE_F32 && h_dtype == MHE_F32)
+        hipLaunchKernelGGL((flowbwd::lrelu_bwd_mixed_kernel<float, float>), grid, block, 0, s, (const float *)g, (const float *)h, out_f32, ob, n / 4, slope);
+    else if (g_dtype == MHE_F32)
+        hipLaunchKernelGGL((flowbwd::lrelu_bwd_mixed_kernel<float, u16>), grid, block, 0, s, (const float *)g, (const u16 *)h, out_f32, ob, n / 4, slope);
+    else if (h_dtype == MHE_F32)
+        hipLaunchKernelGGL((flowbwd::lrelu_bwd_mixed_kernel<u16, float>), grid, block, 0, s, (const u16 *)g, (const float *)h, out_f32, ob, n / 4, slope);
+    else
+        hipLaunchKernelGGL((flowbwd::lrelu_bwd_mixed_kernel<u16, u16>), grid, block, 0, s, (const u16 *)g, (const u16 *)h, out_f32, ob, n / 4, slope);
+    return check_launch("lrelu_bwd_mixed_kernel");
 }

@@ -331,11 +331,14 @@ extern "C" int mhe_conv_wgrad_nhwc(const mhe_conv_desc *d, const void *x, const 
     const bool small = d->Cout <= 64;
     const int BM = small ? 64 : 128, BN = 128;
     const int gx = (p.N + BN - 1) / BN, gyy = (d->Cout + BM - 1) / BM;
-    // split the pixel range so that the launch has ~2048 workgroups, at least 64 pixels each
-    long want = 2048 / ((long)gx * gyy);
+    // split the pixel range: enough workgroups to fill 256 CUs a few times over, but every split adds a full tile of
+    // f32 atomics - the bf16 kernel (4x faster mainloop) wants longer slices
+    const bool bf16k = d->dtype == MHE_BF16 && d->Cin % 8 == 0 && d->Cout % 8 == 0 && !getenv("MHE_WGRAD_F32MFMA");
+    long want = (bf16k ? 1024 : 2048) / ((long)gx * gyy);
     if (want < 1) want = 1;
     long chunk = (p.P + want - 1) / want;
-    if (chunk < 64) chunk = 64;
+    const long min_chunk = bf16k ? 512 : 64;
+    if (chunk < min_chunk) chunk = min_chunk;
     chunk = (chunk + 31) / 32 * 32;
     p.chunk = (int)chunk;
     const int gz = (int)((p.P + chunk - 1) / chunk);
@@ -344,7 +347,7 @@ extern "C" int mhe_conv_wgrad_nhwc(const mhe_conv_desc *d, const void *x, const 
     if (d->dtype == MHE_F32) {
         if (small) hipLaunchKernelGGL((wgrad::wgrad_kernel<float, 64, 128>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((wgrad::wgrad_kernel<float, 128, 128>), grid, block, 0, s, p);
-    } else if (d->Cin % 8 == 0 && d->Cout % 8 == 0 && !getenv("MHE_WGRAD_F32MFMA")) {
+    } else if (bf16k) {
         if (small) hipLaunchKernelGGL((wgrad::wgrad_bf16_kernel<64, 128, 1, 4>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((wgrad::wgrad_bf16_kernel<128, 128, 2, 2>), grid, block, 0, s, p);
     } else {

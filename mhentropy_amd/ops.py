@@ -511,3 +511,21 @@ def adam_step(p, g, m, v, sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, max_no
         _chk(t, torch.float32, "adam." + nm, (n,))
     check(_lib.lib().mhe_adam_step_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, _ptr(sq), _ptr(step), float(lr), float(beta1), float(beta2),
                                        float(eps), float(max_norm), float(grad_scale), _stream()), "mhe_adam_step_f32")
+
+
+def flow_cond_lrelu_mixed(pre, cond_slice, cond_stride, B, out_f32=None, out_bf16=None):
+    """leaky_relu(pre + cond[r % B]) from f32 or bf16 `pre` into f32 and / or bf16 outputs"""
+    R, H = pre.shape
+    _chk(pre, pre.dtype, "cond_lrelu_mixed.pre")
+    if out_f32 is not None:
+        _chk(out_f32, torch.float32, "cond_lrelu_mixed.out_f32", (R, H))
+    if out_bf16 is not None:
+        _chk(out_bf16, torch.bfloat16, "cond_lrelu_mixed.out_bf16", (R, H))
+    check(_lib.lib().mhe_flow_cond_lrelu_mixed(_ptr(pre), dtype_code(pre.dtype), cond_slice.data_ptr(), int(cond_stride), _ptr(out_f32),
+                                               _ptr(out_bf16), R, B, H, _stream()), "mhe_flow_cond_lrelu_mixed")
+
+
+def flow_lrelu_bwd_mixed(g, h, out_f32=None, out_bf16=None, slope=0.01):
+    _chk(g, g.dtype, "lrelu_bwd_mixed.g"); _chk(h, h.dtype, "lrelu_bwd_mixed.h", g.shape)
+    check(_lib.lib().mhe_flow_lrelu_bwd_mixed(_ptr(g), dtype_code(g.dtype), _ptr(h), dtype_code(h.dtype), _ptr(out_f32), _ptr(out_bf16),
+                                              g.numel(), float(slope), _stream()), "mhe_flow_lrelu_bwd_mixed")

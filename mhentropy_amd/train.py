@@ -273,6 +273,9 @@ class TrainStep:
                 b2i = torch.full((64,), -1, dtype=torch.int64); b2i[:dim] = self._pidx(net.l[2].bias)
                 d["w0"], d["w0T"] = self._derived(w0i, torch.float32), self._derived(w0i.t().contiguous(), torch.float32)
                 d["w1"], d["w1T"] = net.l[1].weight.data, self._derived(self._pidx(net.l[1].weight).t().contiguous(), torch.float32)
+                if bf16:        # operands of the hidden x hidden products on bf16 MFMA
+                    d["w1b"] = self._derived(self._pidx(net.l[1].weight), torch.bfloat16)
+                    d["w1Tb"] = self._derived(self._pidx(net.l[1].weight).t().contiguous(), torch.bfloat16)
                 d["w2"], d["w2T"] = self._derived(w2i, torch.float32), self._derived(w2i.t().contiguous(), torch.float32)
                 d["b2"] = self._derived(b2i, torch.float32)
                 d["r0"], d["r1"], d["r2"], d["rb2"] = (self._raw_slot(s) for s in ((h, 64), (h, h), (64, h), (64,)))
@@ -418,25 +421,45 @@ class TrainStep:
         Gc = self._buf("Gcond", (B, cstride))                     # gradient of the conditioning table, all nets / layers
         cflat = cond.view(B, cstride)
         x_cur, g_cur = x_out, g_x
+        mixed = self.flow_bf16
+        if mixed:
+            bf = torch.bfloat16
+            H1b = [self._buf(f"H1b{n}", (R, h), bf) for n in range(2)]
+            P2b, G2b, GH1b = self._buf("P2b", (R, h), bf), self._buf("G2b", (R, h), bf), self._buf("GH1b", (R, h), bf)
+            v4 = lambda t: t.view(R, 1, 1, t.shape[1])
         for i in range(ncoup - 1, -1, -1):
             m = fl.mask[i]
             ops.flow_mask_pad(x_cur, m, XP)
             for n in range(2):
                 d, slot = self.fnets[2 * i + n], (2 * i + n) * 2
                 ops.linear(XP, d["w0"], out=Hb[n][0])
-                ops.flow_cond_lrelu(Hb[n][0], cflat[:, slot * h:], cstride, B)
-                ops.linear(Hb[n][0], d["w1"], out=Hb[n][1])
-                ops.flow_cond_lrelu(Hb[n][1], cflat[:, (slot + 1) * h:], cstride, B)
+                if mixed:
+                    ops.flow_cond_lrelu_mixed(Hb[n][0], cflat[:, slot * h:], cstride, B, out_bf16=H1b[n])
+                    ops.conv2d_nhwc(v4(H1b[n]), d["w1b"], 1, 1, 1, 0, out=v4(P2b))
+                    ops.flow_cond_lrelu_mixed(P2b, cflat[:, (slot + 1) * h:], cstride, B, out_f32=Hb[n][1])
+                else:
+                    ops.flow_cond_lrelu(Hb[n][0], cflat[:, slot * h:], cstride, B)
+                    ops.linear(Hb[n][0], d["w1"], out=Hb[n][1])
+                    ops.flow_cond_lrelu(Hb[n][1], cflat[:, (slot + 1) * h:], cstride, B)
                 ops.linear(Hb[n][1], d["w2"], d["b2"], out=O[n])
             x_in, g_in = (xa, ga) if x_cur is not xa else (xb, gb)
             ops.flow_couple_bwd(x_cur, O[0], O[1], m, g_cur, g_logp, -1.0 / N if g_logp is not None else 0.0, B, x_in, GO[0], GO[1], gpart)
             for n in range(2):
                 d, slot = self.fnets[2 * i + n], (2 * i + n) * 2
                 ops.linear_wgrad(Hb[n][1], GO[n], d["dw2"]); ops.colsum(GO[n], d["db2"])
-                ops.linear(GO[n], d["w2T"], out=G2); ops.flow_lrelu_bwd(G2, Hb[n][1])
-                ops.linear_wgrad(Hb[n][0], G2, d["dw1"])
+                ops.linear(GO[n], d["w2T"], out=G2)
+                if mixed:
+                    ops.flow_lrelu_bwd_mixed(G2, Hb[n][1], out_f32=G2, out_bf16=G2b)
+                    ops.conv_wgrad(v4(H1b[n]), v4(G2b), 1, 1, 1, 0, d["dw1"])
+                else:
+                    ops.flow_lrelu_bwd(G2, Hb[n][1])
+                    ops.linear_wgrad(Hb[n][0], G2, d["dw1"])
                 ops.sum_over_hypotheses(G2, N, B, out=Gc[:, (slot + 1) * h:], out_stride=Gc.shape[1])
-                ops.linear(G2, d["w1T"], out=G1); ops.flow_lrelu_bwd(G1, Hb[n][0])
+                if mixed:
+                    ops.conv2d_nhwc(v4(G2b), d["w1Tb"], 1, 1, 1, 0, out=v4(GH1b))
+                    ops.flow_lrelu_bwd_mixed(GH1b, H1b[n], out_f32=G1)
+                else:
+                    ops.linear(G2, d["w1T"], out=G1); ops.flow_lrelu_bwd(G1, Hb[n][0])
                 ops.linear_wgrad(XP, G1, d["dw0"])
                 ops.sum_over_hypotheses(G1, N, B, out=Gc[:, slot * h:], out_stride=Gc.shape[1])
                 ops.linear(G1, d["w0T"], out=GX[n])

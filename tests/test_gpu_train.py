@@ -245,3 +245,52 @@ def test_full_step_matches_oracle_clip_adam(gpu_lib):
     assert int(model.feat_extractor.res.bn1.num_batches_tracked) == 1
     # dead head: no gradient, no movement
     assert (model.feat_extractor.l2[0].weight.detach().cpu() == sd["feat_extractor.l2.0.weight"]).all()
+
+
+def test_bf16_flow_reverse_close_to_fp32_autograd(gpu_lib):
+    """performance mode of the flow (bf16 operands on the hidden x hidden products, forward kernel and reverse pass):
+    gradients stay within bf16 rounding of the fp32 autograd reference (norm-wise; f32 trunk so that only the flow differs)"""
+    from mhentropy_amd.train import TrainStep
+    from oracle import train_ref, mano_ref
+    B, N, h, steps = 4, 8, 128, 2
+    model, sd = _model_and_state("resnet18", h, steps)
+    model.q_z_giv_i.compute_dtype = torch.bfloat16
+    tb = mano_ref.tables_from_numpy(synth.mano_tables(0))
+    xn, yn = synth.batch(11, B, image_size=96)
+    z0 = torch.as_tensor(synth.noise(11, N * B))
+    x, y = torch.as_tensor(xn), {k: torch.as_tensor(v) for k, v in yn.items()}
+    out_ref, _, grads, _ = train_ref.loss_and_grads(sd, tb, x, y, z0, N, arch="resnet18")
+    ts = TrainStep(model)
+    assert ts.flow_bf16
+    out = ts.forward_backward(x.cuda(), {k: v.cuda() for k, v in y.items()}, noise=z0.cuda(), N=N)
+    assert_close(out["log_p"].cpu(), out_ref["log_p"].detach(), 2e-2, what="log_p (bf16 flow)")
+    rows = _grad_report(ts, model, grads)
+    flow = [r for r in rows if r[2].startswith("q_z_giv_i")]
+    assert len(flow) == 2 * steps * 2 * 10
+    assert max(r[1] for r in flow) < 0.15, sorted(flow, key=lambda r: -r[1])[:5]
+    assert sorted(r[1] for r in flow)[len(flow) // 2] < 3e-2, sorted(r[1] for r in flow)[len(flow) // 2]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_repeated_steps_minimise_the_loss(gpu_lib, dt):
+    """40 train steps on one fixed batch: mean(-log_p) must fall well below its starting value in both the fp32 parity
+    mode and the bf16 performance mode (Adam's first step moves every weight by lr, so the loss is allowed to rise
+    first - the reference's optimizer does the same)."""
+    from mhentropy_amd import harness
+    from mhentropy_amd.train import TrainStep
+    torch.manual_seed(0)
+    model = harness.build_mhent(backbone="resnet18", h_dims=(128, 128), num_steps=2, tables=synth.mano_tables(0), compute_dtype=dt).cuda().train()
+    xn, yn = synth.batch(3, 16, image_size=128)
+    x, y = torch.as_tensor(xn).cuda(), {k: torch.as_tensor(v).cuda() for k, v in yn.items()}
+    z0 = torch.as_tensor(synth.noise(3, 8 * 16)).cuda()
+    ts = TrainStep(model)
+    losses = [float(ts.step(x, y, noise=z0, N=8)["total"]) for _ in range(40)]
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < 0.35 * losses[0], (losses[0], losses[-1])
+    # the flat buffers stay consistent with the module's parameters (views) and the packed caches were dropped
+    p = model.det_head[0].weight
+    assert p.data_ptr() == ts.P[ts.off[id(p)]:].data_ptr()
+    model.eval()
+    with torch.no_grad():
+        s = model.sample(x, N=[4, 4], temp=0.8, y=y)
+    assert torch.isfinite(s["uv"]).all()

@@ -9,13 +9,17 @@ B, K = int(os.environ.get("B", 256)), int(os.environ.get("K", 64))
 dt = torch.bfloat16 if os.environ.get("DT", "bf16") == "bf16" else torch.float32
 bb, h, steps = os.environ.get("BB", "resnet50"), int(os.environ.get("H", 512)), int(os.environ.get("STEPS", 6))
 model = harness.build_mhent(backbone=bb, h_dims=(h, h), num_steps=steps, tables=synth.mano_tables(0), compute_dtype=dt).cuda().train()
-x, yn = synth.batch(0, B, image_size=256)
+x, yn = synth.batch(0, B, image_size=int(os.environ.get("S", 256)))
 x = torch.as_tensor(x).cuda(); y = {k: torch.as_tensor(v).cuda() for k, v in yn.items()}
 noise = torch.as_tensor(synth.noise(0, K * B)).cuda()
 ts = TrainStep(model)
 for i in range(2):
     out = ts.step(x, y, noise=noise, N=K); torch.cuda.synchronize()
     print("warm", i, float(out["total"]), flush=True)
+if os.environ.get("TRACE"):
+    for i in range(int(os.environ["TRACE"])):
+        out = ts.step(x, y, noise=noise, N=K)
+        if i % 5 == 0: print("step", i, float(out["total"]), flush=True)
 n = int(os.environ.get("ITERS", 3))
 t0 = time.time()
 for _ in range(n):
