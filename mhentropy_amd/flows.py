@@ -54,6 +54,9 @@ class RealNVP(nn.Module):
 
     # ---- device-side packed parameters, rebuilt when any weight changes ------
     def _packed(self):
+        ext = getattr(self, "_external_pack", None)
+        if ext is not None:         # kept current on the device by train.TrainStep (gathers from its flat parameter buffer)
+            return ext
         bf16 = self.compute_dtype == torch.bfloat16 and self.hidden % 128 == 0
         ver = tuple(p._version for p in self.parameters()) + (str(self.mask.device), bf16)
         if self._pack is None or self._pack[0] != ver:

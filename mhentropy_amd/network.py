@@ -142,7 +142,7 @@ class MHEnt(nn.Module):
         """reference hand/network.py:838-844."""
         return self.log_prob(y, x, div_type=div_type, mods=mods, return_dict=return_dict, **kw)
 
-    def sample(self, x, N: Union[int, list] = 5, temp=0.5, mods=None, y=None, noise=None):
+    def sample(self, x, N: Union[int, list] = 5, temp=0.5, mods=None, y=None, noise=None, feat=None):
         """reference hand/network.py:846-883 -> th_bt (N,B,58), logs_t (N,B,3), verts (N,B,2334),
         xyz (N,B,63), uv (N,B,42) in pixels, faces."""
         N_quant = N
@@ -151,7 +151,8 @@ class MHEnt(nn.Module):
         out = {}
         if y is not None and "image" in y:
             out["image"] = y["image"]
-        _, feat, _ = self.feat_extractor(x)
+        if feat is None:       # `feat=` (extension): the conditioning feature of a forward already run on x
+            _, feat, _ = self.feat_extractor(x)
         B = feat.shape[0]
         z0 = self._noise(N * B, temp, noise, feat.device)
         if N_quant < N:        # keep the N_quant most likely hypotheses per image (network.py:866-871); log q comes

@@ -91,6 +91,9 @@ class ResNetTrunk(nn.Module):
     # -- packed-weight cache keyed on the parameter's version counter
     def _w(self, conv, cin_pad=None, stem=False):
         p = conv.weight
+        ext = getattr(self, "_external_w", None)
+        if ext is not None and id(p) in ext:        # kept current on the device by train.TrainStep
+            return ext[id(p)]
         key = (id(p), p._version, self.compute_dtype, p.device)
         hit = self._wcache.get(id(p))
         if hit is None or hit[0] != key:

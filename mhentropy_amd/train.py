@@ -89,7 +89,11 @@ class TrainStep:
         self.step_t = torch.zeros(1, device=self.dev, dtype=torch.int32)
         self.sq = torch.zeros(1, device=self.dev, dtype=torch.float32)
         self._ws = {}
-        self.g_logp_scale = 1.0
+        # the modules' forward paths (eval, sample) read the same device-resident operand packs, refreshed after every
+        # optimizer step - no host re-pack, never stale
+        self.repack()
+        self.flow._external_pack = (self.f_stream, self.f_b2, self.f_wc, self.f_bc)
+        self.trunk._external_w = {id(u.conv.weight): u.w_fwd for u in self.units}
 
     # ------------------------------------------------------------------ parameter arena
     def _flatten_params(self):
@@ -474,7 +478,6 @@ class TrainStep:
         m = self.model
         N = N or m.loss_N
         B = x.shape[0]
-        self.repack()
         self.raw.zero_()
         # ---- forward (hand/network.py:760-831)
         f = self._trunk_forward(x.contiguous())
@@ -536,12 +539,17 @@ class TrainStep:
             ops.sqnorm(self.G, self.sq)
         ops.adam_step(self.P, self.G, self.M, self.V, self.sq, self.step_t, self.lr, self.betas[0], self.betas[1], self.eps,
                       self.max_norm or 0.0, 1.0 / self.world)
-        # the kernels wrote the parameters behind torch's version counters: drop the modules' packed-weight caches
-        # so that eval()/sample() on the same model see the new weights
-        self.flow._pack = None
-        self.trunk._wcache.clear()
+        self.repack()          # every derived operand layout follows the new parameters
 
-    def step(self, x, y, noise=None, N=None):
+    def step(self, x, y, noise=None, N=None, test_samples=0, temp=0.8):
+        """one iteration of the reference's training loop (hand/CrossModalHand.py:353-361,455-470).  test_samples > 0
+        adds its per-iteration metrics pass `sample(N=[n,n], temp=0.8, mods={uv,xyz,verts})` to the returned dict,
+        from the conditioning feature of THIS forward (the reference runs the encoder a second time on the same
+        batch in train mode, which reproduces the same feature)."""
         out = self.forward_backward(x, y, noise=noise, N=N)
+        if test_samples:
+            with torch.no_grad():
+                out.update(self.model.sample(None, N=[test_samples, test_samples], temp=temp, mods={"uv", "xyz", "verts"}, y=y,
+                                             feat=self.tape["feat"]))
         self.optimizer_step()
         return out

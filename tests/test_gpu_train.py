@@ -290,6 +290,13 @@ def test_repeated_steps_minimise_the_loss(gpu_lib, dt):
     # the flat buffers stay consistent with the module's parameters (views) and the packed caches were dropped
     p = model.det_head[0].weight
     assert p.data_ptr() == ts.P[ts.off[id(p)]:].data_ptr()
+    # the reference's per-iteration metrics pass rides on the same forward (hand/CrossModalHand.py:357-361)
+    o = ts.step(x, y, noise=z0, N=8, test_samples=5)
+    assert o["xyz"].shape == (5, 16, 63) and o["verts"].shape == (5, 16, 2334) and o["uv"].shape == (5, 16, 42)
+    # module forward paths read the trainer's device-resident packs: same loss from the module API as from the trainer
+    again = model.get_loss(x, y, mods=["uv"], N=8, noise=z0)
+    probe = ts.forward_backward(x, y, noise=z0, N=8)
+    assert_close(again["log_p"].cpu(), probe["log_p"].cpu(), 5e-3 if dt == torch.float32 else 5e-2, what="module forward after training")
     model.eval()
     with torch.no_grad():
         s = model.sample(x, N=[4, 4], temp=0.8, y=y)
