@@ -101,7 +101,13 @@ def main():
         args.dtype = "bf16" if args.workload == "c2" else "f32"
 
     from mhentropy_amd import dist as mdist
-    rank, local_rank, world, dist = mdist.init("nccl")
+    # MHE_BENCH_REHEARSE=1 (development only): all ranks share cuda:0 and talk over gloo, to rehearse the N>1 code
+    # path on a one-GPU box; the driver's runs use RCCL with one GPU per rank
+    rehearse = os.environ.get("MHE_BENCH_REHEARSE") == "1"
+    rank, local_rank, world, dist = mdist.init("gloo" if rehearse else "nccl")
+    if rehearse:
+        local_rank = 0
+        torch.cuda.set_device(0)
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
                          "python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
@@ -206,7 +212,7 @@ def main():
                     "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
                     "launches_per_step": cnt // steps_timed, "avg_launch_us": round(sec / cnt * 1e6, 2),
                     "share_of_step": round(sec / steps_timed / (dt / args.steps), 3)}
-        cpu = None if args.no_cpu_baseline else cpu_baseline(cfg, sd, args.seed)
+        cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(cfg, sd, args.seed)      # rank 0 at N=1 only
         line = {
             "metric": "hypotheses/sec (BxK) fwd+loss, 256x256",
             "value": round(world * B * K * args.steps / dt, 1), "unit": "hypotheses/s",
