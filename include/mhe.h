@@ -316,6 +316,23 @@ int mhe_train_tick(int *step, float *sqnorm, void *stream);
 int mhe_adam_step_f32(float *p, const float *g, float *m, float *v, size_t n, const float *sqnorm, const int *step,
                       float lr, float beta1, float beta2, float eps, float max_norm, float grad_scale, void *stream);
 
+/* ---- conditional Glow (q_z_giv_i_model == 'glow', hand/network.py:342-344,693-694,736-742) ------------------
+ * PARITY UNPINNED: the class is the third-party nkolot/nflows ConditionalGlow (unpinned git dependency,
+ * hand/environment.yml:284), absent from the reference tree; these stages follow the published nflows algorithm
+ * (oracle/glow_ref.py).  Dense products go through mhe_linear_f32; context-only terms are per image and indexed
+ * by image = (row / row_div) % n_img.  The flow variable is carried zero-padded to 64 columns. */
+int mhe_glow_add_image_rows_f32(float *H, const float *img, long img_stride, long R, int C, int row_div, int n_img, void *stream);
+int mhe_relu_copy_f32(const float *in, float *out, long n, void *stream);
+int mhe_glow_glu_residual_f32(float *H, const float *T, const float *gate, long gate_stride, long R, int C, int row_div,
+                              int n_img, void *stream);
+/* params [R,64] = [shift (T) | unconstrained scale (T)]; transform feature j is column first + 2j; logdet accumulates. */
+int mhe_glow_coupling_f32(const float *u, const float *params, float *y, float *logdet, long R, int dim, int first,
+                          int n_transform, int inverse, void *stream);
+int mhe_pad64_f32(const float *x, float *xp, long R, int dim, void *stream);
+/* log_prob[r] = log N(z_r; 0, I) + sign * (logdet[r] + logdet_const); optionally un-pads v_padded into v_out [R,dim]. */
+int mhe_glow_finish_f32(const float *z_padded, const float *v_padded, const float *logdet, float *v_out, float *log_prob,
+                        long R, int dim, float sign, float logdet_const, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,141 @@
+// Elementwise stages of the conditional Glow (ActNorm -> LU linear -> affine coupling with a context-conditioned
+// residual MLP), the flow the reference builds for q_z_giv_i_model == 'glow' (hand/network.py:342-344; call sites
+// :693-694, :736-742).  The class itself (ConditionalGlow of the unpinned git dependency nkolot/nflows,
+// hand/environment.yml:284) is absent from the reference tree: these kernels follow the published nflows
+// algorithm restated in oracle/glow_ref.py - PARITY UNPINNED.  The dense products run on mhe_linear_f32; the
+// context-only terms (initial-layer context columns, GLU gates) are evaluated once per image and indexed here by
+// image = (row / row_div) % n_img  (row_div = 1: sample-major rows n*B+b; row_div = N: nflows' batch-major b*N+n).
+#include "common.h"
+#include "../../include/mhe.h"
+
+namespace mhe { namespace glow {
+
+// H[r][c] += img[(image of r)][c]
+__global__ __launch_bounds__(256) void add_image_rows_kernel(float *__restrict__ H, const float *__restrict__ img, long img_stride,
+                                                             long R, int C, int row_div, int n_img) {
+    const long n4 = R * C / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long r = i / (C / 4);
+        const int c = (int)(i % (C / 4)) * 4;
+        v4f v = *reinterpret_cast<v4f *>(H + i * 4);
+        const v4f b = *reinterpret_cast<const v4f *>(img + ((r / row_div) % n_img) * img_stride + c);
+        v += b;
+        *reinterpret_cast<v4f *>(H + i * 4) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void relu_copy_kernel(const float *__restrict__ in, float *__restrict__ out, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        v4f v = *reinterpret_cast<const v4f *>(in + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        *reinterpret_cast<v4f *>(out + i * 4) = v;
+    }
+}
+
+// residual block tail: H += T * sigmoid(gate[(image of r)])      (F.glu(cat(T, gate)) = T * sigmoid(gate))
+__global__ __launch_bounds__(256) void glu_residual_kernel(float *__restrict__ H, const float *__restrict__ T,
+                                                           const float *__restrict__ gate, long gate_stride, long R, int C,
+                                                           int row_div, int n_img) {
+    const long n4 = R * C / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long r = i / (C / 4);
+        const int c = (int)(i % (C / 4)) * 4;
+        v4f h = *reinterpret_cast<v4f *>(H + i * 4);
+        const v4f t = *reinterpret_cast<const v4f *>(T + i * 4);
+        const v4f g = *reinterpret_cast<const v4f *>(gate + ((r / row_div) % n_img) * gate_stride + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] += t[e] / (1.f + expf(-g[e]));
+        *reinterpret_cast<v4f *>(H + i * 4) = h;
+    }
+}
+
+// Affine coupling on a [R,64]-padded variable u with the net's raw output prm [R,64] = [shift(T) | unconstrained scale(T)]:
+//   scale = sigmoid(us + 2) + 1e-3;  forward: y_t = u_t * scale + shift, logdet += sum log scale
+//                                    inverse: y_t = (u_t - shift) / scale, logdet -= sum log scale
+// transform feature j (0..T-1) is column first + 2*j (the alternating mask); identity columns are copied.
+__global__ __launch_bounds__(256) void coupling_kernel(const float *__restrict__ u, const float *__restrict__ prm, float *__restrict__ y,
+                                                       float *__restrict__ logdet, long R, int dim, int first, int T, int inverse) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    float v = lane < dim ? u[r * 64 + lane] : 0.f;
+    float ls = 0.f;
+    const int j = (lane - first) >> 1;
+    if (lane < dim && lane >= first && ((lane - first) & 1) == 0 && j < T) {
+        const float shift = prm[r * 64 + j], us = prm[r * 64 + T + j];
+        const float scale = 1.f / (1.f + expf(-(us + 2.f))) + 1e-3f;
+        ls = logf(scale);
+        v = inverse ? (v - shift) / scale : v * scale + shift;
+    }
+    y[r * 64 + lane] = v;
+    ls = wave_sum(ls);
+    if (lane == 0) logdet[r] += inverse ? -ls : ls;
+}
+
+// x [R,dim] <-> xp [R,64] zero padded; and the base density: out[r] = -|z|^2/2 - dim/2 log(2 pi) + sign * logdet[r] + const
+__global__ __launch_bounds__(256) void pad64_kernel(const float *__restrict__ x, float *__restrict__ xp, long R, int dim) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * 64) return;
+    const int d = (int)(i & 63);
+    xp[i] = d < dim ? x[(i >> 6) * dim + d] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void finish_kernel(const float *__restrict__ zp, const float *__restrict__ vp, const float *__restrict__ logdet,
+                                                     float *__restrict__ v_out, float *__restrict__ logp, long R, int dim, float sign,
+                                                     float logdet_const) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float z = lane < dim ? zp[r * 64 + lane] : 0.f;
+    const float sq = wave_sum(z * z);
+    if (v_out && lane < dim) v_out[r * dim + lane] = vp[r * 64 + lane];
+    if (lane == 0) logp[r] = -0.5f * sq - 0.5f * dim * 1.8378770664093453f + sign * (logdet[r] + logdet_const);
+}
+}}  // namespace mhe::glow
+
+using namespace mhe;
+static inline unsigned gg(long n) { long b = (n + 255) / 256; return (unsigned)(b < 1 ? 1 : (b > 16384 ? 16384 : b)); }
+
+extern "C" int mhe_glow_add_image_rows_f32(float *H, const float *img, long img_stride, long R, int C, int row_div, int n_img, void *stream) {
+    MHE_REQUIRE(H && img && R > 0 && C > 0 && C % 4 == 0 && img_stride % 4 == 0 && row_div > 0 && n_img > 0, "mhe_glow_add_image_rows_f32: bad arguments");
+    hipLaunchKernelGGL(glow::add_image_rows_kernel, dim3(gg(R * C / 4)), dim3(256), 0, (hipStream_t)stream, H, img, img_stride, R, C, row_div, n_img);
+    return check_launch("add_image_rows_kernel");
+}
+
+extern "C" int mhe_relu_copy_f32(const float *in, float *out, long n, void *stream) {
+    MHE_REQUIRE(in && out && n > 0 && n % 4 == 0, "mhe_relu_copy_f32: bad arguments");
+    hipLaunchKernelGGL(glow::relu_copy_kernel, dim3(gg(n / 4)), dim3(256), 0, (hipStream_t)stream, in, out, n / 4);
+    return check_launch("relu_copy_kernel");
+}
+
+extern "C" int mhe_glow_glu_residual_f32(float *H, const float *T, const float *gate, long gate_stride, long R, int C, int row_div,
+                                         int n_img, void *stream) {
+    MHE_REQUIRE(H && T && gate && R > 0 && C > 0 && C % 4 == 0 && gate_stride % 4 == 0 && row_div > 0 && n_img > 0, "mhe_glow_glu_residual_f32: bad arguments");
+    hipLaunchKernelGGL(glow::glu_residual_kernel, dim3(gg(R * C / 4)), dim3(256), 0, (hipStream_t)stream, H, T, gate, gate_stride, R, C, row_div, n_img);
+    return check_launch("glu_residual_kernel");
+}
+
+extern "C" int mhe_glow_coupling_f32(const float *u, const float *params, float *y, float *logdet, long R, int dim, int first,
+                                     int n_transform, int inverse, void *stream) {
+    MHE_REQUIRE(u && params && y && logdet && R > 0 && dim > 0 && dim <= 64 && (first == 0 || first == 1) && n_transform > 0 &&
+                    first + 2 * (n_transform - 1) < dim && 2 * n_transform <= 64,
+                "mhe_glow_coupling_f32: bad arguments");
+    hipLaunchKernelGGL(glow::coupling_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, u, params, y, logdet, R, dim,
+                       first, n_transform, inverse);
+    return check_launch("coupling_kernel");
+}
+
+extern "C" int mhe_pad64_f32(const float *x, float *xp, long R, int dim, void *stream) {
+    MHE_REQUIRE(x && xp && R > 0 && dim > 0 && dim <= 64, "mhe_pad64_f32: bad arguments");
+    hipLaunchKernelGGL(glow::pad64_kernel, dim3((unsigned)((R * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, xp, R, dim);
+    return check_launch("pad64_kernel");
+}
+
+extern "C" int mhe_glow_finish_f32(const float *z_padded, const float *v_padded, const float *logdet, float *v_out, float *log_prob,
+                                   long R, int dim, float sign, float logdet_const, void *stream) {
+    MHE_REQUIRE(z_padded && logdet && log_prob && (!v_out || v_padded) && R > 0 && dim > 0 && dim <= 64, "mhe_glow_finish_f32: bad arguments");
+    hipLaunchKernelGGL(glow::finish_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z_padded, v_padded, logdet, v_out,
+                       log_prob, R, dim, sign, logdet_const);
+    return check_launch("finish_kernel");
+}

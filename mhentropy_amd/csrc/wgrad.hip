@@ -334,10 +334,12 @@ extern "C" int mhe_conv_wgrad_nhwc(const mhe_conv_desc *d, const void *x, const 
     // split the pixel range: enough workgroups to fill 256 CUs a few times over, but every split adds a full tile of
     // f32 atomics - the bf16 kernel (4x faster mainloop) wants longer slices
     const bool bf16k = d->dtype == MHE_BF16 && d->Cin % 8 == 0 && d->Cout % 8 == 0 && !getenv("MHE_WGRAD_F32MFMA");
-    long want = (bf16k ? 1024 : 2048) / ((long)gx * gyy);
+    static const long target_wgs = getenv("MHE_WGRAD_WGS") ? atol(getenv("MHE_WGRAD_WGS")) : 1024;
+    long want = (bf16k ? target_wgs : 2048) / ((long)gx * gyy);
     if (want < 1) want = 1;
     long chunk = (p.P + want - 1) / want;
-    const long min_chunk = bf16k ? 512 : 64;
+    static const long min_bf16 = getenv("MHE_WGRAD_MINCHUNK") ? atol(getenv("MHE_WGRAD_MINCHUNK")) : 512;
+    const long min_chunk = bf16k ? min_bf16 : 64;
     if (chunk < min_chunk) chunk = min_chunk;
     chunk = (chunk + 31) / 32 * 32;
     p.chunk = (int)chunk;

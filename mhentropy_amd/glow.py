@@ -1,0 +1,236 @@
+"""ConditionalGlow with the call surface the reference uses for `q_z_giv_i_model == 'glow'`
+(reference hand/network.py:342-344 ctor `(45, 512, 4, 2, context_features=512, dropout_probability=0.2)`;
+:693-694 `log_prob(z, context=feat) -> (log_prob, z)`; :736-742 `sample_and_log_prob(N, noise, context)
+-> (samples (B,N,D), log_prob (B,N), z)`; `_distribution._shape`), on HIP kernels.
+
+**PARITY UNPINNED.**  The reference imports the class from the ProHMR fork of nflows
+(`git+https://github.com/nkolot/nflows.git`, unpinned, hand/environment.yml:284), which is neither vendored
+nor installed; no reference test or fixture covers it.  This module follows the published nflows algorithm as
+restated in oracle/glow_ref.py (per layer ActNorm -> LULinear -> AffineCouplingTransform whose scale/shift come
+from a context-conditioned ResidualNet with GLU gating; alternating +-1 mask; StandardNormal base) and keeps
+nflows' module tree so that its state_dict keys (`_transform._transforms.{i}...`) line up.  Dropout is evaluated
+in eval mode (the reference's train-mode dropout draws from torch's RNG and cannot be reproduced);
+batch norm inside the nets is off (nflows' default).
+
+MI355X shape of the computation: ActNorm and the LU product collapse into one 45x45 affine map per layer (and its
+inverse for sampling), the flow variable is carried zero-padded to 64 columns so every dense product is an
+mhe_linear_f32 call, and everything that depends on the context only (initial-layer context columns, the GLU
+gates of every block of every layer) is ONE GEMM per image, indexed per hypothesis row by the kernels.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops, _lib
+
+
+class _ActNorm(nn.Module):
+    def __init__(self, features):
+        super().__init__()
+        self.register_buffer("initialized", torch.tensor(True))
+        self.log_scale = nn.Parameter(torch.zeros(features))
+        self.shift = nn.Parameter(torch.zeros(features))
+
+
+class _LULinear(nn.Module):
+    def __init__(self, features, eps=1e-3):
+        super().__init__()
+        self.features, self.eps = features, eps
+        n = features * (features - 1) // 2
+        self.lower_entries = nn.Parameter(torch.zeros(n))
+        self.upper_entries = nn.Parameter(torch.zeros(n))
+        self.unconstrained_upper_diag = nn.Parameter(torch.full((features,), math.log(math.exp(1 - eps) - 1)))   # identity init
+        self.bias = nn.Parameter(torch.zeros(features))
+
+    def weight_and_diag(self):
+        D = self.features
+        lower = torch.zeros(D, D, dtype=torch.float64)
+        li = np.tril_indices(D, k=-1)
+        lower[li[0], li[1]] = self.lower_entries.detach().double().cpu()
+        lower[range(D), range(D)] = 1.0
+        upper = torch.zeros(D, D, dtype=torch.float64)
+        ui = np.triu_indices(D, k=1)
+        upper[ui[0], ui[1]] = self.upper_entries.detach().double().cpu()
+        diag = F.softplus(self.unconstrained_upper_diag.detach().double().cpu()) + self.eps
+        upper[range(D), range(D)] = diag
+        return lower @ upper, diag
+
+
+class _ResidualBlock(nn.Module):
+    def __init__(self, features, context_features, dropout_probability):
+        super().__init__()
+        self.context_layer = nn.Linear(context_features, features)
+        self.linear_layers = nn.ModuleList([nn.Linear(features, features) for _ in range(2)])
+        self.dropout = nn.Dropout(p=dropout_probability)
+        nn.init.uniform_(self.linear_layers[-1].weight, -1e-3, 1e-3)     # nflows zero_initialization
+        nn.init.uniform_(self.linear_layers[-1].bias, -1e-3, 1e-3)
+
+
+class _ResidualNet(nn.Module):
+    def __init__(self, in_features, out_features, hidden_features, context_features, num_blocks, dropout_probability):
+        super().__init__()
+        self.initial_layer = nn.Linear(in_features + context_features, hidden_features)
+        self.blocks = nn.ModuleList([_ResidualBlock(hidden_features, context_features, dropout_probability) for _ in range(num_blocks)])
+        self.final_layer = nn.Linear(hidden_features, out_features)
+
+
+class _AffineCoupling(nn.Module):
+    def __init__(self, mask, make_net):
+        super().__init__()
+        idx = torch.arange(len(mask))
+        self.register_buffer("identity_features", idx[mask <= 0])
+        self.register_buffer("transform_features", idx[mask > 0])
+        self.transform_net = make_net(int((mask <= 0).sum()), 2 * int((mask > 0).sum()))
+
+
+class _Composite(nn.Module):
+    def __init__(self, transforms):
+        super().__init__()
+        self._transforms = nn.ModuleList(transforms)
+
+
+class _StandardNormal(nn.Module):
+    def __init__(self, shape):
+        super().__init__()
+        self._shape = torch.Size(shape)
+        self.register_buffer("_log_z", torch.tensor(0.5 * np.prod(shape) * np.log(2 * np.pi), dtype=torch.float64), persistent=False)
+
+
+class ConditionalGlow(nn.Module):
+    def __init__(self, features, hidden_features, num_layers, num_blocks_per_layer, activation=F.relu, dropout_probability=0.5,
+                 context_features=None, batch_norm_within_layers=False):
+        super().__init__()
+        if context_features is None or batch_norm_within_layers or activation is not F.relu:
+            raise NotImplementedError("only the context-conditioned, batch-norm-free ReLU configuration the reference builds")
+        if features > 64 or hidden_features % 64:
+            raise NotImplementedError(f"unsupported geometry features={features} hidden={hidden_features}")
+        self.features, self.hidden, self.num_layers, self.num_blocks, self.context_features = \
+            features, hidden_features, num_layers, num_blocks_per_layer, context_features
+        mask = torch.ones(features)
+        mask[::2] = -1
+        make = lambda i, o: _ResidualNet(i, o, hidden_features, context_features, num_blocks_per_layer, dropout_probability)
+        layers = []
+        for _ in range(num_layers):
+            layers += [_ActNorm(features), _LULinear(features), _AffineCoupling(mask.clone(), make)]
+            mask = -mask
+        self._transform = _Composite(layers)
+        self._distribution = _StandardNormal([features])
+        self._embedding_net = nn.Identity()
+        self._pack = None
+
+    # ---- derived device operands, rebuilt when a parameter changes --------------------------------------
+    def _packed(self):
+        dev = next(self.parameters()).device
+        ver = tuple(p._version for p in self.parameters()) + (str(dev),)
+        if self._pack is not None and self._pack[0] == ver:
+            return self._pack[1]
+        D, H, Fc, T = self.features, self.hidden, self.context_features, self._transform._transforms
+        pk = {"layers": [], "const": 0.0}
+        wctx, bctx = [], []
+        for l in range(self.num_layers):
+            an, lu, cp = T[3 * l], T[3 * l + 1], T[3 * l + 2]
+            W, diag = lu.weight_and_diag()
+            s = torch.exp(an.log_scale.detach().double().cpu())
+            A = W * s[None, :]                                           # x -> W (s*x + shift) + b
+            c = W @ an.shift.detach().double().cpu() + lu.bias.detach().double().cpu()
+            Ainv = torch.linalg.inv(A)
+            pad = lambda M, v: (F.pad(M, (0, 64 - D, 0, 64 - D)).float().to(dev).contiguous(), F.pad(v, (0, 64 - D)).float().to(dev).contiguous())
+            d = {}
+            d["A"], d["c"] = pad(A, c)
+            d["Ainv"], d["cinv"] = pad(Ainv, -(Ainv @ c))
+            pk["const"] += float(an.log_scale.detach().double().sum().cpu() + torch.log(diag).sum())
+            net = cp.transform_net
+            idf = cp.identity_features.cpu()
+            w0 = net.initial_layer.weight.detach()
+            wx = torch.zeros(H, 64, device=dev)
+            wx[:, idf.to(dev)] = w0[:, :idf.numel()]
+            d["wx"] = wx.contiguous()
+            wctx.append(w0[:, idf.numel():]); bctx.append(net.initial_layer.bias.detach())
+            d["blocks"] = []
+            for blk in net.blocks:
+                d["blocks"].append(tuple(t.detach().contiguous() for t in (blk.linear_layers[0].weight, blk.linear_layers[0].bias,
+                                                                         blk.linear_layers[1].weight, blk.linear_layers[1].bias)))
+                wctx.append(blk.context_layer.weight.detach()); bctx.append(blk.context_layer.bias.detach())
+            nt = int(cp.transform_features.numel())
+            wf = torch.zeros(64, H, device=dev); wf[:2 * nt] = net.final_layer.weight.detach()
+            bf = torch.zeros(64, device=dev); bf[:2 * nt] = net.final_layer.bias.detach()
+            d["wf"], d["bf"], d["T"], d["first"] = wf.contiguous(), bf.contiguous(), nt, int(cp.transform_features[0])
+            pk["layers"].append(d)
+        pk["wctx"], pk["bctx"] = torch.cat(wctx).contiguous(), torch.cat(bctx).contiguous()
+        self._pack = (ver, pk)
+        return pk
+
+    # ---- the two directions ------------------------------------------------------------------------------
+    def _net(self, d, v, ctab, slot, R, row_div, n_img, bufs):
+        """coupling parameters [R,64] of layer `d` from the (padded) variable v whose identity columns are current"""
+        L, H = _lib.lib(), self.hidden
+        h, t, t2 = bufs
+        s = ops._stream
+        ops.linear(v, d["wx"], out=h)
+        cs = ctab.shape[1]
+        ops.check(L.mhe_glow_add_image_rows_f32(ops._ptr(h), C.c_void_p(ctab[:, slot * H:].data_ptr()), cs, R, H, row_div, n_img, s()), "mhe_glow_add_image_rows_f32")
+        for b, (w0, b0, w1, b1) in enumerate(d["blocks"]):
+            ops.check(L.mhe_relu_copy_f32(ops._ptr(h), ops._ptr(t), h.numel(), s()), "mhe_relu_copy_f32")
+            ops.linear(t, w0, b0, relu=True, out=t2)
+            ops.linear(t2, w1, b1, out=t)
+            ops.check(L.mhe_glow_glu_residual_f32(ops._ptr(h), ops._ptr(t), C.c_void_p(ctab[:, (slot + 1 + b) * H:].data_ptr()), cs, R, H, row_div,
+                                                  n_img, s()), "mhe_glow_glu_residual_f32")
+        return ops.linear(h, d["wf"], d["bf"])
+
+    def _run(self, v_in, context, inverse, row_div, n_img):
+        """v_in (R,D) data (forward) or noise (inverse); returns (out (R,D), log_prob (R,))"""
+        ops._chk(v_in, torch.float32, "glow.in"); ops._chk(context, torch.float32, "glow.context", (context.shape[0], self.context_features))
+        pk, L, D, H = self._packed(), _lib.lib(), self.features, self.hidden
+        R = v_in.shape[0]
+        dev = v_in.device
+        s = ops._stream
+        ctab = ops.linear(context, pk["wctx"], pk["bctx"])                       # every context-only term, once per image
+        v = torch.empty(R, 64, device=dev)
+        ops.check(L.mhe_pad64_f32(ops._ptr(v_in), ops._ptr(v), R, D, s()), "mhe_pad64_f32")
+        z_in = v
+        logdet = torch.zeros(R, device=dev)
+        bufs = tuple(torch.empty(R, H, device=dev) for _ in range(3))
+        per = 1 + self.num_blocks
+        order = range(self.num_layers - 1, -1, -1) if inverse else range(self.num_layers)
+        for l in order:
+            d = pk["layers"][l]
+            if not inverse:
+                v = ops.linear(v, d["A"], d["c"])
+            prm = self._net(d, v, ctab, l * per, R, row_div, n_img, bufs)
+            y = torch.empty(R, 64, device=dev)
+            ops.check(L.mhe_glow_coupling_f32(ops._ptr(v), ops._ptr(prm), ops._ptr(y), ops._ptr(logdet), R, D, d["first"], d["T"], int(inverse), s()),
+                      "mhe_glow_coupling_f32")
+            v = ops.linear(y, d["Ainv"], d["cinv"]) if inverse else y
+        out = torch.empty(R, D, device=dev)
+        logp = torch.empty(R, device=dev)
+        z = z_in if inverse else v                                               # the base-density argument
+        ops.check(L.mhe_glow_finish_f32(ops._ptr(z), ops._ptr(v), ops._ptr(logdet), ops._ptr(out), ops._ptr(logp), R, D,
+                                        -1.0 if inverse else 1.0, -pk["const"] if inverse else pk["const"], s()), "mhe_glow_finish_f32")
+        return out, logp
+
+    # ---- reference call surface ----------------------------------------------------------------------------
+    def log_prob(self, inputs, context=None, rows_per_context=None):
+        """(log_prob (R,), noise (R,D)).  `context` has R rows (the reference passes `feat.repeat(N,1)`), or B rows with
+        sample-major inputs (row r uses context[r % B]; extension, hoists the context terms)."""
+        R, Bc = inputs.shape[0], context.shape[0]
+        if R % Bc:
+            raise ValueError(f"glow rows ({R}) must be a multiple of context rows ({Bc})")
+        z, lp = self._run(inputs.contiguous(), context.contiguous(), False, 1, Bc)
+        return lp, z
+
+    def sample_and_log_prob(self, num_samples, noise=None, context=None):
+        """samples (B,N,D), log_prob (B,N), noise - rows batch-major as nflows lays them out."""
+        B = context.shape[0]
+        if noise is None:
+            noise = torch.randn(B, num_samples, self.features, device=context.device)
+        x, lp = self._run(noise.reshape(B * num_samples, self.features).contiguous(), context.contiguous(), True, num_samples, B)
+        return x.view(B, num_samples, -1), lp.view(B, num_samples), noise
+
+    def forward(self, context, num_samples=1):
+        """ProHMR call form `flow(conditioning_feats, num_samples)` (reference README.md:34,39)"""
+        s, lp, _ = self.sample_and_log_prob(num_samples, context=context)
+        return s, lp

@@ -24,6 +24,7 @@ from torch import nn
 from . import ops, resnet
 from .ManoLayer import ManoLayer
 from .flows import RealNVP
+from .glow import ConditionalGlow
 
 
 class BasicEnc(nn.Module):
@@ -61,11 +62,12 @@ class MHEnt(nn.Module):
             raise NotImplementedError
         self.feat_extractor = BasicEnc(**common_cfg)
         model = special_cfg["q_z_giv_i_model"]
-        if model != "realnvp":
-            raise NotImplementedError(
-                f"q_z_giv_i_model={model!r}: only the shipped RealNVP branch is built (ConditionalGlow is the "
-                "third-party nkolot/nflows class, absent from the reference tree; SURVEY.md section 8c)")
-        self.q_z_giv_i = RealNVP(**special_cfg["q_z_giv_i_cfg"])
+        if model == "realnvp":
+            self.q_z_giv_i = RealNVP(**special_cfg["q_z_giv_i_cfg"])
+        elif model == "glow":       # reference hand/network.py:342-344; parity unpinned (third-party class absent, see glow.py)
+            self.q_z_giv_i = ConditionalGlow(45, 512, 4, 2, context_features=512, dropout_probability=0.2)
+        else:
+            raise NotImplementedError(f"q_z_giv_i_model={model!r}")
         self.ds = special_cfg["ds"]
         if self.ds not in ("rhd", "ho3d"):
             raise NotImplementedError(self.ds)
@@ -108,6 +110,16 @@ class MHEnt(nn.Module):
         noise = noise.reshape(rows, 45)
         return (noise * temp).contiguous() if temp != 1.0 else noise.contiguous()
 
+    def _glow_sample(self, feat, N, temp, noise):
+        """reference hand/network.py:736-742: noise (B,N,45)*temp -> sample_and_log_prob -> rows permuted to sample-major.
+        Here the flow runs directly on sample-major rows (row n*B+b uses feat[b]); a `noise` given in the reference's
+        (B,N,45) layout is re-ordered, a (N*B,45) one is taken as sample-major."""
+        B = feat.shape[0]
+        if noise is not None and noise.dim() == 3:
+            noise = noise.permute(1, 0, 2).reshape(N * B, 45)
+        z0 = self._noise(N * B, temp, noise, feat.device)
+        return self.q_z_giv_i._run(z0, feat.contiguous(), True, 1, B)
+
     # ---- reference surface ------------------------------------------------------
     def _reverse_kld(self, y, x, mods=None, return_dict=True, N=None, noise=None):
         """reference hand/network.py:760-831."""
@@ -116,10 +128,13 @@ class MHEnt(nn.Module):
         N = N or self.loss_N
         _, feat, _ = self.feat_extractor(x)
         B = feat.shape[0]
-        z0 = self._noise(N * B, 1.0, noise, feat.device)
-        if self.entropy and self.fused_entropy:
+        if isinstance(self.q_z_giv_i, ConditionalGlow):      # entropy from the sampling pass itself (network.py:781-783,798-799)
+            th45, log_q = self._glow_sample(feat, N, 1.0, noise)
+        elif self.entropy and self.fused_entropy:
+            z0 = self._noise(N * B, 1.0, noise, feat.device)
             th45, log_q = self.q_z_giv_i.sample_with_log_prob(z0, feat)
         else:
+            z0 = self._noise(N * B, 1.0, noise, feat.device)
             th45 = self.q_z_giv_i.forward_p(z0, cond=feat)
             log_q = self.q_z_giv_i.log_prob(th45, logvar=feat) if self.entropy else None       # network.py:801
         o = ops.mano_joints(th45, self._det(feat), self.mano_dec.table_blob(), y["crop_uv"].contiguous(),
@@ -154,13 +169,17 @@ class MHEnt(nn.Module):
         if feat is None:       # `feat=` (extension): the conditioning feature of a forward already run on x
             _, feat, _ = self.feat_extractor(x)
         B = feat.shape[0]
-        z0 = self._noise(N * B, temp, noise, feat.device)
-        if N_quant < N:        # keep the N_quant most likely hypotheses per image (network.py:866-871); log q comes
-            th45, log_q = self.q_z_giv_i.sample_with_log_prob(z0, feat)      # from the sampling pass itself
+        if isinstance(self.q_z_giv_i, ConditionalGlow):
+            th45, log_q = self._glow_sample(feat, N, temp, noise)
+        else:                   # log q comes from the sampling pass itself (only needed for the top-k selection)
+            z0 = self._noise(N * B, temp, noise, feat.device)
+            if N_quant < N:
+                th45, log_q = self.q_z_giv_i.sample_with_log_prob(z0, feat)
+            else:
+                th45 = self.q_z_giv_i.forward_p(z0, cond=feat)
+        if N_quant < N:         # keep the N_quant most likely hypotheses per image (network.py:866-871)
             _, th45 = ops.topk_gather(log_q, th45, N, B, N_quant)
             N = N_quant
-        else:
-            th45 = self.q_z_giv_i.forward_p(z0, cond=feat)
         mods = {"xyz", "uv", "verts"} if mods is None else set(mods)
         blob = self.mano_dec.table_blob()
         o = ops.mano_joints(th45, self._det(feat), blob, inv_norm=True, image_size=float(self.image_size),

@@ -173,3 +173,32 @@ def noise(seed, rows, dim=45):
     must feed captured noise, GPU and CPU generators differ)."""
     rng = np.random.default_rng(seed + 4000)
     return rng.normal(0, 1, (rows, dim)).astype(np.float32)
+
+
+def glow_state(seed=0, features=45, hidden=512, num_layers=4, num_blocks=2, context_features=512):
+    """state_dict (nflows key names) of a ConditionalGlow with well-conditioned random parameters: LU factors near
+    identity, small last layers (nflows initialises them ~0) so that the inverse pass stays O(1)."""
+    rng = np.random.default_rng(seed + 4000)
+    f32 = lambda a: np.asarray(a, np.float32)
+    sd = {}
+    mask = np.ones(features); mask[::2] = -1
+    for l in range(num_layers):
+        p = f"_transform._transforms.{3 * l}."
+        sd[p + "log_scale"], sd[p + "shift"] = f32(rng.normal(0, 0.1, features)), f32(rng.normal(0, 0.1, features))
+        p = f"_transform._transforms.{3 * l + 1}."
+        n = features * (features - 1) // 2
+        sd[p + "lower_entries"], sd[p + "upper_entries"] = f32(rng.normal(0, 0.03, n)), f32(rng.normal(0, 0.03, n))
+        sd[p + "unconstrained_upper_diag"], sd[p + "bias"] = f32(0.5 + rng.normal(0, 0.1, features)), f32(rng.normal(0, 0.1, features))
+        p = f"_transform._transforms.{3 * l + 2}.transform_net."
+        nid, nt = int((mask <= 0).sum()), int((mask > 0).sum())
+        sd[p + "initial_layer.weight"], sd[p + "initial_layer.bias"] = _linear(rng, hidden, nid + context_features)
+        for b in range(num_blocks):
+            q = p + f"blocks.{b}."
+            sd[q + "linear_layers.0.weight"], sd[q + "linear_layers.0.bias"] = _linear(rng, hidden, hidden)
+            w, bb = _linear(rng, hidden, hidden)
+            sd[q + "linear_layers.1.weight"], sd[q + "linear_layers.1.bias"] = w * 0.3, bb * 0.3
+            sd[q + "context_layer.weight"], sd[q + "context_layer.bias"] = _linear(rng, hidden, context_features)
+        w, bb = _linear(rng, 2 * nt, hidden)
+        sd[p + "final_layer.weight"], sd[p + "final_layer.bias"] = w * 0.2, bb * 0.2
+        mask = -mask
+    return sd

@@ -251,6 +251,9 @@ class TrainStep:
 
     def _build_flow(self):
         fl = self.model.q_z_giv_i
+        from .flows import RealNVP
+        if not isinstance(fl, RealNVP):
+            raise NotImplementedError("TrainStep: only the shipped RealNVP flow has a reverse pass (the Glow branch is forward-only)")
         self.flow = fl
         dim, h, ncoup = fl.dim, fl.hidden, len(fl.mask)
         bf16 = fl.compute_dtype == torch.bfloat16 and h % 128 == 0

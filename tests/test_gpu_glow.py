@@ -1,0 +1,81 @@
+"""GPU tests of the conditional Glow branch.  PARITY UNPINNED: the reference's class is the
+third-party nkolot/nflows ConditionalGlow, absent from the reference tree; the HIP path is checked against the
+restatement of the published nflows algorithm (oracle/glow_ref.py) and against the flow's own identities."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close
+from mhentropy_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _glow(seed, hidden, layers=4, blocks=2, ctx=512):
+    from mhentropy_amd.glow import ConditionalGlow
+    g = ConditionalGlow(45, hidden, layers, blocks, context_features=ctx, dropout_probability=0.2)
+    sd = {k: torch.as_tensor(v) for k, v in synth.glow_state(seed, 45, hidden, layers, blocks, ctx).items()}
+    missing, unexpected = g.load_state_dict(sd, strict=False)
+    assert not unexpected and all("identity_features" in k or "transform_features" in k or k.endswith("initialized") for k in missing), (missing, unexpected)
+    return g.cuda().eval(), sd
+
+
+@pytest.mark.parametrize("hidden,B,N", [(64, 3, 5), (512, 4, 16)])
+def test_glow_matches_the_nflows_restatement(gpu_lib, hidden, B, N):
+    from oracle import glow_ref
+    g, sd = _glow(1, hidden)
+    rng = np.random.default_rng(2)
+    noise = torch.as_tensor(rng.normal(0, 0.8, (B, N, 45)).astype(np.float32))
+    ctx = torch.as_tensor(rng.normal(0, 0.5, (B, 512)).astype(np.float32))
+    x_ref, lp_ref, _ = glow_ref.sample_and_log_prob(sd, noise, ctx)
+    x, lp, nz = g.sample_and_log_prob(N, noise=noise.cuda(), context=ctx.cuda())
+    assert x.shape == (B, N, 45) and lp.shape == (B, N) and g._distribution._shape == torch.Size([45])
+    assert_close(x.cpu(), x_ref, 1e-4, what="samples"); assert_close(lp.cpu(), lp_ref, 1e-4, what="log_prob of the samples")
+    # density of given points, reference call form log_prob(z, context=feat.repeat(N,1)) with sample-major rows (network.py:693-694)
+    xs = x_ref.permute(1, 0, 2).reshape(N * B, 45)
+    lq_ref, z_ref = glow_ref.log_prob(sd, xs, ctx.repeat(N, 1))
+    lq, z = g.log_prob(xs.cuda(), context=ctx.repeat(N, 1).cuda())
+    assert_close(lq.cpu(), lq_ref, 1e-4, what="log_prob"); assert_close(z.cpu(), z_ref, 1e-4, what="noise")
+    lq2, _ = g.log_prob(xs.cuda(), context=ctx.cuda())                       # B-row context, hoisted per image
+    assert_close(lq2.cpu(), lq_ref, 1e-4, what="log_prob (per-image context)")
+    # the flow's own identities: forward(inverse(noise)) == noise, same density from both directions
+    assert_close(z.cpu(), noise.permute(1, 0, 2).reshape(N * B, 45), 2e-4, what="round trip")
+    assert_close(lq.cpu(), lp_ref.t().reshape(-1), 2e-4, what="density consistency")
+
+
+def test_mhent_glow_branch(gpu_lib):
+    """MHEnt with q_z_giv_i_model='glow' (hand/network.py:342-344,736-742,781-799): loss dict from the sampling pass's own log-prob"""
+    from mhentropy_amd import harness
+    from mhentropy_amd.network import MHEnt
+    from oracle import glow_ref, network_ref, mano_ref
+    special, common = harness.mhent_cfgs(backbone="resnet18", tables=synth.mano_tables(0))
+    special["q_z_giv_i_model"] = "glow"
+    model = MHEnt(special, **common)
+    gsd = {k: torch.as_tensor(v) for k, v in synth.glow_state(3).items()}
+    model.q_z_giv_i.load_state_dict(gsd, strict=False)
+    hsd = {k: torch.as_tensor(v) for k, v in synth.head_state(4, 512).items()}
+    model.load_state_dict(hsd, strict=False)
+    model = model.cuda().train()
+    B, N = 3, 6
+    _, yn = synth.batch(5, B, with_image=False)
+    y = {k: torch.as_tensor(v) for k, v in yn.items()}
+    feat = torch.as_tensor(np.random.default_rng(6).normal(0, 0.5, (B, 512)).astype(np.float32))
+    model.feat_extractor.forward = lambda x: (feat.cuda(), feat.cuda(), None)
+    noise = torch.as_tensor(np.random.default_rng(7).normal(0, 1, (B, N, 45)).astype(np.float32))
+    out = model.get_loss(None, {k: v.cuda() for k, v in y.items()}, mods=["uv"], N=N, noise=noise.cuda())
+    # oracle composition of the same lines
+    tb = mano_ref.tables_from_numpy(synth.mano_tables(0))
+    x, lp, _ = glow_ref.sample_and_log_prob(gsd, noise, feat)
+    th45 = x.permute(1, 0, 2).flatten(0, 1)
+    log_q = lp.transpose(0, 1).flatten()
+    z = network_ref.combine_z(network_ref.det_head(hsd, feat).repeat(N, 1), th45)
+    q = network_ref.forward_log_p(tb, z, y, N)["log_p"].reshape(N, -1).mean(0)
+    h = (-log_q).reshape(N, -1).mean(0)
+    assert_close(out["q_log_p_z_giv_y"].cpu(), q, 1e-4, what="q_log_p_z_giv_y")
+    assert_close(out["h_q_z_giv_i"].cpu(), h, 1e-4, what="entropy")
+    assert_close(out["log_p"].cpu(), q + h, 1e-4, what="log_p")
+    s = model.sample(None, N=[6, 3], temp=0.8, y={k: v.cuda() for k, v in y.items()}, noise=noise.cuda())
+    assert s["xyz"].shape == (3, B, 63) and torch.isfinite(s["verts"]).all()
+    from mhentropy_amd.train import TrainStep
+    with pytest.raises(NotImplementedError):
+        TrainStep(model)
