@@ -28,3 +28,45 @@ def build_mhent(**kw):
     model = MHEnt(special, **common)
     model.q_z_giv_i.compute_dtype = kw.get("compute_dtype", torch.float32)
     return model
+
+
+# ---- trainer-shell parity -------------------------------------------------------
+class AverageMeter:
+    """reference hand/utils.py:75-91, including its quirk: `n` is overwritten by `int(val != 0)`, so zero values are
+    skipped and every non-zero update counts once whatever `n` was passed."""
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        n = int(val != 0)
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count if self.count != 0 else 0
+
+
+def save_model(path, model):
+    """checkpoint in the reference's format (hand/CrossModalHand.py:573-587): {'decoderPose': ..., 'encoderRGB': state_dict}.
+    The reference builds `decoderPose` as an empty nn.Sequential for MHEnt (its state_dict is empty)."""
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    torch.save({"decoderPose": {}, "encoderRGB": sd}, path)
+
+
+def load_model(path, model, map_location=None):
+    """hand/CrossModalHand.py:589-602: loads check_point['encoderRGB'] into the model; like the reference it reports a
+    key/shape mismatch instead of raising.  Works with a TrainStep attached (parameters are views into its flat buffer:
+    load_state_dict copies in place; call trainer.repack() afterwards)."""
+    ck = torch.load(path, map_location=map_location or "cpu")
+    try:
+        model.load_state_dict(ck["encoderRGB"])
+    except RuntimeError as e:
+        print(e)
+    return ck
+
+
+def multistep_lr(base_lr, epoch, milestones=(150, 250), gamma=0.1):
+    """torch.optim.lr_scheduler.MultiStepLR as the reference configures it (hand/CrossModalHand.py:202, run per epoch)"""
+    return base_lr * gamma ** sum(epoch >= m for m in milestones)

@@ -56,3 +56,23 @@ def test_two_ranks_over_gloo(tmp_path):
     assert recs[0]["dt"] >= 3 * 0.04 - 1e-3                                # ... which is the slow rank's time
     assert recs[0]["avg"] == recs[1]["avg"] == {"loss": 0.5, "n": 3.5}
     assert recs[0]["sum_x"] != recs[1]["sum_x"]                            # different shards
+
+
+def test_trainer_shell_helpers(tmp_path):
+    """row f3: AverageMeter quirk, MultiStepLR schedule, checkpoint container (reference hand/utils.py:75-91,
+    hand/CrossModalHand.py:202,573-602)"""
+    import torch
+    from mhentropy_amd import harness
+    m = harness.AverageMeter()
+    for v in (2.0, 0.0, 4.0):
+        m.update(v, n=8)
+    assert (m.count, m.avg, m.val) == (2, 3.0, 4.0)
+    assert [harness.multistep_lr(2e-4, e) for e in (0, 149, 150, 249, 250, 400)] == [2e-4, 2e-4, 2e-5, 2e-5, 2e-4 * 0.1 ** 2, 2e-4 * 0.1 ** 2]
+    sched_ref = torch.optim.lr_scheduler.MultiStepLR(torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=2e-4), milestones=[150, 250], gamma=0.1)
+    lin = torch.nn.Linear(3, 2)
+    harness.save_model(tmp_path / "ck.pth", lin)
+    ck = torch.load(tmp_path / "ck.pth")
+    assert set(ck) == {"decoderPose", "encoderRGB"} and set(ck["encoderRGB"]) == {"weight", "bias"}
+    lin2 = torch.nn.Linear(3, 2)
+    harness.load_model(tmp_path / "ck.pth", lin2)
+    assert torch.equal(lin2.weight, lin.weight)
