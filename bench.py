@@ -38,13 +38,16 @@ def log(msg):
     print(f"[bench +{time.time() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
-def build_model(cfg, dtype, seed):
+def build_model(cfg, dtype, seed, flow="realnvp"):
     from mhentropy_amd import harness, synth
     cd = torch.float32 if dtype == "f32" else torch.bfloat16
     model = harness.build_mhent(backbone=cfg["backbone"], h_dims=(cfg["h"], cfg["h"]), num_steps=cfg["steps"],
-                                tables=synth.mano_tables(0), compute_dtype=cd)
+                                tables=synth.mano_tables(0), compute_dtype=cd, flow=flow)
     feat_dim = 2048 if cfg["backbone"] == "resnet50" else 512
-    sd = {"q_z_giv_i." + k: v for k, v in synth.flow_state(seed, 45, 512, (cfg["h"], cfg["h"]), cfg["steps"]).items()}
+    if flow == "glow":
+        sd = {"q_z_giv_i." + k: v for k, v in synth.glow_state(seed).items()}
+    else:
+        sd = {"q_z_giv_i." + k: v for k, v in synth.flow_state(seed, 45, 512, (cfg["h"], cfg["h"]), cfg["steps"]).items()}
     sd.update(synth.head_state(seed, feat_dim, 512, 16))
     sd.update({"feat_extractor.res." + k: v for k, v in synth.resnet_state(seed, cfg["backbone"]).items()})
     model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=False)
@@ -90,6 +93,9 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
                     help="default: the dtype BASELINE.json's configs name for the workload (c2: bf16; c0, c1: f32)")
+    ap.add_argument("--flow", default="realnvp", choices=["realnvp", "glow"],
+                    help="realnvp: the flow the reference ships (configs/ho3d.yaml:39) - the measured default; glow: the 4-layer "
+                         "ConditionalGlow branch (parity unpinned, forward + loss only: no train leg, no CPU baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-steps", type=int, default=5,
                     help="also time this many full train steps (forward + reverse + all-reduce + clip + Adam) for the metric's "
@@ -119,7 +125,9 @@ def main():
     cfg = WORKLOADS[args.workload]
     B, K = cfg["B"], cfg["K"]
     log(f"building model for workload {args.workload} ({args.dtype})")
-    model, sd = build_model(cfg, args.dtype, args.seed)
+    model, sd = build_model(cfg, args.dtype, args.seed, args.flow)
+    if args.flow == "glow":
+        args.train_steps, args.no_cpu_baseline = 0, True
     model = model.to(dev).train()
     # rank-private shard of synthetic images / targets / base noise, resident in HBM before timing
     x, yn = synth.batch(args.seed + 17 * rank, B, image_size=256)
@@ -220,7 +228,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: MHEnt.get_loss forward+loss, {cfg['backbone']} encoder (train-mode BN), "
-                                   f"{2 * cfg['steps']}-coupling RealNVP h={cfg['h']}, MANO joints, B={B}/GPU, K={K}, 256x256",
+                                   f"{'4-layer ConditionalGlow h=512 (parity unpinned)' if args.flow == 'glow' else str(2 * cfg['steps']) + '-coupling RealNVP h=' + str(cfg['h'])}, MANO joints, B={B}/GPU, K={K}, 256x256",
                        "images_per_gpu": B, "hypotheses_per_image": K, "global_batch": world * B,
                        "launch": "hip-graph replay" if args.graph else "eager",
                        "img_per_s": round(world * B * args.steps / dt, 1)},

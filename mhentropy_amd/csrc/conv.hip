@@ -666,26 +666,6 @@ __global__ void bn_finalize_kernel(const float *__restrict__ stats, const float 
     if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * var * (count / (count - 1.f));
 }
 
-template <typename T> __device__ __forceinline__ void load4(const T *p, float *v);
-template <> __device__ __forceinline__ void load4<float>(const float *p, float *v) {
-    const float4 t = *reinterpret_cast<const float4 *>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-}
-template <> __device__ __forceinline__ void load4<u16>(const u16 *p, float *v) {
-    const uint2 t = *reinterpret_cast<const uint2 *>(p);
-    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
-}
-template <typename T> __device__ __forceinline__ void store4(T *p, const float *v);
-template <> __device__ __forceinline__ void store4<float>(float *p, const float *v) {
-    *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
-}
-template <> __device__ __forceinline__ void store4<u16>(u16 *p, const float *v) {
-    uint2 o;
-    o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-    o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-    *reinterpret_cast<uint2 *>(p) = o;
-}
-
 // y = relu?(x*scale+shift + (res*rscale+rshift | res))   4 channels per thread
 template <typename T>
 __global__ void bn_act_kernel(const T *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift,

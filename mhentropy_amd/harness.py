@@ -8,9 +8,9 @@ from .network import MHEnt
 from .criteria import MHEntLoss
 
 
-def mhent_cfgs(backbone="resnet50", h_dims=(512, 512), num_steps=6, tables=None, compute_dtype=torch.float32):
+def mhent_cfgs(backbone="resnet50", h_dims=(512, 512), num_steps=6, tables=None, compute_dtype=torch.float32, flow="realnvp"):
     special = dict(
-        q_z_giv_i_model="realnvp",                                              # ho3d.yaml:39
+        q_z_giv_i_model=flow,                                                   # ho3d.yaml:39 ships "realnvp"
         q_z_giv_i_cfg=dict(dim=45, tsfm_on=512, kemb=False, jointN=21, h_dims=list(h_dims), num_steps=num_steps),
         ds="ho3d", image_size=[256, 256],
         mano_cfg=dict(flat_hand_mean=False, ncomps=45, use_pca=True, tables=tables),
@@ -26,7 +26,7 @@ def mhent_cfgs(backbone="resnet50", h_dims=(512, 512), num_steps=6, tables=None,
 def build_mhent(**kw):
     special, common = mhent_cfgs(**kw)
     model = MHEnt(special, **common)
-    model.q_z_giv_i.compute_dtype = kw.get("compute_dtype", torch.float32)
+    model.q_z_giv_i.compute_dtype = kw.get("compute_dtype", torch.float32)      # (the Glow branch computes in f32 regardless)
     return model
 
 
