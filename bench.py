@@ -85,6 +85,46 @@ def cpu_baseline(cfg, sd, seed, budget_s=20.0):
                       f"median of {max(len(times) - 1, 1)} runs after 1 warm-up, {t * 1e3:.0f} ms/pass"}
 
 
+def time_train_step(model, x, y, noise, B, K, args, dist, world, dev):
+    """img/s of TrainStep.step (forward + hand-written reverse pass + all-reduce + clip + Adam) on the bench workload"""
+    from mhentropy_amd import dist as mdist
+    from mhentropy_amd.train import TrainStep
+    ts = TrainStep(model, dist=dist)
+    tstep = lambda: ts.step(x, y, noise=noise, N=K)
+    for i in range(2):
+        tout = tstep()
+        torch.cuda.synchronize()
+        log(f"train warm-up step {i} done (loss {float(tout['total']):.3f})")
+    tlaunch = "eager"
+    if args.graph and world == 1:
+        # the whole step (~1,500 launches; step count and gradient norm live in device memory) replays from one captured
+        # HIP graph; with N > 1 the RCCL all-reduce keeps it eager
+        try:
+            gs = torch.cuda.Stream()
+            gs.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(gs):
+                tstep()
+            torch.cuda.current_stream().wait_stream(gs)
+            tgraph, tres = torch.cuda.CUDAGraph(), {}
+            with torch.cuda.graph(tgraph):
+                tres["out"] = tstep()
+            tgraph.replay()
+            torch.cuda.synchronize()
+            tout, tstep, tlaunch = tres["out"], tgraph.replay, "hip-graph replay"
+        except Exception as e:          # capture is an optimisation, never a requirement
+            log(f"train-step graph capture unavailable ({type(e).__name__}: {e}); timing eager launches")
+            torch.cuda.synchronize()
+            tstep = lambda: ts.step(x, y, noise=noise, N=K)
+    dtt = mdist.timed_region(tstep, args.train_steps, dist, dev)
+    assert torch.isfinite(tout["log_p"]).all(), "non-finite loss in the train step"
+    train = {"img_per_s": round(world * B * args.train_steps / dtt, 1), "ms_per_step": round(dtt / args.train_steps * 1e3, 3),
+             "steps": args.train_steps, "launch": tlaunch, "params": int(ts.n_params),
+             "includes": "forward + hand-written reverse pass + %sclip_grad_norm_(1.0) + Adam(lr 2e-4)"
+                         % ("RCCL all-reduce of the flat f32 gradient + " if world > 1 else "")}
+    log(f"train step: {train['ms_per_step']} ms/step, {train['img_per_s']} img/s")
+    return train
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,23 +219,14 @@ def main():
     # same model, inputs and hypotheses; every rank takes part (gradient all-reduce over RCCL when N > 1)
     train = None
     if args.train_steps > 0:
-        from mhentropy_amd.train import TrainStep
         del last, run
         if args.graph:
             del graph
-        ts = TrainStep(model, dist=dist)
-        tstep = lambda: ts.step(x, y, noise=noise, N=K)
-        for i in range(2):
-            tout = tstep()
-            torch.cuda.synchronize()
-            log(f"train warm-up step {i} done (loss {float(tout['total']):.3f})")
-        dtt = mdist.timed_region(tstep, args.train_steps, dist, dev)
-        assert torch.isfinite(tout["log_p"]).all(), "non-finite loss in the train step"
-        train = {"img_per_s": round(world * B * args.train_steps / dtt, 1), "ms_per_step": round(dtt / args.train_steps * 1e3, 3),
-                 "steps": args.train_steps, "launch": "eager", "params": int(ts.n_params),
-                 "includes": "forward + hand-written reverse pass + %sclip_grad_norm_(1.0) + Adam(lr 2e-4)"
-                             % ("RCCL all-reduce of the flat f32 gradient + " if world > 1 else "")}
-        log(f"train step: {train['ms_per_step']} ms/step, {train['img_per_s']} img/s")
+        try:
+            train = time_train_step(model, x, y, noise, B, K, args, dist, world, dev)
+        except Exception as e:      # the headline (forward + loss) line must survive a failure of the secondary leg
+            log(f"train-step leg failed: {type(e).__name__}: {e}")
+            train = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         # ---- roofline of the dominant kernel (the MFMA implicit-GEMM conv instance with the most time)

@@ -21,9 +21,22 @@ if os.environ.get("TRACE"):
         out = ts.step(x, y, noise=noise, N=K)
         if i % 5 == 0: print("step", i, float(out["total"]), flush=True)
 n = int(os.environ.get("ITERS", 3))
+run = lambda: ts.step(x, y, noise=noise, N=K)
+if os.environ.get("GRAPH") == "1":
+    gs = torch.cuda.Stream(); gs.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(gs):
+        ts.step(x, y, noise=noise, N=K)
+    torch.cuda.current_stream().wait_stream(gs)
+    graph = torch.cuda.CUDAGraph(); res = {}
+    with torch.cuda.graph(graph):
+        res["out"] = ts.step(x, y, noise=noise, N=K)
+    graph.replay(); torch.cuda.synchronize()
+    print("graph captured; loss", float(res["out"]["total"]), flush=True)
+    def run():
+        graph.replay(); return res["out"]
 t0 = time.time()
 for _ in range(n):
-    out = ts.step(x, y, noise=noise, N=K)
+    out = run()
 torch.cuda.synchronize()
 dtm = (time.time() - t0) / n
 print(f"train step {bb} B={B} K={K} {os.environ.get('DT', 'bf16')}: {dtm * 1e3:.2f} ms/step  {B / dtm:.1f} img/s  loss {float(out['total']):.4f}", flush=True)
