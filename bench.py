@@ -231,12 +231,17 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel (the MFMA implicit-GEMM conv instance with the most time)
         agg = {}
-        for name, flops, ev0, ev1 in ops.KERNEL_TIMES:
-            a = agg.setdefault(name, [0.0, 0.0, 0])
-            a[0] += flops; a[1] += ev0.elapsed_time(ev1) * 1e-3; a[2] += 1
+        HBM_PEAK = 8.0e12               # MI355X_MICROARCH.md (spec; ~6.3e12 achievable)
+        bound_all = time_all = 0.0
+        for name, flops, ev0, ev1, nbytes in ops.KERNEL_TIMES:
+            a = agg.setdefault(name, [0.0, 0.0, 0, 0.0, 0.0])
+            t = ev0.elapsed_time(ev1) * 1e-3
+            b = max(flops / PEAK[args.dtype], nbytes / HBM_PEAK)      # this launch's binding roofline (MFMA or HBM), seconds
+            a[0] += flops; a[1] += t; a[2] += 1; a[3] += b; a[4] += nbytes
+            bound_all += b; time_all += t
         roof = None
         if agg:
-            name, (fl, sec, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
+            name, (fl, sec, cnt, bnd, nby) = max(agg.items(), key=lambda kv: kv[1][1])
             ach = fl / sec / 1e12
             steps_timed = min(args.steps, 3)
             # HBM bytes per launch of that kernel from the committed PMC passes (tools/pmc_traffic.py), if profiled
@@ -250,6 +255,10 @@ def main():
                     "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK[args.dtype], 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
                     "launches_per_step": cnt // steps_timed, "avg_launch_us": round(sec / cnt * 1e6, 2),
+                    # the same launches against whichever roofline binds each of them (several of this kernel's layers are
+                    # HBM-bound at 128 FLOP/B), and the same for all convolution launches of the step
+                    "algorithmic_bytes_per_launch": int(nby / cnt),
+                    "frac_of_binding_roofline": round(bnd / sec, 4), "all_convs_frac_of_binding_roofline": round(bound_all / time_all, 4),
                     "share_of_step": round(sec / steps_timed / (dt / args.steps), 3)}
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(cfg, sd, args.seed)      # rank 0 at N=1 only
         line = {

@@ -244,8 +244,10 @@ def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in
           "mhe_conv2d_nhwc")
     if TIMING:
         ev1.record()
+        es = x.element_size()      # algorithmic HBM bytes: input once, output once, weights once (+ residual)
+        nbytes = es * (x.numel() + y.numel() + w.numel() + (residual.numel() if residual is not None else 0))
         KERNEL_TIMES.append((_conv_kernel_name(d, dt, 1 if in_scale is not None else 0),
-                             2.0 * B * Ho * Wo * Cout * KH * KW * Cin, ev0, ev1))
+                             2.0 * B * Ho * Wo * Cout * KH * KW * Cin, ev0, ev1, nbytes))
     return y
 
 
@@ -272,7 +274,9 @@ def conv1x1_residual_in(x, x2, w, in_scale, in_shift, x2_scale=None, x2_shift=No
           "mhe_conv1x1_residual_in_nhwc")
     if TIMING:
         ev1.record()
-        KERNEL_TIMES.append((_conv_kernel_name(d, dt, 2), 2.0 * B * H * W * Cout * Cin, ev0, ev1))
+        es = x.element_size()
+        nbytes = es * (2 * x.numel() + y.numel() + w.numel() + (a_out.numel() if a_out is not None else 0))
+        KERNEL_TIMES.append((_conv_kernel_name(d, dt, 2), 2.0 * B * H * W * Cout * Cin, ev0, ev1, nbytes))
     return y
 
 
@@ -294,7 +298,7 @@ def stem_conv7x7s2(x, w, dtype, stats=None):
     if TIMING:
         ev1.record()
         KERNEL_TIMES.append(("mhe::conv::stem_kernel<%s>" % ("float" if dtype == torch.float32 else "unsigned short"),
-                             2.0 * B * Ho * Wo * 64 * 147, ev0, ev1))
+                             2.0 * B * Ho * Wo * 64 * 147, ev0, ev1, 4 * x.numel() + y.element_size() * y.numel()))
     return y
 
 
