@@ -476,14 +476,16 @@ class TrainStep:
         return Gc
 
     # ------------------------------------------------------------------ the step
-    def forward_backward(self, x, y, noise=None, N=None):
-        """forward of MHEnt.get_loss + full reverse pass; fills self.G.  Returns the get_loss dict + 'total'."""
+    def forward_backward(self, x, y, noise=None, N=None, trunk_out=None):
+        """forward of MHEnt.get_loss + full reverse pass; fills self.G.  Returns the get_loss dict + 'total'.
+        trunk_out (B, feat_dim) f32 (testing aid): stands in for the ResNet trunk's output, whose forward and reverse
+        passes are then skipped - the reference's golden gradients are pinned from the trunk feature on."""
         m = self.model
         N = N or m.loss_N
-        B = x.shape[0]
+        B = x.shape[0] if trunk_out is None else trunk_out.shape[0]
         self.raw.zero_()
         # ---- forward (hand/network.py:760-831)
-        f = self._trunk_forward(x.contiguous())
+        f = self._trunk_forward(x.contiguous()) if trunk_out is None else trunk_out.contiguous()
         feat = ops.linear(f, self.l1["w"], self.l1["b"])
         hd = ops.linear(feat, self.d0["w"], self.d0["b"], relu=True)
         det = ops.linear(hd, self.d2["w"], self.d2["b"])[:, :16].contiguous()
@@ -517,10 +519,11 @@ class TrainStep:
         ops.add(g_feat, ops.linear(ghd, self.d0["wT"]))
         ops.linear_wgrad(f, g_feat, self.l1["dw"]); ops.colsum(g_feat, self.l1["db"])
         g_f = ops.linear(g_feat, self.l1["wT"])
-        self._trunk_backward(g_f)
+        if trunk_out is None:
+            self._trunk_backward(g_f)
         ops.gather(self.raw, self._unpack_idx, self.G)
         out["total"] = -log_p.mean() if m.entropy else -q_log_p.mean()
-        self.tape = {"feat": feat, "det": det, "th45": th45, "g_feat": g_feat, "g_th45": g45}
+        self.tape = {"feat": feat, "det": det, "th45": th45, "g_feat": g_feat, "g_th45": g45, "g_trunk_out": g_f}
         return out
 
     def _mano_bwd(self, th45, det, blob, cu, vis, g_logp, N):

@@ -301,3 +301,27 @@ def test_repeated_steps_minimise_the_loss(gpu_lib, dt):
     with torch.no_grad():
         s = model.sample(x, N=[4, 4], temp=0.8, y=y)
     assert torch.isfinite(s["uv"]).all()
+
+
+@pytest.mark.parametrize("tag", ["small", "shipped"])
+def test_reverse_pass_matches_the_references_own_gradients(gpu_lib, tag):
+    """the gradients torch autograd produced on the REFERENCE's MHEnt (captured by oracle/gen_golden.py from
+    /root/reference/hand/network.py with N=10, loss = mean(-log_p), criteria.py:55,173): det_head.2.weight, the first s-net's
+    input layer, the last t-net's output layer and the conditioning feature - from the trunk feature on"""
+    from mhentropy_amd import harness
+    from mhentropy_amd.train import TrainStep
+    g = load_golden(f"mhent_{tag}")
+    seed, h, steps, B, N = int(g["seed"]), int(g["h"]), int(g["steps"]), int(g["B"]), int(g["N_loss"])
+    model = harness.build_mhent(backbone="resnet50", h_dims=(h, h), num_steps=steps, tables=synth.mano_tables(0))
+    sd = {"q_z_giv_i." + k: torch.as_tensor(v) for k, v in synth.flow_state(seed, 45, 512, (h, h), steps).items()}
+    sd.update({k: torch.as_tensor(v) for k, v in synth.head_state(seed, 2048, 512, 16).items()})
+    assert not model.load_state_dict(sd, strict=False)[1]
+    ts = TrainStep(model.cuda().train())
+    y = {k[2:]: torch.as_tensor(v).cuda() for k, v in g.items() if k.startswith("y_")}
+    out = ts.forward_backward(None, y, noise=torch.as_tensor(g["z0_loss"]).cuda(), N=N, trunk_out=torch.as_tensor(g["trunk"]).cuda())
+    for k in ("log_p", "q_log_p_z_giv_y", "h_q_z_giv_i"):
+        assert_close(out[k].cpu(), g["loss_" + k], RTOL, what=k)
+    params = dict(model.named_parameters())
+    for name in ("det_head.2.weight", "q_z_giv_i.s.0.l.0.weight", f"q_z_giv_i.t.{2 * steps - 1}.l.2.weight"):
+        assert_close(ts.grad_of(params[name]).cpu(), g["grad_" + name], 2e-4, what="d loss / d " + name)
+    assert_close(ts.tape["g_feat"].cpu(), g["grad_feat"], 2e-4, what="d loss / d feat")
