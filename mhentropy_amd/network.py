@@ -126,6 +126,12 @@ class MHEnt(nn.Module):
         if mods is not None and list(mods) != ["uv"]:
             raise NotImplementedError("only the weakly supervised 'uv' likelihood of the shipped config is built")
         N = N or self.loss_N
+        tr = getattr(self, "_trainer", None)
+        if tr is not None and self.training and torch.is_grad_enabled():
+            # a train.TrainStep is attached: the loss dict comes out as ONE autograd node whose backward is the
+            # hand-written reverse pass, so the reference's `total_loss.backward()` works unchanged
+            from .train import differentiable_get_loss
+            return differentiable_get_loss(tr, x, y, N=N, noise=noise)
         _, feat, _ = self.feat_extractor(x)
         B = feat.shape[0]
         if isinstance(self.q_z_giv_i, ConditionalGlow):      # entropy from the sampling pass itself (network.py:781-783,798-799)

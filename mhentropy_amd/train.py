@@ -108,6 +108,7 @@ class TrainStep:
             o = self.off[id(p)]
             self.P[o:o + p.numel()].copy_(p.data.reshape(-1).float())
             p.data = self.P[o:o + p.numel()].view(p.shape)
+        self._params, self._param_ver = ps, sum(p._version for p in ps)
         self.G = torch.zeros_like(self.P)
         self.M = torch.zeros_like(self.P)
         self.V = torch.zeros_like(self.P)
@@ -476,15 +477,17 @@ class TrainStep:
         return Gc
 
     # ------------------------------------------------------------------ the step
-    def forward_backward(self, x, y, noise=None, N=None, trunk_out=None):
-        """forward of MHEnt.get_loss + full reverse pass; fills self.G.  Returns the get_loss dict + 'total'.
+    def forward(self, x, y, noise=None, N=None, trunk_out=None):
+        """forward of MHEnt.get_loss (hand/network.py:760-831) keeping what the reverse pass needs.  Returns the get_loss dict.
         trunk_out (B, feat_dim) f32 (testing aid): stands in for the ResNet trunk's output, whose forward and reverse
         passes are then skipped - the reference's golden gradients are pinned from the trunk feature on."""
         m = self.model
         N = N or m.loss_N
         B = x.shape[0] if trunk_out is None else trunk_out.shape[0]
-        self.raw.zero_()
-        # ---- forward (hand/network.py:760-831)
+        ver = sum(p._version for p in self._params)
+        if ver != self._param_ver:           # someone else (torch.optim, load_state_dict) wrote the parameters: refresh the packs
+            self.repack()
+            self._param_ver = ver
         f = self._trunk_forward(x.contiguous()) if trunk_out is None else trunk_out.contiguous()
         feat = ops.linear(f, self.l1["w"], self.l1["b"])
         hd = ops.linear(feat, self.d0["w"], self.d0["b"], relu=True)
@@ -502,10 +505,22 @@ class TrainStep:
                "log_p": log_p if m.entropy else q_log_p}
         if m.entropy:
             out["h_q_z_giv_i"] = hq
-        # ---- reverse: total = mean_b(-log_p[b])  (hand/criteria.py:55,173)
+        self.tape = {"f": f, "feat": feat, "hd": hd, "det": det, "cond": cond, "th45": th45, "blob": blob, "cu": cu, "vis": vis,
+                     "N": N, "B": B, "trunk": trunk_out is None}
+        return out
+
+    def backward(self, g_log_p=None):
+        """reverse pass of the last forward() for d loss / d log_p = g_log_p (B,) - default -1/B, the reference's
+        total = mean_b(-log_p[b]) (hand/criteria.py:55,173); fills self.G."""
+        m, t = self.model, self.tape
+        N, B, f, feat, hd, det, cond, th45 = t["N"], t["B"], t["f"], t["feat"], t["hd"], t["det"], t["cond"], t["th45"]
+        self.raw.zero_()
         g_logp = self._buf("g_logp", (B,))
-        g_logp.fill_(-1.0 / B)
-        g45, gdet_rows = self._mano_bwd(th45, det, blob, cu, vis, g_logp, N)
+        if g_log_p is None:
+            g_logp.fill_(-1.0 / B)
+        else:
+            g_logp.copy_(g_log_p.reshape(B))
+        g45, gdet_rows = self._mano_bwd(th45, det, t["blob"], t["cu"], t["vis"], g_logp, N)
         Gc = self._flow_backward(th45, cond, g45, g_logp if m.entropy else None, N, B)
         # det head: gdet [B,16] -> padded [B,32]
         gdet = self._buf("gdet", (B, 32)); gdet.zero_()
@@ -519,12 +534,26 @@ class TrainStep:
         ops.add(g_feat, ops.linear(ghd, self.d0["wT"]))
         ops.linear_wgrad(f, g_feat, self.l1["dw"]); ops.colsum(g_feat, self.l1["db"])
         g_f = ops.linear(g_feat, self.l1["wT"])
-        if trunk_out is None:
+        if t["trunk"]:
             self._trunk_backward(g_f)
         ops.gather(self.raw, self._unpack_idx, self.G)
-        out["total"] = -log_p.mean() if m.entropy else -q_log_p.mean()
-        self.tape = {"feat": feat, "det": det, "th45": th45, "g_feat": g_feat, "g_th45": g45, "g_trunk_out": g_f}
+        t.update({"g_feat": g_feat, "g_th45": g45, "g_trunk_out": g_f})
+
+    def forward_backward(self, x, y, noise=None, N=None, trunk_out=None):
+        """forward + reverse pass of total = mean_b(-log_p[b]); fills self.G.  Returns the get_loss dict + 'total'."""
+        out = self.forward(x, y, noise=noise, N=N, trunk_out=trunk_out)
+        self.backward()
+        out["total"] = -out["log_p"].mean()
         return out
+
+    # ------------------------------------------------------------------ torch.autograd bridge
+    def attach(self):
+        """make `model.get_loss(...)` (training mode, grad enabled) differentiable: `total_loss.backward()` of the reference's
+        loop (hand/CrossModalHand.py:455-470) then runs the hand-written reverse pass and leaves the gradients in every
+        parameter's `.grad` (views of the flat gradient buffer), so the reference's own `clip_grad_norm_` and
+        `torch.optim.Adam` work unchanged.  (The fused `step()` stays the fast path.)"""
+        self.model._trainer = self
+        return self
 
     def _mano_bwd(self, th45, det, blob, cu, vis, g_logp, N):
         R, B = th45.shape[0], det.shape[0]
@@ -546,6 +575,7 @@ class TrainStep:
         ops.adam_step(self.P, self.G, self.M, self.V, self.sq, self.step_t, self.lr, self.betas[0], self.betas[1], self.eps,
                       self.max_norm or 0.0, 1.0 / self.world)
         self.repack()          # every derived operand layout follows the new parameters
+        self._param_ver = sum(p._version for p in self._params)
 
     def step(self, x, y, noise=None, N=None, test_samples=0, temp=0.8):
         """one iteration of the reference's training loop (hand/CrossModalHand.py:353-361,455-470).  test_samples > 0
@@ -559,3 +589,30 @@ class TrainStep:
                                              feat=self.tape["feat"]))
         self.optimizer_step()
         return out
+
+
+class _LossFn(torch.autograd.Function):
+    """MHEnt.get_loss as one autograd node: forward = TrainStep.forward, backward = TrainStep.backward(d loss / d log_p)."""
+    @staticmethod
+    def forward(ctx, trainer, x, y, N, noise, *params):
+        out = trainer.forward(x, y, noise=noise, N=N)
+        ctx.trainer, ctx.keys = trainer, list(out)
+        vals = tuple(out[k] for k in ctx.keys)
+        ctx.mark_non_differentiable(*[v for k, v in zip(ctx.keys, vals) if k != "log_p"])
+        return vals
+
+    @staticmethod
+    def backward(ctx, *grads):
+        tr = ctx.trainer
+        g = grads[ctx.keys.index("log_p")]
+        tr.backward(None if g is None else g.contiguous().float())
+        return (None, None, None, None, None) + tuple(tr.grad_of(p) for p in tr._params)
+
+
+def differentiable_get_loss(trainer, x, y, N=None, noise=None):
+    vals = _LossFn.apply(trainer, x, y, N, noise, *trainer._params)
+    return dict(zip(_LossFn_keys(trainer), vals))
+
+
+def _LossFn_keys(trainer):
+    return ["th_norm", "bt_norm", "q_log_p_z_giv_y", "log_p"] + (["h_q_z_giv_i"] if trainer.model.entropy else [])

@@ -325,3 +325,41 @@ def test_reverse_pass_matches_the_references_own_gradients(gpu_lib, tag):
     for name in ("det_head.2.weight", "q_z_giv_i.s.0.l.0.weight", f"q_z_giv_i.t.{2 * steps - 1}.l.2.weight"):
         assert_close(ts.grad_of(params[name]).cpu(), g["grad_" + name], 2e-4, what="d loss / d " + name)
     assert_close(ts.tape["g_feat"].cpu(), g["grad_feat"], 2e-4, what="d loss / d feat")
+
+
+def test_autograd_bridge_runs_the_references_loop_unchanged(gpu_lib):
+    """hand/CrossModalHand.py:452-470 verbatim: get_loss -> criterion -> zero_grad -> total_loss.backward() ->
+    clip_grad_norm_ -> torch.optim.Adam.step(), with a TrainStep attached: .grad equals the explicit reverse pass and the
+    parameters move exactly like the fused step's."""
+    from mhentropy_amd import harness
+    from mhentropy_amd.criteria import MHEntLoss
+    from mhentropy_amd.train import TrainStep
+    xn, yn = synth.batch(3, 4, image_size=96)
+    x, y = torch.as_tensor(xn).cuda(), {k: torch.as_tensor(v).cuda() for k, v in yn.items()}
+    z0 = torch.as_tensor(synth.noise(3, 6 * 4)).cuda()
+    models = []
+    for _ in range(2):
+        m, _sd = _model_and_state("resnet18", 64, 2)
+        models.append(m)
+    fused = TrainStep(models[0])
+    bridge = TrainStep(models[1]).attach()
+    opt = torch.optim.Adam(models[1].parameters(), lr=2e-4)
+    crit = MHEntLoss()
+    for it in range(3):
+        ref = fused.step(x, y, noise=z0, N=6)
+        out = models[1].get_loss(x, y, mods=["uv"], N=6, noise=z0)
+        assert out["log_p"].requires_grad and not out["th_norm"].requires_grad
+        total, losses, _ = crit(dict(out), y)
+        opt.zero_grad()
+        total.backward()
+        if it == 0:
+            for (n, p), (_, q) in zip(models[1].named_parameters(), models[0].named_parameters()):
+                if p.grad is None:
+                    continue
+                assert_close(p.grad.cpu(), fused.grad_of(q).cpu(), 1e-5, what="grad " + n)
+        torch.nn.utils.clip_grad_norm_(models[1].parameters(), 1.0)
+        opt.step()
+        assert_close(total.detach().cpu(), ref["total"].cpu(), 1e-3 if it else 1e-6, what=f"loss at step {it}")
+    worst = max(((p.detach() - q.detach()).abs().max() / (q.detach().abs().max() + 1e-12)).item()
+                for p, q in zip(models[1].parameters(), models[0].parameters()))
+    assert worst < 5e-3, worst
