@@ -308,10 +308,12 @@ int mhe_avgpool_bwd_nhwc(const float *g, void *gx, int B, int HW, int C, int dty
 /* out[b,2i,2j,c] = g[b,i,j,c] (+ base), 0 (+ base) elsewhere; out is [B,H,W,C], g is [B,ceil(H/2),ceil(W/2),C]:
  * data gradient of stride-2 sampling (zero-dilated operand of a 3x3 data-gradient conv, or 1x1 downsample). */
 int mhe_upsample2_nhwc(const void *g, const void *base, void *out, int B, int H, int W, int C, int dtype, void *stream);
-/* Optimizer tail (hand/CrossModalHand.py:201,463-470): out[0] += |g|^2; tick: step += 1, sqnorm = 0;
+/* Optimizer tail (hand/CrossModalHand.py:201,463-470): out[0] = |g|^2 in a fixed summation order (replicas must agree
+ * bit for bit; workspace of mhe_sqnorm_workspace_floats() floats); tick: step += 1, sqnorm = 0;
  * adam: clip_grad_norm_(max_norm) (max_norm <= 0: none) folded into torch.optim.Adam's default update,
  * g pre-multiplied by grad_scale (1/world after a sum all-reduce).  step/sqnorm live in device memory. */
-int mhe_sqnorm_f32(const float *g, size_t n, float *out, void *stream);
+size_t mhe_sqnorm_workspace_floats(void);
+int mhe_sqnorm_f32(const float *g, size_t n, float *workspace, float *out, void *stream);
 int mhe_train_tick(int *step, float *sqnorm, void *stream);
 int mhe_adam_step_f32(float *p, const float *g, float *m, float *v, size_t n, const float *sqnorm, const int *step,
                       float lr, float beta1, float beta2, float eps, float max_norm, float grad_scale, void *stream);

@@ -53,7 +53,8 @@ SIGNATURES = {
     "mhe_maxpool3x3s2_bwd_nhwc": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mhe_avgpool_bwd_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mhe_upsample2_nhwc": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "mhe_sqnorm_f32": (_i, [_p, _sz, _p, _p]),
+    "mhe_sqnorm_workspace_floats": (_sz, []),
+    "mhe_sqnorm_f32": (_i, [_p, _sz, _p, _p, _p]),
     "mhe_train_tick": (_i, [_p, _p, _p]),
     "mhe_adam_step_f32": (_i, [_p] * 4 + [_sz, _p, _p] + [_f] * 6 + [_p]),
     "mhe_glow_add_image_rows_f32": (_i, [_p, _p, _l, _l, _i, _i, _i, _p]),

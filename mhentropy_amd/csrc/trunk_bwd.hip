@@ -231,15 +231,27 @@ __global__ void upsample2_kernel(const T *__restrict__ g, const T *__restrict__ 
     }
 }
 
-// sum of squares of the flat gradient buffer -> out[0] (f32 atomics of per-block f64-free partials)
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float *__restrict__ g, size_t n, float *__restrict__ out) {
+// sum of squares of the flat gradient buffer -> out[0], in a FIXED summation order (per-block partials, then one block
+// folds them): data-parallel replicas that hold the same all-reduced gradient must compute the same clip coefficient bit
+// for bit, or they drift apart (atomics would make the order, hence the rounding, vary from rank to rank)
+constexpr int SQ_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float *__restrict__ g, size_t n, float *__restrict__ partial) {
     __shared__ float red[4];
     float acc = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc = fmaf(g[i], g[i], acc);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)SQ_BLOCKS * 256) acc = fmaf(g[i], g[i], acc);
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sqnorm_final_kernel(const float *__restrict__ partial, float *__restrict__ out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < SQ_BLOCKS; i += 256) acc += partial[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // clip_grad_norm_(max_norm) folded into torch.optim.Adam's update (defaults: no weight decay, no amsgrad):
@@ -366,11 +378,12 @@ extern "C" int mhe_upsample2_nhwc(const void *g, const void *base, void *out, in
     return check_launch("upsample2_kernel");
 }
 
-extern "C" int mhe_sqnorm_f32(const float *g, size_t n, float *out, void *stream) {
-    MHE_REQUIRE(g && out && n > 0, "mhe_sqnorm_f32: bad arguments");
-    size_t blocks = (n + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(tb::sqnorm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
+extern "C" size_t mhe_sqnorm_workspace_floats(void) { return tb::SQ_BLOCKS; }
+
+extern "C" int mhe_sqnorm_f32(const float *g, size_t n, float *workspace, float *out, void *stream) {
+    MHE_REQUIRE(g && workspace && out && n > 0, "mhe_sqnorm_f32: bad arguments");
+    hipLaunchKernelGGL(tb::sqnorm_partial_kernel, dim3(tb::SQ_BLOCKS), dim3(256), 0, (hipStream_t)stream, g, n, workspace);
+    hipLaunchKernelGGL(tb::sqnorm_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, out);
     return check_launch("sqnorm_kernel");
 }
 

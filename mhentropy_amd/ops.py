@@ -498,9 +498,16 @@ def upsample2(g, H, W, base=None):
     return out
 
 
+_SQ_WS = {}
+
+
 def sqnorm(g, out):
+    """out[0] = |g|^2, summed in a fixed order (bitwise reproducible for equal inputs)"""
     _chk(g, torch.float32, "sqnorm.g"); _chk(out, torch.float32, "sqnorm.out", (1,))
-    check(_lib.lib().mhe_sqnorm_f32(_ptr(g), g.numel(), _ptr(out), _stream()), "mhe_sqnorm_f32")
+    ws = _SQ_WS.get(g.device)
+    if ws is None:
+        ws = _SQ_WS[g.device] = torch.empty(_lib.lib().mhe_sqnorm_workspace_floats(), device=g.device, dtype=torch.float32)
+    check(_lib.lib().mhe_sqnorm_f32(_ptr(g), g.numel(), _ptr(ws), _ptr(out), _stream()), "mhe_sqnorm_f32")
     return out
 
 

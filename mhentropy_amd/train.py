@@ -80,6 +80,8 @@ class TrainStep:
         self._build_trunk()
         self._build_heads()
         self._build_flow()
+        self._bucket_bounds = self._gradient_buckets()
+        self._works = []
         self.raw = torch.zeros(self._raw_n, device=self.dev, dtype=torch.float32)
         for u in self._raw_views:
             u()
@@ -112,6 +114,27 @@ class TrainStep:
         self.G = torch.zeros_like(self.P)
         self.M = torch.zeros_like(self.P)
         self.V = torch.zeros_like(self.P)
+
+    def _gradient_buckets(self):
+        """flat-buffer ranges in the order the reverse pass completes them: [l1, l2, flow, det head] (done before the trunk's
+        reverse pass starts), layer4, layer3, [stem, layer1, layer2].  Each range is un-packed and handed to RCCL as soon as
+        it is complete, so its all-reduce runs under the rest of the reverse pass."""
+        t = self.trunk
+        first = lambda mod: self.off[id(next(mod.parameters()))]
+        cuts = [0, first(t.layer3), first(t.layer4), self.off[id(self.model.feat_extractor.l1[0].weight)], self.n_params]
+        return [(cuts[i], cuts[i + 1]) for i in range(4)]           # index 3 = ready first ... index 0 = ready last
+
+    def _grad_ready(self, i):
+        lo, hi = self._bucket_bounds[i]
+        ops.gather(self.raw, self._unpack_idx[lo:hi], self.G[lo:hi])
+        if self.dist is not None and self.world > 1:
+            self._works.append(self.dist.all_reduce(self.G[lo:hi], op=self.dist.ReduceOp.SUM, async_op=True))
+
+    def finish_allreduce(self):
+        """wait for the gradient buckets' all-reduces (sum over ranks; the mean is taken by grad_scale = 1/world)"""
+        for w in self._works:
+            w.wait()
+        self._works = []
 
     def _pidx(self, p):
         """int64 index tensor shaped like p holding each element's position in the flat buffer"""
@@ -189,7 +212,7 @@ class TrainStep:
         self.blocks = []
         for li in range(4):
             for blk in getattr(t, f"layer{li + 1}"):
-                b = {"kind": blk.kind, "stride": blk.stride}
+                b = {"kind": blk.kind, "stride": blk.stride, "layer": li + 1}
                 if blk.kind == "bottleneck":
                     b["u"] = [add(blk.conv1, blk.bn1, 1, 1, 0), add(blk.conv2, blk.bn2, 3, blk.stride, 1), add(blk.conv3, blk.bn3, 1, 1, 0)]
                 else:
@@ -389,7 +412,10 @@ class TrainStep:
         pool = resnet._StatsPool(self.dev, channels=65536)
         B, Hh, Ww, Cc = self.a_last.shape
         g = ops.avgpool_bwd(g_f, Hh * Ww, self.T).view(B, Hh, Ww, Cc)
-        for b in reversed(self.blocks):
+        for bi in range(len(self.blocks) - 1, -1, -1):
+            b = self.blocks[bi]
+            if bi + 1 < len(self.blocks) and self.blocks[bi + 1]["layer"] != b["layer"] and self.blocks[bi + 1]["layer"] >= 3:
+                self._grad_ready(self.blocks[bi + 1]["layer"] - 2)      # layer4 complete -> bucket 2, layer3 -> bucket 1
             us, ud = b["u"], b["ud"]
             ul = us[-1]
             if ud is not None:
@@ -410,6 +436,7 @@ class TrainStep:
         g_r0 = ops.maxpool3x3s2_bwd(g, self.pool_idx, self.r0.shape[1], self.r0.shape[2])
         gy0 = self._bn_bwd(u, g_r0, self.r0, pool)
         ops.conv_wgrad(self.x_nhwc, gy0, 7, 7, 2, 3, u.dw)
+        self._grad_ready(0)
 
     # ------------------------------------------------------------------ flow reverse
     def _flow_backward(self, x_out, cond, g_x, g_logp, N, B):
@@ -534,10 +561,17 @@ class TrainStep:
         ops.add(g_feat, ops.linear(ghd, self.d0["wT"]))
         ops.linear_wgrad(f, g_feat, self.l1["dw"]); ops.colsum(g_feat, self.l1["db"])
         g_f = ops.linear(g_feat, self.l1["wT"])
+        self._grad_ready(3)
         if t["trunk"]:
             self._trunk_backward(g_f)
-        ops.gather(self.raw, self._unpack_idx, self.G)
+        else:
+            for i in (2, 1, 0):
+                self._grad_ready(i)
         t.update({"g_feat": g_feat, "g_th45": g45, "g_trunk_out": g_f})
+        if getattr(self.model, "_trainer", None) is self and self.world > 1:
+            # autograd-bridge use under data parallelism: torch's optimizer expects the averaged gradient in .grad
+            self.finish_allreduce()
+            self.G.mul_(1.0 / self.world)
 
     def forward_backward(self, x, y, noise=None, N=None, trunk_out=None):
         """forward + reverse pass of total = mean_b(-log_p[b]); fills self.G.  Returns the get_loss dict + 'total'."""
@@ -566,9 +600,7 @@ class TrainStep:
 
     def optimizer_step(self):
         """all-reduce (sum) over ranks, clip_grad_norm_(max_norm) and Adam in one fused pass"""
-        if self.dist is not None and self.world > 1:
-            from . import dist as mdist
-            mdist.allreduce_gradients(self.G, self.dist)
+        self.finish_allreduce()          # the buckets were handed to RCCL as the reverse pass completed them
         ops.train_tick(self.step_t, self.sq)
         if self.max_norm and self.max_norm > 0:
             ops.sqnorm(self.G, self.sq)
