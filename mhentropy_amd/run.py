@@ -1,0 +1,83 @@
+"""Training entry point with the shape of the reference's `hand/run.py` -> `CrossModalHand.train()` loop
+(hand/CrossModalHand.py:205-225 epochs + MultiStepLR, :430-470 iteration: training_step_start, model_forward =
+get_loss + the N-sample metrics pass, criterion, backward/clip/Adam, AverageMeter bookkeeping, :573-587 checkpoint),
+on synthetic batches (no dataset ships with this repository; the HO3D pipeline is out of scope).
+
+    python -m mhentropy_amd.run --backbone resnet50 --batch 256 --hyps 64 --dtype bf16 --epochs 1 --iters 20
+    python -m torch.distributed.run --nproc-per-node 8 -m mhentropy_amd.run ...      # one process per GPU, RCCL
+"""
+import argparse
+import json
+import sys
+import time
+
+import torch
+
+from . import dist as mdist, harness, synth
+from .criteria import MHEntLoss
+from .train import TrainStep
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--backbone", default="resnet50", choices=["resnet18", "resnet50"])
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU (configs/ho3d.yaml: 64)")
+    ap.add_argument("--hyps", type=int, default=10, help="hypotheses per image in the loss (the reference hard-codes 10)")
+    ap.add_argument("--test-samples", type=int, default=0, help="per-iteration metrics pass, training.test_samples (reference: 200)")
+    ap.add_argument("--hidden", type=int, default=512)
+    ap.add_argument("--flow-steps", type=int, default=6)
+    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"])
+    ap.add_argument("--lr", type=float, default=2e-4)
+    ap.add_argument("--epochs", type=int, default=1)
+    ap.add_argument("--iters", type=int, default=10, help="iterations per epoch")
+    ap.add_argument("--image-size", type=int, default=256)
+    ap.add_argument("--milestones", type=int, nargs="*", default=[150, 250])
+    ap.add_argument("--save", default="", help="write a checkpoint in the reference's container format here (rank 0)")
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args(argv)
+
+    rank, local_rank, world, dist = mdist.init()
+    if not torch.cuda.is_available():
+        raise SystemExit("mhentropy_amd.run needs a HIP device (there is no CPU path)")
+    torch.cuda.set_device(local_rank if world > 1 else 0)
+    torch.manual_seed(args.seed)                      # same initial weights on every rank
+    cd = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = harness.build_mhent(backbone=args.backbone, h_dims=(args.hidden, args.hidden), num_steps=args.flow_steps,
+                                tables=synth.mano_tables(0), compute_dtype=cd).cuda().train()
+    trainer = TrainStep(model, lr=args.lr, max_norm=1.0, dist=dist)
+    criterion = MHEntLoss()
+    meters = {"loss": harness.AverageMeter(), "epe3d": harness.AverageMeter(), "epe2d": harness.AverageMeter()}
+    step, log = 0, []
+    for epoch in range(args.epochs):
+        trainer.lr = harness.multistep_lr(args.lr, epoch, tuple(args.milestones))
+        for m in meters.values():
+            m.reset()
+        t0 = time.time()
+        for it in range(args.iters):
+            xn, yn = synth.batch(args.seed + 1000 * rank + step, args.batch, image_size=args.image_size)
+            x = torch.as_tensor(xn).cuda()
+            y = {k: torch.as_tensor(v).cuda() for k, v in yn.items()}
+            model.training_step_start(step)
+            out = trainer.step(x, y, N=args.hyps, test_samples=args.test_samples)
+            with torch.no_grad():
+                total, losses, metrics = criterion(dict(out), y)
+            meters["loss"].update(float(total))
+            if args.test_samples:
+                meters["epe3d"].update(float(metrics["eucLoss_3d_rgb_sample"].mean()))
+                meters["epe2d"].update(float(metrics["eucLoss_2d_rgb_sample"].mean()))
+            step += 1
+        torch.cuda.synchronize()
+        rec = mdist.reduce_mean_scalars({k: float(m.avg) for k, m in meters.items()}, dist, device=torch.device("cuda"))
+        rec.update(epoch=epoch, lr=trainer.lr, img_per_s=round(world * args.batch * args.iters / (time.time() - t0), 1))
+        log.append(rec)
+        if rank == 0:
+            print(json.dumps(rec), flush=True)
+    if args.save and rank == 0:
+        harness.save_model(args.save, model)
+    if dist is not None:
+        dist.destroy_process_group()
+    return log
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -363,3 +363,19 @@ def test_autograd_bridge_runs_the_references_loop_unchanged(gpu_lib):
     worst = max(((p.detach() - q.detach()).abs().max() / (q.detach().abs().max() + 1e-12)).item()
                 for p, q in zip(models[1].parameters(), models[0].parameters()))
     assert worst < 5e-3, worst
+
+
+def test_run_entry_point(gpu_lib, tmp_path):
+    """`python -m mhentropy_amd.run` (shape of the reference's run.py / CrossModalHand.train): two short epochs on synthetic
+    batches with the per-iteration metrics pass, MultiStepLR and a checkpoint in the reference's container"""
+    from mhentropy_amd import run, harness
+    ck = tmp_path / "ck.pth"
+    log = run.main(["--backbone", "resnet18", "--batch", "8", "--hyps", "6", "--test-samples", "5", "--hidden", "64", "--flow-steps", "2",
+                    "--dtype", "f32", "--epochs", "2", "--iters", "4", "--image-size", "96", "--milestones", "1", "--save", str(ck)])
+    assert len(log) == 2 and all(np.isfinite(r["loss"]) and r["epe3d"] > 0 and r["epe2d"] > 0 for r in log)
+    assert log[0]["lr"] == 2e-4 and abs(log[1]["lr"] - 2e-5) < 1e-12
+    sd = torch.load(ck)
+    assert set(sd) == {"decoderPose", "encoderRGB"} and "q_z_giv_i.s.0.l.0.weight" in sd["encoderRGB"]
+    fresh = harness.build_mhent(backbone="resnet18", h_dims=(64, 64), num_steps=2, tables=synth.mano_tables(0))
+    harness.load_model(ck, fresh)
+    assert torch.equal(fresh.det_head[0].weight, sd["encoderRGB"]["det_head.0.weight"])
