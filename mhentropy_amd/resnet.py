@@ -85,6 +85,10 @@ class ResNetTrunk(nn.Module):
         # cheaper in both dtypes (bf16 15.2 -> 13.6 ms, f32 38.9 -> 35.7 ms per C2 step); "load" stays selectable.
         import os
         self.bn_apply = os.environ.get("MHE_BN_APPLY", "pass")
+        # the 1x1 conv3 of a bottleneck reads its operand exactly once per output-channel tile: there the on-load form
+        # saves the in-place pass over y2 without the 9-tap repetition a 3x3 consumer would pay - measured equal on
+        # MI355X (C2 bf16 step 10.03 ms on-load vs 10.06 ms in-place), so the simpler in-place pass stays the default
+        self.bn_apply_1x1 = os.environ.get("MHE_BN_APPLY_1X1", "pass")
         # evaluate relu(bn3(conv3) + identity) inside the next block's conv1 (one read of the block output saved)
         self.fuse_tail = os.environ.get("MHE_FUSE_TAIL", "1") == "1"
 
@@ -111,10 +115,10 @@ class ResNetTrunk(nn.Module):
         sc = bn.weight.detach() / torch.sqrt(bn.running_var + BN_EPS)
         return sc.contiguous(), (bn.bias.detach() - bn.running_mean * sc).contiguous()
 
-    def _conv_bn(self, x, conv, bn, stats_pool, in_aff=None, stride=1, pad=0, k=1, cin_pad=None):
+    def _conv_bn(self, x, conv, bn, stats_pool, in_aff=None, stride=1, pad=0, k=1, cin_pad=None, apply=None):
         """raw conv output + this layer's BatchNorm folded to (scale, shift)."""
         w = self._w(conv, cin_pad)
-        if in_aff is not None and self.bn_apply == "pass":
+        if in_aff is not None and (apply or self.bn_apply) == "pass":
             x = ops.bn_act(x, in_aff[0], in_aff[1], relu=True, out=x)
             in_aff = None
         isc, ish = in_aff if in_aff is not None else (None, None)
@@ -149,7 +153,7 @@ class ResNetTrunk(nn.Module):
                 else:
                     y1, a1 = self._conv_bn(a, blk.conv1, blk.bn1, pool)
                 y2, a2 = self._conv_bn(y1, blk.conv2, blk.bn2, pool, a1, blk.stride, 1, 3)
-                yl, al = self._conv_bn(y2, blk.conv3, blk.bn3, pool, a2)
+                yl, al = self._conv_bn(y2, blk.conv3, blk.bn3, pool, a2, apply=self.bn_apply_1x1)
             else:
                 y1, a1 = self._conv_bn(a, blk.conv1, blk.bn1, pool, None, blk.stride, 1, 3)
                 yl, al = self._conv_bn(y1, blk.conv2, blk.bn2, pool, a1, 1, 1, 3)
