@@ -160,6 +160,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const Params p) {
 // ds_read_b64_tr_b16 (a 4-pixel x 16-channel block per 16-lane group, delivered channel-major), two reads per
 // operand fragment.  Row pitch = tile bytes + 64: the four 64-byte row segments a 32-lane half touches land in
 // four different 64-byte bank groups (pitch = 64 or 192 mod 256) -> conflict-free transposed reads.
+// Measured on MI355X at ResNet-50's shapes (tools/wgrad_bench.py, B=256): 230-515 TFLOP/s; the f32-atomic epilogue is
+// 10-35 % of a launch (main loop alone: 3x3 256ch@16x16 135 of 155 us); ~1024 workgroups with >= 512 pixels each is the
+// best split (512 or 2048 workgroups: -15 %); a 4-deep register prefetch ring ran 20 % SLOWER (116 VGPRs: 4 -> 2
+// waves/SIMD), so one stage of register prefetch under 4 co-resident workgroups per CU stays.
 typedef short v4s __attribute__((ext_vector_type(4)));
 typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
 typedef __attribute__((address_space(3))) v4s lds_v4s;
