@@ -104,6 +104,20 @@ __device__ __forceinline__ uint4 in_transform(uint4 raw, const float *sc, const 
     return Chunk<T>::pack(v);
 }
 
+// XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.  With the
+// plain (x = M tile, y = N tile) order the N tiles that re-read one activation tile run gridDim.x launches apart on
+// arbitrary XCDs; here XCD x walks M tiles x, x+8, ... and takes all N tiles of an M tile back to back, so the
+// activation tile is fetched from HBM once and re-read from that XCD's L2 (the weights are small enough to sit in every L2).
+__device__ __forceinline__ void tile_of_block(int &mt, int &nt) {
+    const int gm = gridDim.x, gn = gridDim.y;
+    mt = blockIdx.x; nt = blockIdx.y;
+    if (gn > 1 && (gm & 7) == 0) {
+        const int L = blockIdx.x + gm * blockIdx.y, slot = L >> 3;
+        nt = slot % gn;
+        mt = (slot / gn) * 8 + (L & 7);
+    }
+}
+
 // ---- epilogue shared by the conv kernels.  The accumulator holds y^T: lane (l15, q) owns channels
 // 4q..4q+3 of tile nt for tile row 16mt + l15; pix(row) maps a tile row to the global output pixel
 // index (or -1 when the row is outside the image / batch).
@@ -114,7 +128,6 @@ __device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int q = lane >> 4, l15 = lane & 15;
     const int wr = wave / WN, wc = wave % WN;
-    (void)m0;
     // ---- epilogue.  The accumulator holds y^T: lane (l15, q) owns channels 4q..4q+3 of tile nt
     // for pixel 16mt + l15.  (1) batch statistics: per-thread partials -> LDS -> one thread per
     // (statistic, channel) -> ONE coalesced f32 atomic per thread into this block's shard.
@@ -158,7 +171,7 @@ __device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, 
                 for (int l = 0; l < 16; ++l) sum += src[l];
             }
             const int n = n0 + ch;
-            if (n < p.Cout) atomicAdd(p.stats + ((size_t)(blockIdx.x % NSH) * 2 + stat) * p.Cout + n, sum);
+            if (n < p.Cout) atomicAdd(p.stats + ((size_t)((m0 / BM) % NSH) * 2 + stat) * p.Cout + n, sum);
         }
         __syncthreads();
     }
@@ -238,7 +251,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_kernel(const Params p) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int q = lane >> 4, l15 = lane & 15;
     const int wr = wave / WN, wc = wave % WN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    int mtile, ntile;
+    tile_of_block(mtile, ntile);
+    const int m0 = mtile * BM, n0 = ntile * BN;
     const int s = tid & 7, rbase = tid >> 3;
     const T *xg = reinterpret_cast<const T *>(p.x);
     const T *wg = reinterpret_cast<const T *>(p.w);
@@ -309,7 +324,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_kernel(const Params p) {
                 if ((okbits >> j) & 1u) {          // padding stays zero
                     v = in_transform<T>(v, aff[0], aff[1], c_ld, p.relu_in, dual, ra2[dual ? j : 0], p.x2_scale, p.x2_shift);
                     if constexpr (dual) {
-                        if (p.a_out && blockIdx.y == 0) *reinterpret_cast<uint4 *>(reinterpret_cast<T *>(p.a_out) + aoff[j]) = v;
+                        if (p.a_out && ntile == 0) *reinterpret_cast<uint4 *>(reinterpret_cast<T *>(p.a_out) + aoff[j]) = v;
                     }
                 }
             }
