@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libmhe_hip.so")
 SOURCES = ["api.hip", "mano.hip", "mano_bwd.hip", "flow.hip", "flow_bf16.hip", "conv.hip", "wgrad.hip", "flow_bwd.hip", "trunk_bwd.hip", "glow.hip", "metrics.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"] + os.environ.get("MHE_EXTRA_FLAGS", "").split()
 
 
 def _stale(target, deps):

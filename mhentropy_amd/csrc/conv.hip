@@ -108,10 +108,14 @@ __device__ __forceinline__ uint4 in_transform(uint4 raw, const float *sc, const 
 // plain (x = M tile, y = N tile) order the N tiles that re-read one activation tile run gridDim.x launches apart on
 // arbitrary XCDs; here XCD x walks M tiles x, x+8, ... and takes all N tiles of an M tile back to back, so the
 // activation tile is fetched from HBM once and re-read from that XCD's L2 (the weights are small enough to sit in every L2).
+#ifndef MHE_CONV_XCD_ORDER
+#define MHE_CONV_XCD_ORDER 1
+#endif
+constexpr bool XCD_ORDER = MHE_CONV_XCD_ORDER;
 __device__ __forceinline__ void tile_of_block(int &mt, int &nt) {
     const int gm = gridDim.x, gn = gridDim.y;
     mt = blockIdx.x; nt = blockIdx.y;
-    if (gn > 1 && (gm & 7) == 0) {
+    if (XCD_ORDER && gn > 1 && (gm & 7) == 0) {
         const int L = blockIdx.x + gm * blockIdx.y, slot = L >> 3;
         nt = slot % gn;
         mt = (slot / gn) * 8 + (L & 7);

