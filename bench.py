@@ -159,6 +159,8 @@ def main():
                          "python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if world == 1:
         torch.cuda.set_device(0)
+    else:           # host-side table building / synthetic data: share the node's cores between the ranks
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
     from mhentropy_amd import ops, synth
