@@ -331,6 +331,12 @@ int mhe_glow_glu_residual_f32(float *H, const float *T, const float *gate, long 
 int mhe_glow_coupling_f32(const float *u, const float *params, float *y, float *logdet, long R, int dim, int first,
                           int n_transform, int inverse, void *stream);
 int mhe_pad64_f32(const float *x, float *xp, long R, int dim, void *stream);
+/* reverse stages of the sampling direction (train step of the Glow branch; formulas in csrc/glow.hip) */
+int mhe_glow_coupling_inv_bwd_f32(const float *v, const float *params, const float *g_y, const float *g_log_p, float q_weight,
+                                  float *g_v, float *g_params, long R, int B, int dim, int first, int n_transform, void *stream);
+int mhe_glow_glu_bwd_f32(const float *g_h, const float *t3, const float *gate, long gate_stride, float *g_t3, float *g_gate_rows,
+                         long R, int C, int row_div, int n_img, void *stream);
+int mhe_relu_bwd_add_f32(float *acc, const float *g, const float *h, long n, void *stream);
 /* log_prob[r] = log N(z_r; 0, I) + sign * (logdet[r] + logdet_const); optionally un-pads v_padded into v_out [R,dim]. */
 int mhe_glow_finish_f32(const float *z_padded, const float *v_padded, const float *logdet, float *v_out, float *log_prob,
                         long R, int dim, float sign, float logdet_const, void *stream);

@@ -62,6 +62,9 @@ SIGNATURES = {
     "mhe_glow_glu_residual_f32": (_i, [_p, _p, _p, _l, _l, _i, _i, _i, _p]),
     "mhe_glow_coupling_f32": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _i, _p]),
     "mhe_pad64_f32": (_i, [_p, _p, _l, _i, _p]),
+    "mhe_glow_coupling_inv_bwd_f32": (_i, [_p, _p, _p, _p, _f, _p, _p, _l, _i, _i, _i, _i, _p]),
+    "mhe_glow_glu_bwd_f32": (_i, [_p, _p, _p, _l, _p, _p, _l, _i, _i, _i, _p]),
+    "mhe_relu_bwd_add_f32": (_i, [_p, _p, _p, _l, _p]),
     "mhe_glow_finish_f32": (_i, [_p, _p, _p, _p, _p, _l, _i, _f, _f, _p]),
     "mhe_mano_regress_joints_f32": (_i, [_p, _p, _p, _i, _p]),
     "mhe_elbo_reduce_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),

@@ -73,6 +73,65 @@ __global__ __launch_bounds__(256) void coupling_kernel(const float *__restrict__
     if (lane == 0) logdet[r] += inverse ? -ls : ls;
 }
 
+// Reverse of the INVERSE coupling (the sampling direction the train step differentiates):
+//   y_t = (v_t - shift) / scale, scale = sigmoid(us + 2) + 1e-3, and log q gains + sum_t log scale
+// given g_y = dL/dy and a_q = dL/dlog q (= g_log_p[r % B] * q_weight): g_v (identity columns pass through),
+// g_prm [R,64] = [d/d shift (T) | d/d us (T) | 0].
+__global__ __launch_bounds__(256) void coupling_inv_bwd_kernel(const float *__restrict__ v, const float *__restrict__ prm,
+                                                               const float *__restrict__ g_y, const float *__restrict__ g_logp,
+                                                               float q_weight, float *__restrict__ g_v, float *__restrict__ g_prm, long R,
+                                                               int B, int dim, int first, int T) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float gy = lane < dim ? g_y[r * 64 + lane] : 0.f;
+    float gv = gy;
+    if (lane >= 2 * T) g_prm[r * 64 + lane] = 0.f;
+    const int j = (lane - first) >> 1;
+    if (lane < dim && lane >= first && ((lane - first) & 1) == 0 && j < T) {
+        const float shift = prm[r * 64 + j], us = prm[r * 64 + T + j];
+        const float sig = 1.f / (1.f + expf(-(us + 2.f))), scale = sig + 1e-3f;
+        const float a_q = g_logp ? g_logp[r % B] * q_weight : 0.f;
+        gv = gy / scale;
+        g_prm[r * 64 + j] = -gv;
+        g_prm[r * 64 + T + j] = (-gv * (v[r * 64 + lane] - shift) / scale + a_q / scale) * sig * (1.f - sig);
+    }
+    g_v[r * 64 + lane] = lane < dim ? gv : 0.f;
+}
+
+// residual block tail reverse: H_out = H_in + T3 * sigmoid(gate[image]):  g_t3 = g_h * s,  g_gate_rows = g_h * T3 * s (1 - s)
+__global__ __launch_bounds__(256) void glu_bwd_kernel(const float *__restrict__ g_h, const float *__restrict__ t3,
+                                                      const float *__restrict__ gate, long gate_stride, float *__restrict__ g_t3,
+                                                      float *__restrict__ g_gate, long R, int C, int row_div, int n_img) {
+    const long n4 = R * C / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long r = i / (C / 4);
+        const int c = (int)(i % (C / 4)) * 4;
+        const v4f gh = *reinterpret_cast<const v4f *>(g_h + i * 4), t = *reinterpret_cast<const v4f *>(t3 + i * 4);
+        const v4f g = *reinterpret_cast<const v4f *>(gate + ((r / row_div) % n_img) * gate_stride + c);
+        v4f a, b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float s = 1.f / (1.f + expf(-g[e]));
+            a[e] = gh[e] * s;
+            b[e] = gh[e] * t[e] * s * (1.f - s);
+        }
+        *reinterpret_cast<v4f *>(g_t3 + i * 4) = a;
+        *reinterpret_cast<v4f *>(g_gate + i * 4) = b;
+    }
+}
+
+// acc += g * [h > 0]   (reverse of t = relu(h) feeding a layer, accumulated onto the residual path's gradient)
+__global__ __launch_bounds__(256) void relu_bwd_add_kernel(float *__restrict__ acc, const float *__restrict__ g, const float *__restrict__ h, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        v4f a = *reinterpret_cast<v4f *>(acc + i * 4);
+        const v4f gg = *reinterpret_cast<const v4f *>(g + i * 4), hh = *reinterpret_cast<const v4f *>(h + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] += hh[e] > 0.f ? gg[e] : 0.f;
+        *reinterpret_cast<v4f *>(acc + i * 4) = a;
+    }
+}
+
 // x [R,dim] <-> xp [R,64] zero padded; and the base density: out[r] = -|z|^2/2 - dim/2 log(2 pi) + sign * logdet[r] + const
 __global__ __launch_bounds__(256) void pad64_kernel(const float *__restrict__ x, float *__restrict__ xp, long R, int dim) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -138,4 +197,29 @@ extern "C" int mhe_glow_finish_f32(const float *z_padded, const float *v_padded,
     hipLaunchKernelGGL(glow::finish_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z_padded, v_padded, logdet, v_out,
                        log_prob, R, dim, sign, logdet_const);
     return check_launch("finish_kernel");
+}
+
+extern "C" int mhe_glow_coupling_inv_bwd_f32(const float *v, const float *params, const float *g_y, const float *g_log_p, float q_weight,
+                                             float *g_v, float *g_params, long R, int B, int dim, int first, int n_transform, void *stream) {
+    MHE_REQUIRE(v && params && g_y && g_v && g_params && R > 0 && B > 0 && dim > 0 && dim <= 64 && (first == 0 || first == 1) &&
+                    n_transform > 0 && first + 2 * (n_transform - 1) < dim && 2 * n_transform <= 64,
+                "mhe_glow_coupling_inv_bwd_f32: bad arguments");
+    hipLaunchKernelGGL(glow::coupling_inv_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, v, params, g_y, g_log_p,
+                       q_weight, g_v, g_params, R, B, dim, first, n_transform);
+    return check_launch("coupling_inv_bwd_kernel");
+}
+
+extern "C" int mhe_glow_glu_bwd_f32(const float *g_h, const float *t3, const float *gate, long gate_stride, float *g_t3, float *g_gate_rows,
+                                    long R, int C, int row_div, int n_img, void *stream) {
+    MHE_REQUIRE(g_h && t3 && gate && g_t3 && g_gate_rows && R > 0 && C > 0 && C % 4 == 0 && gate_stride % 4 == 0 && row_div > 0 && n_img > 0,
+                "mhe_glow_glu_bwd_f32: bad arguments");
+    hipLaunchKernelGGL(glow::glu_bwd_kernel, dim3(gg(R * C / 4)), dim3(256), 0, (hipStream_t)stream, g_h, t3, gate, gate_stride, g_t3, g_gate_rows,
+                       R, C, row_div, n_img);
+    return check_launch("glu_bwd_kernel");
+}
+
+extern "C" int mhe_relu_bwd_add_f32(float *acc, const float *g, const float *h, long n, void *stream) {
+    MHE_REQUIRE(acc && g && h && n > 0 && n % 4 == 0, "mhe_relu_bwd_add_f32: bad arguments");
+    hipLaunchKernelGGL(glow::relu_bwd_add_kernel, dim3(gg(n / 4)), dim3(256), 0, (hipStream_t)stream, acc, g, h, n / 4);
+    return check_launch("relu_bwd_add_kernel");
 }

@@ -94,7 +94,8 @@ class TrainStep:
         # the modules' forward paths (eval, sample) read the same device-resident operand packs, refreshed after every
         # optimizer step - no host re-pack, never stale
         self.repack()
-        self.flow._external_pack = (self.f_stream, self.f_b2, self.f_wc, self.f_bc)
+        if self.glow is None:
+            self.flow._external_pack = (self.f_stream, self.f_b2, self.f_wc, self.f_bc)
         self.trunk._external_w = {id(u.conv.weight): u.w_fwd for u in self.units}
 
     # ------------------------------------------------------------------ parameter arena
@@ -276,8 +277,15 @@ class TrainStep:
     def _build_flow(self):
         fl = self.model.q_z_giv_i
         from .flows import RealNVP
+        self.glow = None
         if not isinstance(fl, RealNVP):
-            raise NotImplementedError("TrainStep: only the shipped RealNVP flow has a reverse pass (the Glow branch is forward-only)")
+            from .glow import ConditionalGlow
+            from .train_glow import GlowPart
+            if not isinstance(fl, ConditionalGlow):
+                raise NotImplementedError(f"TrainStep: no reverse pass for {type(fl).__name__}")
+            self.flow, self.flow_bf16, self.fnets = fl, False, []
+            self.glow = GlowPart(self, fl)         # parity unpinned (third-party class absent); eager only: its 45x45
+            return                                 # re-parameterisation gradients are computed on the host
         self.flow = fl
         dim, h, ncoup = fl.dim, fl.hidden, len(fl.mask)
         bf16 = fl.compute_dtype == torch.bfloat16 and h % 128 == 0
@@ -514,16 +522,25 @@ class TrainStep:
         ver = sum(p._version for p in self._params)
         if ver != self._param_ver:           # someone else (torch.optim, load_state_dict) wrote the parameters: refresh the packs
             self.repack()
+            if self.glow is not None:
+                self.glow.invalidate()
             self._param_ver = ver
         f = self._trunk_forward(x.contiguous()) if trunk_out is None else trunk_out.contiguous()
         feat = ops.linear(f, self.l1["w"], self.l1["b"])
         hd = ops.linear(feat, self.d0["w"], self.d0["b"], relu=True)
         det = ops.linear(hd, self.d2["w"], self.d2["b"])[:, :16].contiguous()
         fl = self.flow
-        h, ncoup = fl.hidden, len(fl.mask)
-        cond = ops.linear(feat, self.f_wc, self.f_bc).view(B, 2 * ncoup, 2, h)
-        z0 = m._noise(N * B, 1.0, noise, self.dev)
-        th45, _, log_q = ops.flow_couplings(z0, cond, self.f_stream, self.f_b2, fl.mask, B, h, ops.FLOW_FORWARD)
+        if self.glow is not None:
+            if noise is not None and noise.dim() == 3:          # the reference's (B,N,45) layout -> sample-major rows
+                noise = noise.permute(1, 0, 2).reshape(N * B, 45)
+            z0 = m._noise(N * B, 1.0, noise, self.dev)
+            cond = None
+            th45, log_q = self.glow.forward(z0, feat)
+        else:
+            h, ncoup = fl.hidden, len(fl.mask)
+            cond = ops.linear(feat, self.f_wc, self.f_bc).view(B, 2 * ncoup, 2, h)
+            z0 = m._noise(N * B, 1.0, noise, self.dev)
+            th45, _, log_q = ops.flow_couplings(z0, cond, self.f_stream, self.f_b2, fl.mask, B, h, ops.FLOW_FORWARD)
         blob = m.mano_dec.table_blob()
         cu, vis = y["crop_uv"].contiguous(), y["vis"].contiguous()
         o = ops.mano_joints(th45, det, blob, cu, vis, m.b_2d, m.th45_ref_alpha, want=("log_p", "norms"))
@@ -548,16 +565,19 @@ class TrainStep:
         else:
             g_logp.copy_(g_log_p.reshape(B))
         g45, gdet_rows = self._mano_bwd(th45, det, t["blob"], t["cu"], t["vis"], g_logp, N)
-        Gc = self._flow_backward(th45, cond, g45, g_logp if m.entropy else None, N, B)
+        if self.glow is not None:
+            g_feat = self.glow.backward(g45, g_logp if m.entropy else None, N, B)
+        else:
+            Gc = self._flow_backward(th45, cond, g45, g_logp if m.entropy else None, N, B)
         # det head: gdet [B,16] -> padded [B,32]
         gdet = self._buf("gdet", (B, 32)); gdet.zero_()
         ops.sum_over_hypotheses(gdet_rows, N, B, out=gdet, out_stride=32)
         ops.linear_wgrad(hd, gdet, self.d2["dw"]); ops.colsum(gdet, self.d2["db"])
         ghd = ops.linear(gdet, self.d2["wT"]); ops.flow_lrelu_bwd(ghd, hd, slope=0.0)
         ops.linear_wgrad(feat, ghd, self.d0["dw"]); ops.colsum(ghd, self.d0["db"])
-        # conditioning projections of all nets in one pass
-        ops.linear_wgrad(feat, Gc, self.dwc); ops.colsum(Gc, self.dbc)
-        g_feat = ops.linear(Gc, self.f_wcT)
+        if self.glow is None:       # conditioning projections of all nets in one pass
+            ops.linear_wgrad(feat, Gc, self.dwc); ops.colsum(Gc, self.dbc)
+            g_feat = ops.linear(Gc, self.f_wcT)
         ops.add(g_feat, ops.linear(ghd, self.d0["wT"]))
         ops.linear_wgrad(f, g_feat, self.l1["dw"]); ops.colsum(g_feat, self.l1["db"])
         g_f = ops.linear(g_feat, self.l1["wT"])
@@ -607,6 +627,8 @@ class TrainStep:
         ops.adam_step(self.P, self.G, self.M, self.V, self.sq, self.step_t, self.lr, self.betas[0], self.betas[1], self.eps,
                       self.max_norm or 0.0, 1.0 / self.world)
         self.repack()          # every derived operand layout follows the new parameters
+        if self.glow is not None:
+            self.glow.invalidate()
         self._param_ver = sum(p._version for p in self._params)
 
     def step(self, x, y, noise=None, N=None, test_samples=0, temp=0.8):

@@ -1,0 +1,201 @@
+"""Train-step part for the conditional Glow branch (`q_z_giv_i_model == 'glow'`): the sampling pass
+`sample_and_log_prob` with a tape, and its hand-written reverse pass - what autograd does for the reference in
+`loss_ent = log_prob.mean()` (reference README.md:36-42) / hand/network.py:736-742,781-799 + CrossModalHand.py:455-470.
+
+PARITY UNPINNED like the forward (mhentropy_amd/glow.py): checked against torch autograd on the nflows restatement
+(oracle/glow_ref.py), not against the absent third-party class.
+
+Per layer (sampling order L-1 .. 0, reverse pass 0 .. L-1):
+    params = ResidualNet(v[identity columns], context);  y = (v - shift) / scale on the transform columns;  v' = Ainv y + cinv
+with (A, c) the ActNorm + LU affine map.  Dense products: mhe_linear_f32 / mhe_conv_wgrad_nhwc; elementwise stages: csrc/glow.hip.
+The gradients of the 45x45 re-parameterisation (log_scale, shift, LU entries, softplus diagonal, bias from dAinv, dcinv and the
+log-det constant) are a few 45x45 products per layer, done in float64 on the host - bookkeeping of the same kind as weight
+packing, not part of the per-hypothesis path.  Dropout is taken in eval mode (see glow.py).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops, _lib
+
+
+class GlowPart:
+    def __init__(self, ts, glow):
+        self.ts, self.g = ts, glow
+        D, H, Fc, L, NB = glow.features, glow.hidden, glow.context_features, glow.num_layers, glow.num_blocks
+        self.per = 1 + NB
+        T = glow._transform._transforms
+        slots = L * self.per
+        self.raw_wctx, self.raw_bctx = ts._raw_slot((slots * H, Fc)), ts._raw_slot((slots * H,))
+        self.layers = []
+        ar = lambda n: torch.arange(n, dtype=torch.int64)
+        for l in range(L):
+            an, lu, cp = T[3 * l], T[3 * l + 1], T[3 * l + 2]
+            net = cp.transform_net
+            idf = cp.identity_features.cpu()
+            nid, nt = idf.numel(), int(cp.transform_features.numel())
+            d = {"an": an, "lu": lu, "cp": cp, "nid": nid, "nt": nt, "idf": idf}
+            # small re-parameterisation gradients land in exact-size raw slots (written from the host chain)
+            for name, p in (("log_scale", an.log_scale), ("shift", an.shift), ("lower", lu.lower_entries), ("upper", lu.upper_entries),
+                            ("udiag", lu.unconstrained_upper_diag), ("bias", lu.bias)):
+                d["r_" + name] = ts._raw_slot(p.shape)
+                ts._map_grad(p, ar(p.numel()).view(p.shape) + d["r_" + name])
+            d["r_ainv"], d["r_cinv"] = ts._raw_slot((64, 64)), ts._raw_slot((64,))
+            d["r_wx"], d["r_wf"], d["r_bf"] = ts._raw_slot((H, 64)), ts._raw_slot((64, H)), ts._raw_slot((64,))
+            s0 = l * self.per
+            wi = torch.empty(H, nid + Fc, dtype=torch.int64)
+            wi[:, :nid] = (ar(H * 64).view(H, 64) + d["r_wx"])[:, idf]
+            wi[:, nid:] = ar(H * Fc).view(H, Fc) + self.raw_wctx + s0 * H * Fc
+            ts._map_grad(net.initial_layer.weight, wi)
+            ts._map_grad(net.initial_layer.bias, ar(H) + self.raw_bctx + s0 * H)
+            ts._map_grad(net.final_layer.weight, (ar(64 * H).view(64, H) + d["r_wf"])[:2 * nt])
+            ts._map_grad(net.final_layer.bias, ar(2 * nt) + d["r_bf"])
+            d["r_blocks"] = []
+            for b, blk in enumerate(net.blocks):
+                rb = {k: ts._raw_slot(s) for k, s in (("w0", (H, H)), ("b0", (H,)), ("w1", (H, H)), ("b1", (H,)))}
+                for j in range(2):
+                    ts._map_grad(blk.linear_layers[j].weight, ar(H * H).view(H, H) + rb[f"w{j}"])
+                    ts._map_grad(blk.linear_layers[j].bias, ar(H) + rb[f"b{j}"])
+                ts._map_grad(blk.context_layer.weight, ar(H * Fc).view(H, Fc) + self.raw_wctx + (s0 + 1 + b) * H * Fc)
+                ts._map_grad(blk.context_layer.bias, ar(H) + self.raw_bctx + (s0 + 1 + b) * H)
+                d["r_blocks"].append(rb)
+            self.layers.append(d)
+        self._tp = None
+
+    # ------------------------------------------------------------------ derived operands (rebuilt after every update)
+    def _pack(self):
+        pk = self.g._packed()
+        if "T" not in pk:
+            for d in pk["layers"]:
+                d["AinvT"] = d["Ainv"].t().contiguous()
+                d["wxT"], d["wfT"] = d["wx"].t().contiguous(), d["wf"].t().contiguous()
+                d["blocksT"] = [(w0.t().contiguous(), w1.t().contiguous()) for (w0, _, w1, _) in d["blocks"]]
+            pk["wctxT"] = pk["wctx"].t().contiguous()
+            pk["T"] = True
+        return pk
+
+    def invalidate(self):
+        self.g._pack = None
+
+    # ------------------------------------------------------------------ sampling pass with tape
+    def forward(self, z0, feat):
+        ts, g = self.ts, self.g
+        L_, D, H, B, R = _lib.lib(), g.features, g.hidden, feat.shape[0], z0.shape[0]
+        pk = self._pack()
+        s, dev = ops._stream, z0.device
+        ctab = ops.linear(feat, pk["wctx"], pk["bctx"])
+        cs = ctab.shape[1]
+        v = torch.empty(R, 64, device=dev)
+        ops.check(L_.mhe_pad64_f32(ops._ptr(z0), ops._ptr(v), R, D, s()), "mhe_pad64_f32")
+        zp = v
+        logdet = torch.zeros(R, device=dev)
+        tape = [None] * g.num_layers
+        for l in range(g.num_layers - 1, -1, -1):
+            d = pk["layers"][l]
+            slot = l * self.per
+            h = ops.linear(v, d["wx"])
+            ops.check(L_.mhe_glow_add_image_rows_f32(ops._ptr(h), C.c_void_p(ctab[:, slot * H:].data_ptr()), cs, R, H, 1, B, s()), "mhe_glow_add_image_rows_f32")
+            hs, t2s, t3s = [h], [], []
+            for b, (w0, b0, w1, b1) in enumerate(d["blocks"]):
+                t = torch.empty_like(h)
+                ops.check(L_.mhe_relu_copy_f32(ops._ptr(hs[-1]), ops._ptr(t), t.numel(), s()), "mhe_relu_copy_f32")
+                t2 = ops.linear(t, w0, b0, relu=True)
+                t3 = ops.linear(t2, w1, b1)
+                hn = hs[-1].clone()
+                ops.check(L_.mhe_glow_glu_residual_f32(ops._ptr(hn), ops._ptr(t3), C.c_void_p(ctab[:, (slot + 1 + b) * H:].data_ptr()), cs, R, H, 1, B, s()),
+                          "mhe_glow_glu_residual_f32")
+                hs.append(hn); t2s.append(t2); t3s.append(t3)
+            prm = ops.linear(hs[-1], d["wf"], d["bf"])
+            y = torch.empty(R, 64, device=dev)
+            ops.check(L_.mhe_glow_coupling_f32(ops._ptr(v), ops._ptr(prm), ops._ptr(y), ops._ptr(logdet), R, D, d["first"], d["T"], 1, s()),
+                      "mhe_glow_coupling_f32")
+            tape[l] = {"v": v, "hs": hs, "t2": t2s, "t3": t3s, "prm": prm, "y": y}
+            v = ops.linear(y, d["Ainv"], d["cinv"])
+        x = torch.empty(R, D, device=dev)
+        logq = torch.empty(R, device=dev)
+        ops.check(L_.mhe_glow_finish_f32(ops._ptr(zp), ops._ptr(v), ops._ptr(logdet), ops._ptr(x), ops._ptr(logq), R, D, -1.0, -pk["const"], s()),
+                  "mhe_glow_finish_f32")
+        self._tp = {"tape": tape, "ctab": ctab, "feat": feat}
+        return x, logq
+
+    # ------------------------------------------------------------------ reverse pass
+    def backward(self, g_x, g_logp, N, B):
+        """g_x (R,45) = dL/d sample, g_logp (B,) = dL/d log_p per image (None: no entropy term).  Writes every Glow
+        parameter's gradient into the trainer's raw arena and returns dL/d feat (B, F) through the context terms."""
+        ts, g = self.ts, self.g
+        L_, D, H, R = _lib.lib(), g.features, g.hidden, g_x.shape[0]
+        pk, tp = self._pack(), self._tp
+        s, dev = ops._stream, g_x.device
+        raw = lambda o, shape: ts._raw(o, shape)
+        ctab, cs = tp["ctab"], tp["ctab"].shape[1]
+        gv = torch.empty(R, 64, device=dev)
+        ops.check(L_.mhe_pad64_f32(ops._ptr(g_x), ops._ptr(gv), R, D, s()), "mhe_pad64_f32")
+        Gct = torch.zeros(B, cs, device=dev)
+        for l in range(g.num_layers):
+            d, rs, t = pk["layers"][l], self.layers[l], tp["tape"][l]
+            slot = l * self.per
+            ops.linear_wgrad(t["y"], gv, raw(rs["r_ainv"], (64, 64))); ops.colsum(gv, raw(rs["r_cinv"], (64,)))
+            gy = ops.linear(gv, d["AinvT"])
+            gvc, gprm = torch.empty(R, 64, device=dev), torch.empty(R, 64, device=dev)
+            ops.check(L_.mhe_glow_coupling_inv_bwd_f32(ops._ptr(t["v"]), ops._ptr(t["prm"]), ops._ptr(gy), ops._ptr(g_logp), -1.0 / N,
+                                                       ops._ptr(gvc), ops._ptr(gprm), R, B, D, d["first"], d["T"], s()), "mhe_glow_coupling_inv_bwd_f32")
+            ops.linear_wgrad(t["hs"][-1], gprm, raw(rs["r_wf"], (64, H))); ops.colsum(gprm, raw(rs["r_bf"], (64,)))
+            gh = ops.linear(gprm, d["wfT"])
+            for b in range(g.num_blocks - 1, -1, -1):
+                rb = rs["r_blocks"][b]
+                w0T, w1T = d["blocksT"][b]
+                gt3, ggate = torch.empty(R, H, device=dev), torch.empty(R, H, device=dev)
+                ops.check(L_.mhe_glow_glu_bwd_f32(ops._ptr(gh), ops._ptr(t["t3"][b]), C.c_void_p(ctab[:, (slot + 1 + b) * H:].data_ptr()), cs,
+                                                  ops._ptr(gt3), ops._ptr(ggate), R, H, 1, B, s()), "mhe_glow_glu_bwd_f32")
+                ops.sum_over_hypotheses(ggate, N, B, out=Gct[:, (slot + 1 + b) * H:], out_stride=cs)
+                ops.linear_wgrad(t["t2"][b], gt3, raw(rb["w1"], (H, H))); ops.colsum(gt3, raw(rb["b1"], (H,)))
+                gt2 = ops.linear(gt3, w1T)
+                ops.flow_lrelu_bwd(gt2, t["t2"][b], slope=0.0)
+                tt = torch.empty(R, H, device=dev)
+                ops.check(L_.mhe_relu_copy_f32(ops._ptr(t["hs"][b]), ops._ptr(tt), tt.numel(), s()), "mhe_relu_copy_f32")
+                ops.linear_wgrad(tt, gt2, raw(rb["w0"], (H, H))); ops.colsum(gt2, raw(rb["b0"], (H,)))
+                gt = ops.linear(gt2, w0T)
+                ops.check(L_.mhe_relu_bwd_add_f32(ops._ptr(gh), ops._ptr(gt), ops._ptr(t["hs"][b]), gh.numel(), s()), "mhe_relu_bwd_add_f32")
+            ops.linear_wgrad(t["v"], gh, raw(rs["r_wx"], (H, 64)))
+            ops.sum_over_hypotheses(gh, N, B, out=Gct[:, slot * H:], out_stride=cs)
+            gv = ops.add(gvc, ops.linear(gh, d["wxT"]))
+        ops.linear_wgrad(tp["feat"], Gct, raw(self.raw_wctx, (cs, g.context_features))); ops.colsum(Gct, raw(self.raw_bctx, (cs,)))
+        g_feat = ops.linear(Gct, pk["wctxT"])
+        self._reparam_backward(g_logp)
+        return g_feat
+
+    def _reparam_backward(self, g_logp):
+        """ActNorm / LU parameter gradients from dAinv, dcinv and the log-det constant (float64, host)."""
+        ts, D = self.ts, self.g.features
+        S = 0.0 if g_logp is None else -float(g_logp.double().sum())        # sum_r dL/dlog q[r]
+        for rs in self.layers:
+            an, lu = rs["an"], rs["lu"]
+            G = ts._raw(rs["r_ainv"], (64, 64))[:D, :D].double().cpu()
+            gc = ts._raw(rs["r_cinv"], (64,))[:D].double().cpu()
+            W, diag = lu.weight_and_diag()
+            s = torch.exp(an.log_scale.detach().double().cpu())
+            shift, bias = an.shift.detach().double().cpu(), lu.bias.detach().double().cpu()
+            A = W * s[None, :]
+            c = W @ shift + bias
+            Ainv = torch.linalg.inv(A)
+            G = G - torch.outer(gc, c)                           # cinv = -Ainv c
+            dc = -Ainv.t() @ gc
+            dA = -Ainv.t() @ G @ Ainv.t()
+            dW = dA * s[None, :] + torch.outer(dc, shift)
+            d_log_scale = (dA * W).sum(0) * s + S
+            d_shift = W.t() @ dc
+            # W = L U
+            Dn = lu.features
+            lower = torch.zeros(Dn, Dn, dtype=torch.float64); li = np.tril_indices(Dn, k=-1)
+            lower[li[0], li[1]] = lu.lower_entries.detach().double().cpu(); lower[range(Dn), range(Dn)] = 1.0
+            upper = torch.zeros(Dn, Dn, dtype=torch.float64); ui = np.triu_indices(Dn, k=1)
+            upper[ui[0], ui[1]] = lu.upper_entries.detach().double().cpu(); upper[range(Dn), range(Dn)] = diag
+            dL, dU = dW @ upper.t(), lower.t() @ dW
+            u = lu.unconstrained_upper_diag.detach().double().cpu()
+            d_udiag = (torch.diagonal(dU) + S / diag) * torch.sigmoid(u)
+            put = lambda key, val, p: ts._raw(rs[key], p.shape).copy_(val.to(torch.float32).reshape(p.shape).to(ts.dev))
+            put("r_log_scale", d_log_scale, an.log_scale); put("r_shift", d_shift, an.shift)
+            put("r_lower", dL[li[0], li[1]], lu.lower_entries); put("r_upper", dU[ui[0], ui[1]], lu.upper_entries)
+            put("r_udiag", d_udiag, lu.unconstrained_upper_diag); put("r_bias", dc, lu.bias)
