@@ -135,7 +135,7 @@ def main():
                     help="default: the dtype BASELINE.json's configs name for the workload (c2: bf16; c0, c1: f32)")
     ap.add_argument("--flow", default="realnvp", choices=["realnvp", "glow"],
                     help="realnvp: the flow the reference ships (configs/ho3d.yaml:39) - the measured default; glow: the 4-layer "
-                         "ConditionalGlow branch (parity unpinned, forward + loss only: no train leg, no CPU baseline)")
+                         "ConditionalGlow branch (parity unpinned; its train leg runs eagerly; no CPU baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-steps", type=int, default=5,
                     help="also time this many full train steps (forward + reverse + all-reduce + clip + Adam) for the metric's "
@@ -169,7 +169,7 @@ def main():
     log(f"building model for workload {args.workload} ({args.dtype})")
     model, sd = build_model(cfg, args.dtype, args.seed, args.flow)
     if args.flow == "glow":
-        args.train_steps, args.no_cpu_baseline = 0, True
+        args.no_cpu_baseline = True
     model = model.to(dev).train()
     # rank-private shard of synthetic images / targets / base noise, resident in HBM before timing
     x, yn = synth.batch(args.seed + 17 * rank, B, image_size=256)

@@ -30,6 +30,7 @@ class GlowPart:
         slots = L * self.per
         self.raw_wctx, self.raw_bctx = ts._raw_slot((slots * H, Fc)), ts._raw_slot((slots * H,))
         self.layers = []
+        wctx_idx, bctx_idx = [], []
         ar = lambda n: torch.arange(n, dtype=torch.int64)
         for l in range(L):
             an, lu, cp = T[3 * l], T[3 * l + 1], T[3 * l + 2]
@@ -61,31 +62,95 @@ class GlowPart:
                 ts._map_grad(blk.context_layer.weight, ar(H * Fc).view(H, Fc) + self.raw_wctx + (s0 + 1 + b) * H * Fc)
                 ts._map_grad(blk.context_layer.bias, ar(H) + self.raw_bctx + (s0 + 1 + b) * H)
                 d["r_blocks"].append(rb)
+                # operand layouts refreshed on the device by the trainer's gather tables (like every other derived weight)
+            wxi = torch.full((H, 64), -1, dtype=torch.int64)
+            wxi[:, idf] = ts._pidx(net.initial_layer.weight)[:, :nid]
+            wfi = torch.full((64, H), -1, dtype=torch.int64)
+            wfi[:2 * nt] = ts._pidx(net.final_layer.weight)
+            bfi = torch.full((64,), -1, dtype=torch.int64)
+            bfi[:2 * nt] = ts._pidx(net.final_layer.bias)
+            f32 = torch.float32
+            d["wx"], d["wxT"] = ts._derived(wxi, f32), ts._derived(wxi.t().contiguous(), f32)
+            d["wf"], d["wfT"], d["bf"] = ts._derived(wfi, f32), ts._derived(wfi.t().contiguous(), f32), ts._derived(bfi, f32)
+            d["blocks"] = [(blk.linear_layers[0].weight.data, blk.linear_layers[0].bias.data, blk.linear_layers[1].weight.data,
+                            blk.linear_layers[1].bias.data) for blk in net.blocks]
+            d["blocksT"] = [(ts._derived(ts._pidx(blk.linear_layers[0].weight).t().contiguous(), f32),
+                             ts._derived(ts._pidx(blk.linear_layers[1].weight).t().contiguous(), f32)) for blk in net.blocks]
+            d["first"], d["T"] = int(cp.transform_features[0]), nt
+            wctx_idx.append(ts._pidx(net.initial_layer.weight)[:, nid:]); bctx_idx.append(ts._pidx(net.initial_layer.bias))
+            for blk in net.blocks:
+                wctx_idx.append(ts._pidx(blk.context_layer.weight)); bctx_idx.append(ts._pidx(blk.context_layer.bias))
+            # the layer's small parameters sit next to each other in the flat buffer: one device->host copy per layer
+            small = [an.log_scale, an.shift, lu.lower_entries, lu.upper_entries, lu.unconstrained_upper_diag, lu.bias]
+            lo = min(ts.off[id(p)] for p in small)
+            hi = max(ts.off[id(p)] + p.numel() for p in small)
+            d["small"] = (lo, hi, [(ts.off[id(p)] - lo, p.numel()) for p in small])
             self.layers.append(d)
+        self.wctx = ts._derived(torch.cat(wctx_idx), torch.float32)
+        self.bctx = ts._derived(torch.cat(bctx_idx), torch.float32)
+        self.wctxT = ts._derived(torch.cat(wctx_idx).t().contiguous(), torch.float32)
+        dev = ts.dev
+        self.aff = {k: torch.zeros(L, 64, 64, device=dev) for k in ("A", "Ainv", "AinvT")}
+        self.aff.update({k: torch.zeros(L, 64, device=dev) for k in ("c", "cinv")})
+        self.const = 0.0
+        self._host = None
         self._tp = None
+        li, ui = np.tril_indices(D, k=-1), np.triu_indices(D, k=1)
+        self._li, self._ui = li, ui
 
-    # ------------------------------------------------------------------ derived operands (rebuilt after every update)
+    # ------------------------------------------------------------------ the 45x45 affine maps (host float64, tiny)
+    def _small_params(self):
+        """log_scale, shift, lower, upper, unconstrained diag, bias of every layer as float64 numpy (one small D2H per layer)"""
+        out = []
+        for d in self.layers:
+            lo, hi, parts = d["small"]
+            seg = self.ts.P[lo:hi].cpu().numpy().astype(np.float64)
+            out.append([seg[o:o + n] for o, n in parts])
+        return out
+
+    def _lu(self, lower_e, upper_e, udiag):
+        D = self.g.features
+        Lm, U = np.eye(D), np.zeros((D, D))
+        Lm[self._li] = lower_e
+        U[self._ui] = upper_e
+        diag = np.logaddexp(0.0, udiag) + self.layers[0]["lu"].eps        # softplus + eps (nflows LULinear)
+        U[np.arange(D), np.arange(D)] = diag
+        return Lm, U, diag
+
+    def refresh_affine(self):
+        """A = W diag(exp(log_scale)), c = W shift + b and their inverse, padded to 64, from the current parameters"""
+        D = self.g.features
+        host = {k: np.zeros(v.shape, np.float32) for k, v in self.aff.items()}
+        const, keep = 0.0, []
+        for l, (ls, sh, lo_e, up_e, ud, bias) in enumerate(self._small_params()):
+            Lm, U, diag = self._lu(lo_e, up_e, ud)
+            W, sc = Lm @ U, np.exp(ls)
+            A, c = W * sc[None, :], W @ sh + bias
+            Ainv = np.linalg.inv(A)
+            host["A"][l, :D, :D], host["Ainv"][l, :D, :D], host["AinvT"][l, :D, :D] = A, Ainv, Ainv.T
+            host["c"][l, :D], host["cinv"][l, :D] = c, -(Ainv @ c)
+            const += ls.sum() + np.log(diag).sum()
+            keep.append((Lm, U, diag, W, sc, sh, ud, A, c, Ainv))
+        for k, v in self.aff.items():
+            v.copy_(torch.from_numpy(host[k]))
+        self.const, self._host = float(const), keep
+
     def _pack(self):
-        pk = self.g._packed()
-        if "T" not in pk:
-            for d in pk["layers"]:
-                d["AinvT"] = d["Ainv"].t().contiguous()
-                d["wxT"], d["wfT"] = d["wx"].t().contiguous(), d["wf"].t().contiguous()
-                d["blocksT"] = [(w0.t().contiguous(), w1.t().contiguous()) for (w0, _, w1, _) in d["blocks"]]
-            pk["wctxT"] = pk["wctx"].t().contiguous()
-            pk["T"] = True
-        return pk
+        if self._host is None:
+            self.refresh_affine()
+        return self
 
     def invalidate(self):
-        self.g._pack = None
+        self._host = None
+        self.g._pack = None          # the module's own (inference) operand cache follows the new parameters too
 
     # ------------------------------------------------------------------ sampling pass with tape
     def forward(self, z0, feat):
         ts, g = self.ts, self.g
         L_, D, H, B, R = _lib.lib(), g.features, g.hidden, feat.shape[0], z0.shape[0]
-        pk = self._pack()
+        self._pack()
         s, dev = ops._stream, z0.device
-        ctab = ops.linear(feat, pk["wctx"], pk["bctx"])
+        ctab = ops.linear(feat, self.wctx, self.bctx)
         cs = ctab.shape[1]
         v = torch.empty(R, 64, device=dev)
         ops.check(L_.mhe_pad64_f32(ops._ptr(z0), ops._ptr(v), R, D, s()), "mhe_pad64_f32")
@@ -93,7 +158,7 @@ class GlowPart:
         logdet = torch.zeros(R, device=dev)
         tape = [None] * g.num_layers
         for l in range(g.num_layers - 1, -1, -1):
-            d = pk["layers"][l]
+            d = self.layers[l]
             slot = l * self.per
             h = ops.linear(v, d["wx"])
             ops.check(L_.mhe_glow_add_image_rows_f32(ops._ptr(h), C.c_void_p(ctab[:, slot * H:].data_ptr()), cs, R, H, 1, B, s()), "mhe_glow_add_image_rows_f32")
@@ -112,10 +177,10 @@ class GlowPart:
             ops.check(L_.mhe_glow_coupling_f32(ops._ptr(v), ops._ptr(prm), ops._ptr(y), ops._ptr(logdet), R, D, d["first"], d["T"], 1, s()),
                       "mhe_glow_coupling_f32")
             tape[l] = {"v": v, "hs": hs, "t2": t2s, "t3": t3s, "prm": prm, "y": y}
-            v = ops.linear(y, d["Ainv"], d["cinv"])
+            v = ops.linear(y, self.aff["Ainv"][l], self.aff["cinv"][l])
         x = torch.empty(R, D, device=dev)
         logq = torch.empty(R, device=dev)
-        ops.check(L_.mhe_glow_finish_f32(ops._ptr(zp), ops._ptr(v), ops._ptr(logdet), ops._ptr(x), ops._ptr(logq), R, D, -1.0, -pk["const"], s()),
+        ops.check(L_.mhe_glow_finish_f32(ops._ptr(zp), ops._ptr(v), ops._ptr(logdet), ops._ptr(x), ops._ptr(logq), R, D, -1.0, -self.const, s()),
                   "mhe_glow_finish_f32")
         self._tp = {"tape": tape, "ctab": ctab, "feat": feat}
         return x, logq
@@ -126,7 +191,8 @@ class GlowPart:
         parameter's gradient into the trainer's raw arena and returns dL/d feat (B, F) through the context terms."""
         ts, g = self.ts, self.g
         L_, D, H, R = _lib.lib(), g.features, g.hidden, g_x.shape[0]
-        pk, tp = self._pack(), self._tp
+        self._pack()
+        tp = self._tp
         s, dev = ops._stream, g_x.device
         raw = lambda o, shape: ts._raw(o, shape)
         ctab, cs = tp["ctab"], tp["ctab"].shape[1]
@@ -134,10 +200,11 @@ class GlowPart:
         ops.check(L_.mhe_pad64_f32(ops._ptr(g_x), ops._ptr(gv), R, D, s()), "mhe_pad64_f32")
         Gct = torch.zeros(B, cs, device=dev)
         for l in range(g.num_layers):
-            d, rs, t = pk["layers"][l], self.layers[l], tp["tape"][l]
+            d = rs = self.layers[l]
+            t = tp["tape"][l]
             slot = l * self.per
             ops.linear_wgrad(t["y"], gv, raw(rs["r_ainv"], (64, 64))); ops.colsum(gv, raw(rs["r_cinv"], (64,)))
-            gy = ops.linear(gv, d["AinvT"])
+            gy = ops.linear(gv, self.aff["AinvT"][l])
             gvc, gprm = torch.empty(R, 64, device=dev), torch.empty(R, 64, device=dev)
             ops.check(L_.mhe_glow_coupling_inv_bwd_f32(ops._ptr(t["v"]), ops._ptr(t["prm"]), ops._ptr(gy), ops._ptr(g_logp), -1.0 / N,
                                                        ops._ptr(gvc), ops._ptr(gprm), R, B, D, d["first"], d["T"], s()), "mhe_glow_coupling_inv_bwd_f32")
@@ -162,40 +229,27 @@ class GlowPart:
             ops.sum_over_hypotheses(gh, N, B, out=Gct[:, slot * H:], out_stride=cs)
             gv = ops.add(gvc, ops.linear(gh, d["wxT"]))
         ops.linear_wgrad(tp["feat"], Gct, raw(self.raw_wctx, (cs, g.context_features))); ops.colsum(Gct, raw(self.raw_bctx, (cs,)))
-        g_feat = ops.linear(Gct, pk["wctxT"])
+        g_feat = ops.linear(Gct, self.wctxT)
         self._reparam_backward(g_logp)
         return g_feat
 
     def _reparam_backward(self, g_logp):
-        """ActNorm / LU parameter gradients from dAinv, dcinv and the log-det constant (float64, host)."""
+        """ActNorm / LU parameter gradients from dAinv, dcinv and the log-det constant (float64 numpy on the host:
+        one device->host copy of the 4 x (64x64 + 64) sums, a few 45x45 products per layer, one host->device copy back)."""
         ts, D = self.ts, self.g.features
         S = 0.0 if g_logp is None else -float(g_logp.double().sum())        # sum_r dL/dlog q[r]
-        for rs in self.layers:
+        for rs, (Lm, U, diag, W, sc, sh, ud, A, c, Ainv) in zip(self.layers, self._host):
+            G = ts._raw(rs["r_ainv"], (64, 64))[:D, :D].cpu().numpy().astype(np.float64)
+            gc = ts._raw(rs["r_cinv"], (64,))[:D].cpu().numpy().astype(np.float64)
+            G = G - np.outer(gc, c)                              # cinv = -Ainv c
+            dc = -Ainv.T @ gc
+            dA = -Ainv.T @ G @ Ainv.T
+            dW = dA * sc[None, :] + np.outer(dc, sh)
+            d_log_scale = (dA * W).sum(0) * sc + S
+            d_shift = W.T @ dc
+            dL, dU = dW @ U.T, Lm.T @ dW                          # W = L U
+            d_udiag = (np.diagonal(dU) + S / diag) / (1.0 + np.exp(-ud))
             an, lu = rs["an"], rs["lu"]
-            G = ts._raw(rs["r_ainv"], (64, 64))[:D, :D].double().cpu()
-            gc = ts._raw(rs["r_cinv"], (64,))[:D].double().cpu()
-            W, diag = lu.weight_and_diag()
-            s = torch.exp(an.log_scale.detach().double().cpu())
-            shift, bias = an.shift.detach().double().cpu(), lu.bias.detach().double().cpu()
-            A = W * s[None, :]
-            c = W @ shift + bias
-            Ainv = torch.linalg.inv(A)
-            G = G - torch.outer(gc, c)                           # cinv = -Ainv c
-            dc = -Ainv.t() @ gc
-            dA = -Ainv.t() @ G @ Ainv.t()
-            dW = dA * s[None, :] + torch.outer(dc, shift)
-            d_log_scale = (dA * W).sum(0) * s + S
-            d_shift = W.t() @ dc
-            # W = L U
-            Dn = lu.features
-            lower = torch.zeros(Dn, Dn, dtype=torch.float64); li = np.tril_indices(Dn, k=-1)
-            lower[li[0], li[1]] = lu.lower_entries.detach().double().cpu(); lower[range(Dn), range(Dn)] = 1.0
-            upper = torch.zeros(Dn, Dn, dtype=torch.float64); ui = np.triu_indices(Dn, k=1)
-            upper[ui[0], ui[1]] = lu.upper_entries.detach().double().cpu(); upper[range(Dn), range(Dn)] = diag
-            dL, dU = dW @ upper.t(), lower.t() @ dW
-            u = lu.unconstrained_upper_diag.detach().double().cpu()
-            d_udiag = (torch.diagonal(dU) + S / diag) * torch.sigmoid(u)
-            put = lambda key, val, p: ts._raw(rs[key], p.shape).copy_(val.to(torch.float32).reshape(p.shape).to(ts.dev))
-            put("r_log_scale", d_log_scale, an.log_scale); put("r_shift", d_shift, an.shift)
-            put("r_lower", dL[li[0], li[1]], lu.lower_entries); put("r_upper", dU[ui[0], ui[1]], lu.upper_entries)
-            put("r_udiag", d_udiag, lu.unconstrained_upper_diag); put("r_bias", dc, lu.bias)
+            for key, val, p in (("r_log_scale", d_log_scale, an.log_scale), ("r_shift", d_shift, an.shift), ("r_lower", dL[self._li], lu.lower_entries),
+                                ("r_upper", dU[self._ui], lu.upper_entries), ("r_udiag", d_udiag, lu.unconstrained_upper_diag), ("r_bias", dc, lu.bias)):
+                ts._raw(rs[key], p.shape).copy_(torch.from_numpy(np.ascontiguousarray(val, dtype=np.float32)).reshape(p.shape))
