@@ -136,6 +136,9 @@ def main():
     ap.add_argument("--flow", default="realnvp", choices=["realnvp", "glow"],
                     help="realnvp: the flow the reference ships (configs/ho3d.yaml:39) - the measured default; glow: the 4-layer "
                          "ConditionalGlow branch (parity unpinned; its train leg runs eagerly; no CPU baseline)")
+    ap.add_argument("--no-glow-variant", action="store_true",
+                    help="skip the extra forward+loss timing of the same workload with the ConditionalGlow flow (BASELINE.json's "
+                         "configs name a 4-block Glow; the reference ships RealNVP, which stays the measured default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-steps", type=int, default=5,
                     help="also time this many full train steps (forward + reverse + all-reduce + clip + Adam) for the metric's "
@@ -230,6 +233,25 @@ def main():
             log(f"train-step leg failed: {type(e).__name__}: {e}")
             train = {"error": f"{type(e).__name__}: {e}"[:300]}
 
+    # ---- the same forward+loss workload with the Glow branch (parity unpinned), reported beside the headline, N=1 only
+    glow_variant = None
+    if args.flow == "realnvp" and world == 1 and not args.no_glow_variant:
+        try:
+            del model
+            torch.cuda.empty_cache()
+            gmodel, _ = build_model(cfg, args.dtype, args.seed, "glow")
+            gmodel = gmodel.to(dev).train()
+            gstep = lambda: gmodel.get_loss(x, y, mods=["uv"], N=K, noise=noise)
+            for _ in range(2):
+                gstep()
+            dtg = mdist.timed_region(gstep, args.steps, None, dev)
+            glow_variant = {"flow": "4-layer ConditionalGlow h=512, f32 flow (parity unpinned: third-party class absent from the reference)",
+                            "value": round(B * K * args.steps / dtg, 1), "unit": "hypotheses/s", "ms_per_step": round(dtg / args.steps * 1e3, 3),
+                            "launch": "eager"}
+            log(f"glow variant: {glow_variant['ms_per_step']} ms/step")
+        except Exception as e:
+            log(f"glow variant skipped: {type(e).__name__}: {e}")
+
     if rank == 0:
         # ---- roofline of the dominant kernel (the MFMA implicit-GEMM conv instance with the most time)
         agg = {}
@@ -273,7 +295,7 @@ def main():
                                    f"{'4-layer ConditionalGlow h=512 (parity unpinned)' if args.flow == 'glow' else str(2 * cfg['steps']) + '-coupling RealNVP h=' + str(cfg['h'])}, MANO joints, B={B}/GPU, K={K}, 256x256",
                        "images_per_gpu": B, "hypotheses_per_image": K, "global_batch": world * B,
                        "launch": "hip-graph replay" if args.graph else "eager",
-                       "img_per_s": round(world * B * args.steps / dt, 1)},
+                       "img_per_s": round(world * B * args.steps / dt, 1), "glow_variant": glow_variant},
             "train_step": train, "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
