@@ -183,6 +183,10 @@ int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *
                     const float *in_scale, const float *in_shift,
                     const float *out_scale, const float *out_shift, const void *residual,
                     float *stats, void *stream);
+/* y = (conv(x, w) + residual) * [mask > 0]: the data-gradient form (residual may be NULL; mask is shaped like y) - the
+ * ReLU gate of the tensor the gradient is taken with respect to, applied where the gradient is produced. */
+int mhe_conv2d_masked_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const void *residual,
+                           const void *mask, void *stream);
 int mhe_conv_stat_shards(void);
 /* tile the launcher picks for a geometry: 0 = 128x64, 1 = 128x128 (4 waves), 2 = 256x256 (8 waves, bf16) */
 int mhe_conv_tile(const mhe_conv_desc *d);
@@ -303,8 +307,8 @@ int mhe_bn_bwd_apply_nhwc(const void *g, const void *a, const void *y, const flo
 /* 3x3/s2/p1 max pool recording the winning tap (first maximum, as torch), and its reverse gather. */
 int mhe_maxpool3x3s2_idx_nhwc(const void *x, void *y, unsigned char *idx, int B, int H, int W, int C, int dtype, void *stream);
 int mhe_maxpool3x3s2_bwd_nhwc(const void *gy, const unsigned char *idx, void *gx, int B, int H, int W, int C, int dtype, void *stream);
-/* gx[b,p,c] = g[b,c] / HW. */
-int mhe_avgpool_bwd_nhwc(const float *g, void *gx, int B, int HW, int C, int dtype, void *stream);
+/* gx[b,p,c] = g[b,c] / HW, zeroed where mask[b,p,c] <= 0 (mask optional: ReLU gate of the pooled tensor). */
+int mhe_avgpool_bwd_nhwc(const float *g, const void *mask, void *gx, int B, int HW, int C, int dtype, void *stream);
 /* out[b,2i,2j,c] = g[b,i,j,c] (+ base), 0 (+ base) elsewhere; out is [B,H,W,C], g is [B,ceil(H/2),ceil(W/2),C]:
  * data gradient of stride-2 sampling (zero-dilated operand of a 3x3 data-gradient conv, or 1x1 downsample). */
 int mhe_upsample2_nhwc(const void *g, const void *base, void *out, int B, int H, int W, int C, int dtype, void *stream);

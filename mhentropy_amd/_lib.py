@@ -51,7 +51,7 @@ SIGNATURES = {
     "mhe_bn_bwd_apply_nhwc": (_i, [_p] * 6 + [_l, _i, _i, _p]),
     "mhe_maxpool3x3s2_idx_nhwc": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mhe_maxpool3x3s2_bwd_nhwc": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "mhe_avgpool_bwd_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "mhe_avgpool_bwd_nhwc": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "mhe_upsample2_nhwc": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mhe_sqnorm_workspace_floats": (_sz, []),
     "mhe_sqnorm_f32": (_i, [_p, _sz, _p, _p, _p]),
@@ -69,6 +69,7 @@ SIGNATURES = {
     "mhe_mano_regress_joints_f32": (_i, [_p, _p, _p, _i, _p]),
     "mhe_elbo_reduce_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
     "mhe_conv2d_nhwc": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "mhe_conv2d_masked_nhwc": (_i, [_p] * 7),
     "mhe_conv_stat_shards": (_i, []),
     "mhe_conv_tile": (_i, [C.POINTER(ConvDesc)]),
     "mhe_conv1x1_residual_in_nhwc": (_i, [C.POINTER(ConvDesc)] + [_p] * 11),

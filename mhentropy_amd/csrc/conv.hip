@@ -26,6 +26,7 @@ struct Params {
     const void *x; const void *w; void *y;
     const float *in_scale, *in_shift, *out_scale, *out_shift;
     const void *residual;
+    const void *mask;      // optional, shaped like y: outputs are zeroed where mask <= 0 (ReLU gate of a data gradient)
     float *stats;          // [NSH][2][Cout] sharded accumulators
     // dual-input prologue (1x1, stride 1): operand = relu(x*in_scale+in_shift + (x2*x2_scale+x2_shift | x2)),
     // i.e. the tail of the previous residual block evaluated on load; a_out (optional) receives it once
@@ -203,7 +204,8 @@ __device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, 
         __syncthreads();
         T *yg = reinterpret_cast<T *>(p.y);
         const T *rg = reinterpret_cast<const T *>(p.residual);
-        const bool plain = !p.out_scale && !p.out_shift && !rg && !p.relu_out;
+        const T *mk = reinterpret_cast<const T *>(p.mask);
+        const bool plain = !p.out_scale && !p.out_shift && !rg && !p.relu_out && !mk;
 #pragma unroll
         for (int j = 0; j < BM * CPR / NTH; ++j) {
             const int id = tid + NTH * j;
@@ -230,6 +232,12 @@ __device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, 
                 if (p.relu_out) {
 #pragma unroll
                     for (int i = 0; i < EPC; ++i) v[i] = fmaxf(v[i], 0.f);
+                }
+                if (mk) {
+                    float g2[EPC];
+                    Chunk<T>::unpack(*reinterpret_cast<const uint4 *>(mk + off), g2);
+#pragma unroll
+                    for (int i = 0; i < EPC; ++i) v[i] = g2[i] > 0.f ? v[i] : 0.f;
                 }
                 raw = Chunk<T>::pack(v);
             }
@@ -844,7 +852,8 @@ static inline int elem_chunk(int dtype) { return dtype == MHE_F32 ? 4 : 8; }
 
 static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
                       const float *in_shift, const float *out_scale, const float *out_shift, const void *residual,
-                      float *stats, const void *x2, const float *x2_scale, const float *x2_shift, void *a_out, void *stream);
+                      float *stats, const void *x2, const float *x2_scale, const float *x2_shift, void *a_out, void *stream,
+                      const void *mask = nullptr);
 
 extern "C" int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
                                const float *in_shift, const float *out_scale, const float *out_shift,
@@ -862,9 +871,16 @@ extern "C" int mhe_conv1x1_residual_in_nhwc(const mhe_conv_desc *d, const void *
     return conv_entry(d, x, w, y, in_scale, in_shift, nullptr, nullptr, nullptr, stats, x2, x2_scale, x2_shift, a_out, stream);
 }
 
+extern "C" int mhe_conv2d_masked_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const void *residual,
+                                      const void *mask, void *stream) {
+    MHE_REQUIRE(mask, "mhe_conv2d_masked_nhwc: mask is required");
+    return conv_entry(d, x, w, y, nullptr, nullptr, nullptr, nullptr, residual, nullptr, nullptr, nullptr, nullptr, nullptr, stream, mask);
+}
+
 static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
                       const float *in_shift, const float *out_scale, const float *out_shift, const void *residual,
-                      float *stats, const void *x2, const float *x2_scale, const float *x2_shift, void *a_out, void *stream) {
+                      float *stats, const void *x2, const float *x2_scale, const float *x2_shift, void *a_out, void *stream,
+                      const void *mask) {
     MHE_REQUIRE(d && x && w && y, "mhe_conv2d_nhwc: null pointer");
     MHE_REQUIRE(d->dtype == MHE_F32 || d->dtype == MHE_BF16, "mhe_conv2d_nhwc: dtype=%d", d->dtype);
     const int ce = elem_chunk(d->dtype), bke = 8 * ce;
@@ -876,7 +892,7 @@ static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void
     MHE_REQUIRE(!in_scale || d->Cin <= conv::MAXC, "mhe_conv2d_nhwc: fused input affine supports Cin <= %d", conv::MAXC);
     conv::Params p;
     p.x = x; p.w = w; p.y = y; p.in_scale = in_scale; p.in_shift = in_shift; p.out_scale = out_scale;
-    p.out_shift = out_shift; p.residual = residual; p.stats = stats;
+    p.out_shift = out_shift; p.residual = residual; p.stats = stats; p.mask = mask;
     p.x2 = x2; p.x2_scale = x2_scale; p.x2_shift = x2_shift; p.a_out = a_out;
     p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
     p.stride = d->stride; p.pad = d->pad;

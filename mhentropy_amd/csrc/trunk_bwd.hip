@@ -194,14 +194,20 @@ __global__ void maxpool_bwd_kernel(const T *__restrict__ gy, const unsigned char
 
 // gx[b,p,c] = g[b,c] / HW  (global average pool)
 template <typename T>
-__global__ void avgpool_bwd_kernel(const float *__restrict__ g, T *__restrict__ gx, int HW, int C, size_t n4) {
+__global__ void avgpool_bwd_kernel(const float *__restrict__ g, const T *__restrict__ mask, T *__restrict__ gx, int HW, int C, size_t n4) {
     const float inv = 1.f / (float)HW;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const size_t e = i * 4;
         const int c = (int)(e % C);
         const size_t b = e / ((size_t)HW * C);
         const float4 v = *reinterpret_cast<const float4 *>(g + b * C + c);
-        const float o[4] = {v.x * inv, v.y * inv, v.z * inv, v.w * inv};
+        float o[4] = {v.x * inv, v.y * inv, v.z * inv, v.w * inv};
+        if (mask) {
+            float mv[4];
+            load4<T>(mask + e, mv);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = mv[k] > 0.f ? o[k] : 0.f;
+        }
         store4<T>(gx + e, o);
     }
 }
@@ -357,13 +363,13 @@ extern "C" int mhe_maxpool3x3s2_bwd_nhwc(const void *gy, const unsigned char *id
     return check_launch("maxpool_bwd_kernel");
 }
 
-extern "C" int mhe_avgpool_bwd_nhwc(const float *g, void *gx, int B, int HW, int C, int dtype, void *stream) {
+extern "C" int mhe_avgpool_bwd_nhwc(const float *g, const void *mask, void *gx, int B, int HW, int C, int dtype, void *stream) {
     MHE_REQUIRE(g && gx && B > 0 && HW > 0 && C > 0 && C % 4 == 0, "mhe_avgpool_bwd_nhwc: bad arguments");
     const size_t n4 = (size_t)B * HW * C / 4;
     if (dtype == MHE_F32)
-        hipLaunchKernelGGL(tb::avgpool_bwd_kernel<float>, dim3(ewg(n4)), dim3(256), 0, (hipStream_t)stream, g, (float *)gx, HW, C, n4);
+        hipLaunchKernelGGL(tb::avgpool_bwd_kernel<float>, dim3(ewg(n4)), dim3(256), 0, (hipStream_t)stream, g, (const float *)mask, (float *)gx, HW, C, n4);
     else
-        hipLaunchKernelGGL(tb::avgpool_bwd_kernel<u16>, dim3(ewg(n4)), dim3(256), 0, (hipStream_t)stream, g, (u16 *)gx, HW, C, n4);
+        hipLaunchKernelGGL(tb::avgpool_bwd_kernel<u16>, dim3(ewg(n4)), dim3(256), 0, (hipStream_t)stream, g, (const u16 *)mask, (u16 *)gx, HW, C, n4);
     return check_launch("avgpool_bwd_kernel");
 }
 

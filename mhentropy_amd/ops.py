@@ -218,8 +218,9 @@ def metrics(xyz, uv, pose3d, scale, crop_uv, vis):
 
 
 def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in=False, out_scale=None,
-                out_shift=None, residual=None, relu_out=False, stats=None, out=None):
-    """x [B,H,W,Cin], w packed [Cout, Kpad]; returns y [B,Ho,Wo,Cout] of x.dtype."""
+                out_shift=None, residual=None, relu_out=False, stats=None, out=None, mask=None):
+    """x [B,H,W,Cin], w packed [Cout, Kpad]; returns y [B,Ho,Wo,Cout] of x.dtype.  mask (shaped like y, data-gradient
+    form only): y = (conv + residual) * [mask > 0]."""
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
     dt = x.dtype
@@ -236,6 +237,12 @@ def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in
     if stats is not None:
         _chk(stats, torch.float32, "conv.stats", (stat_shards(), 2, Cout))
     d = ConvDesc(B, H, W, Cin, Cout, KH, KW, stride, pad, dtype_code(dt), int(relu_in), int(relu_out))
+    if mask is not None:
+        if in_scale is not None or out_scale is not None or out_shift is not None or stats is not None or relu_in or relu_out:
+            raise ValueError("conv2d_nhwc: mask= is the plain data-gradient form (no affine / statistics / relu)")
+        _chk(mask, dt, "conv.mask", (B, Ho, Wo, Cout))
+        check(_lib.lib().mhe_conv2d_masked_nhwc(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _ptr(residual), _ptr(mask), _stream()), "mhe_conv2d_masked_nhwc")
+        return y
     if TIMING:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -477,11 +484,16 @@ def maxpool3x3s2_bwd(gy, idx, H, W):
     return gx
 
 
-def avgpool_bwd(g, HW, dtype):
+def avgpool_bwd(g, HW, dtype, mask=None):
+    """gx[b,p,c] = g[b,c] / HW, zeroed where mask[b,p,c] <= 0 (ReLU gate of the pooled tensor) when a mask is given"""
     B, Cc = g.shape
     _chk(g, torch.float32, "avgpool_bwd.g")
     gx = torch.empty(B, HW, Cc, device=g.device, dtype=dtype)
-    check(_lib.lib().mhe_avgpool_bwd_nhwc(_ptr(g), _ptr(gx), B, HW, Cc, dtype_code(dtype), _stream()), "mhe_avgpool_bwd_nhwc")
+    if mask is not None:
+        _chk(mask, dtype, "avgpool_bwd.mask")
+        if mask.numel() != gx.numel():
+            raise ValueError("avgpool_bwd.mask: wrong size")
+    check(_lib.lib().mhe_avgpool_bwd_nhwc(_ptr(g), _ptr(mask), _ptr(gx), B, HW, Cc, dtype_code(dtype), _stream()), "mhe_avgpool_bwd_nhwc")
     return gx
 
 

@@ -41,17 +41,20 @@ def dgrad_operand_index(idx):
     return idx.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, KH * KW * Cout)
 
 
-def conv_dgrad(gy, w_dg, k, stride, pad, H, W, residual=None):
+def conv_dgrad(gy, w_dg, k, stride, pad, H, W, residual=None, mask=None):
     """gradient of a k x k / stride / pad convolution w.r.t. its [B,H,W,Cin] input (+ residual), through the
     FORWARD implicit-GEMM kernel: stride 1 is a convolution of gy with the transposed, tap-flipped weights at
     padding k-1-pad; a stride-2 3x3 runs the same on the zero-dilated gy; a stride-2 1x1 is computed on the
-    coarse grid and scattered to the even positions."""
+    coarse grid and scattered to the even positions.  mask (the convolution's own post-ReLU input): the result is
+    gated by [mask > 0] in the kernel's epilogue, i.e. it leaves as the gradient w.r.t. the PRE-activation."""
     if stride == 1:
-        return ops.conv2d_nhwc(gy, w_dg, k, k, 1, k - 1 - pad, residual=residual)
+        return ops.conv2d_nhwc(gy, w_dg, k, k, 1, k - 1 - pad, residual=residual, mask=mask)
     if stride != 2 or k not in (1, 3):
         raise NotImplementedError(f"conv_dgrad: k={k} stride={stride}")
     if k == 3:
-        return ops.conv2d_nhwc(ops.upsample2(gy, H, W), w_dg, 3, 3, 1, 1, residual=residual)
+        return ops.conv2d_nhwc(ops.upsample2(gy, H, W), w_dg, 3, 3, 1, 1, residual=residual, mask=mask)
+    if mask is not None:
+        raise NotImplementedError("conv_dgrad: mask with a stride-2 1x1 (only the un-gated downsample branch uses it)")
     half = ops.conv2d_nhwc(gy, w_dg, 1, 1, 1, 0)
     return ops.upsample2(half, H, W, base=residual)
 
@@ -406,40 +409,45 @@ class TrainStep:
         self.a_last = a
         return ops.avgpool(a)
 
-    def _bn_bwd(self, u, g, a, pool, want_masked=False):
-        return ops.bn_backward(g, a, u.y, u.mi, u.bn.weight.data, pool.take(u.cout), u.dgamma, u.dbeta, want_masked=want_masked)
+    def _bn_bwd(self, u, g, a, pool):
+        """g: gradient w.r.t. the unit's BatchNorm OUTPUT (already ReLU-gated by its producer when a is None)"""
+        return ops.bn_backward(g, a, u.y, u.mi, u.bn.weight.data, pool.take(u.cout), u.dgamma, u.dbeta)
 
     def _wgrad(self, u, gy):
         ops.conv_wgrad(u.x, gy, u.k, u.k, u.stride, u.pad, u.dw)
 
-    def _dgrad(self, u, gy, residual=None):
-        """gradient w.r.t. the unit's input (+ residual)"""
-        return conv_dgrad(gy, u.w_dg, u.k, u.stride, u.pad, u.x.shape[1], u.x.shape[2], residual)
+    def _dgrad(self, u, gy, residual=None, gate=True):
+        """gradient w.r.t. the pre-activation of the unit's input (+ residual): every unit input in the trunk is a post-ReLU
+        tensor, so the ReLU gate [x > 0] is applied in the producing kernel's epilogue and the BatchNorm reverse passes
+        downstream read one tensor less"""
+        return conv_dgrad(gy, u.w_dg, u.k, u.stride, u.pad, u.x.shape[1], u.x.shape[2], residual, u.x if gate else None)
 
     def _trunk_backward(self, g_f):
         pool = resnet._StatsPool(self.dev, channels=65536)
         B, Hh, Ww, Cc = self.a_last.shape
-        g = ops.avgpool_bwd(g_f, Hh * Ww, self.T).view(B, Hh, Ww, Cc)
+        # g is always the gradient w.r.t. the block output's PRE-ReLU value: the gate is applied where g is produced
+        g = ops.avgpool_bwd(g_f, Hh * Ww, self.T, mask=self.a_last.view(B, Hh * Ww, Cc)).view(B, Hh, Ww, Cc)
         for bi in range(len(self.blocks) - 1, -1, -1):
             b = self.blocks[bi]
             if bi + 1 < len(self.blocks) and self.blocks[bi + 1]["layer"] != b["layer"] and self.blocks[bi + 1]["layer"] >= 3:
                 self._grad_ready(self.blocks[bi + 1]["layer"] - 2)      # layer4 complete -> bucket 2, layer3 -> bucket 1
             us, ud = b["u"], b["ud"]
             ul = us[-1]
+            gy = self._bn_bwd(ul, g, None, pool)
             if ud is not None:
-                gy = self._bn_bwd(ul, g, b["out"], pool)
-                gyd = self._bn_bwd(ud, g, b["out"], pool)
+                gyd = self._bn_bwd(ud, g, None, pool)
                 self._wgrad(ud, gyd)
-                skip = self._dgrad(ud, gyd)
+                skip = self._dgrad(ud, gyd, gate=False)          # summed with the main branch before the gate
             else:
-                gy, skip = self._bn_bwd(ul, g, b["out"], pool, want_masked=True)
+                skip = g
             for j in range(len(us) - 1, 0, -1):
                 u = us[j]
                 self._wgrad(u, gy)
                 ga = self._dgrad(u, gy)
-                gy = self._bn_bwd(us[j - 1], ga, b["acts"][j - 1], pool)
+                gy = self._bn_bwd(us[j - 1], ga, None, pool)
             self._wgrad(us[0], gy)
-            g = self._dgrad(us[0], gy, residual=skip)
+            first = bi == 0            # the first block's input is the max-pooled stem output (>= 0; the pool's reverse gates it)
+            g = self._dgrad(us[0], gy, residual=skip, gate=not first)
         u = self.stem
         g_r0 = ops.maxpool3x3s2_bwd(g, self.pool_idx, self.r0.shape[1], self.r0.shape[2])
         gy0 = self._bn_bwd(u, g_r0, self.r0, pool)
