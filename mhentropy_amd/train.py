@@ -77,7 +77,10 @@ class TrainStep:
         if self.dev.type != "cuda":
             raise RuntimeError("TrainStep needs the model on a HIP device (there is no CPU path)")
         self._flatten_params()
-        self._src_tabs = []        # (dst tensor, idx, idx2) gathers from the flat parameters, run once per step
+        # derived operand layouts: two arenas (f32 / bf16), each refreshed by ONE gather per step over one concatenated index
+        # table (a gather per tensor was ~340 launches of ~5 us)
+        self._arena = {dt: {"buf": torch.zeros(3 * self.n_params, device=self.dev, dtype=dt), "used": 0, "idx": [], "idx2": []}
+                       for dt in (torch.float32, torch.bfloat16)}
         self._raw_n = 0
         self._unpack = torch.full((self.n_params,), -1, dtype=torch.int64)
         self._build_trunk()
@@ -89,8 +92,12 @@ class TrainStep:
         for u in self._raw_views:
             u()
         self._unpack_idx = self._unpack.to(torch.int32).to(self.dev)
-        self._src_tabs = [(d, i.to(torch.int32).to(self.dev).contiguous(), None if j is None else j.to(torch.int32).to(self.dev).contiguous())
-                          for d, i, j in self._src_tabs]
+        for a in self._arena.values():
+            n = a["used"]
+            a["view"] = a["buf"][:n]
+            a["idx"] = (torch.cat(a["idx"]) if a["idx"] else torch.zeros(0, dtype=torch.int64)).to(torch.int32).to(self.dev).contiguous()
+            i2 = torch.cat(a["idx2"]) if a["idx2"] else torch.zeros(0, dtype=torch.int64)
+            a["idx2"] = i2.to(torch.int32).to(self.dev).contiguous() if bool((i2 >= 0).any()) else None
         self.step_t = torch.zeros(1, device=self.dev, dtype=torch.int32)
         self.sq = torch.zeros(1, device=self.dev, dtype=torch.float32)
         self._ws = {}
@@ -151,8 +158,16 @@ class TrainStep:
 
     def _derived(self, idx, dtype, idx2=None):
         """a tensor refreshed every step as P[idx] (+ P[idx2]); idx int64 with -1 = 0"""
-        dst = torch.zeros(idx.shape, device=self.dev, dtype=dtype)
-        self._src_tabs.append((dst, idx.reshape(-1), None if idx2 is None else idx2.reshape(-1)))
+        a = self._arena[dtype]
+        n = idx.numel()
+        room = _ceil(n, 8)                                    # 16-byte aligned views
+        if a["used"] + room > a["buf"].numel():
+            raise RuntimeError("TrainStep: derived-operand arena exhausted")
+        dst = a["buf"][a["used"]:a["used"] + n].view(idx.shape)
+        pad = torch.full((room - n,), -1, dtype=torch.int64)
+        a["idx"] += [idx.reshape(-1), pad]
+        a["idx2"] += [torch.full((n,), -1, dtype=torch.int64) if idx2 is None else idx2.reshape(-1), pad]
+        a["used"] += room
         return dst
 
     def _raw_slot(self, shape):
@@ -351,8 +366,9 @@ class TrainStep:
 
     # ------------------------------------------------------------------ per-step plumbing
     def repack(self):
-        for dst, idx, idx2 in self._src_tabs:
-            ops.gather(self.P, idx, dst.view(-1), idx2)
+        for a in self._arena.values():
+            if a["idx"].numel():
+                ops.gather(self.P, a["idx"], a["view"], a["idx2"])
 
     def _buf(self, name, shape, dtype=torch.float32):
         key = (name, tuple(shape), dtype)
