@@ -213,9 +213,10 @@ int mhe_stem_conv7x7s2(const float *x_nchw, const void *w, void *y, float *stats
  * -> affine (train mode), torch semantics
  * (momentum 0.1, eps 1e-5, unbiased running_var):
  *   mean = sum/n, var = sumsq/n - mean^2; scale = gamma/sqrt(var+eps);
- *   shift = beta - mean*scale; running stats updated in place when non-NULL. */
+ *   shift = beta - mean*scale; running stats updated in place when non-NULL;
+ *   mean_invstd [2,C] (optional) receives mean and 1/sqrt(var+eps) for the reverse pass. */
 int mhe_bn_finalize(const float *stats, const float *gamma, const float *beta,
-                    float *running_mean, float *running_var, float *scale, float *shift,
+                    float *running_mean, float *running_var, float *scale, float *shift, float *mean_invstd,
                     int C, float count, float momentum, float eps, void *stream);
 
 /* y = relu?(x*scale+shift (+ r*r_scale+r_shift | + r)) elementwise over NHWC

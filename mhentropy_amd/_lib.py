@@ -74,7 +74,7 @@ SIGNATURES = {
     "mhe_conv_tile": (_i, [C.POINTER(ConvDesc)]),
     "mhe_conv1x1_residual_in_nhwc": (_i, [C.POINTER(ConvDesc)] + [_p] * 11),
     "mhe_stem_conv7x7s2": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "mhe_bn_finalize": (_i, [_p] * 7 + [_i, _f, _f, _f, _p]),
+    "mhe_bn_finalize": (_i, [_p] * 8 + [_i, _f, _f, _f, _p]),
     "mhe_bn_act_nhwc": (_i, [_p] * 7 + [_l, _i, _i, _i, _p]),
     "mhe_maxpool3x3s2_nhwc": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mhe_avgpool_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),

@@ -671,8 +671,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ x, 
 // ---------------------------------------------------------------------------
 __global__ void bn_finalize_kernel(const float *__restrict__ stats, const float *__restrict__ gamma,
                                    const float *__restrict__ beta, float *__restrict__ rmean, float *__restrict__ rvar,
-                                   float *__restrict__ scale, float *__restrict__ shift, int C, float count, float momentum,
-                                   float eps) {
+                                   float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean_invstd, int C,
+                                   float count, float momentum, float eps) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     // shard sums are f32 (each shard holds <= M/(128*NSH) block partials); combine them in f64 so that
@@ -689,6 +689,7 @@ __global__ void bn_finalize_kernel(const float *__restrict__ stats, const float 
     const float sc = gamma[c] / sqrtf(var + eps);
     scale[c] = sc;
     shift[c] = beta[c] - mean * sc;
+    if (mean_invstd) { mean_invstd[c] = mean; mean_invstd[C + c] = 1.f / sqrtf(var + eps); }     // kept for the reverse pass
     if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
     if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * var * (count / (count - 1.f));
 }
@@ -953,11 +954,11 @@ extern "C" int mhe_linear_f32(const float *X, const float *W, const float *bias,
 }
 
 extern "C" int mhe_bn_finalize(const float *stats, const float *gamma, const float *beta, float *running_mean,
-                               float *running_var, float *scale, float *shift, int C, float count, float momentum,
-                               float eps, void *stream) {
+                               float *running_var, float *scale, float *shift, float *mean_invstd, int C, float count,
+                               float momentum, float eps, void *stream) {
     MHE_REQUIRE(stats && gamma && beta && scale && shift && C > 0 && count > 1.f, "mhe_bn_finalize: bad arguments");
     hipLaunchKernelGGL(conv::bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, gamma,
-                       beta, running_mean, running_var, scale, shift, C, count, momentum, eps);
+                       beta, running_mean, running_var, scale, shift, mean_invstd, C, count, momentum, eps);
     return check_launch("bn_finalize_kernel");
 }
 

@@ -309,14 +309,15 @@ def stem_conv7x7s2(x, w, dtype, stats=None):
     return y
 
 
-def bn_finalize(stats, gamma, beta, running_mean, running_var, count, momentum=0.1, eps=1e-5):
+def bn_finalize(stats, gamma, beta, running_mean, running_var, count, momentum=0.1, eps=1e-5, want_mean_invstd=False):
     Cn = gamma.shape[0]
     scale = torch.empty(Cn, device=gamma.device, dtype=torch.float32)
     shift = torch.empty_like(scale)
+    mi = torch.empty(2, Cn, device=gamma.device, dtype=torch.float32) if want_mean_invstd else None
     check(_lib.lib().mhe_bn_finalize(_ptr(stats), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
-                                     _ptr(scale), _ptr(shift), Cn, float(count), float(momentum), float(eps), _stream()),
+                                     _ptr(scale), _ptr(shift), _ptr(mi), Cn, float(count), float(momentum), float(eps), _stream()),
           "mhe_bn_finalize")
-    return scale, shift
+    return (scale, shift, mi) if want_mean_invstd else (scale, shift)
 
 
 def bn_act(x, scale, shift, res=None, res_scale=None, res_shift=None, relu=True, out=None):

@@ -386,8 +386,8 @@ class TrainStep:
     def _bn_tape(self, u, x, y, st):
         count = y.numel() // u.cout
         bn = u.bn
-        u.scale, u.shift = ops.bn_finalize(st, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, count, BN_MOMENTUM, BN_EPS)
-        u.mi = ops.bn_mean_invstd(st, count, BN_EPS)
+        u.scale, u.shift, u.mi = ops.bn_finalize(st, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, count, BN_MOMENTUM,
+                                                 BN_EPS, want_mean_invstd=True)
         u.x, u.y = x, y
         self._bn_touched.append(bn.num_batches_tracked)
         return y
