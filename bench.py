@@ -245,7 +245,7 @@ def main():
             for _ in range(2):
                 gstep()
             dtg = mdist.timed_region(gstep, args.steps, None, dev)
-            glow_variant = {"flow": "4-layer ConditionalGlow h=512, f32 flow (parity unpinned: third-party class absent from the reference)",
+            glow_variant = {"flow": "4-layer ConditionalGlow h=512, %s (parity unpinned: third-party class absent from the reference)" % ("bf16 hidden products, f32 elsewhere" if args.dtype == "bf16" else "f32"),
                             "value": round(B * K * args.steps / dtg, 1), "unit": "hypotheses/s", "ms_per_step": round(dtg / args.steps * 1e3, 3),
                             "launch": "eager"}
             log(f"glow variant: {glow_variant['ms_per_step']} ms/step")

@@ -329,9 +329,9 @@ int mhe_adam_step_f32(float *p, const float *g, float *m, float *v, size_t n, co
  * (oracle/glow_ref.py).  Dense products go through mhe_linear_f32; context-only terms are per image and indexed
  * by image = (row / row_div) % n_img.  The flow variable is carried zero-padded to 64 columns. */
 int mhe_glow_add_image_rows_f32(float *H, const float *img, long img_stride, long R, int C, int row_div, int n_img, void *stream);
-int mhe_relu_copy_f32(const float *in, float *out, long n, void *stream);
-int mhe_glow_glu_residual_f32(float *H, const float *T, const float *gate, long gate_stride, long R, int C, int row_div,
-                              int n_img, void *stream);
+int mhe_relu_copy_f32(const float *in, void *out, long n, int out_dtype, void *stream);          /* out f32 or bf16 */
+int mhe_glow_glu_residual_f32(float *H, const void *T, int t_dtype, const float *gate, long gate_stride, long R, int C,
+                              int row_div, int n_img, void *stream);                         /* T f32 or bf16 */
 /* params [R,64] = [shift (T) | unconstrained scale (T)]; transform feature j is column first + 2j; logdet accumulates. */
 int mhe_glow_coupling_f32(const float *u, const float *params, float *y, float *logdet, long R, int dim, int first,
                           int n_transform, int inverse, void *stream);

@@ -58,8 +58,8 @@ SIGNATURES = {
     "mhe_train_tick": (_i, [_p, _p, _p]),
     "mhe_adam_step_f32": (_i, [_p] * 4 + [_sz, _p, _p] + [_f] * 6 + [_p]),
     "mhe_glow_add_image_rows_f32": (_i, [_p, _p, _l, _l, _i, _i, _i, _p]),
-    "mhe_relu_copy_f32": (_i, [_p, _p, _l, _p]),
-    "mhe_glow_glu_residual_f32": (_i, [_p, _p, _p, _l, _l, _i, _i, _i, _p]),
+    "mhe_relu_copy_f32": (_i, [_p, _p, _l, _i, _p]),
+    "mhe_glow_glu_residual_f32": (_i, [_p, _p, _i, _p, _l, _l, _i, _i, _i, _p]),
     "mhe_glow_coupling_f32": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _i, _p]),
     "mhe_pad64_f32": (_i, [_p, _p, _l, _i, _p]),
     "mhe_glow_coupling_inv_bwd_f32": (_i, [_p, _p, _p, _p, _f, _p, _p, _l, _i, _i, _i, _i, _p]),

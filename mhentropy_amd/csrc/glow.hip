@@ -24,17 +24,20 @@ __global__ __launch_bounds__(256) void add_image_rows_kernel(float *__restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void relu_copy_kernel(const float *__restrict__ in, float *__restrict__ out, long n4) {
+template <typename TO>
+__global__ __launch_bounds__(256) void relu_copy_kernel(const float *__restrict__ in, TO *__restrict__ out, long n4) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        v4f v = *reinterpret_cast<const v4f *>(in + i * 4);
+        float v[4];
+        load4<float>(in + i * 4, v);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        *reinterpret_cast<v4f *>(out + i * 4) = v;
+        store4<TO>(out + i * 4, v);
     }
 }
 
 // residual block tail: H += T * sigmoid(gate[(image of r)])      (F.glu(cat(T, gate)) = T * sigmoid(gate))
-__global__ __launch_bounds__(256) void glu_residual_kernel(float *__restrict__ H, const float *__restrict__ T,
+template <typename TT>
+__global__ __launch_bounds__(256) void glu_residual_kernel(float *__restrict__ H, const TT *__restrict__ T,
                                                            const float *__restrict__ gate, long gate_stride, long R, int C,
                                                            int row_div, int n_img) {
     const long n4 = R * C / 4;
@@ -42,7 +45,8 @@ __global__ __launch_bounds__(256) void glu_residual_kernel(float *__restrict__ H
         const long r = i / (C / 4);
         const int c = (int)(i % (C / 4)) * 4;
         v4f h = *reinterpret_cast<v4f *>(H + i * 4);
-        const v4f t = *reinterpret_cast<const v4f *>(T + i * 4);
+        float t[4];
+        load4<TT>(T + i * 4, t);
         const v4f g = *reinterpret_cast<const v4f *>(gate + ((r / row_div) % n_img) * gate_stride + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) h[e] += t[e] / (1.f + expf(-g[e]));
@@ -162,16 +166,25 @@ extern "C" int mhe_glow_add_image_rows_f32(float *H, const float *img, long img_
     return check_launch("add_image_rows_kernel");
 }
 
-extern "C" int mhe_relu_copy_f32(const float *in, float *out, long n, void *stream) {
-    MHE_REQUIRE(in && out && n > 0 && n % 4 == 0, "mhe_relu_copy_f32: bad arguments");
-    hipLaunchKernelGGL(glow::relu_copy_kernel, dim3(gg(n / 4)), dim3(256), 0, (hipStream_t)stream, in, out, n / 4);
+extern "C" int mhe_relu_copy_f32(const float *in, void *out, long n, int out_dtype, void *stream) {
+    MHE_REQUIRE(in && out && n > 0 && n % 4 == 0 && (out_dtype == MHE_F32 || out_dtype == MHE_BF16), "mhe_relu_copy_f32: bad arguments");
+    if (out_dtype == MHE_F32)
+        hipLaunchKernelGGL(glow::relu_copy_kernel<float>, dim3(gg(n / 4)), dim3(256), 0, (hipStream_t)stream, in, (float *)out, n / 4);
+    else
+        hipLaunchKernelGGL(glow::relu_copy_kernel<u16>, dim3(gg(n / 4)), dim3(256), 0, (hipStream_t)stream, in, (u16 *)out, n / 4);
     return check_launch("relu_copy_kernel");
 }
 
-extern "C" int mhe_glow_glu_residual_f32(float *H, const float *T, const float *gate, long gate_stride, long R, int C, int row_div,
-                                         int n_img, void *stream) {
-    MHE_REQUIRE(H && T && gate && R > 0 && C > 0 && C % 4 == 0 && gate_stride % 4 == 0 && row_div > 0 && n_img > 0, "mhe_glow_glu_residual_f32: bad arguments");
-    hipLaunchKernelGGL(glow::glu_residual_kernel, dim3(gg(R * C / 4)), dim3(256), 0, (hipStream_t)stream, H, T, gate, gate_stride, R, C, row_div, n_img);
+extern "C" int mhe_glow_glu_residual_f32(float *H, const void *T, int t_dtype, const float *gate, long gate_stride, long R, int C,
+                                         int row_div, int n_img, void *stream) {
+    MHE_REQUIRE(H && T && gate && R > 0 && C > 0 && C % 4 == 0 && gate_stride % 4 == 0 && row_div > 0 && n_img > 0 &&
+                    (t_dtype == MHE_F32 || t_dtype == MHE_BF16), "mhe_glow_glu_residual_f32: bad arguments");
+    if (t_dtype == MHE_F32)
+        hipLaunchKernelGGL(glow::glu_residual_kernel<float>, dim3(gg(R * C / 4)), dim3(256), 0, (hipStream_t)stream, H, (const float *)T, gate,
+                           gate_stride, R, C, row_div, n_img);
+    else
+        hipLaunchKernelGGL(glow::glu_residual_kernel<u16>, dim3(gg(R * C / 4)), dim3(256), 0, (hipStream_t)stream, H, (const u16 *)T, gate,
+                           gate_stride, R, C, row_div, n_img);
     return check_launch("glu_residual_kernel");
 }
 

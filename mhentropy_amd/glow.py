@@ -121,6 +121,9 @@ class ConditionalGlow(nn.Module):
         self._distribution = _StandardNormal([features])
         self._embedding_net = nn.Identity()
         self._pack = None
+        # operand dtype of the four hidden x hidden products per layer (95 % of the flow's FLOP): float32 (parity mode) or
+        # bfloat16 with f32 accumulate (performance mode; forward / loss / sample only - the train step's pass stays f32)
+        self.compute_dtype = torch.float32
 
     # ---- derived device operands, rebuilt when a parameter changes --------------------------------------
     def _packed(self):
@@ -154,6 +157,8 @@ class ConditionalGlow(nn.Module):
             for blk in net.blocks:
                 d["blocks"].append(tuple(t.detach().contiguous() for t in (blk.linear_layers[0].weight, blk.linear_layers[0].bias,
                                                                          blk.linear_layers[1].weight, blk.linear_layers[1].bias)))
+                d.setdefault("blocks_bf16", []).append((blk.linear_layers[0].weight.detach().to(torch.bfloat16).contiguous(),
+                                                        blk.linear_layers[1].weight.detach().to(torch.bfloat16).contiguous()))
                 wctx.append(blk.context_layer.weight.detach()); bctx.append(blk.context_layer.bias.detach())
             nt = int(cp.transform_features.numel())
             wf = torch.zeros(64, H, device=dev); wf[:2 * nt] = net.final_layer.weight.detach()
@@ -173,11 +178,20 @@ class ConditionalGlow(nn.Module):
         ops.linear(v, d["wx"], out=h)
         cs = ctab.shape[1]
         ops.check(L.mhe_glow_add_image_rows_f32(ops._ptr(h), C.c_void_p(ctab[:, slot * H:].data_ptr()), cs, R, H, row_div, n_img, s()), "mhe_glow_add_image_rows_f32")
+        bf16 = self.compute_dtype == torch.bfloat16 and H % 64 == 0
+        if bf16:
+            tb, t2b = (torch.empty(R, 1, 1, H, device=v.device, dtype=torch.bfloat16) for _ in range(2))
         for b, (w0, b0, w1, b1) in enumerate(d["blocks"]):
-            ops.check(L.mhe_relu_copy_f32(ops._ptr(h), ops._ptr(t), h.numel(), s()), "mhe_relu_copy_f32")
-            ops.linear(t, w0, b0, relu=True, out=t2)
-            ops.linear(t2, w1, b1, out=t)
-            ops.check(L.mhe_glow_glu_residual_f32(ops._ptr(h), ops._ptr(t), C.c_void_p(ctab[:, (slot + 1 + b) * H:].data_ptr()), cs, R, H, row_div,
+            if bf16:        # relu(h) -> bf16, two h x h products on bf16 MFMA (bias + relu in the kernel's epilogue), gate in f32
+                w0b, w1b = d["blocks_bf16"][b]
+                ops.check(L.mhe_relu_copy_f32(ops._ptr(h), ops._ptr(tb), h.numel(), ops.BF16, s()), "mhe_relu_copy_f32")
+                ops.conv2d_nhwc(tb, w0b, 1, 1, 1, 0, out_shift=b0, relu_out=True, out=t2b)
+                t = ops.conv2d_nhwc(t2b, w1b, 1, 1, 1, 0, out_shift=b1, out=tb).view(R, H)
+            else:
+                ops.check(L.mhe_relu_copy_f32(ops._ptr(h), ops._ptr(t), h.numel(), ops.dtype_code(t.dtype), s()), "mhe_relu_copy_f32")
+                ops.linear(t, w0, b0, relu=True, out=t2)
+                ops.linear(t2, w1, b1, out=t)
+            ops.check(L.mhe_glow_glu_residual_f32(ops._ptr(h), ops._ptr(t), ops.dtype_code(t.dtype), C.c_void_p(ctab[:, (slot + 1 + b) * H:].data_ptr()), cs, R, H, row_div,
                                                   n_img, s()), "mhe_glow_glu_residual_f32")
         return ops.linear(h, d["wf"], d["bf"])
 

@@ -26,7 +26,7 @@ def mhent_cfgs(backbone="resnet50", h_dims=(512, 512), num_steps=6, tables=None,
 def build_mhent(**kw):
     special, common = mhent_cfgs(**kw)
     model = MHEnt(special, **common)
-    model.q_z_giv_i.compute_dtype = kw.get("compute_dtype", torch.float32)      # (the Glow branch computes in f32 regardless)
+    model.q_z_giv_i.compute_dtype = kw.get("compute_dtype", torch.float32)
     return model
 
 

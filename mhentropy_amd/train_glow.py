@@ -165,11 +165,11 @@ class GlowPart:
             hs, t2s, t3s = [h], [], []
             for b, (w0, b0, w1, b1) in enumerate(d["blocks"]):
                 t = torch.empty_like(h)
-                ops.check(L_.mhe_relu_copy_f32(ops._ptr(hs[-1]), ops._ptr(t), t.numel(), s()), "mhe_relu_copy_f32")
+                ops.check(L_.mhe_relu_copy_f32(ops._ptr(hs[-1]), ops._ptr(t), t.numel(), 0, s()), "mhe_relu_copy_f32")
                 t2 = ops.linear(t, w0, b0, relu=True)
                 t3 = ops.linear(t2, w1, b1)
                 hn = hs[-1].clone()
-                ops.check(L_.mhe_glow_glu_residual_f32(ops._ptr(hn), ops._ptr(t3), C.c_void_p(ctab[:, (slot + 1 + b) * H:].data_ptr()), cs, R, H, 1, B, s()),
+                ops.check(L_.mhe_glow_glu_residual_f32(ops._ptr(hn), ops._ptr(t3), 0, C.c_void_p(ctab[:, (slot + 1 + b) * H:].data_ptr()), cs, R, H, 1, B, s()),
                           "mhe_glow_glu_residual_f32")
                 hs.append(hn); t2s.append(t2); t3s.append(t3)
             prm = ops.linear(hs[-1], d["wf"], d["bf"])
@@ -221,7 +221,7 @@ class GlowPart:
                 gt2 = ops.linear(gt3, w1T)
                 ops.flow_lrelu_bwd(gt2, t["t2"][b], slope=0.0)
                 tt = torch.empty(R, H, device=dev)
-                ops.check(L_.mhe_relu_copy_f32(ops._ptr(t["hs"][b]), ops._ptr(tt), tt.numel(), s()), "mhe_relu_copy_f32")
+                ops.check(L_.mhe_relu_copy_f32(ops._ptr(t["hs"][b]), ops._ptr(tt), tt.numel(), 0, s()), "mhe_relu_copy_f32")
                 ops.linear_wgrad(tt, gt2, raw(rb["w0"], (H, H))); ops.colsum(gt2, raw(rb["b0"], (H,)))
                 gt = ops.linear(gt2, w0T)
                 ops.check(L_.mhe_relu_bwd_add_f32(ops._ptr(gh), ops._ptr(gt), ops._ptr(t["hs"][b]), gh.numel(), s()), "mhe_relu_bwd_add_f32")

@@ -132,3 +132,21 @@ def test_glow_train_step_gradients(gpu_lib, hidden):
     assert (ts.P - p0).abs().max() > 1e-5
     again = ts.forward(None, {k: v.cuda() for k, v in y.items()}, noise=noise.cuda(), N=N, trunk_out=f.cuda())
     assert torch.isfinite(again["log_p"]).all()
+
+
+def test_glow_bf16_products_stay_close_to_fp32(gpu_lib):
+    """performance mode: the hidden x hidden products of the coupling nets on bf16 MFMA (f32 accumulate, f32 gates and flow variable)"""
+    from oracle import glow_ref
+    g, sd = _glow(1, 512)
+    g.compute_dtype = torch.bfloat16
+    rng = np.random.default_rng(2)
+    B, N = 4, 16
+    noise = torch.as_tensor(rng.normal(0, 0.8, (B, N, 45)).astype(np.float32))
+    ctx = torch.as_tensor(rng.normal(0, 0.5, (B, 512)).astype(np.float32))
+    x_ref, lp_ref, _ = glow_ref.sample_and_log_prob(sd, noise, ctx)
+    x, lp, _ = g.sample_and_log_prob(N, noise=noise.cuda(), context=ctx.cuda())
+    assert_close(x.cpu(), x_ref, 2e-2, what="samples (bf16 products)")
+    assert_close(lp.cpu(), lp_ref, 2e-2, what="log_prob (bf16 products)")
+    g.compute_dtype = torch.float32
+    x32, _, _ = g.sample_and_log_prob(N, noise=noise.cuda(), context=ctx.cuda())
+    assert (x32.cpu() - x.cpu()).abs().max() > 0          # the two modes really are different code paths
