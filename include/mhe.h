@@ -268,8 +268,8 @@ int mhe_sum_over_hypotheses_f32(const float *rows, float *out, int N, int B, int
  * pixel-range split are added with f32 atomics.  With H = W = KH = KW = 1 it is the weight gradient of a dense
  * layer, dW[N][K] += gy[R,N]^T x[R,K] (torch.nn.Linear layout).  Cin, Cout multiples of 4. */
 int mhe_conv_wgrad_nhwc(const mhe_conv_desc *d, const void *x, const void *gy, float *dw, int ldw, void *stream);
-/* out[c] += sum_r rows[r][c] (bias gradients; caller zeroes out). */
-int mhe_colsum_f32(const float *rows, float *out, long R, int C, void *stream);
+/* out[c] += sum_r rows[r][c] (bias gradients; caller zeroes out); rows f32 or bf16, sums f32. */
+int mhe_colsum_f32(const void *rows, float *out, long R, int C, int dtype, void *stream);
 /* dst[i] = (idx[i] < 0 ? 0 : src[idx[i]]) + (idx2 != NULL && idx2[i] >= 0 ? src[idx2[i]] : 0) ; dst f32 or bf16.  Every weight re-layout of a train step (forward
  * operand packs, transposed / tap-flipped operands of the data-gradient convolutions, un-packing of weight
  * gradients into the flat gradient buffer) is one gather over an index table built once on the host. */
@@ -339,9 +339,9 @@ int mhe_pad64_f32(const float *x, float *xp, long R, int dim, void *stream);
 /* reverse stages of the sampling direction (train step of the Glow branch; formulas in csrc/glow.hip) */
 int mhe_glow_coupling_inv_bwd_f32(const float *v, const float *params, const float *g_y, const float *g_log_p, float q_weight,
                                   float *g_v, float *g_params, long R, int B, int dim, int first, int n_transform, void *stream);
-int mhe_glow_glu_bwd_f32(const float *g_h, const float *t3, const float *gate, long gate_stride, float *g_t3, float *g_gate_rows,
-                         long R, int C, int row_div, int n_img, void *stream);
-int mhe_relu_bwd_add_f32(float *acc, const float *g, const float *h, long n, void *stream);
+int mhe_glow_glu_bwd_f32(const float *g_h, const void *t3, const float *gate, long gate_stride, void *g_t3, float *g_gate_rows,
+                         long R, int C, int row_div, int n_img, int t_dtype, void *stream);     /* t3, g_t3: f32 or bf16 */
+int mhe_relu_bwd_add_f32(float *acc, const void *g, const float *h, long n, int g_dtype, void *stream);
 /* log_prob[r] = log N(z_r; 0, I) + sign * (logdet[r] + logdet_const); optionally un-pads v_padded into v_out [R,dim]. */
 int mhe_glow_finish_f32(const float *z_padded, const float *v_padded, const float *logdet, float *v_out, float *log_prob,
                         long R, int dim, float sign, float logdet_const, void *stream);

@@ -35,7 +35,7 @@ SIGNATURES = {
     "mhe_mano_joints_bwd_f32": (_i, [_p] * 8 + [_i, _i, _f, _f, _f, _p]),
     "mhe_sum_over_hypotheses_f32": (_i, [_p, _p, _i, _i, _i, _i, _l, _p]),
     "mhe_conv_wgrad_nhwc": (_i, [_p, _p, _p, _p, _i, _p]),
-    "mhe_colsum_f32": (_i, [_p, _p, _l, _i, _p]),
+    "mhe_colsum_f32": (_i, [_p, _p, _l, _i, _i, _p]),
     "mhe_gather_f32": (_i, [_p, _p, _p, _p, _sz, _i, _p]),
     "mhe_flow_mask_pad_f32": (_i, [_p, _p, _p, _l, _i, _p]),
     "mhe_flow_cond_lrelu_f32": (_i, [_p, _p, _l, _l, _i, _i, _p]),
@@ -63,8 +63,8 @@ SIGNATURES = {
     "mhe_glow_coupling_f32": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _i, _p]),
     "mhe_pad64_f32": (_i, [_p, _p, _l, _i, _p]),
     "mhe_glow_coupling_inv_bwd_f32": (_i, [_p, _p, _p, _p, _f, _p, _p, _l, _i, _i, _i, _i, _p]),
-    "mhe_glow_glu_bwd_f32": (_i, [_p, _p, _p, _l, _p, _p, _l, _i, _i, _i, _p]),
-    "mhe_relu_bwd_add_f32": (_i, [_p, _p, _p, _l, _p]),
+    "mhe_glow_glu_bwd_f32": (_i, [_p, _p, _p, _l, _p, _p, _l, _i, _i, _i, _i, _p]),
+    "mhe_relu_bwd_add_f32": (_i, [_p, _p, _p, _l, _i, _p]),
     "mhe_glow_finish_f32": (_i, [_p, _p, _p, _p, _p, _l, _i, _f, _f, _p]),
     "mhe_mano_regress_joints_f32": (_i, [_p, _p, _p, _i, _p]),
     "mhe_elbo_reduce_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),

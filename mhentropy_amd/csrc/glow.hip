@@ -104,32 +104,38 @@ __global__ __launch_bounds__(256) void coupling_inv_bwd_kernel(const float *__re
 }
 
 // residual block tail reverse: H_out = H_in + T3 * sigmoid(gate[image]):  g_t3 = g_h * s,  g_gate_rows = g_h * T3 * s (1 - s)
-__global__ __launch_bounds__(256) void glu_bwd_kernel(const float *__restrict__ g_h, const float *__restrict__ t3,
-                                                      const float *__restrict__ gate, long gate_stride, float *__restrict__ g_t3,
+template <typename TT>       // storage type of t3 and g_t3 (operands of the bf16 products in performance mode); g_gate stays f32
+__global__ __launch_bounds__(256) void glu_bwd_kernel(const float *__restrict__ g_h, const TT *__restrict__ t3,
+                                                      const float *__restrict__ gate, long gate_stride, TT *__restrict__ g_t3,
                                                       float *__restrict__ g_gate, long R, int C, int row_div, int n_img) {
     const long n4 = R * C / 4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const long r = i / (C / 4);
         const int c = (int)(i % (C / 4)) * 4;
-        const v4f gh = *reinterpret_cast<const v4f *>(g_h + i * 4), t = *reinterpret_cast<const v4f *>(t3 + i * 4);
+        const v4f gh = *reinterpret_cast<const v4f *>(g_h + i * 4);
+        float t[4], a[4];
+        load4<TT>(t3 + i * 4, t);
         const v4f g = *reinterpret_cast<const v4f *>(gate + ((r / row_div) % n_img) * gate_stride + c);
-        v4f a, b;
+        v4f b;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float s = 1.f / (1.f + expf(-g[e]));
             a[e] = gh[e] * s;
             b[e] = gh[e] * t[e] * s * (1.f - s);
         }
-        *reinterpret_cast<v4f *>(g_t3 + i * 4) = a;
+        store4<TT>(g_t3 + i * 4, a);
         *reinterpret_cast<v4f *>(g_gate + i * 4) = b;
     }
 }
 
 // acc += g * [h > 0]   (reverse of t = relu(h) feeding a layer, accumulated onto the residual path's gradient)
-__global__ __launch_bounds__(256) void relu_bwd_add_kernel(float *__restrict__ acc, const float *__restrict__ g, const float *__restrict__ h, long n4) {
+template <typename TG>
+__global__ __launch_bounds__(256) void relu_bwd_add_kernel(float *__restrict__ acc, const TG *__restrict__ g, const float *__restrict__ h, long n4) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         v4f a = *reinterpret_cast<v4f *>(acc + i * 4);
-        const v4f gg = *reinterpret_cast<const v4f *>(g + i * 4), hh = *reinterpret_cast<const v4f *>(h + i * 4);
+        float gg[4];
+        load4<TG>(g + i * 4, gg);
+        const v4f hh = *reinterpret_cast<const v4f *>(h + i * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) a[e] += hh[e] > 0.f ? gg[e] : 0.f;
         *reinterpret_cast<v4f *>(acc + i * 4) = a;
@@ -222,17 +228,24 @@ extern "C" int mhe_glow_coupling_inv_bwd_f32(const float *v, const float *params
     return check_launch("coupling_inv_bwd_kernel");
 }
 
-extern "C" int mhe_glow_glu_bwd_f32(const float *g_h, const float *t3, const float *gate, long gate_stride, float *g_t3, float *g_gate_rows,
-                                    long R, int C, int row_div, int n_img, void *stream) {
-    MHE_REQUIRE(g_h && t3 && gate && g_t3 && g_gate_rows && R > 0 && C > 0 && C % 4 == 0 && gate_stride % 4 == 0 && row_div > 0 && n_img > 0,
-                "mhe_glow_glu_bwd_f32: bad arguments");
-    hipLaunchKernelGGL(glow::glu_bwd_kernel, dim3(gg(R * C / 4)), dim3(256), 0, (hipStream_t)stream, g_h, t3, gate, gate_stride, g_t3, g_gate_rows,
-                       R, C, row_div, n_img);
+extern "C" int mhe_glow_glu_bwd_f32(const float *g_h, const void *t3, const float *gate, long gate_stride, void *g_t3, float *g_gate_rows,
+                                    long R, int C, int row_div, int n_img, int t_dtype, void *stream) {
+    MHE_REQUIRE(g_h && t3 && gate && g_t3 && g_gate_rows && R > 0 && C > 0 && C % 4 == 0 && gate_stride % 4 == 0 && row_div > 0 && n_img > 0 &&
+                    (t_dtype == MHE_F32 || t_dtype == MHE_BF16), "mhe_glow_glu_bwd_f32: bad arguments");
+    if (t_dtype == MHE_F32)
+        hipLaunchKernelGGL(glow::glu_bwd_kernel<float>, dim3(gg(R * C / 4)), dim3(256), 0, (hipStream_t)stream, g_h, (const float *)t3, gate,
+                           gate_stride, (float *)g_t3, g_gate_rows, R, C, row_div, n_img);
+    else
+        hipLaunchKernelGGL(glow::glu_bwd_kernel<u16>, dim3(gg(R * C / 4)), dim3(256), 0, (hipStream_t)stream, g_h, (const u16 *)t3, gate,
+                           gate_stride, (u16 *)g_t3, g_gate_rows, R, C, row_div, n_img);
     return check_launch("glu_bwd_kernel");
 }
 
-extern "C" int mhe_relu_bwd_add_f32(float *acc, const float *g, const float *h, long n, void *stream) {
-    MHE_REQUIRE(acc && g && h && n > 0 && n % 4 == 0, "mhe_relu_bwd_add_f32: bad arguments");
-    hipLaunchKernelGGL(glow::relu_bwd_add_kernel, dim3(gg(n / 4)), dim3(256), 0, (hipStream_t)stream, acc, g, h, n / 4);
+extern "C" int mhe_relu_bwd_add_f32(float *acc, const void *g, const float *h, long n, int g_dtype, void *stream) {
+    MHE_REQUIRE(acc && g && h && n > 0 && n % 4 == 0 && (g_dtype == MHE_F32 || g_dtype == MHE_BF16), "mhe_relu_bwd_add_f32: bad arguments");
+    if (g_dtype == MHE_F32)
+        hipLaunchKernelGGL(glow::relu_bwd_add_kernel<float>, dim3(gg(n / 4)), dim3(256), 0, (hipStream_t)stream, acc, (const float *)g, h, n / 4);
+    else
+        hipLaunchKernelGGL(glow::relu_bwd_add_kernel<u16>, dim3(gg(n / 4)), dim3(256), 0, (hipStream_t)stream, acc, (const u16 *)g, h, n / 4);
     return check_launch("relu_bwd_add_kernel");
 }

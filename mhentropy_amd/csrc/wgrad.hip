@@ -283,14 +283,18 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const Params p) {
 }
 
 // out[c] += sum_r in[r][c]  (bias gradients); one block per 64-row slab x 256 columns
-__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ in, float *__restrict__ out, long R, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ in, float *__restrict__ out, long R, int C,
                                                      int rows_per_block) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     const long r0 = (long)blockIdx.y * rows_per_block;
     const long r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
     float acc = 0.f;
-    for (long r = r0; r < r1; ++r) acc += in[r * C + c];
+    for (long r = r0; r < r1; ++r) {
+        if constexpr (sizeof(T) == 4) acc += in[r * C + c];
+        else acc += bf16_to_f32(in[r * C + c]);
+    }
     atomicAdd(out + c, acc);
 }
 
@@ -363,11 +367,14 @@ extern "C" int mhe_conv_wgrad_nhwc(const mhe_conv_desc *d, const void *x, const 
     return check_launch("wgrad_kernel");
 }
 
-extern "C" int mhe_colsum_f32(const float *rows, float *out, long R, int C, void *stream) {
-    MHE_REQUIRE(rows && out && R > 0 && C > 0, "mhe_colsum_f32: bad arguments");
+extern "C" int mhe_colsum_f32(const void *rows, float *out, long R, int C, int dtype, void *stream) {
+    MHE_REQUIRE(rows && out && R > 0 && C > 0 && (dtype == MHE_F32 || dtype == MHE_BF16), "mhe_colsum_f32: bad arguments");
     const int rpb = 64;
-    hipLaunchKernelGGL(wgrad::colsum_kernel, dim3((C + 255) / 256, (unsigned)((R + rpb - 1) / rpb)), dim3(256), 0,
-                       (hipStream_t)stream, rows, out, R, C, rpb);
+    const dim3 grid((C + 255) / 256, (unsigned)((R + rpb - 1) / rpb));
+    if (dtype == MHE_F32)
+        hipLaunchKernelGGL(wgrad::colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)rows, out, R, C, rpb);
+    else
+        hipLaunchKernelGGL(wgrad::colsum_kernel<u16>, grid, dim3(256), 0, (hipStream_t)stream, (const u16 *)rows, out, R, C, rpb);
     return check_launch("colsum_kernel");
 }
 

@@ -378,9 +378,10 @@ def linear_wgrad(x, gy, dw):
 
 def colsum(rows, out):
     """out[c] += sum_r rows[r][c]"""
-    R, Cc = rows.shape
-    _chk(rows, torch.float32, "colsum.rows"); _chk(out, torch.float32, "colsum.out", (Cc,))
-    check(_lib.lib().mhe_colsum_f32(_ptr(rows), _ptr(out), R, Cc, _stream()), "mhe_colsum_f32")
+    Cc = rows.shape[-1]
+    R = rows.numel() // Cc
+    _chk(rows, rows.dtype, "colsum.rows"); _chk(out, torch.float32, "colsum.out", (Cc,))
+    check(_lib.lib().mhe_colsum_f32(_ptr(rows), _ptr(out), R, Cc, dtype_code(rows.dtype), _stream()), "mhe_colsum_f32")
     return out
 
 

@@ -26,6 +26,7 @@ class GlowPart:
         self.ts, self.g = ts, glow
         D, H, Fc, L, NB = glow.features, glow.hidden, glow.context_features, glow.num_layers, glow.num_blocks
         self.per = 1 + NB
+        self.mixed = glow.compute_dtype == torch.bfloat16 and H % 64 == 0
         T = glow._transform._transforms
         slots = L * self.per
         self.raw_wctx, self.raw_bctx = ts._raw_slot((slots * H, Fc)), ts._raw_slot((slots * H,))
@@ -77,6 +78,11 @@ class GlowPart:
             d["blocksT"] = [(ts._derived(ts._pidx(blk.linear_layers[0].weight).t().contiguous(), f32),
                              ts._derived(ts._pidx(blk.linear_layers[1].weight).t().contiguous(), f32)) for blk in net.blocks]
             d["first"], d["T"] = int(cp.transform_features[0]), nt
+            if self.mixed:      # operands of the hidden x hidden products on bf16 MFMA (performance mode)
+                bf = torch.bfloat16
+                d["blocks_b"] = [(ts._derived(ts._pidx(blk.linear_layers[0].weight), bf), ts._derived(ts._pidx(blk.linear_layers[1].weight), bf),
+                                  ts._derived(ts._pidx(blk.linear_layers[0].weight).t().contiguous(), bf),
+                                  ts._derived(ts._pidx(blk.linear_layers[1].weight).t().contiguous(), bf)) for blk in net.blocks]
             wctx_idx.append(ts._pidx(net.initial_layer.weight)[:, nid:]); bctx_idx.append(ts._pidx(net.initial_layer.bias))
             for blk in net.blocks:
                 wctx_idx.append(ts._pidx(blk.context_layer.weight)); bctx_idx.append(ts._pidx(blk.context_layer.bias))
@@ -164,12 +170,19 @@ class GlowPart:
             ops.check(L_.mhe_glow_add_image_rows_f32(ops._ptr(h), C.c_void_p(ctab[:, slot * H:].data_ptr()), cs, R, H, 1, B, s()), "mhe_glow_add_image_rows_f32")
             hs, t2s, t3s = [h], [], []
             for b, (w0, b0, w1, b1) in enumerate(d["blocks"]):
-                t = torch.empty_like(h)
-                ops.check(L_.mhe_relu_copy_f32(ops._ptr(hs[-1]), ops._ptr(t), t.numel(), 0, s()), "mhe_relu_copy_f32")
-                t2 = ops.linear(t, w0, b0, relu=True)
-                t3 = ops.linear(t2, w1, b1)
+                if self.mixed:
+                    w0b, w1b = d["blocks_b"][b][:2]
+                    t = torch.empty(R, 1, 1, H, device=dev, dtype=torch.bfloat16)
+                    ops.check(L_.mhe_relu_copy_f32(ops._ptr(hs[-1]), ops._ptr(t), t.numel(), ops.BF16, s()), "mhe_relu_copy_f32")
+                    t2 = ops.conv2d_nhwc(t, w0b, 1, 1, 1, 0, out_shift=b0, relu_out=True)
+                    t3 = ops.conv2d_nhwc(t2, w1b, 1, 1, 1, 0, out_shift=b1)
+                else:
+                    t = torch.empty_like(h)
+                    ops.check(L_.mhe_relu_copy_f32(ops._ptr(hs[-1]), ops._ptr(t), t.numel(), 0, s()), "mhe_relu_copy_f32")
+                    t2 = ops.linear(t, w0, b0, relu=True)
+                    t3 = ops.linear(t2, w1, b1)
                 hn = hs[-1].clone()
-                ops.check(L_.mhe_glow_glu_residual_f32(ops._ptr(hn), ops._ptr(t3), 0, C.c_void_p(ctab[:, (slot + 1 + b) * H:].data_ptr()), cs, R, H, 1, B, s()),
+                ops.check(L_.mhe_glow_glu_residual_f32(ops._ptr(hn), ops._ptr(t3), ops.dtype_code(t3.dtype), C.c_void_p(ctab[:, (slot + 1 + b) * H:].data_ptr()), cs, R, H, 1, B, s()),
                           "mhe_glow_glu_residual_f32")
                 hs.append(hn); t2s.append(t2); t3s.append(t3)
             prm = ops.linear(hs[-1], d["wf"], d["bf"])
@@ -213,18 +226,31 @@ class GlowPart:
             for b in range(g.num_blocks - 1, -1, -1):
                 rb = rs["r_blocks"][b]
                 w0T, w1T = d["blocksT"][b]
-                gt3, ggate = torch.empty(R, H, device=dev), torch.empty(R, H, device=dev)
-                ops.check(L_.mhe_glow_glu_bwd_f32(ops._ptr(gh), ops._ptr(t["t3"][b]), C.c_void_p(ctab[:, (slot + 1 + b) * H:].data_ptr()), cs,
-                                                  ops._ptr(gt3), ops._ptr(ggate), R, H, 1, B, s()), "mhe_glow_glu_bwd_f32")
+                t3b, t2b = t["t3"][b], t["t2"][b]
+                gt3, ggate = torch.empty_like(t3b), torch.empty(R, H, device=dev)
+                ops.check(L_.mhe_glow_glu_bwd_f32(ops._ptr(gh), ops._ptr(t3b), C.c_void_p(ctab[:, (slot + 1 + b) * H:].data_ptr()), cs,
+                                                  ops._ptr(gt3), ops._ptr(ggate), R, H, 1, B, ops.dtype_code(t3b.dtype), s()), "mhe_glow_glu_bwd_f32")
                 ops.sum_over_hypotheses(ggate, N, B, out=Gct[:, (slot + 1 + b) * H:], out_stride=cs)
-                ops.linear_wgrad(t["t2"][b], gt3, raw(rb["w1"], (H, H))); ops.colsum(gt3, raw(rb["b1"], (H,)))
+                if self.mixed:
+                    # the four h x h products of the block's reverse pass on bf16 MFMA; bias sums from an f32 view of the bf16 gradient
+                    _, _, w0Tb, w1Tb = d["blocks_b"][b]
+                    ops.conv_wgrad(t2b, gt3, 1, 1, 1, 0, raw(rb["w1"], (H, H))); ops.colsum(gt3, raw(rb["b1"], (H,)))
+                    gt2 = ops.conv2d_nhwc(gt3, w1Tb, 1, 1, 1, 0)
+                    ops.flow_lrelu_bwd_mixed(gt2.view(R, H), t2b.view(R, H), out_bf16=gt2.view(R, H), slope=0.0)
+                    tt = torch.empty(R, 1, 1, H, device=dev, dtype=torch.bfloat16)
+                    ops.check(L_.mhe_relu_copy_f32(ops._ptr(t["hs"][b]), ops._ptr(tt), tt.numel(), ops.BF16, s()), "mhe_relu_copy_f32")
+                    ops.conv_wgrad(tt, gt2, 1, 1, 1, 0, raw(rb["w0"], (H, H))); ops.colsum(gt2, raw(rb["b0"], (H,)))
+                    gt = ops.conv2d_nhwc(gt2, w0Tb, 1, 1, 1, 0)
+                    ops.check(L_.mhe_relu_bwd_add_f32(ops._ptr(gh), ops._ptr(gt), ops._ptr(t["hs"][b]), gh.numel(), ops.BF16, s()), "mhe_relu_bwd_add_f32")
+                    continue
+                ops.linear_wgrad(t2b, gt3, raw(rb["w1"], (H, H))); ops.colsum(gt3, raw(rb["b1"], (H,)))
                 gt2 = ops.linear(gt3, w1T)
-                ops.flow_lrelu_bwd(gt2, t["t2"][b], slope=0.0)
+                ops.flow_lrelu_bwd(gt2, t2b, slope=0.0)
                 tt = torch.empty(R, H, device=dev)
                 ops.check(L_.mhe_relu_copy_f32(ops._ptr(t["hs"][b]), ops._ptr(tt), tt.numel(), 0, s()), "mhe_relu_copy_f32")
                 ops.linear_wgrad(tt, gt2, raw(rb["w0"], (H, H))); ops.colsum(gt2, raw(rb["b0"], (H,)))
                 gt = ops.linear(gt2, w0T)
-                ops.check(L_.mhe_relu_bwd_add_f32(ops._ptr(gh), ops._ptr(gt), ops._ptr(t["hs"][b]), gh.numel(), s()), "mhe_relu_bwd_add_f32")
+                ops.check(L_.mhe_relu_bwd_add_f32(ops._ptr(gh), ops._ptr(gt), ops._ptr(t["hs"][b]), gh.numel(), 0, s()), "mhe_relu_bwd_add_f32")
             ops.linear_wgrad(t["v"], gh, raw(rs["r_wx"], (H, 64)))
             ops.sum_over_hypotheses(gh, N, B, out=Gct[:, slot * H:], out_stride=cs)
             gv = ops.add(gvc, ops.linear(gh, d["wxT"]))

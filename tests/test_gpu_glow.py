@@ -150,3 +150,32 @@ def test_glow_bf16_products_stay_close_to_fp32(gpu_lib):
     g.compute_dtype = torch.float32
     x32, _, _ = g.sample_and_log_prob(N, noise=noise.cuda(), context=ctx.cuda())
     assert (x32.cpu() - x.cpu()).abs().max() > 0          # the two modes really are different code paths
+
+
+def test_glow_train_step_bf16_products(gpu_lib):
+    """performance mode of the Glow train pass (bf16 operands on the hidden x hidden products, forward and reverse): gradients within
+    bf16 rounding of the fp32 pass on the same inputs (norm-wise)"""
+    from mhentropy_amd import harness
+    from mhentropy_amd.network import MHEnt
+    from mhentropy_amd.train import TrainStep
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        special, common = harness.mhent_cfgs(backbone="resnet18", tables=synth.mano_tables(0))
+        special["q_z_giv_i_model"] = "glow"
+        model = MHEnt(special, **common)
+        model.q_z_giv_i.load_state_dict({k: torch.as_tensor(v) for k, v in synth.glow_state(3).items()}, strict=False)
+        model.load_state_dict({k: torch.as_tensor(v) for k, v in synth.head_state(4, 512).items()}, strict=False)
+        model.q_z_giv_i.compute_dtype = dt
+        model = model.cuda().train()
+        B, N = 4, 8
+        _, yn = synth.batch(5, B, with_image=False)
+        y = {k: torch.as_tensor(v).cuda() for k, v in yn.items()}
+        f = torch.as_tensor(np.random.default_rng(6).normal(0, 0.5, (B, 512)).astype(np.float32)).cuda()
+        noise = torch.as_tensor(np.random.default_rng(7).normal(0, 1, (N * B, 45)).astype(np.float32)).cuda()
+        ts = TrainStep(model)
+        assert ts.glow.mixed == (dt == torch.bfloat16)
+        out = ts.forward_backward(None, y, noise=noise, N=N, trunk_out=f)
+        res[dt] = (out["log_p"].cpu(), {n: ts.grad_of(p).cpu().double().clone() for n, p in model.named_parameters() if n.startswith("q_z_giv_i")})
+    assert_close(res[torch.bfloat16][0], res[torch.float32][0], 2e-2, what="log_p")
+    errs = sorted(((res[torch.bfloat16][1][n] - g).norm() / (g.norm() + 1e-30)).item() for n, g in res[torch.float32][1].items() if g.norm() > 0)
+    assert errs[-1] < 0.15 and errs[len(errs) // 2] < 3e-2, (errs[-3:], errs[len(errs) // 2])
