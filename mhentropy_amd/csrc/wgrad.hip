@@ -337,11 +337,12 @@ extern "C" int mhe_conv_wgrad_nhwc(const mhe_conv_desc *d, const void *x, const 
     MHE_REQUIRE(p.ldw >= p.N, "mhe_conv_wgrad_nhwc: ldw=%d < KH*KW*Cin=%d", ldw, p.N);
     p.P = (long)d->B * p.Ho * p.Wo;
     const bool small = d->Cout <= 64;
-    const int BM = small ? 64 : 128, BN = 128;
+    const bool bf16k = d->dtype == MHE_BF16 && d->Cin % 8 == 0 && d->Cout % 8 == 0 && !getenv("MHE_WGRAD_F32MFMA");
+    const bool narrow = bf16k && p.N <= 64;          // 1x1 layers with 64 input channels: a 128-wide N tile would be half empty
+    const int BM = small ? 64 : 128, BN = narrow ? 64 : 128;
     const int gx = (p.N + BN - 1) / BN, gyy = (d->Cout + BM - 1) / BM;
     // split the pixel range: enough workgroups to fill 256 CUs a few times over, but every split adds a full tile of
     // f32 atomics - the bf16 kernel (4x faster mainloop) wants longer slices
-    const bool bf16k = d->dtype == MHE_BF16 && d->Cin % 8 == 0 && d->Cout % 8 == 0 && !getenv("MHE_WGRAD_F32MFMA");
     static const long target_wgs = getenv("MHE_WGRAD_WGS") ? atol(getenv("MHE_WGRAD_WGS")) : 1024;
     long want = (bf16k ? target_wgs : 2048) / ((long)gx * gyy);
     if (want < 1) want = 1;
@@ -357,6 +358,9 @@ extern "C" int mhe_conv_wgrad_nhwc(const mhe_conv_desc *d, const void *x, const 
     if (d->dtype == MHE_F32) {
         if (small) hipLaunchKernelGGL((wgrad::wgrad_kernel<float, 64, 128>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((wgrad::wgrad_kernel<float, 128, 128>), grid, block, 0, s, p);
+    } else if (narrow) {
+        if (small) hipLaunchKernelGGL((wgrad::wgrad_bf16_kernel<64, 64, 2, 2>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((wgrad::wgrad_bf16_kernel<128, 64, 4, 1>), grid, block, 0, s, p);
     } else if (bf16k) {
         if (small) hipLaunchKernelGGL((wgrad::wgrad_bf16_kernel<64, 128, 1, 4>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((wgrad::wgrad_bf16_kernel<128, 128, 2, 2>), grid, block, 0, s, p);
