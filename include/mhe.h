@@ -184,9 +184,13 @@ int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *
                     const float *out_scale, const float *out_shift, const void *residual,
                     float *stats, void *stream);
 /* y = (conv(x, w) + residual) * [mask > 0]: the data-gradient form (residual may be NULL; mask is shaped like y) - the
- * ReLU gate of the tensor the gradient is taken with respect to, applied where the gradient is produced. */
+ * ReLU gate of the tensor the gradient is taken with respect to, applied where the gradient is produced.  Optionally the
+ * epilogue also accumulates the BatchNorm-reverse statistics of y for up to two BN units whose raw outputs bn_y* are shaped
+ * like y (the tail of a residual block feeds bn3 and the downsample's BN): bn_stats*[shard][0][c] += sum y,
+ * [1][c] += sum y (bn_y - mean) invstd, exactly what mhe_bn_bwd_reduce_nhwc would compute in a separate pass. */
 int mhe_conv2d_masked_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const void *residual,
-                           const void *mask, void *stream);
+                           const void *mask, const void *bn_y0, const float *bn_mean_invstd0, float *bn_stats0,
+                           const void *bn_y1, const float *bn_mean_invstd1, float *bn_stats1, void *stream);
 int mhe_conv_stat_shards(void);
 /* tile the launcher picks for a geometry: 0 = 128x64, 1 = 128x128 (4 waves), 2 = 256x256 (8 waves, bf16) */
 int mhe_conv_tile(const mhe_conv_desc *d);

@@ -27,6 +27,9 @@ struct Params {
     const float *in_scale, *in_shift, *out_scale, *out_shift;
     const void *residual;
     const void *mask;      // optional, shaped like y: outputs are zeroed where mask <= 0 (ReLU gate of a data gradient)
+    // optional BatchNorm-reverse statistics of the (gated) outputs g: for up to two BN units whose raw outputs bn_y[u] are shaped like y,
+    // bn_stats[u][shard][0][c] += sum g, [1][c] += sum g * (bn_y - mean) * invstd   (bn_mi[u] = [mean | invstd])
+    const void *bn_y[2]; const float *bn_mi[2]; float *bn_stats[2];
     float *stats;          // [NSH][2][Cout] sharded accumulators
     // dual-input prologue (1x1, stride 1): operand = relu(x*in_scale+in_shift + (x2*x2_scale+x2_shift | x2)),
     // i.e. the tail of the previous residual block evaluated on load; a_out (optional) receives it once
@@ -113,6 +116,10 @@ __device__ __forceinline__ uint4 in_transform(uint4 raw, const float *sc, const 
 #define MHE_CONV_XCD_ORDER 1
 #endif
 constexpr bool XCD_ORDER = MHE_CONV_XCD_ORDER;
+#ifndef MHE_CONV_BN_EPILOGUE
+#define MHE_CONV_BN_EPILOGUE 1
+#endif
+constexpr bool BN_EPILOGUE = MHE_CONV_BN_EPILOGUE;      // measurement switch for the BatchNorm-reverse sums in the epilogue
 __device__ __forceinline__ void tile_of_block(int &mt, int &nt) {
     const int gm = gridDim.x, gn = gridDim.y;
     mt = blockIdx.x; nt = blockIdx.y;
@@ -126,7 +133,9 @@ __device__ __forceinline__ void tile_of_block(int &mt, int &nt) {
 // ---- epilogue shared by the conv kernels.  The accumulator holds y^T: lane (l15, q) owns channels
 // 4q..4q+3 of tile nt for tile row 16mt + l15; pix(row) maps a tile row to the global output pixel
 // index (or -1 when the row is outside the image / batch).
-template <typename T, int BM, int BN, int WM, int WN, typename LdsT, typename AccT, typename PixF>
+// DG: data-gradient form - ReLU gate by p.mask and (optionally) BatchNorm-reverse sums; compiled out of the forward kernels
+// (with the code present behind run-time flags the forward step was 1.5 % slower: register pressure in the store loop).
+template <typename T, int BM, int BN, int WM, int WN, bool DG, typename LdsT, typename AccT, typename PixF>
 __device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, int m0, int n0, PixF pix) {
     constexpr int NTH = 64 * WM * WN;
     constexpr int MTW = BM / WM / 16, NTW = BN / WN / 16;
@@ -204,8 +213,24 @@ __device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, 
         __syncthreads();
         T *yg = reinterpret_cast<T *>(p.y);
         const T *rg = reinterpret_cast<const T *>(p.residual);
-        const T *mk = reinterpret_cast<const T *>(p.mask);
-        const bool plain = !p.out_scale && !p.out_shift && !rg && !p.relu_out && !mk;
+        const T *mk = DG ? reinterpret_cast<const T *>(p.mask) : nullptr;
+        const bool bnr = DG && BN_EPILOGUE && p.bn_y[0] != nullptr;
+        const bool plain = !p.out_scale && !p.out_shift && !rg && !p.relu_out && !mk && !bnr;
+        static_assert(NTH % CPR == 0, "a thread keeps one 16-byte column chunk across its rows");
+        float bs1[DG ? 2 : 1][EPC], bs2[DG ? 2 : 1][EPC], bmu[DG ? 2 : 1][EPC], biv[DG ? 2 : 1][EPC];
+        const int cfix = tid % CPR;
+        if constexpr (DG) if (bnr) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < EPC; ++i) {
+                    const int n = n0 + cfix * EPC + i;
+                    const bool ok = p.bn_y[u] && n < p.Cout;
+                    bs1[u][i] = bs2[u][i] = 0.f;
+                    bmu[u][i] = ok ? p.bn_mi[u][n] : 0.f;
+                    biv[u][i] = ok ? p.bn_mi[u][p.Cout + n] : 0.f;
+                }
+        }
 #pragma unroll
         for (int j = 0; j < BM * CPR / NTH; ++j) {
             const int id = tid + NTH * j;
@@ -233,15 +258,51 @@ __device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, 
 #pragma unroll
                     for (int i = 0; i < EPC; ++i) v[i] = fmaxf(v[i], 0.f);
                 }
-                if (mk) {
+                if constexpr (DG) if (mk) {
                     float g2[EPC];
                     Chunk<T>::unpack(*reinterpret_cast<const uint4 *>(mk + off), g2);
 #pragma unroll
                     for (int i = 0; i < EPC; ++i) v[i] = g2[i] > 0.f ? v[i] : 0.f;
                 }
+                if constexpr (DG) if (bnr) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if (!p.bn_y[u]) continue;
+                        float yv[EPC];
+                        Chunk<T>::unpack(*reinterpret_cast<const uint4 *>(reinterpret_cast<const T *>(p.bn_y[u]) + off), yv);
+#pragma unroll
+                        for (int i = 0; i < EPC; ++i) {
+                            bs1[u][i] += v[i];
+                            bs2[u][i] = fmaf(v[i], (yv[i] - bmu[u][i]) * biv[u][i], bs2[u][i]);
+                        }
+                    }
+                }
                 raw = Chunk<T>::pack(v);
             }
             *reinterpret_cast<uint4 *>(yg + off) = raw;
+        }
+        if constexpr (DG) if (bnr) {
+            // threads sharing a column chunk (NTH / CPR of them) fold their partial sums through LDS; one thread per channel adds
+            // the tile's two sums to this block's statistic shard
+            float *red = reinterpret_cast<float *>(lds);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (!p.bn_y[u]) continue;
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < EPC; ++i) { red[tid * (2 * EPC) + i] = bs1[u][i]; red[tid * (2 * EPC) + EPC + i] = bs2[u][i]; }
+                __syncthreads();
+                if (tid < CPR * EPC) {
+                    const int c = tid / EPC, e = tid % EPC, n = n0 + tid;
+                    float a = 0.f, b = 0.f;
+                    for (int k = 0; k < NTH / CPR; ++k) { a += red[(c + CPR * k) * (2 * EPC) + e]; b += red[(c + CPR * k) * (2 * EPC) + EPC + e]; }
+                    if (n < p.Cout) {
+                        float *st = p.bn_stats[u] + (size_t)((m0 / BM) % NSH) * 2 * p.Cout;
+                        atomicAdd(st + n, a);
+                        atomicAdd(st + p.Cout + n, b);
+                    }
+                }
+            }
         }
     }
 }
@@ -250,7 +311,7 @@ __device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, 
 // Tile BM x BN computed by WM x WN wavefronts (64 * WM * WN threads); each wave owns (BM/WM) x (BN/WN).
 // Shipped shapes: 128x64 and 128x128 on 2x2 waves (2 workgroups per CU), 256x256 on 2x4 waves (one per CU,
 // half the L2->LDS bytes per MAC of 128x128 - the 128-tiles measure L2-fill-bound at ~11 TB/s).
-template <typename T, int BM, int BN, int WM, int WN, bool FAST, int MODE>
+template <typename T, int BM, int BN, int WM, int WN, bool FAST, int MODE, bool DG = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_kernel(const Params p) {
     constexpr int NTH = 64 * WM * WN;
     constexpr int CE = El<T>::CE, BKE = 8 * CE;
@@ -393,7 +454,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_kernel(const Params p) {
         cur ^= 1;
     }
 
-    epilogue<T, BM, BN, WM, WN>(p, acc, lds, m0, n0, [&](int row) { const int m = m0 + row; return m < p.M ? (long)m : -1l; });
+    epilogue<T, BM, BN, WM, WN, DG>(p, acc, lds, m0, n0, [&](int row) { const int m = m0 + row; return m < p.M ? (long)m : -1l; });
 }
 
 // ---------------------------------------------------------------------------
@@ -549,7 +610,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dma_kernel(const Params p) 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the tail re-fetches must not land on the epilogue's staging
     __syncthreads();
-    epilogue<T, BM, BN, WM, WN>(p, acc, lds, m0, n0, [&](int row) { const int m = m0 + row; return m < p.M ? (long)m : -1l; });
+    epilogue<T, BM, BN, WM, WN, false>(p, acc, lds, m0, n0, [&](int row) { const int m = m0 + row; return m < p.M ? (long)m : -1l; });
 }
 
 // ---------------------------------------------------------------------------
@@ -662,7 +723,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ x, 
         }
     }
     __syncthreads();
-    epilogue<T, BM, BN, WM, WN>(p, acc, lds, 0, 0, [&](int row) {
+    epilogue<T, BM, BN, WM, WN, false>(p, acc, lds, 0, 0, [&](int row) {
         const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
         return (oy < p.Ho && ox < p.Wo) ? ((long)b * p.Ho + oy) * p.Wo + ox : -1l;
     });
@@ -795,6 +856,8 @@ static void launch_mode(const Params &p, hipStream_t s) {
         if constexpr (FAST) hipLaunchKernelGGL((conv_kernel<T, BM, BN, WM, WN, true, 2>), grid, block, 0, s, p);
     } else if (p.in_scale) {
         hipLaunchKernelGGL((conv_kernel<T, BM, BN, WM, WN, FAST, 1>), grid, block, 0, s, p);
+    } else if (p.mask) {
+        hipLaunchKernelGGL((conv_kernel<T, BM, BN, WM, WN, FAST, 0, true>), grid, block, 0, s, p);
     } else {
         hipLaunchKernelGGL((conv_kernel<T, BM, BN, WM, WN, FAST, 0>), grid, block, 0, s, p);
     }
@@ -821,7 +884,7 @@ static int launch_conv(const Params &p, hipStream_t s) {
     static const int use_dma = getenv("MHE_CONV_DMA") ? atoi(getenv("MHE_CONV_DMA")) : 0;
     if constexpr (sizeof(T) == 2) {
         // plain bf16 operands (no producer BatchNorm, no residual tail) can be DMA'd straight into LDS
-        if (use_dma && fast && !p.in_scale && !p.x2) {
+        if (use_dma && fast && !p.in_scale && !p.x2 && !p.mask) {
             const int tile = choose_tile(p, fast, true);
             if (tile == 2) {
                 const dim3 grid((p.M + 255) / 256, (p.Cout + 255) / 256);
@@ -854,7 +917,8 @@ static inline int elem_chunk(int dtype) { return dtype == MHE_F32 ? 4 : 8; }
 static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
                       const float *in_shift, const float *out_scale, const float *out_shift, const void *residual,
                       float *stats, const void *x2, const float *x2_scale, const float *x2_shift, void *a_out, void *stream,
-                      const void *mask = nullptr);
+                      const void *mask = nullptr, const struct BnRev *bn = nullptr);
+struct BnRev { const void *y[2]; const float *mi[2]; float *stats[2]; };
 
 extern "C" int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
                                const float *in_shift, const float *out_scale, const float *out_shift,
@@ -873,15 +937,19 @@ extern "C" int mhe_conv1x1_residual_in_nhwc(const mhe_conv_desc *d, const void *
 }
 
 extern "C" int mhe_conv2d_masked_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const void *residual,
-                                      const void *mask, void *stream) {
+                                      const void *mask, const void *bn_y0, const float *bn_mean_invstd0, float *bn_stats0,
+                                      const void *bn_y1, const float *bn_mean_invstd1, float *bn_stats1, void *stream) {
     MHE_REQUIRE(mask, "mhe_conv2d_masked_nhwc: mask is required");
-    return conv_entry(d, x, w, y, nullptr, nullptr, nullptr, nullptr, residual, nullptr, nullptr, nullptr, nullptr, nullptr, stream, mask);
+    MHE_REQUIRE((!bn_y0 || (bn_mean_invstd0 && bn_stats0)) && (!bn_y1 || (bn_y0 && bn_mean_invstd1 && bn_stats1)),
+                "mhe_conv2d_masked_nhwc: each bn_y needs its mean_invstd and stats (and bn_y1 needs bn_y0)");
+    const BnRev bn = {{bn_y0, bn_y1}, {bn_mean_invstd0, bn_mean_invstd1}, {bn_stats0, bn_stats1}};
+    return conv_entry(d, x, w, y, nullptr, nullptr, nullptr, nullptr, residual, nullptr, nullptr, nullptr, nullptr, nullptr, stream, mask, &bn);
 }
 
 static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
                       const float *in_shift, const float *out_scale, const float *out_shift, const void *residual,
                       float *stats, const void *x2, const float *x2_scale, const float *x2_shift, void *a_out, void *stream,
-                      const void *mask) {
+                      const void *mask, const BnRev *bn) {
     MHE_REQUIRE(d && x && w && y, "mhe_conv2d_nhwc: null pointer");
     MHE_REQUIRE(d->dtype == MHE_F32 || d->dtype == MHE_BF16, "mhe_conv2d_nhwc: dtype=%d", d->dtype);
     const int ce = elem_chunk(d->dtype), bke = 8 * ce;
@@ -894,6 +962,7 @@ static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void
     conv::Params p;
     p.x = x; p.w = w; p.y = y; p.in_scale = in_scale; p.in_shift = in_shift; p.out_scale = out_scale;
     p.out_shift = out_shift; p.residual = residual; p.stats = stats; p.mask = mask;
+    for (int u = 0; u < 2; ++u) { p.bn_y[u] = bn ? bn->y[u] : nullptr; p.bn_mi[u] = bn ? bn->mi[u] : nullptr; p.bn_stats[u] = bn ? bn->stats[u] : nullptr; }
     p.x2 = x2; p.x2_scale = x2_scale; p.x2_shift = x2_shift; p.a_out = a_out;
     p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
     p.stride = d->stride; p.pad = d->pad;

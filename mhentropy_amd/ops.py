@@ -51,9 +51,9 @@ _TILES = {0: "128, 64, 2, 2", 1: "128, 128, 2, 2", 2: "256, 256, 2, 4", 3: "256,
 def _conv_kernel_name(d, dt, mode):
     """the template instantiation the launcher will pick, spelled as rocprofv3 prints it"""
     bke = 32 if dt == torch.float32 else 64
-    return "mhe::conv::conv_kernel<%s, %s, %s, %d>" % ("float" if dt == torch.float32 else "unsigned short",
-                                                      _TILES[_lib.lib().mhe_conv_tile(C.byref(d))],
-                                                      "true" if d.Cin % bke == 0 else "false", mode)
+    return "mhe::conv::conv_kernel<%s, %s, %s, %d, false>" % ("float" if dt == torch.float32 else "unsigned short",
+                                                             _TILES[_lib.lib().mhe_conv_tile(C.byref(d))],
+                                                             "true" if d.Cin % bke == 0 else "false", mode)
 
 
 def dtype_code(dt):
@@ -218,9 +218,10 @@ def metrics(xyz, uv, pose3d, scale, crop_uv, vis):
 
 
 def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in=False, out_scale=None,
-                out_shift=None, residual=None, relu_out=False, stats=None, out=None, mask=None):
+                out_shift=None, residual=None, relu_out=False, stats=None, out=None, mask=None, bn=None):
     """x [B,H,W,Cin], w packed [Cout, Kpad]; returns y [B,Ho,Wo,Cout] of x.dtype.  mask (shaped like y, data-gradient
-    form only): y = (conv + residual) * [mask > 0]."""
+    form only): y = (conv + residual) * [mask > 0]; bn = up to two (bn_y, mean_invstd [2,C], stats [S,2,C]) triples: the epilogue
+    also accumulates the BatchNorm-reverse sums of y for those units (see mhe_conv2d_masked_nhwc)."""
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
     dt = x.dtype
@@ -241,8 +242,17 @@ def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in
         if in_scale is not None or out_scale is not None or out_shift is not None or stats is not None or relu_in or relu_out:
             raise ValueError("conv2d_nhwc: mask= is the plain data-gradient form (no affine / statistics / relu)")
         _chk(mask, dt, "conv.mask", (B, Ho, Wo, Cout))
-        check(_lib.lib().mhe_conv2d_masked_nhwc(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _ptr(residual), _ptr(mask), _stream()), "mhe_conv2d_masked_nhwc")
+        ext = []
+        for by, bmi, bst in (list(bn or []) + [(None, None, None)] * 2)[:2]:
+            if by is not None:
+                _chk(by, dt, "conv.bn_y", (B, Ho, Wo, Cout)); _chk(bmi, torch.float32, "conv.bn_mean_invstd", (2, Cout))
+                _chk(bst, torch.float32, "conv.bn_stats", (stat_shards(), 2, Cout))
+            ext += [_ptr(by), _ptr(bmi), _ptr(bst)]
+        check(_lib.lib().mhe_conv2d_masked_nhwc(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _ptr(residual), _ptr(mask), *ext, _stream()),
+              "mhe_conv2d_masked_nhwc")
         return y
+    if bn:
+        raise ValueError("conv2d_nhwc: bn= needs mask= (data-gradient form)")
     if TIMING:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -448,8 +458,9 @@ def bn_mean_invstd(stats, count, eps=1e-5):
     return mi
 
 
-def bn_backward(g, a, y, mean_invstd, gamma, stats, dgamma, dbeta, want_masked=False, out=None):
-    """train-mode BatchNorm(+ReLU) reverse: returns gy (and g [a>0] when want_masked); writes dgamma / dbeta."""
+def bn_backward(g, a, y, mean_invstd, gamma, stats, dgamma, dbeta, want_masked=False, out=None, reduced=False):
+    """train-mode BatchNorm(+ReLU) reverse: returns gy (and g [a>0] when want_masked); writes dgamma / dbeta.
+    reduced=True: `stats` already holds the sums (accumulated by the epilogue of the kernel that produced g)."""
     Cc = y.shape[-1]
     P = y.numel() // Cc
     dt = y.dtype
@@ -459,7 +470,8 @@ def bn_backward(g, a, y, mean_invstd, gamma, stats, dgamma, dbeta, want_masked=F
     _chk(stats, torch.float32, "bn_bwd.stats", (stat_shards(), 2, Cc)); _chk(mean_invstd, torch.float32, "bn_bwd.mean_invstd", (2, Cc))
     _chk(gamma, torch.float32, "bn_bwd.gamma", (Cc,)); _chk(dgamma, torch.float32, "bn_bwd.dgamma", (Cc,)); _chk(dbeta, torch.float32, "bn_bwd.dbeta", (Cc,))
     L = _lib.lib()
-    check(L.mhe_bn_bwd_reduce_nhwc(_ptr(g), _ptr(a), _ptr(y), _ptr(mean_invstd), _ptr(stats), P, Cc, dtype_code(dt), _stream()), "mhe_bn_bwd_reduce_nhwc")
+    if not reduced:
+        check(L.mhe_bn_bwd_reduce_nhwc(_ptr(g), _ptr(a), _ptr(y), _ptr(mean_invstd), _ptr(stats), P, Cc, dtype_code(dt), _stream()), "mhe_bn_bwd_reduce_nhwc")
     coef = torch.empty(3, Cc, device=y.device, dtype=torch.float32)
     check(L.mhe_bn_bwd_finalize(_ptr(stats), _ptr(gamma), _ptr(mean_invstd), _ptr(dgamma), _ptr(dbeta), _ptr(coef), Cc, float(P), _stream()), "mhe_bn_bwd_finalize")
     gy = out if out is not None else torch.empty_like(y)

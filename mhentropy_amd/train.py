@@ -41,18 +41,18 @@ def dgrad_operand_index(idx):
     return idx.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, KH * KW * Cout)
 
 
-def conv_dgrad(gy, w_dg, k, stride, pad, H, W, residual=None, mask=None):
+def conv_dgrad(gy, w_dg, k, stride, pad, H, W, residual=None, mask=None, bn=None):
     """gradient of a k x k / stride / pad convolution w.r.t. its [B,H,W,Cin] input (+ residual), through the
     FORWARD implicit-GEMM kernel: stride 1 is a convolution of gy with the transposed, tap-flipped weights at
     padding k-1-pad; a stride-2 3x3 runs the same on the zero-dilated gy; a stride-2 1x1 is computed on the
     coarse grid and scattered to the even positions.  mask (the convolution's own post-ReLU input): the result is
     gated by [mask > 0] in the kernel's epilogue, i.e. it leaves as the gradient w.r.t. the PRE-activation."""
     if stride == 1:
-        return ops.conv2d_nhwc(gy, w_dg, k, k, 1, k - 1 - pad, residual=residual, mask=mask)
+        return ops.conv2d_nhwc(gy, w_dg, k, k, 1, k - 1 - pad, residual=residual, mask=mask, bn=bn)
     if stride != 2 or k not in (1, 3):
         raise NotImplementedError(f"conv_dgrad: k={k} stride={stride}")
     if k == 3:
-        return ops.conv2d_nhwc(ops.upsample2(gy, H, W), w_dg, 3, 3, 1, 1, residual=residual, mask=mask)
+        return ops.conv2d_nhwc(ops.upsample2(gy, H, W), w_dg, 3, 3, 1, 1, residual=residual, mask=mask, bn=bn)
     if mask is not None:
         raise NotImplementedError("conv_dgrad: mask with a stride-2 1x1 (only the un-gated downsample branch uses it)")
     half = ops.conv2d_nhwc(gy, w_dg, 1, 1, 1, 0)
@@ -86,6 +86,9 @@ class TrainStep:
         self._build_trunk()
         self._build_heads()
         self._build_flow()
+        import os
+        # BatchNorm-reverse sums accumulated by the data-gradient epilogues (no separate reduce pass); MHE_BN_REDUCE_FUSED=0: separate pass
+        self.fuse_bn_reduce = os.environ.get("MHE_BN_REDUCE_FUSED", "1") == "1"
         self._bucket_bounds = self._gradient_buckets()
         self._works = []
         self.raw = torch.zeros(self._raw_n, device=self.dev, dtype=torch.float32)
@@ -425,18 +428,26 @@ class TrainStep:
         self.a_last = a
         return ops.avgpool(a)
 
-    def _bn_bwd(self, u, g, a, pool):
-        """g: gradient w.r.t. the unit's BatchNorm OUTPUT (already ReLU-gated by its producer when a is None)"""
-        return ops.bn_backward(g, a, u.y, u.mi, u.bn.weight.data, pool.take(u.cout), u.dgamma, u.dbeta)
+    def _bn_bwd(self, u, g, a, pool, stats=None):
+        """g: gradient w.r.t. the unit's BatchNorm OUTPUT (already ReLU-gated by its producer when a is None).  stats: the
+        reverse sums already accumulated by the producer's epilogue (then only finalize + apply run here)."""
+        return ops.bn_backward(g, a, u.y, u.mi, u.bn.weight.data, stats if stats is not None else pool.take(u.cout), u.dgamma, u.dbeta,
+                               reduced=stats is not None)
 
     def _wgrad(self, u, gy):
         ops.conv_wgrad(u.x, gy, u.k, u.k, u.stride, u.pad, u.dw)
 
-    def _dgrad(self, u, gy, residual=None, gate=True):
+    def _dgrad(self, u, gy, residual=None, gate=True, consumers=(), pool=None):
         """gradient w.r.t. the pre-activation of the unit's input (+ residual): every unit input in the trunk is a post-ReLU
         tensor, so the ReLU gate [x > 0] is applied in the producing kernel's epilogue and the BatchNorm reverse passes
         downstream read one tensor less"""
-        return conv_dgrad(gy, u.w_dg, u.k, u.stride, u.pad, u.x.shape[1], u.x.shape[2], residual, u.x if gate else None)
+        bn = None
+        if gate and consumers and self.fuse_bn_reduce:
+            # the BatchNorm units that consume this gradient: their reverse sums are accumulated by this kernel's epilogue
+            bn = [(c.y, c.mi, pool.take(c.cout)) for c in consumers]
+            for c, (_, _, st) in zip(consumers, bn):
+                c.rev_stats = st
+        return conv_dgrad(gy, u.w_dg, u.k, u.stride, u.pad, u.x.shape[1], u.x.shape[2], residual, u.x if gate else None, bn)
 
     def _trunk_backward(self, g_f):
         pool = resnet._StatsPool(self.dev, channels=65536)
@@ -449,9 +460,9 @@ class TrainStep:
                 self._grad_ready(self.blocks[bi + 1]["layer"] - 2)      # layer4 complete -> bucket 2, layer3 -> bucket 1
             us, ud = b["u"], b["ud"]
             ul = us[-1]
-            gy = self._bn_bwd(ul, g, None, pool)
+            gy = self._bn_bwd(ul, g, None, pool, stats=getattr(ul, "rev_stats", None))
             if ud is not None:
-                gyd = self._bn_bwd(ud, g, None, pool)
+                gyd = self._bn_bwd(ud, g, None, pool, stats=getattr(ud, "rev_stats", None))
                 self._wgrad(ud, gyd)
                 skip = self._dgrad(ud, gyd, gate=False)          # summed with the main branch before the gate
             else:
@@ -459,11 +470,15 @@ class TrainStep:
             for j in range(len(us) - 1, 0, -1):
                 u = us[j]
                 self._wgrad(u, gy)
-                ga = self._dgrad(u, gy)
-                gy = self._bn_bwd(us[j - 1], ga, None, pool)
+                ga = self._dgrad(u, gy, consumers=(us[j - 1],), pool=pool)
+                gy = self._bn_bwd(us[j - 1], ga, None, pool, stats=getattr(us[j - 1], "rev_stats", None))
             self._wgrad(us[0], gy)
             first = bi == 0            # the first block's input is the max-pooled stem output (>= 0; the pool's reverse gates it)
-            g = self._dgrad(us[0], gy, residual=skip, gate=not first)
+            prev = self.blocks[bi - 1] if bi else None
+            cons = () if first else tuple(x for x in (prev["u"][-1], prev["ud"]) if x is not None)
+            g = self._dgrad(us[0], gy, residual=skip, gate=not first, consumers=cons, pool=pool)
+        for u in self.units:
+            u.rev_stats = None
         u = self.stem
         g_r0 = ops.maxpool3x3s2_bwd(g, self.pool_idx, self.r0.shape[1], self.r0.shape[2])
         gy0 = self._bn_bwd(u, g_r0, self.r0, pool)
