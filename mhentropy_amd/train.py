@@ -59,6 +59,28 @@ def conv_dgrad(gy, w_dg, k, stride, pad, H, W, residual=None, mask=None, bn=None
     return ops.upsample2(half, H, W, base=residual)
 
 
+def flow_stream_table(dim, h, bf16):
+    """gather table of ONE net's fragment-ordered weight stream, as local indices into [W0 | W1 | W2]
+    (obtained by running the host packer on index-valued weights)"""
+    n0, n1, n2 = h * dim, h * h, dim * h
+    loc = np.arange(n0 + n1 + n2, dtype=np.int64)
+    parts = lambda a: (a[:n0].reshape(h, dim), a[n0:n0 + n1].reshape(h, h), a[n0 + n1:].reshape(dim, h))
+    if not bf16:
+        w = parts((loc + 1).astype(np.float32))               # < 2^24: exact in f32
+        return ops.flow_pack_net(*w).astype(np.int64) - 1
+    out, pad = None, None
+    for dig in range(3):                                        # base-128 digits (+1) are exact in bf16
+        w = parts((((loc >> (7 * dig)) & 127) + 1).astype(np.float32))
+        s = ops.flow_pack_net_bf16(*w)
+        v = (s.astype(np.uint32) << 16).view(np.float32).astype(np.int64)
+        if dig == 0:
+            pad, out = v == 0, np.zeros_like(v)
+        out += (np.maximum(v, 1) - 1) << (7 * dig)
+    out[pad] = -1
+    return out
+
+
+
 class _Unit:
     """one convolution + BatchNorm of the trunk"""
     def __init__(self, conv, bn, k, stride, pad):
@@ -274,27 +296,6 @@ class TrainStep:
         # feat_extractor.l2 is dead for MHEnt (hand/network.py:779): its gradient stays zero (-1 in the unpack table)
 
     # ------------------------------------------------------------------ flow tables
-    def _flow_stream_table(self, flow, bf16):
-        """gather table of ONE net's fragment-ordered weight stream, as local indices into [W0 | W1 | W2]
-        (obtained by running the host packer on index-valued weights)"""
-        dim, h = flow.dim, flow.hidden
-        n0, n1, n2 = h * dim, h * h, dim * h
-        loc = np.arange(n0 + n1 + n2, dtype=np.int64)
-        parts = lambda a: (a[:n0].reshape(h, dim), a[n0:n0 + n1].reshape(h, h), a[n0 + n1:].reshape(dim, h))
-        if not bf16:
-            w = parts((loc + 1).astype(np.float32))               # < 2^24: exact in f32
-            return ops.flow_pack_net(*w).astype(np.int64) - 1
-        out, pad = None, None
-        for dig in range(3):                                        # base-128 digits (+1) are exact in bf16
-            w = parts((((loc >> (7 * dig)) & 127) + 1).astype(np.float32))
-            s = ops.flow_pack_net_bf16(*w)
-            v = (s.astype(np.uint32) << 16).view(np.float32).astype(np.int64)
-            if dig == 0:
-                pad, out = v == 0, np.zeros_like(v)
-            out += (np.maximum(v, 1) - 1) << (7 * dig)
-        out[pad] = -1
-        return out
-
     def _build_flow(self):
         fl = self.model.q_z_giv_i
         from .flows import RealNVP
@@ -311,7 +312,7 @@ class TrainStep:
         dim, h, ncoup = fl.dim, fl.hidden, len(fl.mask)
         bf16 = fl.compute_dtype == torch.bfloat16 and h % 128 == 0
         self.flow_bf16 = bf16
-        loc = torch.from_numpy(self._flow_stream_table(fl, bf16))
+        loc = torch.from_numpy(flow_stream_table(fl.dim, fl.hidden, bf16))
         n0, n1 = h * dim, h * h
         streams, b2, wc, bc1, bc2, nets = [], [], [], [], [], []
         self.fnets = []
