@@ -17,295 +17,10 @@
 // The accumulator holds y^T (row = channel 4q+r, column = pixel lane&15), so each
 // lane owns 4 consecutive channels of one pixel: the epilogue's per-channel
 // scale/shift are one float4 load and the store is one 16 B (f32) / 8 B (bf16) write.
-#include "common.h"
+#include "conv_shared.h"
 #include <cstdlib>
 
 namespace mhe { namespace conv {
-
-struct Params {
-    const void *x; const void *w; void *y;
-    const float *in_scale, *in_shift, *out_scale, *out_shift;
-    const void *residual;
-    const void *mask;      // optional, shaped like y: outputs are zeroed where mask <= 0 (ReLU gate of a data gradient)
-    // optional BatchNorm-reverse statistics of the (gated) outputs g: for up to two BN units whose raw outputs bn_y[u] are shaped like y,
-    // bn_stats[u][shard][0][c] += sum g, [1][c] += sum g * (bn_y - mean) * invstd   (bn_mi[u] = [mean | invstd])
-    const void *bn_y[2]; const float *bn_mi[2]; float *bn_stats[2];
-    float *stats;          // [NSH][2][Cout] sharded accumulators
-    // dual-input prologue (1x1, stride 1): operand = relu(x*in_scale+in_shift + (x2*x2_scale+x2_shift | x2)),
-    // i.e. the tail of the previous residual block evaluated on load; a_out (optional) receives it once
-    const void *x2; const float *x2_scale, *x2_shift; void *a_out;
-    int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, M, Kpad, relu_in, relu_out;
-};
-
-constexpr int NSH = 64;          // statistic shards: block b adds into shard b % NSH
-constexpr int MAXC = 2048;       // largest Cin whose BatchNorm affine is staged in LDS
-
-template <typename T> struct El;
-template <> struct El<float> { static constexpr int CE = 4; };
-template <> struct El<u16>   { static constexpr int CE = 8; };
-
-__device__ __forceinline__ int swz(int row, int slot) { return row * 8 + (slot ^ ((row >> 1) & 7)); }
-
-// one 16-byte chunk of activations -> floats and back
-template <typename T> struct Chunk;
-template <> struct Chunk<float> {
-    static constexpr int N = 4;
-    static __device__ __forceinline__ void unpack(uint4 r, float *v) {
-        v[0] = __uint_as_float(r.x); v[1] = __uint_as_float(r.y); v[2] = __uint_as_float(r.z); v[3] = __uint_as_float(r.w);
-    }
-    static __device__ __forceinline__ uint4 pack(const float *v) {
-        return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
-    }
-};
-template <> struct Chunk<u16> {
-    static constexpr int N = 8;
-    static __device__ __forceinline__ void unpack(uint4 r, float *v) {
-        const unsigned in[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(in[i] << 16); v[2 * i + 1] = __uint_as_float(in[i] & 0xffff0000u); }
-    }
-    static __device__ __forceinline__ uint4 pack(const float *v) {
-        unsigned o[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = (unsigned)f32_to_bf16(v[2 * i]) | ((unsigned)f32_to_bf16(v[2 * i + 1]) << 16);
-        return make_uint4(o[0], o[1], o[2], o[3]);
-    }
-};
-
-// relu?(x*scale+shift [+ x2*scale2+shift2 | + x2]); sc/sh point into LDS, sc2/sh2 (optional) into global memory
-template <typename T>
-__device__ __forceinline__ uint4 in_transform(uint4 raw, const float *sc, const float *sh, int c, int relu,
-                                              bool dual, uint4 raw2, const float *sc2, const float *sh2) {
-    constexpr int N = Chunk<T>::N;
-    float v[N], ss[N], tt[N];
-    Chunk<T>::unpack(raw, v);
-#pragma unroll
-    for (int i = 0; i < N; i += 4) {
-        const float4 a = *reinterpret_cast<const float4 *>(sc + c + i), b = *reinterpret_cast<const float4 *>(sh + c + i);
-        ss[i] = a.x; ss[i + 1] = a.y; ss[i + 2] = a.z; ss[i + 3] = a.w;
-        tt[i] = b.x; tt[i + 1] = b.y; tt[i + 2] = b.z; tt[i + 3] = b.w;
-    }
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = fmaf(v[i], ss[i], tt[i]);
-    if (dual) {
-        float w[N];
-        Chunk<T>::unpack(raw2, w);
-        if (sc2) {
-#pragma unroll
-            for (int i = 0; i < N; i += 4) {
-                const float4 a = *reinterpret_cast<const float4 *>(sc2 + c + i), b = *reinterpret_cast<const float4 *>(sh2 + c + i);
-                w[i] = fmaf(w[i], a.x, b.x); w[i + 1] = fmaf(w[i + 1], a.y, b.y);
-                w[i + 2] = fmaf(w[i + 2], a.z, b.z); w[i + 3] = fmaf(w[i + 3], a.w, b.w);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < N; ++i) v[i] += w[i];
-    }
-    if (relu) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = fmaxf(v[i], 0.f);
-    }
-    return Chunk<T>::pack(v);
-}
-
-// XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.  With the
-// plain (x = M tile, y = N tile) order the N tiles that re-read one activation tile run gridDim.x launches apart on
-// arbitrary XCDs; here XCD x walks M tiles x, x+8, ... and takes all N tiles of an M tile back to back, so the
-// activation tile is fetched from HBM once and re-read from that XCD's L2 (the weights are small enough to sit in every L2).
-#ifndef MHE_CONV_XCD_ORDER
-#define MHE_CONV_XCD_ORDER 1
-#endif
-constexpr bool XCD_ORDER = MHE_CONV_XCD_ORDER;
-#ifndef MHE_CONV_BN_EPILOGUE
-#define MHE_CONV_BN_EPILOGUE 1
-#endif
-constexpr bool BN_EPILOGUE = MHE_CONV_BN_EPILOGUE;      // measurement switch for the BatchNorm-reverse sums in the epilogue
-__device__ __forceinline__ void tile_of_block(int &mt, int &nt) {
-    const int gm = gridDim.x, gn = gridDim.y;
-    mt = blockIdx.x; nt = blockIdx.y;
-    if (XCD_ORDER && gn > 1 && (gm & 7) == 0) {
-        const int L = blockIdx.x + gm * blockIdx.y, slot = L >> 3;
-        nt = slot % gn;
-        mt = (slot / gn) * 8 + (L & 7);
-    }
-}
-
-// ---- epilogue shared by the conv kernels.  The accumulator holds y^T: lane (l15, q) owns channels
-// 4q..4q+3 of tile nt for tile row 16mt + l15; pix(row) maps a tile row to the global output pixel
-// index (or -1 when the row is outside the image / batch).
-// DG: data-gradient form - ReLU gate by p.mask and (optionally) BatchNorm-reverse sums; compiled out of the forward kernels
-// (with the code present behind run-time flags the forward step was 1.5 % slower: register pressure in the store loop).
-template <typename T, int BM, int BN, int WM, int WN, bool DG, typename LdsT, typename AccT, typename PixF>
-__device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, int m0, int n0, PixF pix) {
-    constexpr int NTH = 64 * WM * WN;
-    constexpr int MTW = BM / WM / 16, NTW = BN / WN / 16;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int q = lane >> 4, l15 = lane & 15;
-    const int wr = wave / WN, wc = wave % WN;
-    // ---- epilogue.  The accumulator holds y^T: lane (l15, q) owns channels 4q..4q+3 of tile nt
-    // for pixel 16mt + l15.  (1) batch statistics: per-thread partials -> LDS -> one thread per
-    // (statistic, channel) -> ONE coalesced f32 atomic per thread into this block's shard.
-    // (2) the tile is transposed through LDS (16-byte chunks XOR-swizzled by row) so that global
-    // stores are whole 16-byte pieces of contiguous channel rows instead of 8-byte row-strided ones.
-    constexpr int CPR = BN * (int)sizeof(T) / 16;          // 16-byte chunks per output row
-    constexpr int CMASK = (CPR - 1) & 15;
-    constexpr int EPC = 16 / (int)sizeof(T);               // elements per chunk
-    constexpr int NV = 8 * NTW;                            // partial values per thread: 2 stats x NTW tiles x 4 channels
-    static_assert((size_t)BM * BN * sizeof(T) <= sizeof(lds), "output tile must fit the staging buffers");
-    static_assert((size_t)WM * WN * NV * 64 * 4 <= sizeof(lds), "statistics partials must fit the staging buffers");
-    if (p.stats) {
-        float *red = reinterpret_cast<float *>(lds);       // [waves][NV][64 lanes]
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const bool nv = n0 + wc * (BN / WN) + nt * 16 + 4 * q < p.Cout;
-            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) {
-                if (nv && pix(wr * (BM / WM) + mt * 16 + l15) >= 0) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { const float v = acc[nt][mt][r]; s1[r] += v; s2[r] = fmaf(v, v, s2[r]); }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                red[(wave * NV + nt * 4 + r) * 64 + lane] = s1[r];
-                red[(wave * NV + 4 * NTW + nt * 4 + r) * 64 + lane] = s2[r];
-            }
-        }
-        __syncthreads();
-        for (int t = tid; t < 2 * BN; t += NTH) {
-            const int stat = t / BN, ch = t % BN;
-            const int wcc = ch / (BN / WN), cc = ch % (BN / WN), nt = cc >> 4, qq = (cc >> 2) & 3, r = cc & 3;
-            const int v = stat * 4 * NTW + nt * 4 + r;
-            float sum = 0.f;
-#pragma unroll
-            for (int w2 = 0; w2 < WM; ++w2) {
-                const float *src = red + ((w2 * WN + wcc) * NV + v) * 64 + qq * 16;
-#pragma unroll
-                for (int l = 0; l < 16; ++l) sum += src[l];
-            }
-            const int n = n0 + ch;
-            if (n < p.Cout) atomicAdd(p.stats + ((size_t)((m0 / BM) % NSH) * 2 + stat) * p.Cout + n, sum);
-        }
-        __syncthreads();
-    }
-    {
-        unsigned char *ot = reinterpret_cast<unsigned char *>(lds);
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) {
-                const int row = wr * (BM / WM) + mt * 16 + l15;
-                const int e0 = wc * (BN / WN) + nt * 16 + 4 * q;             // first of 4 channels within the tile
-                const int boff = e0 * (int)sizeof(T);
-                const int chunk = (boff >> 4) ^ (row & CMASK);
-                unsigned char *dst = ot + ((size_t)row * CPR + chunk) * 16 + (boff & 15);
-                const v4f v = acc[nt][mt];
-                if constexpr (sizeof(T) == 4) {
-                    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    uint2 o;
-                    o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-                    o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-                    *reinterpret_cast<uint2 *>(dst) = o;
-                }
-            }
-        __syncthreads();
-        T *yg = reinterpret_cast<T *>(p.y);
-        const T *rg = reinterpret_cast<const T *>(p.residual);
-        const T *mk = DG ? reinterpret_cast<const T *>(p.mask) : nullptr;
-        const bool bnr = DG && BN_EPILOGUE && p.bn_y[0] != nullptr;
-        const bool plain = !p.out_scale && !p.out_shift && !rg && !p.relu_out && !mk && !bnr;
-        static_assert(NTH % CPR == 0, "a thread keeps one 16-byte column chunk across its rows");
-        float bs1[DG ? 2 : 1][EPC], bs2[DG ? 2 : 1][EPC], bmu[DG ? 2 : 1][EPC], biv[DG ? 2 : 1][EPC];
-        const int cfix = tid % CPR;
-        if constexpr (DG) if (bnr) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int i = 0; i < EPC; ++i) {
-                    const int n = n0 + cfix * EPC + i;
-                    const bool ok = p.bn_y[u] && n < p.Cout;
-                    bs1[u][i] = bs2[u][i] = 0.f;
-                    bmu[u][i] = ok ? p.bn_mi[u][n] : 0.f;
-                    biv[u][i] = ok ? p.bn_mi[u][p.Cout + n] : 0.f;
-                }
-        }
-#pragma unroll
-        for (int j = 0; j < BM * CPR / NTH; ++j) {
-            const int id = tid + NTH * j;
-            const int row = id / CPR, c = id % CPR;
-            const long m = pix(row);
-            const int n = n0 + c * EPC;
-            if (m < 0 || n >= p.Cout) continue;
-            uint4 raw = *reinterpret_cast<const uint4 *>(ot + ((size_t)row * CPR + (c ^ (row & CMASK))) * 16);
-            const size_t off = (size_t)m * p.Cout + n;
-            if (!plain) {
-                float v[EPC];
-                Chunk<T>::unpack(raw, v);
-#pragma unroll
-                for (int i = 0; i < EPC; ++i) {
-                    const float sc = p.out_scale ? p.out_scale[n + i] : 1.f, sh = p.out_shift ? p.out_shift[n + i] : 0.f;
-                    v[i] = fmaf(v[i], sc, sh);
-                }
-                if (rg) {
-                    float r2[EPC];
-                    Chunk<T>::unpack(*reinterpret_cast<const uint4 *>(rg + off), r2);
-#pragma unroll
-                    for (int i = 0; i < EPC; ++i) v[i] += r2[i];
-                }
-                if (p.relu_out) {
-#pragma unroll
-                    for (int i = 0; i < EPC; ++i) v[i] = fmaxf(v[i], 0.f);
-                }
-                if constexpr (DG) if (mk) {
-                    float g2[EPC];
-                    Chunk<T>::unpack(*reinterpret_cast<const uint4 *>(mk + off), g2);
-#pragma unroll
-                    for (int i = 0; i < EPC; ++i) v[i] = g2[i] > 0.f ? v[i] : 0.f;
-                }
-                if constexpr (DG) if (bnr) {
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        if (!p.bn_y[u]) continue;
-                        float yv[EPC];
-                        Chunk<T>::unpack(*reinterpret_cast<const uint4 *>(reinterpret_cast<const T *>(p.bn_y[u]) + off), yv);
-#pragma unroll
-                        for (int i = 0; i < EPC; ++i) {
-                            bs1[u][i] += v[i];
-                            bs2[u][i] = fmaf(v[i], (yv[i] - bmu[u][i]) * biv[u][i], bs2[u][i]);
-                        }
-                    }
-                }
-                raw = Chunk<T>::pack(v);
-            }
-            *reinterpret_cast<uint4 *>(yg + off) = raw;
-        }
-        if constexpr (DG) if (bnr) {
-            // threads sharing a column chunk (NTH / CPR of them) fold their partial sums through LDS; one thread per channel adds
-            // the tile's two sums to this block's statistic shard
-            float *red = reinterpret_cast<float *>(lds);
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (!p.bn_y[u]) continue;
-                __syncthreads();
-#pragma unroll
-                for (int i = 0; i < EPC; ++i) { red[tid * (2 * EPC) + i] = bs1[u][i]; red[tid * (2 * EPC) + EPC + i] = bs2[u][i]; }
-                __syncthreads();
-                if (tid < CPR * EPC) {
-                    const int c = tid / EPC, e = tid % EPC, n = n0 + tid;
-                    float a = 0.f, b = 0.f;
-                    for (int k = 0; k < NTH / CPR; ++k) { a += red[(c + CPR * k) * (2 * EPC) + e]; b += red[(c + CPR * k) * (2 * EPC) + EPC + e]; }
-                    if (n < p.Cout) {
-                        float *st = p.bn_stats[u] + (size_t)((m0 / BM) % NSH) * 2 * p.Cout;
-                        atomicAdd(st + n, a);
-                        atomicAdd(st + p.Cout + n, b);
-                    }
-                }
-            }
-        }
-    }
-}
 
 // MODE 0: plain operand load; 1: producer BatchNorm(+ReLU) applied to the operand; 2: residual-tail (dual input)
 // Tile BM x BN computed by WM x WN wavefronts (64 * WM * WN threads); each wave owns (BM/WM) x (BN/WN).
@@ -454,7 +169,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_kernel(const Params p) {
         cur ^= 1;
     }
 
-    epilogue<T, BM, BN, WM, WN, DG>(p, acc, lds, m0, n0, [&](int row) { const int m = m0 + row; return m < p.M ? (long)m : -1l; });
+    epilogue<T, BM, BN, WM, WN, DG>(p, acc, lds, mtile % NSH, n0, [&](int row) { const int m = m0 + row; return m < p.M ? (long)m : -1l; });
 }
 
 // ---------------------------------------------------------------------------
@@ -610,7 +325,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dma_kernel(const Params p) 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the tail re-fetches must not land on the epilogue's staging
     __syncthreads();
-    epilogue<T, BM, BN, WM, WN, false>(p, acc, lds, m0, n0, [&](int row) { const int m = m0 + row; return m < p.M ? (long)m : -1l; });
+    epilogue<T, BM, BN, WM, WN, false>(p, acc, lds, (int)(blockIdx.x % NSH), n0, [&](int row) { const int m = m0 + row; return m < p.M ? (long)m : -1l; });
 }
 
 // ---------------------------------------------------------------------------
@@ -723,7 +438,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ x, 
         }
     }
     __syncthreads();
-    epilogue<T, BM, BN, WM, WN, false>(p, acc, lds, 0, 0, [&](int row) {
+    epilogue<T, BM, BN, WM, WN, false>(p, acc, lds, (int)(blockIdx.x % NSH), 0, [&](int row) {
         const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
         return (oy < p.Ho && ox < p.Wo) ? ((long)b * p.Ho + oy) * p.Wo + ox : -1l;
     });
@@ -863,10 +578,15 @@ static void launch_mode(const Params &p, hipStream_t s) {
     }
 }
 
+bool p8_supports(const Params &p);             // conv_p8.hip: the phase-pipelined 256x256 bf16 kernel (variant 7)
+int launch_p8(const Params &p, hipStream_t s);
+
 // tile choice: 0 = 128x64, 1 = 128x128, 2 = 256x256 (FAST only; needs >= ~3/4 of the CUs' worth of tiles)
 static int choose_tile(const Params &p, bool fast, bool bf16) {
-    static const int force = getenv("MHE_CONV_TILE") ? atoi(getenv("MHE_CONV_TILE")) : -1;    // tuning knob
-    if (force >= 0 && (force < 2 || (fast && bf16))) return force;
+    static const int env_force = getenv("MHE_CONV_TILE") ? atoi(getenv("MHE_CONV_TILE")) : -1;    // tuning knob
+    const int force = p.force >= 0 ? p.force : env_force;
+    if (force == 7 && bf16 && p8_supports(p)) return 7;
+    if (force >= 0 && force <= 4 && (force < 2 || (fast && bf16))) return force;
     if (p.Cout <= 64) return 0;
     if (fast && bf16 && p.Cout >= 256) {      // (an f32 256x256 output tile would not fit the LDS staging buffers)
         const long tiles = (long)((p.M + 255) / 256) * ((p.Cout + 255) / 256);
@@ -879,13 +599,17 @@ template <typename T>
 static int launch_conv(const Params &p, hipStream_t s) {
     constexpr int BKE = 8 * El<T>::CE;
     const bool fast = (p.Cin % BKE) == 0;
+    if constexpr (sizeof(T) == 2) {
+        if (choose_tile(p, fast, true) == 7) return launch_p8(p, s);
+    }
     if (p.x2 && !fast) { set_error("residual-tail prologue needs Cin %% %d == 0", BKE); return MHE_ERR_ARG; }
     // the LDS-DMA kernel measures equal to the register-staged one (see its header): opt-in, bit 0 = 256x256, bit 1 = 128x128
-    static const int use_dma = getenv("MHE_CONV_DMA") ? atoi(getenv("MHE_CONV_DMA")) : 0;
+    static const int env_dma = getenv("MHE_CONV_DMA") ? atoi(getenv("MHE_CONV_DMA")) : 0;
+    const int use_dma = p.force == 5 ? 1 : p.force == 6 ? 3 : p.force >= 0 ? 0 : env_dma;      // variants 5 / 6: the LDS-DMA kernel on the 256x256 / 128x128 tile
     if constexpr (sizeof(T) == 2) {
         // plain bf16 operands (no producer BatchNorm, no residual tail) can be DMA'd straight into LDS
         if (use_dma && fast && !p.in_scale && !p.x2 && !p.mask) {
-            const int tile = choose_tile(p, fast, true);
+            const int tile = p.force == 5 ? 2 : p.force == 6 ? 1 : choose_tile(p, fast, true);
             if (tile == 2) {
                 const dim3 grid((p.M + 255) / 256, (p.Cout + 255) / 256);
                 hipLaunchKernelGGL((conv_dma_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, p);
@@ -975,6 +699,7 @@ static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void
     const int ktot = d->KH * d->KW * d->Cin;
     p.Kpad = (ktot + bke - 1) / bke * bke;       // weight rows are zero-padded to this length by the packer
     p.relu_in = d->relu_in; p.relu_out = d->relu_out;
+    p.force = d->tile - 1;
     if (d->dtype == MHE_F32) return conv::launch_conv<float>(p, (hipStream_t)stream);
     return conv::launch_conv<u16>(p, (hipStream_t)stream);
 }
@@ -988,6 +713,7 @@ extern "C" int mhe_conv_tile(const mhe_conv_desc *d) {
     p.Cin = d->Cin; p.Cout = d->Cout;
     const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
     p.M = d->B * Ho * Wo;
+    p.force = d->tile - 1;
     const int bke = d->dtype == MHE_F32 ? 32 : 64;
     return conv::choose_tile(p, d->Cin % bke == 0, d->dtype == MHE_BF16);
 }
@@ -998,6 +724,7 @@ extern "C" int mhe_stem_conv7x7s2(const float *x_nchw, const void *w, void *y, f
     MHE_REQUIRE(B > 0 && H > 0 && W > 0, "mhe_stem_conv7x7s2: bad geometry");
     MHE_REQUIRE(dtype == MHE_F32 || dtype == MHE_BF16, "mhe_stem_conv7x7s2: dtype=%d", dtype);
     conv::Params p{};
+    p.force = -1;
     p.w = w; p.y = y; p.stats = stats;
     p.B = B; p.H = H; p.W = W; p.Cin = 3; p.Cout = 64; p.KH = p.KW = 7; p.stride = 2; p.pad = 3;
     p.Ho = (H + 6 - 7) / 2 + 1; p.Wo = (W + 6 - 7) / 2 + 1;

@@ -218,10 +218,11 @@ def metrics(xyz, uv, pose3d, scale, crop_uv, vis):
 
 
 def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in=False, out_scale=None,
-                out_shift=None, residual=None, relu_out=False, stats=None, out=None, mask=None, bn=None):
+                out_shift=None, residual=None, relu_out=False, stats=None, out=None, mask=None, bn=None, tile=0):
     """x [B,H,W,Cin], w packed [Cout, Kpad]; returns y [B,Ho,Wo,Cout] of x.dtype.  mask (shaped like y, data-gradient
     form only): y = (conv + residual) * [mask > 0]; bn = up to two (bn_y, mean_invstd [2,C], stats [S,2,C]) triples: the epilogue
-    also accumulates the BatchNorm-reverse sums of y for those units (see mhe_conv2d_masked_nhwc)."""
+    also accumulates the BatchNorm-reverse sums of y for those units (see mhe_conv2d_masked_nhwc).  tile > 0 forces kernel
+    variant tile-1 (mhe_conv_desc.tile; tests and tuning)."""
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
     dt = x.dtype
@@ -237,7 +238,7 @@ def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in
         _chk(residual, dt, "conv.residual", (B, Ho, Wo, Cout))
     if stats is not None:
         _chk(stats, torch.float32, "conv.stats", (stat_shards(), 2, Cout))
-    d = ConvDesc(B, H, W, Cin, Cout, KH, KW, stride, pad, dtype_code(dt), int(relu_in), int(relu_out))
+    d = ConvDesc(B, H, W, Cin, Cout, KH, KW, stride, pad, dtype_code(dt), int(relu_in), int(relu_out), int(tile))
     if mask is not None:
         if in_scale is not None or out_scale is not None or out_shift is not None or stats is not None or relu_in or relu_out:
             raise ValueError("conv2d_nhwc: mask= is the plain data-gradient form (no affine / statistics / relu)")
@@ -268,7 +269,7 @@ def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in
     return y
 
 
-def conv1x1_residual_in(x, x2, w, in_scale, in_shift, x2_scale=None, x2_shift=None, a_out=None, stats=None):
+def conv1x1_residual_in(x, x2, w, in_scale, in_shift, x2_scale=None, x2_shift=None, a_out=None, stats=None, tile=0):
     """y = conv1x1(relu(x*in_scale+in_shift + (x2*x2_scale+x2_shift | x2))); optionally writes that operand to a_out."""
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
@@ -282,7 +283,7 @@ def conv1x1_residual_in(x, x2, w, in_scale, in_shift, x2_scale=None, x2_shift=No
     if stats is not None:
         _chk(stats, torch.float32, "conv_res.stats", (stat_shards(), 2, Cout))
     y = torch.empty(B, H, W, Cout, device=x.device, dtype=dt)
-    d = ConvDesc(B, H, W, Cin, Cout, 1, 1, 1, 0, dtype_code(dt), 1, 0)
+    d = ConvDesc(B, H, W, Cin, Cout, 1, 1, 1, 0, dtype_code(dt), 1, 0, int(tile))
     if TIMING:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()

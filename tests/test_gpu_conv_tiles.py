@@ -1,0 +1,166 @@
+"""GPU parity of EVERY instantiation of the implicit-GEMM convolution, the large tiles included.
+
+The launcher picks the 256x256 tiles only for big problems (>= 192 output tiles), which no oracle-sized test reaches
+by itself; `mhe_conv_desc.tile` forces a kernel variant per call, so each variant is compared with F.conv2d on the same
+bf16-rounded operands (f32 accumulate, tolerance = bf16 output rounding), in all the forms the trunk uses it:
+plain + batch statistics, fused output affine / residual / ReLU, producer-BatchNorm operand load, the residual-tail
+operand load, and the data-gradient form with ReLU gate and BatchNorm-reverse sums.  Then shapes at which the launcher
+selects the large tile by itself.  Replaces torchvision's convolutions: reference hand/network.py:54-61,110."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+TOL = 6e-3                       # bf16 output rounding (2^-9) relative to the tensor's scale
+
+# variant id -> (name, supports the producer-BatchNorm / residual-tail operand loads)
+VARIANTS = {2: ("256x256", True), 3: ("256x128", True), 4: ("256x64", True), 5: ("dma 256x256", False),
+            6: ("dma 128x128", False), 7: ("8-phase 256x256", False)}
+# B, H, W, Cin, Cout, k, stride, pad
+SHAPES = [
+    (2, 24, 20, 64, 256, 1, 1, 0),      # K = a single 64-deep stage, partial M tile
+    (3, 20, 20, 128, 320, 3, 1, 1),     # partial N tile, padding taps
+    (2, 33, 31, 256, 512, 1, 2, 0),     # stride-2 1x1 (the downsample form)
+    (2, 17, 19, 192, 256, 3, 2, 1),     # stride-2 3x3, odd number of K stages (27)
+    (5, 16, 16, 256, 256, 3, 1, 1),     # layer3 conv2 at a small batch: 5 M tiles
+]
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().bfloat16().cuda()
+
+
+def _operands(seed, B, H, W, Cin, Cout, k):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5).bfloat16().float()
+    return g, x, w
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("variant", sorted(VARIANTS), ids=lambda v: VARIANTS[v][0].replace(" ", "-"))
+def test_forced_variant_matches_torch(gpu_lib, variant, shape):
+    from mhentropy_amd import ops, resnet
+    B, H, W, Cin, Cout, k, stride, pad = shape
+    g, x, w = _operands(variant * 100 + Cin + k, B, H, W, Cin, Cout, k)
+    ref = F.conv2d(x.double(), w.double(), None, stride, pad)
+    xd = _nhwc(x)
+    wd = resnet.pack_conv_weight(w, torch.bfloat16).cuda()
+    tile = variant + 1
+    stats = torch.zeros(ops.stat_shards(), 2, Cout, device="cuda")
+    y = ops.conv2d_nhwc(xd, wd, k, k, stride, pad, stats=stats, tile=tile)
+    assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, TOL, what="raw conv")
+    n = ref.numel() / Cout
+    st = stats.double().sum(0).cpu()
+    assert_close(st[0] / n, ref.mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean")
+    assert_close(st[1] / n, (ref ** 2).mean((0, 2, 3)), 1e-5, what="batch E[x^2]")
+    assert (stats.abs().sum((1, 2)) > 0).sum().item() >= min(ops.stat_shards(), (ref.numel() // Cout + 255) // 256), \
+        "statistics must be spread over the shards"
+    # fused eval-mode epilogue: relu(conv*scale+shift + residual)
+    osc = torch.rand(Cout, generator=g) + 0.5
+    osh = torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn(ref.shape, generator=g).bfloat16().float()
+    y2 = ops.conv2d_nhwc(xd, wd, k, k, stride, pad, out_scale=osc.cuda(), out_shift=osh.cuda(), residual=_nhwc(res),
+                         relu_out=True, tile=tile)
+    ref2 = torch.relu(ref * osc.view(1, -1, 1, 1) + osh.view(1, -1, 1, 1) + res)
+    assert_close(y2.float().cpu().permute(0, 3, 1, 2), ref2, TOL, what="fused epilogue")
+    if VARIANTS[variant][1]:
+        # producer BatchNorm + ReLU applied while the operand is loaded (padding must stay zero)
+        isc = torch.rand(Cin, generator=g) + 0.5
+        ish = torch.randn(Cin, generator=g) * 0.3
+        y3 = ops.conv2d_nhwc(xd, wd, k, k, stride, pad, in_scale=isc.cuda(), in_shift=ish.cuda(), relu_in=True, tile=tile)
+        xin = torch.relu(x * isc.view(1, -1, 1, 1) + ish.view(1, -1, 1, 1)).bfloat16().float()
+        ref3 = F.conv2d(xin.double(), w.double(), None, stride, pad)
+        assert_close(y3.float().cpu().permute(0, 3, 1, 2), ref3, TOL, what="fused input transform")
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 20, 256, 256, 1, 1, 0), (3, 20, 20, 128, 320, 3, 1, 1), (5, 16, 16, 256, 256, 3, 1, 1)],
+                         ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("variant", [1, 2, 7], ids=lambda v: {1: "128x128"}.get(v, VARIANTS.get(v, ("",))[0]).replace(" ", "-"))
+def test_data_gradient_form_gate_and_bn_sums(gpu_lib, variant, shape):
+    """y = (conv + residual) [mask > 0] and, for two BatchNorm units fed by y, sum y and sum y (bn_y - mean) invstd
+    (mhe_conv2d_masked_nhwc) against the same quantities from torch; reference hand/CrossModalHand.py:455-470 (backward)."""
+    from mhentropy_amd import ops, resnet
+    B, H, W, Cin, Cout, k, stride, pad = shape
+    g, x, w = _operands(variant * 10 + Cout + k, B, H, W, Cin, Cout, k)
+    conv = F.conv2d(x.double(), w.double(), None, stride, pad)
+    res = torch.randn(conv.shape, generator=g).bfloat16().float()
+    mask = torch.randn(conv.shape, generator=g).bfloat16().float()
+    bny = [(torch.randn(conv.shape, generator=g) * 1.5 + 0.3).bfloat16().float() for _ in range(2)]
+    mi = [torch.stack([torch.randn(Cout, generator=g) * 0.2, torch.rand(Cout, generator=g) + 0.5]) for _ in range(2)]
+    want = (conv + res) * (mask > 0)
+    st = [torch.zeros(ops.stat_shards(), 2, Cout, device="cuda") for _ in range(2)]
+    y = ops.conv2d_nhwc(_nhwc(x), resnet.pack_conv_weight(w, torch.bfloat16).cuda(), k, k, stride, pad, residual=_nhwc(res),
+                        mask=_nhwc(mask), bn=[(_nhwc(bny[u]), mi[u].cuda().contiguous(), st[u]) for u in range(2)], tile=variant + 1)
+    assert_close(y.float().cpu().permute(0, 3, 1, 2), want, TOL, what="gated data gradient")
+    # the sums are taken over the tile as staged for the store (convolution rounded to bf16, then + residual, gate), exactly
+    # what the separate reduce pass would read back: each term carries a rounding error of <= 2^-9 of its value, so a
+    # channel's sum may differ from the exact one by a few 2^-9 sqrt(sum of squares)
+    for u in range(2):
+        s = st[u].double().sum(0).cpu()
+        xhat = (bny[u].double() - mi[u][0].view(1, -1, 1, 1)) * mi[u][1].view(1, -1, 1, 1)
+        for name, got, terms in (("sum g", s[0], conv * (mask > 0)), ("sum g xhat", s[1], conv * (mask > 0) * xhat)):
+            exact = (want if name == "sum g" else want * xhat).sum((0, 2, 3))
+            bound = 5 * 2.0 ** -9 * terms.pow(2).sum((0, 2, 3)).sqrt() + 1e-4 * exact.abs().max()
+            worst = ((got - exact).abs() / bound).max().item()
+            assert worst <= 1.0, f"{name} (unit {u}): |diff| is {worst:.2f} x the bf16 staging bound"
+
+
+@pytest.mark.parametrize("variant", [1, 2], ids=["128x128", "256x256"])
+@pytest.mark.parametrize("affine2", [False, True], ids=["identity", "downsample-bn"])
+def test_residual_tail_operand_load(gpu_lib, variant, affine2):
+    """mhe_conv1x1_residual_in_nhwc: a = relu(x*s+t + (x2*s2+t2 | x2)), y = conv1x1(a), a written out once."""
+    from mhentropy_amd import ops, resnet
+    B, H, W, Cin, Cout = 3, 20, 24, 256, 320
+    g, x, w = _operands(5 + variant, B, H, W, Cin, Cout, 1)
+    x2 = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    sc2, sh2 = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    a = x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + (x2 * sc2.view(1, -1, 1, 1) + sh2.view(1, -1, 1, 1) if affine2 else x2)
+    a = torch.relu(a).bfloat16().float()
+    ref = F.conv2d(a.double(), w.double())
+    a_out = torch.empty(B, H, W, Cin, device="cuda", dtype=torch.bfloat16)
+    stats = torch.zeros(ops.stat_shards(), 2, Cout, device="cuda")
+    y = ops.conv1x1_residual_in(_nhwc(x), _nhwc(x2), resnet.pack_conv_weight(w, torch.bfloat16).cuda(), sc.cuda(), sh.cuda(),
+                                sc2.cuda() if affine2 else None, sh2.cuda() if affine2 else None, a_out=a_out, stats=stats,
+                                tile=variant + 1)
+    assert_close(a_out.float().cpu().permute(0, 3, 1, 2), a, 4e-3, what="block output written by the operand load")
+    assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, TOL, what="conv1x1 of the fused tail")
+    n = ref.numel() / Cout
+    assert_close(stats.double().sum(0).cpu()[0] / n, ref.mean((0, 2, 3)), 1e-4, 1e-4, what="batch mean")
+
+
+@pytest.mark.parametrize("shape", [(12, 64, 64, 64, 256, 1, 1, 0), (192, 16, 16, 256, 256, 3, 1, 1), (48, 32, 32, 128, 512, 1, 1, 0)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_launcher_selected_large_tile_matches_torch(gpu_lib, shape):
+    """shapes big enough (>= 192 output tiles) that the launcher itself takes a 256x256 variant, as at the bench batch"""
+    from mhentropy_amd import ops, resnet, _lib
+    import ctypes as C
+    B, H, W, Cin, Cout, k, stride, pad = shape
+    d = _lib.ConvDesc(B, H, W, Cin, Cout, k, k, stride, pad, ops.BF16, 0, 0, 0)
+    assert _lib.lib().mhe_conv_tile(C.byref(d)) in (2, 7), "expected one of the 256x256 variants for this geometry"
+    g, x, w = _operands(Cin + Cout, B, H, W, Cin, Cout, k)
+    ref = F.conv2d(x, w, None, stride, pad)              # f32 on the bf16-rounded operands (29 GMAC at the 3x3 shape)
+    stats = torch.zeros(ops.stat_shards(), 2, Cout, device="cuda")
+    y = ops.conv2d_nhwc(_nhwc(x), resnet.pack_conv_weight(w, torch.bfloat16).cuda(), k, k, stride, pad, stats=stats)
+    assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, TOL, what="raw conv")
+    n = ref.numel() / Cout
+    st = stats.double().sum(0).cpu()
+    assert_close(st[0] / n, ref.double().mean((0, 2, 3)), 1e-4, 1e-4, what="batch mean")
+    assert_close(st[1] / n, (ref.double() ** 2).mean((0, 2, 3)), 1e-4, what="batch E[x^2]")
+    assert (stats.abs().sum((1, 2)) > 0).sum().item() > 1, "statistics must be spread over more than one shard"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_stem_statistics_use_every_shard(gpu_lib, dtype):
+    """regression: the stem once added every workgroup's partial sums into shard 0 (contended atomics, 3x slower)"""
+    from mhentropy_amd import ops, resnet
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(4, 3, 128, 128, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    stats = torch.zeros(ops.stat_shards(), 2, 64, device="cuda")
+    ops.stem_conv7x7s2(x.cuda(), resnet.pack_stem_weight(w, dtype).cuda(), dtype, stats=stats)
+    assert (stats.abs().sum((1, 2)) > 0).all(), "every statistic shard should receive workgroups"

@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--no-stats", action="store_true")
     ap.add_argument("--no-affine", action="store_true")
+    ap.add_argument("--tile", type=int, default=0, help="force kernel variant tile-1 (mhe_conv_desc.tile)")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     es = 2 if dt == torch.bfloat16 else 4
@@ -66,7 +67,7 @@ def main():
         if fused and not args.no_affine:
             isc, ish = torch.rand(Cp, device="cuda") + 0.5, torch.randn(Cp, device="cuda") * 0.1
         run = lambda: ops.conv2d_nhwc(x, w, k, k, stride, pad, in_scale=isc, in_shift=ish, relu_in=isc is not None,
-                                      stats=st, out=y)
+                                      stats=st, out=y, tile=args.tile)
         run(); run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
