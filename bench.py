@@ -149,6 +149,20 @@ def main():
     if args.dtype is None:
         args.dtype = "bf16" if args.workload == "c2" else "f32"
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing has touched the GPU yet in this process; the N ranks
+        # are fresh children of torch.distributed.run (one per GPU, RCCL over xGMI), rank 0 prints the JSON line on the
+        # inherited stdout, and this process exits with the launcher's status.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log("spawning " + " ".join(cmd))
+        raise SystemExit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode)
+
     from mhentropy_amd import dist as mdist
     # MHE_BENCH_REHEARSE=1 (development only): all ranks share cuda:0 and talk over gloo, to rehearse the N>1 code
     # path on a one-GPU box; the driver's runs use RCCL with one GPU per rank

@@ -195,7 +195,7 @@ int mhe_conv2d_masked_nhwc(const mhe_conv_desc *d, const void *x, const void *w,
                            const void *mask, const void *bn_y0, const float *bn_mean_invstd0, float *bn_stats0,
                            const void *bn_y1, const float *bn_mean_invstd1, float *bn_stats1, void *stream);
 int mhe_conv_stat_shards(void);
-/* tile the launcher picks for a geometry: 0 = 128x64, 1 = 128x128 (4 waves), 2 = 256x256 (8 waves, bf16) */
+/* kernel variant the launcher picks for a geometry with plain operands (numbering of mhe_conv_desc.tile, minus 1) */
 int mhe_conv_tile(const mhe_conv_desc *d);
 
 /* 1x1 stride-1 convolution whose operand is the TAIL of the previous residual block evaluated while

@@ -585,12 +585,15 @@ int launch_p8(const Params &p, hipStream_t s);
 static int choose_tile(const Params &p, bool fast, bool bf16) {
     static const int env_force = getenv("MHE_CONV_TILE") ? atoi(getenv("MHE_CONV_TILE")) : -1;    // tuning knob
     const int force = p.force >= 0 ? p.force : env_force;
-    if (force == 7 && bf16 && p8_supports(p)) return 7;
+    if ((force & 15) == 7 && bf16 && p8_supports(p)) return 7;      // (higher bits: ablation builds of tuning runs)
     if (force >= 0 && force <= 4 && (force < 2 || (fast && bf16))) return force;
     if (p.Cout <= 64) return 0;
     if (fast && bf16 && p.Cout >= 256) {      // (an f32 256x256 output tile would not fit the LDS staging buffers)
         const long tiles = (long)((p.M + 255) / 256) * ((p.Cout + 255) / 256);
-        if (tiles >= 192) return 2;
+        // plain operands go to the phase-pipelined kernel (conv_p8.hip: 0.85-1.0x the time of the register-staged 256x256
+        // kernel on every trunk shape, tools/conv_variants.py); the producer-BatchNorm / residual-tail operand loads need
+        // the register path
+        if (tiles >= 192) return p8_supports(p) && force < 0 ? 7 : 2;
     }
     return 1;
 }
@@ -706,15 +709,17 @@ static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void
 
 extern "C" int mhe_conv_stat_shards(void) { return conv::NSH; }
 
-// which tile the launcher picks for a geometry: 0 = 128x64, 1 = 128x128 (4 waves), 2 = 256x256 (8 waves)
+// which kernel variant the launcher picks for a geometry with plain operands (see mhe_conv_desc.tile); with a producer-BatchNorm /
+// residual-tail operand load variant 7 becomes 2
 extern "C" int mhe_conv_tile(const mhe_conv_desc *d) {
     if (!d) return -1;
     conv::Params p{};
-    p.Cin = d->Cin; p.Cout = d->Cout;
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
     const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
     p.M = d->B * Ho * Wo;
     p.force = d->tile - 1;
     const int bke = d->dtype == MHE_F32 ? 32 : 64;
+    p.Kpad = (d->KH * d->KW * d->Cin + bke - 1) / bke * bke;
     return conv::choose_tile(p, d->Cin % bke == 0, d->dtype == MHE_BF16);
 }
 

@@ -56,6 +56,7 @@ class RealNVP(nn.Module):
     def _packed(self):
         ext = getattr(self, "_external_pack", None)
         if ext is not None:         # kept current on the device by train.TrainStep (gathers from its flat parameter buffer)
+            self._external_sync()   # ... re-gathered here if the parameters were written since (optimizer.step, load_state_dict)
             return ext
         bf16 = self.compute_dtype == torch.bfloat16 and self.hidden % 128 == 0
         ver = tuple(p._version for p in self.parameters()) + (str(self.mask.device), bf16)

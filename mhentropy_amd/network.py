@@ -12,8 +12,9 @@ Extensions (all optional, defaults reproduce the reference):
   * `fused_entropy=True`: log q from the sampling pass instead of a second,
     inverse pass through the flow (same value to fp32 round-off, SURVEY.md A2 ii);
     set False to run the reference's two-pass form.
-Dead reference branches (ConditionalGlow - third-party nflows, absent; VAE prior;
-renderer; GT evidences) raise NotImplementedError.
+The `q_z_giv_i_model='glow'` branch (hand/network.py:342-344,736-742) runs on mhentropy_amd/glow.py's ConditionalGlow - a
+restatement of the published nflows algorithm, parity UNPINNED (the third-party class is absent from the reference tree).
+Dead reference branches (VAE prior, renderer, GT evidences) raise NotImplementedError.
 """
 from typing import Union
 

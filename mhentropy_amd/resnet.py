@@ -129,6 +129,8 @@ class ResNetTrunk(nn.Module):
     def forward(self, x):
         """x (B,3,H,W) float32 NCHW -> (B, feat_dim) float32."""
         dt = self.compute_dtype
+        if getattr(self, "_external_sync", None) is not None:
+            self._external_sync()             # trainer-owned operand packs follow the parameters (optimizer.step, load_state_dict)
         pool = _StatsPool(x.device)
         self._bn_touched = []
         st = pool.take(64) if self.training else None

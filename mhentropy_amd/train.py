@@ -131,7 +131,10 @@ class TrainStep:
         self.repack()
         if self.glow is None:
             self.flow._external_pack = (self.f_stream, self.f_b2, self.f_wc, self.f_bc)
+            self.flow._external_sync = self.sync
         self.trunk._external_w = {id(u.conv.weight): u.w_fwd for u in self.units}
+        self.trunk._external_sync = self.sync
+        self._G_averaged = False
 
     # ------------------------------------------------------------------ parameter arena
     def _flatten_params(self):
@@ -374,6 +377,17 @@ class TrainStep:
             if a["idx"].numel():
                 ops.gather(self.P, a["idx"], a["view"], a["idx2"])
 
+    def sync(self):
+        """refresh every derived operand layout if someone else (torch.optim through the attach() bridge, load_state_dict)
+        wrote the parameters since the last repack; called by every entry point that reads the packs - this class's
+        forward() and the modules' own forward / sample / log_prob paths (ResNetTrunk.forward, RealNVP._packed)"""
+        ver = sum(p._version for p in self._params)
+        if ver != self._param_ver:
+            self.repack()
+            if self.glow is not None:
+                self.glow.invalidate()
+            self._param_ver = ver
+
     def _buf(self, name, shape, dtype=torch.float32):
         key = (name, tuple(shape), dtype)
         b = self._ws.get(key)
@@ -559,12 +573,7 @@ class TrainStep:
         m = self.model
         N = N or m.loss_N
         B = x.shape[0] if trunk_out is None else trunk_out.shape[0]
-        ver = sum(p._version for p in self._params)
-        if ver != self._param_ver:           # someone else (torch.optim, load_state_dict) wrote the parameters: refresh the packs
-            self.repack()
-            if self.glow is not None:
-                self.glow.invalidate()
-            self._param_ver = ver
+        self.sync()           # someone else (torch.optim, load_state_dict) may have written the parameters
         f = self._trunk_forward(x.contiguous()) if trunk_out is None else trunk_out.contiguous()
         feat = ops.linear(f, self.l1["w"], self.l1["b"])
         hd = ops.linear(feat, self.d0["w"], self.d0["b"], relu=True)
@@ -632,6 +641,7 @@ class TrainStep:
             # autograd-bridge use under data parallelism: torch's optimizer expects the averaged gradient in .grad
             self.finish_allreduce()
             self.G.mul_(1.0 / self.world)
+            self._G_averaged = True        # optimizer_step() must not divide by world a second time
 
     def forward_backward(self, x, y, noise=None, N=None, trunk_out=None):
         """forward + reverse pass of total = mean_b(-log_p[b]); fills self.G.  Returns the get_loss dict + 'total'."""
@@ -664,20 +674,39 @@ class TrainStep:
         ops.train_tick(self.step_t, self.sq)
         if self.max_norm and self.max_norm > 0:
             ops.sqnorm(self.G, self.sq)
+        self.last_grad_scale = 1.0 if self._G_averaged else 1.0 / self.world
         ops.adam_step(self.P, self.G, self.M, self.V, self.sq, self.step_t, self.lr, self.betas[0], self.betas[1], self.eps,
-                      self.max_norm or 0.0, 1.0 / self.world)
+                      self.max_norm or 0.0, self.last_grad_scale)
+        self._G_averaged = False
         self.repack()          # every derived operand layout follows the new parameters
         if self.glow is not None:
             self.glow.invalidate()
         self._param_ver = sum(p._version for p in self._params)
 
-    def step(self, x, y, noise=None, N=None, test_samples=0, temp=0.8):
+    def second_bn_update(self):
+        """what a SECOND train-mode encoder pass over the same batch does to the BatchNorm buffers (the reference's metrics
+        pass, hand/CrossModalHand.py:355-361: identical batch statistics, so running = (1-m) running + m stat once more and
+        num_batches_tracked + 1), from the statistics the forward kept - a handful of multi-tensor launches, no second pass"""
+        units = [u for u in self.units if getattr(u, "mi", None) is not None]
+        means = [u.mi[0] for u in units]
+        var = torch._foreach_pow([u.mi[1] for u in units], -2.0)            # 1/invstd^2 = biased var + eps
+        torch._foreach_sub_(var, BN_EPS)
+        torch._foreach_mul_(var, [float(u.y.numel() // u.cout) / max(float(u.y.numel() // u.cout) - 1.0, 1.0) for u in units])
+        torch._foreach_lerp_([u.bn.running_mean for u in units], means, BN_MOMENTUM)
+        torch._foreach_lerp_([u.bn.running_var for u in units], var, BN_MOMENTUM)
+        torch._foreach_add_([u.bn.num_batches_tracked for u in units], 1)
+
+    def step(self, x, y, noise=None, N=None, test_samples=0, temp=0.8, double_bn_update=True):
         """one iteration of the reference's training loop (hand/CrossModalHand.py:353-361,455-470).  test_samples > 0
         adds its per-iteration metrics pass `sample(N=[n,n], temp=0.8, mods={uv,xyz,verts})` to the returned dict,
-        from the conditioning feature of THIS forward (the reference runs the encoder a second time on the same
-        batch in train mode, which reproduces the same feature)."""
+        from the conditioning feature of THIS forward.  The reference runs the encoder a second time on the same
+        batch in train mode for it: same feature, but the BatchNorm running statistics advance twice per iteration -
+        double_bn_update=True (default) reproduces that on the buffers, so checkpoints / eval-mode results match a
+        reference-trained model."""
         out = self.forward_backward(x, y, noise=noise, N=N)
         if test_samples:
+            if double_bn_update and self.tape["trunk"]:
+                self.second_bn_update()
             with torch.no_grad():
                 out.update(self.model.sample(None, N=[test_samples, test_samples], temp=temp, mods={"uv", "xyz", "verts"}, y=y,
                                              feat=self.tape["feat"]))

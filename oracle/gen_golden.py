@@ -300,6 +300,68 @@ def gen_mhent(network, criteria, tables, tag, seed, h, steps, B, Ns):
     np.savez_compressed(os.path.join(GOLD, f"mhent_{tag}.npz"), **gold)
 
 
+def gen_priors(network, tables):
+    """the soft-support priors far OUTSIDE their supports (network.py:155-165, 429-435): th3 up to 3 pi (ball of radius pi),
+    th45 up to +-5 (box +-2), bt up to +-0.2 (box +-0.03) - the get_loss fixtures sit inside them, where those terms are 0.
+    det-head quantities (th3, bt, logs, t) are per image and repeated over the N hypothesis rows, as in the product."""
+    print("[priors_outside]")
+    model, _ = _mhent(network, tables, 21, 64, 2)
+    tb = mano_ref.tables_from_numpy(tables)
+    B, N = 6, 4
+    _, yn = synth.batch(31, B, with_image=False)
+    y = _t(yn)
+    rng = np.random.default_rng(123)
+    det = np.zeros((B, 16), np.float32)                       # th3 | bt | logs | t
+    dirs = rng.normal(0, 1, (B, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    det[:, :3] = dirs * (np.pi * np.array([0.5, 0.999, 1.001, 1.5, 2.2, 3.0]))[:, None]
+    det[:, 3:13] = rng.uniform(-1, 1, (B, 10)) * np.array([0.02, 0.03, 0.031, 0.06, 0.12, 0.2])[:, None]
+    det[:, 13] = rng.normal(0, 0.3, B); det[:, 14:16] = rng.normal(0, 0.2, (B, 2))
+    th45 = (rng.uniform(-1, 1, (N * B, 45)) * rng.choice([0.5, 1.9, 2.0, 2.1, 3.0, 5.0], (N * B, 1))).astype(np.float32)
+    th45[0, :] = 2.0; th45[1, :] = -2.0                         # exactly on the box faces
+    d = np.tile(det, (N, 1))
+    z = torch.as_tensor(np.concatenate([d[:, :3], th45, d[:, 3:13], d[:, 13:14], d[:, 14:16]], 1).astype(np.float32))
+    with torch.no_grad():
+        ref = model._forward_log_p(z, y, use_gt=[], mods=["uv"], feat=torch.zeros(B, 512))
+        mine = network_ref.forward_log_p(tb, z, y, N)
+    keys = ("log_p_uv_giv_z", "log_p_th3", "log_p_th45", "log_p_bt", "log_p")
+    for k in keys:
+        _close("terms." + k, mine[k], ref[k], 5e-5, 5e-4)
+    assert float(ref["log_p_th3"].min()) < -10 and float(ref["log_p_bt"].min()) < -100 and float(ref["log_p_th45"].min()) < -1000
+    gold = {"B": B, "N": N, "z": z.numpy(), "det": det, "th45": th45}
+    gold.update({"y_" + k: v for k, v in yn.items()})
+    gold.update({"terms_" + k: ref[k].numpy() for k in keys})
+    np.savez_compressed(os.path.join(GOLD, "priors_outside.npz"), **gold)
+
+
+def gen_rot6d():
+    """6D rotation representation -> R (manopth/rot6d.py:4-24 and the 'robust' variant :26-51), the first piece of the body-model
+    path (reached at manopth/manolayer.py:150-156)"""
+    print("[rot6d]")
+    from manopth import rot6d        # reference module
+    from oracle import rot6d_ref
+    rng = np.random.default_rng(66)
+    poses = rng.normal(0, 1, (64, 6)).astype(np.float32)
+    poses[0] = [1, 0, 0, 0, 1, 0]                    # already orthonormal
+    poses[1] = [2, 0, 0, 1, 1, 0]                    # needs Gram-Schmidt
+    poses[2] = [1e-3, 0, 0, 0, 2e-3, 0]              # small magnitudes (normalisation)
+    poses[3] = [0, 0, 5, 0.3, 0, 5]                  # nearly parallel pair
+    pt = torch.as_tensor(poses)
+    with torch.no_grad():
+        ref = rot6d.compute_rotation_matrix_from_ortho6d(pt)
+        rob = rot6d.robust_compute_rotation_matrix_from_ortho6d(pt)
+    _close("rot6d", rot6d_ref.rotation_from_ortho6d(pt), ref, 1e-6, 1e-6)
+    _close("rot6d robust", rot6d_ref.rotation_from_ortho6d_robust(pt), rob, 1e-6, 1e-6)
+    # gradient of a fixed linear functional of R, for the reverse kernel
+    w = torch.as_tensor(rng.normal(0, 1, (64, 3, 3)).astype(np.float32))
+    pr = pt.clone().requires_grad_(True)
+    (rot6d.compute_rotation_matrix_from_ortho6d(pr) * w).sum().backward()
+    pm = pt.clone().requires_grad_(True)
+    (rot6d_ref.rotation_from_ortho6d(pm) * w).sum().backward()
+    _close("rot6d grad", pm.grad, pr.grad, 1e-5, 1e-6)
+    np.savez_compressed(os.path.join(GOLD, "rot6d.npz"), poses=poses, R=ref.numpy(), R_robust=rob.numpy(), w=w.numpy(),
+                        grad_poses=pr.grad.numpy())
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     tables = synth.mano_tables(0)
@@ -318,6 +380,8 @@ def main():
     gen_mano(ManoWrapperMod.ManoLayer, tables)
     gen_mhent(network, criteria, tables, "small", 21, 64, 2, 2, (4,))
     gen_mhent(network, criteria, tables, "shipped", 22, 512, 6, 3, (16,))
+    gen_priors(network, tables)
+    gen_rot6d()
     print("golden fixtures written to", GOLD)
 
 

@@ -61,6 +61,24 @@ def test_index_tables_are_the_references():
     assert _c_array(src, "kWrapTipVert") == [mano_ref.WRAPPER_TIP_VERTS[k] for k in (4, 8, 12, 16, 20)]
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference/hand"), reason="the reference tree only exists in the build container")
+def test_index_tables_against_the_reference_source_text():
+    """the same tables parsed straight out of the reference's source text (reading it is study, nothing is imported):
+    hand/manopth/manolayer.py:197-199,228,251,260, hand/utils.py:15, hand/ManoLayer.py:112-127"""
+    ml = open("/root/reference/hand/manopth/manolayer.py").read()
+    lists = [[int(v) for v in m.split(",")] for m in re.findall(r"\[((?:\s*\d+\s*,)+\s*\d+\s*)\]", ml)]
+    assert [1, 4, 7, 10, 13] in lists and [2, 5, 8, 11, 14] in lists and [3, 6, 9, 12, 15] in lists
+    assert [0, 1, 6, 11, 2, 7, 12, 3, 8, 13, 4, 9, 14, 5, 10, 15] in lists                   # reorder_idxs
+    assert list(mano_ref.TIP_VERTS_RIGHT) in lists                                            # [745, 317, 444, 556, 673]
+    assert list(mano_ref.JOINT_REORDER) in lists
+    ut = open("/root/reference/hand/utils.py").read()
+    m = re.search(r"FreiHand2RHD_skeidx\s*=\s*\[([^\]]*)\]", ut)
+    assert [int(v) for v in m.group(1).split(",")] == list(mano_ref.FREIHAND2RHD)
+    wl = open("/root/reference/hand/ManoLayer.py").read()
+    for k, v in mano_ref.WRAPPER_TIP_VERTS.items():
+        assert re.search(rf"\b{v}\b", wl), (k, v)
+
+
 def test_flow_pack_roundtrip():
     """every weight appears exactly once in the packed stream at the documented position"""
     from mhentropy_amd import ops

@@ -68,7 +68,12 @@ def test_trainer_shell_helpers(tmp_path):
         m.update(v, n=8)
     assert (m.count, m.avg, m.val) == (2, 3.0, 4.0)
     assert [harness.multistep_lr(2e-4, e) for e in (0, 149, 150, 249, 250, 400)] == [2e-4, 2e-4, 2e-5, 2e-5, 2e-4 * 0.1 ** 2, 2e-4 * 0.1 ** 2]
-    sched_ref = torch.optim.lr_scheduler.MultiStepLR(torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=2e-4), milestones=[150, 250], gamma=0.1)
+    # ... and against torch's own scheduler, stepped once per epoch like the reference does
+    opt_ref = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=2e-4)
+    sched_ref = torch.optim.lr_scheduler.MultiStepLR(opt_ref, milestones=[150, 250], gamma=0.1)
+    for epoch in range(300):
+        assert abs(harness.multistep_lr(2e-4, epoch) - opt_ref.param_groups[0]["lr"]) < 1e-12, epoch
+        opt_ref.step(); sched_ref.step()
     lin = torch.nn.Linear(3, 2)
     harness.save_model(tmp_path / "ck.pth", lin)
     ck = torch.load(tmp_path / "ck.pth")

@@ -44,8 +44,14 @@ err = ((ts.G / world - want).abs().max() / want.abs().max()).item()
 ts.forward_backward(x, y, noise=z0, N=N)
 ts.optimizer_step()
 psum = float(ts.P.double().sum())
+# attach() bridge + fused step(): backward() already averages G for torch's optimizer; optimizer_step must not divide by world again
+model3, _ = _model_and_state("resnet18", 64, 2)
+tb = TrainStep(model3, dist=dist, lr=0.0).attach()
+tb.forward_backward(x, y, noise=z0, N=N)
+avg_err = ((tb.G - want).abs().max() / want.abs().max()).item()        # .grad holds the mean over ranks for torch's optimizer
+tb.optimizer_step()
 with open(os.path.join(os.environ["MHE_OUT"], f"rank{rank}.json"), "w") as fh:
-    json.dump({"err": err, "psum": psum, "sq": float(ts.sq)}, fh)
+    json.dump({"err": err, "psum": psum, "sq": float(ts.sq), "bridge_avg_err": avg_err, "bridge_scale": tb.last_grad_scale, "plain_scale": ts.last_grad_scale}, fh)
 dist.destroy_process_group()
 '''
 
@@ -63,3 +69,6 @@ def test_two_ranks_average_their_gradients(gpu_lib, tmp_path):
     assert max(r["err"] for r in recs) < 2e-3, recs
     assert recs[0]["psum"] == recs[1]["psum"], recs                # replicas stay bit-identical after clip + Adam
     assert abs(recs[0]["sq"] - recs[1]["sq"]) == 0.0
+    # attach() + step(): the gradient is averaged once (by backward(), for torch's optimizer), not again by the optimizer kernel
+    assert max(r["bridge_avg_err"] for r in recs) < 2e-3, recs
+    assert all(r["bridge_scale"] == 1.0 and r["plain_scale"] == 0.5 for r in recs), recs

@@ -96,6 +96,19 @@ def test_prior_terms_outside_their_support(gpu_lib):
         assert_close(o["terms"][:, i].cpu(), ref[k], 1e-4, what=k)
 
 
+def test_prior_terms_outside_their_support_match_reference_vectors(gpu_lib):
+    """the same, against what the REFERENCE's own _forward_log_p returned (tests/golden/priors_outside.npz: th3 up to 3 pi,
+    th45 up to +-5 and on the box faces, bt up to +-0.2; reference hand/network.py:155-165,429-435,612-667)"""
+    from mhentropy_amd import ops
+    from conftest import load_golden
+    g = load_golden("priors_outside")
+    o = ops.mano_joints(_dev(g["th45"]), _dev(g["det"]), _blob(), _dev(g["y_crop_uv"]), _dev(g["y_vis"]))
+    assert_close(o["z"].cpu(), g["z"], 0.0, what="z assembly (pure copy)")
+    for i, k in enumerate(("log_p_uv_giv_z", "log_p_th3", "log_p_th45", "log_p_bt")):
+        assert_close(o["terms"][:, i].cpu(), g["terms_" + k], 1e-4, what=k)
+    assert_close(o["log_p"].cpu(), g["terms_log_p"], 1e-4, what="log_p rows")
+
+
 def test_vis_flags_other_than_one_are_masked(gpu_lib):
     """the reference masks with (vis == 1): 0 and 2 (H3.6M-style 'invisible') both drop the joint (network.py:255-257)"""
     from mhentropy_amd import ops

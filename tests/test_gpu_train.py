@@ -373,6 +373,67 @@ def test_autograd_bridge_runs_the_references_loop_unchanged(gpu_lib):
             assert off < 5e-3 * tot, (off, tot)
 
 
+def test_module_paths_follow_parameters_written_outside_the_trainer(gpu_lib):
+    """after torch's optimizer.step() on the attach() bridge (hand/CrossModalHand.py:470) and after load_state_dict, the
+    modules' own paths (eval-mode sample, no-grad get_loss) must run on the NEW weights: compared with a fresh model built
+    from the state_dict, which packs its operands from scratch"""
+    from mhentropy_amd.criteria import MHEntLoss
+    from mhentropy_amd.train import TrainStep
+    xn, yn = synth.batch(5, 4, image_size=96)
+    x, y = torch.as_tensor(xn).cuda(), {k: torch.as_tensor(v).cuda() for k, v in yn.items()}
+    z0 = torch.as_tensor(synth.noise(5, 6 * 4)).cuda()
+    model, _ = _model_and_state("resnet18", 64, 2)
+    TrainStep(model).attach()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)       # a step large enough that stale packs would be visible
+    total, _, _ = MHEntLoss()(dict(model.get_loss(x, y, mods=["uv"], N=6, noise=z0)), y)
+    opt.zero_grad(); total.backward(); opt.step()
+
+    def outputs(m):
+        m.eval()
+        with torch.no_grad():
+            o = m.sample(x, N=[3, 3], temp=0.8, mods={"uv", "xyz"}, y=y, noise=z0[:12])
+            l = m.get_loss(x, y, mods=["uv"], N=6, noise=z0)
+        return o["uv"].float().cpu(), l["log_p"].float().cpu()
+
+    fresh, _ = _model_and_state("resnet18", 64, 2)
+    fresh.load_state_dict(model.state_dict())
+    for got, want, what in zip(outputs(model), outputs(fresh), ("sample uv", "log_p")):
+        assert_close(got, want, 1e-5, what=what + " right after optimizer.step()")
+    # ... and a checkpoint load into the trainer-owned model
+    other, _ = _model_and_state("resnet18", 64, 2)
+    with torch.no_grad():
+        for p_ in other.parameters():
+            p_.mul_(1.05)
+    model.load_state_dict(other.state_dict())
+    fresh.load_state_dict(other.state_dict())
+    for got, want, what in zip(outputs(model), outputs(fresh), ("sample uv", "log_p")):
+        assert_close(got, want, 1e-5, what=what + " right after load_state_dict")
+
+
+def test_metrics_pass_advances_batchnorm_buffers_twice(gpu_lib):
+    """the reference runs the encoder twice per iteration in train mode (get_loss, then sample: hand/CrossModalHand.py:355-361),
+    so running_mean / running_var take two momentum updates and num_batches_tracked += 2; step(test_samples=) reuses the
+    feature and applies the second update to the buffers"""
+    from mhentropy_amd.train import TrainStep
+    xn, yn = synth.batch(6, 4, image_size=96)
+    x, y = torch.as_tensor(xn).cuda(), {k: torch.as_tensor(v).cuda() for k, v in yn.items()}
+    z0 = torch.as_tensor(synth.noise(6, 4 * 4)).cuda()
+    ref, _ = _model_and_state("resnet18", 64, 2)
+    ref.train()
+    with torch.no_grad():                        # two train-mode encoder passes over the same batch
+        ref.feat_extractor.res(x); ref.feat_extractor.res(x)
+    model, _ = _model_and_state("resnet18", 64, 2)
+    ts = TrainStep(model, lr=0.0)
+    ts.step(x, y, noise=z0, N=4, test_samples=2)
+    for name in ("bn1", "layer1.0.bn2", "layer3.0.downsample.1", "layer4.1.bn1"):
+        a, b = model.feat_extractor.res.get_submodule(name), ref.feat_extractor.res.get_submodule(name)
+        assert_close(a.running_mean.cpu(), b.running_mean.cpu(), 1e-5, 1e-7, what=name + ".running_mean")
+        assert_close(a.running_var.cpu(), b.running_var.cpu(), 1e-5, what=name + ".running_var")
+        assert int(a.num_batches_tracked) == int(b.num_batches_tracked) == 2
+    ts.step(x, y, noise=z0, N=4, test_samples=2, double_bn_update=False)
+    assert int(model.feat_extractor.res.bn1.num_batches_tracked) == 3
+
+
 def test_run_entry_point(gpu_lib, tmp_path):
     """`python -m mhentropy_amd.run` (shape of the reference's run.py / CrossModalHand.train): two short epochs on synthetic
     batches with the per-iteration metrics pass, MultiStepLR and a checkpoint in the reference's container"""

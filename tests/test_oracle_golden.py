@@ -89,3 +89,30 @@ def test_mhent_oracle_matches_reference_vectors(tag):
     assert_close(tot, g["criterion_total"], 1e-6, what="criterion")
     for k, v in met.items():
         assert_close(v, g["metric_" + k], 1e-6, what=k)
+
+
+def test_priors_oracle_outside_their_supports_matches_reference_vectors():
+    """soft-support priors far outside their supports (reference hand/network.py:155-165,429-435), pinned by values the
+    reference's own _forward_log_p returned (oracle/gen_golden.py:gen_priors)"""
+    g = load_golden("priors_outside")
+    tb = mano_ref.tables_from_numpy(synth.mano_tables(0))
+    y = _t({k[2:]: v for k, v in g.items() if k.startswith("y_")})
+    with torch.no_grad():
+        out = network_ref.forward_log_p(tb, torch.as_tensor(g["z"]), y, int(g["N"]))
+    for k in ("log_p_uv_giv_z", "log_p_th3", "log_p_th45", "log_p_bt", "log_p"):
+        assert_close(out[k], g["terms_" + k], 1e-6, what=k)
+    assert g["terms_log_p_th3"].min() < -10 and g["terms_log_p_bt"].min() < -100 and g["terms_log_p_th45"].min() < -1000
+
+
+def test_rot6d_oracle_matches_reference_vectors():
+    from oracle import rot6d_ref
+    g = load_golden("rot6d")
+    p = torch.as_tensor(g["poses"])
+    assert_close(rot6d_ref.rotation_from_ortho6d(p), g["R"], 1e-6, what="R")
+    assert_close(rot6d_ref.rotation_from_ortho6d_robust(p), g["R_robust"], 1e-6, what="R (robust form)")
+    R = rot6d_ref.rotation_from_ortho6d(p.double())
+    assert_close(R.transpose(1, 2) @ R, torch.eye(3).expand(len(p), 3, 3), 1e-12, 1e-12, what="orthonormal")
+    assert_close(torch.linalg.det(R), np.ones(len(p)), 1e-12, 1e-12, what="det +1")
+    pr = p.clone().requires_grad_(True)
+    (rot6d_ref.rotation_from_ortho6d(pr) * torch.as_tensor(g["w"])).sum().backward()
+    assert_close(pr.grad, g["grad_poses"], 1e-5, what="d/d poses")
