@@ -299,6 +299,27 @@ int mhe_flow_couple_bwd_f32(const float *x_out, const float *Os, const float *Ot
 int mhe_flow_couple_accum_f32(const float *g_part, const float *GXs, const float *GXt, const float *mask,
                               float *g_in, long R, int dim, void *stream);
 
+/* Body-model path of a ProHMR-style head (reference README.md:26-42) ------------------------
+ * 6D rotation representation -> rotation matrix: poses6 [n,6] -> rotmats [n,3,3] row-major with columns (x, y, z);
+ * robust = 0: x = n(a), z = n(x x b), y = z x x (hand/manopth/rot6d.py:4-24); robust = 1: the symmetric form (:26-51);
+ * normalisation n(v) = v / max(|v|, 1e-8) (:54-60).  Reached at hand/manopth/manolayer.py:150-156.  _bwd: reverse of the
+ * Gram-Schmidt form, g_poses6 = (d rotmats / d poses6)^T g_rotmats. */
+int mhe_rot6d_to_rotmat_f32(const float *poses6, float *rotmats, long n, int robust, void *stream);
+int mhe_rot6d_to_rotmat_bwd_f32(const float *poses6, const float *g_rotmats, float *g_poses6, long n, void *stream);
+/* Linear-blend skinning for a body model of runtime size - the arithmetic of hand/manopth/manolayer.py:181-246 with J <= 32
+ * joints on any kinematic tree (parents[0] = -1, parents[j] < j), nb shape coefficients, 9(J-1) pose-blend coefficients and
+ * NV vertices (SMPL: 24 / 10 / 207 / 6,890), from ROTATION MATRICES rotmats [R,J,3,3] and betas [R,nb].
+ *   pose:  j_template [J,3] = J_regressor v_template, j_shapedirs [J,3,nb] = J_regressor shapedirs (the joint regression
+ *          folded into the tables, SURVEY.md A2 iii) -> one workspace row per hypothesis (mhe_lbs_workspace_floats(R,J,nb)
+ *          floats in all): pose map, betas, the J skinning transforms, posed joints; joints [R,J,3] optional copy
+ *   skin:  vertex-fastest tables v_template [3][VP], v_shapedirs [nb][3][VP], v_posedirs [9(J-1)][3][VP], v_weights [J][VP]
+ *          (VP >= NV: padded pitch) -> verts [R,NV,3] * scale.  Hypotheses are independent: shard R across GPUs freely. */
+size_t mhe_lbs_workspace_floats(int R, int J, int nb);
+int mhe_lbs_pose_f32(const float *rotmats, const float *betas, const float *j_template, const float *j_shapedirs,
+                     const int *parents, float *workspace, float *joints, int R, int J, int nb, void *stream);
+int mhe_lbs_skin_f32(const float *workspace, const float *v_template, const float *v_shapedirs, const float *v_posedirs,
+                     const float *v_weights, float *verts, int R, int J, int nb, int NV, int VP, float scale, void *stream);
+
 /* Train-mode BatchNorm(+ReLU) reverse over NHWC activations of storage `dtype` (F.batch_norm backward):
  *   g' = g [a > 0] (a = the unit's post-activation output, NULL = no ReLU);  xhat = (y - mean) invstd
  *   reduce:   stats[shard][0][c] += sum g',  stats[shard][1][c] += sum g' xhat   (mhe_conv_stat_shards() shards, zeroed by caller)
@@ -339,7 +360,9 @@ int mhe_glow_add_image_rows_f32(float *H, const float *img, long img_stride, lon
 int mhe_relu_copy_f32(const float *in, void *out, long n, int out_dtype, void *stream);          /* out f32 or bf16 */
 int mhe_glow_glu_residual_f32(float *H, const void *T, int t_dtype, const float *gate, long gate_stride, long R, int C,
                               int row_div, int n_img, void *stream);                         /* T f32 or bf16 */
-/* params [R,64] = [shift (T) | unconstrained scale (T)]; transform feature j is column first + 2j; logdet accumulates. */
+/* The flow variable is carried zero-padded to ld = ceil(dim/64)*64 columns (64 for the 45-D hand flow, 192 for a 144-D body
+ * pose; dim <= 256); params [R, ceil(2T/64)*64] = [shift (T) | unconstrained scale (T)]; transform feature j is column
+ * first + 2j; logdet accumulates. */
 int mhe_glow_coupling_f32(const float *u, const float *params, float *y, float *logdet, long R, int dim, int first,
                           int n_transform, int inverse, void *stream);
 int mhe_pad64_f32(const float *x, float *xp, long R, int dim, void *stream);

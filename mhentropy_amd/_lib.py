@@ -79,6 +79,11 @@ SIGNATURES = {
     "mhe_maxpool3x3s2_nhwc": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mhe_avgpool_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mhe_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "mhe_rot6d_to_rotmat_f32": (_i, [_p, _p, _l, _i, _p]),
+    "mhe_rot6d_to_rotmat_bwd_f32": (_i, [_p, _p, _p, _l, _p]),
+    "mhe_lbs_workspace_floats": (_sz, [_i, _i, _i]),
+    "mhe_lbs_pose_f32": (_i, [_p] * 7 + [_i, _i, _i, _p]),
+    "mhe_lbs_skin_f32": (_i, [_p] * 6 + [_i, _i, _i, _i, _i, _f, _p]),
     "mhe_topk_gather_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mhe_metrics_f32": (_i, [_p] * 7 + [_i, _i, _p]),
 }

@@ -58,21 +58,26 @@ __global__ __launch_bounds__(256) void glu_residual_kernel(float *__restrict__ H
 //   scale = sigmoid(us + 2) + 1e-3;  forward: y_t = u_t * scale + shift, logdet += sum log scale
 //                                    inverse: y_t = (u_t - shift) / scale, logdet -= sum log scale
 // transform feature j (0..T-1) is column first + 2*j (the alternating mask); identity columns are copied.
+// (ld / ldp: row pitches of the padded variable and of the parameter rows, multiples of 64 - 64 for the 45-D hand flow, 192 for
+// a 144-D body pose)
 __global__ __launch_bounds__(256) void coupling_kernel(const float *__restrict__ u, const float *__restrict__ prm, float *__restrict__ y,
-                                                       float *__restrict__ logdet, long R, int dim, int first, int T, int inverse) {
+                                                       float *__restrict__ logdet, long R, int dim, int first, int T, int inverse, int ld,
+                                                       int ldp) {
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
-    float v = lane < dim ? u[r * 64 + lane] : 0.f;
     float ls = 0.f;
-    const int j = (lane - first) >> 1;
-    if (lane < dim && lane >= first && ((lane - first) & 1) == 0 && j < T) {
-        const float shift = prm[r * 64 + j], us = prm[r * 64 + T + j];
-        const float scale = 1.f / (1.f + expf(-(us + 2.f))) + 1e-3f;
-        ls = logf(scale);
-        v = inverse ? (v - shift) / scale : v * scale + shift;
+    for (int c = lane; c < ld; c += 64) {
+        float v = c < dim ? u[r * ld + c] : 0.f;
+        const int j = (c - first) >> 1;
+        if (c < dim && c >= first && ((c - first) & 1) == 0 && j < T) {
+            const float shift = prm[r * ldp + j], us = prm[r * ldp + T + j];
+            const float scale = 1.f / (1.f + expf(-(us + 2.f))) + 1e-3f;
+            ls += logf(scale);
+            v = inverse ? (v - shift) / scale : v * scale + shift;
+        }
+        y[r * ld + c] = v;
     }
-    y[r * 64 + lane] = v;
     ls = wave_sum(ls);
     if (lane == 0) logdet[r] += inverse ? -ls : ls;
 }
@@ -143,22 +148,26 @@ __global__ __launch_bounds__(256) void relu_bwd_add_kernel(float *__restrict__ a
 }
 
 // x [R,dim] <-> xp [R,64] zero padded; and the base density: out[r] = -|z|^2/2 - dim/2 log(2 pi) + sign * logdet[r] + const
-__global__ __launch_bounds__(256) void pad64_kernel(const float *__restrict__ x, float *__restrict__ xp, long R, int dim) {
+__global__ __launch_bounds__(256) void pad64_kernel(const float *__restrict__ x, float *__restrict__ xp, long R, int dim, int ld) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= R * 64) return;
-    const int d = (int)(i & 63);
-    xp[i] = d < dim ? x[(i >> 6) * dim + d] : 0.f;
+    if (i >= R * ld) return;
+    const int d = (int)(i % ld);
+    xp[i] = d < dim ? x[(i / ld) * dim + d] : 0.f;
 }
 
 __global__ __launch_bounds__(256) void finish_kernel(const float *__restrict__ zp, const float *__restrict__ vp, const float *__restrict__ logdet,
                                                      float *__restrict__ v_out, float *__restrict__ logp, long R, int dim, float sign,
-                                                     float logdet_const) {
+                                                     float logdet_const, int ld) {
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
-    const float z = lane < dim ? zp[r * 64 + lane] : 0.f;
-    const float sq = wave_sum(z * z);
-    if (v_out && lane < dim) v_out[r * dim + lane] = vp[r * 64 + lane];
+    float sq = 0.f;
+    for (int c = lane; c < dim; c += 64) {
+        const float z = zp[r * ld + c];
+        sq = fmaf(z, z, sq);
+        if (v_out) v_out[r * dim + c] = vp[r * ld + c];
+    }
+    sq = wave_sum(sq);
     if (lane == 0) logp[r] = -0.5f * sq - 0.5f * dim * 1.8378770664093453f + sign * (logdet[r] + logdet_const);
 }
 }}  // namespace mhe::glow
@@ -194,27 +203,30 @@ extern "C" int mhe_glow_glu_residual_f32(float *H, const void *T, int t_dtype, c
     return check_launch("glu_residual_kernel");
 }
 
+static inline int pad_cols(int n) { return (n + 63) / 64 * 64; }
+
 extern "C" int mhe_glow_coupling_f32(const float *u, const float *params, float *y, float *logdet, long R, int dim, int first,
                                      int n_transform, int inverse, void *stream) {
-    MHE_REQUIRE(u && params && y && logdet && R > 0 && dim > 0 && dim <= 64 && (first == 0 || first == 1) && n_transform > 0 &&
-                    first + 2 * (n_transform - 1) < dim && 2 * n_transform <= 64,
+    MHE_REQUIRE(u && params && y && logdet && R > 0 && dim > 0 && dim <= 256 && (first == 0 || first == 1) && n_transform > 0 &&
+                    first + 2 * (n_transform - 1) < dim,
                 "mhe_glow_coupling_f32: bad arguments");
     hipLaunchKernelGGL(glow::coupling_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, u, params, y, logdet, R, dim,
-                       first, n_transform, inverse);
+                       first, n_transform, inverse, pad_cols(dim), pad_cols(2 * n_transform));
     return check_launch("coupling_kernel");
 }
 
 extern "C" int mhe_pad64_f32(const float *x, float *xp, long R, int dim, void *stream) {
-    MHE_REQUIRE(x && xp && R > 0 && dim > 0 && dim <= 64, "mhe_pad64_f32: bad arguments");
-    hipLaunchKernelGGL(glow::pad64_kernel, dim3((unsigned)((R * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, xp, R, dim);
+    MHE_REQUIRE(x && xp && R > 0 && dim > 0 && dim <= 256, "mhe_pad64_f32: bad arguments");
+    const int ld = pad_cols(dim);
+    hipLaunchKernelGGL(glow::pad64_kernel, dim3((unsigned)((R * ld + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, xp, R, dim, ld);
     return check_launch("pad64_kernel");
 }
 
 extern "C" int mhe_glow_finish_f32(const float *z_padded, const float *v_padded, const float *logdet, float *v_out, float *log_prob,
                                    long R, int dim, float sign, float logdet_const, void *stream) {
-    MHE_REQUIRE(z_padded && logdet && log_prob && (!v_out || v_padded) && R > 0 && dim > 0 && dim <= 64, "mhe_glow_finish_f32: bad arguments");
+    MHE_REQUIRE(z_padded && logdet && log_prob && (!v_out || v_padded) && R > 0 && dim > 0 && dim <= 256, "mhe_glow_finish_f32: bad arguments");
     hipLaunchKernelGGL(glow::finish_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z_padded, v_padded, logdet, v_out,
-                       log_prob, R, dim, sign, logdet_const);
+                       log_prob, R, dim, sign, logdet_const, pad_cols(dim));
     return check_launch("finish_kernel");
 }
 

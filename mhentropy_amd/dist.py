@@ -80,3 +80,67 @@ def allreduce_gradients(flat, dist=None, bucket_elems=16 << 20):
     for w in works:
         w.wait()
     return flat
+
+
+class HypothesisShards:
+    """Hypothesis-sharded exchange around the image-sharded encoder (SURVEY.md section 8e, "optional hypothesis sharding";
+    config C4).  Given the conditioning feature, an image's K hypotheses are independent, so once the encoder has run on each
+    rank's OWN images:
+      * gather_rows():    all-gather of the per-image rows (conditioning feature (B,512), targets) -> every rank holds all
+                          world*B images - at most a few MB;
+      * hypotheses():     the rank's contiguous slice [lo, hi) of the K hypotheses, which it evaluates for EVERY image
+                          (flow + decode + likelihood on (hi-lo) * world * B rows);
+      * reduce_images():  per-image partial sums over the local hypotheses -> all-reduce (sum): the means over all K;
+      * scatter_grad():   dL/dfeat for all images from the local hypotheses -> reduce-scatter (sum): each rank receives the
+                          gradient rows of its own images and continues its encoder's reverse pass.
+    Parameter gradients of everything after the encoder are partial sums over the local hypotheses; the train step's ordinary
+    flat-gradient all-reduce (sum over ranks, / world) completes them exactly as it completes the image-sharded ones.
+    Worth it when flow + decode cost dominates the encoder (SMPL-size LBS, K = 128), not for the hand model at K = 64.
+    Absent in the reference (no torch.distributed call site)."""
+
+    def __init__(self, dist, K):
+        self.dist, self.K = dist, K
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.rank = dist.get_rank() if dist is not None else 0
+
+    def hypotheses(self):
+        return shard_range(self.K, self.rank, self.world)
+
+    def gather_rows(self, t):
+        """(B, ...) per rank -> (world*B, ...) on every rank, rank-major"""
+        if self.world == 1:
+            return t
+        t = t.contiguous()
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+        self.dist.all_gather_into_tensor(out, t)
+        return out
+
+    def gather_hypothesis_rows(self, t, B):
+        """sample-major rows (K*B, ...) of the rank's own images -> this rank's hypotheses of ALL images, sample-major over the
+        gathered batch: ((hi-lo) * world*B, ...).  (Only parity runs ship host noise this way; a production run draws the
+        slice's base noise on the device.)"""
+        if self.world == 1:
+            return t
+        K = self.K
+        full = self.gather_rows(t.reshape(K, B, *t.shape[1:]).transpose(0, 1).contiguous())        # (world*B, K, ...)
+        lo, hi = self.hypotheses()
+        return full[:, lo:hi].transpose(0, 1).reshape((hi - lo) * full.shape[0], *t.shape[1:]).contiguous()
+
+    def reduce_images(self, t):
+        """sum over ranks of a per-image tensor (in place)"""
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t
+
+    def scatter_grad(self, g_all):
+        """(world*B, F) partial gradients -> (B, F): the sum over ranks of the rows of this rank's own images"""
+        if self.world == 1:
+            return g_all
+        B = g_all.shape[0] // self.world
+        g_all = g_all.contiguous()
+        if self.dist.get_backend() == "nccl":               # RCCL: one reduce-scatter, every xGMI link carries 1/world of it
+            out = torch.empty((B,) + tuple(g_all.shape[1:]), device=g_all.device, dtype=g_all.dtype)
+            self.dist.reduce_scatter_tensor(out, g_all, op=self.dist.ReduceOp.SUM)
+            return out
+        self.dist.all_reduce(g_all, op=self.dist.ReduceOp.SUM)       # gloo (CPU tests, one-GPU rehearsal) has no reduce-scatter
+        return g_all[self.rank * B:(self.rank + 1) * B].contiguous()

@@ -106,8 +106,11 @@ class ConditionalGlow(nn.Module):
         super().__init__()
         if context_features is None or batch_norm_within_layers or activation is not F.relu:
             raise NotImplementedError("only the context-conditioned, batch-norm-free ReLU configuration the reference builds")
-        if features > 64 or hidden_features % 64:
-            raise NotImplementedError(f"unsupported geometry features={features} hidden={hidden_features}")
+        if features > 256 or hidden_features % 64 or context_features % 64:
+            raise NotImplementedError(f"unsupported geometry features={features} hidden={hidden_features} context={context_features}")
+        # the flow variable / the nets' parameter rows are carried zero-padded to multiples of 64 columns
+        # (45 -> 64 for the hand flow; 144 -> 192 for a ProHMR-style 24 x 6D body pose)
+        self.Dp = (features + 63) // 64 * 64
         self.features, self.hidden, self.num_layers, self.num_blocks, self.context_features = \
             features, hidden_features, num_layers, num_blocks_per_layer, context_features
         mask = torch.ones(features)
@@ -141,7 +144,8 @@ class ConditionalGlow(nn.Module):
             A = W * s[None, :]                                           # x -> W (s*x + shift) + b
             c = W @ an.shift.detach().double().cpu() + lu.bias.detach().double().cpu()
             Ainv = torch.linalg.inv(A)
-            pad = lambda M, v: (F.pad(M, (0, 64 - D, 0, 64 - D)).float().to(dev).contiguous(), F.pad(v, (0, 64 - D)).float().to(dev).contiguous())
+            Dp = self.Dp
+            pad = lambda M, v: (F.pad(M, (0, Dp - D, 0, Dp - D)).float().to(dev).contiguous(), F.pad(v, (0, Dp - D)).float().to(dev).contiguous())
             d = {}
             d["A"], d["c"] = pad(A, c)
             d["Ainv"], d["cinv"] = pad(Ainv, -(Ainv @ c))
@@ -149,7 +153,7 @@ class ConditionalGlow(nn.Module):
             net = cp.transform_net
             idf = cp.identity_features.cpu()
             w0 = net.initial_layer.weight.detach()
-            wx = torch.zeros(H, 64, device=dev)
+            wx = torch.zeros(H, self.Dp, device=dev)
             wx[:, idf.to(dev)] = w0[:, :idf.numel()]
             d["wx"] = wx.contiguous()
             wctx.append(w0[:, idf.numel():]); bctx.append(net.initial_layer.bias.detach())
@@ -161,8 +165,9 @@ class ConditionalGlow(nn.Module):
                                                         blk.linear_layers[1].weight.detach().to(torch.bfloat16).contiguous()))
                 wctx.append(blk.context_layer.weight.detach()); bctx.append(blk.context_layer.bias.detach())
             nt = int(cp.transform_features.numel())
-            wf = torch.zeros(64, H, device=dev); wf[:2 * nt] = net.final_layer.weight.detach()
-            bf = torch.zeros(64, device=dev); bf[:2 * nt] = net.final_layer.bias.detach()
+            Pp = (2 * nt + 63) // 64 * 64
+            wf = torch.zeros(Pp, H, device=dev); wf[:2 * nt] = net.final_layer.weight.detach()
+            bf = torch.zeros(Pp, device=dev); bf[:2 * nt] = net.final_layer.bias.detach()
             d["wf"], d["bf"], d["T"], d["first"] = wf.contiguous(), bf.contiguous(), nt, int(cp.transform_features[0])
             pk["layers"].append(d)
         pk["wctx"], pk["bctx"] = torch.cat(wctx).contiguous(), torch.cat(bctx).contiguous()
@@ -203,7 +208,7 @@ class ConditionalGlow(nn.Module):
         dev = v_in.device
         s = ops._stream
         ctab = ops.linear(context, pk["wctx"], pk["bctx"])                       # every context-only term, once per image
-        v = torch.empty(R, 64, device=dev)
+        v = torch.empty(R, self.Dp, device=dev)
         ops.check(L.mhe_pad64_f32(ops._ptr(v_in), ops._ptr(v), R, D, s()), "mhe_pad64_f32")
         z_in = v
         logdet = torch.zeros(R, device=dev)
@@ -215,7 +220,7 @@ class ConditionalGlow(nn.Module):
             if not inverse:
                 v = ops.linear(v, d["A"], d["c"])
             prm = self._net(d, v, ctab, l * per, R, row_div, n_img, bufs)
-            y = torch.empty(R, 64, device=dev)
+            y = torch.empty(R, self.Dp, device=dev)
             ops.check(L.mhe_glow_coupling_f32(ops._ptr(v), ops._ptr(prm), ops._ptr(y), ops._ptr(logdet), R, D, d["first"], d["T"], int(inverse), s()),
                       "mhe_glow_coupling_f32")
             v = ops.linear(y, d["Ainv"], d["cinv"]) if inverse else y

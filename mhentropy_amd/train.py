@@ -89,9 +89,12 @@ class _Unit:
 
 
 class TrainStep:
-    def __init__(self, model, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, dist=None):
+    def __init__(self, model, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, dist=None, shard_hypotheses=False):
         self.model, self.lr, self.betas, self.eps, self.max_norm, self.dist = model, lr, betas, eps, max_norm, dist
         self.world = dist.get_world_size() if dist is not None else 1
+        # hypothesis-sharded exchange (dist.HypothesisShards): images stay sharded for the encoder, every rank evaluates its
+        # slice of the K hypotheses for ALL images from the gathered conditioning features
+        self.shard_hypotheses = bool(shard_hypotheses) and self.world > 1
         trunk = model.feat_extractor.res
         self.trunk = trunk
         self.T = trunk.compute_dtype
@@ -501,7 +504,10 @@ class TrainStep:
         self._grad_ready(0)
 
     # ------------------------------------------------------------------ flow reverse
-    def _flow_backward(self, x_out, cond, g_x, g_logp, N, B):
+    def _flow_backward(self, x_out, cond, g_x, g_logp, N, B, N_all=None):
+        """N: hypotheses per image among the rows; N_all: hypotheses per image the means are taken over (differs only under
+        hypothesis sharding)"""
+        N_all = N_all or N
         fl = self.flow
         h, dim, ncoup = fl.hidden, fl.dim, len(fl.mask)
         R = x_out.shape[0]
@@ -540,7 +546,7 @@ class TrainStep:
                     ops.flow_cond_lrelu(Hb[n][1], cflat[:, (slot + 1) * h:], cstride, B)
                 ops.linear(Hb[n][1], d["w2"], d["b2"], out=O[n])
             x_in, g_in = (xa, ga) if x_cur is not xa else (xb, gb)
-            ops.flow_couple_bwd(x_cur, O[0], O[1], m, g_cur, g_logp, -1.0 / N if g_logp is not None else 0.0, B, x_in, GO[0], GO[1], gpart)
+            ops.flow_couple_bwd(x_cur, O[0], O[1], m, g_cur, g_logp, -1.0 / N_all if g_logp is not None else 0.0, B, x_in, GO[0], GO[1], gpart)
             for n in range(2):
                 d, slot = self.fnets[2 * i + n], (2 * i + n) * 2
                 ops.linear_wgrad(Hb[n][1], GO[n], d["dw2"]); ops.colsum(GO[n], d["db2"])
@@ -576,6 +582,18 @@ class TrainStep:
         self.sync()           # someone else (torch.optim, load_state_dict) may have written the parameters
         f = self._trunk_forward(x.contiguous()) if trunk_out is None else trunk_out.contiguous()
         feat = ops.linear(f, self.l1["w"], self.l1["b"])
+        hs, B_own, N_all, feat_own = None, B, N, feat
+        if self.shard_hypotheses:
+            if self.glow is not None:
+                raise NotImplementedError("hypothesis sharding is wired for the RealNVP branch")
+            from .dist import HypothesisShards
+            hs = HypothesisShards(self.dist, N)
+            feat_own, feat = feat, hs.gather_rows(feat)                       # (world*B, 512): every image's conditioning feature
+            y = {"crop_uv": hs.gather_rows(y["crop_uv"]), "vis": hs.gather_rows(y["vis"])}
+            if noise is not None:
+                noise = hs.gather_hypothesis_rows(noise.reshape(N * B, 45), B)
+            lo, hi = hs.hypotheses()
+            N, B = hi - lo, feat.shape[0]                                      # local hypotheses x all images
         hd = ops.linear(feat, self.d0["w"], self.d0["b"], relu=True)
         det = ops.linear(hd, self.d2["w"], self.d2["b"])[:, :16].contiguous()
         fl = self.flow
@@ -594,12 +612,19 @@ class TrainStep:
         cu, vis = y["crop_uv"].contiguous(), y["vis"].contiguous()
         o = ops.mano_joints(th45, det, blob, cu, vis, m.b_2d, m.th45_ref_alpha, want=("log_p", "norms"))
         q_log_p, hq, log_p = ops.elbo_reduce(o["log_p"], log_q if m.entropy else None, N, B)
+        if hs is not None:
+            # means over the local hypotheses -> sums -> all-reduce -> means over all K; each rank reports its own images
+            part = torch.stack([q_log_p, hq]) * (float(N) / N_all)
+            hs.reduce_images(part)
+            own = slice(hs.rank * B_own, (hs.rank + 1) * B_own)
+            q_log_p, hq = part[0, own].contiguous(), part[1, own].contiguous()
+            log_p = hq + q_log_p
         out = {"th_norm": o["norms"][:, 0], "bt_norm": o["norms"][:, 1], "q_log_p_z_giv_y": q_log_p,
                "log_p": log_p if m.entropy else q_log_p}
         if m.entropy:
             out["h_q_z_giv_i"] = hq
         self.tape = {"f": f, "feat": feat, "hd": hd, "det": det, "cond": cond, "th45": th45, "blob": blob, "cu": cu, "vis": vis,
-                     "N": N, "B": B, "trunk": trunk_out is None}
+                     "N": N, "B": B, "trunk": trunk_out is None, "hs": hs, "B_own": B_own, "N_all": N_all, "feat_own": feat_own}
         return out
 
     def backward(self, g_log_p=None):
@@ -607,17 +632,20 @@ class TrainStep:
         total = mean_b(-log_p[b]) (hand/criteria.py:55,173); fills self.G."""
         m, t = self.model, self.tape
         N, B, f, feat, hd, det, cond, th45 = t["N"], t["B"], t["f"], t["feat"], t["hd"], t["det"], t["cond"], t["th45"]
+        hs, B_own, N_all = t.get("hs"), t.get("B_own", B), t.get("N_all", N)
         self.raw.zero_()
         g_logp = self._buf("g_logp", (B,))
         if g_log_p is None:
-            g_logp.fill_(-1.0 / B)
+            g_logp.fill_(-1.0 / B_own)          # per-rank mean over its own images; the ranks' gradients are averaged (/ world)
+        elif hs is not None:
+            g_logp.copy_(hs.gather_rows(g_log_p.reshape(B_own).contiguous()))
         else:
             g_logp.copy_(g_log_p.reshape(B))
-        g45, gdet_rows = self._mano_bwd(th45, det, t["blob"], t["cu"], t["vis"], g_logp, N)
+        g45, gdet_rows = self._mano_bwd(th45, det, t["blob"], t["cu"], t["vis"], g_logp, N_all)
         if self.glow is not None:
             g_feat = self.glow.backward(g45, g_logp if m.entropy else None, N, B)
         else:
-            Gc = self._flow_backward(th45, cond, g45, g_logp if m.entropy else None, N, B)
+            Gc = self._flow_backward(th45, cond, g45, g_logp if m.entropy else None, N, B, N_all)
         # det head: gdet [B,16] -> padded [B,32]
         gdet = self._buf("gdet", (B, 32)); gdet.zero_()
         ops.sum_over_hypotheses(gdet_rows, N, B, out=gdet, out_stride=32)
@@ -628,6 +656,8 @@ class TrainStep:
             ops.linear_wgrad(feat, Gc, self.dwc); ops.colsum(Gc, self.dbc)
             g_feat = ops.linear(Gc, self.f_wcT)
         ops.add(g_feat, ops.linear(ghd, self.d0["wT"]))
+        if hs is not None:          # partial over the local hypotheses, all images -> this rank's images, all hypotheses
+            g_feat = hs.scatter_grad(g_feat)
         ops.linear_wgrad(f, g_feat, self.l1["dw"]); ops.colsum(g_feat, self.l1["db"])
         g_f = ops.linear(g_feat, self.l1["wT"])
         self._grad_ready(3)
@@ -709,7 +739,7 @@ class TrainStep:
                 self.second_bn_update()
             with torch.no_grad():
                 out.update(self.model.sample(None, N=[test_samples, test_samples], temp=temp, mods={"uv", "xyz", "verts"}, y=y,
-                                             feat=self.tape["feat"]))
+                                             feat=self.tape["feat_own"]))
         self.optimizer_step()
         return out
 

@@ -25,6 +25,9 @@ class GlowPart:
     def __init__(self, ts, glow):
         self.ts, self.g = ts, glow
         D, H, Fc, L, NB = glow.features, glow.hidden, glow.context_features, glow.num_layers, glow.num_blocks
+        if D > 64:
+            raise NotImplementedError("the Glow reverse pass is built for the hand flow (features <= 64); the 144-D body geometry runs "
+                                      "forward / sample / log_prob only")
         self.per = 1 + NB
         self.mixed = glow.compute_dtype == torch.bfloat16 and H % 64 == 0
         T = glow._transform._transforms

@@ -58,6 +58,69 @@ def test_two_ranks_over_gloo(tmp_path):
     assert recs[0]["sum_x"] != recs[1]["sum_x"]                            # different shards
 
 
+X2_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["MHE_ROOT"])
+import torch
+from mhentropy_amd import dist as mdist
+rank, _, world, dist = mdist.init("gloo")
+torch.manual_seed(0)
+B, K, F = 3, 6, 8                      # images per rank, hypotheses per image, feature width
+W = torch.randn(F, 5, dtype=torch.float64)                                   # "flow + decoder" parameters (replicated)
+feat_all = torch.randn(world * B, F, dtype=torch.float64)
+noise_all = torch.randn(K, world * B, 5, dtype=torch.float64)               # sample-major over the global batch
+def rows_loss(feat, noise):          # per-row log-density of a toy conditional model: rows (n, b)
+    return -((feat @ W)[None] + noise).pow(2).sum(-1) + torch.sin(feat.sum(-1))[None]
+# unsharded reference on the global batch: per-image mean over K, loss = mean over images
+fa = feat_all.clone().requires_grad_(True); Wa = W.clone().requires_grad_(True)
+W_saved = W; W = Wa
+per_img = rows_loss(fa, noise_all).mean(0)
+(-per_img.mean()).backward()
+W = W_saved
+# sharded: own images' features -> gather; own hypothesis slice for ALL images; partial sums -> all-reduce; grad -> reduce-scatter
+hs = mdist.HypothesisShards(dist, K)
+own = slice(rank * B, (rank + 1) * B)
+feat_own = feat_all[own].clone()
+noise_own = noise_all[:, own].reshape(K * B, 5)                              # what a rank holds: sample-major over ITS images
+g = hs.gather_rows(feat_own).clone().requires_grad_(True)
+Wl = W.clone().requires_grad_(True)
+W = Wl
+lo, hi = hs.hypotheses()
+nz = hs.gather_hypothesis_rows(noise_own, B).reshape(hi - lo, world * B, 5)
+assert torch.equal(nz, noise_all[lo:hi]), "the rank's hypotheses of all images, sample-major"
+rows = rows_loss(g, nz)
+part = rows.sum(0) / K
+tot = hs.reduce_images(part.detach().clone())
+# reverse: d(-mean_b per_img)/d rows, with the per-rank convention -1/B_own followed by / world
+(part * (-1.0 / B)).sum().backward()
+g_own = hs.scatter_grad(g.grad.clone()) / world
+gW = Wl.grad.clone(); dist.all_reduce(gW); gW /= world
+rec = {"per_img_err": float((tot - per_img.detach()).abs().max()), "gfeat_err": float((g_own - fa.grad[own]).abs().max()),
+       "gW_err": float((gW - Wa.grad).abs().max()), "lo": lo, "hi": hi}
+with open(os.path.join(os.environ["MHE_OUT"], f"x2_rank{rank}.json"), "w") as fh:
+    json.dump(rec, fh)
+dist.destroy_process_group()
+'''
+
+
+def test_hypothesis_sharded_exchange_equals_the_unsharded_loss_and_gradient(tmp_path):
+    """dist.HypothesisShards over gloo, world 2 (SURVEY.md section 8e optional hypothesis sharding): gathering the features,
+    evaluating a slice of the hypotheses for all images, all-reducing the per-image sums and reduce-scattering dL/dfeat gives
+    the unsharded per-image values, feature gradients and (after the ordinary gradient all-reduce) parameter gradients"""
+    import json
+    script = tmp_path / "x2_worker.py"
+    script.write_text(X2_WORKER)
+    env = dict(os.environ, MHE_ROOT=ROOT, MHE_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    recs = [json.load(open(tmp_path / f"x2_rank{r}.json")) for r in range(2)]
+    assert [(r["lo"], r["hi"]) for r in recs] == [(0, 3), (3, 6)]
+    for r in recs:
+        assert r["per_img_err"] < 1e-12 and r["gfeat_err"] < 1e-12 and r["gW_err"] < 1e-12, r
+
+
 def test_trainer_shell_helpers(tmp_path):
     """row f3: AverageMeter quirk, MultiStepLR schedule, checkpoint container (reference hand/utils.py:75-91,
     hand/CrossModalHand.py:202,573-602)"""

@@ -72,3 +72,49 @@ def test_two_ranks_average_their_gradients(gpu_lib, tmp_path):
     # attach() + step(): the gradient is averaged once (by backward(), for torch's optimizer), not again by the optimizer kernel
     assert max(r["bridge_avg_err"] for r in recs) < 2e-3, recs
     assert all(r["bridge_scale"] == 1.0 and r["plain_scale"] == 0.5 for r in recs), recs
+
+
+X2_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["MHE_ROOT"]); sys.path.insert(0, os.path.join(os.environ["MHE_ROOT"], "tests"))
+import torch
+from mhentropy_amd import dist as mdist, synth
+from mhentropy_amd.train import TrainStep
+from test_gpu_train import _model_and_state
+rank, _, world, dist = mdist.init("gloo")
+torch.cuda.set_device(0)
+B, N = 3, 4
+xn, yn = synth.batch(60 + rank, B, image_size=96)
+x, y = torch.as_tensor(xn).cuda(), {k: torch.as_tensor(v).cuda() for k, v in yn.items()}
+z0 = torch.as_tensor(synth.noise(60 + rank, N * B)).cuda()
+res = {}
+for name, sharded in (("images", False), ("hypotheses", True)):
+    model, _ = _model_and_state("resnet18", 64, 2)
+    ts = TrainStep(model, dist=dist, shard_hypotheses=sharded)
+    out = ts.forward_backward(x, y, noise=z0, N=N)
+    ts.finish_allreduce()
+    res[name] = (out["log_p"].clone(), out["h_q_z_giv_i"].clone(), ts.G.clone() / world, ts.tape["g_feat"].clone())
+a, b = res["images"], res["hypotheses"]
+rel = lambda u, v: float((u - v).abs().max() / (v.abs().max() + 1e-30))
+with open(os.path.join(os.environ["MHE_OUT"], f"x2_rank{rank}.json"), "w") as fh:
+    json.dump({"log_p": rel(b[0], a[0]), "h": rel(b[1], a[1]), "grad": rel(b[2], a[2]), "g_feat": rel(b[3], a[3])}, fh)
+dist.destroy_process_group()
+'''
+
+
+def test_hypothesis_sharded_train_step_equals_the_image_sharded_one(gpu_lib, tmp_path):
+    """TrainStep(shard_hypotheses=True) on two ranks (gloo, one GPU): same per-image loss terms, same dL/dfeat for the rank's own
+    images and the same averaged flat gradient as the plain image-sharded step (SURVEY.md section 8e, north_star "optionally
+    hypotheses")"""
+    script = tmp_path / "x2_worker.py"
+    script.write_text(X2_WORKER)
+    env = dict(os.environ, MHE_ROOT=ROOT, MHE_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29635", str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    for r in range(2):
+        rec = json.load(open(tmp_path / f"x2_rank{r}.json"))
+        assert rec["log_p"] < 1e-5 and rec["h"] < 1e-5, rec
+        # two runs of the reverse pass: f32 atomics order differs (see test_two_ranks_average_their_gradients)
+        assert rec["g_feat"] < 2e-3 and rec["grad"] < 2e-3, rec

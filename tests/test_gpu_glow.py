@@ -11,35 +11,40 @@ from mhentropy_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def _glow(seed, hidden, layers=4, blocks=2, ctx=512):
+def _glow(seed, hidden, layers=4, blocks=2, ctx=512, features=45):
     from mhentropy_amd.glow import ConditionalGlow
-    g = ConditionalGlow(45, hidden, layers, blocks, context_features=ctx, dropout_probability=0.2)
-    sd = {k: torch.as_tensor(v) for k, v in synth.glow_state(seed, 45, hidden, layers, blocks, ctx).items()}
+    g = ConditionalGlow(features, hidden, layers, blocks, context_features=ctx, dropout_probability=0.2)
+    sd = {k: torch.as_tensor(v) for k, v in synth.glow_state(seed, features, hidden, layers, blocks, ctx).items()}
     missing, unexpected = g.load_state_dict(sd, strict=False)
     assert not unexpected and all("identity_features" in k or "transform_features" in k or k.endswith("initialized") for k in missing), (missing, unexpected)
     return g.cuda().eval(), sd
 
 
-@pytest.mark.parametrize("hidden,B,N", [(64, 3, 5), (512, 4, 16)])
-def test_glow_matches_the_nflows_restatement(gpu_lib, hidden, B, N):
+# the last case is the body-model geometry SURVEY.md appendix A5 recalls for ProHMR (24 joints x 6D = 144 features, hidden 1024,
+# context 2048; row f1): same kernels, the variable carried padded to 192 columns
+@pytest.mark.parametrize("hidden,B,N,D,F", [(64, 3, 5, 45, 512), (512, 4, 16, 45, 512), (1024, 2, 3, 144, 2048)])
+def test_glow_matches_the_nflows_restatement(gpu_lib, hidden, B, N, D, F):
     from oracle import glow_ref
-    g, sd = _glow(1, hidden)
+    g, sd = _glow(1, hidden, ctx=F, features=D)
     rng = np.random.default_rng(2)
-    noise = torch.as_tensor(rng.normal(0, 0.8, (B, N, 45)).astype(np.float32))
-    ctx = torch.as_tensor(rng.normal(0, 0.5, (B, 512)).astype(np.float32))
+    noise = torch.as_tensor(rng.normal(0, 0.8, (B, N, D)).astype(np.float32))
+    ctx = torch.as_tensor(rng.normal(0, 0.5, (B, F)).astype(np.float32))
     x_ref, lp_ref, _ = glow_ref.sample_and_log_prob(sd, noise, ctx)
     x, lp, nz = g.sample_and_log_prob(N, noise=noise.cuda(), context=ctx.cuda())
-    assert x.shape == (B, N, 45) and lp.shape == (B, N) and g._distribution._shape == torch.Size([45])
+    assert x.shape == (B, N, D) and lp.shape == (B, N) and g._distribution._shape == torch.Size([D])
     assert_close(x.cpu(), x_ref, 1e-4, what="samples"); assert_close(lp.cpu(), lp_ref, 1e-4, what="log_prob of the samples")
     # density of given points, reference call form log_prob(z, context=feat.repeat(N,1)) with sample-major rows (network.py:693-694)
-    xs = x_ref.permute(1, 0, 2).reshape(N * B, 45)
+    xs = x_ref.permute(1, 0, 2).reshape(N * B, D)
     lq_ref, z_ref = glow_ref.log_prob(sd, xs, ctx.repeat(N, 1))
     lq, z = g.log_prob(xs.cuda(), context=ctx.repeat(N, 1).cuda())
     assert_close(lq.cpu(), lq_ref, 1e-4, what="log_prob"); assert_close(z.cpu(), z_ref, 1e-4, what="noise")
     lq2, _ = g.log_prob(xs.cuda(), context=ctx.cuda())                       # B-row context, hoisted per image
     assert_close(lq2.cpu(), lq_ref, 1e-4, what="log_prob (per-image context)")
     # the flow's own identities: forward(inverse(noise)) == noise, same density from both directions
-    assert_close(z.cpu(), noise.permute(1, 0, 2).reshape(N * B, 45), 2e-4, what="round trip")
+    assert_close(z.cpu(), noise.permute(1, 0, 2).reshape(N * B, D), 2e-4, what="round trip")
+    if D == 144:        # ProHMR call form flow(conditioning_feats, num_samples) (reference README.md:34,39)
+        s2, lp2 = g(ctx.cuda(), 2)
+        assert s2.shape == (B, 2, D) and lp2.shape == (B, 2) and torch.isfinite(lp2).all()
     assert_close(lq.cpu(), lp_ref.t().reshape(-1), 2e-4, what="density consistency")
 
 

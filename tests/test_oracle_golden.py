@@ -116,3 +116,19 @@ def test_rot6d_oracle_matches_reference_vectors():
     pr = p.clone().requires_grad_(True)
     (rot6d_ref.rotation_from_ortho6d(pr) * torch.as_tensor(g["w"])).sum().backward()
     assert_close(pr.grad, g["grad_poses"], 1e-5, what="d/d poses")
+
+
+def test_body_lbs_oracle_at_mano_size_is_the_pinned_hand_forward():
+    """the size-generic skinning restatement (oracle/body_ref.py, row f1) reproduces the reference-pinned hand forward when fed the
+    MANO tables, the hand's kinematic tree and the hand's rotations (reference hand/manopth/manolayer.py:181-246)"""
+    from oracle import body_ref
+    g = load_golden("mano")
+    tb = mano_ref.tables_from_numpy(synth.mano_tables(int(g["table_seed"])))
+    theta, beta = torch.as_tensor(g["theta"]), torch.as_tensor(g["beta"])
+    full_pose = torch.cat([theta[:, :3], tb["th_hands_mean"] + theta[:, 3:48].mm(tb["th_selected_comps"])], 1)
+    rots = mano_ref.rodrigues(full_pose.reshape(-1, 3)).view(-1, 16, 3, 3)
+    bt = {"v_template": tb["th_v_template"][0], "shapedirs": tb["th_shapedirs"], "posedirs": tb["th_posedirs"],
+          "J_regressor": tb["th_J_regressor"], "weights": tb["th_weights"], "parents": mano_ref.PARENTS}
+    verts, joints = body_ref.lbs(bt, rots, beta)
+    centre = joints[:, mano_ref.JOINT_REORDER[9]].unsqueeze(1)             # manolayer.py:262-266
+    assert_close((verts - centre) * 1000, g["mesh"], 1e-6, what="mesh")
