@@ -275,6 +275,12 @@ int mhe_sum_over_hypotheses_f32(const float *rows, float *out, int N, int B, int
  * pixel-range split are added with f32 atomics.  With H = W = KH = KW = 1 it is the weight gradient of a dense
  * layer, dW[N][K] += gy[R,N]^T x[R,K] (torch.nn.Linear layout).  Cin, Cout multiples of 4. */
 int mhe_conv_wgrad_nhwc(const mhe_conv_desc *d, const void *x, const void *gy, float *dw, int ldw, void *stream);
+/* The same with a workspace of >= mhe_conv_wgrad_workspace_floats(d) floats: every pixel-range slice stores its partial tile
+ * into the workspace with plain coalesced stores and a reducer launch adds the slabs to dW (dW += as above; nothing needs
+ * zeroing in the workspace).  Falls back to the atomic form when the workspace is NULL or too small. */
+size_t mhe_conv_wgrad_workspace_floats(const mhe_conv_desc *d);
+int mhe_conv_wgrad_ws_nhwc(const mhe_conv_desc *d, const void *x, const void *gy, float *dw, int ldw, float *workspace,
+                           size_t workspace_floats, void *stream);
 /* out[c] += sum_r rows[r][c] (bias gradients; caller zeroes out); rows f32 or bf16, sums f32. */
 int mhe_colsum_f32(const void *rows, float *out, long R, int C, int dtype, void *stream);
 /* dst[i] = (idx[i] < 0 ? 0 : src[idx[i]]) + (idx2 != NULL && idx2[i] >= 0 ? src[idx2[i]] : 0) ; dst f32 or bf16.  Every weight re-layout of a train step (forward

@@ -34,7 +34,9 @@ SIGNATURES = {
     "mhe_mano_verts_f32": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "mhe_mano_joints_bwd_f32": (_i, [_p] * 8 + [_i, _i, _f, _f, _f, _p]),
     "mhe_sum_over_hypotheses_f32": (_i, [_p, _p, _i, _i, _i, _i, _l, _p]),
-    "mhe_conv_wgrad_nhwc": (_i, [_p, _p, _p, _p, _i, _p]),
+    "mhe_conv_wgrad_nhwc": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _i, _p]),
+    "mhe_conv_wgrad_workspace_floats": (_sz, [C.POINTER(ConvDesc)]),
+    "mhe_conv_wgrad_ws_nhwc": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _i, _p, _sz, _p]),
     "mhe_colsum_f32": (_i, [_p, _p, _l, _i, _i, _p]),
     "mhe_gather_f32": (_i, [_p, _p, _p, _p, _sz, _i, _p]),
     "mhe_flow_mask_pad_f32": (_i, [_p, _p, _p, _l, _i, _p]),

@@ -24,6 +24,11 @@ struct Params {
     int N;               // KH*KW*Cin
     long P;              // B*Ho*Wo
     int chunk;           // pixels per gridDim.z slice (multiple of BK)
+    // partial-slab mode (ws != nullptr): slice z stores its tile into ws[z][Mp][Np] with plain coalesced stores and a reducer
+    // pass adds the slabs to dW; otherwise the tiles are added to dW with f32 atomics (~1.3 TB/s chip-wide on gfx950: with
+    // ~1000 slices of 64 KiB that was 10-35 % of a launch)
+    float *ws;
+    int Mp, Np;
 };
 
 constexpr int BK = 16;
@@ -148,7 +153,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const Params p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm * (BM / 2) + 16 * i + 4 * fk + r;
-                if (m < p.Cout && n < p.N) atomicAdd(p.dw + (size_t)m * p.ldw + n, acc[i][j][r]);
+                if (p.ws) p.ws[((size_t)blockIdx.z * p.Mp + m) * p.Np + n] = acc[i][j][r];
+                else if (m < p.Cout && n < p.N) atomicAdd(p.dw + (size_t)m * p.ldw + n, acc[i][j][r]);
             }
         }
 }
@@ -277,9 +283,28 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const Params p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < p.Cout && n < p.N) atomicAdd(p.dw + (size_t)m * p.ldw + n, acc[i][j][r]);
+                if (p.ws) p.ws[((size_t)blockIdx.z * p.Mp + m) * p.Np + n] = acc[i][j][r];
+                else if (m < p.Cout && n < p.N) atomicAdd(p.dw + (size_t)m * p.ldw + n, acc[i][j][r]);
             }
         }
+}
+
+// dW[m][n..n+3] += sum_z ws[z][m][n..n+3]: the reducer of the partial-slab mode (one float4 per thread, slabs read coalesced)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, int gz, int Mp, int Np,
+                                                          int M, int N, int ldw) {
+    const int n4 = N / 4;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)M * n4) return;
+    const int m = (int)(i / n4), n = (int)(i % n4) * 4;
+    v4f a = {0.f, 0.f, 0.f, 0.f};
+    const float *src = ws + (size_t)m * Np + n;
+#pragma unroll 4
+    for (int z = 0; z < gz; ++z) {
+        const v4f v = *reinterpret_cast<const v4f *>(src + (size_t)z * Mp * Np);
+        a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+    }
+    float *dst = dw + (size_t)m * ldw + n;
+    dst[0] += a[0]; dst[1] += a[1]; dst[2] += a[2]; dst[3] += a[3];
 }
 
 // out[c] += sum_r in[r][c]  (bias gradients); one block per 64-row slab x 256 columns
@@ -319,7 +344,52 @@ __global__ __launch_bounds__(256) void gather_kernel(const float *__restrict__ s
 
 using namespace mhe;
 
+// geometry of a launch: tile, grid and pixel chunk (shared by the launcher and the workspace query)
+struct WgradPlan { int BM, BN, gx, gy, gz; long chunk; bool bf16k, small, narrow; };
+static WgradPlan plan_wgrad(const mhe_conv_desc *d) {
+    WgradPlan w;
+    const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+    const int N = d->KH * d->KW * d->Cin;
+    const long P = (long)d->B * Ho * Wo;
+    w.small = d->Cout <= 64;
+    w.bf16k = d->dtype == MHE_BF16 && d->Cin % 8 == 0 && d->Cout % 8 == 0 && !getenv("MHE_WGRAD_F32MFMA");
+    w.narrow = w.bf16k && N <= 64;          // 1x1 layers with 64 input channels: a 128-wide N tile would be half empty
+    w.BM = w.small ? 64 : 128; w.BN = w.narrow ? 64 : 128;
+    w.gx = (N + w.BN - 1) / w.BN; w.gy = (d->Cout + w.BM - 1) / w.BM;
+    // split the pixel range: enough workgroups to fill 256 CUs a few times over; every split adds a full output tile of
+    // partial sums - the bf16 kernel (4x faster mainloop) wants longer slices
+    static const long target_wgs = getenv("MHE_WGRAD_WGS") ? atol(getenv("MHE_WGRAD_WGS")) : 1024;
+    long want = (w.bf16k ? target_wgs : 2048) / ((long)w.gx * w.gy);
+    if (want < 1) want = 1;
+    long chunk = (P + want - 1) / want;
+    static const long min_bf16 = getenv("MHE_WGRAD_MINCHUNK") ? atol(getenv("MHE_WGRAD_MINCHUNK")) : 512;
+    const long min_chunk = w.bf16k ? min_bf16 : 64;
+    if (chunk < min_chunk) chunk = min_chunk;
+    w.chunk = (chunk + 31) / 32 * 32;
+    w.gz = (int)((P + w.chunk - 1) / w.chunk);
+    return w;
+}
+
+extern "C" size_t mhe_conv_wgrad_workspace_floats(const mhe_conv_desc *d) {
+    if (!d || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0) return 0;
+    const WgradPlan w = plan_wgrad(d);
+    // measured (tools/wgrad_bench.py, SLABS=0/1): slabs win 3-25 % from ~16 output tiles up (<= 64 slices each), and lose below
+    // that (many thin slices of a small dW: the reducer walks them serially) - there the atomics stay
+    return (w.gz > 1 && w.gz <= 64) ? (size_t)w.gz * (w.gy * w.BM) * (size_t)(w.gx * w.BN) : 0;
+}
+
+static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, float *dw, int ldw, float *ws, size_t ws_floats, void *stream);
+
 extern "C" int mhe_conv_wgrad_nhwc(const mhe_conv_desc *d, const void *x, const void *gy, float *dw, int ldw, void *stream) {
+    return wgrad_entry(d, x, gy, dw, ldw, nullptr, 0, stream);
+}
+
+extern "C" int mhe_conv_wgrad_ws_nhwc(const mhe_conv_desc *d, const void *x, const void *gy, float *dw, int ldw, float *workspace,
+                                      size_t workspace_floats, void *stream) {
+    return wgrad_entry(d, x, gy, dw, ldw, workspace, workspace_floats, stream);
+}
+
+static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, float *dw, int ldw, float *ws, size_t ws_floats, void *stream) {
     MHE_REQUIRE(d && x && gy && dw, "mhe_conv_wgrad_nhwc: null pointer");
     MHE_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0,
                 "mhe_conv_wgrad_nhwc: bad geometry");
@@ -336,23 +406,13 @@ extern "C" int mhe_conv_wgrad_nhwc(const mhe_conv_desc *d, const void *x, const 
     p.ldw = ldw > 0 ? ldw : p.N;
     MHE_REQUIRE(p.ldw >= p.N, "mhe_conv_wgrad_nhwc: ldw=%d < KH*KW*Cin=%d", ldw, p.N);
     p.P = (long)d->B * p.Ho * p.Wo;
-    const bool small = d->Cout <= 64;
-    const bool bf16k = d->dtype == MHE_BF16 && d->Cin % 8 == 0 && d->Cout % 8 == 0 && !getenv("MHE_WGRAD_F32MFMA");
-    const bool narrow = bf16k && p.N <= 64;          // 1x1 layers with 64 input channels: a 128-wide N tile would be half empty
-    const int BM = small ? 64 : 128, BN = narrow ? 64 : 128;
-    const int gx = (p.N + BN - 1) / BN, gyy = (d->Cout + BM - 1) / BM;
-    // split the pixel range: enough workgroups to fill 256 CUs a few times over, but every split adds a full tile of
-    // f32 atomics - the bf16 kernel (4x faster mainloop) wants longer slices
-    static const long target_wgs = getenv("MHE_WGRAD_WGS") ? atol(getenv("MHE_WGRAD_WGS")) : 1024;
-    long want = (bf16k ? target_wgs : 2048) / ((long)gx * gyy);
-    if (want < 1) want = 1;
-    long chunk = (p.P + want - 1) / want;
-    static const long min_bf16 = getenv("MHE_WGRAD_MINCHUNK") ? atol(getenv("MHE_WGRAD_MINCHUNK")) : 512;
-    const long min_chunk = bf16k ? min_bf16 : 64;
-    if (chunk < min_chunk) chunk = min_chunk;
-    chunk = (chunk + 31) / 32 * 32;
-    p.chunk = (int)chunk;
-    const int gz = (int)((p.P + chunk - 1) / chunk);
+    const WgradPlan w = plan_wgrad(d);
+    const bool small = w.small, bf16k = w.bf16k, narrow = w.narrow;
+    const int gx = w.gx, gyy = w.gy, gz = w.gz;
+    p.chunk = (int)w.chunk;
+    p.Mp = gyy * w.BM; p.Np = gx * w.BN;
+    const size_t need = (size_t)gz * p.Mp * p.Np;
+    p.ws = (ws && gz > 1 && gz <= 64 && need <= ws_floats) ? ws : nullptr;
     const dim3 grid(gx, gyy, gz), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == MHE_F32) {
@@ -368,7 +428,13 @@ extern "C" int mhe_conv_wgrad_nhwc(const mhe_conv_desc *d, const void *x, const 
         if (small) hipLaunchKernelGGL((wgrad::wgrad_kernel<u16, 64, 128>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((wgrad::wgrad_kernel<u16, 128, 128>), grid, block, 0, s, p);
     }
-    return check_launch("wgrad_kernel");
+    if (int rc = check_launch("wgrad_kernel")) return rc;
+    if (p.ws) {
+        const long n = (long)d->Cout * (p.N / 4);
+        hipLaunchKernelGGL(wgrad::slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), block, 0, s, p.ws, dw, gz, p.Mp, p.Np, d->Cout, p.N, p.ldw);
+        return check_launch("slab_reduce_kernel");
+    }
+    return MHE_OK;
 }
 
 extern "C" int mhe_colsum_f32(const void *rows, float *out, long R, int C, int dtype, void *stream) {

@@ -372,6 +372,10 @@ def nchw_to_nhwc(x, dtype=torch.float32):
 
 
 # ---- train-step (reverse) kernels ---------------------------------------------------------------------
+_WGRAD_WS = {}          # per device: one workspace for the partial slabs of the pixel-range split, grown to the largest layer
+WGRAD_SLABS = True      # False: f32 atomics into dw (the form without a workspace)
+
+
 def conv_wgrad(x, gy, KH, KW, stride, pad, dw, ldw=0):
     """dw[Cout, KH*KW*Cin] (f32, pre-zeroed or accumulating) += gy^T (*) x ; x [B,H,W,Cin], gy [B,Ho,Wo,Cout]."""
     B, H, W, Cin = x.shape
@@ -382,7 +386,15 @@ def conv_wgrad(x, gy, KH, KW, stride, pad, dw, ldw=0):
     if dw.numel() < (Cout - 1) * (ldw or KH * KW * Cin) + KH * KW * Cin:
         raise ValueError(f"wgrad.dw: {dw.numel()} floats cannot hold [{Cout}, {KH * KW * Cin}] at pitch {ldw or KH * KW * Cin}")
     d = ConvDesc(B, H, W, Cin, Cout, KH, KW, stride, pad, dtype_code(dt), 0, 0)
-    check(_lib.lib().mhe_conv_wgrad_nhwc(C.byref(d), _ptr(x), _ptr(gy), _ptr(dw), int(ldw), _stream()), "mhe_conv_wgrad_nhwc")
+    L = _lib.lib()
+    need = L.mhe_conv_wgrad_workspace_floats(C.byref(d)) if WGRAD_SLABS else 0
+    if need:
+        ws = _WGRAD_WS.get(x.device)
+        if ws is None or ws.numel() < need:
+            ws = _WGRAD_WS[x.device] = torch.empty(need, device=x.device, dtype=torch.float32)
+        check(L.mhe_conv_wgrad_ws_nhwc(C.byref(d), _ptr(x), _ptr(gy), _ptr(dw), int(ldw), _ptr(ws), ws.numel(), _stream()), "mhe_conv_wgrad_ws_nhwc")
+    else:
+        check(L.mhe_conv_wgrad_nhwc(C.byref(d), _ptr(x), _ptr(gy), _ptr(dw), int(ldw), _stream()), "mhe_conv_wgrad_nhwc")
     return dw
 
 

@@ -119,23 +119,25 @@ CONV_CASES = [(64, 64, 3, 1, 1, 16, 4), (128, 128, 3, 2, 1, 16, 3), (1024, 2048,
               (2048, 512, 1, 1, 0, 4, 4), (512, 512, 3, 1, 1, 8, 2), (64, 256, 1, 1, 0, 16, 2)]
 
 
+@pytest.mark.parametrize("slabs", [True, False], ids=["partial-slabs", "atomics"])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("Cin,Cout,k,stride,pad,H,B", CONV_CASES)
-def test_conv_weight_and_data_gradients(gpu_lib, Cin, Cout, k, stride, pad, H, B, dt):
+def test_conv_weight_and_data_gradients(gpu_lib, Cin, Cout, k, stride, pad, H, B, dt, slabs, monkeypatch):
     """mhe_conv_wgrad_nhwc and the data gradient (forward kernel on flipped / transposed weights) vs autograd of
     F.conv2d on the same (storage-rounded) operands"""
     from mhentropy_amd import ops, train
     import torch.nn.functional as F
+    monkeypatch.setattr(ops, "WGRAD_SLABS", slabs)       # pixel-range partials through workspace slabs + reducer, or f32 atomics
     g = torch.Generator().manual_seed(Cin + Cout + k)
     x = torch.randn(B, Cin, H, H, generator=g).to(dt).float().requires_grad_(True)
     w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(dt).float().requires_grad_(True)
     y = F.conv2d(x, w, stride=stride, padding=pad)
     gy = torch.randn(y.shape, generator=g).to(dt).float()
     y.backward(gy)
-    dw = torch.zeros(Cout, k * k * Cin, device="cuda")
+    dw = torch.ones(Cout, k * k * Cin, device="cuda")              # dW += : the ones must survive
     ops.conv_wgrad(_nhwc(x.detach(), dt), _nhwc(gy, dt), k, k, stride, pad, dw)
     want_dw = w.grad.permute(0, 2, 3, 1).reshape(Cout, -1)
-    assert_close(dw.cpu(), want_dw, 2e-5 if dt == torch.float32 else 2e-5, what="dW")     # bf16 operands, f32 accumulate: exact products
+    assert_close(dw.cpu() - 1.0, want_dw, 2e-5 if dt == torch.float32 else 2e-5, what="dW")     # bf16 operands, f32 accumulate: exact products
     bke = 32 if dt == torch.float32 else 64
     idx = torch.arange(w.numel()).view(w.shape)
     di = train.dgrad_operand_index(idx)

@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mhentropy_amd import ops
 B = int(os.environ.get("B", 256))
+ops.WGRAD_SLABS = os.environ.get("SLABS", "1") == "1"
 dt = torch.bfloat16 if os.environ.get("DT", "bf16") == "bf16" else torch.float32
 shapes = [(64, 64, 1, 1, 64), (64, 64, 3, 1, 64), (64, 256, 1, 1, 64), (256, 64, 1, 1, 64), (256, 128, 1, 1, 64), (128, 128, 3, 2, 64),
           (128, 512, 1, 1, 32), (512, 128, 1, 1, 32), (128, 128, 3, 1, 32), (512, 256, 1, 1, 32), (256, 256, 3, 2, 32), (256, 1024, 1, 1, 16),
