@@ -299,6 +299,16 @@ int mhe_flow_cond_lrelu_mixed(const void *pre, int pre_dtype, const float *cond,
                               void *out_bf16, long R, int B, int H, void *stream);
 int mhe_flow_lrelu_bwd_mixed(const void *g, int g_dtype, const void *h, int h_dtype, float *out_f32, void *out_bf16,
                              long n, float slope, void *stream);
+/* out = g * (h > 0 ? 1 : slope) as f32 and / or bf16 (either may be NULL) AND sum_out[b][c] = sum over the N hypotheses of image b
+ * (row r = n*B + b; sum_out row pitch sum_stride floats): the leaky-ReLU reverse fused with the per-image reduction that
+ * gives the gradient of the conditioning table. */
+int mhe_flow_lrelu_bwd_sum(const void *g, int g_dtype, const void *h, int h_dtype, float *out_f32, void *out_bf16,
+                           float *sum_out, long sum_stride, int N, int B, int H, float slope, void *stream);
+/* mhe_flow_mask_pad_f32 / mhe_flow_couple_bwd_f32 with optional bf16 copies of the GEMM operands they produce */
+int mhe_flow_mask_pad_mixed(const float *x, const float *mask, float *xp, void *xp_bf16, long R, int dim, void *stream);
+int mhe_flow_couple_bwd_mixed(const float *x_out, const float *Os, const float *Ot, const float *mask,
+                              const float *g_out, const float *g_log_p, float q_weight, float *x_in, float *GOs,
+                              float *GOt, float *g_part, void *GOs_bf16, void *GOt_bf16, long R, int B, int dim, void *stream);
 int mhe_flow_couple_bwd_f32(const float *x_out, const float *Os, const float *Ot, const float *mask,
                             const float *g_out, const float *g_log_p, float q_weight, float *x_in, float *GOs,
                             float *GOt, float *g_part, long R, int B, int dim, void *stream);

@@ -12,12 +12,14 @@ namespace mhe { namespace flowbwd {
 constexpr int XP = 64;        // padded width of the flow variable as a GEMM operand
 
 __global__ __launch_bounds__(256) void mask_pad_kernel(const float *__restrict__ x, const float *__restrict__ mask,
-                                                       float *__restrict__ xp, long R, int dim) {
+                                                       float *__restrict__ xp, u16 *__restrict__ xp_b, long R, int dim) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= R * XP) return;
     const long r = i / XP;
     const int d = (int)(i % XP);
-    xp[i] = d < dim ? x[r * dim + d] * mask[d] : 0.f;
+    const float v = d < dim ? x[r * dim + d] * mask[d] : 0.f;
+    if (xp) xp[i] = v;
+    if (xp_b) xp_b[i] = f32_to_bf16(v);
 }
 
 // P[r][c] = leaky_relu(P[r][c] + cond[r % B][c], 0.01)      (hand/flows.py:108-117)
@@ -108,6 +110,35 @@ __global__ __launch_bounds__(256) void lrelu_bwd_mixed_kernel(const TG *__restri
     }
 }
 
+// out[n*B+b][c] = g * (h > 0 ? 1 : slope)  AND  sum_out[b][c] = sum_n out[n*B+b][c]  (the gradient of the per-image conditioning
+// term): one thread per (image, column pair) walks the N hypotheses - the separate sum-over-hypotheses pass re-read the whole
+// f32 tensor (48 launches of ~17 us per train step at the bench size)
+template <typename TG, typename TH>
+__global__ __launch_bounds__(256) void lrelu_bwd_sum_kernel(const TG *__restrict__ g, const TH *__restrict__ h, float *__restrict__ out_f,
+                                                            u16 *__restrict__ out_b, float *__restrict__ sum_out, long sum_stride,
+                                                            int N, int B, int H, float slope) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int hc = H / 2;
+    if (t >= B * hc) return;
+    const int b = t / hc, c = (t % hc) * 2;
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll 8
+    for (int n = 0; n < N; ++n) {
+        const size_t e = ((size_t)n * B + b) * H + c;
+        float g0, g1, h0, h1;
+        if constexpr (sizeof(TG) == 4) { const float2 v = *reinterpret_cast<const float2 *>(g + e); g0 = v.x; g1 = v.y; }
+        else { const unsigned v = *reinterpret_cast<const unsigned *>(g + e); g0 = __uint_as_float(v << 16); g1 = __uint_as_float(v & 0xffff0000u); }
+        if constexpr (sizeof(TH) == 4) { const float2 v = *reinterpret_cast<const float2 *>(h + e); h0 = v.x; h1 = v.y; }
+        else { const unsigned v = *reinterpret_cast<const unsigned *>(h + e); h0 = __uint_as_float(v << 16); h1 = __uint_as_float(v & 0xffff0000u); }
+        g0 = h0 > 0.f ? g0 : slope * g0;
+        g1 = h1 > 0.f ? g1 : slope * g1;
+        if (out_f) *reinterpret_cast<float2 *>(out_f + e) = make_float2(g0, g1);
+        if (out_b) *reinterpret_cast<unsigned *>(out_b + e) = (unsigned)f32_to_bf16(g0) | ((unsigned)f32_to_bf16(g1) << 16);
+        a0 += g0; a1 += g1;
+    }
+    *reinterpret_cast<float2 *>(sum_out + (size_t)b * sum_stride + c) = make_float2(a0, a1);
+}
+
 // One coupling, reverse: from its output x_out and the nets' raw outputs Os, Ot (bias included, 64-wide)
 //   s = tanh(Os)(1-m), t = Ot(1-m), x_in = m x_out + (1-m)(x_out - t) e^{-s}          (hand/flows.py:213-216)
 // and the adjoints of x_out (g_out) and of log q (a_q per row; log q = logN(z0) - sum s):
@@ -116,7 +147,7 @@ __global__ __launch_bounds__(256) void couple_bwd_kernel(
     const float *__restrict__ x_out, const float *__restrict__ Os, const float *__restrict__ Ot,
     const float *__restrict__ mask, const float *__restrict__ g_out, const float *__restrict__ g_logp, float q_weight,
     float *__restrict__ x_in, float *__restrict__ GOs, float *__restrict__ GOt, float *__restrict__ g_part,
-    long R, int B, int dim) {
+    long R, int B, int dim, u16 *__restrict__ GOs_b, u16 *__restrict__ GOt_b) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= R * XP) return;
     const long r = i / XP;
@@ -139,6 +170,7 @@ __global__ __launch_bounds__(256) void couple_bwd_kernel(
     }
     GOs[i] = gos;
     GOt[i] = got;
+    if (GOs_b) { GOs_b[i] = f32_to_bf16(gos); GOt_b[i] = f32_to_bf16(got); }
 }
 
 // g_in = g_part + m (GXs + GXt): the nets' input is m * x
@@ -156,10 +188,15 @@ __global__ __launch_bounds__(256) void couple_accum_kernel(const float *__restri
 using namespace mhe;
 static inline unsigned ew_grid(long n) { long b = (n + 255) / 256; return (unsigned)(b < 1 ? 1 : (b > 16384 ? 16384 : b)); }
 
-extern "C" int mhe_flow_mask_pad_f32(const float *x, const float *mask, float *xp, long R, int dim, void *stream) {
-    MHE_REQUIRE(x && mask && xp && R > 0 && dim > 0 && dim <= flowbwd::XP, "mhe_flow_mask_pad_f32: bad arguments");
-    hipLaunchKernelGGL(flowbwd::mask_pad_kernel, dim3((unsigned)((R * flowbwd::XP + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, mask, xp, R, dim);
+extern "C" int mhe_flow_mask_pad_mixed(const float *x, const float *mask, float *xp, void *xp_bf16, long R, int dim, void *stream) {
+    MHE_REQUIRE(x && mask && (xp || xp_bf16) && R > 0 && dim > 0 && dim <= flowbwd::XP, "mhe_flow_mask_pad: bad arguments");
+    hipLaunchKernelGGL(flowbwd::mask_pad_kernel, dim3((unsigned)((R * flowbwd::XP + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, mask, xp,
+                       (u16 *)xp_bf16, R, dim);
     return check_launch("mask_pad_kernel");
+}
+
+extern "C" int mhe_flow_mask_pad_f32(const float *x, const float *mask, float *xp, long R, int dim, void *stream) {
+    return mhe_flow_mask_pad_mixed(x, mask, xp, nullptr, R, dim, stream);
 }
 
 extern "C" int mhe_flow_cond_lrelu_f32(float *P, const float *cond, long cond_stride, long R, int B, int H, void *stream) {
@@ -180,14 +217,39 @@ extern "C" int mhe_flow_lrelu_bwd_f32(float *G, const float *Hact, long n, float
     return check_launch("lrelu_bwd_kernel");
 }
 
+extern "C" int mhe_flow_couple_bwd_mixed(const float *x_out, const float *Os, const float *Ot, const float *mask,
+                                         const float *g_out, const float *g_log_p, float q_weight, float *x_in, float *GOs,
+                                         float *GOt, float *g_part, void *GOs_bf16, void *GOt_bf16, long R, int B, int dim, void *stream) {
+    MHE_REQUIRE(x_out && Os && Ot && mask && g_out && x_in && GOs && GOt && g_part, "mhe_flow_couple_bwd: null pointer");
+    MHE_REQUIRE((GOs_bf16 == nullptr) == (GOt_bf16 == nullptr), "mhe_flow_couple_bwd: the bf16 copies come together");
+    MHE_REQUIRE(R > 0 && B > 0 && R % B == 0 && dim > 0 && dim <= flowbwd::XP, "mhe_flow_couple_bwd: bad sizes");
+    hipLaunchKernelGGL(flowbwd::couple_bwd_kernel, dim3((unsigned)((R * flowbwd::XP + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       x_out, Os, Ot, mask, g_out, g_log_p, q_weight, x_in, GOs, GOt, g_part, R, B, dim, (u16 *)GOs_bf16, (u16 *)GOt_bf16);
+    return check_launch("couple_bwd_kernel");
+}
+
 extern "C" int mhe_flow_couple_bwd_f32(const float *x_out, const float *Os, const float *Ot, const float *mask,
                                        const float *g_out, const float *g_log_p, float q_weight, float *x_in, float *GOs,
                                        float *GOt, float *g_part, long R, int B, int dim, void *stream) {
-    MHE_REQUIRE(x_out && Os && Ot && mask && g_out && x_in && GOs && GOt && g_part, "mhe_flow_couple_bwd_f32: null pointer");
-    MHE_REQUIRE(R > 0 && B > 0 && R % B == 0 && dim > 0 && dim <= flowbwd::XP, "mhe_flow_couple_bwd_f32: bad sizes");
-    hipLaunchKernelGGL(flowbwd::couple_bwd_kernel, dim3((unsigned)((R * flowbwd::XP + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       x_out, Os, Ot, mask, g_out, g_log_p, q_weight, x_in, GOs, GOt, g_part, R, B, dim);
-    return check_launch("couple_bwd_kernel");
+    return mhe_flow_couple_bwd_mixed(x_out, Os, Ot, mask, g_out, g_log_p, q_weight, x_in, GOs, GOt, g_part, nullptr, nullptr, R, B, dim, stream);
+}
+
+extern "C" int mhe_flow_lrelu_bwd_sum(const void *g, int g_dtype, const void *h, int h_dtype, float *out_f32, void *out_bf16,
+                                      float *sum_out, long sum_stride, int N, int B, int H, float slope, void *stream) {
+    MHE_REQUIRE(g && h && sum_out && N > 0 && B > 0 && H > 0 && H % 2 == 0 && sum_stride >= H && sum_stride % 2 == 0,
+                "mhe_flow_lrelu_bwd_sum: bad arguments");
+    const dim3 grid((unsigned)(((long)B * (H / 2) + 255) / 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    u16 *ob = (u16 *)out_bf16;
+    if (g_dtype == MHE_F32 && h_dtype == MHE_F32)
+        hipLaunchKernelGGL((flowbwd::lrelu_bwd_sum_kernel<float, float>), grid, block, 0, s, (const float *)g, (const float *)h, out_f32, ob, sum_out, sum_stride, N, B, H, slope);
+    else if (g_dtype == MHE_F32)
+        hipLaunchKernelGGL((flowbwd::lrelu_bwd_sum_kernel<float, u16>), grid, block, 0, s, (const float *)g, (const u16 *)h, out_f32, ob, sum_out, sum_stride, N, B, H, slope);
+    else if (h_dtype == MHE_F32)
+        hipLaunchKernelGGL((flowbwd::lrelu_bwd_sum_kernel<u16, float>), grid, block, 0, s, (const u16 *)g, (const float *)h, out_f32, ob, sum_out, sum_stride, N, B, H, slope);
+    else
+        hipLaunchKernelGGL((flowbwd::lrelu_bwd_sum_kernel<u16, u16>), grid, block, 0, s, (const u16 *)g, (const u16 *)h, out_f32, ob, sum_out, sum_stride, N, B, H, slope);
+    return check_launch("lrelu_bwd_sum_kernel");
 }
 
 extern "C" int mhe_flow_couple_accum_f32(const float *g_part, const float *GXs, const float *GXt, const float *mask,

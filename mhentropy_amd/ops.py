@@ -431,6 +431,29 @@ def flow_mask_pad(x, mask_row, out):
     return out
 
 
+def flow_mask_pad_mixed(x, mask_row, out_f32=None, out_bf16=None):
+    R, dim = x.shape
+    _chk(x, torch.float32, "mask_pad.x"); _chk(mask_row, torch.float32, "mask_pad.mask", (dim,))
+    if out_f32 is not None:
+        _chk(out_f32, torch.float32, "mask_pad.out", (R, 64))
+    if out_bf16 is not None:
+        _chk(out_bf16, torch.bfloat16, "mask_pad.out_bf16", (R, 64))
+    check(_lib.lib().mhe_flow_mask_pad_mixed(_ptr(x), _ptr(mask_row), _ptr(out_f32), _ptr(out_bf16), R, dim, _stream()), "mhe_flow_mask_pad_mixed")
+
+
+def flow_lrelu_bwd_sum(g, h, N, B, sum_out, sum_stride, out_f32=None, out_bf16=None, slope=0.01):
+    """out = g * (h > 0 ? 1 : slope) (f32 and / or bf16) and sum_out[b] = sum over the image's N hypothesis rows; sum_out may be a
+    column slice of a wider [B, sum_stride] matrix"""
+    R, H = g.shape
+    _chk(g, g.dtype, "lrelu_bwd_sum.g", (N * B, H)); _chk(h, h.dtype, "lrelu_bwd_sum.h", (R, H))
+    if out_f32 is not None:
+        _chk(out_f32, torch.float32, "lrelu_bwd_sum.out_f32", (R, H))
+    if out_bf16 is not None:
+        _chk(out_bf16, torch.bfloat16, "lrelu_bwd_sum.out_bf16", (R, H))
+    check(_lib.lib().mhe_flow_lrelu_bwd_sum(_ptr(g), dtype_code(g.dtype), _ptr(h), dtype_code(h.dtype), _ptr(out_f32), _ptr(out_bf16),
+                                            C.c_void_p(sum_out.data_ptr()), int(sum_stride), N, B, H, float(slope), _stream()), "mhe_flow_lrelu_bwd_sum")
+
+
 def flow_cond_lrelu(P, cond_slice, cond_stride, B):
     """P[r] = leaky_relu(P[r] + cond_slice[(r % B) * cond_stride : +H]) in place; cond_slice = view starting at the net/layer's column"""
     R, H = P.shape
@@ -452,14 +475,16 @@ def add(a, b, out=None):
     return out
 
 
-def flow_couple_bwd(x_out, Os, Ot, mask_row, g_out, g_log_p, q_weight, B, x_in, GOs, GOt, g_part):
+def flow_couple_bwd(x_out, Os, Ot, mask_row, g_out, g_log_p, q_weight, B, x_in, GOs, GOt, g_part, GOs_bf16=None, GOt_bf16=None):
     R, dim = x_out.shape
+    if GOs_bf16 is not None:
+        _chk(GOs_bf16, torch.bfloat16, "couple_bwd.GOs_bf16", (R, 64)); _chk(GOt_bf16, torch.bfloat16, "couple_bwd.GOt_bf16", (R, 64))
     for t, n, s in ((x_out, "x_out", (R, dim)), (Os, "Os", (R, 64)), (Ot, "Ot", (R, 64)), (g_out, "g_out", (R, dim)),
                     (x_in, "x_in", (R, dim)), (GOs, "GOs", (R, 64)), (GOt, "GOt", (R, 64)), (g_part, "g_part", (R, dim))):
         _chk(t, torch.float32, "couple_bwd." + n, s)
-    check(_lib.lib().mhe_flow_couple_bwd_f32(_ptr(x_out), _ptr(Os), _ptr(Ot), _ptr(mask_row), _ptr(g_out), _ptr(g_log_p),
-                                             float(q_weight), _ptr(x_in), _ptr(GOs), _ptr(GOt), _ptr(g_part), R, B, dim, _stream()),
-          "mhe_flow_couple_bwd_f32")
+    check(_lib.lib().mhe_flow_couple_bwd_mixed(_ptr(x_out), _ptr(Os), _ptr(Ot), _ptr(mask_row), _ptr(g_out), _ptr(g_log_p),
+                                               float(q_weight), _ptr(x_in), _ptr(GOs), _ptr(GOt), _ptr(g_part), _ptr(GOs_bf16), _ptr(GOt_bf16),
+                                               R, B, dim, _stream()), "mhe_flow_couple_bwd_mixed")
 
 
 def flow_couple_accum(g_part, GXs, GXt, mask_row, g_in):

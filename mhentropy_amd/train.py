@@ -340,9 +340,11 @@ class TrainStep:
                 b2i = torch.full((64,), -1, dtype=torch.int64); b2i[:dim] = self._pidx(net.l[2].bias)
                 d["w0"], d["w0T"] = self._derived(w0i, torch.float32), self._derived(w0i.t().contiguous(), torch.float32)
                 d["w1"], d["w1T"] = net.l[1].weight.data, self._derived(self._pidx(net.l[1].weight).t().contiguous(), torch.float32)
-                if bf16:        # operands of the hidden x hidden products on bf16 MFMA
+                if bf16:        # bf16 operand copies for the products that run on bf16 MFMA (all but the two 64-wide f32 ones)
                     d["w1b"] = self._derived(self._pidx(net.l[1].weight), torch.bfloat16)
                     d["w1Tb"] = self._derived(self._pidx(net.l[1].weight).t().contiguous(), torch.bfloat16)
+                    d["w0b"] = self._derived(w0i, torch.bfloat16)                           # [h, 64]: XP W0^T
+                    d["w2Tb"] = self._derived(w2i.t().contiguous(), torch.bfloat16)         # [h, 64]: GO W2
                 d["w2"], d["w2T"] = self._derived(w2i, torch.float32), self._derived(w2i.t().contiguous(), torch.float32)
                 d["b2"] = self._derived(b2i, torch.float32)
                 d["r0"], d["r1"], d["r2"], d["rb2"] = (self._raw_slot(s) for s in ((h, 64), (h, h), (64, h), (64,)))
@@ -530,6 +532,41 @@ class TrainStep:
             H1b = [self._buf(f"H1b{n}", (R, h), bf) for n in range(2)]
             P2b, G2b, GH1b = self._buf("P2b", (R, h), bf), self._buf("G2b", (R, h), bf), self._buf("GH1b", (R, h), bf)
             v4 = lambda t: t.view(R, 1, 1, t.shape[1])
+        if mixed:
+            # bf16 performance mode: every product except the two that feed exp/tanh (H1 W2^T -> s, t) or the flow variable's own
+            # gradient chain (G1 W0 -> GX) takes bf16 operands with f32 accumulation - as the forward kernel does; the leaky-ReLU
+            # reverse is fused with the per-image sums that give the conditioning table's gradient
+            XPb, P0b = self._buf("XPb", (R, 64), bf), self._buf("P0b", (R, h), bf)
+            H2b = [self._buf(f"H2b{n}", (R, h), bf) for n in range(2)]
+            GOb = [self._buf(f"GOb{n}", (R, 64), bf) for n in range(2)]
+            G1b = self._buf("G1b", (R, h), bf)
+            for i in range(ncoup - 1, -1, -1):
+                m = fl.mask[i]
+                ops.flow_mask_pad_mixed(x_cur, m, out_bf16=XPb)
+                for n in range(2):
+                    d, slot = self.fnets[2 * i + n], (2 * i + n) * 2
+                    ops.conv2d_nhwc(v4(XPb), d["w0b"], 1, 1, 1, 0, out=v4(P0b))
+                    ops.flow_cond_lrelu_mixed(P0b, cflat[:, slot * h:], cstride, B, out_bf16=H1b[n])
+                    ops.conv2d_nhwc(v4(H1b[n]), d["w1b"], 1, 1, 1, 0, out=v4(P2b))
+                    ops.flow_cond_lrelu_mixed(P2b, cflat[:, (slot + 1) * h:], cstride, B, out_f32=Hb[n][1], out_bf16=H2b[n])
+                    ops.linear(Hb[n][1], d["w2"], d["b2"], out=O[n])
+                x_in, g_in = (xa, ga) if x_cur is not xa else (xb, gb)
+                ops.flow_couple_bwd(x_cur, O[0], O[1], m, g_cur, g_logp, -1.0 / N_all if g_logp is not None else 0.0, B, x_in, GO[0], GO[1], gpart,
+                                    GOb[0], GOb[1])
+                for n in range(2):
+                    d, slot = self.fnets[2 * i + n], (2 * i + n) * 2
+                    ops.conv_wgrad(v4(H2b[n]), v4(GOb[n]), 1, 1, 1, 0, d["dw2"]); ops.colsum(GO[n], d["db2"])
+                    ops.conv2d_nhwc(v4(GOb[n]), d["w2Tb"], 1, 1, 1, 0, out=v4(P2b))
+                    ops.flow_lrelu_bwd_sum(P2b, H2b[n], N, B, Gc[:, (slot + 1) * h:], Gc.shape[1], out_bf16=G2b)
+                    ops.conv_wgrad(v4(H1b[n]), v4(G2b), 1, 1, 1, 0, d["dw1"])
+                    ops.conv2d_nhwc(v4(G2b), d["w1Tb"], 1, 1, 1, 0, out=v4(GH1b))
+                    ops.flow_lrelu_bwd_sum(GH1b, H1b[n], N, B, Gc[:, slot * h:], Gc.shape[1], out_f32=G1, out_bf16=G1b)
+                    ops.conv_wgrad(v4(XPb), v4(G1b), 1, 1, 1, 0, d["dw0"])
+                    ops.linear(G1, d["w0T"], out=GX[n])
+                ops.flow_couple_accum(gpart, GX[0], GX[1], m, g_in)
+                x_cur, g_cur = x_in, g_in
+            self.z0_recovered = x_cur
+            return Gc
         for i in range(ncoup - 1, -1, -1):
             m = fl.mask[i]
             ops.flow_mask_pad(x_cur, m, XP)

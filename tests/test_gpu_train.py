@@ -270,7 +270,9 @@ def test_bf16_flow_reverse_close_to_fp32_autograd(gpu_lib):
     flow = [r for r in rows if r[2].startswith("q_z_giv_i")]
     assert len(flow) == 2 * steps * 2 * 10
     assert max(r[1] for r in flow) < 0.15, sorted(flow, key=lambda r: -r[1])[:5]
-    assert sorted(r[1] for r in flow)[len(flow) // 2] < 3e-2, sorted(r[1] for r in flow)[len(flow) // 2]
+    # (with only N*B = 32 rows the bf16 roundings do not average out: the median sits at ~3e-2 since round 2, when the 45-wide
+    # products' operands went to bf16 as well - like the forward kernel's; every product accumulates in f32)
+    assert sorted(r[1] for r in flow)[len(flow) // 2] < 4e-2, sorted(r[1] for r in flow)[len(flow) // 2]
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
