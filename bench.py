@@ -54,7 +54,7 @@ def build_model(cfg, dtype, seed, flow="realnvp"):
     return model, sd
 
 
-def cpu_baseline(cfg, sd, seed, budget_s=20.0):
+def cpu_baseline(cfg, sd, seed, budget_s=26.0):
     """The oracle restatement (kind 'port') timed on this host's cores on a bounded
     sample of the same workload: same networks, same K, fewer images."""
     from mhentropy_amd import synth
@@ -71,18 +71,21 @@ def cpu_baseline(cfg, sd, seed, budget_s=20.0):
     xt = torch.as_tensor(x)
     times = []
     t_start = time.time()
+    WARM = 2                                 # median of the timed runs after 2 warm-ups
     with torch.no_grad():
-        for i in range(6):
+        for i in range(WARM + 5):
             t0 = time.time()
             network_ref.get_loss(sdt, tb, xt, y, z0, K, cfg["backbone"], True)
             times.append(time.time() - t0)
             log(f"cpu baseline pass {i}: {times[-1]:.2f}s")
-            if time.time() - t_start > budget_s and len(times) >= 2:
+            if time.time() - t_start > budget_s and len(times) >= WARM + 3:
                 break
-    t = float(np.median(times[1:])) if len(times) > 1 else times[0]
+    timed = times[WARM:] if len(times) > WARM else times[-1:]
+    t = float(np.median(timed))
     return {"value": Bs * K / t, "unit": "hypotheses/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle get_loss (torch CPU fp32, train-mode BN), B={Bs} images x K={K}, 256x256, "
-                      f"median of {max(len(times) - 1, 1)} runs after 1 warm-up, {t * 1e3:.0f} ms/pass"}
+            "sample": f"oracle get_loss (torch CPU fp32, train-mode BN) on B={Bs} of the GPU line's {cfg['B']} images x K={K} "
+                      f"hypotheses, 256x256 (same networks and seeds; a {cfg['B']}-image pass would take ~{cfg['B'] / Bs * t:.0f} s), "
+                      f"median of {len(timed)} runs after {min(WARM, len(times) - 1)} warm-ups, {t * 1e3:.0f} ms/pass"}
 
 
 def time_train_step(model, x, y, noise, B, K, args, dist, world, dev):
@@ -267,9 +270,13 @@ def main():
             log(f"glow variant skipped: {type(e).__name__}: {e}")
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (the MFMA implicit-GEMM conv instance with the most time)
+        # ---- roofline of the dominant kernel: the convolution instantiation with the most time in the step, priced against the
+        # roofline that binds its launches IN AGGREGATE - bf16 MFMA (2.5 PFLOP/s dense) when sum(flops)/peak exceeds
+        # sum(algorithmic bytes)/8 TB/s, HBM otherwise (the plain 1x1 layers at 64-512 input channels move 128-512 B per
+        # pixel for 64-512 MACs per byte pair: HBM-bound on this chip).  Timed live: HIP events on the launch stream around
+        # every launch (ops.TIMING), eager pass.
         agg = {}
-        HBM_PEAK = 8.0e12               # MI355X_MICROARCH.md (spec; ~6.3e12 achievable)
+        HBM_PEAK = 8.0e12               # MI355X_MICROARCH.md (spec; ~5-6.3e12 achievable, tools/hbm_probe.py)
         bound_all = time_all = 0.0
         for name, flops, ev0, ev1, nbytes in ops.KERNEL_TIMES:
             a = agg.setdefault(name, [0.0, 0.0, 0, 0.0, 0.0])
@@ -279,25 +286,38 @@ def main():
             bound_all += b; time_all += t
         roof = None
         if agg:
-            name, (fl, sec, cnt, bnd, nby) = max(agg.items(), key=lambda kv: kv[1][1])
-            ach = fl / sec / 1e12
             steps_timed = min(args.steps, 3)
-            # HBM bytes per launch of that kernel from the committed PMC passes (tools/pmc_traffic.py), if profiled
-            traffic = None
+
+            def entry(name):
+                fl, sec, cnt, bnd, nby = agg[name]
+                mfma_bound = fl / PEAK[args.dtype] >= nby / HBM_PEAK
+                ach, peak, unit = (fl / sec / 1e12, PEAK[args.dtype] / 1e12, "TFLOP/s") if mfma_bound else (nby / sec / 1e9, HBM_PEAK / 1e9, "GB/s")
+                return {"bound": "mfma" if mfma_bound else "hbm", "kernel": name, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+                        "frac": round(ach / peak, 4), "launches_per_step": cnt // steps_timed, "avg_launch_us": round(sec / cnt * 1e6, 2),
+                        "algorithmic_flop_per_launch": int(fl / cnt), "algorithmic_bytes_per_launch": int(nby / cnt),
+                        "tflops": round(fl / sec / 1e12, 1), "share_of_step": round(sec / steps_timed / (dt / args.steps), 3)}
+            order = sorted(agg, key=lambda k: -agg[k][1])
+            roof = entry(order[0])
+            # HBM bytes per launch of that kernel from the committed PMC passes (tools/pmc_traffic.py) - used only while the
+            # kernel sources are the ones that were profiled (sha1 of csrc/conv*.hip + conv_shared.h stored with the counters)
+            traffic, tnote = None, "no PMC summary for this kernel"
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-                traffic = pmc.get(name, {}).get("hbm_bytes_per_launch")
+                import hashlib
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+                cs = os.path.join(ROOT, "mhentropy_amd", "csrc")
+                sha = hashlib.sha1(b"".join(open(os.path.join(cs, f), "rb").read() for f in ("conv.hip", "conv_p8.hip", "conv_shared.h"))).hexdigest()
+                if pmc.get("source_sha1") == sha:
+                    traffic = pmc["kernels"].get(order[0], {}).get("hbm_bytes_per_launch")
+                    tnote = "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r02_pmc_traffic.json, same kernel sources)"
+                else:
+                    tnote = "profiles/r02_pmc_traffic.json was collected on other kernel sources: not reported"
             except Exception:
                 pass
-            roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK[args.dtype] / 1e12,
-                    "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK[args.dtype], 4), "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
-                    "launches_per_step": cnt // steps_timed, "avg_launch_us": round(sec / cnt * 1e6, 2),
-                    # the same launches against whichever roofline binds each of them (several of this kernel's layers are
-                    # HBM-bound at 128 FLOP/B), and the same for all convolution launches of the step
-                    "algorithmic_bytes_per_launch": int(nby / cnt),
-                    "frac_of_binding_roofline": round(bnd / sec, 4), "all_convs_frac_of_binding_roofline": round(bound_all / time_all, 4),
-                    "share_of_step": round(sec / steps_timed / (dt / args.steps), 3)}
+            roof.update({"traffic": traffic, "traffic_note": tnote,
+                         # the same launches each against its own binding roofline, and all convolution launches of the step
+                         "frac_of_binding_roofline": round(agg[order[0]][3] / agg[order[0]][1], 4),
+                         "all_convs_frac_of_binding_roofline": round(bound_all / time_all, 4),
+                         "next_kernels": [entry(k) for k in order[1:4]]})
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(cfg, sd, args.seed)      # rank 0 at N=1 only
         line = {
             "metric": "hypotheses/sec (BxK) fwd+loss, 256x256",

@@ -66,17 +66,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict_
 
 // dbeta = sum g', dgamma = sum g' xhat; coefficients of gy = k2 g' + k1 y + k0 with
 //   gy = gamma invstd (g' - dbeta/M - xhat dgamma/M)       (F.batch_norm backward, training mode)
-__global__ void bn_bwd_finalize_kernel(const float *__restrict__ stats, const float *__restrict__ gamma,
-                                       const float *__restrict__ mean_invstd, float *__restrict__ dgamma,
-                                       float *__restrict__ dbeta, float *__restrict__ coef, int C, float count) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// (one wavefront per channel, lane = statistic shard: see bn_finalize_kernel in conv.hip)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__restrict__ stats, const float *__restrict__ gamma,
+                                                              const float *__restrict__ mean_invstd, float *__restrict__ dgamma,
+                                                              float *__restrict__ dbeta, float *__restrict__ coef, int C, float count) {
+    static_assert(NSH == 64, "one lane per statistic shard");
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-#pragma unroll 8
-    for (int sh = 0; sh < NSH; ++sh) {
-        s1 += (double)stats[((size_t)sh * 2) * C + c];
-        s2 += (double)stats[((size_t)sh * 2 + 1) * C + c];
-    }
+    double s1 = (double)stats[((size_t)lane * 2) * C + c], s2 = (double)stats[((size_t)lane * 2 + 1) * C + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (lane) return;
     const float db = (float)s1, dg = (float)s2;
     dbeta[c] = db;
     dgamma[c] = dg;
@@ -323,7 +323,7 @@ extern "C" int mhe_bn_bwd_reduce_nhwc(const void *g, const void *a, const void *
 extern "C" int mhe_bn_bwd_finalize(const float *stats, const float *gamma, const float *mean_invstd, float *dgamma,
                                    float *dbeta, float *coef, int C, float count, void *stream) {
     MHE_REQUIRE(stats && gamma && mean_invstd && dgamma && dbeta && coef && C > 0 && count > 0.f, "mhe_bn_bwd_finalize: bad arguments");
-    hipLaunchKernelGGL(tb::bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, gamma,
+    hipLaunchKernelGGL(tb::bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, stats, gamma,
                        mean_invstd, dgamma, dbeta, coef, C, count);
     return check_launch("bn_bwd_finalize_kernel");
 }

@@ -375,6 +375,7 @@ extern "C" size_t mhe_conv_wgrad_workspace_floats(const mhe_conv_desc *d) {
     const WgradPlan w = plan_wgrad(d);
     // measured (tools/wgrad_bench.py, SLABS=0/1): slabs win 3-25 % from ~16 output tiles up (<= 64 slices each), and lose below
     // that (many thin slices of a small dW: the reducer walks them serially) - there the atomics stay
+    if ((size_t)d->Cout * d->KH * d->KW * d->Cin < 131072) return 0;       // small dW: the extra reducer launch costs more than the atomics
     return (w.gz > 1 && w.gz <= 64) ? (size_t)w.gz * (w.gy * w.BM) * (size_t)(w.gx * w.BN) : 0;
 }
 
@@ -412,7 +413,7 @@ static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, fl
     p.chunk = (int)w.chunk;
     p.Mp = gyy * w.BM; p.Np = gx * w.BN;
     const size_t need = (size_t)gz * p.Mp * p.Np;
-    p.ws = (ws && gz > 1 && gz <= 64 && need <= ws_floats) ? ws : nullptr;
+    p.ws = (ws && gz > 1 && gz <= 64 && need <= ws_floats && (size_t)d->Cout * p.N >= 131072) ? ws : nullptr;
     const dim3 grid(gx, gyy, gz), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == MHE_F32) {

@@ -4,10 +4,14 @@ HBM bytes per launch per kernel.  Units and gfx950 correction per /opt/skills/gu
 section HBM: the counters are in KiB; FETCH_SIZE reports exactly half of the bytes of wide coalesced
 streaming reads on gfx950, so it is doubled; WRITE_SIZE is exact for 16-byte-per-lane stores.
 
-    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_traffic.json
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 2 ... (and WRITE_SIZE)
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r02_pmc_traffic.json
+The summary records the sha1 of the convolution sources it was collected on; bench.py reports `traffic` only while they match.
 """
 import collections
 import csv
+import hashlib
+import os
 import glob
 import json
 import re
@@ -33,7 +37,9 @@ def main():
         wr = write[k][0] / nw * 1024
         res[k] = {"launches_profiled": nf, "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
                   "hbm_bytes_per_launch": round(rd + wr)}
-    json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py "
+    cs = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mhentropy_amd", "csrc")
+    sha = hashlib.sha1(b"".join(open(os.path.join(cs, f), "rb").read() for f in ("conv.hip", "conv_p8.hip", "conv_shared.h"))).hexdigest()
+    json.dump({"source_sha1": sha, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py "
                          "--steps 2 --warmup 1 --dtype bf16 --no-cpu-baseline --graph 0 --train-steps 0 --no-glow-variant",
                "correction": "FETCH_SIZE x2 (gfx950 wide coalesced reads), counters in KiB", "kernels": res},
               open(dst, "w"), indent=1, sort_keys=True)
