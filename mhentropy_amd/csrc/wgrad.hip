@@ -289,6 +289,178 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const Params p) {
         }
 }
 
+// ---------------------------------------------------------------------------
+// LDS-DMA form of the bf16 kernel.  The register-staged kernel above keeps ONE 32-pixel stage of global loads in flight per
+// wave (PMC: 45 % of its wave time parked at s_waitcnt, MFMA utilisation 0.16): with three workgroups per CU that hides
+// ~1/3 of a ~2,000-cycle load.  Here both operands go HBM/L2 -> LDS by buffer_load_dwordx4 ... lds into a 4-slot ring, three
+// stages in flight behind a counted vmcnt, one raw s_barrier per stage, no VGPR staging and no ds_write pass:
+//   * the stage image is the tensor's own [pixel][channel] rows WITHOUT the row pad (a DMA wave-instruction writes 1 KiB
+//     lane-linearly, i.e. several whole rows); the bank-conflict remedy of the transposing reads moves into a 64-byte-segment
+//     XOR applied to the per-lane SOURCE offset (256-byte rows: segment ^= row & 3; 128-byte rows: segment ^= (row >> 1) & 1),
+//     so the four rows x 64 bytes a 32-lane half reads with ds_read_b64_tr_b16 land in four different bank groups;
+//   * pixels past the slice end, channels / columns past the tensor and padding taps get an out-of-range offset: the DMA
+//     writes zeros (tools/probes/lds_dma_oob.hip);
+//   * the DMA and its wait are inline asm (hipcc would fence every LDS read behind a DMA it sees with vmcnt(0)); the
+//     transposing reads and MFMAs stay compiler-scheduled;
+//   * pixel -> (image, row, column) by multiply-high with host-made reciprocals instead of two integer divisions per load.
+struct DmaParams {
+    Params p;
+    unsigned rcp_wo, rcp_ho;          // ceil(2^32 / Wo), ceil(2^32 / Ho): exact quotients for pixel counts < 2^32 / max(Wo, Ho)
+    unsigned x_bytes, gy_bytes;
+    int plain;                        // 1x1, stride 1, pad 0: the operand row is the pixel's own channel vector
+};
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void wgrad_dma_kernel(const DmaParams dp) {
+    const Params &p = dp.p;
+    constexpr int BKB = 32, NBUF = 4, DEPTH = 3;
+    constexpr int PA = BM * 2, PB = BN * 2;                       // row pitches in bytes (128 or 256)
+    constexpr int STAGE = BKB * (PA + PB);
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int RA = 1024 / PA, RB = 1024 / PB;                 // rows per DMA wave-instruction
+    constexpr int IA = BKB / RA / 4, IB = BKB / RB / 4;           // DMA instructions per wave per stage
+    static_assert(WM * WN == 4 && (PA == 128 || PA == 256) && (PB == 128 || PB == 256) && IA >= 1 && IB >= 1, "tile");
+    __shared__ __attribute__((aligned(1024))) char ring[NBUF * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const long k_begin = (long)blockIdx.z * p.chunk;
+    const long k_end = k_begin + p.chunk < p.P ? k_begin + p.chunk : p.P;
+    const unsigned OOB = 0x80000000u;
+    auto seg_swz = [](int pitch, int row) { return pitch == 256 ? (row & 3) : ((row >> 1) & 1); };
+
+    // ---- DMA role: per operand, instruction j of this wave fills rows R*(I*wave + j) .. +R-1 of the stage
+    unsigned a_col[IA], b_col[IB];          // byte offset of this lane's 16 source bytes within a pixel's channel vector, or OOB
+    int a_row[IA], b_row[IB], b_dh[IB], b_dw[IB];
+#pragma unroll
+    for (int j = 0; j < IA; ++j) {
+        const int row = RA * (IA * wave + j) + lane / (PA / 16), pc = lane % (PA / 16);
+        const int lc = (((pc >> 2) ^ seg_swz(PA, row)) << 2) | (pc & 3);
+        a_row[j] = row;
+        a_col[j] = m0 + lc * 8 < p.Cout ? (unsigned)(m0 + lc * 8) * 2u : OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < IB; ++j) {
+        const int row = RB * (IB * wave + j) + lane / (PB / 16), pc = lane % (PB / 16);
+        const int lc = (((pc >> 2) ^ seg_swz(PB, row)) << 2) | (pc & 3);
+        const int n = n0 + lc * 8;
+        b_row[j] = row;
+        const int tap = n < p.N ? n / p.Cin : 0;
+        b_col[j] = n < p.N ? (unsigned)(n - tap * p.Cin) * 2u : OOB;
+        b_dh[j] = tap / p.KW - p.pad; b_dw[j] = tap % p.KW - p.pad;
+    }
+    const u4v rs_g = {(unsigned)(size_t)p.gy, (unsigned)((size_t)p.gy >> 32) & 0xffffu, dp.gy_bytes, 0x00020000u};
+    const u4v rs_x = {(unsigned)(size_t)p.x, (unsigned)((size_t)p.x >> 32) & 0xffffu, dp.x_bytes, 0x00020000u};
+    const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) char *)ring);
+    const long nst = (k_end - k_begin + BKB - 1) / BKB;
+
+    auto dma = [&](unsigned voff, u4v rs, unsigned dst) {
+        unsigned keep;
+        asm volatile("s_nop 4\n\ts_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[dst]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[rs], 0 offen lds\n\ts_mov_b32 m0, %[keep]"
+                     : [keep] "=&s"(keep) : [v] "v"(voff), [rs] "s"(rs), [dst] "s"(dst) : "memory");
+    };
+    // stage st (may lie past the end: zero fill, keeps the counted wait uniform).  Branch-free: every offset is computed with
+    // wrapping 32-bit arithmetic and replaced by the out-of-range value when the row is not to be loaded.
+    const unsigned kend32 = (unsigned)k_end;
+    auto issue = [&](long st) {
+        const unsigned slot = lds_base + (unsigned)(st % NBUF) * STAGE;
+        const unsigned k0 = (unsigned)(k_begin + st * BKB);
+        const bool st_ok = st < nst;
+#pragma unroll
+        for (int j = 0; j < IA; ++j) {
+            const unsigned pix = k0 + (unsigned)a_row[j];
+            const bool ok = st_ok && pix < kend32 && a_col[j] != OOB;
+            const unsigned v = pix * (unsigned)(p.Cout * 2) + a_col[j];
+            dma(ok ? v : OOB, rs_g, slot + (unsigned)(IA * wave + j) * 1024u);
+        }
+#pragma unroll
+        for (int j = 0; j < IB; ++j) {
+            const unsigned pix = k0 + (unsigned)b_row[j];
+            bool ok = st_ok && pix < kend32 && b_col[j] != OOB;
+            unsigned v;
+            if (dp.plain) v = pix * (unsigned)(p.Cin * 2) + b_col[j];
+            else {
+                const unsigned t = __umulhi(pix, dp.rcp_wo), wo = pix - t * (unsigned)p.Wo;
+                const unsigned bi = __umulhi(t, dp.rcp_ho), ho = t - bi * (unsigned)p.Ho;
+                const unsigned hi = ho * (unsigned)p.stride + (unsigned)b_dh[j], wi = wo * (unsigned)p.stride + (unsigned)b_dw[j];
+                ok = ok && hi < (unsigned)p.H && wi < (unsigned)p.W;
+                v = ((bi * (unsigned)p.H + hi) * (unsigned)p.W + wi) * (unsigned)(p.Cin * 2) + b_col[j];
+            }
+            dma(ok ? v : OOB, rs_x, slot + (unsigned)(BKB * PA) + (unsigned)(IB * wave + j) * 1024u);
+        }
+    };
+
+    v16f acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposed-read lane geometry (as in wgrad_bf16_kernel): 16-lane group g reads pixels 8(g>>1) + q (+4), channels 16(g&1) + 4pq
+    const int g = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
+    const int fr = 8 * (g >> 1) + q;                              // fr & 3 == q, (fr >> 1) & 1 == q >> 1 (the row adds 0/4/16 below)
+    int a_off[TM], b_off[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int seg = (wm * (BM / WM) + 32 * i) / 32;
+        a_off[i] = fr * PA + ((seg ^ seg_swz(PA, fr)) * 64) + (16 * (g & 1) + 4 * pq) * 2;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int seg = (wn * (BN / WN) + 32 * j) / 32;
+        b_off[j] = BKB * PA + fr * PB + ((seg ^ seg_swz(PB, fr)) * 64) + (16 * (g & 1) + 4 * pq) * 2;
+    }
+
+#pragma unroll
+    for (int s0 = 0; s0 < DEPTH; ++s0) issue(s0);
+    for (long st = 0; st < nst; ++st) {
+        if constexpr (IA + IB == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // (IA + IB) * (DEPTH - 1): stage st has landed
+        else if constexpr (IA + IB == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue(st + DEPTH);                                           // slot (st+3)%4 was last read in iteration st-1
+        const char *base = ring + (st % NBUF) * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < BKB; kk += 16) {
+            v8s fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(base + a_off[i] + kk * PA));
+                const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(base + a_off[i] + (kk + 4) * PA));
+                fa[i] = v8s{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(base + b_off[j] + kk * PB));
+                const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(base + b_off[j] + (kk + 4) * PB));
+                fb[j] = v8s{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, fa[i]), __builtin_bit_cast(bf8, fb[j]), acc[i][j], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the past-the-end zero fills land before the workgroup retires
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / WN) + 32 * j + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (p.ws) p.ws[((size_t)blockIdx.z * p.Mp + m) * p.Np + n] = acc[i][j][r];
+                else if (m < p.Cout && n < p.N) atomicAdd(p.dw + (size_t)m * p.ldw + n, acc[i][j][r]);
+            }
+        }
+}
+
 // dW[m][n..n+3] += sum_z ws[z][m][n..n+3]: the reducer of the partial-slab mode (one float4 per thread, slabs read coalesced)
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, int gz, int Mp, int Np,
                                                           int M, int N, int ldw) {
@@ -416,9 +588,27 @@ static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, fl
     p.ws = (ws && gz > 1 && gz <= 64 && need <= ws_floats && (size_t)d->Cout * p.N >= 131072) ? ws : nullptr;
     const dim3 grid(gx, gyy, gz), block(256);
     hipStream_t s = (hipStream_t)stream;
+    // LDS-DMA kernel: 32-bit byte offsets into x / gy, exact reciprocal quotients (pixel count < 2^32 / max(Wo, Ho))
+    const size_t xb = (size_t)d->B * d->H * d->W * d->Cin * 2, gb = (size_t)p.P * d->Cout * 2;
+    static const int dma_env = getenv("MHE_WGRAD_DMA") ? atoi(getenv("MHE_WGRAD_DMA")) : 1;
+    const bool use_dma = dma_env && xb < 0x7fff0000ull && gb < 0x7fff0000ull && p.P < (long)(0xffffffffull / (p.Wo > p.Ho ? p.Wo : p.Ho)) &&
+                         d->KH * d->KW <= 64;
     if (d->dtype == MHE_F32) {
         if (small) hipLaunchKernelGGL((wgrad::wgrad_kernel<float, 64, 128>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((wgrad::wgrad_kernel<float, 128, 128>), grid, block, 0, s, p);
+    } else if (bf16k && use_dma) {
+        wgrad::DmaParams dp;
+        dp.p = p;
+        dp.rcp_wo = (unsigned)((0x100000000ull + p.Wo - 1) / p.Wo); dp.rcp_ho = (unsigned)((0x100000000ull + p.Ho - 1) / p.Ho);
+        dp.x_bytes = (unsigned)xb; dp.gy_bytes = (unsigned)gb;
+        dp.plain = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0;
+        if (narrow) {
+            if (small) hipLaunchKernelGGL((wgrad::wgrad_dma_kernel<64, 64, 2, 2>), grid, block, 0, s, dp);
+            else hipLaunchKernelGGL((wgrad::wgrad_dma_kernel<128, 64, 4, 1>), grid, block, 0, s, dp);
+        } else {
+            if (small) hipLaunchKernelGGL((wgrad::wgrad_dma_kernel<64, 128, 1, 4>), grid, block, 0, s, dp);
+            else hipLaunchKernelGGL((wgrad::wgrad_dma_kernel<128, 128, 2, 2>), grid, block, 0, s, dp);
+        }
     } else if (narrow) {
         if (small) hipLaunchKernelGGL((wgrad::wgrad_bf16_kernel<64, 64, 2, 2>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((wgrad::wgrad_bf16_kernel<128, 64, 4, 1>), grid, block, 0, s, p);
