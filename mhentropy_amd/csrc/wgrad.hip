@@ -530,7 +530,7 @@ static WgradPlan plan_wgrad(const mhe_conv_desc *d) {
     w.gx = (N + w.BN - 1) / w.BN; w.gy = (d->Cout + w.BM - 1) / w.BM;
     // split the pixel range: enough workgroups to fill 256 CUs a few times over; every split adds a full output tile of
     // partial sums - the bf16 kernel (4x faster mainloop) wants longer slices
-    static const long target_wgs = getenv("MHE_WGRAD_WGS") ? atol(getenv("MHE_WGRAD_WGS")) : 1024;
+    static const long target_wgs = getenv("MHE_WGRAD_WGS") ? atol(getenv("MHE_WGRAD_WGS")) : 512;      // 2 workgroups of the LDS-DMA kernel per CU: one resident wave of workgroups (measured 256-2048: 512 best)
     long want = (w.bf16k ? target_wgs : 2048) / ((long)w.gx * w.gy);
     if (want < 1) want = 1;
     long chunk = (P + want - 1) / want;
