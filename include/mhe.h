@@ -303,7 +303,9 @@ int mhe_flow_lrelu_bwd_mixed(const void *g, int g_dtype, const void *h, int h_dt
  * (row r = n*B + b; sum_out row pitch sum_stride floats): the leaky-ReLU reverse fused with the per-image reduction that
  * gives the gradient of the conditioning table. */
 int mhe_flow_lrelu_bwd_sum(const void *g, int g_dtype, const void *h, int h_dtype, float *out_f32, void *out_bf16,
-                           float *sum_out, long sum_stride, int N, int B, int H, float slope, void *stream);
+                           float *sum_out, long sum_stride, float *sum_out_t, int N, int B, int H, float slope, void *stream);
+/* (sum_out_t, optional: the same sums transposed, sum_out_t[c][b] with row pitch B - the operand layout of the split-K product
+ * that turns the conditioning table's gradient into the feature's) */
 /* mhe_flow_mask_pad_f32 / mhe_flow_couple_bwd_f32 with optional bf16 copies of the GEMM operands they produce */
 int mhe_flow_mask_pad_mixed(const float *x, const float *mask, float *xp, void *xp_bf16, long R, int dim, void *stream);
 int mhe_flow_couple_bwd_mixed(const float *x_out, const float *Os, const float *Ot, const float *mask,

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void lrelu_bwd_mixed_kernel(const TG *__restri
 template <typename TG, typename TH>
 __global__ __launch_bounds__(256) void lrelu_bwd_sum_kernel(const TG *__restrict__ g, const TH *__restrict__ h, float *__restrict__ out_f,
                                                             u16 *__restrict__ out_b, float *__restrict__ sum_out, long sum_stride,
-                                                            int N, int B, int H, float slope) {
+                                                            float *__restrict__ sum_t, int N, int B, int H, float slope) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int hc = H / 2;
     if (t >= B * hc) return;
@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256) void lrelu_bwd_sum_kernel(const TG *__restrict
         a0 += g0; a1 += g1;
     }
     *reinterpret_cast<float2 *>(sum_out + (size_t)b * sum_stride + c) = make_float2(a0, a1);
+    if (sum_t) { sum_t[(size_t)c * B + b] = a0; sum_t[(size_t)(c + 1) * B + b] = a1; }      // the same, [column][image]
 }
 
 // One coupling, reverse: from its output x_out and the nets' raw outputs Os, Ot (bias included, 64-wide)
@@ -235,20 +236,20 @@ extern "C" int mhe_flow_couple_bwd_f32(const float *x_out, const float *Os, cons
 }
 
 extern "C" int mhe_flow_lrelu_bwd_sum(const void *g, int g_dtype, const void *h, int h_dtype, float *out_f32, void *out_bf16,
-                                      float *sum_out, long sum_stride, int N, int B, int H, float slope, void *stream) {
+                                      float *sum_out, long sum_stride, float *sum_out_t, int N, int B, int H, float slope, void *stream) {
     MHE_REQUIRE(g && h && sum_out && N > 0 && B > 0 && H > 0 && H % 2 == 0 && sum_stride >= H && sum_stride % 2 == 0,
                 "mhe_flow_lrelu_bwd_sum: bad arguments");
     const dim3 grid((unsigned)(((long)B * (H / 2) + 255) / 256)), block(256);
     hipStream_t s = (hipStream_t)stream;
     u16 *ob = (u16 *)out_bf16;
     if (g_dtype == MHE_F32 && h_dtype == MHE_F32)
-        hipLaunchKernelGGL((flowbwd::lrelu_bwd_sum_kernel<float, float>), grid, block, 0, s, (const float *)g, (const float *)h, out_f32, ob, sum_out, sum_stride, N, B, H, slope);
+        hipLaunchKernelGGL((flowbwd::lrelu_bwd_sum_kernel<float, float>), grid, block, 0, s, (const float *)g, (const float *)h, out_f32, ob, sum_out, sum_stride, sum_out_t, N, B, H, slope);
     else if (g_dtype == MHE_F32)
-        hipLaunchKernelGGL((flowbwd::lrelu_bwd_sum_kernel<float, u16>), grid, block, 0, s, (const float *)g, (const u16 *)h, out_f32, ob, sum_out, sum_stride, N, B, H, slope);
+        hipLaunchKernelGGL((flowbwd::lrelu_bwd_sum_kernel<float, u16>), grid, block, 0, s, (const float *)g, (const u16 *)h, out_f32, ob, sum_out, sum_stride, sum_out_t, N, B, H, slope);
     else if (h_dtype == MHE_F32)
-        hipLaunchKernelGGL((flowbwd::lrelu_bwd_sum_kernel<u16, float>), grid, block, 0, s, (const u16 *)g, (const float *)h, out_f32, ob, sum_out, sum_stride, N, B, H, slope);
+        hipLaunchKernelGGL((flowbwd::lrelu_bwd_sum_kernel<u16, float>), grid, block, 0, s, (const u16 *)g, (const float *)h, out_f32, ob, sum_out, sum_stride, sum_out_t, N, B, H, slope);
     else
-        hipLaunchKernelGGL((flowbwd::lrelu_bwd_sum_kernel<u16, u16>), grid, block, 0, s, (const u16 *)g, (const u16 *)h, out_f32, ob, sum_out, sum_stride, N, B, H, slope);
+        hipLaunchKernelGGL((flowbwd::lrelu_bwd_sum_kernel<u16, u16>), grid, block, 0, s, (const u16 *)g, (const u16 *)h, out_f32, ob, sum_out, sum_stride, sum_out_t, N, B, H, slope);
     return check_launch("lrelu_bwd_sum_kernel");
 }
 

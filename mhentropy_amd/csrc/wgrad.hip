@@ -479,20 +479,30 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
     dst[0] += a[0]; dst[1] += a[1]; dst[2] += a[2]; dst[3] += a[3];
 }
 
-// out[c] += sum_r in[r][c]  (bias gradients); one block per 64-row slab x 256 columns
+// out[c] += sum_r in[r][c]  (bias gradients).  A block owns a slab of rows and ALL of its 256 threads: thread t reads column
+// t % CW of row-lane t / CW (CW = min(C, 256) columns per pass), the row-lanes are folded through LDS and one atomic per
+// column leaves the block - for the 64-wide operands of the flow (C = 64) the one-thread-per-column form idled 3/4 of a block
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ in, float *__restrict__ out, long R, int C,
                                                      int rows_per_block) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float part[256];
+    const int CW = C < 256 ? C : 256, NRL = 256 / CW;           // C is a power of two below 256 or a multiple of 256 (checked by the launcher)
+    const int cl = threadIdx.x % CW, rl = threadIdx.x / CW;
     const long r0 = (long)blockIdx.y * rows_per_block;
     const long r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+    const int c = blockIdx.x * CW + cl;
     float acc = 0.f;
-    for (long r = r0; r < r1; ++r) {
-        if constexpr (sizeof(T) == 4) acc += in[r * C + c];
-        else acc += bf16_to_f32(in[r * C + c]);
+    if (rl < NRL && c < C)
+        for (long r = r0 + rl; r < r1; r += NRL) {
+            if constexpr (sizeof(T) == 4) acc += in[r * C + c];
+            else acc += bf16_to_f32(in[r * C + c]);
+        }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        for (int k = 1; k < NRL; ++k) acc += part[k * CW + cl];
+        atomicAdd(out + c, acc);
     }
-    atomicAdd(out + c, acc);
 }
 
 // dst[i] = (idx[i] < 0 ? 0 : src[idx[i]]) + (idx2 && idx2[i] >= 0 ? src[idx2[i]] : 0)  (f32 source; f32 or bf16 destination): every weight re-layout of the
@@ -630,8 +640,10 @@ static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, fl
 
 extern "C" int mhe_colsum_f32(const void *rows, float *out, long R, int C, int dtype, void *stream) {
     MHE_REQUIRE(rows && out && R > 0 && C > 0 && (dtype == MHE_F32 || dtype == MHE_BF16), "mhe_colsum_f32: bad arguments");
-    const int rpb = 64;
-    const dim3 grid((C + 255) / 256, (unsigned)((R + rpb - 1) / rpb));
+    const int cw = C < 256 ? C : 256;
+    MHE_REQUIRE(256 % cw == 0, "mhe_colsum_f32: C=%d must divide 256 or be at least 256", C);
+    const int rpb = 128;
+    const dim3 grid((C + cw - 1) / cw, (unsigned)((R + rpb - 1) / rpb));
     if (dtype == MHE_F32)
         hipLaunchKernelGGL(wgrad::colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)rows, out, R, C, rpb);
     else

@@ -441,7 +441,7 @@ def flow_mask_pad_mixed(x, mask_row, out_f32=None, out_bf16=None):
     check(_lib.lib().mhe_flow_mask_pad_mixed(_ptr(x), _ptr(mask_row), _ptr(out_f32), _ptr(out_bf16), R, dim, _stream()), "mhe_flow_mask_pad_mixed")
 
 
-def flow_lrelu_bwd_sum(g, h, N, B, sum_out, sum_stride, out_f32=None, out_bf16=None, slope=0.01):
+def flow_lrelu_bwd_sum(g, h, N, B, sum_out, sum_stride, out_f32=None, out_bf16=None, slope=0.01, sum_out_t=None):
     """out = g * (h > 0 ? 1 : slope) (f32 and / or bf16) and sum_out[b] = sum over the image's N hypothesis rows; sum_out may be a
     column slice of a wider [B, sum_stride] matrix"""
     R, H = g.shape
@@ -451,7 +451,8 @@ def flow_lrelu_bwd_sum(g, h, N, B, sum_out, sum_stride, out_f32=None, out_bf16=N
     if out_bf16 is not None:
         _chk(out_bf16, torch.bfloat16, "lrelu_bwd_sum.out_bf16", (R, H))
     check(_lib.lib().mhe_flow_lrelu_bwd_sum(_ptr(g), dtype_code(g.dtype), _ptr(h), dtype_code(h.dtype), _ptr(out_f32), _ptr(out_bf16),
-                                            C.c_void_p(sum_out.data_ptr()), int(sum_stride), N, B, H, float(slope), _stream()), "mhe_flow_lrelu_bwd_sum")
+                                            C.c_void_p(sum_out.data_ptr()), int(sum_stride), C.c_void_p(0 if sum_out_t is None else sum_out_t.data_ptr()),
+                                            N, B, H, float(slope), _stream()), "mhe_flow_lrelu_bwd_sum")
 
 
 def flow_cond_lrelu(P, cond_slice, cond_stride, B):

@@ -540,6 +540,8 @@ class TrainStep:
             H2b = [self._buf(f"H2b{n}", (R, h), bf) for n in range(2)]
             GOb = [self._buf(f"GOb{n}", (R, 64), bf) for n in range(2)]
             G1b = self._buf("G1b", (R, h), bf)
+            GcT = self._buf("GcondT", (cstride, B))              # the same sums as Gc, [column][image]: split-K operand of g_feat
+            self._GcT = GcT
             for i in range(ncoup - 1, -1, -1):
                 m = fl.mask[i]
                 ops.flow_mask_pad_mixed(x_cur, m, out_bf16=XPb)
@@ -557,10 +559,10 @@ class TrainStep:
                     d, slot = self.fnets[2 * i + n], (2 * i + n) * 2
                     ops.conv_wgrad(v4(H2b[n]), v4(GOb[n]), 1, 1, 1, 0, d["dw2"]); ops.colsum(GO[n], d["db2"])
                     ops.conv2d_nhwc(v4(GOb[n]), d["w2Tb"], 1, 1, 1, 0, out=v4(P2b))
-                    ops.flow_lrelu_bwd_sum(P2b, H2b[n], N, B, Gc[:, (slot + 1) * h:], Gc.shape[1], out_bf16=G2b)
+                    ops.flow_lrelu_bwd_sum(P2b, H2b[n], N, B, Gc[:, (slot + 1) * h:], Gc.shape[1], out_bf16=G2b, sum_out_t=GcT[(slot + 1) * h:])
                     ops.conv_wgrad(v4(H1b[n]), v4(G2b), 1, 1, 1, 0, d["dw1"])
                     ops.conv2d_nhwc(v4(G2b), d["w1Tb"], 1, 1, 1, 0, out=v4(GH1b))
-                    ops.flow_lrelu_bwd_sum(GH1b, H1b[n], N, B, Gc[:, slot * h:], Gc.shape[1], out_f32=G1, out_bf16=G1b)
+                    ops.flow_lrelu_bwd_sum(GH1b, H1b[n], N, B, Gc[:, slot * h:], Gc.shape[1], out_f32=G1, out_bf16=G1b, sum_out_t=GcT[slot * h:])
                     ops.conv_wgrad(v4(XPb), v4(G1b), 1, 1, 1, 0, d["dw0"])
                     ops.linear(G1, d["w0T"], out=GX[n])
                 ops.flow_couple_accum(gpart, GX[0], GX[1], m, g_in)
@@ -691,7 +693,15 @@ class TrainStep:
         ops.linear_wgrad(feat, ghd, self.d0["dw"]); ops.colsum(ghd, self.d0["db"])
         if self.glow is None:       # conditioning projections of all nets in one pass
             ops.linear_wgrad(feat, Gc, self.dwc); ops.colsum(Gc, self.dbc)
-            g_feat = ops.linear(Gc, self.f_wcT)
+            if self.flow_bf16 and B % 4 == 0:
+                # g_feat = Gc Wc is a (B x 24,576) x (24,576 x 512) product: 8 output tiles walking K serially as a plain GEMM
+                # (~0.75 ms); as a split-K reduction over the 24,576 columns ("pixels" of the weight-gradient kernel, operands
+                # GcT [k][b] and Wc [k][f] as they lie) it fills the chip
+                K_, F_ = self.f_wc.shape
+                g_feat = self._buf("g_feat_flow", (B, F_)); g_feat.zero_()
+                ops.conv_wgrad(self.f_wc.view(K_, 1, 1, F_), self._GcT.view(K_, 1, 1, B), 1, 1, 1, 0, g_feat)
+            else:
+                g_feat = ops.linear(Gc, self.f_wcT)
         ops.add(g_feat, ops.linear(ghd, self.d0["wT"]))
         if hs is not None:          # partial over the local hypotheses, all images -> this rank's images, all hypotheses
             g_feat = hs.scatter_grad(g_feat)

@@ -14,7 +14,7 @@ from mhentropy_amd import ops, resnet
 SHAPES = {  # name: (H, Cin, Cout, k, stride)
     "l1c3": (64, 64, 256, 1, 1), "l2c3": (32, 128, 512, 1, 1), "l2ds": (64, 256, 512, 1, 2), "l3c2": (16, 256, 256, 3, 1),
     "l3c3": (16, 256, 1024, 1, 1), "l3ds": (32, 512, 1024, 1, 2), "l4c3": (8, 512, 2048, 1, 1), "l4ds": (16, 1024, 2048, 1, 2),
-    "l4c2": (8, 512, 512, 3, 1), "l3c1": (16, 1024, 256, 1, 1), "l4c1": (8, 2048, 512, 1, 1), "l2c2": (32, 128, 128, 3, 1),
+    "l4c2": (8, 512, 512, 3, 1), "flowhh": (8, 512, 512, 1, 1), "l3c1": (16, 1024, 256, 1, 1), "l4c1": (8, 2048, 512, 1, 1), "l2c2": (32, 128, 128, 3, 1),
 }
 
 
