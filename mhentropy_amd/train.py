@@ -426,23 +426,48 @@ class TrainStep:
         self._bn_tape(u, self.x_nhwc, y0, st)
         self.r0 = ops.bn_act(y0, u.scale, u.shift, relu=True)
         a, self.pool_idx = ops.maxpool3x3s2_idx(self.r0)
-        for b in self.blocks:
-            b["a"] = a
+        pending = None          # (raw conv3 output, its unit, identity tensor, downsample unit | None): a block tail not yet evaluated
+        fuse = self.trunk.fuse_tail
+        for bi, b in enumerate(self.blocks):
             us = b["u"]
-            h = a
-            b["acts"] = []
-            for u in us[:-1]:
+            if pending is not None:
+                # relu(bn3(y3) + identity) of the previous block is evaluated inside this conv1's operand load, which also
+                # writes it out once (this block's input / identity and the reverse pass's ReLU mask): one read of the widest
+                # tensor of the block saved, as in the inference path (resnet.py)
+                yl_p, ul_p, idt_p, ud_p = pending
+                a = torch.empty_like(yl_p)
+                u0 = us[0]
+                st = pool.take(u0.cout)
+                y = ops.conv1x1_residual_in(yl_p, idt_p, u0.w_fwd, ul_p.scale, ul_p.shift, None if ud_p is None else ud_p.scale,
+                                            None if ud_p is None else ud_p.shift, a_out=a, stats=st)
+                self._bn_tape(u0, a, y, st)
+                self.blocks[bi - 1]["out"] = a
+                pending = None
+                b["a"] = a
+                h = ops.bn_act(y, u0.scale, u0.shift, relu=True)
+                b["acts"] = [h]
+                rest = us[1:-1]
+            else:
+                b["a"] = a
+                h = a
+                b["acts"] = []
+                rest = us[:-1]
+            for u in rest:
                 y = self._unit_fwd(u, h, pool)
                 h = ops.bn_act(y, u.scale, u.shift, relu=True)
                 b["acts"].append(h)
             ul = us[-1]
             yl = self._unit_fwd(ul, h, pool)
-            if b["ud"] is not None:
-                ud = b["ud"]
-                yd = self._unit_fwd(ud, a, pool)
+            ud = b["ud"]
+            yd = self._unit_fwd(ud, b["a"], pool) if ud is not None else None
+            nxt = self.blocks[bi + 1] if bi + 1 < len(self.blocks) else None
+            if fuse and nxt is not None and nxt["kind"] == "bottleneck" and b["kind"] == "bottleneck":
+                pending = (yl, ul, yd if ud is not None else b["a"], ud)
+                continue
+            if ud is not None:
                 a = ops.bn_act(yl, ul.scale, ul.shift, yd, ud.scale, ud.shift, relu=True)
             else:
-                a = ops.bn_act(yl, ul.scale, ul.shift, a, relu=True)
+                a = ops.bn_act(yl, ul.scale, ul.shift, b["a"], relu=True)
             b["out"] = a
         torch._foreach_add_(self._bn_touched, 1)
         self.a_last = a
