@@ -27,7 +27,7 @@ namespace mhe { namespace conv {
 // Shipped shapes: 128x64 and 128x128 on 2x2 waves (2 workgroups per CU), 256x256 on 2x4 waves (one per CU,
 // half the L2->LDS bytes per MAC of 128x128 - the 128-tiles measure L2-fill-bound at ~11 TB/s).
 template <typename T, int BM, int BN, int WM, int WN, bool FAST, int MODE, bool DG = false>
-__global__ __launch_bounds__(64 * WM * WN) void conv_kernel(const Params p) {
+__global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_kernel(const Params p) {
     constexpr int NTH = 64 * WM * WN;
     constexpr int CE = El<T>::CE, BKE = 8 * CE;
     constexpr int RSTEP = NTH / 8;                  // rows covered by one pass of the thread block

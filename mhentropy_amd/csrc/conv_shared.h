@@ -229,7 +229,10 @@ __device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, 
                 const T *y0g = reinterpret_cast<const T *>(p.bn_y[0]), *y1g = reinterpret_cast<const T *>(p.bn_y[1]);
                 auto run = [&](auto RES, auto NB) {
                     constexpr bool HAS_RES = decltype(RES)::value;
-                    constexpr int NBN = decltype(NB)::value, G = 4, NJ = BM * CPR / NTH;
+                    constexpr int NBN = decltype(NB)::value, NJ = BM * CPR / NTH;
+                    // rows in flight per thread: 4 on the one-workgroup-per-CU 256x256 tiles; 2 on the 256-thread tiles, which must
+                    // stay within 256 registers to keep two workgroups per CU (4 took 128x128 to one wave per SIMD: 166 -> 210 us)
+                    constexpr int G = NTH >= 512 ? 4 : 2;
                     static_assert(NJ % G == 0, "rows per thread");
 #pragma unroll
                     for (int j0 = 0; j0 < NJ; j0 += G) {
