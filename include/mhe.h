@@ -186,6 +186,9 @@ int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *
                     const float *in_scale, const float *in_shift,
                     const float *out_scale, const float *out_shift, const void *residual,
                     float *stats, void *stream);
+/* bf16 operands, f32 accumulation, F32 RESULT y_f32 [B,Ho,Wo,Cout] (+ out_shift per channel, optional): products whose result
+ * feeds exp / tanh or a long f32 gradient chain (the 64-wide layers of the flow's reverse pass) at the bf16 MFMA rate. */
+int mhe_conv2d_f32out_nhwc(const mhe_conv_desc *d, const void *x, const void *w, float *y_f32, const float *out_shift, void *stream);
 /* y = (conv(x, w) + residual) * [mask > 0]: the data-gradient form (residual may be NULL; mask is shaped like y) - the
  * ReLU gate of the tensor the gradient is taken with respect to, applied where the gradient is produced.  Optionally the
  * epilogue also accumulates the BatchNorm-reverse statistics of y for up to two BN units whose raw outputs bn_y* are shaped

@@ -75,6 +75,7 @@ SIGNATURES = {
     "mhe_elbo_reduce_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
     "mhe_conv2d_nhwc": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "mhe_conv2d_masked_nhwc": (_i, [_p] * 13),
+    "mhe_conv2d_f32out_nhwc": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p]),
     "mhe_conv_stat_shards": (_i, []),
     "mhe_conv_tile": (_i, [C.POINTER(ConvDesc)]),
     "mhe_conv1x1_residual_in_nhwc": (_i, [C.POINTER(ConvDesc)] + [_p] * 11),

@@ -645,7 +645,7 @@ static inline int elem_chunk(int dtype) { return dtype == MHE_F32 ? 4 : 8; }
 static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
                       const float *in_shift, const float *out_scale, const float *out_shift, const void *residual,
                       float *stats, const void *x2, const float *x2_scale, const float *x2_shift, void *a_out, void *stream,
-                      const void *mask = nullptr, const struct BnRev *bn = nullptr);
+                      const void *mask = nullptr, const struct BnRev *bn = nullptr, float *y32 = nullptr);
 struct BnRev { const void *y[2]; const float *mi[2]; float *stats[2]; };
 
 extern "C" int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
@@ -653,6 +653,12 @@ extern "C" int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void
                                const void *residual, float *stats, void *stream) {
     return conv_entry(d, x, w, y, in_scale, in_shift, out_scale, out_shift, residual, stats, nullptr, nullptr, nullptr,
                       nullptr, stream);
+}
+
+extern "C" int mhe_conv2d_f32out_nhwc(const mhe_conv_desc *d, const void *x, const void *w, float *y_f32, const float *out_shift, void *stream) {
+    MHE_REQUIRE(y_f32, "mhe_conv2d_f32out_nhwc: null output");
+    return conv_entry(d, x, w, nullptr, nullptr, nullptr, nullptr, out_shift, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream, nullptr,
+                      nullptr, y_f32);
 }
 
 extern "C" int mhe_conv1x1_residual_in_nhwc(const mhe_conv_desc *d, const void *x, const void *x2, const void *w, void *y,
@@ -677,8 +683,8 @@ extern "C" int mhe_conv2d_masked_nhwc(const mhe_conv_desc *d, const void *x, con
 static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
                       const float *in_shift, const float *out_scale, const float *out_shift, const void *residual,
                       float *stats, const void *x2, const float *x2_scale, const float *x2_shift, void *a_out, void *stream,
-                      const void *mask, const BnRev *bn) {
-    MHE_REQUIRE(d && x && w && y, "mhe_conv2d_nhwc: null pointer");
+                      const void *mask, const BnRev *bn, float *y32) {
+    MHE_REQUIRE(d && x && w && (y || y32), "mhe_conv2d_nhwc: null pointer");
     MHE_REQUIRE(d->dtype == MHE_F32 || d->dtype == MHE_BF16, "mhe_conv2d_nhwc: dtype=%d", d->dtype);
     const int ce = elem_chunk(d->dtype), bke = 8 * ce;
     MHE_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0,
@@ -704,6 +710,13 @@ static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void
     p.Kpad = (ktot + bke - 1) / bke * bke;       // weight rows are zero-padded to this length by the packer
     p.relu_in = d->relu_in; p.relu_out = d->relu_out;
     p.force = d->tile - 1;
+    p.y32 = nullptr;
+    if (y32) {        // f32 result of a bf16 product: register-staged kernels only (their epilogue stores straight from the accumulators)
+        MHE_REQUIRE(d->dtype == MHE_BF16 && !in_scale && !out_scale && !residual && !stats && !x2 && !mask && !d->relu_out && d->Cout % 4 == 0,
+                    "mhe_conv2d_f32out_nhwc: bf16 operands, optional out_shift only");
+        p.y32 = y32;
+        if (p.force < 0 || p.force > 4) p.force = p.Cout <= 64 ? 0 : 1;
+    }
     if (d->dtype == MHE_F32) return conv::launch_conv<float>(p, (hipStream_t)stream);
     return conv::launch_conv<u16>(p, (hipStream_t)stream);
 }

@@ -20,6 +20,7 @@ struct Params {
     // i.e. the tail of the previous residual block evaluated on load; a_out (optional) receives it once
     const void *x2; const float *x2_scale, *x2_shift; void *a_out;
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, M, Kpad, relu_in, relu_out;
+    float *y32;            // optional f32 result of a bf16 convolution (plain + out_shift only), instead of y
     int force;             // mhe_conv_desc.tile - 1: kernel variant forced by the caller (tests / tuning), -1 = launcher's choice
 };
 
@@ -174,6 +175,25 @@ __device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, 
             if (n < p.Cout) atomicAdd(p.stats + ((size_t)shard * 2 + stat) * p.Cout + n, sum);
         }
         __syncthreads();
+    }
+    if constexpr (sizeof(T) == 2 && !DG) {
+        // f32 result from bf16 operands (mhe_conv2d_f32out_nhwc): the accumulator's own layout gives every lane 4 consecutive
+        // channels of one pixel = one 16-byte store; used by the narrow (<= 64 output channels) products of the flow's reverse
+        // pass whose results feed exp / tanh or the flow variable's gradient chain
+        if (p.y32) {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) {
+                    const long m = pix(wr * (BM / WM) + mt * 16 + l15);
+                    const int n = n0 + wc * (BN / WN) + nt * 16 + 4 * q;
+                    if (m < 0 || n >= p.Cout) continue;
+                    v4f v = acc[nt][mt];
+                    if (p.out_shift) { const float4 b = *reinterpret_cast<const float4 *>(p.out_shift + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                    *reinterpret_cast<float4 *>(p.y32 + (size_t)m * p.Cout + n) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            return;
+        }
     }
     {
         unsigned char *ot = reinterpret_cast<unsigned char *>(lds);

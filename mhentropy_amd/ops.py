@@ -274,6 +274,20 @@ def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in
     return y
 
 
+def linear_bf16_f32out(x, w, bias=None, out=None):
+    """out[R,N] (f32) = x[R,K] (bf16) w[N,K]^T (bf16) + bias, f32 accumulation (mhe_conv2d_f32out_nhwc); K % 64 == 0, N % 4 == 0"""
+    R, K = x.shape
+    N = w.shape[0]
+    _chk(x, torch.bfloat16, "linear_bf16.x"); _chk(w, torch.bfloat16, "linear_bf16.w", (N, K))
+    if bias is not None:
+        _chk(bias, torch.float32, "linear_bf16.bias", (N,))
+    y = out if out is not None else torch.empty(R, N, device=x.device, dtype=torch.float32)
+    _chk(y, torch.float32, "linear_bf16.out", (R, N))
+    d = ConvDesc(R, 1, 1, K, N, 1, 1, 1, 0, BF16, 0, 0, 0)
+    check(_lib.lib().mhe_conv2d_f32out_nhwc(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _ptr(bias), _stream()), "mhe_conv2d_f32out_nhwc")
+    return y
+
+
 def conv1x1_residual_in(x, x2, w, in_scale, in_shift, x2_scale=None, x2_shift=None, a_out=None, stats=None, tile=0):
     """y = conv1x1(relu(x*in_scale+in_shift + (x2*x2_scale+x2_shift | x2))); optionally writes that operand to a_out."""
     B, H, W, Cin = x.shape

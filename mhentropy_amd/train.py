@@ -345,6 +345,8 @@ class TrainStep:
                     d["w1Tb"] = self._derived(self._pidx(net.l[1].weight).t().contiguous(), torch.bfloat16)
                     d["w0b"] = self._derived(w0i, torch.bfloat16)                           # [h, 64]: XP W0^T
                     d["w2Tb"] = self._derived(w2i.t().contiguous(), torch.bfloat16)         # [h, 64]: GO W2
+                    d["w2b"] = self._derived(w2i, torch.bfloat16)                           # [64, h]: H1 W2^T (f32 result)
+                    d["w0Tb"] = self._derived(w0i.t().contiguous(), torch.bfloat16)         # [64, h]: G1 W0 (f32 result)
                 d["w2"], d["w2T"] = self._derived(w2i, torch.float32), self._derived(w2i.t().contiguous(), torch.float32)
                 d["b2"] = self._derived(b2i, torch.float32)
                 d["r0"], d["r1"], d["r2"], d["rb2"] = (self._raw_slot(s) for s in ((h, 64), (h, h), (64, h), (64,)))
@@ -575,8 +577,8 @@ class TrainStep:
                     ops.conv2d_nhwc(v4(XPb), d["w0b"], 1, 1, 1, 0, out=v4(P0b))
                     ops.flow_cond_lrelu_mixed(P0b, cflat[:, slot * h:], cstride, B, out_bf16=H1b[n])
                     ops.conv2d_nhwc(v4(H1b[n]), d["w1b"], 1, 1, 1, 0, out=v4(P2b))
-                    ops.flow_cond_lrelu_mixed(P2b, cflat[:, (slot + 1) * h:], cstride, B, out_f32=Hb[n][1], out_bf16=H2b[n])
-                    ops.linear(Hb[n][1], d["w2"], d["b2"], out=O[n])
+                    ops.flow_cond_lrelu_mixed(P2b, cflat[:, (slot + 1) * h:], cstride, B, out_bf16=H2b[n])
+                    ops.linear_bf16_f32out(H2b[n], d["w2b"], d["b2"], out=O[n])            # s, t pre-activations: f32 result, as the forward kernel
                 x_in, g_in = (xa, ga) if x_cur is not xa else (xb, gb)
                 ops.flow_couple_bwd(x_cur, O[0], O[1], m, g_cur, g_logp, -1.0 / N_all if g_logp is not None else 0.0, B, x_in, GO[0], GO[1], gpart,
                                     GOb[0], GOb[1])
@@ -587,9 +589,9 @@ class TrainStep:
                     ops.flow_lrelu_bwd_sum(P2b, H2b[n], N, B, Gc[:, (slot + 1) * h:], Gc.shape[1], out_bf16=G2b, sum_out_t=GcT[(slot + 1) * h:])
                     ops.conv_wgrad(v4(H1b[n]), v4(G2b), 1, 1, 1, 0, d["dw1"])
                     ops.conv2d_nhwc(v4(G2b), d["w1Tb"], 1, 1, 1, 0, out=v4(GH1b))
-                    ops.flow_lrelu_bwd_sum(GH1b, H1b[n], N, B, Gc[:, slot * h:], Gc.shape[1], out_f32=G1, out_bf16=G1b, sum_out_t=GcT[slot * h:])
+                    ops.flow_lrelu_bwd_sum(GH1b, H1b[n], N, B, Gc[:, slot * h:], Gc.shape[1], out_bf16=G1b, sum_out_t=GcT[slot * h:])
                     ops.conv_wgrad(v4(XPb), v4(G1b), 1, 1, 1, 0, d["dw0"])
-                    ops.linear(G1, d["w0T"], out=GX[n])
+                    ops.linear_bf16_f32out(G1b, d["w0Tb"], out=GX[n])
                 ops.flow_couple_accum(gpart, GX[0], GX[1], m, g_in)
                 x_cur, g_cur = x_in, g_in
             self.z0_recovered = x_cur
