@@ -34,7 +34,17 @@ def main(argv=None):
     ap.add_argument("--milestones", type=int, nargs="*", default=[150, 250])
     ap.add_argument("--save", default="", help="write a checkpoint in the reference's container format here (rank 0)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cfg", default="", help="a YAML file in the reference's schema (hand/configs/ho3d.yaml): network / training sections "
+                                              "override the flags above (backbone, h_dims, num_steps, batch_size, lr, milestones, test_samples)")
+    ap.add_argument("--load", default="", help="checkpoint in the reference's container format to start from (training.pth)")
+    ap.add_argument("--scalars", default="", help="write the reference's TensorBoard scalars here as JSON lines (rank 0)")
     args = ap.parse_args(argv)
+    cfg = None
+    if args.cfg:
+        cfg = harness.load_config(args.cfg)
+        args.backbone, args.hidden, args.flow_steps = cfg.network.backbone, cfg.network.h_dims[0], cfg.network.num_steps
+        args.batch, args.lr, args.milestones = cfg.training.batch_size, cfg.training.lr, list(cfg.training.milestones)
+        args.test_samples = cfg.training.get("test_samples", args.test_samples)
 
     rank, local_rank, world, dist = mdist.init()
     if not torch.cuda.is_available():
@@ -42,8 +52,18 @@ def main(argv=None):
     torch.cuda.set_device(local_rank if world > 1 else 0)
     torch.manual_seed(args.seed)                      # same initial weights on every rank
     cd = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    model = harness.build_mhent(backbone=args.backbone, h_dims=(args.hidden, args.hidden), num_steps=args.flow_steps,
-                                tables=synth.mano_tables(0), compute_dtype=cd).cuda().train()
+    if cfg is not None:
+        from .network import MHEnt
+        special, common = harness.mhent_cfgs_from_config(cfg, tables=synth.mano_tables(0), compute_dtype=cd)
+        model = MHEnt(special, **common)
+        model.q_z_giv_i.compute_dtype = cd
+        model = model.cuda().train()
+    else:
+        model = harness.build_mhent(backbone=args.backbone, h_dims=(args.hidden, args.hidden), num_steps=args.flow_steps,
+                                    tables=synth.mano_tables(0), compute_dtype=cd).cuda().train()
+    if args.load:
+        harness.load_model(args.load, model, map_location="cuda")
+    scalars = harness.ScalarLog(args.scalars) if (args.scalars and rank == 0) else None
     trainer = TrainStep(model, lr=args.lr, max_norm=1.0, dist=dist)
     criterion = MHEntLoss()
     meters = {"loss": harness.AverageMeter(), "epe3d": harness.AverageMeter(), "epe2d": harness.AverageMeter()}
@@ -62,6 +82,8 @@ def main(argv=None):
             with torch.no_grad():
                 total, losses, metrics = criterion(dict(out), y)
             meters["loss"].update(float(total))
+            if scalars is not None:
+                scalars.iteration(step, losses, metrics, out)
             if args.test_samples:
                 meters["epe3d"].update(float(metrics["eucLoss_3d_rgb_sample"].mean()))
                 meters["epe2d"].update(float(metrics["eucLoss_2d_rgb_sample"].mean()))
@@ -70,8 +92,12 @@ def main(argv=None):
         rec = mdist.reduce_mean_scalars({k: float(m.avg) for k, m in meters.items()}, dist, device=torch.device("cuda"))
         rec.update(epoch=epoch, lr=trainer.lr, img_per_s=round(world * args.batch * args.iters / (time.time() - t0), 1))
         log.append(rec)
+        if scalars is not None:
+            scalars.epoch(step, rec["loss"], rec["epe3d"])
         if rank == 0:
             print(json.dumps(rec), flush=True)
+    if scalars is not None:
+        scalars.close()
     if args.save and rank == 0:
         harness.save_model(args.save, model)
     if dist is not None:

@@ -144,3 +144,65 @@ def test_trainer_shell_helpers(tmp_path):
     lin2 = torch.nn.Linear(3, 2)
     harness.load_model(tmp_path / "ck.pth", lin2)
     assert torch.equal(lin2.weight, lin.weight)
+
+
+def test_config_ingestion_matches_the_reference_tree(tmp_path):
+    """row f3: a YAML file in the reference's schema -> (special_cfg, common_cfg) as hand/CrossModalHand.py:53-85 builds them;
+    with the reference's own configs/ho3d.yaml (read as data where the tree exists) this is the shipped model"""
+    import os
+    import pytest
+    from mhentropy_amd import harness
+    cfg = harness.load_config(os.path.join(ROOT, "configs", "c2_bench.yaml"))
+    special, common = harness.mhent_cfgs_from_config(cfg)
+    want_s, want_c = harness.mhent_cfgs(backbone="resnet50", h_dims=(512, 512), num_steps=6)
+    assert special == want_s and common == want_c
+    assert cfg.training.batch_size == 256 and cfg.training.epochs == 80            # file value, default value
+    with pytest.raises(KeyError):
+        bad = tmp_path / "bad.yaml"
+        bad.write_text("dataset:\n  no_such_key: 1\n")
+        harness.load_config(bad)
+    ref = "/root/reference/hand/configs/ho3d.yaml"
+    if os.path.exists(ref):
+        rc = harness.load_config(ref)
+        rs, rcom = harness.mhent_cfgs_from_config(rc)
+        assert rs == want_s and {k: v for k, v in rcom.items()} == want_c
+        assert (rc.training.lr, list(rc.training.milestones), rc.training.batch_size, rc.training.test_samples) == (2e-4, [150, 250], 64, 200)
+        assert rc.training.criterion == "MHEntLoss" and rc.network.regressor == "realnvp"
+
+
+def test_checkpoint_container_round_trip_of_the_full_model(tmp_path):
+    """row f3: harness.save_model / load_model on the whole MHEnt state_dict in the reference's container
+    (hand/CrossModalHand.py:573-602: {'decoderPose', 'encoderRGB'}), every key family of SURVEY.md section 8b present"""
+    import torch
+    from mhentropy_amd import harness, synth
+    m = harness.build_mhent(backbone="resnet18", h_dims=(64, 64), num_steps=2, tables=synth.mano_tables(0))
+    with torch.no_grad():
+        for p_ in m.parameters():
+            p_.add_(torch.randn_like(p_) * 0.01)
+    harness.save_model(tmp_path / "ent.pth", m)
+    ck = torch.load(tmp_path / "ent.pth")
+    assert set(ck) == {"decoderPose", "encoderRGB"} and ck["decoderPose"] == {}
+    keys = set(ck["encoderRGB"])
+    for fam in ("feat_extractor.res.conv1.weight", "feat_extractor.res.layer4.1.bn2.running_var", "feat_extractor.l1.0.weight",
+                "feat_extractor.l2.0.bias", "q_z_giv_i.mask", "q_z_giv_i.s.3.l.2.weight", "q_z_giv_i.t.0.c.1.bias", "det_head.0.weight",
+                "det_head.2.bias", "mano_dec.mano_layer.th_posedirs", "mano_dec.mano_layer.th_faces"):
+        assert fam in keys, fam
+    m2 = harness.build_mhent(backbone="resnet18", h_dims=(64, 64), num_steps=2, tables=synth.mano_tables(0))
+    harness.load_model(tmp_path / "ent.pth", m2)
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+def test_scalar_log_uses_the_reference_tags(tmp_path):
+    import json
+    import torch
+    from mhentropy_amd import harness
+    log = harness.ScalarLog(tmp_path / "scalars.jsonl")
+    log.iteration(3, {"neg_log_p": torch.tensor([1.0, 3.0])}, {"eucLoss_3d_rgb_sample": torch.tensor([0.5])},
+                  {"th_norm": torch.tensor([2.0]), "bt_norm": torch.tensor([0.1])})
+    log.epoch(4, 2.0, 0.012)
+    log.close()
+    recs = [json.loads(l) for l in open(tmp_path / "scalars.jsonl")]
+    tags = {r["tag"]: r for r in recs}
+    assert tags["loss_it/neg_log_p"]["value"] == 2.0 and tags["param/theta_norm"]["value"] == 2.0
+    assert tags["loss_avg/loss_total"]["step"] == 4 and abs(tags["metric_train/eval_3d_rgb"]["value"] - 12.0) < 1e-9

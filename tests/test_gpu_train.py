@@ -452,6 +452,17 @@ def test_run_entry_point(gpu_lib, tmp_path):
     fresh = harness.build_mhent(backbone="resnet18", h_dims=(64, 64), num_steps=2, tables=synth.mano_tables(0))
     harness.load_model(ck, fresh)
     assert torch.equal(fresh.det_head[0].weight, sd["encoderRGB"]["det_head.0.weight"])
+    # ... and driven by a YAML file in the reference's schema, resumed from that checkpoint, with the TensorBoard scalars' tags
+    cfg = tmp_path / "tiny.yaml"
+    cfg.write_text("dataset:\n  dataset_name: ho3d\nnetwork:\n  enc_type: MHEnt\n  input: image\n  num_latent: 512\n  backbone: resnet18\n"
+                   "  h_dims: [64, 64]\n  num_steps: 2\n  regressor: realnvp\n  rot_prior: null\n  w_reg_th: 50\n  w_prior_2d: 0\n  w_reg_ds: 0\n"
+                   "  b_2d: 0.03\n  entropy: true\n  mode: false\ntraining:\n  batch_size: 8\n  lr: 0.0002\n  milestones: [150, 250]\n  test_samples: 5\n")
+    sc = tmp_path / "scalars.jsonl"
+    log2 = run.main(["--cfg", str(cfg), "--load", str(ck), "--hyps", "6", "--dtype", "f32", "--epochs", "1", "--iters", "2", "--image-size", "96",
+                     "--scalars", str(sc)])
+    assert len(log2) == 1 and np.isfinite(log2[0]["loss"]) and log2[0]["loss"] < log[0]["loss"] + 50      # resumed, not re-initialised
+    tags = {__import__("json").loads(l)["tag"] for l in open(sc)}
+    assert {"loss_it/neg_log_p", "loss_avg/loss_total", "metric_train/eval_3d_rgb", "param/theta_norm", "param/beta_norm"} <= tags
 
 
 def test_full_size_train_step_properties(gpu_lib):
