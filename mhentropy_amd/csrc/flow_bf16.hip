@@ -14,6 +14,13 @@
 #include "common.h"
 #include <cstring>
 
+namespace mhe { namespace flowns {      // flow_ns.hip: hidden = 512
+size_t packed_bytes_per_net();
+void pack_net_host(const float *W0, const float *W1, const float *W2, int dim, unsigned short *out);
+int launch(const float *in, float *out, const float *cond, const void *wstream, const float *bias2, const float *mask,
+           float *sum_s, float *log_prob, int R, int B, int dim, int ncoup, int inv, hipStream_t s);
+}}
+
 namespace mhe { namespace flowb {
 
 constexpr int STAGE_BLOCKS = 16;                 // 1 KiB blocks per stage
@@ -348,11 +355,13 @@ using namespace mhe;
 
 extern "C" size_t mhe_flow_packed_bytes_per_net_bf16(int dim, int hidden) {
     if (dim <= 0 || dim > 48 || hidden < 128 || hidden % 128) return 0;
+    if (hidden == 512) return flowns::packed_bytes_per_net();
     return (size_t)flowb::net_stages(hidden) * flowb::STAGE_BYTES;
 }
 
 // 1 KiB block (To, kb) of W[rows][cols]: lane l = 32h + n, element j <-> W[32To+n][16kb + (j&3) + 8(j>>2) + 4h]
-static void pack_block_bf16(const float *W, int rows, int cols, int To, int kb, unsigned short *dst) {
+namespace mhe { namespace flowb {
+void pack_block_bf16(const float *W, int rows, int cols, int To, int kb, unsigned short *dst) {
     for (int l = 0; l < 64; ++l) {
         const int h = l >> 5, n = l & 31;
         for (int j = 0; j < 8; ++j) {
@@ -366,11 +375,17 @@ static void pack_block_bf16(const float *W, int rows, int cols, int To, int kb, 
         }
     }
 }
+}}
+using mhe::flowb::pack_block_bf16;
 
 extern "C" int mhe_flow_pack_net_bf16_host(const float *W0, const float *W1, const float *W2, int dim, int hidden,
                                            void *out_host) {
     const size_t total = mhe_flow_packed_bytes_per_net_bf16(dim, hidden);
     MHE_REQUIRE(total && W0 && W1 && W2 && out_host, "mhe_flow_pack_net_bf16_host: dim=%d (<=48) hidden=%d (multiple of 128)", dim, hidden);
+    if (hidden == 512) {
+        flowns::pack_net_host(W0, W1, W2, dim, reinterpret_cast<unsigned short *>(out_host));
+        return MHE_OK;
+    }
     const int NT = hidden / 32, CH = NT / 4, RT = NT > 8 ? 8 : NT, NP = NT / RT, L1S = 8 * RT / 16, L2S = RT / 4;
     unsigned short *out = reinterpret_cast<unsigned short *>(out_host);
     memset(out, 0, total);
@@ -402,8 +417,10 @@ extern "C" int mhe_flow_couplings_bf16(const float *in, float *out, const float 
     MHE_REQUIRE(dim > 0 && dim <= 48, "mhe_flow_couplings_bf16: dim=%d unsupported (1..48)", dim);
     MHE_REQUIRE(ncoup > 0, "mhe_flow_couplings_bf16: ncoup=%d", ncoup);
     MHE_REQUIRE(direction == MHE_FLOW_FORWARD || direction == MHE_FLOW_INVERSE, "mhe_flow_couplings_bf16: direction=%d", direction);
-    const dim3 grid((R + 127) / 128), block(256);
     const int inv = direction == MHE_FLOW_INVERSE;
+    if (hidden == 512)
+        return flowns::launch(in, out, cond, wstream, bias2, mask, sum_s, log_prob, R, B, dim, ncoup, inv, (hipStream_t)stream);
+    const dim3 grid((R + 127) / 128), block(256);
     const bool uni = ((R / B) % 32) == 0;          // every 32-row wavefront tile lies inside one image
     MHE_REQUIRE(ncoup <= 64, "mhe_flow_couplings_bf16: ncoup=%d > 64", ncoup);
     const size_t lds = (size_t)flowb::RING * flowb::STAGE_BYTES + 4 * 32 * 64 * sizeof(float) + 4 * 2 * 2 * (size_t)hidden * 4 +
@@ -430,7 +447,6 @@ extern "C" int mhe_flow_couplings_bf16(const float *in, float *out, const float 
     switch (hidden) {
         case 128: LAUNCH(4); break;
         case 256: LAUNCH(8); break;
-        case 512: LAUNCH(16); break;
         default: MHE_REQUIRE(false, "mhe_flow_couplings_bf16: hidden=%d unsupported (128,256,512)", hidden);
     }
 #undef LAUNCH

@@ -198,3 +198,70 @@ def test_full_path_end_to_end_vs_oracle(gpu_lib):
         ref = network_ref.get_loss(sd, tb, torch.as_tensor(x), _t(yn, "cpu"), torch.as_tensor(z0), N, "resnet18", True)
     for k in ("th_norm", "bt_norm", "q_log_p_z_giv_y", "h_q_z_giv_i", "log_p"):
         assert_close(out[k].cpu(), ref[k], 2e-4, what=k)       # 18 BN layers of round-off in front of the 1e-4 path
+
+
+def test_resnet50_trunk_256x256_f32_matches_oracle(gpu_lib):
+    """the encoder at the reference's input size (hand/network.py:54-61,110: torchvision resnet50 on 256x256 crops) in f32, train-mode
+    BatchNorm, against the CPU restatement; B = 6 keeps the oracle at a few seconds and makes the launcher pick the large tiles on
+    layer1/2 (M = 6*64*64 = 24,576 pixels)."""
+    from mhentropy_amd import resnet
+    from oracle import resnet_ref
+    B = 6
+    sdn = synth.resnet_state(17, "resnet50")
+    sd = {k: torch.as_tensor(v) for k, v in sdn.items()}
+    x, _ = synth.batch(17, B, image_size=256)
+    trunk = resnet.ResNetTrunk("resnet50")
+    trunk.load_state_dict(sd)
+    trunk = trunk.cuda().train()
+    f = trunk(torch.as_tensor(x).cuda())
+    stats = {}
+    with torch.no_grad():
+        ref = resnet_ref.forward(sd, torch.as_tensor(x), "resnet50", True, stats)
+    assert f.shape == (B, 2048)
+    assert_close(f.cpu(), ref, RTOL, what="pooled feature, ResNet-50 @ 256x256")
+    for name, mod in (("layer1.0.bn1", trunk.layer1[0].bn1), ("layer4.2.bn3", trunk.layer4[2].bn3)):
+        mean, var, rm, rv = stats[name]
+        assert_close(mod.running_mean.cpu(), rm, RTOL, 1e-6, what=name + ".running_mean")
+        assert_close(mod.running_var.cpu(), rv, RTOL, what=name + ".running_var")
+
+
+def test_c1_full_size_f32_vs_oracle_and_properties(gpu_lib):
+    """config C1 (BASELINE.json configs[1]): ResNet-50 + the shipped 12-coupling h=512 RealNVP, B = 64 images x K = 16 hypotheses, f32,
+    forward + loss at 256x256 - the whole workload against the CPU restatement (about 10 s of oracle time), plus two properties
+    that hold at any size: (i) the per-image terms do not depend on the order of an image's hypotheses (noise rows permuted within
+    each image: K-means agree to summation-order round-off), (ii) the K hypotheses of an image see the same conditioning: feeding the
+    same noise row K times gives K identical rows (h_q_z_giv_i = that row's -log q, q_log_p = its own value)."""
+    from mhentropy_amd import harness
+    from oracle import network_ref, mano_ref
+    B, N = 64, 16
+    sdn = {"q_z_giv_i." + k: v for k, v in synth.flow_state(41, 45, 512, (512, 512), 6).items()}
+    sdn.update(synth.head_state(41, 2048, 512, 16))
+    sdn.update({"feat_extractor.res." + k: v for k, v in synth.resnet_state(41, "resnet50").items()})
+    x, yn = synth.batch(41, B, image_size=256)
+    z0 = synth.noise(41, N * B)
+    model = harness.build_mhent(backbone="resnet50", h_dims=(512, 512), num_steps=6, tables=synth.mano_tables(0))
+    missing, unexpected = model.load_state_dict({k: torch.as_tensor(v) for k, v in sdn.items()}, strict=False)
+    assert not unexpected and all(k.startswith("mano_dec.") for k in missing)
+    model = model.cuda().train()
+    xg, yg, zg = torch.as_tensor(x).cuda(), _t(yn), torch.as_tensor(z0).cuda()
+    keys = ("th_norm", "bt_norm", "q_log_p_z_giv_y", "h_q_z_giv_i", "log_p")
+    out = {k: v.clone() for k, v in model.get_loss(xg, yg, mods=["uv"], N=N, noise=zg).items() if k in keys}
+    sd = {k: torch.as_tensor(v) for k, v in sdn.items()}
+    tb = mano_ref.tables_from_numpy(synth.mano_tables(0))
+    with torch.no_grad():
+        ref = network_ref.get_loss(sd, tb, torch.as_tensor(x), _t(yn, "cpu"), torch.as_tensor(z0), N, "resnet50", True)
+    for k in keys:
+        assert out[k].shape == ref[k].shape
+        assert_close(out[k].cpu(), ref[k], 3e-4, what="C1 " + k)   # 53 train-mode BN layers of round-off in front of the 1e-4 path
+    # (i) hypothesis order within an image is irrelevant (rows are sample-major: r = n*B + b)
+    perm = torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(b)) for b in range(B)], 1).cuda()      # (N, B)
+    zp = zg.view(N, B, -1).gather(0, perm[:, :, None].expand(-1, -1, zg.shape[-1])).reshape(N * B, -1).contiguous()
+    outp = model.get_loss(xg, yg, mods=["uv"], N=N, noise=zp)
+    for k in ("q_log_p_z_giv_y", "h_q_z_giv_i", "log_p"):
+        assert_close(outp[k].cpu(), out[k].cpu(), 2e-5, what="permuted hypotheses " + k)
+    # (ii) K copies of one noise row: per-image means equal the single-hypothesis values
+    z1 = zg.view(N, B, -1)[:1].expand(N, -1, -1).reshape(N * B, -1).contiguous()
+    o1 = {k: v.clone() for k, v in model.get_loss(xg, yg, mods=["uv"], N=N, noise=z1).items() if k in keys}
+    oK = model.get_loss(xg, yg, mods=["uv"], N=1, noise=zg[:B].contiguous())
+    for k in ("q_log_p_z_giv_y", "h_q_z_giv_i", "log_p"):
+        assert_close(o1[k].cpu(), oK[k].cpu(), 2e-5, what="repeated hypothesis " + k)
