@@ -97,8 +97,9 @@ int mhe_flow_couplings_f32(const float *in, float *out, const float *cond,
  * between layers; flow variable, s, t, exp and log-det in f32): same contract as
  * mhe_flow_couplings_f32 with `wstream` = 2*ncoup nets packed by mhe_flow_pack_net_bf16_host and
  * `bias2` zero-padded to [2*ncoup, 64] (uniform scalar loads, no bounds test in the kernel).
- * v_mfma_f32_32x32x16_bf16, 32 rows per wave, weights DMA'd (global_load_lds) into an LDS ring.
- * hidden in {128, 256, 512}, dim <= 48. */
+ * v_mfma_f32_32x32x16_bf16, weights DMA'd (global_load_lds) into LDS rings.  hidden in {128, 256, 512}, dim <= 48:
+ * 512 runs the unit-split kernel (csrc/flow_ns.hip: 64 rows per workgroup, 64 units per wave), 128 / 256 the
+ * row-split one (csrc/flow_bf16.hip: 32 rows per wave); the packed stream's block order follows the kernel. */
 size_t mhe_flow_packed_bytes_per_net_bf16(int dim, int hidden);
 int mhe_flow_pack_net_bf16_host(const float *W0_host, const float *W1_host, const float *W2_host,
                                 int dim, int hidden, void *out_host);
@@ -107,6 +108,14 @@ int mhe_flow_couplings_bf16(const float *in, float *out, const float *cond,
                             float *sum_s, float *log_prob,
                             int R, int B, int dim, int hidden, int ncoup, int direction,
                             void *stream);
+/* the same pass (hidden = 512 only) also writing out what the reverse pass of the train step needs, so that it does not
+ * re-evaluate the nets (what autograd keeps for hand/flows.py:105-122): h1, h2 = hidden activations after the leaky-ReLU, bf16
+ * [2*ncoup nets][R][512]; o = s / t pre-activations (l2 output incl. bias, before tanh), f32 [2*ncoup][R][64] (cols >= 48 untouched). */
+int mhe_flow_couplings_bf16_emit(const float *in, float *out, const float *cond,
+                                 const void *wstream, const float *bias2, const float *mask,
+                                 float *sum_s, float *log_prob, void *h1, void *h2, float *o,
+                                 int R, int B, int dim, int hidden, int ncoup, int direction,
+                                 void *stream);
 
 /* MANO decode + likelihood ------------------------------------------------- */
 

@@ -28,6 +28,7 @@ SIGNATURES = {
     "mhe_flow_packed_bytes_per_net_bf16": (_sz, [_i, _i]),
     "mhe_flow_pack_net_bf16_host": (_i, [_p, _p, _p, _i, _i, _p]),
     "mhe_flow_couplings_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "mhe_flow_couplings_bf16_emit": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mhe_mano_table_floats": (_sz, []),
     "mhe_mano_joints_f32": (_i, [_p] * 12 + [_i, _i, _f, _f, _i, _f, _p]),
     "mhe_mano_verts_workspace_floats": (_sz, [_i]),

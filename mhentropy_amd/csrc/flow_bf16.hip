@@ -18,7 +18,8 @@ namespace mhe { namespace flowns {      // flow_ns.hip: hidden = 512
 size_t packed_bytes_per_net();
 void pack_net_host(const float *W0, const float *W1, const float *W2, int dim, unsigned short *out);
 int launch(const float *in, float *out, const float *cond, const void *wstream, const float *bias2, const float *mask,
-           float *sum_s, float *log_prob, int R, int B, int dim, int ncoup, int inv, hipStream_t s);
+           float *sum_s, float *log_prob, int R, int B, int dim, int ncoup, int inv, hipStream_t s,
+           unsigned short *h1e, unsigned short *h2e, float *oe);
 }}
 
 namespace mhe { namespace flowb {
@@ -409,6 +410,19 @@ extern "C" int mhe_flow_pack_net_bf16_host(const float *W0, const float *W1, con
     return MHE_OK;
 }
 
+extern "C" int mhe_flow_couplings_bf16_emit(const float *in, float *out, const float *cond, const void *wstream,
+                                            const float *bias2, const float *mask, float *sum_s, float *log_prob, void *h1,
+                                            void *h2, float *o, int R, int B, int dim, int hidden, int ncoup, int direction,
+                                            void *stream) {
+    MHE_REQUIRE(in && out && cond && wstream && bias2 && mask && h1 && h2 && o, "mhe_flow_couplings_bf16_emit: null pointer");
+    MHE_REQUIRE(hidden == 512, "mhe_flow_couplings_bf16_emit: hidden=%d (only the 512-wide kernel writes its activations out)", hidden);
+    MHE_REQUIRE(R > 0 && B > 0 && R % B == 0, "mhe_flow_couplings_bf16_emit: R=%d must be a positive multiple of B=%d", R, B);
+    MHE_REQUIRE(dim > 0 && dim <= 48 && ncoup > 0 && ncoup <= 64, "mhe_flow_couplings_bf16_emit: dim=%d (1..48) ncoup=%d (1..64)", dim, ncoup);
+    MHE_REQUIRE(direction == MHE_FLOW_FORWARD || direction == MHE_FLOW_INVERSE, "mhe_flow_couplings_bf16_emit: direction=%d", direction);
+    return flowns::launch(in, out, cond, wstream, bias2, mask, sum_s, log_prob, R, B, dim, ncoup, direction == MHE_FLOW_INVERSE,
+                          (hipStream_t)stream, reinterpret_cast<unsigned short *>(h1), reinterpret_cast<unsigned short *>(h2), o);
+}
+
 extern "C" int mhe_flow_couplings_bf16(const float *in, float *out, const float *cond, const void *wstream,
                                        const float *bias2, const float *mask, float *sum_s, float *log_prob, int R,
                                        int B, int dim, int hidden, int ncoup, int direction, void *stream) {
@@ -419,7 +433,7 @@ extern "C" int mhe_flow_couplings_bf16(const float *in, float *out, const float 
     MHE_REQUIRE(direction == MHE_FLOW_FORWARD || direction == MHE_FLOW_INVERSE, "mhe_flow_couplings_bf16: direction=%d", direction);
     const int inv = direction == MHE_FLOW_INVERSE;
     if (hidden == 512)
-        return flowns::launch(in, out, cond, wstream, bias2, mask, sum_s, log_prob, R, B, dim, ncoup, inv, (hipStream_t)stream);
+        return flowns::launch(in, out, cond, wstream, bias2, mask, sum_s, log_prob, R, B, dim, ncoup, inv, (hipStream_t)stream, nullptr, nullptr, nullptr);
     const dim3 grid((R + 127) / 128), block(256);
     const bool uni = ((R / B) % 32) == 0;          // every 32-row wavefront tile lies inside one image
     MHE_REQUIRE(ncoup <= 64, "mhe_flow_couplings_bf16: ncoup=%d > 64", ncoup);

@@ -76,11 +76,14 @@ __device__ __forceinline__ void u4_to_acc(v16f &a, int r0, const u4 &c) {
 }
 
 // UNI: every 32-row tile lies inside one image (N % 32 == 0): the conditioning rows are wave-uniform and travel by DMA
-template <bool UNI>
+// EMIT (train step): the hidden activations of every net (bf16, [net][row][512], after the leaky-ReLU) and the s / t
+// pre-activations (f32, [net][row][64]) are also written out - the reverse pass reads them instead of re-evaluating the nets
+template <bool UNI, bool EMIT>
 __global__ __launch_bounds__(512) void couplings_ns_kernel(
     const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ cond,
     const unsigned char *__restrict__ wstream, const float *__restrict__ bias2, const float *__restrict__ mask,
-    float *__restrict__ sum_s_o, float *__restrict__ logp_o, int R, int B, int dim, int ncoup, int inverse) {
+    float *__restrict__ sum_s_o, float *__restrict__ logp_o, int R, int B, int dim, int ncoup, int inverse,
+    unsigned short *__restrict__ h1e, unsigned short *__restrict__ h2e, float *__restrict__ oe) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int h = lane >> 5, m = lane & 31;
@@ -89,12 +92,25 @@ __global__ __launch_bounds__(512) void couplings_ns_kernel(
     const unsigned l16 = lds_base + lane * 16;
 
     // rows of the two 32-row tiles (image-major tiling of the sample-major rows r = n*B + b)
-    int bimg[2];
+    int bimg[2], erow[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         const int g = blockIdx.x * ROWS + a * 32 + m, gc = g < R ? g : R - 1;
         bimg[a] = gc / N;
+        erow[a] = g < R ? (gc % N) * B + bimg[a] : -1;
     }
+    // one hidden tile of this lane's row -> 4 x 8 bytes of the row-major bf16 activations (units 32T + 8g + 4h + {0..3})
+    auto emit_tile = [&](unsigned short *base, int net, int a, int t, const u4 &f0, const u4 &f1) {
+        if (erow[a] >= 0) {
+            unsigned short *p = base + ((size_t)net * R + erow[a]) * H + 64 * w + 32 * t + 4 * h;
+            typedef unsigned u2 __attribute__((ext_vector_type(2)));
+            u2 d0, d1, d2, d3;
+            d0[0] = f0[0]; d0[1] = f0[1]; d1[0] = f0[2]; d1[1] = f0[3]; d2[0] = f1[0]; d2[1] = f1[1]; d3[0] = f1[2]; d3[1] = f1[3];
+            asm volatile("global_store_dwordx2 %0, %1, off\n\tglobal_store_dwordx2 %0, %2, off offset:16\n\t"
+                         "global_store_dwordx2 %0, %3, off offset:32\n\tglobal_store_dwordx2 %0, %4, off offset:48"
+                         :: "v"(p), "v"(d0), "v"(d1), "v"(d2), "v"(d3) : "memory");
+        }
+    };
     const int b_uni0 = __builtin_amdgcn_readfirstlane(bimg[0]), b_uni1 = __builtin_amdgcn_readfirstlane(bimg[1]);
 
     // ---- owner waves: wave o < 6 holds the flow variable of row tile o/3, dims 16*(o%3) + (j&3) + 8(j>>2) + 4h, j < 8
@@ -235,6 +251,7 @@ __global__ __launch_bounds__(512) void couplings_ns_kernel(
                 const unsigned xa = l16 + XB_OFF + ((4 * w + 2 * t) * 2 + a) * 1024;
                 NS_W(xa, f0, 0);
                 NS_W(xa, f1, 2048);
+                if constexpr (EMIT) emit_tile(h1e, net, a, t, f0, f1);
             }
         // ================= layer 1: h2[own 64 units][64 rows] = W1 . h1 + c1
         v16f a2[2][2];
@@ -267,6 +284,7 @@ __global__ __launch_bounds__(512) void couplings_ns_kernel(
                 for (int i = 0; i < 16; ++i) a2[t][a][i] = leaky(a2[t][a][i]);
                 hf[t][0][a] = pack8(a2[t][a], 0);
                 hf[t][1][a] = pack8(a2[t][a], 8);
+                if constexpr (EMIT) emit_tile(h2e, net, a, t, hf[t][0][a], hf[t][1][a]);
             }
         v16f o[2][2];                                 // [dim tile][row tile]
 #pragma unroll
@@ -331,6 +349,15 @@ __global__ __launch_bounds__(512) void couplings_ns_kernel(
             const unsigned ba = lds_base + CW_OFF + w * CW_BYTES + 1024 + (seq & 1) * 256 + (16 * okb + 4 * h) * 4;
             NS_R2(b0, b1, ba, 0, 32);
             const unsigned long long mw = mask_word(ci);
+            if constexpr (EMIT) {
+                if (ovalid) {                           // pre-activation incl. bias, dims 16*okb + 4h + {0..3} and + 8
+                    float *p = oe + ((size_t)net * R + orow) * 64 + 16 * okb + 4 * h;
+                    v4f e0, e1;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { e0[k] = acc8[k] + __uint_as_float(b0[k]); e1[k] = acc8[4 + k] + __uint_as_float(b1[k]); }
+                    asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:32" :: "v"(p), "v"(e0), "v"(e1) : "memory");
+                }
+            }
             if (netk == 0) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -410,19 +437,27 @@ void pack_net_host(const float *W0, const float *W1, const float *W2, int dim, u
 }
 
 int launch(const float *in, float *out, const float *cond, const void *wstream, const float *bias2, const float *mask,
-           float *sum_s, float *log_prob, int R, int B, int dim, int ncoup, int inv, hipStream_t s) {
+           float *sum_s, float *log_prob, int R, int B, int dim, int ncoup, int inv, hipStream_t s,
+           unsigned short *h1e, unsigned short *h2e, float *oe) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(couplings_ns_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(couplings_ns_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(couplings_ns_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(couplings_ns_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(couplings_ns_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(couplings_ns_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
     const dim3 grid((R + ROWS - 1) / ROWS), block(512);
     const unsigned char *ws = reinterpret_cast<const unsigned char *>(wstream);
-    if (((R / B) % 32) == 0)
-        hipLaunchKernelGGL((couplings_ns_kernel<true>), grid, block, LDS_BYTES, s, in, out, cond, ws, bias2, mask, sum_s, log_prob, R, B, dim, ncoup, inv);
-    else
-        hipLaunchKernelGGL((couplings_ns_kernel<false>), grid, block, LDS_BYTES, s, in, out, cond, ws, bias2, mask, sum_s, log_prob, R, B, dim, ncoup, inv);
+    const bool uni = ((R / B) % 32) == 0, emit = h1e != nullptr;
+#define NS_LAUNCH(U, E)                                                                                                        \
+    hipLaunchKernelGGL((couplings_ns_kernel<U, E>), grid, block, LDS_BYTES, s, in, out, cond, ws, bias2, mask, sum_s, log_prob, R, B, dim, \
+                       ncoup, inv, h1e, h2e, oe)
+    if (uni && emit) NS_LAUNCH(true, true);
+    else if (uni) NS_LAUNCH(true, false);
+    else if (emit) NS_LAUNCH(false, true);
+    else NS_LAUNCH(false, false);
+#undef NS_LAUNCH
     return check_launch("flowns::couplings_ns_kernel");
 }
 

@@ -128,6 +128,25 @@ def flow_couplings(x_in, cond, wstream, bias2, mask, B, hidden, direction, want_
     return out, sum_s, logp
 
 
+def flow_couplings_emit(x_in, cond, wstream, bias2, mask, B, hidden, direction, h1, h2, o):
+    """flow_couplings (bf16 stream, hidden 512) that also writes the nets' hidden activations h1, h2 (bf16 [nets, R, 512]) and
+    the s / t pre-activations o (f32 [nets, R, 64]) for the reverse pass; returns (out, sum_s, log_prob)."""
+    R, dim = x_in.shape
+    ncoup = mask.shape[0]
+    _chk(x_in, torch.float32, "flow.in"); _chk(cond, torch.float32, "flow.cond", (B, 2 * ncoup, 2, hidden))
+    _chk(wstream, wstream.dtype, "flow.wstream"); _chk(bias2, torch.float32, "flow.bias2", (2 * ncoup, 64))
+    _chk(mask, torch.float32, "flow.mask", (ncoup, dim))
+    _chk(h1, torch.bfloat16, "flow.h1", (2 * ncoup, R, hidden)); _chk(h2, torch.bfloat16, "flow.h2", (2 * ncoup, R, hidden))
+    _chk(o, torch.float32, "flow.o", (2 * ncoup, R, 64))
+    out = torch.empty_like(x_in)
+    sum_s = torch.empty(R, device=x_in.device, dtype=torch.float32)
+    logp = torch.empty(R, device=x_in.device, dtype=torch.float32)
+    check(_lib.lib().mhe_flow_couplings_bf16_emit(_ptr(x_in), _ptr(out), _ptr(cond), _ptr(wstream), _ptr(bias2), _ptr(mask), _ptr(sum_s),
+                                                  _ptr(logp), _ptr(h1), _ptr(h2), _ptr(o), R, B, dim, hidden, ncoup, direction, _stream()),
+          "mhe_flow_couplings_bf16_emit")
+    return out, sum_s, logp
+
+
 def mano_joints(th45, det, tables, crop_uv=None, vis=None, laplace_b=0.03, th45_alpha=50.0, inv_norm=False,
                 image_size=256.0, want=("z", "xyz", "uv", "terms", "log_p", "norms")):
     """want may also include "joints_mm"."""

@@ -23,6 +23,8 @@ layout their kernel produces and one final gather maps them onto the flat gradie
 """
 import math
 
+import os
+
 import numpy as np
 import torch
 
@@ -569,10 +571,15 @@ class TrainStep:
             G1b = self._buf("G1b", (R, h), bf)
             GcT = self._buf("GcondT", (cstride, B))              # the same sums as Gc, [column][image]: split-K operand of g_feat
             self._GcT = GcT
+            kept = getattr(self, "_flow_kept", None)
+            if kept is not None and kept[0].shape[1] != R:
+                kept = None
             for i in range(ncoup - 1, -1, -1):
                 m = fl.mask[i]
                 ops.flow_mask_pad_mixed(x_cur, m, out_bf16=XPb)
-                for n in range(2):
+                if kept is not None:                   # written out by the forward kernel (mhe_flow_couplings_bf16_emit)
+                    H1b, H2b, O = [[k[2 * i + n] for n in range(2)] for k in kept]
+                for n in range(2 if kept is None else 0):
                     d, slot = self.fnets[2 * i + n], (2 * i + n) * 2
                     ops.conv2d_nhwc(v4(XPb), d["w0b"], 1, 1, 1, 0, out=v4(P0b))
                     ops.flow_cond_lrelu_mixed(P0b, cflat[:, slot * h:], cstride, B, out_bf16=H1b[n])
@@ -673,7 +680,17 @@ class TrainStep:
             h, ncoup = fl.hidden, len(fl.mask)
             cond = ops.linear(feat, self.f_wc, self.f_bc).view(B, 2 * ncoup, 2, h)
             z0 = m._noise(N * B, 1.0, noise, self.dev)
-            th45, _, log_q = ops.flow_couplings(z0, cond, self.f_stream, self.f_b2, fl.mask, B, h, ops.FLOW_FORWARD)
+            self._flow_kept = None
+            if self.flow_bf16 and h == 512 and os.environ.get("MHE_FLOW_RECOMPUTE") != "1":
+                # the 512-wide kernel writes the nets' activations out on the way: the reverse pass reads them instead of re-evaluating
+                # the nets coupling by coupling (what autograd would have kept)
+                Rr = N * B
+                kept = (self._buf("fl_h1", (2 * ncoup, Rr, h), torch.bfloat16), self._buf("fl_h2", (2 * ncoup, Rr, h), torch.bfloat16),
+                        self._buf("fl_o", (2 * ncoup, Rr, 64)))
+                th45, _, log_q = ops.flow_couplings_emit(z0, cond, self.f_stream, self.f_b2, fl.mask, B, h, ops.FLOW_FORWARD, *kept)
+                self._flow_kept = kept
+            else:
+                th45, _, log_q = ops.flow_couplings(z0, cond, self.f_stream, self.f_b2, fl.mask, B, h, ops.FLOW_FORWARD)
         blob = m.mano_dec.table_blob()
         cu, vis = y["crop_uv"].contiguous(), y["vis"].contiguous()
         o = ops.mano_joints(th45, det, blob, cu, vis, m.b_2d, m.th45_ref_alpha, want=("log_p", "norms"))

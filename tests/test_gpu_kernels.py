@@ -246,3 +246,57 @@ def test_metrics_match_reference_vectors(gpu_lib):
                           _dev(g["y_crop_uv"]), _dev(g["y_vis"]))
         for i, k in enumerate(criteria.METRIC_KEYS):
             assert_close(out[i].cpu(), g["metric_" + k], RTOL, what=k)
+
+
+@pytest.mark.parametrize("B,N", [(3, 64), (2, 40)])
+def test_flow_bf16_emitted_activations(gpu_lib, B, N):
+    """mhe_flow_couplings_bf16_emit: same outputs as the plain launch, and the hidden activations / s,t pre-activations it writes out for
+    the reverse pass are those of the nets (hand/flows.py:105-122) on bf16-rounded operands - checked for the first coupling (whose
+    input is the kernel's input) and, through the last coupling's o, for the chain"""
+    from mhentropy_amd import ops
+    h, steps = 512, 2
+    sd = synth.flow_state(5, 45, 512, (h, h), steps)
+    ncoup = 2 * steps
+    packs, b2, wc, bc = [], [], [], []
+    for i in range(ncoup):
+        for net in ("s", "t"):
+            p = f"{net}.{i}."
+            packs.append(ops.flow_pack_net_bf16(sd[p + "l.0.weight"], sd[p + "l.1.weight"], sd[p + "l.2.weight"]))
+            b2.append(sd[p + "l.2.bias"])
+            for j in range(2):
+                wc.append(sd[p + f"c.{j}.weight"]); bc.append(sd[p + f"c.{j}.bias"] + sd[p + f"l.{j}.bias"])
+    wstream = _dev(np.concatenate(packs).view(np.int16))
+    rng = np.random.default_rng(3)
+    feat = rng.normal(0, 1, (B, 512)).astype(np.float32)
+    z0 = _dev(rng.normal(0, 1, (N * B, 45)).astype(np.float32))
+    R = N * B
+    cond = ops.linear(_dev(feat), _dev(np.concatenate(wc)), _dev(np.concatenate(bc))).view(B, 2 * ncoup, 2, h)
+    b2d = _dev(np.pad(np.stack(b2), ((0, 0), (0, 64 - 45))))
+    mask = _dev(sd["mask"])
+    h1 = torch.zeros(2 * ncoup, R, h, device="cuda", dtype=torch.bfloat16)
+    h2 = torch.zeros_like(h1)
+    o = torch.zeros(2 * ncoup, R, 64, device="cuda")
+    x, sum_s, logq = ops.flow_couplings_emit(z0, cond, wstream, b2d, mask, B, h, ops.FLOW_FORWARD, h1, h2, o)
+    x0, sum_s0, logq0 = ops.flow_couplings(z0, cond, wstream, b2d, mask, B, h, ops.FLOW_FORWARD)
+    assert torch.equal(x, x0) and torch.equal(sum_s, sum_s0) and torch.equal(logq, logq0)
+    rb = lambda t: t.to(torch.bfloat16).float()
+    lrelu = torch.nn.functional.leaky_relu
+    img = torch.arange(R, device="cuda") % B                     # sample-major rows
+    xin = z0
+    for ci in range(ncoup):
+        xm = rb(xin * mask[ci])
+        pre = []
+        for n, name in enumerate(("s", "t")):
+            net = 2 * ci + n
+            W = [rb(_dev(sd[f"{name}.{ci}.l.{j}.weight"])) for j in range(3)]
+            a1 = rb(lrelu(xm @ W[0].T + cond[img, net, 0], 0.01))
+            a2 = rb(lrelu(a1 @ W[1].T + cond[img, net, 1], 0.01))
+            oo = a2 @ W[2].T + _dev(sd[f"{name}.{ci}.l.2.bias"])
+            # one bf16 ulp (2^-8 relative) where a rounding flips; the kernel's own bf16 inputs otherwise
+            assert_close(h1[net].float().cpu(), a1.cpu(), 8e-3, what=f"h1 net {net}")
+            assert_close(h2[net].float().cpu(), a2.cpu(), 8e-3, what=f"h2 net {net}")
+            assert_close(o[net, :, :45].cpu(), oo.cpu(), 1e-2, what=f"o net {net}")
+            pre.append(o[net, :, :45])
+        s, t = torch.tanh(pre[0]), pre[1]
+        xin = xin * mask[ci] + (1 - mask[ci]) * (xin * torch.exp(s) + t)      # hand/flows.py:216, from the kernel's own s, t
+    assert_close(x.cpu(), xin.cpu(), 1e-5, what="x rebuilt from the emitted pre-activations")
