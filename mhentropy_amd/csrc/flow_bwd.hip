@@ -140,6 +140,44 @@ __global__ __launch_bounds__(256) void lrelu_bwd_sum_kernel(const TG *__restrict
     if (sum_t) { sum_t[(size_t)c * B + b] = a0; sum_t[(size_t)(c + 1) * B + b] = a1; }      // the same, [column][image]
 }
 
+// the same at H = 512 with bf16 in and out (the train step's case): one workgroup per image, a wave reads whole 1 KiB rows with 16-byte
+// lanes and takes every 8th hypothesis, partial sums meet in LDS - 2,048 waves with 16-byte accesses instead of 1,024 with 4-byte ones
+__global__ __launch_bounds__(512) void lrelu_bwd_sum512_kernel(const u16 *__restrict__ g, const u16 *__restrict__ h, u16 *__restrict__ out_b,
+                                                               float *__restrict__ sum_out, long sum_stride, float *__restrict__ sum_t,
+                                                               int N, int B, float slope) {
+    __shared__ float part[8][512];
+    const int b = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = 0.f;
+#pragma unroll 4
+    for (int n = w; n < N; n += 8) {
+        const size_t e = ((size_t)n * B + b) * 512 + lane * 8;
+        const uint4 gv = *reinterpret_cast<const uint4 *>(g + e), hv = *reinterpret_cast<const uint4 *>(h + e);
+        const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, hw[4] = {hv.x, hv.y, hv.z, hv.w};
+        unsigned ow[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float g0 = __uint_as_float(gw[k] << 16), g1 = __uint_as_float(gw[k] & 0xffff0000u);
+            const float h0 = __uint_as_float(hw[k] << 16), h1 = __uint_as_float(hw[k] & 0xffff0000u);
+            g0 = h0 > 0.f ? g0 : slope * g0;
+            g1 = h1 > 0.f ? g1 : slope * g1;
+            ow[k] = (unsigned)f32_to_bf16(g0) | ((unsigned)f32_to_bf16(g1) << 16);
+            a[2 * k] += g0; a[2 * k + 1] += g1;
+        }
+        *reinterpret_cast<uint4 *>(out_b + e) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) part[w][lane * 8 + k] = a[k];
+    __syncthreads();
+    const int c = threadIdx.x;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += part[k][c];
+    sum_out[(size_t)b * sum_stride + c] = s;
+    if (sum_t) sum_t[(size_t)c * B + b] = s;
+}
+
 // One coupling, reverse: from its output x_out and the nets' raw outputs Os, Ot (bias included, 64-wide)
 //   s = tanh(Os)(1-m), t = Ot(1-m), x_in = m x_out + (1-m)(x_out - t) e^{-s}          (hand/flows.py:213-216)
 // and the adjoints of x_out (g_out) and of log q (a_q per row; log q = logN(z0) - sum s):
@@ -248,6 +286,8 @@ extern "C" int mhe_flow_lrelu_bwd_sum(const void *g, int g_dtype, const void *h,
         hipLaunchKernelGGL((flowbwd::lrelu_bwd_sum_kernel<float, u16>), grid, block, 0, s, (const float *)g, (const u16 *)h, out_f32, ob, sum_out, sum_stride, sum_out_t, N, B, H, slope);
     else if (h_dtype == MHE_F32)
         hipLaunchKernelGGL((flowbwd::lrelu_bwd_sum_kernel<u16, float>), grid, block, 0, s, (const u16 *)g, (const float *)h, out_f32, ob, sum_out, sum_stride, sum_out_t, N, B, H, slope);
+    else if (H == 512 && ob && !out_f32)
+        hipLaunchKernelGGL(flowbwd::lrelu_bwd_sum512_kernel, dim3(B), dim3(512), 0, s, (const u16 *)g, (const u16 *)h, ob, sum_out, sum_stride, sum_out_t, N, B, slope);
     else
         hipLaunchKernelGGL((flowbwd::lrelu_bwd_sum_kernel<u16, u16>), grid, block, 0, s, (const u16 *)g, (const u16 *)h, out_f32, ob, sum_out, sum_stride, sum_out_t, N, B, H, slope);
     return check_launch("lrelu_bwd_sum_kernel");

@@ -300,3 +300,23 @@ def test_flow_bf16_emitted_activations(gpu_lib, B, N):
         s, t = torch.tanh(pre[0]), pre[1]
         xin = xin * mask[ci] + (1 - mask[ci]) * (xin * torch.exp(s) + t)      # hand/flows.py:216, from the kernel's own s, t
     assert_close(x.cpu(), xin.cpu(), 1e-5, what="x rebuilt from the emitted pre-activations")
+
+
+@pytest.mark.parametrize("H,N,B", [(512, 64, 5), (512, 10, 3), (256, 12, 4)])
+def test_flow_lrelu_bwd_sum(gpu_lib, H, N, B):
+    """leaky-ReLU reverse fused with the per-image sums over the hypothesis rows (rows are sample-major, r = n*B + b), bf16 in / out;
+    H = 512 takes the one-workgroup-per-image kernel"""
+    from mhentropy_amd import ops
+    gen = torch.Generator(device="cuda").manual_seed(H + N)
+    g = torch.randn(N * B, H, device="cuda", generator=gen).to(torch.bfloat16)
+    h = torch.randn(N * B, H, device="cuda", generator=gen).to(torch.bfloat16)
+    out = torch.empty_like(g)
+    sums = torch.zeros(B, 2 * H + 8, device="cuda")
+    sums_t = torch.zeros(H, B, device="cuda")
+    ops.flow_lrelu_bwd_sum(g, h, N, B, sums[:, H:], sums.shape[1], out_bf16=out, sum_out_t=sums_t)
+    ref = torch.where(h.float() > 0, g.float(), 0.01 * g.float())
+    assert torch.equal(out, ref.to(torch.bfloat16))
+    want = ref.view(N, B, H).sum(0)
+    assert_close(sums[:, H:2 * H].cpu(), want.cpu(), 1e-6, what="per-image sums")
+    assert torch.equal(sums_t.t().contiguous(), sums[:, H:2 * H].contiguous())
+    assert float(sums[:, :H].abs().max()) == 0 and float(sums[:, 2 * H:].abs().max()) == 0
