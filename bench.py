@@ -99,24 +99,20 @@ def time_train_step(model, x, y, noise, B, K, args, dist, world, dev):
         torch.cuda.synchronize()
         log(f"train warm-up step {i} done (loss {float(tout['total']):.3f})")
     tlaunch = "eager"
-    if args.graph and world == 1:
-        # the whole step (~1,500 launches; step count and gradient norm live in device memory) replays from one captured
-        # HIP graph; with N > 1 the RCCL all-reduce keeps it eager
+    if args.graph:
+        # the whole step (~840 launches; step count and gradient norm live in device memory) replays from one captured HIP
+        # graph; with N > 1 from six graphs cut at the gradient buckets, the RCCL all-reduces issued between them
         try:
-            gs = torch.cuda.Stream()
-            gs.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(gs):
-                tstep()
-            torch.cuda.current_stream().wait_stream(gs)
-            tgraph, tres = torch.cuda.CUDAGraph(), {}
-            with torch.cuda.graph(tgraph):
-                tres["out"] = tstep()
-            tgraph.replay()
+            from mhentropy_amd.train import GraphedStep
+            gstep = GraphedStep(ts, x, y, noise=noise, N=K)
+            gstep.replay()
             torch.cuda.synchronize()
-            tout, tstep, tlaunch = tres["out"], tgraph.replay, "hip-graph replay"
+            tout, tstep = gstep.out, gstep.replay
+            tlaunch = "hip-graph replay" if world == 1 else f"{len(gstep.graphs)} hip graphs, all-reduce between them"
         except Exception as e:          # capture is an optimisation, never a requirement
             log(f"train-step graph capture unavailable ({type(e).__name__}: {e}); timing eager launches")
             torch.cuda.synchronize()
+            ts._capture = None
             tstep = lambda: ts.step(x, y, noise=noise, N=K)
     dtt = mdist.timed_region(tstep, args.train_steps, dist, dev)
     assert torch.isfinite(tout["log_p"]).all(), "non-finite loss in the train step"

@@ -172,10 +172,22 @@ class TrainStep:
         lo, hi = self._bucket_bounds[i]
         ops.gather(self.raw, self._unpack_idx[lo:hi], self.G[lo:hi])
         if self.dist is not None and self.world > 1:
-            self._works.append(self.dist.all_reduce(self.G[lo:hi], op=self.dist.ReduceOp.SUM, async_op=True))
+            cap = getattr(self, "_capture", None)
+            if cap is not None:              # GraphedStep: the graph ends here, the collective is issued between two graph launches
+                cap.cut(("allreduce", i))
+            else:
+                self._all_reduce_bucket(i)
+
+    def _all_reduce_bucket(self, i):
+        lo, hi = self._bucket_bounds[i]
+        self._works.append(self.dist.all_reduce(self.G[lo:hi], op=self.dist.ReduceOp.SUM, async_op=True))
 
     def finish_allreduce(self):
         """wait for the gradient buckets' all-reduces (sum over ranks; the mean is taken by grad_scale = 1/world)"""
+        cap = getattr(self, "_capture", None)
+        if cap is not None and self.dist is not None and self.world > 1:
+            cap.cut(("wait",))
+            return
         for w in self._works:
             w.wait()
         self._works = []
@@ -833,6 +845,59 @@ class TrainStep:
                                              feat=self.tape["feat_own"]))
         self.optimizer_step()
         return out
+
+
+class GraphedStep:
+    """TrainStep.step replayed from HIP graphs (launch-bound: ~840 kernels per step).  One process: one graph.  Data parallel:
+    the step is cut where a gradient bucket is complete - a graph ends there, the bucket's all-reduce is issued eagerly
+    (RCCL, async_op: it runs on the communicator's stream under the next graph's kernels), the next graph starts; the last
+    graph (norm, clip, Adam, operand re-pack) is launched after the waits.  Six graphs and four collectives per step."""
+
+    def __init__(self, ts, x, y, noise=None, N=None):
+        if ts.shard_hypotheses:
+            raise NotImplementedError("GraphedStep: the hypothesis-sharded forward has collectives inside the forward pass")
+        self.ts, self.graphs, self.actions = ts, [], []
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            ts.step(x, y, noise=noise, N=N)              # allocations and lazy initialisation happen here, not under capture
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        self._mode = "thread_local" if ts.world > 1 else "global"      # the communicator's watchdog thread may touch the device
+        with torch.cuda.stream(side):
+            self._cur = torch.cuda.CUDAGraph()
+            self._cur.capture_begin(capture_error_mode=self._mode)
+            ts._capture = self
+            try:
+                self.out = ts.step(x, y, noise=noise, N=N)
+            finally:
+                ts._capture = None
+                self._cur.capture_end()
+            self.graphs.append(self._cur)
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+
+    def cut(self, action):
+        self._cur.capture_end()
+        self.graphs.append(self._cur)
+        self.actions.append(action)
+        self._cur = torch.cuda.CUDAGraph()
+        self._cur.capture_begin(pool=self.graphs[0].pool(), capture_error_mode=self._mode)
+
+    def replay(self):
+        ts = self.ts
+        for k, g in enumerate(self.graphs):
+            g.replay()
+            if k < len(self.actions):
+                a = self.actions[k]
+                if a[0] == "allreduce":
+                    ts._all_reduce_bucket(a[1])
+                else:
+                    for w in ts._works:
+                        w.wait()
+                    ts._works = []
+        return self.out
 
 
 class _LossFn(torch.autograd.Function):

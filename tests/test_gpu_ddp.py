@@ -118,3 +118,55 @@ def test_hypothesis_sharded_train_step_equals_the_image_sharded_one(gpu_lib, tmp
         assert rec["log_p"] < 1e-5 and rec["h"] < 1e-5, rec
         # two runs of the reverse pass: f32 atomics order differs (see test_two_ranks_average_their_gradients)
         assert rec["g_feat"] < 2e-3 and rec["grad"] < 2e-3, rec
+
+
+GRAPH_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["MHE_ROOT"]); sys.path.insert(0, os.path.join(os.environ["MHE_ROOT"], "tests"))
+import torch
+from mhentropy_amd import dist as mdist, synth
+from mhentropy_amd.train import TrainStep, GraphedStep
+from test_gpu_train import _model_and_state
+rank, _, world, dist = mdist.init("gloo")
+torch.cuda.set_device(0)
+B, N = 3, 4
+xn, yn = synth.batch(70 + rank, B, image_size=96)
+x, y = torch.as_tensor(xn).cuda(), {k: torch.as_tensor(v).cuda() for k, v in yn.items()}
+z0 = torch.as_tensor(synth.noise(70 + rank, N * B)).cuda()
+model, _ = _model_and_state("resnet18", 64, 2)
+ts = TrainStep(model, dist=dist, lr=0.0)                   # lr 0: every step sees the same parameters
+out = ts.step(x, y, noise=z0, N=N)
+G_eager, loss_eager = ts.G.clone(), float(out["total"])
+gs = GraphedStep(ts, x, y, noise=z0, N=N)
+res = []
+for _ in range(2):
+    o = gs.replay(); torch.cuda.synchronize()
+    res.append((float((ts.G - G_eager).abs().max() / G_eager.abs().max()), float(o["total"])))
+model2, _ = _model_and_state("resnet18", 64, 2)
+ts2 = TrainStep(model2, dist=dist, lr=1e-3)
+gs2 = GraphedStep(ts2, x, y, noise=z0, N=N)                # capture itself takes one eager step
+gs2.replay(); gs2.replay(); torch.cuda.synchronize()
+with open(os.path.join(os.environ["MHE_OUT"], f"graph_rank{rank}.json"), "w") as fh:
+    json.dump({"graphs": len(gs.graphs), "actions": [a[0] for a in gs.actions], "err": [r[0] for r in res], "loss": [r[1] for r in res],
+               "loss_eager": loss_eager, "psum": float(ts2.P.double().sum()), "steps": int(ts2.step_t.item()) if hasattr(ts2.step_t, "item") else -1}, fh)
+dist.destroy_process_group()
+'''
+
+
+def test_graphed_step_cut_at_the_gradient_buckets(gpu_lib, tmp_path):
+    """GraphedStep under data parallelism (two ranks, gloo, one GPU): the step replays from six HIP graphs with the four bucket
+    all-reduces issued between them; same all-reduced gradient and loss as the eager step, replicas bit-identical after Adam"""
+    script = tmp_path / "graph_worker.py"
+    script.write_text(GRAPH_WORKER)
+    env = dict(os.environ, MHE_ROOT=ROOT, MHE_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29637", str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    recs = [json.load(open(tmp_path / f"graph_rank{r}.json")) for r in range(2)]
+    for r in recs:
+        assert r["graphs"] == 6 and r["actions"] == ["allreduce"] * 4 + ["wait"], r
+        assert max(r["err"]) < 2e-3, r                      # f32 atomics order differs run to run
+        assert all(abs(l - r["loss_eager"]) <= 1e-5 * abs(r["loss_eager"]) for l in r["loss"]), r
+    assert recs[0]["psum"] == recs[1]["psum"], recs
+    assert recs[0]["steps"] == recs[1]["steps"] == 3, recs   # the eager warm-up step inside GraphedStep + two replays (capture executes nothing)
