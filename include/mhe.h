@@ -209,6 +209,8 @@ int mhe_conv2d_masked_nhwc(const mhe_conv_desc *d, const void *x, const void *w,
 int mhe_conv_stat_shards(void);
 /* kernel variant the launcher picks for a geometry with plain operands (numbering of mhe_conv_desc.tile, minus 1) */
 int mhe_conv_tile(const mhe_conv_desc *d);
+/* the same for an operand-load form: mode 1 = producer BatchNorm on load, 2 = residual-block tail, 0 = plain operands */
+int mhe_conv_tile_mode(const mhe_conv_desc *d, int mode);
 
 /* 1x1 stride-1 convolution whose operand is the TAIL of the previous residual block evaluated while
  * loading (torchvision Bottleneck: out = relu(bn3(conv3) + identity)):

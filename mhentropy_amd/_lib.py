@@ -79,6 +79,7 @@ SIGNATURES = {
     "mhe_conv2d_f32out_nhwc": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p]),
     "mhe_conv_stat_shards": (_i, []),
     "mhe_conv_tile": (_i, [C.POINTER(ConvDesc)]),
+    "mhe_conv_tile_mode": (_i, [C.POINTER(ConvDesc), _i]),
     "mhe_conv1x1_residual_in_nhwc": (_i, [C.POINTER(ConvDesc)] + [_p] * 11),
     "mhe_stem_conv7x7s2": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mhe_bn_finalize": (_i, [_p] * 8 + [_i, _f, _f, _f, _p]),

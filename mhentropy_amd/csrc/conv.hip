@@ -594,6 +594,9 @@ static int choose_tile(const Params &p, bool fast, bool bf16) {
         // plain operands go to the phase-pipelined kernel (conv_p8.hip: 0.85-1.0x the time of the register-staged 256x256
         // kernel on every trunk shape, tools/conv_variants.py); the producer-BatchNorm / residual-tail operand loads need
         // the register path
+        // residual-tail loads with a single wave of 256x256 workgroups (layer3's conv1: 256 tiles) have nothing to overlap their
+        // epilogue with: 113 vs 135 us on the 128x128 tile, two workgroups per CU (tools/conv_variants.py --tail)
+        if (p.x2 && tiles < 512) return 1;
         if (tiles >= 192) return p8_supports(p) && force < 0 ? 7 : 2;
     }
     return 1;
@@ -734,6 +737,23 @@ extern "C" int mhe_conv_tile(const mhe_conv_desc *d) {
     p.force = d->tile - 1;
     const int bke = d->dtype == MHE_F32 ? 32 : 64;
     p.Kpad = (d->KH * d->KW * d->Cin + bke - 1) / bke * bke;
+    return conv::choose_tile(p, d->Cin % bke == 0, d->dtype == MHE_BF16);
+}
+
+// the same for an operand-load form: 1 = producer BatchNorm on load (mhe_conv2d_nhwc with in_scale), 2 = residual-block tail
+// (mhe_conv1x1_residual_in_nhwc); 0 = plain (mhe_conv_tile)
+extern "C" int mhe_conv_tile_mode(const mhe_conv_desc *d, int mode) {
+    if (!d || mode < 0 || mode > 2) return -1;
+    static const float dummy = 0.f;
+    conv::Params p{};
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
+    const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+    p.M = d->B * Ho * Wo;
+    p.force = d->tile - 1;
+    const int bke = d->dtype == MHE_F32 ? 32 : 64;
+    p.Kpad = (d->KH * d->KW * d->Cin + bke - 1) / bke * bke;
+    if (mode >= 1) p.in_scale = &dummy;
+    if (mode == 2) p.x2 = &dummy;
     return conv::choose_tile(p, d->Cin % bke == 0, d->dtype == MHE_BF16);
 }
 

@@ -51,9 +51,7 @@ _TILES = {0: "128, 64, 2, 2", 1: "128, 128, 2, 2", 2: "256, 256, 2, 4", 3: "256,
 def _conv_kernel_name(d, dt, mode):
     """the template instantiation the launcher will pick, spelled as rocprofv3 prints it"""
     bke = 32 if dt == torch.float32 else 64
-    tile = _lib.lib().mhe_conv_tile(C.byref(d))
-    if tile == 7 and mode != 0:
-        tile = 2
+    tile = _lib.lib().mhe_conv_tile_mode(C.byref(d), mode)
     if tile == 7:
         return "mhe::conv::conv_p8_kernel<false, %s, 0>" % ("false" if d.KH == 1 and d.KW == 1 and d.pad == 0 else "true")
     return "mhe::conv::conv_kernel<%s, %s, %s, %d, false>" % ("float" if dt == torch.float32 else "unsigned short",

@@ -85,10 +85,12 @@ class ResNetTrunk(nn.Module):
         # cheaper in both dtypes (bf16 15.2 -> 13.6 ms, f32 38.9 -> 35.7 ms per C2 step); "load" stays selectable.
         import os
         self.bn_apply = os.environ.get("MHE_BN_APPLY", "pass")
-        # the 1x1 conv3 of a bottleneck reads its operand exactly once per output-channel tile: there the on-load form
-        # saves the in-place pass over y2 without the 9-tap repetition a 3x3 consumer would pay - measured equal on
-        # MI355X (C2 bf16 step 10.03 ms on-load vs 10.06 ms in-place), so the simpler in-place pass stays the default
-        self.bn_apply_1x1 = os.environ.get("MHE_BN_APPLY_1X1", "pass")
+        # the 1x1 conv3 of a bottleneck reads its operand exactly once per output-channel tile: there the on-load form saves the
+        # in-place pass over y2 without the 9-tap repetition a 3x3 consumer would pay, but its register-staged main loop is 12-14 us
+        # per launch behind the LDS-DMA kernel the in-place form can use.  Measured per layer at C2 (tools/conv_variants.py
+        # --bn-load): the saved pass is worth 56 / 28 / 14 / 7 us on layer1..4 -> "auto" = on load where the bottleneck is <= 128
+        # wide (layer1, layer2), in place on layer3 / layer4 (C2 bf16 forward 9.19 ms all in place, 9.02 all on load)
+        self.bn_apply_1x1 = os.environ.get("MHE_BN_APPLY_1X1", "auto")
         # evaluate relu(bn3(conv3) + identity) inside the next block's conv1 (one read of the block output saved)
         self.fuse_tail = os.environ.get("MHE_FUSE_TAIL", "1") == "1"
 
@@ -155,7 +157,8 @@ class ResNetTrunk(nn.Module):
                 else:
                     y1, a1 = self._conv_bn(a, blk.conv1, blk.bn1, pool)
                 y2, a2 = self._conv_bn(y1, blk.conv2, blk.bn2, pool, a1, blk.stride, 1, 3)
-                yl, al = self._conv_bn(y2, blk.conv3, blk.bn3, pool, a2, apply=self.bn_apply_1x1)
+                ap3 = self.bn_apply_1x1 if self.bn_apply_1x1 != "auto" else ("load" if blk.conv3.in_channels <= 128 else "pass")
+                yl, al = self._conv_bn(y2, blk.conv3, blk.bn3, pool, a2, apply=ap3)
             else:
                 y1, a1 = self._conv_bn(a, blk.conv1, blk.bn1, pool, None, blk.stride, 1, 3)
                 yl, al = self._conv_bn(y1, blk.conv2, blk.bn2, pool, a1, 1, 1, 3)

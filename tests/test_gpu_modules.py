@@ -118,7 +118,7 @@ def test_resnet_trunk_matches_oracle(gpu_lib, arch, B, S, training, mode):
     sdn = synth.resnet_state(3, arch)
     x, _ = synth.batch(3, B, image_size=S)
     trunk = resnet.ResNetTrunk(arch)
-    trunk.bn_apply = mode.split("+")[0]
+    trunk.bn_apply = trunk.bn_apply_1x1 = mode.split("+")[0]
     trunk.fuse_tail = mode.endswith("fused-tail")
     trunk.load_state_dict({k: torch.as_tensor(v) for k, v in sdn.items()})
     trunk = trunk.cuda().train(training)
@@ -149,7 +149,7 @@ def test_resnet_trunk_bf16_storage_mode(gpu_lib, arch, bn_apply, monkeypatch):
     sd = {k: torch.as_tensor(v) for k, v in sdn.items()}
     x, _ = synth.batch(4, B, image_size=S)
     trunk = resnet.ResNetTrunk(arch, compute_dtype=torch.bfloat16)
-    trunk.bn_apply = bn_apply
+    trunk.bn_apply = trunk.bn_apply_1x1 = bn_apply
     trunk.load_state_dict(sd)
     trunk = trunk.cuda().train()
     taps, orig = [], ops.bn_act
