@@ -208,6 +208,16 @@ int mhe_conv2d_masked_nhwc(const mhe_conv_desc *d, const void *x, const void *w,
                            const void *bn_y1, const float *bn_mean_invstd1, float *bn_stats1, void *stream);
 int mhe_conv_stat_shards(void);
 /* kernel variant the launcher picks for a geometry with plain operands (numbering of mhe_conv_desc.tile, minus 1) */
+/* Data gradient of a 3x3 / stride 2 / pad 1 convolution (reference: torchvision Bottleneck.conv2 of layer2-4's first block, reached
+ * through hand/network.py:54-61) WITHOUT zero-dilating gy: the four output parity classes (2i+py, 2j+px) are four small
+ * convolutions of gy [B,Ho,Wo,Cout] with (1+py) x (1+px) taps each (9 taps over 4 pixels instead of 36), written straight to
+ * their strided positions of dx [B,2Ho,2Wo,Cin].  w4[2*py+px] = packed [Cin][(th, tw, co)] with forward taps kh = 1 (py = 0) or
+ * kh = 2, 0 for th = 0, 1 (py = 1), likewise kw.  residual / mask / bn_* as mhe_conv2d_masked_nhwc, all shaped like dx
+ * (mask may be NULL: no gate, no BatchNorm-reverse sums). */
+int mhe_conv3x3s2_dgrad_nhwc(int B, int Ho, int Wo, int Cout, int Cin, int dtype, const void *gy, const void *const *w4,
+                             void *dx, const void *residual, const void *mask, const void *bn_y0,
+                             const float *bn_mean_invstd0, float *bn_stats0, const void *bn_y1,
+                             const float *bn_mean_invstd1, float *bn_stats1, int tile /* mhe_conv_desc.tile */, void *stream);
 int mhe_conv_tile(const mhe_conv_desc *d);
 /* the same for an operand-load form: mode 1 = producer BatchNorm on load, 2 = residual-block tail, 0 = plain operands */
 int mhe_conv_tile_mode(const mhe_conv_desc *d, int mode);

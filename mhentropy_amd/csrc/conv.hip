@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_kerne
         cur ^= 1;
     }
 
-    epilogue<T, BM, BN, WM, WN, DG>(p, acc, lds, mtile % NSH, n0, [&](int row) { const int m = m0 + row; return m < p.M ? (long)m : -1l; });
+    epilogue<T, BM, BN, WM, WN, DG>(p, acc, lds, mtile % NSH, n0, [&](int row) { return out_pixel(p, m0 + row); });
 }
 
 // ---------------------------------------------------------------------------
@@ -648,7 +648,7 @@ static inline int elem_chunk(int dtype) { return dtype == MHE_F32 ? 4 : 8; }
 static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
                       const float *in_shift, const float *out_scale, const float *out_shift, const void *residual,
                       float *stats, const void *x2, const float *x2_scale, const float *x2_shift, void *a_out, void *stream,
-                      const void *mask = nullptr, const struct BnRev *bn = nullptr, float *y32 = nullptr);
+                      const void *mask = nullptr, const struct BnRev *bn = nullptr, float *y32 = nullptr, const int *scatter = nullptr);
 struct BnRev { const void *y[2]; const float *mi[2]; float *stats[2]; };
 
 extern "C" int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
@@ -683,10 +683,30 @@ extern "C" int mhe_conv2d_masked_nhwc(const mhe_conv_desc *d, const void *x, con
     return conv_entry(d, x, w, y, nullptr, nullptr, nullptr, nullptr, residual, nullptr, nullptr, nullptr, nullptr, nullptr, stream, mask, &bn);
 }
 
+extern "C" int mhe_conv3x3s2_dgrad_nhwc(int B, int Ho, int Wo, int Cout, int Cin, int dtype, const void *gy, const void *const *w4,
+                                        void *dx, const void *residual, const void *mask, const void *bn_y0,
+                                        const float *bn_mean_invstd0, float *bn_stats0, const void *bn_y1,
+                                        const float *bn_mean_invstd1, float *bn_stats1, int tile, void *stream) {
+    MHE_REQUIRE(gy && w4 && dx && w4[0] && w4[1] && w4[2] && w4[3], "mhe_conv3x3s2_dgrad_nhwc: null pointer");
+    MHE_REQUIRE((!bn_y0 || (bn_mean_invstd0 && bn_stats0 && mask)) && (!bn_y1 || (bn_y0 && bn_mean_invstd1 && bn_stats1)),
+                "mhe_conv3x3s2_dgrad_nhwc: each bn_y needs its mean_invstd and stats (and the gate)");
+    const BnRev bn = {{bn_y0, bn_y1}, {bn_mean_invstd0, bn_mean_invstd1}, {bn_stats0, bn_stats1}};
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            // output rows 2i + py: py = 0 sees forward tap kh = 1 at gy row i; py = 1 sees kh = 2 at row i and kh = 0 at row i + 1
+            mhe_conv_desc d = {B, Ho, Wo, Cout, Cin, 1 + py, 1 + px, 1, 0, dtype, 0, 0, tile};
+            const int sc[2] = {py, px};
+            const int rc = conv_entry(&d, gy, w4[2 * py + px], dx, nullptr, nullptr, nullptr, nullptr, residual, nullptr, nullptr, nullptr,
+                                      nullptr, nullptr, stream, mask, mask ? &bn : nullptr, nullptr, sc);
+            if (rc) return rc;
+        }
+    return MHE_OK;
+}
+
 static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
                       const float *in_shift, const float *out_scale, const float *out_shift, const void *residual,
                       float *stats, const void *x2, const float *x2_scale, const float *x2_shift, void *a_out, void *stream,
-                      const void *mask, const BnRev *bn, float *y32) {
+                      const void *mask, const BnRev *bn, float *y32, const int *scatter) {
     MHE_REQUIRE(d && x && w && (y || y32), "mhe_conv2d_nhwc: null pointer");
     MHE_REQUIRE(d->dtype == MHE_F32 || d->dtype == MHE_BF16, "mhe_conv2d_nhwc: dtype=%d", d->dtype);
     const int ce = elem_chunk(d->dtype), bke = 8 * ce;
@@ -705,6 +725,10 @@ static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void
     p.stride = d->stride; p.pad = d->pad;
     p.Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
     p.Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+    p.os2 = 0; p.os_py = p.os_px = 0;
+    if (scatter) {     // parity class of a stride-2 data gradient: one output per input position (reads past the edge give zeros)
+        p.Ho = d->H; p.Wo = d->W; p.os2 = 1; p.os_py = scatter[0]; p.os_px = scatter[1];
+    }
     MHE_REQUIRE(p.Ho > 0 && p.Wo > 0, "mhe_conv2d_nhwc: empty output");
     const long long M = (long long)p.B * p.Ho * p.Wo;
     MHE_REQUIRE(M < (1ll << 31), "mhe_conv2d_nhwc: too many output pixels");

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(512) void conv_p8_kernel(const Params p) {
             for (int b = 0; b < 8; ++b) asm volatile("" :: "v"(acc[a][b]));
         return;
     }
-    epilogue<T, 256, 256, 2, 4, DG>(p, acc, lds, mtile % NSH, n0, [&](int row) { const int m = m0 + row; return m < p.M ? (long)m : -1l; });
+    epilogue<T, 256, 256, 2, 4, DG>(p, acc, lds, mtile % NSH, n0, [&](int row) { return out_pixel(p, m0 + row); });
 }
 
 // the geometry this kernel takes: bf16, Cin a multiple of the 64-deep K tile, at most 32 taps, operands below 2 GiB

@@ -22,7 +22,18 @@ struct Params {
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, M, Kpad, relu_in, relu_out;
     float *y32;            // optional f32 result of a bf16 convolution (plain + out_shift only), instead of y
     int force;             // mhe_conv_desc.tile - 1: kernel variant forced by the caller (tests / tuning), -1 = launcher's choice
+    // output scatter of the parity-split stride-2 data gradient: output pixel (b, i, j) of the [B, Ho, Wo] grid lands at
+    // (b, 2i + os_py, 2j + os_px) of a [B, 2Ho, 2Wo] tensor (y, residual, mask and bn_y are all addressed there)
+    int os2, os_py, os_px;
 };
+
+// tile row -> global output pixel index the epilogue addresses (or -1 outside the problem)
+__device__ __forceinline__ long out_pixel(const Params &p, int m) {
+    if (m >= p.M) return -1l;
+    if (!p.os2) return (long)m;
+    const int j = m % p.Wo, t = m / p.Wo, i = t % p.Ho, b = t / p.Ho;
+    return ((long)(b * 2 * p.Ho + 2 * i + p.os_py)) * (2 * p.Wo) + 2 * j + p.os_px;
+}
 
 constexpr int NSH = 64;          // statistic shards: block b adds into shard b % NSH
 constexpr int MAXC = 2048;       // largest Cin whose BatchNorm affine is staged in LDS

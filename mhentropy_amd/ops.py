@@ -305,6 +305,31 @@ def linear_bf16_f32out(x, w, bias=None, out=None):
     return y
 
 
+def conv3x3s2_dgrad(gy, w4, residual=None, mask=None, bn=None, tile=0):
+    """dx [B,2Ho,2Wo,Cin] of a 3x3 / stride-2 / pad-1 convolution from gy [B,Ho,Wo,Cout] by the four parity classes
+    (mhe_conv3x3s2_dgrad_nhwc); w4 = the four packed tap subsets (train.dgrad_s2_operand_indices)."""
+    B, Ho, Wo, Cout = gy.shape
+    dt = gy.dtype
+    Cin = w4[0].shape[0]
+    _chk(gy, dt, "dgrad_s2.gy")
+    for i, w in enumerate(w4):
+        _chk(w, dt, f"dgrad_s2.w{i}")
+    dx = torch.empty(B, 2 * Ho, 2 * Wo, Cin, device=gy.device, dtype=dt)
+    for t, name in ((residual, "residual"), (mask, "mask")):
+        if t is not None:
+            _chk(t, dt, "dgrad_s2." + name, dx.shape)
+    ext = []
+    for by, bmi, bst in (list(bn or []) + [(None, None, None)] * 2)[:2]:
+        if by is not None:
+            _chk(by, dt, "dgrad_s2.bn_y", dx.shape); _chk(bmi, torch.float32, "dgrad_s2.bn_mean_invstd", (2, Cin))
+            _chk(bst, torch.float32, "dgrad_s2.bn_stats", (stat_shards(), 2, Cin))
+        ext += [_ptr(by), _ptr(bmi), _ptr(bst)]
+    wp = (C.c_void_p * 4)(*[w.data_ptr() for w in w4])
+    check(_lib.lib().mhe_conv3x3s2_dgrad_nhwc(B, Ho, Wo, Cout, Cin, dtype_code(dt), _ptr(gy), wp, _ptr(dx), _ptr(residual), _ptr(mask), *ext, int(tile), _stream()),
+          "mhe_conv3x3s2_dgrad_nhwc")
+    return dx
+
+
 def conv1x1_residual_in(x, x2, w, in_scale, in_shift, x2_scale=None, x2_shift=None, a_out=None, stats=None, tile=0):
     """y = conv1x1(relu(x*in_scale+in_shift + (x2*x2_scale+x2_shift | x2))); optionally writes that operand to a_out."""
     B, H, W, Cin = x.shape

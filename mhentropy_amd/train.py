@@ -43,7 +43,22 @@ def dgrad_operand_index(idx):
     return idx.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, KH * KW * Cout)
 
 
-def conv_dgrad(gy, w_dg, k, stride, pad, H, W, residual=None, mask=None, bn=None):
+def dgrad_s2_operand_indices(idx):
+    """the four parity-class operands of a 3x3 / stride-2 / pad-1 convolution's data gradient (mhe_conv3x3s2_dgrad_nhwc) as index
+    tables into the torch weight [Cout,Cin,3,3]: class (py, px) -> [Cin][(th, tw, co)] with forward taps kh = (1,) for py = 0 and
+    (2, 0) for py = 1 (output row 2i+py reads gy rows i + th), likewise kw"""
+    Cout, Cin, KH, KW = idx.shape
+    assert KH == 3 and KW == 3
+    taps = ((1,), (2, 0))
+    out = []
+    for py in range(2):
+        for px in range(2):
+            sub = idx[:, :, list(taps[py])][:, :, :, list(taps[px])]            # [Cout, Cin, th, tw]
+            out.append(sub.permute(1, 2, 3, 0).reshape(Cin, len(taps[py]) * len(taps[px]) * Cout))
+    return out
+
+
+def conv_dgrad(gy, w_dg, k, stride, pad, H, W, residual=None, mask=None, bn=None, w_s2=None):
     """gradient of a k x k / stride / pad convolution w.r.t. its [B,H,W,Cin] input (+ residual), through the
     FORWARD implicit-GEMM kernel: stride 1 is a convolution of gy with the transposed, tap-flipped weights at
     padding k-1-pad; a stride-2 3x3 runs the same on the zero-dilated gy; a stride-2 1x1 is computed on the
@@ -53,6 +68,8 @@ def conv_dgrad(gy, w_dg, k, stride, pad, H, W, residual=None, mask=None, bn=None
         return ops.conv2d_nhwc(gy, w_dg, k, k, 1, k - 1 - pad, residual=residual, mask=mask, bn=bn)
     if stride != 2 or k not in (1, 3):
         raise NotImplementedError(f"conv_dgrad: k={k} stride={stride}")
+    if k == 3 and w_s2 is not None and pad == 1 and H == 2 * gy.shape[1] and W == 2 * gy.shape[2]:
+        return ops.conv3x3s2_dgrad(gy, w_s2, residual=residual, mask=mask, bn=bn)       # four parity classes, no zero-dilated copy
     if k == 3:
         return ops.conv2d_nhwc(ops.upsample2(gy, H, W), w_dg, 3, 3, 1, 1, residual=residual, mask=mask, bn=bn)
     if mask is not None:
@@ -257,6 +274,13 @@ class TrainStep:
                 d = torch.full((Cin, _ceil(kd, bke)), -1, dtype=torch.int64)
                 d[:, :kd] = dgrad_operand_index(idx)
                 u.w_dg = self._derived(d, T)
+                u.w_s2 = None
+                if KH == 3 and stride == 2 and pad == 1:
+                    u.w_s2 = []
+                    for tbl in dgrad_s2_operand_indices(idx):
+                        f2 = torch.full((Cin, _ceil(tbl.shape[1], bke)), -1, dtype=torch.int64)
+                        f2[:, :tbl.shape[1]] = tbl
+                        u.w_s2.append(self._derived(f2, T))
                 u.cin_w = Cin
             # raw weight gradient [Cout][KH*KW*cin_w]
             u.raw_w = self._raw_slot((Cout, KH * KW * u.cin_w))
@@ -508,7 +532,8 @@ class TrainStep:
             bn = [(c.y, c.mi, pool.take(c.cout)) for c in consumers]
             for c, (_, _, st) in zip(consumers, bn):
                 c.rev_stats = st
-        return conv_dgrad(gy, u.w_dg, u.k, u.stride, u.pad, u.x.shape[1], u.x.shape[2], residual, u.x if gate else None, bn)
+        return conv_dgrad(gy, u.w_dg, u.k, u.stride, u.pad, u.x.shape[1], u.x.shape[2], residual, u.x if gate else None, bn,
+                          w_s2=getattr(u, "w_s2", None))
 
     def _trunk_backward(self, g_f):
         pool = resnet._StatsPool(self.dev, channels=65536)

@@ -147,6 +147,50 @@ def test_conv_weight_and_data_gradients(gpu_lib, Cin, Cout, k, stride, pad, H, B
     gx = train.conv_dgrad(_nhwc(gy, dt), wd.to(dt).cuda().contiguous(), k, stride, pad, H, H, residual=_nhwc(res, dt))
     want = (x.grad + res).permute(0, 2, 3, 1)
     assert_close(gx.float().cpu(), want, 1e-4 if dt == torch.float32 else 1.5e-2, what="dX + residual")
+    if k == 3 and stride == 2:          # the parity-split form (no zero-dilated copy of gy): same result
+        w_s2 = []
+        for tb in train.dgrad_s2_operand_indices(idx):
+            f2 = torch.zeros(Cin, (tb.shape[1] + bke - 1) // bke * bke)
+            f2[:, :tb.shape[1]] = w.detach().reshape(-1)[tb]
+            w_s2.append(f2.to(dt).cuda().contiguous())
+        gx2 = train.conv_dgrad(_nhwc(gy, dt), None, k, stride, pad, H, H, residual=_nhwc(res, dt), w_s2=w_s2)
+        assert_close(gx2.float().cpu(), want, 1e-4 if dt == torch.float32 else 1.5e-2, what="dX + residual, parity classes")
+
+
+@pytest.mark.parametrize("tile", [0, 2, 3, 8])
+def test_stride2_dgrad_parity_classes_gate_and_bn_sums(gpu_lib, tile):
+    """mhe_conv3x3s2_dgrad_nhwc with the ReLU gate, residual and BatchNorm-reverse sums of the data-gradient epilogue, every output
+    written at its strided position: against the zero-dilated form through the same epilogue (train.conv_dgrad's old path) and
+    against autograd; tile forces the 128x128 / 256x256 register-staged kernels and the phase-pipelined one (partial tiles)"""
+    from mhentropy_amd import ops, train
+    import torch.nn.functional as F
+    dt, B, Cin, Cout, H = torch.bfloat16, 3, 128, 256, 24
+    g = torch.Generator().manual_seed(11)
+    x = torch.relu(torch.randn(B, Cin, H, H, generator=g)).to(dt).float().requires_grad_(True)        # post-ReLU input = the gate
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).to(dt).float()
+    y = F.conv2d(x, w, stride=2, padding=1)
+    gy = torch.randn(y.shape, generator=g).to(dt).float()
+    y.backward(gy)
+    res = torch.randn(B, Cin, H, H, generator=g).to(dt).float()
+    idx = torch.arange(w.numel()).view(w.shape)
+    pack = lambda tb: torch.nn.functional.pad(w.reshape(-1)[tb], (0, (-tb.shape[1]) % 64)).to(dt).cuda().contiguous()
+    w_s2 = [pack(tb) for tb in train.dgrad_s2_operand_indices(idx)]
+    wd = pack(train.dgrad_operand_index(idx))
+    bn_y = torch.randn(B, H, H, Cin, generator=g).to(dt).cuda()
+    mi = torch.stack([torch.randn(Cin, generator=g) * 0.1, torch.rand(Cin, generator=g) + 0.5]).cuda().contiguous()
+    st_new, st_old = (torch.zeros(ops.stat_shards(), 2, Cin, device="cuda") for _ in range(2))
+    mask = _nhwc(x.detach(), dt)
+    new = ops.conv3x3s2_dgrad(_nhwc(gy, dt), w_s2, residual=_nhwc(res, dt), mask=mask, bn=[(bn_y, mi, st_new)], tile=tile)
+    old = ops.conv2d_nhwc(ops.upsample2(_nhwc(gy, dt), H, H), wd, 3, 3, 1, 1, residual=_nhwc(res, dt), mask=mask, bn=[(bn_y, mi, st_old)])
+    want = ((x.grad + res) * (x.detach() > 0)).permute(0, 2, 3, 1)
+    assert_close(new.float().cpu(), want, 1.5e-2, what="gated dX + residual")
+    assert_close(new.float().cpu(), old.float().cpu(), 8e-3, what="parity classes vs zero-dilated form")      # both round to bf16 once
+    sn, so = st_new.sum(0).cpu(), st_old.sum(0).cpu()
+    gf = new.float().cpu().reshape(-1, Cin)
+    xh = (bn_y.float().cpu().reshape(-1, Cin) - mi[0].cpu()) * mi[1].cpu()
+    bound = lambda t: 5 * 2.0 ** -9 * t.pow(2).sum(0).sqrt() + 1e-4        # the kernel sums the values before their bf16 rounding
+    assert ((sn[0] - gf.sum(0)).abs() <= bound(gf)).all() and ((sn[1] - (gf * xh).sum(0)).abs() <= bound(gf * xh)).all()
+    assert ((sn - so).abs() <= 2 * torch.stack([bound(gf), bound(gf * xh)])).all()
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])

@@ -34,6 +34,30 @@ def test_dgrad_operand_index_gives_the_input_gradient(k, stride, pad):
     assert (gx - x.grad).abs().max() < 1e-10
 
 
+def test_parity_split_stride2_dgrad_tables():
+    """the four parity-class operands of a 3x3 / stride-2 / pad-1 data gradient (train.dgrad_s2_operand_indices, consumed by
+    mhe_conv3x3s2_dgrad_nhwc): output pixel (2i+py, 2j+px) = a (1+py) x (1+px)-tap convolution of gy, taps at offsets 0 / +1,
+    reads past the edge are zero - restated with torch convs and checked against autograd"""
+    g = torch.Generator().manual_seed(5)
+    Cin, Cout, H = 6, 5, 10
+    x = torch.randn(2, Cin, H, H, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g, dtype=torch.float64)
+    y = F.conv2d(x, w, stride=2, padding=1)
+    gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(gy)
+    tabs = train.dgrad_s2_operand_indices(torch.arange(w.numel()).view(w.shape))
+    gx = torch.zeros_like(x)
+    for py in range(2):
+        for px in range(2):
+            tb = tabs[2 * py + px]
+            wd = w.reshape(-1)[tb].view(Cin, 1 + py, 1 + px, Cout).permute(0, 3, 1, 2)      # torch conv weight [Cin, Cout, th, tw]
+            gp = F.pad(gy, (0, px, 0, py))                                              # zeros past the bottom / right edge
+            gx[:, :, py::2, px::2] = F.conv2d(gp, wd)
+    assert (gx - x.grad).abs().max() < 1e-10
+    used = torch.cat([t.reshape(-1) for t in tabs])
+    assert used.numel() == w.numel() and torch.equal(torch.sort(used)[0], torch.arange(w.numel()))      # every weight exactly once
+
+
 @pytest.mark.parametrize("bf16", [False, True])
 def test_flow_stream_table_reproduces_the_host_packer(bf16):
     """gathering [W0|W1|W2] through the table == running the host packer on the weights (the table is obtained by packing
