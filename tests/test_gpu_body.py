@@ -80,3 +80,43 @@ def test_body_flow_head_and_hypothesis_slices(gpu_lib):
     for lo, hi in ((0, 3), (3, 6)):
         part = head(feats, K, betas=betas, noise=noise, hyp_slice=(lo, hi))
         assert torch.equal(part["vertices"], full["vertices"][:, lo:hi]) and torch.equal(part["joints"], full["joints"][:, lo:hi])
+
+
+def test_c4_per_gpu_size_properties(gpu_lib):
+    """config C4 (BASELINE.json configs[3]: ProHMR body flow, global batch 1,024 x K = 128 on 8 GPUs -> B = 128 images per GPU,
+    R = 16,384 hypotheses; Glow features 144 / hidden 1,024 / 4 layers x 2 blocks / context 2,048; SMPL-sized body: 24 joints,
+    6,890 vertices).  No oracle at this size (the flow is parity-unpinned anyway): properties -
+    (i) density consistency: log_prob(sample) evaluated by the inverse pass equals the log-probability returned with the sample,
+        and the inverse pass recovers the noise;
+    (ii) a hypothesis whose 6D pose is the identity decodes to the shaped template (skinning with identity transforms);
+    (iii) hypothesis slices decode to exactly the rows of the full decode; everything finite."""
+    from mhentropy_amd import body
+    B, K = 128, 128
+    tables = body.synthetic_body_tables(4)
+    head = body.BodyFlowHead(tables)                                   # ProHMR sizes are the defaults
+    torch.manual_seed(7)
+    for p in head.flow.parameters():                                   # small random weights (the class initialises like nflows)
+        if p.dim() > 1:
+            torch.nn.init.normal_(p, 0, 0.3 / p.shape[1] ** 0.5)
+    head = head.cuda().eval()
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    feats = torch.randn(B, 2048, device="cuda", generator=gen) * 0.5
+    noise = torch.randn(B, K, 144, device="cuda", generator=gen)
+    betas = torch.randn(B, 10, device="cuda", generator=gen)
+    full = head(feats, K, betas=betas, noise=noise)
+    assert full["vertices"].shape == (B, K, 6890, 3) and full["joints"].shape == (B, K, 24, 3)
+    for k in ("pose6d", "log_prob", "vertices", "joints"):
+        assert torch.isfinite(full[k]).all(), k
+    # (i) rows of log_prob are sample-major with B context rows: row r = n*B + b
+    x_sm = full["pose6d"].permute(1, 0, 2).reshape(K * B, 144).contiguous()
+    lp, z = head.flow.log_prob(x_sm, context=feats)
+    assert_close(lp.view(K, B).t().cpu(), full["log_prob"].cpu(), 2e-3, what="log_prob(sample) == log-prob of the sampling pass")
+    assert_close(z.view(K, B, 144).permute(1, 0, 2).cpu(), noise.cpu(), 2e-2, what="inverse pass recovers the noise (bf16 hidden products)")
+    # (ii) identity pose -> shaped template
+    eye6 = torch.tensor([1., 0, 0, 0, 1, 0], device="cuda").repeat(24)
+    rest = head.body(betas[:4].contiguous(), pose6d=eye6.repeat(4, 1).contiguous())
+    tpl = torch.as_tensor(tables["v_template"]).cuda() + torch.einsum("vck,bk->bvc", torch.as_tensor(tables["shapedirs"]).cuda().float(), betas[:4])
+    assert_close(rest["vertices"].cpu(), tpl.cpu(), 1e-5, what="identity pose = shaped template")
+    # (iii) a 1/8 hypothesis slice (what one of 8 hypothesis-sharded ranks decodes)
+    part = head(feats, K, betas=betas, noise=noise, hyp_slice=(32, 48))
+    assert torch.equal(part["vertices"], full["vertices"][:, 32:48]) and torch.equal(part["joints"], full["joints"][:, 32:48])
