@@ -202,3 +202,65 @@ def glow_state(seed=0, features=45, hidden=512, num_layers=4, num_blocks=2, cont
         sd[p + "final_layer.weight"], sd[p + "final_layer.bias"] = w * 0.2, bb * 0.2
         mask = -mask
     return sd
+
+
+def ho3d_sample(seed=0, offset=(0.0, 0.0), n_obj=1200):
+    """A synthetic DECODED HO3D sample (what imageio / cv2 / pickle hand to hand/dataloader/ho3d_dataloader.py:279-291): random RGB
+    frame, 3-channel depth PNG as cv2.imread returns it (BGR: value = R + 256 G), a 120x160 segmentation whose hand / object
+    channels cover the projected hand / object, 21 hand joints and a 778-vertex cloud in OpenGL camera coordinates (metres, z < 0),
+    intrinsics, an object pose and its vertices.  offset moves the hand in the image (towards a border: padded crops)."""
+    rng = np.random.default_rng(seed + 7000)
+    f32 = lambda a: np.asarray(a, np.float32)
+    cam = f32([[617.3, 0, 312.4], [0, 617.1, 241.4], [0, 0, 1]])
+    z = -rng.uniform(0.45, 0.65)
+    centre = np.array([offset[0] * -z / 617.0, -offset[1] * -z / 617.0, z])
+    joints = f32(centre + rng.normal(0, 0.035, (21, 3)) * [1, 1, 0.4])
+    mesh = f32(joints[rng.integers(0, 21, 778)] + rng.normal(0, 0.008, (778, 3)))
+    obj_verts = f32(rng.uniform(-0.06, 0.06, (n_obj, 3)))
+    obj_rot = f32(rng.normal(0, 0.8, 3))
+    obj_trans = f32(centre + rng.normal(0, 0.03, 3) * [1, 1, 0.3])
+    image = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    # projected hand / object blobs (same projection as the reference: flip y, z then pinhole)
+    def proj(p):
+        q = p * [1, -1, -1]
+        return np.stack([q[:, 0] * 617.3 / q[:, 2] + 312.4, q[:, 1] * 617.1 / q[:, 2] + 241.4], 1), q[:, 2]
+    seg = np.zeros((120, 160, 3), np.uint8)
+    depth_m = np.full((480, 640), 1.2)
+    uv_h, z_h = proj(mesh)
+    for (u, v), zz in zip(uv_h[::3], z_h[::3]):
+        if rng.random() < 0.8:
+            a, b = int(v) // 4, int(u) // 4
+            seg[max(a - 1, 0):a + 2, max(b - 1, 0):b + 2, 2] = 255
+            depth_m[max(int(v) - 6, 0):int(v) + 7, max(int(u) - 6, 0):int(u) + 7] = zz + rng.choice([-0.004, 0.0, 0.06])
+    R = _rodrigues(obj_rot)
+    uv_o, _ = proj((obj_verts @ R.T + obj_trans)[::7])
+    for u, v in uv_o:
+        a, b = int(v) // 4, int(u) // 4
+        if 0 <= a < 120 and 0 <= b < 160:
+            seg[a, b, 1] = 230
+    d16 = np.clip(np.round(depth_m / 0.00012498664727900177), 0, 65535).astype(np.uint16)
+    depth_png = np.zeros((480, 640, 3), np.uint8)
+    depth_png[:, :, 2], depth_png[:, :, 1] = d16 & 255, d16 >> 8
+    return {"image": image, "depth_png": depth_png, "seg": seg, "joints3d": joints, "mesh": mesh, "cam": cam, "obj_rot": obj_rot,
+            "obj_trans": obj_trans, "obj_verts": obj_verts}
+
+
+def _rodrigues(r):
+    th = float(np.linalg.norm(r))
+    if th < 1e-12:
+        return np.eye(3)
+    k = np.asarray(r, np.float64) / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.cos(th) * np.eye(3) + (1 - np.cos(th)) * np.outer(k, k) + np.sin(th) * K
+
+
+def ho3d_aug_params(seed):
+    """the random draws of the reference's augmentation in its own order and distributions (ho3d_dataloader.py:162-176,191-194):
+    three colour factors U(0.6, 1.4), scale U(0.8, 1), angle 2 pi U(0, 1), translations N(0, 10) clipped to +-40"""
+    rs = np.random.RandomState(seed)
+    pn = rs.uniform(0.6, 1.4, 3)
+    scale = rs.uniform(low=0.8, high=1.0)
+    angle = 2 * np.pi * rs.rand(1)[0]
+    tx = np.maximum(np.minimum(rs.normal(0.0, 10.0), 40.0), -40.0)
+    ty = np.maximum(np.minimum(rs.normal(0.0, 10.0), 40.0), -40.0)
+    return {"pn": pn, "scale": float(scale), "angle": float(angle), "tx": float(tx), "ty": float(ty)}

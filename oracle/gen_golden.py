@@ -362,6 +362,82 @@ def gen_rot6d():
                         grad_poses=pr.grad.numpy())
 
 
+HO3D_CASES = [(0, (0, 0), False), (0, (0, 0), True), (1, (250, -180), False), (1, (250, -180), True), (2, (-280, 200), True),
+              (3, (120, 60), True)]
+
+
+def gen_ho3d():
+    """row f4: the reference's `Generate_ho3d_uv.__getitem__` (hand/dataloader/ho3d_dataloader.py:272-459) on synthetic decoded
+    samples.  The module is imported from a scratch directory holding the (empty) dataset directories its import-time checks look
+    for; its file readers are pointed at the synthetic arrays, and the OpenCV / torchvision calls it makes are served by the
+    restatements of oracle/ho3d_ref.py (those primitives stay unpinned; the reference's own logic around them is what is pinned)."""
+    import tempfile
+    from oracle import ho3d_ref
+    scratch = tempfile.mkdtemp(prefix="ho3d_ref_")
+    for d in ("datasets/HO3D_v3/HO3D_v3", "datasets/HO3D_v3/models", "datasets/HO3D_v3/HO3D/data"):
+        os.makedirs(os.path.join(scratch, d))
+    for name in ("imageio", "torchvision.transforms", "torchvision.transforms.functional", "easydict", "yacs", "yacs.config", "tensorboardX",
+                 "skimage", "skimage.transform"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    tvt = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision"].transforms = tvt
+    tvt.functional = sys.modules["torchvision.transforms.functional"]
+    tvt.functional.erase = None
+    cwd = os.getcwd()
+    os.chdir(scratch)
+    try:
+        import dataloader.ho3d_dataloader as hd                 # reference module
+    finally:
+        os.chdir(cwd)
+    cv = hd.cv2
+    cv.INTER_NEAREST, cv.BORDER_CONSTANT = 0, 0
+    cv.resize = lambda img, dsize, interpolation=None: ho3d_ref.resize_nearest(img, dsize)
+    cv.Rodrigues = lambda r: (ho3d_ref.rodrigues(r), None)
+    cv.copyMakeBorder = lambda img, t, b, l, r, kind, value=None: ho3d_ref.copy_make_border(img, t, b, l, r, value)
+    cv.getRotationMatrix2D = ho3d_ref.get_rotation_matrix_2d
+    cv.warpAffine = lambda img, M, dsize, flags=None, borderValue=0.0: ho3d_ref.warp_affine_nearest(img, M, dsize)
+
+    class _Compose:
+        def __init__(self, transforms): self.transforms = transforms
+        def __call__(self, x):
+            for t in self.transforms: x = t(x)
+            return x
+    tvt.Compose = hd.torchvision.transforms.Compose = _Compose
+    tvt.ToPILImage = lambda: (lambda a: a)
+    tvt.ToTensor = lambda: (lambda a: torch.from_numpy(a.astype(np.float32).transpose(2, 0, 1) / np.float32(255)))
+    tvt.Normalize = lambda m, s: (lambda t: (t - torch.tensor(m, dtype=torch.float32)[:, None, None]) / torch.tensor(s, dtype=torch.float32)[:, None, None])
+    cur = {}
+    hd.imageio.imread = lambda fn: cur["s"]["seg"] if fn.endswith(".png") else cur["s"]["image"]
+    hd.read_depth_img = lambda *a: ho3d_ref.decode_depth(cur["s"]["depth_png"])
+    hd.read_annotation = lambda *a: {"objName": "obj", "objRot": cur["s"]["obj_rot"], "objTrans": cur["s"]["obj_trans"], "camMat": cur["s"]["cam"]}
+    for ci, (seed, off, aug) in enumerate(HO3D_CASES):
+        smp = synth.ho3d_sample(seed, off)
+        cur["s"] = smp
+        ds = object.__new__(hd.Generate_ho3d_uv)
+        ds.train_file, ds.baseDir, ds.model = np.array(["SEQ/0000"]), "", "train"
+        ds.handJoints3D, ds.handMesh = smp["joints3d"][None], smp["mesh"][None]
+        ds.objmesh_all = {"obj": {"v": smp["obj_verts"], "vn": smp["obj_verts"]}}
+        ds.dpda, ds.aug, ds.joint_idx = "HO3D", aug, "RHD"
+        np.random.seed(100 + seed)
+        img, tgt = ds[0]
+        prm = synth.ho3d_aug_params(100 + seed) if aug else None
+        oimg, ot = ho3d_ref.getitem(smp, prm)
+        _close(f"ho3d[{ci}] image", torch.as_tensor(oimg), img, 0, 0)
+        for k in ("crop_uv", "vis", "depth", "original_pose3d", "verts", "pose3d", "st", "scale", "crop_center", "crop_size", "pose3d_root",
+                  "camera", "rot_mat_inv", "_rot_mat", "uvd"):
+            _close(f"ho3d[{ci}] {k}", torch.as_tensor(ot[k]), tgt[k].reshape(ot[k].shape), 1e-6, 1e-6)
+        for k in ("hand_mask", "object_mask"):
+            assert np.array_equal(ot[k], tgt[k].numpy()), k
+        u8 = np.rint((img.numpy() * 0.5 + 0.5) * 255).astype(np.uint8)
+        out = {k: np.asarray(tgt[k]) for k in ("crop_uv", "vis", "original_pose3d", "pose3d", "st", "scale", "crop_center", "crop_size", "pose3d_root",
+                                               "rot_mat_inv", "_rot_mat", "uvd")}
+        out.update(seed=seed, offset=np.asarray(off), aug=int(aug), aug_seed=100 + seed, image_u8_sub=u8[:, ::4, ::4], image_u8_sum=u8.astype(np.int64).sum((1, 2)),
+                   hand_mask=np.packbits(tgt["hand_mask"].numpy()), object_mask=np.packbits(tgt["object_mask"].numpy()),
+                   depth_sub=tgt["depth"].numpy()[::4, ::4], depth_sum=np.float64(tgt["depth"].numpy().astype(np.float64).sum()),
+                   verts_sum=np.float64(tgt["verts"].numpy().astype(np.float64).sum()))
+        np.savez_compressed(os.path.join(GOLD, f"ho3d_{ci}.npz"), **out)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     tables = synth.mano_tables(0)
@@ -382,6 +458,7 @@ def main():
     gen_mhent(network, criteria, tables, "shipped", 22, 512, 6, 3, (16,))
     gen_priors(network, tables)
     gen_rot6d()
+    gen_ho3d()
     print("golden fixtures written to", GOLD)
 
 

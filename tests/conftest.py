@@ -35,3 +35,21 @@ def gpu_lib():
         pytest.skip("no GPU")
     from mhentropy_amd import _lib
     return _lib.lib()
+
+
+def check_ho3d_against_fixture(img, tgt, g, what, img_tol=0, tol=1e-6):
+    """one sample of the HO3D pipeline (image [3,256,256] f32 in [-1,1], target dict of arrays) against a reference-generated fixture
+    tests/golden/ho3d_*.npz: pixels / masks bit-exact (integer work), floating-point targets to `tol` of their scale"""
+    u8 = np.rint((np.asarray(img, np.float64) * 0.5 + 0.5) * 255).astype(np.int64)
+    assert np.abs(u8[:, ::4, ::4] - g["image_u8_sub"]).max() <= img_tol, what + ": image pixels"
+    assert np.array_equal(u8.sum((1, 2)), g["image_u8_sum"]) or img_tol, what + ": image checksum"
+    for k in ("hand_mask", "object_mask"):
+        assert np.array_equal(np.packbits(np.asarray(tgt[k]).astype(bool)), g[k]), what + ": " + k
+    d = np.asarray(tgt["depth"], np.float32)
+    assert_close(d[::4, ::4], g["depth_sub"], 1e-6, what=what + ": depth")
+    assert abs(float(d.astype(np.float64).sum()) - float(g["depth_sum"])) <= 1e-5 * abs(float(g["depth_sum"])) + 1e-6, what + ": depth checksum"
+    assert np.array_equal(np.asarray(tgt["vis"]).reshape(-1), g["vis"].reshape(-1)), what + ": vis"
+    for k in ("crop_uv", "original_pose3d", "pose3d", "st", "scale", "crop_center", "crop_size", "pose3d_root", "rot_mat_inv", "_rot_mat", "uvd"):
+        assert_close(np.asarray(tgt[k]).reshape(g[k].shape), g[k], tol, 1e-7, what=what + ": " + k)
+    v = np.asarray(tgt["verts"], np.float64).sum()
+    assert abs(v - float(g["verts_sum"])) <= 1e-5 * abs(float(g["verts_sum"])) + 1e-3, what + ": verts checksum"

@@ -132,3 +132,17 @@ def test_body_lbs_oracle_at_mano_size_is_the_pinned_hand_forward():
     verts, joints = body_ref.lbs(bt, rots, beta)
     centre = joints[:, mano_ref.JOINT_REORDER[9]].unsqueeze(1)             # manolayer.py:262-266
     assert_close((verts - centre) * 1000, g["mesh"], 1e-6, what="mesh")
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_ho3d_pipeline_oracle_matches_reference_fixtures(case):
+    """row f4: oracle/ho3d_ref.getitem against what the reference's own Generate_ho3d_uv.__getitem__ returned on the same synthetic
+    decoded sample and the same random draws (fixtures by oracle/gen_golden.py:gen_ho3d; crops inside and across the image
+    border, with and without augmentation)"""
+    from conftest import check_ho3d_against_fixture
+    from oracle import ho3d_ref
+    g = load_golden(f"ho3d_{case}")
+    smp = synth.ho3d_sample(int(g["seed"]), tuple(float(v) for v in g["offset"]))
+    prm = synth.ho3d_aug_params(int(g["aug_seed"])) if int(g["aug"]) else None
+    img, tgt = ho3d_ref.getitem(smp, prm)
+    check_ho3d_against_fixture(img, tgt, g, f"ho3d case {case}")
