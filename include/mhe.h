@@ -117,6 +117,25 @@ int mhe_flow_couplings_bf16_emit(const float *in, float *out, const float *cond,
                                  int R, int B, int dim, int hidden, int ncoup, int direction,
                                  void *stream);
 
+/* HO3D input pipeline from the decoded arrays on (reference: hand/dataloader/ho3d_dataloader.py:272-459 `__getitem__`, helpers
+ * :32-199, `compute_st` hand/dataloader/rhddataloader.py:237-269), batched.  mhe_ho3d_targets: one workgroup per sample - projection,
+ * hand / object boxes -> crop window, crop uv, both visibility passes, normalised pose, augmentation bookkeeping, RHD joint order,
+ * compute_st; writes per-sample geometry (mhe_ho3d_geom_doubles() doubles: crop window, inverse affine map, flag) for
+ * mhe_ho3d_images: one thread per output pixel - OpenCV-style fixed-point inverse affine (INTER_NEAREST), crop + nearest resize,
+ * border fill, colour noise, ToTensor + Normalize(0.5, 0.5); hand / object masks, depth crop.
+ * image u8 [B,480,640,3]; depth_png u8 [B,480,640,3] (BGR, value = R + 256 G); seg u8 [B,120,160,3]; joints3d [B,21,3], mesh
+ * [B,778,3] metres (OpenGL camera frame); cam [B,3,3]; obj_verts [B,NVmax,3] + obj_count [B]; aug [B,7] float64 = colour x3, scale,
+ * angle, tx, ty (the reference's np.random draws) or NULL (evaluation).  Outputs in the reference's target layout (RHD joint order). */
+int mhe_ho3d_geom_doubles(void);
+int mhe_ho3d_targets(const float *joints3d, const float *mesh, const float *cam, const float *obj_rot, const float *obj_trans,
+                     const float *obj_verts, const int *obj_count, int NVmax, const unsigned char *seg, const unsigned char *depth_png,
+                     const double *aug, float *crop_uv, float *vis, float *original_pose3d, float *verts, float *pose3d, float *st,
+                     float *scale, float *crop_center, float *crop_size, float *pose3d_root, float *rot_mat_inv, float *rot_mat, float *uvd,
+                     float *object_verts /* [B,NVmax,3] or NULL */, double *geom, int B, void *stream);
+int mhe_ho3d_images(const unsigned char *image, const unsigned char *seg, const unsigned char *depth_png, const double *geom,
+                    const double *aug, float *image_out /* [B,3,256,256] */, unsigned char *hand_mask /* [B,256,256] */,
+                    unsigned char *object_mask, float *depth_out, int B, void *stream);
+
 /* MANO decode + likelihood ------------------------------------------------- */
 
 /* Number of floats of the packed MANO table blob (layout: mhentropy_amd/mano_pack.py). */

@@ -79,6 +79,9 @@ SIGNATURES = {
     "mhe_conv2d_f32out_nhwc": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p]),
     "mhe_conv_stat_shards": (_i, []),
     "mhe_conv3x3s2_dgrad_nhwc": (_i, [_i, _i, _i, _i, _i, _i, _p, C.POINTER(C.c_void_p), _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
+    "mhe_ho3d_geom_doubles": (_i, []),
+    "mhe_ho3d_targets": (_i, [_p] * 7 + [_i] + [_p] * 18 + [_i, _p]),
+    "mhe_ho3d_images": (_i, [_p] * 9 + [_i, _p]),
     "mhe_conv_tile": (_i, [C.POINTER(ConvDesc)]),
     "mhe_conv_tile_mode": (_i, [C.POINTER(ConvDesc), _i]),
     "mhe_conv1x1_residual_in_nhwc": (_i, [C.POINTER(ConvDesc)] + [_p] * 11),
