@@ -38,6 +38,10 @@ def main(argv=None):
                                               "override the flags above (backbone, h_dims, num_steps, batch_size, lr, milestones, test_samples)")
     ap.add_argument("--load", default="", help="checkpoint in the reference's container format to start from (training.pth)")
     ap.add_argument("--scalars", default="", help="write the reference's TensorBoard scalars here as JSON lines (rank 0)")
+    ap.add_argument("--input-pipeline", action="store_true",
+                    help="feed the step from DECODED synthetic HO3D samples through the GPU input pipeline (ho3d_dataloader.HO3DBatchPipeline: "
+                         "crop, augmentation, visibility, compute_st; hand/dataloader/ho3d_dataloader.py:272-459) instead of ready-made batches; "
+                         "image size is then 256")
     args = ap.parse_args(argv)
     cfg = None
     if args.cfg:
@@ -68,15 +72,25 @@ def main(argv=None):
     criterion = MHEntLoss()
     meters = {"loss": harness.AverageMeter(), "epe3d": harness.AverageMeter(), "epe2d": harness.AverageMeter()}
     step, log = 0, []
+    if args.input_pipeline:
+        import numpy as np
+        from . import ho3d_dataloader as hd
+        pipe = hd.HO3DBatchPipeline()
+        pool = [synth.ho3d_sample(args.seed + 50 * rank + i, ((i * 37) % 400 - 200, (i * 53) % 300 - 150)) for i in range(8)]
+        aug_rng = np.random.RandomState(args.seed + rank)
     for epoch in range(args.epochs):
         trainer.lr = harness.multistep_lr(args.lr, epoch, tuple(args.milestones))
         for m in meters.values():
             m.reset()
         t0 = time.time()
         for it in range(args.iters):
-            xn, yn = synth.batch(args.seed + 1000 * rank + step, args.batch, image_size=args.image_size)
-            x = torch.as_tensor(xn).cuda()
-            y = {k: torch.as_tensor(v).cuda() for k, v in yn.items()}
+            if args.input_pipeline:
+                order = aug_rng.randint(0, len(pool), args.batch)
+                x, y = pipe(hd.collate_decoded([pool[i] for i in order]), aug=hd.draw_aug(args.batch, aug_rng))
+            else:
+                xn, yn = synth.batch(args.seed + 1000 * rank + step, args.batch, image_size=args.image_size)
+                x = torch.as_tensor(xn).cuda()
+                y = {k: torch.as_tensor(v).cuda() for k, v in yn.items()}
             model.training_step_start(step)
             out = trainer.step(x, y, N=args.hyps, test_samples=args.test_samples)
             with torch.no_grad():

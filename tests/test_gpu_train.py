@@ -513,6 +513,10 @@ def test_run_entry_point(gpu_lib, tmp_path, monkeypatch):
                      "--scalars", str(sc)])
     assert len(log2) == 1 and np.isfinite(log2[0]["loss"])
     assert torch.equal(seen["w"], sd["encoderRGB"]["det_head.0.weight"].cpu())
+    # ... and fed from decoded samples through the GPU input pipeline (row f4)
+    log3 = run.main(["--backbone", "resnet18", "--batch", "4", "--hyps", "4", "--test-samples", "3", "--hidden", "64", "--flow-steps", "2",
+                     "--dtype", "f32", "--epochs", "1", "--iters", "2", "--input-pipeline"])
+    assert len(log3) == 1 and np.isfinite(log3[0]["loss"]) and log3[0]["epe2d"] > 0
     tags = {__import__("json").loads(l)["tag"] for l in open(sc)}
     assert {"loss_it/neg_log_p", "loss_avg/loss_total", "metric_train/eval_3d_rgb", "param/theta_norm", "param/beta_norm"} <= tags
 
