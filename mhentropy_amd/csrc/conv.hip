@@ -889,6 +889,8 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const float *__restr
     __shared__ v4f red[3][MT][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, l15 = lane & 15;
     const int n0 = blockIdx.x * 16;
+    // blockIdx.y: slice of 16*MT rows (few output columns, e.g. l1 with N = 512: 32 column groups alone would leave 7/8 of the CUs idle)
+    X += (size_t)blockIdx.y * 16 * MT * K; Y += (size_t)blockIdx.y * 16 * MT * N; M -= blockIdx.y * 16 * MT;
     const int kq = K / 4;                    // each wave reduces a quarter of K (K % 64 == 0)
     const int kbeg = wave * kq, kend = kbeg + kq;
     v4f acc[MT];
@@ -944,6 +946,10 @@ extern "C" int mhe_linear_skinny_f32(const float *X, const float *W, const float
     const dim3 grid((N + 15) / 16), block(256);
     hipStream_t s = (hipStream_t)stream;
     const int relu = act == MHE_ACT_RELU;
+    if (M > 64 && (N + 15) / 16 < 512) {      // few column groups: also split the rows (64 per workgroup)
+        hipLaunchKernelGGL(conv::skinny_linear_kernel<4>, dim3((N + 15) / 16, (M + 63) / 64), block, 0, s, X, W, bias, Y, M, N, K, relu);
+        return check_launch("skinny_linear_kernel");
+    }
     if (M <= 64) hipLaunchKernelGGL(conv::skinny_linear_kernel<4>, grid, block, 0, s, X, W, bias, Y, M, N, K, relu);
     else if (M <= 128) hipLaunchKernelGGL(conv::skinny_linear_kernel<8>, grid, block, 0, s, X, W, bias, Y, M, N, K, relu);
     else hipLaunchKernelGGL(conv::skinny_linear_kernel<16>, grid, block, 0, s, X, W, bias, Y, M, N, K, relu);
