@@ -227,6 +227,17 @@ int mhe_conv2d_masked_nhwc(const mhe_conv_desc *d, const void *x, const void *w,
                            const void *bn_y1, const float *bn_mean_invstd1, float *bn_stats1, void *stream);
 int mhe_conv_stat_shards(void);
 /* kernel variant the launcher picks for a geometry with plain operands (numbering of mhe_conv_desc.tile, minus 1) */
+/* mhe_conv1x1_residual_in_nhwc's dual-input operand load (operand = [relu](x*in_scale+in_shift + x2*x2_scale+x2_shift), d->relu_in
+ * selects the ReLU; a_out optionally receives the operand) combined with the data-gradient epilogue of mhe_conv2d_masked_nhwc
+ * (residual, gate by mask, BatchNorm-reverse sums of one unit).  The train step uses it for the data gradient of a bottleneck's conv3
+ * with the BatchNorm reverse APPLIED ON LOAD: x = gated gradient g', x2 = the unit's raw output y, scales = (k2, k1), shift = k0,
+ * so that gy = k2 g' + k1 y + k0 is formed in the operand load (and written once to a_out for the weight gradient) instead of by a
+ * separate pass over three block-wide tensors. */
+int mhe_conv1x1_residual_in_masked_nhwc(const mhe_conv_desc *d, const void *x, const void *x2, const void *w, void *y,
+                                        const float *in_scale, const float *in_shift, const float *x2_scale, const float *x2_shift,
+                                        void *a_out, const void *residual, const void *mask, const void *bn_y0,
+                                        const float *bn_mean_invstd0, float *bn_stats0, void *stream);
+
 /* Data gradient of a 3x3 / stride 2 / pad 1 convolution (reference: torchvision Bottleneck.conv2 of layer2-4's first block, reached
  * through hand/network.py:54-61) WITHOUT zero-dilating gy: the four output parity classes (2i+py, 2j+px) are four small
  * convolutions of gy [B,Ho,Wo,Cout] with (1+py) x (1+px) taps each (9 taps over 4 pixels instead of 36), written straight to

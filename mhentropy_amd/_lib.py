@@ -78,6 +78,7 @@ SIGNATURES = {
     "mhe_conv2d_masked_nhwc": (_i, [_p] * 13),
     "mhe_conv2d_f32out_nhwc": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p]),
     "mhe_conv_stat_shards": (_i, []),
+    "mhe_conv1x1_residual_in_masked_nhwc": (_i, [C.POINTER(ConvDesc)] + [_p] * 15),
     "mhe_conv3x3s2_dgrad_nhwc": (_i, [_i, _i, _i, _i, _i, _i, _p, C.POINTER(C.c_void_p), _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "mhe_ho3d_geom_doubles": (_i, []),
     "mhe_ho3d_targets": (_i, [_p] * 7 + [_i] + [_p] * 18 + [_i, _p]),

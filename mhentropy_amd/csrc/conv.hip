@@ -569,7 +569,11 @@ template <typename T, int BM, int BN, int WM, int WN, bool FAST>
 static void launch_mode(const Params &p, hipStream_t s) {
     const dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN), block(64 * WM * WN);
     if (p.x2) {
-        if constexpr (FAST) hipLaunchKernelGGL((conv_kernel<T, BM, BN, WM, WN, true, 2>), grid, block, 0, s, p);
+        if constexpr (FAST) {
+            // dual-input operand load with the data-gradient epilogue (BatchNorm-reverse apply on load, train.py): 128-row tiles only
+            if constexpr (BM == 128) { if (p.mask) { hipLaunchKernelGGL((conv_kernel<T, BM, BN, WM, WN, true, 2, true>), grid, block, 0, s, p); return; } }
+            hipLaunchKernelGGL((conv_kernel<T, BM, BN, WM, WN, true, 2>), grid, block, 0, s, p);
+        }
     } else if (p.in_scale) {
         hipLaunchKernelGGL((conv_kernel<T, BM, BN, WM, WN, FAST, 1>), grid, block, 0, s, p);
     } else if (p.mask) {
@@ -589,6 +593,7 @@ static int choose_tile(const Params &p, bool fast, bool bf16) {
     if ((force & 15) == 7 && bf16 && p8_supports(p)) return 7;      // (higher bits: ablation builds of tuning runs)
     if (force >= 0 && force <= 4 && (force < 2 || (fast && bf16))) return force;
     if (p.Cout <= 64) return 0;
+    if (p.x2 && p.mask) return 1;             // dual-input load + data-gradient epilogue: instantiated on the 128-row tiles
     if (fast && bf16 && p.Cout >= 256) {      // (an f32 256x256 output tile would not fit the LDS staging buffers)
         const long tiles = (long)((p.M + 255) / 256) * ((p.Cout + 255) / 256);
         // plain operands go to the phase-pipelined kernel (conv_p8.hip: 0.85-1.0x the time of the register-staged 256x256
@@ -671,6 +676,19 @@ extern "C" int mhe_conv1x1_residual_in_nhwc(const mhe_conv_desc *d, const void *
     MHE_REQUIRE(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0, "mhe_conv1x1_residual_in_nhwc: 1x1 stride-1 only");
     MHE_REQUIRE((x2_scale == nullptr) == (x2_shift == nullptr), "mhe_conv1x1_residual_in_nhwc: x2_scale/x2_shift must come together");
     return conv_entry(d, x, w, y, in_scale, in_shift, nullptr, nullptr, nullptr, stats, x2, x2_scale, x2_shift, a_out, stream);
+}
+
+extern "C" int mhe_conv1x1_residual_in_masked_nhwc(const mhe_conv_desc *d, const void *x, const void *x2, const void *w, void *y,
+                                                   const float *in_scale, const float *in_shift, const float *x2_scale,
+                                                   const float *x2_shift, void *a_out, const void *residual, const void *mask,
+                                                   const void *bn_y0, const float *bn_mean_invstd0, float *bn_stats0, void *stream) {
+    MHE_REQUIRE(d && x2 && in_scale && in_shift && mask, "mhe_conv1x1_residual_in_masked_nhwc: x2, in_scale, in_shift and mask are required");
+    MHE_REQUIRE(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0, "mhe_conv1x1_residual_in_masked_nhwc: 1x1 stride-1 only");
+    MHE_REQUIRE((x2_scale == nullptr) == (x2_shift == nullptr), "mhe_conv1x1_residual_in_masked_nhwc: x2_scale/x2_shift must come together");
+    MHE_REQUIRE(!bn_y0 || (bn_mean_invstd0 && bn_stats0), "mhe_conv1x1_residual_in_masked_nhwc: bn_y needs its mean_invstd and stats");
+    MHE_REQUIRE(d->tile == 0 || d->tile == 1 || d->tile == 2, "mhe_conv1x1_residual_in_masked_nhwc: 128-row tiles only (tile 0, 1 or 2)");
+    const BnRev bn = {{bn_y0, nullptr}, {bn_mean_invstd0, nullptr}, {bn_stats0, nullptr}};
+    return conv_entry(d, x, w, y, in_scale, in_shift, nullptr, nullptr, residual, nullptr, x2, x2_scale, x2_shift, a_out, stream, mask, &bn);
 }
 
 extern "C" int mhe_conv2d_masked_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const void *residual,

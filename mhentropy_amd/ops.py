@@ -359,6 +359,30 @@ def conv1x1_residual_in(x, x2, w, in_scale, in_shift, x2_scale=None, x2_shift=No
     return y
 
 
+def conv1x1_dgrad_bn_apply(g, y_raw, coef, w_dg, a_out, mask, bn=None, zeros=None, tile=0):
+    """data gradient of a 1x1 convolution whose output gradient is still to receive its BatchNorm reverse: the operand
+    gy = k2 g + k1 y_raw + k0 (coef = [k2, k1, k0] of mhe_bn_bwd_finalize) is formed in the operand load and written once to a_out;
+    the result is gated by mask and (optionally) feeds the BatchNorm-reverse sums of one consumer (mhe_conv1x1_residual_in_masked_nhwc)."""
+    B, H, W, Cin = g.shape
+    Cout = w_dg.shape[0]
+    dt = g.dtype
+    _chk(g, dt, "dgrad_apply.g"); _chk(y_raw, dt, "dgrad_apply.y", g.shape); _chk(w_dg, dt, "dgrad_apply.w"); _chk(a_out, dt, "dgrad_apply.a_out", g.shape)
+    _chk(coef, torch.float32, "dgrad_apply.coef", (3, Cin)); _chk(mask, dt, "dgrad_apply.mask", (B, H, W, Cout))
+    if zeros is None:
+        zeros = torch.zeros(Cin, device=g.device, dtype=torch.float32)
+    _chk(zeros, torch.float32, "dgrad_apply.zeros", (Cin,))
+    out = torch.empty(B, H, W, Cout, device=g.device, dtype=dt)
+    by, bmi, bst = bn[0] if bn else (None, None, None)
+    if by is not None:
+        _chk(by, dt, "dgrad_apply.bn_y", out.shape); _chk(bmi, torch.float32, "dgrad_apply.bn_mean_invstd", (2, Cout))
+        _chk(bst, torch.float32, "dgrad_apply.bn_stats", (stat_shards(), 2, Cout))
+    d = ConvDesc(B, H, W, Cin, Cout, 1, 1, 1, 0, dtype_code(dt), 0, 0, int(tile))
+    check(_lib.lib().mhe_conv1x1_residual_in_masked_nhwc(C.byref(d), _ptr(g), _ptr(y_raw), _ptr(w_dg), _ptr(out), _ptr(coef[0]), _ptr(coef[2]),
+                                                         _ptr(coef[1]), _ptr(zeros), _ptr(a_out), None, _ptr(mask), _ptr(by), _ptr(bmi), _ptr(bst),
+                                                         _stream()), "mhe_conv1x1_residual_in_masked_nhwc")
+    return out
+
+
 def stem_conv7x7s2(x, w, dtype, stats=None):
     """x [B,3,H,W] f32 NCHW, w packed [64, Kpad] (dtype) -> raw conv1 output [B,Ho,Wo,64] NHWC (dtype)."""
     B, Cn, H, W = x.shape
@@ -558,7 +582,7 @@ def bn_mean_invstd(stats, count, eps=1e-5):
     return mi
 
 
-def bn_backward(g, a, y, mean_invstd, gamma, stats, dgamma, dbeta, want_masked=False, out=None, reduced=False):
+def bn_backward(g, a, y, mean_invstd, gamma, stats, dgamma, dbeta, want_masked=False, out=None, reduced=False, coef_only=False):
     """train-mode BatchNorm(+ReLU) reverse: returns gy (and g [a>0] when want_masked); writes dgamma / dbeta.
     reduced=True: `stats` already holds the sums (accumulated by the epilogue of the kernel that produced g)."""
     Cc = y.shape[-1]
@@ -574,6 +598,8 @@ def bn_backward(g, a, y, mean_invstd, gamma, stats, dgamma, dbeta, want_masked=F
         check(L.mhe_bn_bwd_reduce_nhwc(_ptr(g), _ptr(a), _ptr(y), _ptr(mean_invstd), _ptr(stats), P, Cc, dtype_code(dt), _stream()), "mhe_bn_bwd_reduce_nhwc")
     coef = torch.empty(3, Cc, device=y.device, dtype=torch.float32)
     check(L.mhe_bn_bwd_finalize(_ptr(stats), _ptr(gamma), _ptr(mean_invstd), _ptr(dgamma), _ptr(dbeta), _ptr(coef), Cc, float(P), _stream()), "mhe_bn_bwd_finalize")
+    if coef_only:              # the consumer applies gy = k2 g + k1 y + k0 itself (conv1x1_dgrad_bn_apply)
+        return coef
     gy = out if out is not None else torch.empty_like(y)
     gm = torch.empty_like(y) if want_masked else None
     check(L.mhe_bn_bwd_apply_nhwc(_ptr(g), _ptr(a), _ptr(y), _ptr(coef), _ptr(gy), _ptr(gm), P, Cc, dtype_code(dt), _stream()), "mhe_bn_bwd_apply_nhwc")

@@ -146,6 +146,7 @@ class TrainStep:
             i2 = torch.cat(a["idx2"]) if a["idx2"] else torch.zeros(0, dtype=torch.int64)
             a["idx2"] = i2.to(torch.int32).to(self.dev).contiguous() if bool((i2 >= 0).any()) else None
         self.step_t = torch.zeros(1, device=self.dev, dtype=torch.int32)
+        self._zeros_c = torch.zeros(4096, device=self.dev, dtype=torch.float32)
         self.sq = torch.zeros(1, device=self.dev, dtype=torch.float32)
         self._ws = {}
         # the modules' forward paths (eval, sample) read the same device-resident operand packs, refreshed after every
@@ -175,6 +176,9 @@ class TrainStep:
         self.G = torch.zeros_like(self.P)
         self.M = torch.zeros_like(self.P)
         self.V = torch.zeros_like(self.P)
+
+    bn_apply_on_load = os.environ.get("MHE_BN_BWD_ON_LOAD", "1") == "1"
+    bn_on_load_max_cin = int(os.environ.get("MHE_BN_BWD_ON_LOAD_MAXC", "128"))   # layer1 / layer2: wider layers lose more on the 128-row tile than the pass costs (measured)
 
     def _gradient_buckets(self):
         """flat-buffer ranges in the order the reverse pass completes them: [l1, l2, flow, det head] (done before the trunk's
@@ -546,7 +550,16 @@ class TrainStep:
                 self._grad_ready(self.blocks[bi + 1]["layer"] - 2)      # layer4 complete -> bucket 2, layer3 -> bucket 1
             us, ud = b["u"], b["ud"]
             ul = us[-1]
-            gy = self._bn_bwd(ul, g, None, pool, stats=getattr(ul, "rev_stats", None))
+            # bottleneck conv3 (1x1, stride 1): its BatchNorm reverse is applied in the operand load of its own data gradient
+            # (ops.conv1x1_dgrad_bn_apply) instead of by a pass over three block-wide tensors
+            on_load = self.bn_apply_on_load and len(us) == 3 and ul.k == 1 and ul.stride == 1 and ul.cin <= self.bn_on_load_max_cin
+            if on_load:
+                rs = getattr(ul, "rev_stats", None)
+                coef = ops.bn_backward(g, None, ul.y, ul.mi, ul.bn.weight.data, rs if rs is not None else pool.take(ul.cout), ul.dgamma,
+                                       ul.dbeta, reduced=rs is not None, coef_only=True)
+                gy = None
+            else:
+                gy = self._bn_bwd(ul, g, None, pool, stats=getattr(ul, "rev_stats", None))
             if ud is not None:
                 gyd = self._bn_bwd(ud, g, None, pool, stats=getattr(ud, "rev_stats", None))
                 self._wgrad(ud, gyd)
@@ -555,8 +568,18 @@ class TrainStep:
                 skip = g
             for j in range(len(us) - 1, 0, -1):
                 u = us[j]
-                self._wgrad(u, gy)
-                ga = self._dgrad(u, gy, consumers=(us[j - 1],), pool=pool)
+                if gy is None:                               # conv3 with its BatchNorm reverse on load
+                    cons = us[j - 1]
+                    bn = None
+                    if self.fuse_bn_reduce:
+                        cons.rev_stats = pool.take(cons.cout)
+                        bn = [(cons.y, cons.mi, cons.rev_stats)]
+                    gy = torch.empty_like(g)
+                    ga = ops.conv1x1_dgrad_bn_apply(g, u.y, coef, u.w_dg, gy, u.x, bn, zeros=self._zeros_c[:u.cout])
+                    self._wgrad(u, gy)
+                else:
+                    self._wgrad(u, gy)
+                    ga = self._dgrad(u, gy, consumers=(us[j - 1],), pool=pool)
                 gy = self._bn_bwd(us[j - 1], ga, None, pool, stats=getattr(us[j - 1], "rev_stats", None))
             self._wgrad(us[0], gy)
             first = bi == 0            # the first block's input is the max-pooled stem output (>= 0; the pool's reverse gates it)

@@ -164,3 +164,34 @@ def test_stem_statistics_use_every_shard(gpu_lib, dtype):
     stats = torch.zeros(ops.stat_shards(), 2, 64, device="cuda")
     ops.stem_conv7x7s2(x.cuda(), resnet.pack_stem_weight(w, dtype).cuda(), dtype, stats=stats)
     assert (stats.abs().sum((1, 2)) > 0).all(), "every statistic shard should receive workgroups"
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("Cin,Cout", [(256, 64), (512, 128), (1024, 256)])
+def test_dgrad_with_batchnorm_reverse_applied_on_load(gpu_lib, Cin, Cout, dt):
+    """mhe_conv1x1_residual_in_masked_nhwc as the train step uses it: operand gy = k2 g + k1 y + k0 formed in the load (and written
+    to a_out), 1x1 product with the data-gradient weights, ReLU gate and BatchNorm-reverse sums in the epilogue - against the two-pass
+    form (mhe_bn_bwd_apply_nhwc, then mhe_conv2d_masked_nhwc) and against torch on the rounded operands"""
+    from mhentropy_amd import ops
+    B, H = 3, 20                                   # M = 1200: partial tiles
+    gen = torch.Generator().manual_seed(Cin + Cout)
+    rnd = lambda *s: torch.randn(*s, generator=gen)
+    g, y = rnd(B, H, H, Cin).to(dt).cuda(), (rnd(B, H, H, Cin) * 2 + 0.3).to(dt).cuda()
+    coef = torch.stack([torch.rand(Cin, generator=gen) + 0.5, rnd(Cin) * 0.2, rnd(Cin) * 0.1]).cuda().contiguous()
+    w = (rnd(Cout, Cin) / Cin ** 0.5).to(dt).cuda().contiguous()
+    mask = rnd(B, H, H, Cout).to(dt).cuda()
+    bn_y = rnd(B, H, H, Cout).to(dt).cuda()
+    mi = torch.stack([rnd(Cout) * 0.1, torch.rand(Cout, generator=gen) + 0.5]).cuda().contiguous()
+    st1, st2 = (torch.zeros(ops.stat_shards(), 2, Cout, device="cuda") for _ in range(2))
+    gy = torch.empty_like(g)
+    out = ops.conv1x1_dgrad_bn_apply(g, y, coef, w, gy, mask, bn=[(bn_y, mi, st1)])
+    gy_ref = (coef[0] * g.float() + coef[1] * y.float() + coef[2])
+    tol = 1e-5 if dt == torch.float32 else 8e-3
+    assert_close(gy.float().cpu(), gy_ref.cpu(), tol, what="operand written out")
+    want = (gy.float() @ w.float().t()) * (mask.float() > 0)          # from the operand as stored (bf16: its rounded value feeds the product)
+    assert_close(out.float().cpu(), want.cpu(), 2e-5 if dt == torch.float32 else 8e-3, what="gated data gradient")
+    ref = ops.conv2d_nhwc(gy, w, 1, 1, 1, 0, mask=mask, bn=[(bn_y, mi, st2)])
+    assert_close(out.float().cpu(), ref.float().cpu(), 2e-5 if dt == torch.float32 else 8e-3, what="vs the two-pass form")
+    s1, s2 = st1.sum(0).cpu(), st2.sum(0).cpu()
+    scale = s2.abs().max(1, keepdim=True)[0] + 1.0
+    assert ((s1 - s2).abs() <= (1e-4 if dt == torch.float32 else 3e-2) * scale).all(), "BatchNorm-reverse sums"
