@@ -148,45 +148,7 @@ __device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, 
     constexpr int CPR = BN * (int)sizeof(T) / 16;          // 16-byte chunks per output row
     constexpr int CMASK = (CPR - 1) & 15;
     constexpr int EPC = 16 / (int)sizeof(T);               // elements per chunk
-    constexpr int NV = 8 * NTW;                            // partial values per thread: 2 stats x NTW tiles x 4 channels
     static_assert((size_t)BM * BN * sizeof(T) <= sizeof(lds), "output tile must fit the staging buffers");
-    static_assert((size_t)WM * WN * NV * 64 * 4 <= sizeof(lds), "statistics partials must fit the staging buffers");
-    if (p.stats) {
-        float *red = reinterpret_cast<float *>(lds);       // [waves][NV][64 lanes]
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const bool nv = n0 + wc * (BN / WN) + nt * 16 + 4 * q < p.Cout;
-            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) {
-                if (nv && pix(wr * (BM / WM) + mt * 16 + l15) >= 0) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { const float v = acc[nt][mt][r]; s1[r] += v; s2[r] = fmaf(v, v, s2[r]); }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                red[(wave * NV + nt * 4 + r) * 64 + lane] = s1[r];
-                red[(wave * NV + 4 * NTW + nt * 4 + r) * 64 + lane] = s2[r];
-            }
-        }
-        __syncthreads();
-        for (int t = tid; t < 2 * BN; t += NTH) {
-            const int stat = t / BN, ch = t % BN;
-            const int wcc = ch / (BN / WN), cc = ch % (BN / WN), nt = cc >> 4, qq = (cc >> 2) & 3, r = cc & 3;
-            const int v = stat * 4 * NTW + nt * 4 + r;
-            float sum = 0.f;
-#pragma unroll
-            for (int w2 = 0; w2 < WM; ++w2) {
-                const float *src = red + ((w2 * WN + wcc) * NV + v) * 64 + qq * 16;
-#pragma unroll
-                for (int l = 0; l < 16; ++l) sum += src[l];
-            }
-            const int n = n0 + ch;
-            if (n < p.Cout) atomicAdd(p.stats + ((size_t)shard * 2 + stat) * p.Cout + n, sum);
-        }
-        __syncthreads();
-    }
     if constexpr (sizeof(T) == 2 && !DG) {
         // f32 result from bf16 operands (mhe_conv2d_f32out_nhwc): the accumulator's own layout gives every lane 4 consecutive
         // channels of one pixel = one 16-byte store; used by the narrow (<= 64 output channels) products of the flow's reverse
@@ -252,6 +214,14 @@ __device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, 
         // below guards each row with a branch, which keeps hipcc from issuing one row's loads before the previous row's stores
         // (measured 2.7 TB/s on the layers whose whole cost is this epilogue: up to four tensors read per output chunk).  Here
         // the loads of G rows x (gate, residual, BatchNorm operands) are issued back to back, then consumed.
+        // batch statistics (forward form): per-channel sum and sum of squares of the tile AS STORED (bf16 storage: of the rounded values,
+        // the ones the consumer will normalise), accumulated per thread while it walks its rows in the store loop - the memory
+        // operations of that loop hide the arithmetic.  (The first version summed the f32 accumulators in a phase of its own before the
+        // transpose: two more barriers and an LDS round trip, 23 % of a write-bound 1x1 launch.)
+        const bool st_on = !DG && p.stats != nullptr;
+        float ss1[EPC], ss2[EPC];
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) ss1[i] = ss2[i] = 0.f;
         bool done = false;
         if constexpr (DG) {
             if (mk && pix(0) >= 0 && pix(BM - 1) >= 0 && n0 + BN <= p.Cout && !p.out_scale && !p.out_shift && !p.relu_out) {
@@ -328,6 +298,12 @@ __device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, 
             if (m < 0 || n >= p.Cout) continue;
             uint4 raw = *reinterpret_cast<const uint4 *>(ot + ((size_t)row * CPR + (c ^ (row & CMASK))) * 16);
             const size_t off = (size_t)m * p.Cout + n;
+            if (st_on) {
+                float sv[EPC];
+                Chunk<T>::unpack(raw, sv);
+#pragma unroll
+                for (int i = 0; i < EPC; ++i) { ss1[i] += sv[i]; ss2[i] = fmaf(sv[i], sv[i], ss2[i]); }
+            }
             if (!plain) {
                 float v[EPC];
                 Chunk<T>::unpack(raw, v);
@@ -368,6 +344,24 @@ __device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, 
                 raw = Chunk<T>::pack(v);
             }
             *reinterpret_cast<uint4 *>(yg + off) = raw;
+        }
+        if (st_on) {
+            // threads sharing a column chunk (NTH / CPR of them) fold their partial sums through LDS; one thread per channel adds the
+            // tile's two sums to this workgroup's statistic shard
+            float *red = reinterpret_cast<float *>(lds);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) { red[tid * (2 * EPC) + i] = ss1[i]; red[tid * (2 * EPC) + EPC + i] = ss2[i]; }
+            __syncthreads();
+            if (tid < CPR * EPC) {
+                const int c = tid / EPC, e = tid % EPC, n = n0 + tid;
+                float a = 0.f, b = 0.f;
+                for (int k = 0; k < NTH / CPR; ++k) { a += red[(c + CPR * k) * (2 * EPC) + e]; b += red[(c + CPR * k) * (2 * EPC) + EPC + e]; }
+                if (n < p.Cout) {
+                    atomicAdd(p.stats + ((size_t)shard * 2) * p.Cout + n, a);
+                    atomicAdd(p.stats + ((size_t)shard * 2 + 1) * p.Cout + n, b);
+                }
+            }
         }
         if constexpr (DG) if (bnr) {
             // threads sharing a column chunk (NTH / CPR of them) fold their partial sums through LDS; one thread per channel adds

@@ -45,19 +45,20 @@ def _q(t):
 def forward_bf16_storage(sd, x, arch="resnet50", training=True, taps=None):
     """The same network with every stored tensor (input, weights, raw conv outputs, activations) rounded
     to bf16 and all arithmetic in f32 - the rounding points of the product's bf16 encoder mode
-    (mhentropy_amd/resnet.py): statistics from the f32 conv result, BN+ReLU evaluated in f32 on the
-    bf16-stored conv output and stored as bf16."""
+    (mhentropy_amd/resnet.py): batch statistics of the conv output AS STORED (bf16-rounded - the tensor the
+    normalisation is applied to; the first version of the kernels summed the f32 accumulators, which differs by the mean of
+    the rounding errors), BN+ReLU evaluated in f32 on the bf16-stored conv output and stored as bf16."""
     kind, blocks, _ = CFG[arch]
 
     def conv_bn(inp, cname, bname, stride=1, pad=0, relu=True, res=None):
-        y = F.conv2d(inp, _q(sd[cname + ".weight"]), None, stride, pad)
+        y = _q(F.conv2d(inp, _q(sd[cname + ".weight"]), None, stride, pad))
         if training:
             mean, var = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
         else:
             mean, var = sd[bname + ".running_mean"], sd[bname + ".running_var"]
         sc = sd[bname + ".weight"] / torch.sqrt(var + BN_EPS)
         sh = sd[bname + ".bias"] - mean * sc
-        return _q(y), sc.view(1, -1, 1, 1), sh.view(1, -1, 1, 1)
+        return y, sc.view(1, -1, 1, 1), sh.view(1, -1, 1, 1)
 
     y, sc, sh = conv_bn(_q(x), "conv1", "bn1", 2, 3)
     a = _q(F.max_pool2d(F.relu(y * sc + sh), 3, 2, 1))

@@ -195,8 +195,9 @@ def test_conv_matches_torch(gpu_lib, dtype, cfg):
     assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, tol, what="raw conv")
     n = ref.numel() / Cout
     st = stats.double().sum(0).cpu()
-    assert_close(st[0] / n, ref.mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean")
-    assert_close(st[1] / n, (ref ** 2).mean((0, 2, 3)), 1e-5, what="batch E[x^2]")
+    ys = y.double().cpu().permute(0, 3, 1, 2)           # the statistics are those of the output AS STORED (what the consumer normalises)
+    assert_close(st[0] / n, ys.mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean")
+    assert_close(st[1] / n, (ys ** 2).mean((0, 2, 3)), 1e-5, what="batch E[x^2]")
     # fused eval-mode epilogue: relu(conv*scale+shift + residual)
     res = rng.normal(0, 1, tuple(ref.shape)).astype(np.float32)
     rd = torch.as_tensor(res).permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
@@ -234,8 +235,9 @@ def test_stem_conv_matches_torch(gpu_lib, dtype, B, H, W):
     assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, tol, what="stem conv")
     n = ref.numel() / 64
     st = stats.double().sum(0).cpu()
-    assert_close(st[0] / n, ref.mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean")
-    assert_close(st[1] / n, (ref ** 2).mean((0, 2, 3)), 1e-5, what="batch E[x^2]")
+    ys = y.double().cpu().permute(0, 3, 1, 2)           # the statistics are those of the output AS STORED (what the consumer normalises)
+    assert_close(st[0] / n, ys.mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean")
+    assert_close(st[1] / n, (ys ** 2).mean((0, 2, 3)), 1e-5, what="batch E[x^2]")
 
 
 def test_metrics_match_reference_vectors(gpu_lib):
