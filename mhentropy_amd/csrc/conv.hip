@@ -599,9 +599,10 @@ static int choose_tile(const Params &p, bool fast, bool bf16) {
         // plain operands go to the phase-pipelined kernel (conv_p8.hip: 0.85-1.0x the time of the register-staged 256x256
         // kernel on every trunk shape, tools/conv_variants.py); the producer-BatchNorm / residual-tail operand loads need
         // the register path
-        // residual-tail loads with a single wave of 256x256 workgroups (layer3's conv1: 256 tiles) have nothing to overlap their
-        // epilogue with: 113 vs 135 us on the 128x128 tile, two workgroups per CU (tools/conv_variants.py --tail)
-        if (p.x2 && tiles < 512) return 1;
+        // residual-tail loads run on the 128x128 tile, two workgroups per CU, whatever the tile count: 113 vs 140 us (layer3's conv1,
+        // 256 tiles of 256x256 = a single wave of workgroups with nothing to overlap their epilogue with), 240 vs 254 us (layer3.0),
+        // equal on layer4.0 (tools/conv_variants.py --tail)
+        if (p.x2) return 1;
         if (tiles >= 192) return p8_supports(p) && force < 0 ? 7 : 2;
     }
     return 1;
