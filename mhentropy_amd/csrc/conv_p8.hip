@@ -176,8 +176,14 @@ __global__ __launch_bounds__(512) void conv_p8_kernel(const Params p) {
             const int m = m0 + (rho >> 6) * 128 + h * 64 + (rho & 63);
             const bool mv = m < p.M;
             const int mm = mv ? m : 0;
-            const int wo_ = mm % p.Wo, t2 = mm / p.Wo, ho = t2 % p.Ho, b = t2 / p.Ho;
-            const int hi0 = ho * p.stride - p.pad, wi0 = wo_ * p.stride - p.pad;
+            int hi0, wi0, b;
+            if (!TAPS && p.stride == 1) {     // 1x1, stride 1, no padding: input pixel = output pixel, no index arithmetic
+                b = 0; hi0 = 0; wi0 = mm;
+            } else {
+                const int wo_ = mm % p.Wo, t2 = mm / p.Wo, ho = t2 % p.Ho;
+                b = t2 / p.Ho;
+                hi0 = ho * p.stride - p.pad; wi0 = wo_ * p.stride - p.pad;
+            }
             unsigned bits = 0;
             if constexpr (TAPS) {
                 for (int tap = 0; tap < p.KH * p.KW; ++tap) {
