@@ -116,6 +116,9 @@ def lib():
             raise MheError(
                 f"{LIB_PATH} is missing: build it with `python -m mhentropy_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # PyTorch-ROCm ships its own HIP runtime; it has to be in the process BEFORE this library is loaded, otherwise the library
+        # binds the system runtime and its kernels later find "no ROCm-capable device" next to torch's tensors
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the export is absent
