@@ -38,6 +38,9 @@ def main(argv=None):
                                               "override the flags above (backbone, h_dims, num_steps, batch_size, lr, milestones, test_samples)")
     ap.add_argument("--load", default="", help="checkpoint in the reference's container format to start from (training.pth)")
     ap.add_argument("--scalars", default="", help="write the reference's TensorBoard scalars here as JSON lines (rank 0)")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="1: replay the whole iteration (forward, reverse, all-reduce, clip, Adam) from HIP graphs (train.GraphedStep; batches are "
+                         "copied into static tensors, the graphs are re-captured when MultiStepLR changes the rate)")
     ap.add_argument("--input-pipeline", action="store_true",
                     help="feed the step from DECODED synthetic HO3D samples through the GPU input pipeline (ho3d_dataloader.HO3DBatchPipeline: "
                          "crop, augmentation, visibility, compute_st; hand/dataloader/ho3d_dataloader.py:272-459) instead of ready-made batches; "
@@ -72,6 +75,7 @@ def main(argv=None):
     criterion = MHEntLoss()
     meters = {"loss": harness.AverageMeter(), "epe3d": harness.AverageMeter(), "epe2d": harness.AverageMeter()}
     step, log = 0, []
+    graphed, graphed_lr, sx, sy = None, None, None, None
     if args.input_pipeline:
         import numpy as np
         from . import ho3d_dataloader as hd
@@ -92,7 +96,18 @@ def main(argv=None):
                 x = torch.as_tensor(xn).cuda()
                 y = {k: torch.as_tensor(v).cuda() for k, v in yn.items()}
             model.training_step_start(step)
-            out = trainer.step(x, y, N=args.hyps, test_samples=args.test_samples)
+            if args.graph and not args.test_samples:
+                from .train import GraphedStep
+                yk = {k: y[k].contiguous() for k in ("crop_uv", "vis")}          # what the loss consumes
+                if graphed is None or graphed_lr != trainer.lr:
+                    sx, sy = x.clone(), {k: v.clone() for k, v in yk.items()}
+                    graphed, graphed_lr = GraphedStep(trainer, sx, sy, N=args.hyps), trainer.lr        # (its warm-up pass is one real step)
+                sx.copy_(x)
+                for k, v in yk.items():
+                    sy[k].copy_(v)
+                out = graphed.replay()
+            else:
+                out = trainer.step(x, y, N=args.hyps, test_samples=args.test_samples)
             with torch.no_grad():
                 total, losses, metrics = criterion(dict(out), y)
             meters["loss"].update(float(total))

@@ -517,6 +517,10 @@ def test_run_entry_point(gpu_lib, tmp_path, monkeypatch):
     log3 = run.main(["--backbone", "resnet18", "--batch", "4", "--hyps", "4", "--test-samples", "3", "--hidden", "64", "--flow-steps", "2",
                      "--dtype", "f32", "--epochs", "1", "--iters", "2", "--input-pipeline"])
     assert len(log3) == 1 and np.isfinite(log3[0]["loss"]) and log3[0]["epe2d"] > 0
+    # ... and replayed from HIP graphs (re-captured when the learning rate steps)
+    log4 = run.main(["--backbone", "resnet18", "--batch", "4", "--hyps", "4", "--hidden", "64", "--flow-steps", "2", "--dtype", "f32", "--epochs", "2",
+                     "--iters", "3", "--image-size", "96", "--milestones", "1", "--graph", "1"])
+    assert len(log4) == 2 and all(np.isfinite(r["loss"]) for r in log4) and abs(log4[1]["lr"] - 2e-5) < 1e-12
     tags = {__import__("json").loads(l)["tag"] for l in open(sc)}
     assert {"loss_it/neg_log_p", "loss_avg/loss_total", "metric_train/eval_3d_rgb", "param/theta_norm", "param/beta_norm"} <= tags
 
