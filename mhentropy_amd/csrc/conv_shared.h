@@ -235,7 +235,7 @@ __device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, 
                     // stay within 256 registers to keep two workgroups per CU (4 took 128x128 to one wave per SIMD: 166 -> 210 us)
                     constexpr int G = NTH >= 512 ? 4 : 2;
                     static_assert(NJ % G == 0, "rows per thread");
-#pragma unroll
+#pragma unroll 1                  // one group of G rows at a time: fully unrolled, hipcc hoists the next groups' loads and spills (179 VGPRs on the 256x256 tile)
                     for (int j0 = 0; j0 < NJ; j0 += G) {
                         uint4 raw[G], gm[G], rr[HAS_RES ? G : 1], ya[NBN >= 1 ? G : 1], yb[NBN == 2 ? G : 1];
                         size_t off[G];
