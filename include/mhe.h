@@ -364,7 +364,9 @@ int mhe_flow_lrelu_bwd_sum(const void *g, int g_dtype, const void *h, int h_dtyp
 int mhe_flow_mask_pad_mixed(const float *x, const float *mask, float *xp, void *xp_bf16, long R, int dim, void *stream);
 int mhe_flow_couple_bwd_mixed(const float *x_out, const float *Os, const float *Ot, const float *mask,
                               const float *g_out, const float *g_log_p, float q_weight, float *x_in, float *GOs,
-                              float *GOt, float *g_part, void *GOs_bf16, void *GOt_bf16, long R, int B, int dim, void *stream);
+                              float *GOt, float *g_part, void *GOs_bf16, void *GOt_bf16,
+                              float *db_s, float *db_t /* optional [64] each: += column sums of GOs / GOt = the l2 bias gradients */,
+                              long R, int B, int dim, void *stream);
 int mhe_flow_couple_bwd_f32(const float *x_out, const float *Os, const float *Ot, const float *mask,
                             const float *g_out, const float *g_log_p, float q_weight, float *x_in, float *GOs,
                             float *GOt, float *g_part, long R, int B, int dim, void *stream);

@@ -49,7 +49,7 @@ SIGNATURES = {
     "mhe_flow_couple_bwd_f32": (_i, [_p] * 6 + [_f] + [_p] * 4 + [_l, _i, _i, _p]),
     "mhe_flow_lrelu_bwd_sum": (_i, [_p, _i, _p, _i, _p, _p, _p, _l, _p, _i, _i, _i, _f, _p]),
     "mhe_flow_mask_pad_mixed": (_i, [_p, _p, _p, _p, _l, _i, _p]),
-    "mhe_flow_couple_bwd_mixed": (_i, [_p] * 6 + [_f] + [_p] * 6 + [_l, _i, _i, _p]),
+    "mhe_flow_couple_bwd_mixed": (_i, [_p] * 6 + [_f] + [_p] * 8 + [_l, _i, _i, _p]),
     "mhe_flow_couple_accum_f32": (_i, [_p] * 5 + [_l, _i, _p]),
     "mhe_bn_mean_invstd": (_i, [_p, _p, _i, _f, _f, _p]),
     "mhe_bn_bwd_reduce_nhwc": (_i, [_p] * 5 + [_l, _i, _i, _p]),

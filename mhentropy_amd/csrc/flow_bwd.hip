@@ -182,34 +182,52 @@ __global__ __launch_bounds__(512) void lrelu_bwd_sum512_kernel(const u16 *__rest
 //   s = tanh(Os)(1-m), t = Ot(1-m), x_in = m x_out + (1-m)(x_out - t) e^{-s}          (hand/flows.py:213-216)
 // and the adjoints of x_out (g_out) and of log q (a_q per row; log q = logN(z0) - sum s):
 //   GOs = (1-m)(g_out x_in e^s - a_q)(1 - tanh^2),  GOt = (1-m) g_out,  g_part = g_out (m + (1-m) e^s)
+// a workgroup takes 64 rows: thread (rg = tid / 64, d = tid % 64) walks rows rg, rg + 4, ...; the column sums of GOs / GOt (the l2 bias
+// gradients of the two nets, formerly two separate column-sum launches per coupling) are folded through LDS and added atomically
 __global__ __launch_bounds__(256) void couple_bwd_kernel(
     const float *__restrict__ x_out, const float *__restrict__ Os, const float *__restrict__ Ot,
     const float *__restrict__ mask, const float *__restrict__ g_out, const float *__restrict__ g_logp, float q_weight,
     float *__restrict__ x_in, float *__restrict__ GOs, float *__restrict__ GOt, float *__restrict__ g_part,
-    long R, int B, int dim, u16 *__restrict__ GOs_b, u16 *__restrict__ GOt_b) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= R * XP) return;
-    const long r = i / XP;
-    const int d = (int)(i % XP);
-    float gos = 0.f, got = 0.f;
-    if (d < dim) {
-        const float m = mask[d], xo = x_out[r * dim + d], go = g_out[r * dim + d];
-        float xi = xo, gp = go;
-        if (m == 0.f) {
-            const float s = tanhf(Os[i]), t = Ot[i];
-            const float es = expf(s);
-            xi = (xo - t) / es;
-            const float a_q = g_logp ? g_logp[r % B] * q_weight : 0.f;
-            gos = (go * xi * es - a_q) * (1.f - s * s);
-            got = go;
-            gp = go * es;
+    long R, int B, int dim, u16 *__restrict__ GOs_b, u16 *__restrict__ GOt_b, float *__restrict__ db_s, float *__restrict__ db_t) {
+    __shared__ float red[2][4][XP];
+    const int d = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const long r0 = (long)blockIdx.x * 64;
+    const float m = d < dim ? mask[d] : 1.f;
+    float cs = 0.f, ct = 0.f;
+    for (int k = 0; k < 16; ++k) {
+        const long r = r0 + rg + 4 * k;
+        if (r >= R) break;
+        const long i = r * XP + d;
+        float gos = 0.f, got = 0.f;
+        if (d < dim) {
+            const float xo = x_out[r * dim + d], go = g_out[r * dim + d];
+            float xi = xo, gp = go;
+            if (m == 0.f) {
+                const float s = tanhf(Os[i]), t = Ot[i];
+                const float es = expf(s);
+                xi = (xo - t) / es;
+                const float a_q = g_logp ? g_logp[r % B] * q_weight : 0.f;
+                gos = (go * xi * es - a_q) * (1.f - s * s);
+                got = go;
+                gp = go * es;
+            }
+            x_in[r * dim + d] = xi;
+            g_part[r * dim + d] = gp;
         }
-        x_in[r * dim + d] = xi;
-        g_part[r * dim + d] = gp;
+        GOs[i] = gos;
+        GOt[i] = got;
+        if (GOs_b) { GOs_b[i] = f32_to_bf16(gos); GOt_b[i] = f32_to_bf16(got); }
+        cs += gos; ct += got;
     }
-    GOs[i] = gos;
-    GOt[i] = got;
-    if (GOs_b) { GOs_b[i] = f32_to_bf16(gos); GOt_b[i] = f32_to_bf16(got); }
+    if (db_s) {
+        red[0][rg][d] = cs; red[1][rg][d] = ct;
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int w = threadIdx.x >> 6;
+            const float v = red[w][0][d] + red[w][1][d] + red[w][2][d] + red[w][3][d];
+            atomicAdd((w ? db_t : db_s) + d, v);
+        }
+    }
 }
 
 // g_in = g_part + m (GXs + GXt): the nets' input is m * x
@@ -258,19 +276,22 @@ extern "C" int mhe_flow_lrelu_bwd_f32(float *G, const float *Hact, long n, float
 
 extern "C" int mhe_flow_couple_bwd_mixed(const float *x_out, const float *Os, const float *Ot, const float *mask,
                                          const float *g_out, const float *g_log_p, float q_weight, float *x_in, float *GOs,
-                                         float *GOt, float *g_part, void *GOs_bf16, void *GOt_bf16, long R, int B, int dim, void *stream) {
+                                         float *GOt, float *g_part, void *GOs_bf16, void *GOt_bf16, float *db_s, float *db_t, long R, int B,
+                                         int dim, void *stream) {
     MHE_REQUIRE(x_out && Os && Ot && mask && g_out && x_in && GOs && GOt && g_part, "mhe_flow_couple_bwd: null pointer");
     MHE_REQUIRE((GOs_bf16 == nullptr) == (GOt_bf16 == nullptr), "mhe_flow_couple_bwd: the bf16 copies come together");
+    MHE_REQUIRE((db_s == nullptr) == (db_t == nullptr), "mhe_flow_couple_bwd: the two bias-gradient accumulators come together");
     MHE_REQUIRE(R > 0 && B > 0 && R % B == 0 && dim > 0 && dim <= flowbwd::XP, "mhe_flow_couple_bwd: bad sizes");
-    hipLaunchKernelGGL(flowbwd::couple_bwd_kernel, dim3((unsigned)((R * flowbwd::XP + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       x_out, Os, Ot, mask, g_out, g_log_p, q_weight, x_in, GOs, GOt, g_part, R, B, dim, (u16 *)GOs_bf16, (u16 *)GOt_bf16);
+    hipLaunchKernelGGL(flowbwd::couple_bwd_kernel, dim3((unsigned)((R + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
+                       x_out, Os, Ot, mask, g_out, g_log_p, q_weight, x_in, GOs, GOt, g_part, R, B, dim, (u16 *)GOs_bf16, (u16 *)GOt_bf16, db_s, db_t);
     return check_launch("couple_bwd_kernel");
 }
 
 extern "C" int mhe_flow_couple_bwd_f32(const float *x_out, const float *Os, const float *Ot, const float *mask,
                                        const float *g_out, const float *g_log_p, float q_weight, float *x_in, float *GOs,
                                        float *GOt, float *g_part, long R, int B, int dim, void *stream) {
-    return mhe_flow_couple_bwd_mixed(x_out, Os, Ot, mask, g_out, g_log_p, q_weight, x_in, GOs, GOt, g_part, nullptr, nullptr, R, B, dim, stream);
+    return mhe_flow_couple_bwd_mixed(x_out, Os, Ot, mask, g_out, g_log_p, q_weight, x_in, GOs, GOt, g_part, nullptr, nullptr, nullptr, nullptr, R, B, dim,
+                                     stream);
 }
 
 extern "C" int mhe_flow_lrelu_bwd_sum(const void *g, int g_dtype, const void *h, int h_dtype, float *out_f32, void *out_bf16,

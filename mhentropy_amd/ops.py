@@ -556,7 +556,9 @@ def add(a, b, out=None):
     return out
 
 
-def flow_couple_bwd(x_out, Os, Ot, mask_row, g_out, g_log_p, q_weight, B, x_in, GOs, GOt, g_part, GOs_bf16=None, GOt_bf16=None):
+def flow_couple_bwd(x_out, Os, Ot, mask_row, g_out, g_log_p, q_weight, B, x_in, GOs, GOt, g_part, GOs_bf16=None, GOt_bf16=None, db_s=None,
+                    db_t=None):
+    """db_s / db_t (optional, [64] f32): += the column sums of GOs / GOt (the l2 bias gradients of the s and t nets)"""
     R, dim = x_out.shape
     if GOs_bf16 is not None:
         _chk(GOs_bf16, torch.bfloat16, "couple_bwd.GOs_bf16", (R, 64)); _chk(GOt_bf16, torch.bfloat16, "couple_bwd.GOt_bf16", (R, 64))
@@ -565,7 +567,7 @@ def flow_couple_bwd(x_out, Os, Ot, mask_row, g_out, g_log_p, q_weight, B, x_in, 
         _chk(t, torch.float32, "couple_bwd." + n, s)
     check(_lib.lib().mhe_flow_couple_bwd_mixed(_ptr(x_out), _ptr(Os), _ptr(Ot), _ptr(mask_row), _ptr(g_out), _ptr(g_log_p),
                                                float(q_weight), _ptr(x_in), _ptr(GOs), _ptr(GOt), _ptr(g_part), _ptr(GOs_bf16), _ptr(GOt_bf16),
-                                               R, B, dim, _stream()), "mhe_flow_couple_bwd_mixed")
+                                               _ptr(db_s), _ptr(db_t), R, B, dim, _stream()), "mhe_flow_couple_bwd_mixed")
 
 
 def flow_couple_accum(g_part, GXs, GXt, mask_row, g_in):

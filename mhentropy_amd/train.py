@@ -648,10 +648,10 @@ class TrainStep:
                     ops.linear_bf16_f32out(H2b[n], d["w2b"], d["b2"], out=O[n])            # s, t pre-activations: f32 result, as the forward kernel
                 x_in, g_in = (xa, ga) if x_cur is not xa else (xb, gb)
                 ops.flow_couple_bwd(x_cur, O[0], O[1], m, g_cur, g_logp, -1.0 / N_all if g_logp is not None else 0.0, B, x_in, GO[0], GO[1], gpart,
-                                    GOb[0], GOb[1])
+                                    GOb[0], GOb[1], db_s=self.fnets[2 * i]["db2"], db_t=self.fnets[2 * i + 1]["db2"])
                 for n in range(2):
                     d, slot = self.fnets[2 * i + n], (2 * i + n) * 2
-                    ops.conv_wgrad(v4(H2b[n]), v4(GOb[n]), 1, 1, 1, 0, d["dw2"]); ops.colsum(GO[n], d["db2"])
+                    ops.conv_wgrad(v4(H2b[n]), v4(GOb[n]), 1, 1, 1, 0, d["dw2"])
                     ops.conv2d_nhwc(v4(GOb[n]), d["w2Tb"], 1, 1, 1, 0, out=v4(P2b))
                     ops.flow_lrelu_bwd_sum(P2b, H2b[n], N, B, Gc[:, (slot + 1) * h:], Gc.shape[1], out_bf16=G2b, sum_out_t=GcT[(slot + 1) * h:])
                     ops.conv_wgrad(v4(H1b[n]), v4(G2b), 1, 1, 1, 0, d["dw1"])
