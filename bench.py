@@ -160,7 +160,14 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         log("spawning " + " ".join(cmd))
-        raise SystemExit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode)
+        # relay rank 0's JSON line only (a communication backend may chat on stdout: gloo does in the one-GPU rehearsal)
+        child = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), stdout=subprocess.PIPE, text=True)
+        for line in child.stdout.splitlines():
+            if line.startswith("{") and line.rstrip().endswith("}"):
+                print(line, flush=True)
+            elif line.strip():
+                print(line, file=sys.stderr, flush=True)
+        raise SystemExit(child.returncode)
 
     from mhentropy_amd import dist as mdist
     # MHE_BENCH_REHEARSE=1 (development only): all ranks share cuda:0 and talk over gloo, to rehearse the N>1 code
