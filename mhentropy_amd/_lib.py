@@ -13,7 +13,7 @@ _p, _i, _f, _sz, _l = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_long
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in
-                ("B", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad", "dtype", "relu_in", "relu_out", "tile")]
+                ("B", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad", "dtype", "relu_in", "relu_out", "tile", "res_half")]
 
 
 # name -> (restype, argtypes); must list every symbol of include/mhe.h

@@ -745,6 +745,8 @@ static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void
     p.Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
     p.Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
     p.os2 = 0; p.os_py = p.os_px = 0;
+    p.res_s2 = d->res_half ? 1 : 0;
+    MHE_REQUIRE(!p.res_s2 || (residual && !scatter && !y32), "mhe_conv2d_nhwc: res_half needs a residual (and no output scatter)");
     if (scatter) {     // parity class of a stride-2 data gradient: one output per input position (reads past the edge give zeros)
         p.Ho = d->H; p.Wo = d->W; p.os2 = 1; p.os_py = scatter[0]; p.os_px = scatter[1];
     }

@@ -25,6 +25,7 @@ struct Params {
     // output scatter of the parity-split stride-2 data gradient: output pixel (b, i, j) of the [B, Ho, Wo] grid lands at
     // (b, 2i + os_py, 2j + os_px) of a [B, 2Ho, 2Wo] tensor (y, residual, mask and bn_y are all addressed there)
     int os2, os_py, os_px;
+    int res_s2;            // residual at half resolution [B, ceil(Ho/2), ceil(Wo/2), Cout], added at even output positions only
 };
 
 // tile row -> global output pixel index the epilogue addresses (or -1 outside the problem)
@@ -126,6 +127,14 @@ __device__ __forceinline__ void tile_of_block(int &mt, int &nt) {
         nt = slot % gn;
         mt = (slot / gn) * 8 + (L & 7);
     }
+}
+
+// element offset (without the channel) of the half-resolution residual row of output pixel m, or -1 at odd positions
+__device__ __forceinline__ long res_half_row(const Params &p, long m) {
+    const int j = (int)(m % p.Wo), t = (int)(m / p.Wo), i = t % p.Ho, b = t / p.Ho;
+    if ((i | j) & 1) return -1l;
+    const int Hh = (p.Ho + 1) >> 1, Wh = (p.Wo + 1) >> 1;
+    return ((long)(b * Hh + (i >> 1))) * Wh + (j >> 1);
 }
 
 // ---- epilogue shared by the conv kernels.  The accumulator holds y^T: lane (l15, q) owns channels
@@ -245,7 +254,12 @@ __device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, 
                             const int row = id / CPR, c = id % CPR;
                             off[g] = (size_t)pix(row) * p.Cout + n0 + c * EPC;
                             gm[g] = *reinterpret_cast<const uint4 *>(mk + off[g]);
-                            if constexpr (HAS_RES) rr[g] = *reinterpret_cast<const uint4 *>(rg + off[g]);
+                            if constexpr (HAS_RES) {
+                                if (p.res_s2) {
+                                    const long hr = res_half_row(p, pix(row));
+                                    rr[g] = hr >= 0 ? *reinterpret_cast<const uint4 *>(rg + (size_t)hr * p.Cout + n0 + c * EPC) : make_uint4(0u, 0u, 0u, 0u);
+                                } else rr[g] = *reinterpret_cast<const uint4 *>(rg + off[g]);
+                            }
                             if constexpr (NBN >= 1) ya[g] = *reinterpret_cast<const uint4 *>(y0g + off[g]);
                             if constexpr (NBN == 2) yb[g] = *reinterpret_cast<const uint4 *>(y1g + off[g]);
                             raw[g] = *reinterpret_cast<const uint4 *>(ot + ((size_t)row * CPR + (c ^ (row & CMASK))) * 16);
@@ -313,10 +327,13 @@ __device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, 
                     v[i] = fmaf(v[i], sc, sh);
                 }
                 if (rg) {
-                    float r2[EPC];
-                    Chunk<T>::unpack(*reinterpret_cast<const uint4 *>(rg + off), r2);
+                    const long hr = p.res_s2 ? res_half_row(p, m) : 0l;
+                    if (hr >= 0) {
+                        float r2[EPC];
+                        Chunk<T>::unpack(*reinterpret_cast<const uint4 *>(rg + (p.res_s2 ? (size_t)hr * p.Cout + n : off)), r2);
 #pragma unroll
-                    for (int i = 0; i < EPC; ++i) v[i] += r2[i];
+                        for (int i = 0; i < EPC; ++i) v[i] += r2[i];
+                    }
                 }
                 if (p.relu_out) {
 #pragma unroll

@@ -240,7 +240,7 @@ def metrics(xyz, uv, pose3d, scale, crop_uv, vis):
 
 
 def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in=False, out_scale=None,
-                out_shift=None, residual=None, relu_out=False, stats=None, out=None, mask=None, bn=None, tile=0):
+                out_shift=None, residual=None, relu_out=False, stats=None, out=None, mask=None, bn=None, tile=0, res_half=False):
     """x [B,H,W,Cin], w packed [Cout, Kpad]; returns y [B,Ho,Wo,Cout] of x.dtype.  mask (shaped like y, data-gradient
     form only): y = (conv + residual) * [mask > 0]; bn = up to two (bn_y, mean_invstd [2,C], stats [S,2,C]) triples: the epilogue
     also accumulates the BatchNorm-reverse sums of y for those units (see mhe_conv2d_masked_nhwc).  tile > 0 forces kernel
@@ -257,10 +257,10 @@ def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in
         if t is not None:
             _chk(t, torch.float32, "conv." + n, (c,))
     if residual is not None:
-        _chk(residual, dt, "conv.residual", (B, Ho, Wo, Cout))
+        _chk(residual, dt, "conv.residual", (B, (Ho + 1) // 2, (Wo + 1) // 2, Cout) if res_half else (B, Ho, Wo, Cout))
     if stats is not None:
         _chk(stats, torch.float32, "conv.stats", (stat_shards(), 2, Cout))
-    d = ConvDesc(B, H, W, Cin, Cout, KH, KW, stride, pad, dtype_code(dt), int(relu_in), int(relu_out), int(tile))
+    d = ConvDesc(B, H, W, Cin, Cout, KH, KW, stride, pad, dtype_code(dt), int(relu_in), int(relu_out), int(tile), int(res_half))
     if mask is not None:
         if in_scale is not None or out_scale is not None or out_shift is not None or stats is not None or relu_in or relu_out:
             raise ValueError("conv2d_nhwc: mask= is the plain data-gradient form (no affine / statistics / relu)")

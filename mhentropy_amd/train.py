@@ -58,14 +58,14 @@ def dgrad_s2_operand_indices(idx):
     return out
 
 
-def conv_dgrad(gy, w_dg, k, stride, pad, H, W, residual=None, mask=None, bn=None, w_s2=None):
+def conv_dgrad(gy, w_dg, k, stride, pad, H, W, residual=None, mask=None, bn=None, w_s2=None, res_half=False, coarse=False):
     """gradient of a k x k / stride / pad convolution w.r.t. its [B,H,W,Cin] input (+ residual), through the
     FORWARD implicit-GEMM kernel: stride 1 is a convolution of gy with the transposed, tap-flipped weights at
     padding k-1-pad; a stride-2 3x3 runs the same on the zero-dilated gy; a stride-2 1x1 is computed on the
     coarse grid and scattered to the even positions.  mask (the convolution's own post-ReLU input): the result is
     gated by [mask > 0] in the kernel's epilogue, i.e. it leaves as the gradient w.r.t. the PRE-activation."""
     if stride == 1:
-        return ops.conv2d_nhwc(gy, w_dg, k, k, 1, k - 1 - pad, residual=residual, mask=mask, bn=bn)
+        return ops.conv2d_nhwc(gy, w_dg, k, k, 1, k - 1 - pad, residual=residual, mask=mask, bn=bn, res_half=res_half)
     if stride != 2 or k not in (1, 3):
         raise NotImplementedError(f"conv_dgrad: k={k} stride={stride}")
     if k == 3 and w_s2 is not None and pad == 1 and H == 2 * gy.shape[1] and W == 2 * gy.shape[2]:
@@ -75,6 +75,8 @@ def conv_dgrad(gy, w_dg, k, stride, pad, H, W, residual=None, mask=None, bn=None
     if mask is not None:
         raise NotImplementedError("conv_dgrad: mask with a stride-2 1x1 (only the un-gated downsample branch uses it)")
     half = ops.conv2d_nhwc(gy, w_dg, 1, 1, 1, 0)
+    if coarse and residual is None:     # the consumer adds it at the even positions itself (mhe_conv_desc.res_half): no scattered copy
+        return half
     return ops.upsample2(half, H, W, base=residual)
 
 
@@ -526,7 +528,7 @@ class TrainStep:
     def _wgrad(self, u, gy):
         ops.conv_wgrad(u.x, gy, u.k, u.k, u.stride, u.pad, u.dw)
 
-    def _dgrad(self, u, gy, residual=None, gate=True, consumers=(), pool=None):
+    def _dgrad(self, u, gy, residual=None, gate=True, consumers=(), pool=None, res_half=False, coarse=False):
         """gradient w.r.t. the pre-activation of the unit's input (+ residual): every unit input in the trunk is a post-ReLU
         tensor, so the ReLU gate [x > 0] is applied in the producing kernel's epilogue and the BatchNorm reverse passes
         downstream read one tensor less"""
@@ -537,7 +539,7 @@ class TrainStep:
             for c, (_, _, st) in zip(consumers, bn):
                 c.rev_stats = st
         return conv_dgrad(gy, u.w_dg, u.k, u.stride, u.pad, u.x.shape[1], u.x.shape[2], residual, u.x if gate else None, bn,
-                          w_s2=getattr(u, "w_s2", None))
+                          w_s2=getattr(u, "w_s2", None), res_half=res_half, coarse=coarse)
 
     def _trunk_backward(self, g_f):
         pool = resnet._StatsPool(self.dev, channels=65536)
@@ -563,7 +565,10 @@ class TrainStep:
             if ud is not None:
                 gyd = self._bn_bwd(ud, g, None, pool, stats=getattr(ud, "rev_stats", None))
                 self._wgrad(ud, gyd)
-                skip = self._dgrad(ud, gyd, gate=False)          # summed with the main branch before the gate
+                # summed with the main branch before the gate; a stride-2 shortcut's gradient stays on its coarse grid and the main
+                # branch's data gradient adds it at the even positions (bottleneck: conv1 is 1x1 stride 1, so that launch takes it)
+                half_skip = ud.stride == 2 and ud.k == 1 and us[0].stride == 1 and bi > 0
+                skip = self._dgrad(ud, gyd, gate=False, coarse=half_skip)
             else:
                 skip = g
             for j in range(len(us) - 1, 0, -1):
@@ -585,7 +590,7 @@ class TrainStep:
             first = bi == 0            # the first block's input is the max-pooled stem output (>= 0; the pool's reverse gates it)
             prev = self.blocks[bi - 1] if bi else None
             cons = () if first else tuple(x for x in (prev["u"][-1], prev["ud"]) if x is not None)
-            g = self._dgrad(us[0], gy, residual=skip, gate=not first, consumers=cons, pool=pool)
+            g = self._dgrad(us[0], gy, residual=skip, gate=not first, consumers=cons, pool=pool, res_half=ud is not None and half_skip)
         for u in self.units:
             u.rev_stats = None
         u = self.stem

@@ -197,3 +197,30 @@ def test_dgrad_with_batchnorm_reverse_applied_on_load(gpu_lib, Cin, Cout, dt):
     s1, s2 = st1.sum(0).cpu(), st2.sum(0).cpu()
     scale = s2.abs().max(1, keepdim=True)[0] + 1.0
     assert ((s1 - s2).abs() <= (1e-4 if dt == torch.float32 else 3e-2) * scale).all(), "BatchNorm-reverse sums"
+
+
+@pytest.mark.parametrize("tile", [0, 2, 8])
+@pytest.mark.parametrize("masked", [True, False])
+def test_half_resolution_residual(gpu_lib, tile, masked):
+    """mhe_conv_desc.res_half: a residual on the coarse grid [B, H/2, W/2, C] added at the even output positions only (the gradient of
+    a stride-2 1x1 shortcut joining the main branch) == the same launch fed the scattered full-resolution tensor; odd sizes included"""
+    from mhentropy_amd import ops
+    B, H, W, Cin, Cout = 3, 14, 10, 64, 256
+    gen = torch.Generator().manual_seed(tile + 7 * masked)
+    bf = torch.bfloat16
+    x = torch.randn(B, H, W, Cin, generator=gen).to(bf).cuda()
+    w = (torch.randn(Cout, Cin, generator=gen) / 8).to(bf).cuda().contiguous()
+    half = torch.randn(B, (H + 1) // 2, (W + 1) // 2, Cout, generator=gen).to(bf).cuda()
+    mask = torch.randn(B, H, W, Cout, generator=gen).to(bf).cuda() if masked else None
+    full = ops.upsample2(half, H, W)
+    bn1 = bn2 = None
+    if masked:
+        bn_y = torch.randn(B, H, W, Cout, generator=gen).to(bf).cuda()
+        mi = torch.stack([torch.randn(Cout, generator=gen) * 0.1, torch.rand(Cout, generator=gen) + 0.5]).cuda().contiguous()
+        st1, st2 = (torch.zeros(ops.stat_shards(), 2, Cout, device="cuda") for _ in range(2))
+        bn1, bn2 = [(bn_y, mi, st1)], [(bn_y, mi, st2)]
+    got = ops.conv2d_nhwc(x, w, 1, 1, 1, 0, residual=half, mask=mask, bn=bn1, tile=tile, res_half=True)
+    want = ops.conv2d_nhwc(x, w, 1, 1, 1, 0, residual=full, mask=mask, bn=bn2, tile=tile)
+    assert torch.equal(got, want)
+    if masked:
+        assert_close(st1.sum(0).cpu(), st2.sum(0).cpu(), 1e-6, 1e-5, what="BatchNorm-reverse sums")
