@@ -585,11 +585,15 @@ static void launch_mode(const Params &p, hipStream_t s) {
 
 bool p8_supports(const Params &p);             // conv_p8.hip: the phase-pipelined 256x256 bf16 kernel (variant 7)
 int launch_p8(const Params &p, hipStream_t s);
+bool stream_supports(const Params &p);         // conv_stream.hip: the streaming 1x1 kernel for K = 64 / 128 (variant 8)
+int launch_stream(const Params &p, hipStream_t s);
 
 // tile choice: 0 = 128x64, 1 = 128x128, 2 = 256x256 (FAST only; needs >= ~3/4 of the CUs' worth of tiles)
 static int choose_tile(const Params &p, bool fast, bool bf16) {
     static const int env_force = getenv("MHE_CONV_TILE") ? atoi(getenv("MHE_CONV_TILE")) : -1;    // tuning knob
     const int force = p.force >= 0 ? p.force : env_force;
+    static const int env_stream = getenv("MHE_CONV_STREAM") ? atoi(getenv("MHE_CONV_STREAM")) : 1;
+    if (bf16 && (force == 8 || (force < 0 && env_stream)) && stream_supports(p)) return 8;
     if ((force & 15) == 7 && bf16 && p8_supports(p)) return 7;      // (higher bits: ablation builds of tuning runs)
     if (force >= 0 && force <= 4 && (force < 2 || (fast && bf16))) return force;
     if (p.Cout <= 64) return 0;
@@ -613,7 +617,9 @@ static int launch_conv(const Params &p, hipStream_t s) {
     constexpr int BKE = 8 * El<T>::CE;
     const bool fast = (p.Cin % BKE) == 0;
     if constexpr (sizeof(T) == 2) {
-        if (choose_tile(p, fast, true) == 7) return launch_p8(p, s);
+        const int t0 = choose_tile(p, fast, true);
+        if (t0 == 8) return launch_stream(p, s);
+        if (t0 == 7) return launch_p8(p, s);
     }
     if (p.x2 && !fast) { set_error("residual-tail prologue needs Cin %% %d == 0", BKE); return MHE_ERR_ARG; }
     // the LDS-DMA kernel measures equal to the register-staged one (see its header): opt-in, bit 0 = 256x256, bit 1 = 128x128
@@ -776,7 +782,7 @@ extern "C" int mhe_conv_stat_shards(void) { return conv::NSH; }
 extern "C" int mhe_conv_tile(const mhe_conv_desc *d) {
     if (!d) return -1;
     conv::Params p{};
-    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
     const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
     p.M = d->B * Ho * Wo;
     p.force = d->tile - 1;
@@ -791,7 +797,7 @@ extern "C" int mhe_conv_tile_mode(const mhe_conv_desc *d, int mode) {
     if (!d || mode < 0 || mode > 2) return -1;
     static const float dummy = 0.f;
     conv::Params p{};
-    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
     const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
     p.M = d->B * Ho * Wo;
     p.force = d->tile - 1;

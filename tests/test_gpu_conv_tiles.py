@@ -224,3 +224,40 @@ def test_half_resolution_residual(gpu_lib, tile, masked):
     assert torch.equal(got, want)
     if masked:
         assert_close(st1.sum(0).cpu(), st2.sum(0).cpu(), 1e-6, 1e-5, what="BatchNorm-reverse sums")
+
+
+@pytest.mark.parametrize("bn_load", [False, True], ids=["plain", "bn-on-load"])
+@pytest.mark.parametrize("shape", [(16, 64, 64, 64, 256), (18, 61, 60, 64, 256), (64, 32, 32, 128, 512), (17, 64, 61, 128, 256)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_streaming_1x1_kernel(gpu_lib, shape, bn_load):
+    """conv1x1_stream_kernel (variant 8: K = 64 / 128 input channels, weights resident in LDS, 64-pixel chunks): the launcher picks it
+    for these shapes by itself AND forced; against conv2d on the same bf16-rounded operands (with the producer BatchNorm + ReLU applied
+    to the operand in f32 and rounded, as the kernel stores it), statistics of the output as stored; pixel counts that are not a
+    multiple of the chunk included"""
+    from mhentropy_amd import ops, resnet, _lib
+    import ctypes as C
+    B, H, W, Cin, Cout = shape
+    g, x, w = _operands(Cin + Cout + H, B, H, W, Cin, Cout, 1)
+    xd = _nhwc(x)
+    wd = resnet.pack_conv_weight(w, torch.bfloat16).cuda()
+    kw = {}
+    xin = x
+    if bn_load:
+        sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.2
+        kw = dict(in_scale=sc.cuda(), in_shift=sh.cuda(), relu_in=True)
+        xin = torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).bfloat16().float()
+    ref = F.conv2d(xin.double(), w.double())
+    d = _lib.ConvDesc(B, H, W, Cin, Cout, 1, 1, 1, 0, ops.BF16, 0, 0, 0)
+    assert _lib.lib().mhe_conv_tile_mode(C.byref(d), 1 if bn_load else 0) == 8, "the launcher should pick the streaming kernel here"
+    for tile in (0, 9):
+        stats = torch.zeros(ops.stat_shards(), 2, Cout, device="cuda")
+        y = ops.conv2d_nhwc(xd, wd, 1, 1, 1, 0, stats=stats, tile=tile, **kw)
+        assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, TOL, what="raw conv")
+        n = ref.numel() / Cout
+        st = stats.double().sum(0).cpu()
+        ys = y.double().cpu().permute(0, 3, 1, 2)
+        assert_close(st[0] / n, ys.mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean")
+        assert_close(st[1] / n, (ys ** 2).mean((0, 2, 3)), 1e-5, what="batch E[x^2]")
+        assert (stats.abs().sum((1, 2)) > 0).sum().item() > 8, "statistics must be spread over the shards"
+    y2 = ops.conv2d_nhwc(xd, wd, 1, 1, 1, 0, tile=9, **kw)                  # without statistics
+    assert torch.equal(y2, y)
