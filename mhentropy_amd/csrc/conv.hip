@@ -535,6 +535,53 @@ __global__ void maxpool_kernel(const T *__restrict__ x, const float *__restrict_
     }
 }
 
+// the same for bf16 with 8 channels (16 bytes) per thread: the nine window loads are issued unconditionally from clamped addresses
+// (out-of-range taps are dropped by a select afterwards), so they are in flight together instead of one guarded 8-byte load at a time
+__global__ __launch_bounds__(256) void maxpool8_kernel(const u16 *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift,
+                                                       u16 *__restrict__ y, int B, int H, int W, int C, int Ho, int Wo) {
+    const size_t n8 = (size_t)B * Ho * Wo * C / 8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * 8;
+        const int c = (int)(e % C);
+        size_t t = e / C;
+        const int wo = (int)(t % Wo); t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        uint4 raw[9];
+        bool ok[9];
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const int hi = 2 * ho - 1 + dh, wi = 2 * wo - 1 + dw;
+                ok[dh * 3 + dw] = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+                const int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi), wc = wi < 0 ? 0 : (wi >= W ? W - 1 : wi);
+                raw[dh * 3 + dw] = *reinterpret_cast<const uint4 *>(x + (((size_t)b * H + hc) * W + wc) * C + c);
+            }
+        float sc[8], sf[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sc[k] = scale ? scale[c + k] : 1.f; sf[k] = scale ? shift[c + k] : 0.f; }
+        float m[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k] = -3.0e38f;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            float v[8];
+            Chunk<u16>::unpack(raw[j], v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float a = fmaf(v[k], sc[k], sf[k]);
+                m[k] = ok[j] ? fmaxf(m[k], a) : m[k];
+            }
+        }
+        if (scale) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], 0.f);       // relu commutes with max
+        }
+        *reinterpret_cast<uint4 *>(y + e) = Chunk<u16>::pack(m);
+    }
+}
+
 // global average pool: block = (image b, 64-channel group); 4 pixel groups x 64 channels
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_kernel(const T *__restrict__ x, float *__restrict__ y, int HW, int C) {
@@ -872,6 +919,9 @@ extern "C" int mhe_maxpool3x3s2_nhwc(const void *x, const float *scale, const fl
     if (dtype == MHE_F32)
         hipLaunchKernelGGL(conv::maxpool_kernel<float>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream,
                            (const float *)x, scale, shift, (float *)y, B, H, W, C, Ho, Wo);
+    else if (C % 8 == 0)
+        hipLaunchKernelGGL(conv::maxpool8_kernel, dim3(ew_blocks(n4 / 2)), dim3(256), 0, (hipStream_t)stream,
+                           (const u16 *)x, scale, shift, (u16 *)y, B, H, W, C, Ho, Wo);
     else
         hipLaunchKernelGGL(conv::maxpool_kernel<u16>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream,
                            (const u16 *)x, scale, shift, (u16 *)y, B, H, W, C, Ho, Wo);
