@@ -11,15 +11,21 @@
 
 namespace mhe { namespace conv {
 
-constexpr int ST_PIX = 64, ST_BN = 256;
+constexpr int ST_PIX = 64;
 
-template <int KT, bool BNLOAD>      // KT = Cin / 64
-__global__ __launch_bounds__(256, KT == 1 ? 2 : 1) void conv1x1_stream_kernel(const Params p, int nchunks, int ntiles_n) {
+// DG: the data-gradient epilogue of conv_shared.h (residual - full or half resolution -, ReLU gate by p.mask, BatchNorm-reverse sums of up to
+// two units) applied in the store loop; used for the data gradient of a bottleneck's conv1 (K = 64 / 128 -> 256 / 512)
+// ST_BN = output channels per workgroup (256, or 128 where the weight tile of 256 would not leave room: K = 256, or to run two workgroups per
+// CU at K = 128)
+template <int KT, int ST_BN, bool BNLOAD, bool DG = false>      // KT = Cin / 64
+__global__ __launch_bounds__(256, (ST_BN * KT + 2 * ST_PIX * KT) * 128 + ST_PIX * ST_BN * 2 <= 80 * 1024 ? 2 : 1)
+void conv1x1_stream_kernel(const Params p, int nchunks, int ntiles_n) {
     using T = u16;
-    constexpr int NTH = 256, CPR = ST_BN * 2 / 16;                // 32 sixteen-byte chunks per output row
+    constexpr int NTH = 256, CPR = ST_BN * 2 / 16;                // sixteen-byte chunks per output row
+    constexpr int NTW = ST_BN / 64, NJ = ST_PIX * CPR / NTH;      // 16-channel tiles per wave; staged chunks per thread
     __shared__ uint4 Wl[ST_BN * 8 * KT];                          // weights: 256 rows x (KT x 128 B), XOR-swizzled like the tiled kernels
     __shared__ uint4 Al[2][ST_PIX * 8 * KT];                      // activations of a chunk, double-buffered
-    __shared__ uint4 Ol[ST_PIX * CPR];                            // output staging (32 KiB); statistic partials at the end
+    __shared__ uint4 Ol[ST_PIX * CPR > NTH ? ST_PIX * CPR : NTH];    // output staging; statistic partials at the end (256 threads x 16 floats)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, l15 = lane & 15;
     const int nt_id = blockIdx.x % ntiles_n, wg = blockIdx.x / ntiles_n, nwg = gridDim.x / ntiles_n;
     const int n0 = nt_id * ST_BN;
@@ -77,10 +83,26 @@ __global__ __launch_bounds__(256, KT == 1 ? 2 : 1) void conv1x1_stream_kernel(co
                 Al[buf][kt * ST_PIX * 8 + swz(rbase + 32 * j, s)] = v;
             }
     };
-    const bool st_on = p.stats != nullptr;
+    const bool st_on = !DG && p.stats != nullptr;
     float ss1[8], ss2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) ss1[i] = ss2[i] = 0.f;
+    // data-gradient form: this thread's 8 channels are fixed (chunk column tid % 32) - BatchNorm-reverse operands and partial sums
+    const int ccol = n0 + (tid % CPR) * 8;
+    const T *mk = reinterpret_cast<const T *>(p.mask), *rg = reinterpret_cast<const T *>(p.residual);
+    const T *y0g = reinterpret_cast<const T *>(p.bn_y[0]), *y1g = reinterpret_cast<const T *>(p.bn_y[1]);
+    float bs1[DG ? 2 : 1][8], bs2[DG ? 2 : 1][8], bmu[DG ? 2 : 1][8], biv[DG ? 2 : 1][8];
+    if constexpr (DG) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool ok = p.bn_y[u] != nullptr && ccol + i < p.Cout;
+                bs1[u][i] = bs2[u][i] = 0.f;
+                bmu[u][i] = ok ? p.bn_mi[u][ccol + i] : 0.f;
+                biv[u][i] = ok ? p.bn_mi[u][p.Cout + ccol + i] : 0.f;
+            }
+    }
 
     load_chunk(wg);
     int it = 0;
@@ -89,22 +111,22 @@ __global__ __launch_bounds__(256, KT == 1 ? 2 : 1) void conv1x1_stream_kernel(co
         store_chunk(buf, c);
         load_chunk(c + nwg);                                     // in flight during this chunk's product and stores
         __syncthreads();
-        v4f acc[4][4];                                           // [channel tile of this wave's 64][pixel tile]
+        v4f acc[NTW][4];                                         // [channel tile of this wave's ST_BN / 4][pixel tile]
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < NTW; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                uint4 fa[4], fb[4];
+                uint4 fa[4], fb[NTW];
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) fa[mt] = Al[buf][kt * ST_PIX * 8 + swz(mt * 16 + l15, kk * 4 + q)];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) fb[nt] = Wl[kt * ST_BN * 8 + swz(wave * 64 + nt * 16 + l15, kk * 4 + q)];
+                for (int nt = 0; nt < NTW; ++nt) fb[nt] = Wl[kt * ST_BN * 8 + swz(wave * (ST_BN / 4) + nt * 16 + l15, kk * 4 + q)];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+                for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt)
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
@@ -115,10 +137,10 @@ __global__ __launch_bounds__(256, KT == 1 ? 2 : 1) void conv1x1_stream_kernel(co
         {
             unsigned char *ot = reinterpret_cast<unsigned char *>(Ol);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
-                    const int row = mt * 16 + l15, boff = (wave * 64 + nt * 16 + 4 * q) * 2;
+                    const int row = mt * 16 + l15, boff = (wave * (ST_BN / 4) + nt * 16 + 4 * q) * 2;
                     const int chunk = (boff >> 4) ^ (row & 15);
                     const v4f v = acc[nt][mt];
                     uint2 o;
@@ -130,14 +152,67 @@ __global__ __launch_bounds__(256, KT == 1 ? 2 : 1) void conv1x1_stream_kernel(co
         __syncthreads();
         {
             const unsigned char *ot = reinterpret_cast<const unsigned char *>(Ol);
-            uint4 raw[8];
+            if constexpr (DG) {
+#pragma unroll 1
+                for (int j0 = 0; j0 < NJ; j0 += 4) {                 // 4 rows at a time: their operand loads are issued together
+                    uint4 raw[4], gm[4], rr[4], ya[4], yb[4];
+                    size_t off[4];
+                    bool okr[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+                    for (int g = 0; g < 4; ++g) {
+                        const int id = tid + NTH * (j0 + g), row = id / CPR, cc = id % CPR;
+                        const long m = (long)c * ST_PIX + row;
+                        okr[g] = m < p.M && ccol < p.Cout;
+                        const long mc = okr[g] ? m : 0;
+                        off[g] = (size_t)mc * p.Cout + ccol;
+                        gm[g] = *reinterpret_cast<const uint4 *>(mk + off[g]);
+                        rr[g] = make_uint4(0u, 0u, 0u, 0u);
+                        if (rg) {
+                            if (p.res_s2) {
+                                const long hr = res_half_row(p, mc);
+                                if (hr >= 0) rr[g] = *reinterpret_cast<const uint4 *>(rg + (size_t)hr * p.Cout + ccol);
+                            } else rr[g] = *reinterpret_cast<const uint4 *>(rg + off[g]);
+                        }
+                        if (y0g) ya[g] = *reinterpret_cast<const uint4 *>(y0g + off[g]);
+                        if (y1g) yb[g] = *reinterpret_cast<const uint4 *>(y1g + off[g]);
+                        raw[g] = *reinterpret_cast<const uint4 *>(ot + ((size_t)row * CPR + (cc ^ (row & 15))) * 16);
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (!okr[g]) continue;
+                        float v[8], t[8];
+                        Chunk<T>::unpack(raw[g], v);
+                        if (rg) {
+                            Chunk<T>::unpack(rr[g], t);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) v[i] += t[i];
+                        }
+                        Chunk<T>::unpack(gm[g], t);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] = t[i] > 0.f ? v[i] : 0.f;
+                        if (y0g) {
+                            Chunk<T>::unpack(ya[g], t);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) { bs1[0][i] += v[i]; bs2[0][i] = fmaf(v[i], (t[i] - bmu[0][i]) * biv[0][i], bs2[0][i]); }
+                        }
+                        if (y1g) {
+                            Chunk<T>::unpack(yb[g], t);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) { bs1[1][i] += v[i]; bs2[1][i] = fmaf(v[i], (t[i] - bmu[1][i]) * biv[1][i], bs2[1][i]); }
+                        }
+                        *reinterpret_cast<uint4 *>(yg + off[g]) = Chunk<T>::pack(v);
+                    }
+                }
+                continue;
+            }
+            uint4 raw[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
                 const int id = tid + NTH * j, row = id / CPR, cc = id % CPR;
                 raw[j] = *reinterpret_cast<const uint4 *>(ot + ((size_t)row * CPR + (cc ^ (row & 15))) * 16);
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int id = tid + NTH * j, row = id / CPR, cc = id % CPR;
                 const long m = (long)c * ST_PIX + row;
                 const int n = n0 + cc * 8;
@@ -154,6 +229,26 @@ __global__ __launch_bounds__(256, KT == 1 ? 2 : 1) void conv1x1_stream_kernel(co
         }
         // (the next iteration's barrier separates these staging reads from its staging writes)
     }
+    if constexpr (DG) {
+        float *red = reinterpret_cast<float *>(Ol);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!p.bn_y[u]) continue;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { red[tid * 16 + i] = bs1[u][i]; red[tid * 16 + 8 + i] = bs2[u][i]; }
+            __syncthreads();
+            const int cch = tid / 8, e = tid % 8, n = n0 + tid;
+            float a = 0.f, b = 0.f;
+            if (tid < ST_BN)
+                for (int k = 0; k < NTH / CPR; ++k) { a += red[(cch + CPR * k) * 16 + e]; b += red[(cch + CPR * k) * 16 + 8 + e]; }
+            if (tid < ST_BN && n < p.Cout) {
+                float *st = p.bn_stats[u] + (size_t)(wg % NSH) * 2 * p.Cout;
+                atomicAdd(st + n, a);
+                atomicAdd(st + p.Cout + n, b);
+            }
+        }
+    }
     if (st_on) {
         float *red = reinterpret_cast<float *>(Ol);
         __syncthreads();
@@ -162,8 +257,9 @@ __global__ __launch_bounds__(256, KT == 1 ? 2 : 1) void conv1x1_stream_kernel(co
         __syncthreads();
         const int cch = tid / 8, e = tid % 8, n = n0 + tid;      // channel tid = chunk column cch, element e
         float a = 0.f, b = 0.f;
-        for (int k = 0; k < NTH / CPR; ++k) { a += red[(cch + CPR * k) * 16 + e]; b += red[(cch + CPR * k) * 16 + 8 + e]; }
-        if (n < p.Cout) {
+        if (tid < ST_BN)
+            for (int k = 0; k < NTH / CPR; ++k) { a += red[(cch + CPR * k) * 16 + e]; b += red[(cch + CPR * k) * 16 + 8 + e]; }
+        if (tid < ST_BN && n < p.Cout) {
             const int shard = wg % NSH;
             atomicAdd(p.stats + ((size_t)shard * 2) * p.Cout + n, a);
             atomicAdd(p.stats + ((size_t)shard * 2 + 1) * p.Cout + n, b);
@@ -172,26 +268,43 @@ __global__ __launch_bounds__(256, KT == 1 ? 2 : 1) void conv1x1_stream_kernel(co
 }
 
 // geometry this kernel takes
+// output-channel tile for a geometry: 256 at K = 64 (two workgroups per CU), 128 at K = 128 (two per CU) and at K = 256 (one)
+// (measured, tools/conv_variants.py / dg_variants.py: at K = 128 the plain / on-load forms run 85 / 95 us on the 256 tile against 96 / 105 us
+// on the 128 tile, the data-gradient form 254 against 227 us)
+static int stream_bn(const Params &p) { return p.Cin == 64 ? 256 : (p.Cin == 128 && !p.mask ? 256 : 128); }
+
 bool stream_supports(const Params &p) {
-    return p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && (p.Cin == 64 || p.Cin == 128) && p.Kpad == p.Cin && p.Cout % ST_BN == 0 &&
-           !p.x2 && !p.mask && !p.residual && !p.out_scale && !p.out_shift && !p.relu_out && !p.y32 && !p.os2 && !p.a_out &&
-           p.M >= 64 * 1024;
+    if (!(p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && (p.Cin == 64 || p.Cin == 128 || p.Cin == 256) && p.Kpad == p.Cin &&
+          !p.x2 && !p.out_scale && !p.out_shift && !p.relu_out && !p.y32 && !p.os2 && !p.a_out && p.M >= 64 * 1024))
+        return false;
+    if (p.Cout % stream_bn(p)) return false;
+    if (p.Cin == 256 && !p.mask) return false;             // K = 256: only the data-gradient form gains (147 vs 158 us); plain 85 vs 63 us on the tiled kernel
+    if (p.mask) return !p.in_scale && !p.stats;            // data-gradient form
+    return !p.residual;
+}
+
+template <int KT, int NB>
+static void launch_stream_t(const Params &p, hipStream_t s, dim3 grid, int nchunks, int ntn) {
+    const dim3 block(256);
+    if (p.mask) hipLaunchKernelGGL((conv1x1_stream_kernel<KT, NB, false, true>), grid, block, 0, s, p, nchunks, ntn);
+    else if constexpr (KT <= 2) {
+        if (p.in_scale) hipLaunchKernelGGL((conv1x1_stream_kernel<KT, NB, true>), grid, block, 0, s, p, nchunks, ntn);
+        else hipLaunchKernelGGL((conv1x1_stream_kernel<KT, NB, false>), grid, block, 0, s, p, nchunks, ntn);
+    } else hipLaunchKernelGGL((conv1x1_stream_kernel<KT, NB, false>), grid, block, 0, s, p, nchunks, ntn);
 }
 
 int launch_stream(const Params &p, hipStream_t s) {
-    const int nchunks = (p.M + ST_PIX - 1) / ST_PIX, ntn = p.Cout / ST_BN;
-    const int per_cu = p.Cin == 64 ? 2 : 1;
+    const int nb = stream_bn(p);
+    const int nchunks = (p.M + ST_PIX - 1) / ST_PIX, ntn = p.Cout / nb;
+    const int per_cu = (p.Cin == 256 || (p.Cin == 128 && nb == 256)) ? 1 : 2;
     int nwg = 256 * per_cu / ntn;                                  // resident workgroups: pixel groups x N tiles
     if (nwg < 1) nwg = 1;
     if (nwg > nchunks) nwg = nchunks;
-    const dim3 grid((unsigned)(nwg * ntn)), block(256);
-    if (p.Cin == 64) {
-        if (p.in_scale) hipLaunchKernelGGL((conv1x1_stream_kernel<1, true>), grid, block, 0, s, p, nchunks, ntn);
-        else hipLaunchKernelGGL((conv1x1_stream_kernel<1, false>), grid, block, 0, s, p, nchunks, ntn);
-    } else {
-        if (p.in_scale) hipLaunchKernelGGL((conv1x1_stream_kernel<2, true>), grid, block, 0, s, p, nchunks, ntn);
-        else hipLaunchKernelGGL((conv1x1_stream_kernel<2, false>), grid, block, 0, s, p, nchunks, ntn);
-    }
+    const dim3 grid((unsigned)(nwg * ntn));
+    if (p.Cin == 64) launch_stream_t<1, 256>(p, s, grid, nchunks, ntn);
+    else if (p.Cin == 128 && nb == 256) launch_stream_t<2, 256>(p, s, grid, nchunks, ntn);
+    else if (p.Cin == 128) launch_stream_t<2, 128>(p, s, grid, nchunks, ntn);
+    else launch_stream_t<4, 128>(p, s, grid, nchunks, ntn);
     return check_launch("conv1x1_stream_kernel");
 }
 

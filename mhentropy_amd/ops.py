@@ -53,7 +53,7 @@ def _conv_kernel_name(d, dt, mode):
     bke = 32 if dt == torch.float32 else 64
     tile = _lib.lib().mhe_conv_tile_mode(C.byref(d), mode)
     if tile == 8:
-        return "mhe::conv::conv1x1_stream_kernel<%d, %s>" % (d.Cin // 64, "true" if mode == 1 else "false")
+        return "mhe::conv::conv1x1_stream_kernel<%d, %d, %s, false>" % (d.Cin // 64, 256 if d.Cin <= 128 else 128, "true" if mode == 1 else "false")
     if tile == 7:
         return "mhe::conv::conv_p8_kernel<false, %s, 0>" % ("false" if d.KH == 1 and d.KW == 1 and d.pad == 0 else "true")
     return "mhe::conv::conv_kernel<%s, %s, %s, %d, false>" % ("float" if dt == torch.float32 else "unsigned short",
