@@ -634,6 +634,8 @@ bool p8_supports(const Params &p);             // conv_p8.hip: the phase-pipelin
 int launch_p8(const Params &p, hipStream_t s);
 bool stream_supports(const Params &p);         // conv_stream.hip: the streaming 1x1 kernel for K = 64 / 128 (variant 8)
 int launch_stream(const Params &p, hipStream_t s);
+bool stream3_supports(const Params &p);        // conv_stream.hip: the row-streaming 3x3 kernel for 64 -> 64 channels (variant 9)
+int launch_stream3(const Params &p, hipStream_t s);
 
 // tile choice: 0 = 128x64, 1 = 128x128, 2 = 256x256 (FAST only; needs >= ~3/4 of the CUs' worth of tiles)
 static int choose_tile(const Params &p, bool fast, bool bf16) {
@@ -641,6 +643,7 @@ static int choose_tile(const Params &p, bool fast, bool bf16) {
     const int force = p.force >= 0 ? p.force : env_force;
     static const int env_stream = getenv("MHE_CONV_STREAM") ? atoi(getenv("MHE_CONV_STREAM")) : 1;
     if (bf16 && (force == 8 || (force < 0 && env_stream)) && stream_supports(p)) return 8;
+    if (bf16 && (force == 9 || (force < 0 && env_stream)) && stream3_supports(p)) return 9;
     if ((force & 15) == 7 && bf16 && p8_supports(p)) return 7;      // (higher bits: ablation builds of tuning runs)
     if (force >= 0 && force <= 4 && (force < 2 || (fast && bf16))) return force;
     if (p.Cout <= 64) return 0;
@@ -666,6 +669,7 @@ static int launch_conv(const Params &p, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
         const int t0 = choose_tile(p, fast, true);
         if (t0 == 8) return launch_stream(p, s);
+        if (t0 == 9) return launch_stream3(p, s);
         if (t0 == 7) return launch_p8(p, s);
     }
     if (p.x2 && !fast) { set_error("residual-tail prologue needs Cin %% %d == 0", BKE); return MHE_ERR_ARG; }

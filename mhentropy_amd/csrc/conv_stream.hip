@@ -269,6 +269,298 @@ void conv1x1_stream_kernel(const Params p, int nchunks, int ntiles_n) {
 
 // geometry this kernel takes
 // output-channel tile for a geometry: 256 at K = 64 (two workgroups per CU), 128 at K = 128 (two per CU) and at K = 256 (one)
+// ---------------------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 at 64 -> 64 channels on 64-pixel-wide maps (ResNet-50 layer1's conv2 at 256x256 input, and its data gradient):
+// 77 GFLOP per launch at C2 but only 268 MB - the tiled kernel re-stages every input pixel nine times (once per tap) through L2 -> LDS and
+// runs at ~570 TF.  Here the 72 KiB of weights stay in LDS, a workgroup walks the rows of whole images keeping the three input rows of
+// the current output row (plus the one in flight) in a ring of LDS row buffers with zero pad columns: every input pixel is loaded once
+// and all nine taps read it from LDS.  Optional producer BatchNorm + ReLU applied once per input element on the load (the tiled on-load
+// form repeats it per tap), statistics / data-gradient epilogue in the store loop as in the 1x1 kernel.
+// Row images read at pixel offsets 0, 1, 2 (the three taps of a row): the ds_read_b128 lane groups are {0-3, 12-15, 20-27}, ... = 8 rows
+// at chunk c and 8 rows at chunk c ^ 1, and conv_shared.h's swz() is conflict-free for them only when the first row is a multiple of
+// 16.  XOR with 2 * ((row >> 1) & 3) is conflict-free for every first row (rows of one parity: the 4 + 4 rows cover all four values).
+__device__ __forceinline__ int swz3(int row, int slot) { return row * 8 + (slot ^ (((row >> 1) & 3) << 1)); }
+
+// Two roles in one 512-thread workgroup (one wave of each role per SIMD):
+//   multiply waves 0-3 : per tick 144 MFMAs (two output rows x 64 pixels x 64 channels; a wave = 32 pixels of one row, all channels), then the
+//                        accumulators as bf16 into the staging buffer of this tick's parity;
+//   transfer waves 4-7 : global loads of the input rows two ticks ahead into registers, (BatchNorm + ReLU,) the row pair of the next tick into
+//                        the ring, and the epilogue of the PREVIOUS tick's output (staging -> batch statistics or the data-gradient
+//                        epilogue -> 16-byte global stores).
+// One barrier per tick.  Input rows travel in pairs (2k - 1, 2k), k = 0 .. ceil(H / 2); tick t holds pair t of the flat stream over this
+// workgroup's images and multiplies the step whose second pair it is (no step on an image's first pair: 1 tick in 33 idle at H = 64).
+// With one role doing everything in turn (the first version) the MFMA pipe idled during loads, staging and stores: 96 us; the 16-pixel
+// wave tile before that needed 320 B/clk of LDS reads per CU: 127 us.
+template <bool BNLOAD, bool DG>
+__global__ __launch_bounds__(512) void conv3x3_c64_stream_kernel(const Params p) {
+    using T = u16;
+    constexpr int NTH = 512, NT2 = 256, CPR = 8, WPX = 64, RROW = (WPX + 2) * 8;   // 16-byte chunks per output row; uint4 per row buffer
+    __shared__ uint4 Wl[9 * 64 * 8];                                        // [tap][64 output channels][64 input channels]          72 KiB
+    __shared__ uint4 Rl[6][RROW];                                           // three pair slots; pixel slots 0 and 65 = zero padding 49.5 KiB
+    __shared__ uint4 Ol[2][1024];                                           // output staging of two rows, by tick parity            32 KiB
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, l15 = lane & 15;
+    const bool mult = wave < 4;
+    const int t2 = tid & (NT2 - 1);
+    const int s = t2 & 7, pbase = t2 >> 3;
+    const int wrow = (wave >> 1) & 1, wpx = (wave & 1) * 32;                // multiply wave: output row y + wrow, pixels wpx .. wpx + 31
+    const T *xg = reinterpret_cast<const T *>(p.x);
+    const T *wg_ = reinterpret_cast<const T *>(p.w);
+    T *yg = reinterpret_cast<T *>(p.y);
+    const int H = p.H;
+    const int npair = (H + 1) / 2 + 1;                                      // pairs per image
+    const int nimg = (p.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int NT = nimg * npair;
+    for (int i = tid; i < 9 * 64 * 8; i += NTH) {
+        const int sl = i & 7, co = (i >> 3) & 63, tap = i >> 9;
+        Wl[tap * 512 + swz3(co, sl)] = *reinterpret_cast<const uint4 *>(wg_ + (size_t)co * p.Kpad + tap * 64 + sl * 8);
+    }
+    if (tid < 6 * 16) {                                                      // pad columns of the row buffers: zero for good
+        const int b = tid >> 4, sl = tid & 7, px = (tid & 8) ? WPX + 1 : 0;
+        Rl[b][swz3(px, sl)] = make_uint4(0, 0, 0, 0);
+    }
+    const bool st_on = !DG && p.stats != nullptr;
+    float ss1[8], ss2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ss1[i] = ss2[i] = 0.f;
+    const int ccol = (t2 % CPR) * 8;
+    float bs1[DG ? 2 : 1][8], bs2[DG ? 2 : 1][8];
+#pragma unroll
+    for (int u = 0; u < (DG ? 2 : 1); ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bs1[u][i] = bs2[u][i] = 0.f;
+
+    if (mult) {
+        int ck = 0, sp = 2, sc_ = 0;                                        // pair index inside the image at this tick; slots of the previous / this pair
+        for (int t = 0; t <= NT; ++t) {
+            __syncthreads();
+            if (t < NT && ck >= 1) {
+                v4f acc[4][2];                                               // [channel tile][pixel tile of this wave's 32]
+#pragma unroll
+                for (int a = 0; a < 4; ++a) { acc[a][0] = v4f{0.f, 0.f, 0.f, 0.f}; acc[a][1] = v4f{0.f, 0.f, 0.f, 0.f}; }
+                // 18 k-steps (tap, 32-channel half), software-pipelined: the fragments of step i + 1 are read while step i multiplies;
+                // per k-step a wave reads 2 activation + 4 weight fragments for 8 MFMAs
+                uint4 fa[2][2], fb[2][4];
+                auto frag = [&](int i, int bi) {
+                    const int kh = i / 6, kw = (i / 2) % 3, kk = i & 1;
+                    const int d = wrow + kh;                                 // input row y - 1 + d: rows 0, 1 of the previous pair, then of this one
+                    const uint4 *row = Rl[(d < 2 ? sp : sc_) * 2 + (d & 1)];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) fa[bi][mt] = row[swz3(wpx + mt * 16 + l15 + kw, kk * 4 + q)];
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) fb[bi][nt] = Wl[(kh * 3 + kw) * 512 + swz3(nt * 16 + l15, kk * 4 + q)];
+                };
+                frag(0, 0);
+#pragma unroll
+                for (int i = 0; i < 18; ++i) {
+                    if (i + 1 < 18) frag(i + 1, (i + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);                       // left alone the scheduler sinks each read to just before its use
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+                            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fb[i & 1][nt]),
+                                __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fa[i & 1][mt]), acc[nt][mt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                unsigned char *ot = reinterpret_cast<unsigned char *>(Ol[t & 1]);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const int row = wrow * WPX + wpx + mt * 16 + l15, boff = (nt * 16 + 4 * q) * 2;     // staging row = (output row, pixel)
+                        const int chunk = (boff >> 4) ^ (row & 7);
+                        const v4f v = acc[nt][mt];
+                        uint2 o;
+                        o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                        o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                        *reinterpret_cast<uint2 *>(ot + ((size_t)row * CPR + chunk) * 16 + (boff & 15)) = o;
+                    }
+            }
+            sp = sc_;
+            sc_ = sc_ == 2 ? 0 : sc_ + 1;
+            if (++ck == npair) ck = 0;
+        }
+    } else {
+        float sc[8], sh[8];
+        if constexpr (BNLOAD) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { sc[i] = p.in_scale[s * 8 + i]; sh[i] = p.in_shift[s * 8 + i]; }
+        }
+        const T *mk = reinterpret_cast<const T *>(p.mask), *rg = reinterpret_cast<const T *>(p.residual);
+        const T *y0g = reinterpret_cast<const T *>(p.bn_y[0]), *y1g = reinterpret_cast<const T *>(p.bn_y[1]);
+        float bmu[DG ? 2 : 1][8], biv[DG ? 2 : 1][8];
+        if constexpr (DG) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const bool ok = p.bn_y[u] != nullptr;
+                    bmu[u][i] = ok ? p.bn_mi[u][ccol + i] : 0.f;
+                    biv[u][i] = ok ? p.bn_mi[u][64 + ccol + i] : 0.f;
+                }
+        }
+        // two pairs in flight in registers (set = pair parity in the flat stream): a pair is loaded two ticks before it is written to LDS
+        uint4 ra[2][2][2];
+        auto load_pair = [&](int img, int k, auto SET) {                     // rows 2k - 1, 2k of this workgroup's img-th image; outside [0, H): zeros
+            constexpr int set = decltype(SET)::value;
+            const size_t b = (size_t)blockIdx.x + (size_t)img * gridDim.x;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    ra[set][e][j] = (unsigned)(2 * k - 1 + e) < (unsigned)H
+                                        ? *reinterpret_cast<const uint4 *>(xg + ((b * H + 2 * k - 1 + e) * WPX + pbase + 32 * j) * 64 + s * 8)
+                                        : make_uint4(0, 0, 0, 0);
+        };
+        auto store_pair = [&](int k, int slot, auto SET) {
+            constexpr int set = decltype(SET)::value;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    uint4 v = ra[set][e][j];
+                    if constexpr (BNLOAD) {
+                        if ((unsigned)(2 * k - 1 + e) < (unsigned)H) {       // padding rows stay zero
+                            float f[8];
+                            Chunk<T>::unpack(v, f);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                f[i] = fmaf(f[i], sc[i], sh[i]);
+                                if (p.relu_in) f[i] = fmaxf(f[i], 0.f);
+                            }
+                            v = Chunk<T>::pack(f);
+                        }
+                    }
+                    Rl[slot * 2 + e][swz3(pbase + 32 * j + 1, s)] = v;
+                }
+        };
+        // the output rows 2(k - 1), 2(k - 1) + 1 of image img, staged in Ol[par]
+        auto epilogue = [&](int img, int k, int par) {
+            const unsigned char *ot = reinterpret_cast<const unsigned char *>(Ol[par]);
+            const int y = 2 * (k - 1);
+            const size_t m0 = (((size_t)blockIdx.x + (size_t)img * gridDim.x) * H + y) * WPX;
+            const int nrows = (y + 1 < H ? 2 : 1) * WPX;                     // staged pixels that exist
+            uint4 raw[4], gm[4], rr[4], ya[4], yb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int id = t2 + NT2 * j, row = id / CPR, cc = id % CPR;
+                const size_t off = (m0 + (row < nrows ? row : 0)) * 64 + ccol;
+                if constexpr (DG) {
+                    gm[j] = *reinterpret_cast<const uint4 *>(mk + off);
+                    rr[j] = rg ? *reinterpret_cast<const uint4 *>(rg + off) : make_uint4(0, 0, 0, 0);
+                    if (y0g) ya[j] = *reinterpret_cast<const uint4 *>(y0g + off);
+                    if (y1g) yb[j] = *reinterpret_cast<const uint4 *>(y1g + off);
+                }
+                raw[j] = *reinterpret_cast<const uint4 *>(ot + ((size_t)row * CPR + (cc ^ (row & 7))) * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int id = t2 + NT2 * j, row = id / CPR;
+                if (row >= nrows) continue;
+                const size_t off = (m0 + row) * 64 + ccol;
+                if constexpr (DG) {
+                    float v[8], t[8];
+                    Chunk<T>::unpack(raw[j], v);
+                    if (rg) {
+                        Chunk<T>::unpack(rr[j], t);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] += t[i];
+                    }
+                    Chunk<T>::unpack(gm[j], t);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = t[i] > 0.f ? v[i] : 0.f;
+                    if (y0g) {
+                        Chunk<T>::unpack(ya[j], t);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { bs1[0][i] += v[i]; bs2[0][i] = fmaf(v[i], (t[i] - bmu[0][i]) * biv[0][i], bs2[0][i]); }
+                    }
+                    if (y1g) {
+                        Chunk<T>::unpack(yb[j], t);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { bs1[1][i] += v[i]; bs2[1][i] = fmaf(v[i], (t[i] - bmu[1][i]) * biv[1][i], bs2[1][i]); }
+                    }
+                    *reinterpret_cast<uint4 *>(yg + off) = Chunk<T>::pack(v);
+                } else {
+                    if (st_on) {
+                        float f[8];
+                        Chunk<T>::unpack(raw[j], f);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { ss1[i] += f[i]; ss2[i] = fmaf(f[i], f[i], ss2[i]); }
+                    }
+                    *reinterpret_cast<uint4 *>(yg + off) = raw[j];
+                }
+            }
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        int li = 0, lk = 0;                                                  // next pair to load
+        auto next_load = [&](auto SET) {
+            if (li < nimg) load_pair(li, lk, SET);
+            if (++lk == npair) { lk = 0; ++li; }
+        };
+        next_load(S0{});
+        store_pair(0, 0, S0{});                                              // pair 0 (the only exposed load)
+        next_load(S1{});                                                     // pair 1: written in tick 0
+        next_load(S0{});                                                     // pair 2: written in tick 1
+        int wk = 1, ws = 1;                                                  // the pair written in this tick (t + 1): index in its image, slot
+        int ci = 0, ck = 0, pi = 0, pk = 0;                                  // pair of this tick, of the previous tick
+        auto tick = [&](int t, auto SET) {
+            __syncthreads();
+            if (t + 1 < NT) store_pair(wk, ws, SET);
+            if (++wk == npair) wk = 0;
+            ws = ws == 2 ? 0 : ws + 1;
+            next_load(SET);                                                  // pair t + 3
+            if (t >= 1 && pk >= 1) epilogue(pi, pk, (t - 1) & 1);
+            pi = ci; pk = ck;
+            if (++ck == npair) { ck = 0; ++ci; }
+        };
+        for (int t = 0; t <= NT; t += 2) {
+            tick(t, S1{});
+            if (t + 1 <= NT) tick(t + 1, S0{});
+        }
+    }
+    // fold the transfer threads' partial sums (threads sharing a column chunk: 32 of them) and add them to this workgroup's shard
+    float *red = reinterpret_cast<float *>(Ol[0]);
+    auto fold = [&](const float *a8, const float *b8, float *dst) {
+        __syncthreads();
+        if (!mult) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { red[t2 * 16 + i] = a8[i]; red[t2 * 16 + 8 + i] = b8[i]; }
+        }
+        __syncthreads();
+        if (!mult && t2 < 64) {
+            const int cch = t2 / 8, e = t2 % 8;
+            float a = 0.f, b = 0.f;
+            for (int k = 0; k < NT2 / CPR; ++k) { a += red[(cch + CPR * k) * 16 + e]; b += red[(cch + CPR * k) * 16 + 8 + e]; }
+            float *st = dst + (size_t)(blockIdx.x % NSH) * 2 * 64;
+            atomicAdd(st + t2, a);
+            atomicAdd(st + 64 + t2, b);
+        }
+    };
+    if constexpr (DG) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (p.bn_y[u]) fold(bs1[u], bs2[u], p.bn_stats[u]);
+    } else if (st_on) fold(ss1, ss2, p.stats);
+}
+
+bool stream3_supports(const Params &p) {
+    if (!(p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cin == 64 && p.Cout == 64 && p.W == 64 && p.Kpad == 576 && p.B >= 128 &&
+          p.H >= 16 && !p.x2 && !p.out_scale && !p.out_shift && !p.relu_out && !p.y32 && !p.os2 && !p.a_out && !p.res_s2))
+        return false;
+    if (p.mask) return !p.in_scale && !p.stats;
+    return !p.residual;
+}
+
+int launch_stream3(const Params &p, hipStream_t s) {
+    const dim3 grid((unsigned)(p.B < 256 ? p.B : 256)), block(512);
+    if (p.mask) hipLaunchKernelGGL((conv3x3_c64_stream_kernel<false, true>), grid, block, 0, s, p);
+    else if (p.in_scale) hipLaunchKernelGGL((conv3x3_c64_stream_kernel<true, false>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((conv3x3_c64_stream_kernel<false, false>), grid, block, 0, s, p);
+    return check_launch("conv3x3_c64_stream_kernel");
+}
+
 // (measured, tools/conv_variants.py / dg_variants.py: at K = 128 the plain / on-load forms run 85 / 95 us on the 256 tile against 96 / 105 us
 // on the 128 tile, the data-gradient form 254 against 227 us)
 static int stream_bn(const Params &p) { return p.Cin == 64 ? 256 : (p.Cin == 128 && !p.mask ? 256 : 128); }

@@ -52,6 +52,8 @@ def _conv_kernel_name(d, dt, mode):
     """the template instantiation the launcher will pick, spelled as rocprofv3 prints it"""
     bke = 32 if dt == torch.float32 else 64
     tile = _lib.lib().mhe_conv_tile_mode(C.byref(d), mode)
+    if tile == 9:
+        return "mhe::conv::conv3x3_c64_stream_kernel<%s, false>" % ("true" if mode == 1 else "false")
     if tile == 8:
         return "mhe::conv::conv1x1_stream_kernel<%d, %d, %s, false>" % (d.Cin // 64, 256 if d.Cin <= 128 else 128, "true" if mode == 1 else "false")
     if tile == 7:
@@ -63,6 +65,14 @@ def _conv_kernel_name(d, dt, mode):
 
 def dtype_code(dt):
     return F32 if dt == torch.float32 else BF16
+
+
+def conv_tile_choice(B, H, W, Cin, Cout, k, stride, pad, dt, mode=0):
+    """the tile variant the launcher picks for this convolution (mhe_conv_tile_mode; include/mhe.h lists the variants).  mode 1 = with the
+    producer's BatchNorm on the operand load.  9 = the row-streaming 3x3 kernel, whose on-load form costs one multiply-add per element read
+    ONCE (rows are normalised on their way into the LDS ring), unlike the tiled kernels that normalise every tap's re-read."""
+    d = ConvDesc(B, H, W, Cin, Cout, k, k, stride, pad, dtype_code(dt), int(mode == 1), 0, 0, 0)
+    return _lib.lib().mhe_conv_tile_mode(C.byref(d), mode)
 
 
 def linear(x, w, bias=None, relu=False, out=None):

@@ -91,6 +91,7 @@ class ResNetTrunk(nn.Module):
         # --bn-load): the saved pass is worth 56 / 28 / 14 / 7 us on layer1..4 -> "auto" = on load where the bottleneck is <= 128
         # wide (layer1, layer2), in place on layer3 / layer4 (C2 bf16 forward 9.19 ms all in place, 9.02 all on load)
         self.bn_apply_1x1 = os.environ.get("MHE_BN_APPLY_1X1", "auto")
+        self.bn_apply_3x3 = os.environ.get("MHE_BN_APPLY_3X3", "auto")
         # evaluate relu(bn3(conv3) + identity) inside the next block's conv1 (one read of the block output saved)
         self.fuse_tail = os.environ.get("MHE_FUSE_TAIL", "1") == "1"
 
@@ -156,7 +157,11 @@ class ResNetTrunk(nn.Module):
                     pending = None
                 else:
                     y1, a1 = self._conv_bn(a, blk.conv1, blk.bn1, pool)
-                y2, a2 = self._conv_bn(y1, blk.conv2, blk.bn2, pool, a1, blk.stride, 1, 3)
+                # 3x3 consumer: in place, except where the row-streaming kernel runs (layer1 at C2) - it normalises each input row once on
+                # its way into LDS (95 us against 56 + 77 us for the pass and the plain form)
+                ap2 = "load" if self.bn_apply_3x3 == "auto" and ops.conv_tile_choice(
+                    y1.shape[0], y1.shape[1], y1.shape[2], y1.shape[3], blk.conv2.out_channels, 3, blk.stride, 1, y1.dtype, 1) == 9 else None
+                y2, a2 = self._conv_bn(y1, blk.conv2, blk.bn2, pool, a1, blk.stride, 1, 3, apply=ap2)
                 ap3 = self.bn_apply_1x1 if self.bn_apply_1x1 != "auto" else ("load" if blk.conv3.in_channels <= 128 else "pass")
                 yl, al = self._conv_bn(y2, blk.conv3, blk.bn3, pool, a2, apply=ap3)
             else:

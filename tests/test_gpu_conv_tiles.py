@@ -294,3 +294,47 @@ def test_streaming_1x1_kernel_data_gradient_form(gpu_lib, shape, nbn, res):
         a, b = bns[0][u][2].sum(0).cpu(), bns[1][u][2].sum(0).cpu()
         scale = b.abs().max(1, keepdim=True)[0] + 1.0
         assert ((a - b).abs() <= 2e-2 * scale).all(), f"BatchNorm-reverse sums of unit {u}"
+
+
+@pytest.mark.parametrize("form", ["plain", "bn-on-load", "data-gradient"])
+@pytest.mark.parametrize("B,H", [(128, 16), (130, 19)])
+def test_row_streaming_3x3_kernel(gpu_lib, B, H, form):
+    """conv3x3_c64_stream_kernel (variant 9: 3x3 / stride 1 / pad 1, 64 -> 64 channels, 64-pixel-wide maps; weights and a ring of input
+    rows resident in LDS): picked by the launcher and forced; against conv2d on the bf16-rounded operands (producer BatchNorm + ReLU
+    applied in f32 to the operand and rounded, zero padding AFTER it), statistics of the stored output, and - data-gradient form - against
+    the register-staged data-gradient kernel"""
+    from mhentropy_amd import ops, resnet
+    W, C = 64, 64
+    g, x, w = _operands(B + H, B, H, W, C, C, 3)
+    xd = _nhwc(x)
+    wd = resnet.pack_conv_weight(w, torch.bfloat16).cuda()
+    if form == "data-gradient":
+        rnd = lambda *s: torch.randn(*s, generator=g).bfloat16().cuda()
+        mask, res, by = rnd(B, H, W, C), rnd(B, H, W, C), rnd(B, H, W, C)
+        mi = torch.stack([torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5]).cuda().contiguous()
+        st = [torch.zeros(ops.stat_shards(), 2, C, device="cuda") for _ in range(2)]
+        got = ops.conv2d_nhwc(xd, wd, 3, 3, 1, 1, residual=res, mask=mask, bn=[(by, mi, st[0])], tile=10)
+        auto = ops.conv2d_nhwc(xd, wd, 3, 3, 1, 1, residual=res, mask=mask, tile=0)
+        want = ops.conv2d_nhwc(xd, wd, 3, 3, 1, 1, residual=res, mask=mask, bn=[(by, mi, st[1])], tile=1)
+        assert torch.equal(got, auto)
+        assert_close(got.float().cpu(), want.float().cpu(), 8e-3, what="gated data gradient")
+        a, b = st[0].sum(0).cpu(), st[1].sum(0).cpu()
+        assert ((a - b).abs() <= 2e-2 * (b.abs().max(1, keepdim=True)[0] + 1.0)).all(), "BatchNorm-reverse sums"
+        return
+    kw, xin = {}, x
+    if form == "bn-on-load":
+        sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+        kw = dict(in_scale=sc.cuda(), in_shift=sh.cuda(), relu_in=True)
+        xin = torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).bfloat16().float()
+    ref = F.conv2d(xin.double(), w.double(), None, 1, 1)
+    for tile in (0, 10):
+        stats = torch.zeros(ops.stat_shards(), 2, C, device="cuda")
+        y = ops.conv2d_nhwc(xd, wd, 3, 3, 1, 1, stats=stats, tile=tile, **kw)
+        assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, TOL, what="raw conv")
+        n = ref.numel() / C
+        stt = stats.double().sum(0).cpu()
+        ys = y.double().cpu().permute(0, 3, 1, 2)
+        assert_close(stt[0] / n, ys.mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean")
+        assert_close(stt[1] / n, (ys ** 2).mean((0, 2, 3)), 1e-5, what="batch E[x^2]")
+    forced = ops.conv2d_nhwc(xd, wd, 3, 3, 1, 1, tile=1, **kw)
+    assert_close(y.float().cpu(), forced.float().cpu(), 8e-3, what="vs the tiled kernel")
