@@ -340,7 +340,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_stream_kernel(const Params p)
                 // 18 k-steps (tap, 32-channel half), software-pipelined: the fragments of step i + 1 are read while step i multiplies;
                 // per k-step a wave reads 2 activation + 4 weight fragments for 8 MFMAs
                 uint4 fa[2][2], fb[2][4];
-                auto frag = [&](int i, int bi) {
+                auto frag = [&](int i, int bi) __attribute__((always_inline)) {
                     const int kh = i / 6, kw = (i / 2) % 3, kk = i & 1;
                     const int d = wrow + kh;                                 // input row y - 1 + d: rows 0, 1 of the previous pair, then of this one
                     const uint4 *row = Rl[(d < 2 ? sp : sc_) * 2 + (d & 1)];
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_stream_kernel(const Params p)
         }
         // two pairs in flight in registers (set = pair parity in the flat stream): a pair is loaded two ticks before it is written to LDS
         uint4 ra[2][2][2];
-        auto load_pair = [&](int img, int k, auto SET) {                     // rows 2k - 1, 2k of this workgroup's img-th image; outside [0, H): zeros
+        auto load_pair = [&](int img, int k, auto SET) __attribute__((always_inline)) {                     // rows 2k - 1, 2k of this workgroup's img-th image; outside [0, H): zeros
             constexpr int set = decltype(SET)::value;
             const size_t b = (size_t)blockIdx.x + (size_t)img * gridDim.x;
 #pragma unroll
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_stream_kernel(const Params p)
                                         ? *reinterpret_cast<const uint4 *>(xg + ((b * H + 2 * k - 1 + e) * WPX + pbase + 32 * j) * 64 + s * 8)
                                         : make_uint4(0, 0, 0, 0);
         };
-        auto store_pair = [&](int k, int slot, auto SET) {
+        auto store_pair = [&](int k, int slot, auto SET) __attribute__((always_inline)) {
             constexpr int set = decltype(SET)::value;
 #pragma unroll
             for (int e = 0; e < 2; ++e)
@@ -435,23 +435,35 @@ __global__ __launch_bounds__(512) void conv3x3_c64_stream_kernel(const Params p)
                     Rl[slot * 2 + e][swz3(pbase + 32 * j + 1, s)] = v;
                 }
         };
-        // the output rows 2(k - 1), 2(k - 1) + 1 of image img, staged in Ol[par]
-        auto epilogue = [&](int img, int k, int par) {
-            const unsigned char *ot = reinterpret_cast<const unsigned char *>(Ol[par]);
-            const int y = 2 * (k - 1);
-            const size_t m0 = (((size_t)blockIdx.x + (size_t)img * gridDim.x) * H + y) * WPX;
-            const int nrows = (y + 1 < H ? 2 : 1) * WPX;                     // staged pixels that exist
-            uint4 raw[4], gm[4], rr[4], ya[4], yb[4];
+        // data-gradient operands (gate, residual, the BatchNorm units' forward outputs) of the step the multiply waves are working on:
+        // loaded one tick before the epilogue that uses them (loaded inside it, their latency was the tick: 600 us per launch)
+        uint4 gm[DG ? 4 : 1], rr[DG ? 4 : 1], ya[DG ? 4 : 1], yb[DG ? 4 : 1];
+        auto dg_load = [&](int img, int k) __attribute__((always_inline)) {
+            if constexpr (DG) {
+                const int y = 2 * (k - 1);
+                const size_t m0 = (((size_t)blockIdx.x + (size_t)img * gridDim.x) * H + y) * WPX;
+                const int nrows = (y + 1 < H ? 2 : 1) * WPX;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int id = t2 + NT2 * j, row = id / CPR, cc = id % CPR;
-                const size_t off = (m0 + (row < nrows ? row : 0)) * 64 + ccol;
-                if constexpr (DG) {
+                for (int j = 0; j < 4; ++j) {
+                    const int row = (t2 + NT2 * j) / CPR;
+                    const size_t off = (m0 + (row < nrows ? row : 0)) * 64 + ccol;
                     gm[j] = *reinterpret_cast<const uint4 *>(mk + off);
                     rr[j] = rg ? *reinterpret_cast<const uint4 *>(rg + off) : make_uint4(0, 0, 0, 0);
                     if (y0g) ya[j] = *reinterpret_cast<const uint4 *>(y0g + off);
                     if (y1g) yb[j] = *reinterpret_cast<const uint4 *>(y1g + off);
                 }
+            }
+        };
+        // the output rows 2(k - 1), 2(k - 1) + 1 of image img, staged in Ol[par]
+        auto epilogue = [&](int img, int k, int par) __attribute__((always_inline)) {
+            const unsigned char *ot = reinterpret_cast<const unsigned char *>(Ol[par]);
+            const int y = 2 * (k - 1);
+            const size_t m0 = (((size_t)blockIdx.x + (size_t)img * gridDim.x) * H + y) * WPX;
+            const int nrows = (y + 1 < H ? 2 : 1) * WPX;                     // staged pixels that exist
+            uint4 raw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int id = t2 + NT2 * j, row = id / CPR, cc = id % CPR;
                 raw[j] = *reinterpret_cast<const uint4 *>(ot + ((size_t)row * CPR + (cc ^ (row & 7))) * 16);
             }
 #pragma unroll
@@ -495,7 +507,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_stream_kernel(const Params p)
         using S0 = std::integral_constant<int, 0>;
         using S1 = std::integral_constant<int, 1>;
         int li = 0, lk = 0;                                                  // next pair to load
-        auto next_load = [&](auto SET) {
+        auto next_load = [&](auto SET) __attribute__((always_inline)) {
             if (li < nimg) load_pair(li, lk, SET);
             if (++lk == npair) { lk = 0; ++li; }
         };
@@ -505,13 +517,14 @@ __global__ __launch_bounds__(512) void conv3x3_c64_stream_kernel(const Params p)
         next_load(S0{});                                                     // pair 2: written in tick 1
         int wk = 1, ws = 1;                                                  // the pair written in this tick (t + 1): index in its image, slot
         int ci = 0, ck = 0, pi = 0, pk = 0;                                  // pair of this tick, of the previous tick
-        auto tick = [&](int t, auto SET) {
+        auto tick = [&](int t, auto SET) __attribute__((always_inline)) {
             __syncthreads();
             if (t + 1 < NT) store_pair(wk, ws, SET);
             if (++wk == npair) wk = 0;
             ws = ws == 2 ? 0 : ws + 1;
-            next_load(SET);                                                  // pair t + 3
-            if (t >= 1 && pk >= 1) epilogue(pi, pk, (t - 1) & 1);
+            if (t >= 1 && pk >= 1) epilogue(pi, pk, (t - 1) & 1);            // first everything that consumes loaded registers ...
+            next_load(SET);                                                  // ... then this tick's loads: pair t + 3
+            if (t < NT && ck >= 1) dg_load(ci, ck);
             pi = ci; pk = ck;
             if (++ck == npair) { ck = 0; ++ci; }
         };
@@ -522,7 +535,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_stream_kernel(const Params p)
     }
     // fold the transfer threads' partial sums (threads sharing a column chunk: 32 of them) and add them to this workgroup's shard
     float *red = reinterpret_cast<float *>(Ol[0]);
-    auto fold = [&](const float *a8, const float *b8, float *dst) {
+    auto fold = [&](const float *a8, const float *b8, float *dst) __attribute__((always_inline)) {
         __syncthreads();
         if (!mult) {
 #pragma unroll
