@@ -177,6 +177,37 @@ def test_resnet_trunk_bf16_storage_mode(gpu_lib, arch, bn_apply, monkeypatch):
     assert err < max(1e-2, 1.5 * err32), (err, err32)
 
 
+def test_row_streamed_3x3_bn_on_load_equals_in_place_pass(gpu_lib):
+    """At C2's geometry layer1's 3x3 convolutions run on the row-streaming kernel, which takes the producer's BatchNorm on its row load
+    (resnet.bn_apply_3x3 = "auto").  The in-place pass rounds relu(y * scale + shift) to bf16 when it stores, the kernel rounds the same
+    f32 value on its way into LDS: with the running statistics (eval) both trunks see the same affine maps and must agree to the bit;
+    with batch statistics the sums are float atomics in an order that changes from launch to launch, so there the two agree as closely as
+    two runs of one policy do."""
+    from mhentropy_amd import resnet, ops
+    B, S = 128, 256
+    assert ops.conv_tile_choice(B, S // 4, S // 4, 64, 64, 3, 1, 1, torch.bfloat16, 1) == 9
+    sd = {k: torch.as_tensor(v) for k, v in synth.resnet_state(5, "resnet50").items()}
+    x = torch.as_tensor(synth.batch(5, 8, image_size=S)[0]).cuda().repeat(B // 8, 1, 1, 1)
+    x = x + 0.01 * torch.randn(x.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(1))
+    feats = {}
+    for training in (False, True):
+        for policy in ("auto", "pass", "pass again"):
+            trunk = resnet.ResNetTrunk("resnet50", compute_dtype=torch.bfloat16)
+            trunk.bn_apply_3x3 = policy.split()[0]
+            trunk.load_state_dict(sd)
+            trunk = trunk.cuda().train(training)
+            feats[policy] = trunk(x)
+        assert torch.isfinite(feats["auto"]).all()
+        if not training:
+            assert torch.equal(feats["auto"], feats["pass"]), (feats["auto"] - feats["pass"]).abs().max().item()
+        else:
+            scale = feats["pass"].abs().mean().item()
+            err = (feats["auto"] - feats["pass"]).abs().mean().item() / scale
+            rerun = (feats["pass again"] - feats["pass"]).abs().mean().item() / scale
+            print(f"3x3 BatchNorm on load vs in place, batch statistics: pooled feature mean-rel {err:.2e} (the in-place policy run twice: {rerun:.2e})")
+            assert err < 2 * rerun + 2e-3, (err, rerun)
+
+
 def test_full_path_end_to_end_vs_oracle(gpu_lib):
     """config C0 (BASELINE.json configs[0]): ResNet-18, 2-block small flow, K=4, B=2, 256x256."""
     from mhentropy_amd import harness
