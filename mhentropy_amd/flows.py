@@ -77,14 +77,20 @@ class RealNVP(nn.Module):
             b2 = torch.stack(b2)
             if bf16:                      # the bf16 kernel wants l2.bias zero-padded to 64 per net
                 b2 = torch.nn.functional.pad(b2, (0, 64 - b2.shape[1]))
-            self._pack = (ver, torch.from_numpy(stream).to(dev), b2.contiguous(),
-                          torch.cat(wc).contiguous(), torch.cat(bc).contiguous())
+            wc = torch.cat(wc).contiguous()
+            self._pack = (ver, torch.from_numpy(stream).to(dev), b2.contiguous(), wc, torch.cat(bc).contiguous(),
+                          wc.to(torch.bfloat16) if bf16 and wc.shape[1] % 64 == 0 else None)
         return self._pack[1:]
 
     def _cond_table(self, cond):
-        """(B, F) features -> (B, 2*ncoup, 2, hidden): c_j(feat) + c_j.bias + l_j.bias per net."""
-        _, _, wc, bc = self._packed()
-        return ops.linear(cond.contiguous(), wc, bc).view(cond.shape[0], 2 * len(self.mask), 2, self.hidden)
+        """(B, F) features -> (B, 2*ncoup, 2, hidden): c_j(feat) + c_j.bias + l_j.bias per net.  In the bf16 mode the product takes
+        bf16 operands like the nets' own layers do (f32 accumulation and bias; 23 us against 117 us for the f32 form at C2)."""
+        _, _, wc, bc, wcb = self._packed()
+        if wcb is not None:
+            t = ops.linear_bf16_f32out(cond.to(torch.bfloat16).contiguous(), wcb, bc)
+        else:
+            t = ops.linear(cond.contiguous(), wc, bc)
+        return t.view(cond.shape[0], 2 * len(self.mask), 2, self.hidden)
 
     def _run(self, v, cond, direction):
         if cond is None:
@@ -92,7 +98,7 @@ class RealNVP(nn.Module):
         R, B = v.shape[0], cond.shape[0]
         if R % B:
             raise ValueError(f"flow rows ({R}) must be a multiple of conditioning rows ({B})")
-        wstream, b2, _, _ = self._packed()
+        wstream, b2 = self._packed()[:2]
         return ops.flow_couplings(v.contiguous(), self._cond_table(cond), wstream, b2, self.mask, B, self.hidden, direction)
 
     # ---- reference call surface ------------------------------------------------

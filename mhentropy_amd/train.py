@@ -155,7 +155,7 @@ class TrainStep:
         # optimizer step - no host re-pack, never stale
         self.repack()
         if self.glow is None:
-            self.flow._external_pack = (self.f_stream, self.f_b2, self.f_wc, self.f_bc)
+            self.flow._external_pack = (self.f_stream, self.f_b2, self.f_wc, self.f_bc, self.f_wcb)
             self.flow._external_sync = self.sync
         self.trunk._external_w = {id(u.conv.weight): u.w_fwd for u in self.units}
         self.trunk._external_sync = self.sync
@@ -402,6 +402,7 @@ class TrainStep:
         self.f_stream = self._derived(torch.cat(streams), torch.bfloat16 if bf16 else torch.float32)
         self.f_b2 = self._derived(torch.stack(b2), torch.float32)
         self.f_wc = self._derived(torch.cat(wc), torch.float32)                       # [2*ncoup*2*h, 512]
+        self.f_wcb = self._derived(torch.cat(wc), torch.bfloat16) if bf16 and fl.tsfm_on % 64 == 0 else None      # forward operand in the bf16 mode
         self.f_bc = self._derived(torch.cat(bc1), torch.float32, torch.cat(bc2))       # c_j.bias + l_j.bias
         self.f_wcT = self._derived(torch.cat(wc).t().contiguous(), torch.float32)     # [512, slots*h]
         slots = 4 * ncoup
@@ -743,7 +744,10 @@ class TrainStep:
             th45, log_q = self.glow.forward(z0, feat)
         else:
             h, ncoup = fl.hidden, len(fl.mask)
-            cond = ops.linear(feat, self.f_wc, self.f_bc).view(B, 2 * ncoup, 2, h)
+            if self.f_wcb is not None:
+                cond = ops.linear_bf16_f32out(feat.to(torch.bfloat16), self.f_wcb, self.f_bc).view(B, 2 * ncoup, 2, h)
+            else:
+                cond = ops.linear(feat, self.f_wc, self.f_bc).view(B, 2 * ncoup, 2, h)
             z0 = m._noise(N * B, 1.0, noise, self.dev)
             self._flow_kept = None
             if self.flow_bf16 and h == 512 and os.environ.get("MHE_FLOW_RECOMPUTE") != "1":
