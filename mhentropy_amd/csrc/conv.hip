@@ -636,6 +636,8 @@ bool stream_supports(const Params &p);         // conv_stream.hip: the streaming
 int launch_stream(const Params &p, hipStream_t s);
 bool stream3_supports(const Params &p);        // conv_stream.hip: the row-streaming 3x3 kernel for 64 -> 64 channels (variant 9)
 int launch_stream3(const Params &p, hipStream_t s);
+bool tail_supports(const Params &p);           // conv_tail.hip: residual tail + conv1 on a 128 x 256 tile with transfer waves (variant 10)
+int launch_tail(const Params &p, hipStream_t s);
 
 // tile choice: 0 = 128x64, 1 = 128x128, 2 = 256x256 (FAST only; needs >= ~3/4 of the CUs' worth of tiles)
 static int choose_tile(const Params &p, bool fast, bool bf16) {
@@ -644,6 +646,8 @@ static int choose_tile(const Params &p, bool fast, bool bf16) {
     static const int env_stream = getenv("MHE_CONV_STREAM") ? atoi(getenv("MHE_CONV_STREAM")) : 1;
     if (bf16 && (force == 8 || (force < 0 && env_stream)) && stream_supports(p)) return 8;
     if (bf16 && (force == 9 || (force < 0 && env_stream)) && stream3_supports(p)) return 9;
+    static const int env_tail = getenv("MHE_CONV_TAIL") ? atoi(getenv("MHE_CONV_TAIL")) : 1;
+    if (bf16 && (force == 10 || (force < 0 && env_tail)) && tail_supports(p)) return 10;
     if ((force & 15) == 7 && bf16 && p8_supports(p)) return 7;      // (higher bits: ablation builds of tuning runs)
     if (force >= 0 && force <= 4 && (force < 2 || (fast && bf16))) return force;
     if (p.Cout <= 64) return 0;
@@ -670,6 +674,7 @@ static int launch_conv(const Params &p, hipStream_t s) {
         const int t0 = choose_tile(p, fast, true);
         if (t0 == 8) return launch_stream(p, s);
         if (t0 == 9) return launch_stream3(p, s);
+        if (t0 == 10) return launch_tail(p, s);
         if (t0 == 7) return launch_p8(p, s);
     }
     if (p.x2 && !fast) { set_error("residual-tail prologue needs Cin %% %d == 0", BKE); return MHE_ERR_ARG; }

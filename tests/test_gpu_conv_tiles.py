@@ -134,6 +134,45 @@ def test_residual_tail_operand_load(gpu_lib, variant, affine2):
     assert_close(stats.double().sum(0).cpu()[0] / n, y.double().cpu().permute(0, 3, 1, 2).mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean (of the stored output)")
 
 
+@pytest.mark.parametrize("geom", [(4, 16, 16, 1024, 256), (2, 8, 16, 2048, 512), (8, 16, 16, 512, 256)], ids=lambda g: "x".join(map(str, g)))
+@pytest.mark.parametrize("affine2", [False, True], ids=["identity", "downsample-bn"])
+def test_residual_tail_kernel_with_transfer_waves(gpu_lib, geom, affine2):
+    """variant 10 (csrc/conv_tail.hip): the residual tail + conv1 of the wide layers on a 128 x 256 tile, load / transform / store work in
+    waves of their own.  Against torch in f64, and against the 128x128 variant: the block output it writes must be the same to the bit
+    (same arithmetic in the same order), the products agree to accumulation order."""
+    from mhentropy_amd import ops, resnet
+    B, H, W, Cin, Cout = geom
+    assert ops.conv_tile_choice(B, H, W, Cin, Cout, 1, 1, 0, torch.bfloat16, 2) == 10
+    g, x, w = _operands(31 + Cin // 512, B, H, W, Cin, Cout, 1)
+    x2 = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    sc2, sh2 = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    a = x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + (x2 * sc2.view(1, -1, 1, 1) + sh2.view(1, -1, 1, 1) if affine2 else x2)
+    a = torch.relu(a).bfloat16().float()
+    ref = F.conv2d(a.double(), w.double())
+    wp = resnet.pack_conv_weight(w, torch.bfloat16).cuda()
+    out = {}
+    for tile in (11, 2):
+        a_out = torch.full((B, H, W, Cin), float("nan"), device="cuda", dtype=torch.bfloat16)
+        stats = torch.zeros(ops.stat_shards(), 2, Cout, device="cuda")
+        y = ops.conv1x1_residual_in(_nhwc(x), _nhwc(x2), wp, sc.cuda(), sh.cuda(), sc2.cuda() if affine2 else None,
+                                    sh2.cuda() if affine2 else None, a_out=a_out, stats=stats, tile=tile)
+        out[tile] = (y, a_out, stats)
+    y, a_out, stats = out[11]
+    assert torch.equal(a_out, out[2][1]), "block output differs from the 128x128 variant's"
+    assert_close(a_out.float().cpu().permute(0, 3, 1, 2), a, 4e-3, what="block output written by the transfer waves")
+    assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, TOL, what="conv1x1 of the fused tail")
+    assert_close(y.float().cpu(), out[2][0].float().cpu(), 8e-3, what="against the 128x128 variant")
+    n = ref.numel() / Cout
+    yd = y.double().cpu().permute(0, 3, 1, 2)
+    assert_close(stats.double().sum(0).cpu()[0] / n, yd.mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean (of the stored output)")
+    assert_close(stats.double().sum(0).cpu()[1] / n, (yd * yd).mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean square (of the stored output)")
+    # without a_out / statistics
+    y2 = ops.conv1x1_residual_in(_nhwc(x), _nhwc(x2), wp, sc.cuda(), sh.cuda(), sc2.cuda() if affine2 else None,
+                                 sh2.cuda() if affine2 else None, tile=11)
+    assert torch.equal(y2, y)
+
+
 @pytest.mark.parametrize("shape", [(12, 64, 64, 64, 256, 1, 1, 0), (192, 16, 16, 256, 256, 3, 1, 1), (48, 32, 32, 128, 512, 1, 1, 0)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_launcher_selected_large_tile_matches_torch(gpu_lib, shape):
