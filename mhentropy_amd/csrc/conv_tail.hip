@@ -10,6 +10,7 @@
 //   multiply waves 0-3 : 64 MFMAs per 64-deep K tile (128 pixels x 64 of the 256 channels each), fragments from the stage of this tick;
 //   transfer waves 4-7 : the K tile three ticks ahead from global memory into registers (two tiles in flight) (both activation tensors + the 256 weight rows), the
 //                        tail arithmetic, the evaluated tile into the other LDS stage and - column tile 0 only - out to a_out.
+// Workgroups are persistent (one per CU): the transfer waves load the next pixel tile's first K tiles while this tile's epilogue runs.
 // One barrier per K tile; two LDS stages of 48 KiB; the epilogue stages the 128 x 256 outputs through the same LDS, stores them with
 // 16-byte lanes and takes the batch statistics of the stored (bf16-rounded) values in the store loop.
 #include "conv_shared.h"
@@ -21,6 +22,8 @@ namespace {
 constexpr int TBM = 128, TBN = 256, TBK = 64, TMAXK = 2048;
 constexpr int T_A = TBM * 8, T_W = TBN * 8, T_STAGE = T_A + T_W;        // uint4 per stage: 16 KiB activations + 32 KiB weights
 
+}  // namespace
+
 __global__ __launch_bounds__(512) void conv_tail_kernel(const Params p) {
     using T = u16;
     __shared__ uint4 lds[2 * T_STAGE];                                   // 96 KiB; the epilogue's 64 KiB staging buffer lies over it
@@ -28,171 +31,199 @@ __global__ __launch_bounds__(512) void conv_tail_kernel(const Params p) {
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, q = lane >> 4, l15 = lane & 15;
     const bool mult = wave < 4;
     const int t2 = tid & 255, s = t2 & 7, rbase = t2 >> 3;
-    int mt, ntile;
-    tile_of_block(mt, ntile);
-    const int m0 = mt * TBM, n0 = ntile * TBN;
     const int K = p.Cin, nk = K / TBK;
+    const int gm = p.M / TBM, gn = p.Cout / TBN, ntiles = gm * gn;
+    // persistent workgroups, XCD-aware order (conv_shared.h tile_of_block): the column tiles of one pixel tile run on one XCD at the same time
+    auto tile_at = [&](int L, int &mt, int &nt) __attribute__((always_inline)) {
+        if (gn > 1 && (gm & 7) == 0) {
+            const int slot = L >> 3;
+            nt = slot % gn;
+            mt = (slot / gn) * 8 + (L & 7);
+        } else { mt = L % gm; nt = L / gm; }
+    };
     const bool aff2 = p.x2_scale != nullptr;
     for (int i = tid; i < K; i += 512) {
         aff[i] = p.in_scale[i]; aff[K + i] = p.in_shift[i];
         aff[2 * K + i] = aff2 ? p.x2_scale[i] : 1.f; aff[3 * K + i] = aff2 ? p.x2_shift[i] : 0.f;
     }
-    __syncthreads();
-    if (mult) {
-        v4f acc[4][8];                                                    // [channel tile of this wave's 64][pixel tile of the 128]
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 8; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
-        for (int t = 0; t < nk; ++t) {
-            __syncthreads();
-            const uint4 *At = lds + (t & 1) * T_STAGE, *Wt = At + T_A + wave * 64 * 8;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                uint4 fa[8], fb[4];
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) fb[nt] = Wt[swz(nt * 16 + l15, kk * 4 + q)];
-#pragma unroll
-                for (int m = 0; m < 8; ++m) fa[m] = At[swz(m * 16 + l15, kk * 4 + q)];
-#pragma unroll
-                for (int m = 0; m < 8; ++m)
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-                        acc[nt][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fb[nt]),
-                            __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fa[m]), acc[nt][m], 0, 0, 0);
-            }
-        }
-        __syncthreads();                                                  // every wave is done with the stages: they become the staging buffer
-        unsigned char *ot = reinterpret_cast<unsigned char *>(lds);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                // D layout: lane (l15, q) holds channels 4q..4q+3 of tile nt for pixel 16m + l15; staging row = pixel, 32 chunks of 16 B
-                const int row = m * 16 + l15, boff = (wave * 64 + nt * 16 + 4 * q) * 2;
-                const int chunk = (boff >> 4) ^ (row & 31);
-                const v4f v = acc[nt][m];
-                uint2 o;
-                o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-                o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-                *reinterpret_cast<uint2 *>(ot + ((size_t)row * 32 + chunk) * 16 + (boff & 15)) = o;
-            }
-    } else {
-        const T *xg = reinterpret_cast<const T *>(p.x), *x2g = reinterpret_cast<const T *>(p.x2), *wg = reinterpret_cast<const T *>(p.w);
-        T *ag = p.a_out && ntile == 0 ? reinterpret_cast<T *>(p.a_out) : nullptr;
-        // this thread: 16-byte chunk s of the K tile, activation rows rbase + 32 j (j < 4), weight rows rbase + 32 j (j < 8).
-        // Two K tiles in flight in registers: a tile is loaded two ticks before it is written to LDS (with one tile in flight a tick
-        // lasted one memory latency, 4.6 us for 64 KiB per CU: the first version ran 148 us against the tiled kernel's 119; three sets
-        // spill)
-        struct Set { uint4 a[4], b[4], w[8]; };
-        Set st0, st1;
-        auto load_tile = [&](int t, Set &st) __attribute__((always_inline)) {
-            const int kc = t * TBK + s * 8;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const size_t off = (size_t)(m0 + rbase + 32 * j) * K + kc;
-                st.a[j] = *reinterpret_cast<const uint4 *>(xg + off);
-                st.b[j] = *reinterpret_cast<const uint4 *>(x2g + off);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) st.w[j] = *reinterpret_cast<const uint4 *>(wg + (size_t)(n0 + rbase + 32 * j) * p.Kpad + kc);
-        };
-        auto store_tile = [&](int t, const Set &st) __attribute__((always_inline)) {
-            uint4 *At = lds + (t & 1) * T_STAGE, *Wt = At + T_A;
-            const int kc = t * TBK + s * 8;
-            float sc[8], sh[8], s2[8], h2[8];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float4 a0 = *reinterpret_cast<const float4 *>(aff + kc + 4 * h), a1 = *reinterpret_cast<const float4 *>(aff + K + kc + 4 * h);
-                const float4 b0 = *reinterpret_cast<const float4 *>(aff + 2 * K + kc + 4 * h), b1 = *reinterpret_cast<const float4 *>(aff + 3 * K + kc + 4 * h);
-                sc[4 * h] = a0.x; sc[4 * h + 1] = a0.y; sc[4 * h + 2] = a0.z; sc[4 * h + 3] = a0.w;
-                sh[4 * h] = a1.x; sh[4 * h + 1] = a1.y; sh[4 * h + 2] = a1.z; sh[4 * h + 3] = a1.w;
-                s2[4 * h] = b0.x; s2[4 * h + 1] = b0.y; s2[4 * h + 2] = b0.z; s2[4 * h + 3] = b0.w;
-                h2[4 * h] = b1.x; h2[4 * h + 1] = b1.y; h2[4 * h + 2] = b1.z; h2[4 * h + 3] = b1.w;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                // the arithmetic of conv_shared.h's in_transform, in its order: x * scale + shift, + (x2 * scale2 + shift2 | x2), relu, round
-                float v[8], w[8];
-                Chunk<T>::unpack(st.a[j], v);
-                Chunk<T>::unpack(st.b[j], w);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    v[i] = fmaf(v[i], sc[i], sh[i]);
-                    if (aff2) w[i] = fmaf(w[i], s2[i], h2[i]);
-                    v[i] += w[i];
-                    if (p.relu_in) v[i] = fmaxf(v[i], 0.f);
-                }
-                const uint4 o = Chunk<T>::pack(v);
-                At[swz(rbase + 32 * j, s)] = o;
-                if (ag) *reinterpret_cast<uint4 *>(ag + (size_t)(m0 + rbase + 32 * j) * K + kc) = o;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) Wt[swz(rbase + 32 * j, s)] = st.w[j];
-        };
-        // tile u lives in set u & 1; prologue: tiles 0 .. 2 in flight, tile 0 written at once (the one exposed load)
-        load_tile(0, st0);
-        if (1 < nk) load_tile(1, st1);
-        store_tile(0, st0);
-        if (2 < nk) load_tile(2, st0);
-        // tick t: write tile t + 1 (set (t + 1) & 1) into the stage the multiply waves are not reading, then reload that set with tile t + 3
-        auto tick = [&](int t, Set &st) __attribute__((always_inline)) {
-            __syncthreads();                                              // stage (t + 1) & 1 was last read during tick t - 1
-            if (t + 1 < nk) store_tile(t + 1, st);                        // first everything that consumes loaded registers ...
-            if (t + 3 < nk) load_tile(t + 3, st);                         // ... then this tick's loads
-        };
-        for (int t = 0; t < nk; t += 2) {
-            tick(t, st1);
-            if (t + 1 < nk) tick(t + 1, st0);
-        }
-        __syncthreads();
-    }
-    __syncthreads();                                                      // the staged outputs are visible
-    // 128 pixels x 32 chunks of 16 B: thread = chunk tid % 32 of rows tid / 32 + 16 j
-    const unsigned char *ot = reinterpret_cast<const unsigned char *>(lds);
+    const T *xg = reinterpret_cast<const T *>(p.x), *x2g = reinterpret_cast<const T *>(p.x2), *wg = reinterpret_cast<const T *>(p.w);
     T *yg = reinterpret_cast<T *>(p.y);
-    const int cc = tid & 31, r0 = tid >> 5;
-    const bool st_on = p.stats != nullptr;
-    float ss1[8], ss2[8];
+    // transfer role.  This thread: 16-byte chunk s of the K tile, activation rows rbase + 32 j (j < 4), weight rows rbase + 32 j (j < 8).
+    // Two K tiles in flight in registers: a tile is loaded two ticks before it is written to LDS (with one tile in flight a tick
+    // lasted one memory latency, 4.6 us for 64 KiB per CU: the first version ran 148 us against the tiled kernel's 119; three sets spill)
+    struct Set { uint4 a[4], b[4], w[8]; };
+    Set st0, st1;
+    auto load_tile = [&](int t, Set &st, int m0, int n0) __attribute__((always_inline)) {
+        const int kc = t * TBK + s * 8;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) ss1[i] = ss2[i] = 0.f;
-    uint4 raw[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int row = r0 + 16 * j;
-        raw[j] = *reinterpret_cast<const uint4 *>(ot + ((size_t)row * 32 + (cc ^ (row & 31))) * 16);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int row = r0 + 16 * j;
-        if (st_on) {
-            float f[8];
-            Chunk<T>::unpack(raw[j], f);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { ss1[i] += f[i]; ss2[i] = fmaf(f[i], f[i], ss2[i]); }
+        for (int j = 0; j < 4; ++j) {
+            const size_t off = (size_t)(m0 + rbase + 32 * j) * K + kc;
+            st.a[j] = *reinterpret_cast<const uint4 *>(xg + off);
+            st.b[j] = *reinterpret_cast<const uint4 *>(x2g + off);
         }
-        *reinterpret_cast<uint4 *>(yg + (size_t)(m0 + row) * p.Cout + n0 + cc * 8) = raw[j];
-    }
-    if (st_on) {
-        // fold the 16 threads that share a column chunk, then add to this workgroup's shard
-        float *red = reinterpret_cast<float *>(lds);
-        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { red[tid * 16 + i] = ss1[i]; red[tid * 16 + 8 + i] = ss2[i]; }
-        __syncthreads();
-        if (tid < 256) {
-            const int ch = tid >> 3, e = tid & 7;
-            float a = 0.f, b = 0.f;
-            for (int k = 0; k < 16; ++k) { a += red[(ch + 32 * k) * 16 + e]; b += red[(ch + 32 * k) * 16 + 8 + e]; }
-            float *st = p.stats + (size_t)(mt % NSH) * 2 * p.Cout;
-            atomicAdd(st + n0 + tid, a);
-            atomicAdd(st + p.Cout + n0 + tid, b);
+        for (int j = 0; j < 8; ++j) st.w[j] = *reinterpret_cast<const uint4 *>(wg + (size_t)(n0 + rbase + 32 * j) * p.Kpad + kc);
+    };
+    auto store_tile = [&](int t, const Set &st, int m0, T *ag) __attribute__((always_inline)) {
+        uint4 *At = lds + (t & 1) * T_STAGE, *Wt = At + T_A;
+        const int kc = t * TBK + s * 8;
+        float sc[8], sh[8], s2[8], h2[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(aff + kc + 4 * h), a1 = *reinterpret_cast<const float4 *>(aff + K + kc + 4 * h);
+            const float4 b0 = *reinterpret_cast<const float4 *>(aff + 2 * K + kc + 4 * h), b1 = *reinterpret_cast<const float4 *>(aff + 3 * K + kc + 4 * h);
+            sc[4 * h] = a0.x; sc[4 * h + 1] = a0.y; sc[4 * h + 2] = a0.z; sc[4 * h + 3] = a0.w;
+            sh[4 * h] = a1.x; sh[4 * h + 1] = a1.y; sh[4 * h + 2] = a1.z; sh[4 * h + 3] = a1.w;
+            s2[4 * h] = b0.x; s2[4 * h + 1] = b0.y; s2[4 * h + 2] = b0.z; s2[4 * h + 3] = b0.w;
+            h2[4 * h] = b1.x; h2[4 * h + 1] = b1.y; h2[4 * h + 2] = b1.z; h2[4 * h + 3] = b1.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // the arithmetic of conv_shared.h's in_transform, in its order: x * scale + shift, + (x2 * scale2 + shift2 | x2), relu, round
+            float v[8], w[8];
+            Chunk<T>::unpack(st.a[j], v);
+            Chunk<T>::unpack(st.b[j], w);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v[i] = fmaf(v[i], sc[i], sh[i]);
+                if (aff2) w[i] = fmaf(w[i], s2[i], h2[i]);
+                v[i] += w[i];
+                if (p.relu_in) v[i] = fmaxf(v[i], 0.f);
+            }
+            const uint4 o = Chunk<T>::pack(v);
+            At[swz(rbase + 32 * j, s)] = o;
+            if (ag) *reinterpret_cast<uint4 *>(ag + (size_t)(m0 + rbase + 32 * j) * K + kc) = o;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Wt[swz(rbase + 32 * j, s)] = st.w[j];
+    };
+    const bool st_on = p.stats != nullptr;
+    // the epilogue both roles run: 128 pixels x 32 chunks of 16 B from the staging buffer, thread = chunk tid % 32 of rows tid / 32 + 16 j
+    auto store_outputs = [&](int mt, int m0, int n0) __attribute__((always_inline)) {
+        const unsigned char *ot = reinterpret_cast<const unsigned char *>(lds);
+        const int cc = tid & 31, r0 = tid >> 5;
+        float ss1[8], ss2[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ss1[i] = ss2[i] = 0.f;
+        uint4 raw[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = r0 + 16 * j;
+            raw[j] = *reinterpret_cast<const uint4 *>(ot + ((size_t)row * 32 + (cc ^ (row & 31))) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = r0 + 16 * j;
+            if (st_on) {
+                float f[8];
+                Chunk<T>::unpack(raw[j], f);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { ss1[i] += f[i]; ss2[i] = fmaf(f[i], f[i], ss2[i]); }
+            }
+            *reinterpret_cast<uint4 *>(yg + (size_t)(m0 + row) * p.Cout + n0 + cc * 8) = raw[j];
+        }
+        if (st_on) {
+            // fold the 16 threads that share a column chunk, then add to this pixel tile's shard
+            float *red = reinterpret_cast<float *>(lds);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { red[tid * 16 + i] = ss1[i]; red[tid * 16 + 8 + i] = ss2[i]; }
+            __syncthreads();
+            if (tid < 256) {
+                const int ch = tid >> 3, e = tid & 7;
+                float a = 0.f, b = 0.f;
+                for (int k = 0; k < 16; ++k) { a += red[(ch + 32 * k) * 16 + e]; b += red[(ch + 32 * k) * 16 + 8 + e]; }
+                float *st = p.stats + (size_t)(mt % NSH) * 2 * p.Cout;
+                atomicAdd(st + n0 + tid, a);
+                atomicAdd(st + p.Cout + n0 + tid, b);
+            }
+        }
+    };
+    // Each role has its own loop over the workgroup's tiles (the transfer waves' register sets must not be live in the multiply waves'
+    // code); both take the same barriers: one at the top of a tile, one per K tile, one when the stages are free, one when the outputs
+    // are staged, two in the statistics fold.
+    if (mult) {
+        for (int L = blockIdx.x; L < ntiles; L += (int)gridDim.x) {
+            int mt, ntile;
+            tile_at(L, mt, ntile);
+            __syncthreads();                                              // affine tables written; the previous tile's staging / fold reads done
+            v4f acc[4][8];                                                // [channel tile of this wave's 64][pixel tile of the 128]
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 8; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < nk; ++t) {
+                __syncthreads();
+                const uint4 *At = lds + (t & 1) * T_STAGE, *Wt = At + T_A + wave * 64 * 8;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    uint4 fa[8], fb[4];
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) fb[nt] = Wt[swz(nt * 16 + l15, kk * 4 + q)];
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) fa[m] = At[swz(m * 16 + l15, kk * 4 + q)];
+#pragma unroll
+                    for (int m = 0; m < 8; ++m)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+                            acc[nt][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fb[nt]),
+                                __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fa[m]), acc[nt][m], 0, 0, 0);
+                }
+            }
+            __syncthreads();                                              // every wave is done with the stages: they become the staging buffer
+            unsigned char *ot = reinterpret_cast<unsigned char *>(lds);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    // D layout: lane (l15, q) holds channels 4q..4q+3 of tile nt for pixel 16m + l15; staging row = pixel, 32 chunks of 16 B
+                    const int row = m * 16 + l15, boff = (wave * 64 + nt * 16 + 4 * q) * 2;
+                    const int chunk = (boff >> 4) ^ (row & 31);
+                    const v4f v = acc[nt][m];
+                    uint2 o;
+                    o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                    o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                    *reinterpret_cast<uint2 *>(ot + ((size_t)row * 32 + chunk) * 16 + (boff & 15)) = o;
+                }
+            __syncthreads();                                              // the staged outputs are visible
+            store_outputs(mt, mt * TBM, ntile * TBN);
+        }
+    } else {
+        int mt, ntile;
+        tile_at(blockIdx.x, mt, ntile);
+        load_tile(0, st0, mt * TBM, ntile * TBN);                         // the first tile's first two K tiles: the one exposed load of the workgroup
+        if (1 < nk) load_tile(1, st1, mt * TBM, ntile * TBN);
+        for (int L = blockIdx.x; L < ntiles; L += (int)gridDim.x) {
+            tile_at(L, mt, ntile);
+            const int m0 = mt * TBM, n0 = ntile * TBN;
+            T *ag = p.a_out && ntile == 0 ? reinterpret_cast<T *>(p.a_out) : nullptr;
+            __syncthreads();
+            // K tile u lives in set u & 1; tiles 0 and 1 are in flight (loaded during the previous pixel tile's epilogue)
+            store_tile(0, st0, m0, ag);
+            if (2 < nk) load_tile(2, st0, m0, n0);
+            // tick t: write tile t + 1 (set (t + 1) & 1) into the stage the multiply waves are not reading, then reload that set with tile t + 3
+            auto tick = [&](int t, Set &st) __attribute__((always_inline)) {
+                __syncthreads();                                          // stage (t + 1) & 1 was last read during tick t - 1
+                if (t + 1 < nk) store_tile(t + 1, st, m0, ag);            // first everything that consumes loaded registers ...
+                if (t + 3 < nk) load_tile(t + 3, st, m0, n0);             // ... then this tick's loads
+            };
+            for (int t = 0; t < nk; t += 2) {
+                tick(t, st1);
+                if (t + 1 < nk) tick(t + 1, st0);
+            }
+            __syncthreads();
+            if (L + (int)gridDim.x < ntiles) {                            // the next pixel tile's first K tiles, in flight across this tile's epilogue
+                int mt2, nt2;
+                tile_at(L + (int)gridDim.x, mt2, nt2);
+                load_tile(0, st0, mt2 * TBM, nt2 * TBN);
+                if (1 < nk) load_tile(1, st1, mt2 * TBM, nt2 * TBN);
+            }
+            __syncthreads();
+            store_outputs(mt, m0, n0);
         }
     }
 }
-
-}  // namespace
 
 bool tail_supports(const Params &p) {
     return p.x2 && p.in_scale && !p.mask && !p.residual && !p.out_scale && !p.out_shift && !p.relu_out && !p.y32 && !p.os2 && !p.res_s2 &&
@@ -201,8 +232,8 @@ bool tail_supports(const Params &p) {
 }
 
 int launch_tail(const Params &p, hipStream_t s) {
-    const dim3 grid((unsigned)(p.M / TBM), (unsigned)(p.Cout / TBN));
-    hipLaunchKernelGGL(conv_tail_kernel, grid, dim3(512), 0, s, p);
+    const int ntiles = (p.M / TBM) * (p.Cout / TBN);
+    hipLaunchKernelGGL(conv_tail_kernel, dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3(512), 0, s, p);
     return check_launch("conv_tail_kernel");
 }
 
