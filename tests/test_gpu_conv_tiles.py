@@ -134,7 +134,10 @@ def test_residual_tail_operand_load(gpu_lib, variant, affine2):
     assert_close(stats.double().sum(0).cpu()[0] / n, y.double().cpu().permute(0, 3, 1, 2).mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean (of the stored output)")
 
 
-@pytest.mark.parametrize("geom", [(4, 16, 16, 1024, 256), (2, 8, 16, 2048, 512), (8, 16, 16, 512, 256)], ids=lambda g: "x".join(map(str, g)))
+# the last three: more tiles than the 256 persistent workgroups (a second tile per workgroup, its first K tiles loaded during the first one's
+# epilogue) with one and with two column tiles, and a pixel-tile count that is not a multiple of 8 (plain tile order)
+@pytest.mark.parametrize("geom", [(4, 16, 16, 1024, 256), (2, 8, 16, 2048, 512), (8, 16, 16, 512, 256), (36, 32, 32, 128, 256), (24, 16, 48, 128, 512),
+                                  (2, 24, 24, 256, 512)], ids=lambda g: "x".join(map(str, g)))
 @pytest.mark.parametrize("affine2", [False, True], ids=["identity", "downsample-bn"])
 def test_residual_tail_kernel_with_transfer_waves(gpu_lib, geom, affine2):
     """variant 10 (csrc/conv_tail.hip): the residual tail + conv1 of the wide layers on a 128 x 256 tile, load / transform / store work in
@@ -336,7 +339,8 @@ def test_streaming_1x1_kernel_data_gradient_form(gpu_lib, shape, nbn, res):
 
 
 @pytest.mark.parametrize("form", ["plain", "bn-on-load", "data-gradient"])
-@pytest.mark.parametrize("B,H", [(128, 16), (130, 19)])
+# (300, 17): more images than the 256 workgroups - the flat pair stream crosses image boundaries inside a workgroup, odd height
+@pytest.mark.parametrize("B,H", [(128, 16), (130, 19), (300, 17)])
 def test_row_streaming_3x3_kernel(gpu_lib, B, H, form):
     """conv3x3_c64_stream_kernel (variant 9: 3x3 / stride 1 / pad 1, 64 -> 64 channels, 64-pixel-wide maps; weights and a ring of input
     rows resident in LDS): picked by the launcher and forced; against conv2d on the bf16-rounded operands (producer BatchNorm + ReLU
