@@ -415,6 +415,15 @@ int mhe_bn_bwd_apply_nhwc(const void *g, const void *a, const void *y, const flo
 /* 3x3/s2/p1 max pool recording the winning tap (first maximum, as torch), and its reverse gather. */
 int mhe_maxpool3x3s2_idx_nhwc(const void *x, void *y, unsigned char *idx, int B, int H, int W, int C, int dtype, void *stream);
 int mhe_maxpool3x3s2_bwd_nhwc(const void *gy, const unsigned char *idx, void *gx, int B, int H, int W, int C, int dtype, void *stream);
+/* The stem's pool with its BatchNorm folded in (torchvision ResNet.forward: `x = self.relu(self.bn1(x)); x = self.maxpool(x)` differentiated
+ * by autograd, reference hand/CrossModalHand.py:455-470).  Forward: y = maxpool(relu(x * scale + shift)) + winning taps from the RAW conv
+ * output x (the normalised copy is never written; winners are chosen on the values as stored in `dtype`, i.e. the same winners as
+ * mhe_maxpool3x3s2_idx_nhwc on the materialised activation).  Reverse: gx = scatter(gy, idx) [relu(y * scale + shift) > 0] and the
+ * BatchNorm-reverse sums of gx into stats[shard][2][C] (as mhe_bn_bwd_reduce_nhwc would add them) in one pass; C / (16 bytes of dtype) must divide 256. */
+int mhe_maxpool3x3s2_idx_affine_nhwc(const void *x, const float *scale, const float *shift, void *y, unsigned char *idx, int B, int H, int W,
+                                     int C, int dtype, void *stream);
+int mhe_maxpool3x3s2_bwd_bn_nhwc(const void *gy, const unsigned char *idx, const void *y, const float *scale, const float *shift,
+                                 const float *mean_invstd, float *stats, void *gx, int B, int H, int W, int C, int dtype, void *stream);
 /* gx[b,p,c] = g[b,c] / HW, zeroed where mask[b,p,c] <= 0 (mask optional: ReLU gate of the pooled tensor). */
 int mhe_avgpool_bwd_nhwc(const float *g, const void *mask, void *gx, int B, int HW, int C, int dtype, void *stream);
 /* out[b,2i,2j,c] = g[b,i,j,c] (+ base), 0 (+ base) elsewhere; out is [B,H,W,C], g is [B,ceil(H/2),ceil(W/2),C]:

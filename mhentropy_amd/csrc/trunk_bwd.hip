@@ -192,6 +192,160 @@ __global__ void maxpool_bwd_kernel(const T *__restrict__ gy, const unsigned char
     }
 }
 
+// ---- the stem's pool with its BatchNorm folded in (train step).  Forward: y = maxpool(relu(x * scale + shift)) + the winning tap, straight
+// from the raw stem output (the normalised copy is never written); reverse: the pool's scatter, the ReLU gate recomputed from the raw
+// output, and the BatchNorm-reverse sums of the gated gradient in ONE pass (separately: scatter 0.4 ms + a reduction over three
+// full-resolution tensors 0.33 ms + an apply pass over four).  16-byte lanes: E = 8 (bf16) or 4 (f32) channels per thread.
+template <typename T> struct Lane;
+template <> struct Lane<float> {
+    static constexpr int E = 4;
+    static __device__ __forceinline__ void get(const float *p, float *v) { const float4 r = *reinterpret_cast<const float4 *>(p); v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w; }
+    static __device__ __forceinline__ void put(float *p, const float *v) { *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+    static __device__ __forceinline__ float stored(float v) { return v; }
+};
+template <> struct Lane<u16> {
+    static constexpr int E = 8;
+    static __device__ __forceinline__ void get(const u16 *p, float *v) {
+        const uint4 r = *reinterpret_cast<const uint4 *>(p);
+        const unsigned in[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(in[i] << 16); v[2 * i + 1] = __uint_as_float(in[i] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ void put(u16 *p, const float *v) {
+        unsigned o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (unsigned)f32_to_bf16(v[2 * i]) | ((unsigned)f32_to_bf16(v[2 * i + 1]) << 16);
+        *reinterpret_cast<uint4 *>(p) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    static __device__ __forceinline__ float stored(float v) { return __uint_as_float((unsigned)f32_to_bf16(v) << 16); }     // the value a bf16 tensor would hold
+};
+
+// y = maxpool3x3s2(relu(x * scale + shift)) and the winning tap; the comparison runs on the values as a stored activation would hold them
+// (bf16-rounded for T = u16), first maximum in scan order - the same winners as maxpool_idx_kernel on the materialised activation
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_idx_affine_kernel(const T *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                 T *__restrict__ y, unsigned char *__restrict__ idx, int B, int H, int W, int C, int Ho, int Wo) {
+    constexpr int E = Lane<T>::E;
+    const int cpp = C / E;                                   // chunks per pixel
+    const unsigned n = (unsigned)B * Ho * Wo * cpp;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int c = (int)(i % cpp) * E;
+        unsigned t = i / cpp;
+        const int wo = (int)(t % Wo); t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        float v[9][E];
+        bool ok[9];
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {                 // nine loads in flight from clamped addresses; out-of-range taps dropped afterwards
+                const int hi = 2 * ho - 1 + dh, wi = 2 * wo - 1 + dw;
+                ok[dh * 3 + dw] = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+                const int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi), wc = wi < 0 ? 0 : (wi >= W ? W - 1 : wi);
+                Lane<T>::get(x + (((size_t)b * H + hc) * W + wc) * C + c, v[dh * 3 + dw]);
+            }
+        float sc[E], sf[E], m[E];
+        unsigned am[E];
+#pragma unroll
+        for (int k = 0; k < E; ++k) { sc[k] = scale[c + k]; sf[k] = shift[c + k]; m[k] = -3.0e38f; am[k] = 0; }
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                const float a = Lane<T>::stored(fmaxf(fmaf(v[j][k], sc[k], sf[k]), 0.f));
+                const bool win = ok[j] && a > m[k];
+                m[k] = win ? a : m[k];
+                am[k] = win ? (unsigned)j : am[k];
+            }
+        const size_t e = (size_t)i * E;
+        Lane<T>::put(y + e, m);
+        unsigned w0 = 0, w1 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w0 |= am[k] << (8 * k);
+        if constexpr (E == 8) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w1 |= am[4 + k] << (8 * k);
+            *reinterpret_cast<uint2 *>(idx + e) = make_uint2(w0, w1);
+        } else *reinterpret_cast<unsigned *>(idx + e) = w0;
+    }
+}
+
+// gx = (scatter of gy to the recorded winners) [relu(y * scale + shift) > 0], written as T, and the BatchNorm-reverse sums of the stored gx:
+// stats[shard][0][c] += sum gx, [1][c] += sum gx * (y - mean) * invstd.  blockDim * gridDim is a multiple of the chunks per pixel, so a thread
+// keeps one channel chunk for its whole walk: sums in registers, folded through LDS at the end.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_bn_kernel(const T *__restrict__ gy, const unsigned char *__restrict__ idx, const T *__restrict__ y,
+                                                             const float *__restrict__ scale, const float *__restrict__ shift,
+                                                             const float *__restrict__ mean_invstd, float *__restrict__ stats, T *__restrict__ gx,
+                                                             int B, int H, int W, int C, int Ho, int Wo) {
+    constexpr int E = Lane<T>::E;
+    __shared__ float red[256 * 2 * E];
+    const int cpp = C / E;
+    const unsigned n = (unsigned)B * H * W * cpp;
+    const int tid = threadIdx.x;
+    const int c = (int)((blockIdx.x * blockDim.x + tid) % cpp) * E;
+    float sc[E], sf[E], mu[E], iv[E], s1[E], s2[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) { sc[k] = scale[c + k]; sf[k] = shift[c + k]; mu[k] = mean_invstd[c + k]; iv[k] = mean_invstd[C + c + k]; s1[k] = s2[k] = 0.f; }
+    for (unsigned i = blockIdx.x * blockDim.x + tid; i < n; i += gridDim.x * blockDim.x) {
+        unsigned t = i / cpp;
+        const int w = (int)(t % W); t /= W;
+        const int h = (int)(t % H);
+        const int b = (int)(t / H);
+        // windows (ho, wo) containing (h, w): ho in {h / 2, (h + 1) / 2}, the second one only for odd h (and inside the pooled grid)
+        float g[4][E];
+        unsigned a0[4], a1[4], tap[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int ho = (h + u) / 2, wo = (w + v) / 2;
+                const int j = 2 * u + v;
+                ok[j] = (u == 0 || (h & 1)) && (v == 0 || (w & 1)) && ho < Ho && wo < Wo;
+                tap[j] = (unsigned)((h - (2 * ho - 1)) * 3 + (w - (2 * wo - 1)));
+                const size_t o = (((size_t)b * Ho + (ho < Ho ? ho : Ho - 1)) * Wo + (wo < Wo ? wo : Wo - 1)) * C + c;
+                Lane<T>::get(gy + o, g[j]);
+                if constexpr (E == 8) { const uint2 r = *reinterpret_cast<const uint2 *>(idx + o); a0[j] = r.x; a1[j] = r.y; }
+                else { a0[j] = *reinterpret_cast<const unsigned *>(idx + o); a1[j] = 0; }
+            }
+        const size_t e = (size_t)i * E;
+        float yv[E], acc[E];
+        Lane<T>::get(y + e, yv);
+#pragma unroll
+        for (int k = 0; k < E; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                const unsigned am = ((k < 4 ? a0[j] : a1[j]) >> (8 * (k & 3))) & 0xffu;
+                acc[k] += (ok[j] && am == tap[j]) ? g[j][k] : 0.f;
+            }
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            const bool on = Lane<T>::stored(fmaxf(fmaf(yv[k], sc[k], sf[k]), 0.f)) > 0.f;
+            acc[k] = on ? Lane<T>::stored(acc[k]) : 0.f;
+            s1[k] += acc[k];
+            s2[k] = fmaf(acc[k], (yv[k] - mu[k]) * iv[k], s2[k]);
+        }
+        Lane<T>::put(gx + e, acc);
+    }
+    // threads tid, tid + cpp, ... of a block share a channel chunk
+#pragma unroll
+    for (int k = 0; k < E; ++k) { red[tid * 2 * E + k] = s1[k]; red[tid * 2 * E + E + k] = s2[k]; }
+    __syncthreads();
+    if (tid < cpp) {
+        float *sh = stats + (size_t)(blockIdx.x % NSH) * 2 * C;
+        for (int k = 0; k < E; ++k) {
+            float a = 0.f, b2 = 0.f;
+            for (int o = tid; o < 256; o += cpp) { a += red[o * 2 * E + k]; b2 += red[o * 2 * E + E + k]; }
+            atomicAdd(sh + c + k, a);
+            atomicAdd(sh + C + c + k, b2);
+        }
+    }
+}
+
 // gx[b,p,c] = g[b,c] / HW  (global average pool)
 template <typename T>
 __global__ void avgpool_bwd_kernel(const float *__restrict__ g, const T *__restrict__ mask, T *__restrict__ gx, int HW, int C, size_t n4) {
@@ -361,6 +515,39 @@ extern "C" int mhe_maxpool3x3s2_bwd_nhwc(const void *gy, const unsigned char *id
     else
         hipLaunchKernelGGL(tb::maxpool_bwd_kernel<u16>, dim3(ewg(n4)), dim3(256), 0, (hipStream_t)stream, (const u16 *)gy, idx, (u16 *)gx, B, H, W, C, Ho, Wo);
     return check_launch("maxpool_bwd_kernel");
+}
+
+extern "C" int mhe_maxpool3x3s2_idx_affine_nhwc(const void *x, const float *scale, const float *shift, void *y, unsigned char *idx, int B, int H, int W,
+                                                int C, int dtype, void *stream) {
+    MHE_REQUIRE(x && scale && shift && y && idx && B > 0 && H > 0 && W > 0, "mhe_maxpool3x3s2_idx_affine_nhwc: bad arguments");
+    MHE_REQUIRE(dtype == MHE_F32 || dtype == MHE_BF16, "mhe_maxpool3x3s2_idx_affine_nhwc: dtype=%d", dtype);
+    const int E = dtype == MHE_F32 ? 4 : 8;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    MHE_REQUIRE(C > 0 && C % E == 0 && (size_t)B * Ho * Wo * (C / E) < (1ull << 31), "mhe_maxpool3x3s2_idx_affine_nhwc: C=%d must be a multiple of %d (and < 2^31 lanes)", C, E);
+    const size_t n = (size_t)B * Ho * Wo * (C / E);
+    if (dtype == MHE_F32)
+        hipLaunchKernelGGL(tb::maxpool_idx_affine_kernel<float>, dim3(ewg(n)), dim3(256), 0, (hipStream_t)stream, (const float *)x, scale, shift, (float *)y, idx, B, H, W, C, Ho, Wo);
+    else
+        hipLaunchKernelGGL(tb::maxpool_idx_affine_kernel<u16>, dim3(ewg(n)), dim3(256), 0, (hipStream_t)stream, (const u16 *)x, scale, shift, (u16 *)y, idx, B, H, W, C, Ho, Wo);
+    return check_launch("maxpool_idx_affine_kernel");
+}
+
+extern "C" int mhe_maxpool3x3s2_bwd_bn_nhwc(const void *gy, const unsigned char *idx, const void *y, const float *scale, const float *shift,
+                                            const float *mean_invstd, float *stats, void *gx, int B, int H, int W, int C, int dtype, void *stream) {
+    MHE_REQUIRE(gy && idx && y && scale && shift && mean_invstd && stats && gx && B > 0 && H > 0 && W > 0, "mhe_maxpool3x3s2_bwd_bn_nhwc: bad arguments");
+    MHE_REQUIRE(dtype == MHE_F32 || dtype == MHE_BF16, "mhe_maxpool3x3s2_bwd_bn_nhwc: dtype=%d", dtype);
+    const int E = dtype == MHE_F32 ? 4 : 8;
+    MHE_REQUIRE(C > 0 && C % E == 0 && 256 % (C / E) == 0 && (size_t)B * H * W * (C / E) < (1ull << 31),
+                "mhe_maxpool3x3s2_bwd_bn_nhwc: C=%d: C / %d must divide 256 (a thread keeps one channel chunk)", C, E);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const size_t n = (size_t)B * H * W * (C / E);
+    if (dtype == MHE_F32)
+        hipLaunchKernelGGL(tb::maxpool_bwd_bn_kernel<float>, dim3(ewg(n)), dim3(256), 0, (hipStream_t)stream, (const float *)gy, idx, (const float *)y, scale, shift,
+                           mean_invstd, stats, (float *)gx, B, H, W, C, Ho, Wo);
+    else
+        hipLaunchKernelGGL(tb::maxpool_bwd_bn_kernel<u16>, dim3(ewg(n)), dim3(256), 0, (hipStream_t)stream, (const u16 *)gy, idx, (const u16 *)y, scale, shift,
+                           mean_invstd, stats, (u16 *)gx, B, H, W, C, Ho, Wo);
+    return check_launch("maxpool_bwd_bn_kernel");
 }
 
 extern "C" int mhe_avgpool_bwd_nhwc(const float *g, const void *mask, void *gx, int B, int HW, int C, int dtype, void *stream) {

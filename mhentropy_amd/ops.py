@@ -622,14 +622,39 @@ def bn_backward(g, a, y, mean_invstd, gamma, stats, dgamma, dbeta, want_masked=F
     return (gy, gm) if want_masked else gy
 
 
-def maxpool3x3s2_idx(x):
+def maxpool3x3s2_idx(x, scale=None, shift=None):
+    """(pooled, winning taps) of a 3x3 / stride-2 / pad-1 max pool; with scale / shift: of relu(x * scale + shift), evaluated on the load
+    (mhe_maxpool3x3s2_idx_affine_nhwc: the normalised activation is never materialised)"""
     B, H, W, Cc = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     y = torch.empty(B, Ho, Wo, Cc, device=x.device, dtype=x.dtype)
     idx = torch.empty(B, Ho, Wo, Cc, device=x.device, dtype=torch.uint8)
     _chk(x, x.dtype, "maxpool_idx.x")
+    if scale is not None:
+        _chk(scale, torch.float32, "maxpool_idx.scale", (Cc,)); _chk(shift, torch.float32, "maxpool_idx.shift", (Cc,))
+        check(_lib.lib().mhe_maxpool3x3s2_idx_affine_nhwc(_ptr(x), _ptr(scale), _ptr(shift), _ptr(y), _ptr(idx), B, H, W, Cc, dtype_code(x.dtype), _stream()),
+              "mhe_maxpool3x3s2_idx_affine_nhwc")
+        return y, idx
     check(_lib.lib().mhe_maxpool3x3s2_idx_nhwc(_ptr(x), _ptr(y), _ptr(idx), B, H, W, Cc, dtype_code(x.dtype), _stream()), "mhe_maxpool3x3s2_idx_nhwc")
     return y, idx
+
+
+def maxpool3x3s2_bwd_bn(gy, idx, y, scale, shift, mean_invstd, stats):
+    """reverse of maxpool(relu(bn(y))) up to the BatchNorm's sums: returns gx = scatter(gy, idx) [relu(y * scale + shift) > 0] and adds
+    sum gx, sum gx * xhat per channel to `stats` (then bn_backward(gx, None, y, ..., stats, reduced=True) finishes the BatchNorm reverse)"""
+    B, Ho, Wo, Cc = gy.shape
+    dt = gy.dtype
+    _chk(gy, dt, "maxpool_bwd_bn.gy"); _chk(idx, torch.uint8, "maxpool_bwd_bn.idx", gy.shape)
+    _chk(y, dt, "maxpool_bwd_bn.y")
+    H, W = y.shape[1], y.shape[2]
+    if y.shape[0] != B or y.shape[3] != Cc or ((H - 1) // 2 + 1, (W - 1) // 2 + 1) != (Ho, Wo):
+        raise ValueError(f"maxpool_bwd_bn: y {tuple(y.shape)} does not pool to gy {tuple(gy.shape)}")
+    _chk(scale, torch.float32, "maxpool_bwd_bn.scale", (Cc,)); _chk(shift, torch.float32, "maxpool_bwd_bn.shift", (Cc,))
+    _chk(mean_invstd, torch.float32, "maxpool_bwd_bn.mean_invstd", (2, Cc)); _chk(stats, torch.float32, "maxpool_bwd_bn.stats", (stat_shards(), 2, Cc))
+    gx = torch.empty_like(y)
+    check(_lib.lib().mhe_maxpool3x3s2_bwd_bn_nhwc(_ptr(gy), _ptr(idx), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean_invstd), _ptr(stats), _ptr(gx),
+                                                  B, H, W, Cc, dtype_code(dt), _stream()), "mhe_maxpool3x3s2_bwd_bn_nhwc")
+    return gx
 
 
 def maxpool3x3s2_bwd(gy, idx, H, W):

@@ -135,6 +135,8 @@ class TrainStep:
         import os
         # BatchNorm-reverse sums accumulated by the data-gradient epilogues (no separate reduce pass); MHE_BN_REDUCE_FUSED=0: separate pass
         self.fuse_bn_reduce = os.environ.get("MHE_BN_REDUCE_FUSED", "1") == "1"
+        # the stem's BatchNorm + ReLU folded into its max pool, forward and reverse (ops.maxpool3x3s2_idx / maxpool3x3s2_bwd_bn)
+        self.stem_pool_fused = os.environ.get("MHE_STEM_POOL_FUSED", "1") == "1"
         self._bucket_bounds = self._gradient_buckets()
         self._works = []
         self.raw = torch.zeros(self._raw_n, device=self.dev, dtype=torch.float32)
@@ -471,8 +473,13 @@ class TrainStep:
         st = pool.take(64)
         y0 = ops.stem_conv7x7s2(x, u.w_fwd, T, stats=st)
         self._bn_tape(u, self.x_nhwc, y0, st)
-        self.r0 = ops.bn_act(y0, u.scale, u.shift, relu=True)
-        a, self.pool_idx = ops.maxpool3x3s2_idx(self.r0)
+        if self.stem_pool_fused:
+            # pool straight from the raw stem output, BatchNorm + ReLU on the load: the normalised full-resolution copy is never written
+            a, self.pool_idx = ops.maxpool3x3s2_idx(y0, u.scale, u.shift)
+            self.r0 = None
+        else:
+            self.r0 = ops.bn_act(y0, u.scale, u.shift, relu=True)
+            a, self.pool_idx = ops.maxpool3x3s2_idx(self.r0)
         pending = None          # (raw conv3 output, its unit, identity tensor, downsample unit | None): a block tail not yet evaluated
         fuse = self.trunk.fuse_tail
         for bi, b in enumerate(self.blocks):
@@ -595,8 +602,14 @@ class TrainStep:
         for u in self.units:
             u.rev_stats = None
         u = self.stem
-        g_r0 = ops.maxpool3x3s2_bwd(g, self.pool_idx, self.r0.shape[1], self.r0.shape[2])
-        gy0 = self._bn_bwd(u, g_r0, self.r0, pool)
+        if self.stem_pool_fused:
+            # pool scatter + ReLU gate (recomputed from the raw output) + the BatchNorm-reverse sums in one pass
+            st = pool.take(u.cout)
+            g_r0 = ops.maxpool3x3s2_bwd_bn(g, self.pool_idx, u.y, u.scale, u.shift, u.mi, st)
+            gy0 = self._bn_bwd(u, g_r0, None, pool, stats=st)
+        else:
+            g_r0 = ops.maxpool3x3s2_bwd(g, self.pool_idx, self.r0.shape[1], self.r0.shape[2])
+            gy0 = self._bn_bwd(u, g_r0, self.r0, pool)
         ops.conv_wgrad(self.x_nhwc, gy0, 7, 7, 2, 3, u.dw)
         self._grad_ready(0)
 

@@ -221,6 +221,46 @@ def test_batchnorm_relu_backward(gpu_lib, C, P, dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("H,W", [(18, 18), (19, 22)])
+def test_stem_pool_with_batchnorm_folded_in(gpu_lib, dt, H, W):
+    """mhe_maxpool3x3s2_idx_affine_nhwc / mhe_maxpool3x3s2_bwd_bn_nhwc against the separate passes they replace in the train step
+    (BatchNorm apply, pool with winners; pool scatter, BatchNorm-reverse reduction with the ReLU gate): pooled values, winning taps and the
+    gated gradient to the bit, the per-channel sums to summation order; and against torch autograd through relu(bn) -> max_pool2d."""
+    from mhentropy_amd import ops
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(11)
+    B, C = 3, 64
+    y0 = torch.randn(B, C, H, W, generator=g).to(dt).float()
+    scale, shift = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    scale[::7] *= -1.0                                                  # negative BatchNorm weights: relu(bn) is decreasing in the raw output
+    mean, invstd = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    y0d, sc, sh = _nhwc(y0, dt), scale.cuda(), shift.cuda()
+    r0 = ops.bn_act(y0d, sc, sh, relu=True)
+    a_ref, idx_ref = ops.maxpool3x3s2_idx(r0)
+    a, idx = ops.maxpool3x3s2_idx(y0d, sc, sh)
+    assert torch.equal(a, a_ref) and torch.equal(idx, idx_ref)
+    gy = torch.randn(a.shape, generator=g).to(dt).cuda()
+    mi = torch.stack([mean, invstd]).cuda().contiguous()
+    st = torch.zeros(ops.stat_shards(), 2, C, device="cuda")
+    gx = ops.maxpool3x3s2_bwd_bn(gy, idx, y0d, sc, sh, mi, st)
+    g_sep = ops.maxpool3x3s2_bwd(gy, idx_ref, H, W)
+    assert torch.equal(gx, torch.where(r0 > 0, g_sep, torch.zeros_like(g_sep)))
+    st_ref = torch.zeros_like(st)
+    from mhentropy_amd import _lib
+    ops.check(_lib.lib().mhe_bn_bwd_reduce_nhwc(ops._ptr(g_sep), ops._ptr(r0), ops._ptr(y0d), ops._ptr(mi), ops._ptr(st_ref), B * H * W, C,
+                                                ops.dtype_code(dt), ops._stream()), "mhe_bn_bwd_reduce_nhwc")
+    assert_close(st.sum(0).cpu(), st_ref.sum(0).cpu(), 1e-5, what="BatchNorm-reverse sums")
+    # torch autograd through the same composition (f32): values up to the storage rounding of dt
+    yt = y0.clone().requires_grad_(True)
+    rt = torch.relu(yt * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    pt = F.max_pool2d(rt.detach().to(dt).float() + (rt - rt.detach()), 3, 2, 1)  # pool over the values as stored, gradient through relu(bn)
+    assert_close(a.float().cpu(), pt.detach().permute(0, 2, 3, 1), 1e-6 if dt == torch.float32 else 8e-3, what="pooled activation")   # torch: mul + add, here fma
+    (pt * gy.float().cpu().permute(0, 3, 1, 2)).sum().backward()
+    want = yt.grad / scale.view(1, -1, 1, 1)                            # d/d(relu(bn) input): the gated pool gradient
+    assert_close(gx.float().cpu(), want.permute(0, 2, 3, 1), 1e-6 if dt == torch.float32 else 1e-2, what="gated pool gradient")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_pool_backward(gpu_lib, dt):
     from mhentropy_amd import ops
     import torch.nn.functional as F
