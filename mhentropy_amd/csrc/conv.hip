@@ -749,7 +749,8 @@ extern "C" int mhe_conv1x1_residual_in_masked_nhwc(const mhe_conv_desc *d, const
     MHE_REQUIRE(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0, "mhe_conv1x1_residual_in_masked_nhwc: 1x1 stride-1 only");
     MHE_REQUIRE((x2_scale == nullptr) == (x2_shift == nullptr), "mhe_conv1x1_residual_in_masked_nhwc: x2_scale/x2_shift must come together");
     MHE_REQUIRE(!bn_y0 || (bn_mean_invstd0 && bn_stats0), "mhe_conv1x1_residual_in_masked_nhwc: bn_y needs its mean_invstd and stats");
-    MHE_REQUIRE(d->tile == 0 || d->tile == 1 || d->tile == 2, "mhe_conv1x1_residual_in_masked_nhwc: 128-row tiles only (tile 0, 1 or 2)");
+    MHE_REQUIRE(d->tile == 0 || d->tile == 1 || d->tile == 2 || d->tile == 11,
+                "mhe_conv1x1_residual_in_masked_nhwc: 128-row tiles only (tile 0, 1, 2, or 11 = the transfer-wave kernel)");
     const BnRev bn = {{bn_y0, nullptr}, {bn_mean_invstd0, nullptr}, {bn_stats0, nullptr}};
     return conv_entry(d, x, w, y, in_scale, in_shift, nullptr, nullptr, residual, nullptr, x2, x2_scale, x2_shift, a_out, stream, mask, &bn);
 }

@@ -24,6 +24,9 @@ constexpr int T_A = TBM * 8, T_W = TBN * 8, T_STAGE = T_A + T_W;        // uint4
 
 }  // namespace
 
+// DG: data-gradient form - the operand is gy = k2 g + k1 y + k0 (the BatchNorm reverse of the convolution's own output gradient, written out
+// once for the weight gradient); the outputs are ReLU-gated by p.mask (+ residual) and feed the BatchNorm-reverse sums of up to two consumers
+template <bool DG>
 __global__ __launch_bounds__(512) void conv_tail_kernel(const Params p) {
     using T = u16;
     __shared__ uint4 lds[2 * T_STAGE];                                   // 96 KiB; the epilogue's 64 KiB staging buffer lies over it
@@ -102,41 +105,100 @@ __global__ __launch_bounds__(512) void conv_tail_kernel(const Params p) {
     auto store_outputs = [&](int mt, int m0, int n0) __attribute__((always_inline)) {
         const unsigned char *ot = reinterpret_cast<const unsigned char *>(lds);
         const int cc = tid & 31, r0 = tid >> 5;
-        float ss1[8], ss2[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ss1[i] = ss2[i] = 0.f;
-        uint4 raw[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int row = r0 + 16 * j;
-            raw[j] = *reinterpret_cast<const uint4 *>(ot + ((size_t)row * 32 + (cc ^ (row & 31))) * 16);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int row = r0 + 16 * j;
-            if (st_on) {
-                float f[8];
-                Chunk<T>::unpack(raw[j], f);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { ss1[i] += f[i]; ss2[i] = fmaf(f[i], f[i], ss2[i]); }
-            }
-            *reinterpret_cast<uint4 *>(yg + (size_t)(m0 + row) * p.Cout + n0 + cc * 8) = raw[j];
-        }
-        if (st_on) {
-            // fold the 16 threads that share a column chunk, then add to this pixel tile's shard
-            float *red = reinterpret_cast<float *>(lds);
+        float *red = reinterpret_cast<float *>(lds);
+        // fold 16 threads' partial sums per column chunk and add them to this pixel tile's shard of dst
+        auto fold = [&](const float *a8, const float *b8, float *dst) __attribute__((always_inline)) {
             __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { red[tid * 16 + i] = ss1[i]; red[tid * 16 + 8 + i] = ss2[i]; }
+            for (int i = 0; i < 8; ++i) { red[tid * 16 + i] = a8[i]; red[tid * 16 + 8 + i] = b8[i]; }
             __syncthreads();
             if (tid < 256) {
                 const int ch = tid >> 3, e = tid & 7;
                 float a = 0.f, b = 0.f;
                 for (int k = 0; k < 16; ++k) { a += red[(ch + 32 * k) * 16 + e]; b += red[(ch + 32 * k) * 16 + 8 + e]; }
-                float *st = p.stats + (size_t)(mt % NSH) * 2 * p.Cout;
+                float *st = dst + (size_t)(mt % NSH) * 2 * p.Cout;
                 atomicAdd(st + n0 + tid, a);
                 atomicAdd(st + p.Cout + n0 + tid, b);
             }
+        };
+        if constexpr (DG) {
+            const T *mk = reinterpret_cast<const T *>(p.mask), *rg = reinterpret_cast<const T *>(p.residual);
+            const T *y0g = reinterpret_cast<const T *>(p.bn_y[0]), *y1g = reinterpret_cast<const T *>(p.bn_y[1]);
+            const int ccol = n0 + cc * 8;
+            float bs1[2][8], bs2[2][8], bmu[2][8], biv[2][8];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const bool ok = p.bn_y[u] != nullptr;
+                    bs1[u][i] = bs2[u][i] = 0.f;
+                    bmu[u][i] = ok ? p.bn_mi[u][ccol + i] : 0.f;
+                    biv[u][i] = ok ? p.bn_mi[u][p.Cout + ccol + i] : 0.f;
+                }
+#pragma unroll 1
+            for (int j0 = 0; j0 < 8; j0 += 4) {                          // four rows at a time: their operand loads in flight together
+                uint4 raw[4], gm[4], rr[4], ya[4], yb[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = r0 + 16 * (j0 + j);
+                    const size_t off = (size_t)(m0 + row) * p.Cout + ccol;
+                    gm[j] = *reinterpret_cast<const uint4 *>(mk + off);
+                    rr[j] = rg ? *reinterpret_cast<const uint4 *>(rg + off) : make_uint4(0, 0, 0, 0);
+                    if (y0g) ya[j] = *reinterpret_cast<const uint4 *>(y0g + off);
+                    if (y1g) yb[j] = *reinterpret_cast<const uint4 *>(y1g + off);
+                    raw[j] = *reinterpret_cast<const uint4 *>(ot + ((size_t)row * 32 + (cc ^ (row & 31))) * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = r0 + 16 * (j0 + j);
+                    float v[8], t[8];
+                    Chunk<T>::unpack(raw[j], v);
+                    if (rg) {
+                        Chunk<T>::unpack(rr[j], t);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] += t[i];
+                    }
+                    Chunk<T>::unpack(gm[j], t);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = t[i] > 0.f ? v[i] : 0.f;
+                    if (y0g) {
+                        Chunk<T>::unpack(ya[j], t);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { bs1[0][i] += v[i]; bs2[0][i] = fmaf(v[i], (t[i] - bmu[0][i]) * biv[0][i], bs2[0][i]); }
+                    }
+                    if (y1g) {
+                        Chunk<T>::unpack(yb[j], t);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { bs1[1][i] += v[i]; bs2[1][i] = fmaf(v[i], (t[i] - bmu[1][i]) * biv[1][i], bs2[1][i]); }
+                    }
+                    *reinterpret_cast<uint4 *>(yg + (size_t)(m0 + row) * p.Cout + ccol) = Chunk<T>::pack(v);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (p.bn_y[u]) fold(bs1[u], bs2[u], p.bn_stats[u]);
+        } else {
+            float ss1[8], ss2[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ss1[i] = ss2[i] = 0.f;
+            uint4 raw[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = r0 + 16 * j;
+                raw[j] = *reinterpret_cast<const uint4 *>(ot + ((size_t)row * 32 + (cc ^ (row & 31))) * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = r0 + 16 * j;
+                if (st_on) {
+                    float f[8];
+                    Chunk<T>::unpack(raw[j], f);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { ss1[i] += f[i]; ss2[i] = fmaf(f[i], f[i], ss2[i]); }
+                }
+                *reinterpret_cast<uint4 *>(yg + (size_t)(m0 + row) * p.Cout + n0 + cc * 8) = raw[j];
+            }
+            if (st_on) fold(ss1, ss2, p.stats);
         }
     };
     // Each role has its own loop over the workgroup's tiles (the transfer waves' register sets must not be live in the multiply waves'
@@ -213,27 +275,40 @@ __global__ __launch_bounds__(512) void conv_tail_kernel(const Params p) {
                 if (t + 1 < nk) tick(t + 1, st0);
             }
             __syncthreads();
-            if (L + (int)gridDim.x < ntiles) {                            // the next pixel tile's first K tiles, in flight across this tile's epilogue
-                int mt2, nt2;
-                tile_at(L + (int)gridDim.x, mt2, nt2);
-                load_tile(0, st0, mt2 * TBM, nt2 * TBN);
-                if (1 < nk) load_tile(1, st1, mt2 * TBM, nt2 * TBN);
+            if constexpr (!DG) {
+                if (L + (int)gridDim.x < ntiles) {                        // the next pixel tile's first K tiles, in flight across this tile's epilogue
+                    int mt2, nt2;
+                    tile_at(L + (int)gridDim.x, mt2, nt2);
+                    load_tile(0, st0, mt2 * TBM, nt2 * TBN);
+                    if (1 < nk) load_tile(1, st1, mt2 * TBM, nt2 * TBN);
+                }
             }
             __syncthreads();
             store_outputs(mt, m0, n0);
+            if constexpr (DG) {                                           // (the epilogue's operand registers and the two sets do not fit together)
+                if (L + (int)gridDim.x < ntiles) {
+                    int mt2, nt2;
+                    tile_at(L + (int)gridDim.x, mt2, nt2);
+                    load_tile(0, st0, mt2 * TBM, nt2 * TBN);
+                    if (1 < nk) load_tile(1, st1, mt2 * TBM, nt2 * TBN);
+                }
+            }
         }
     }
 }
 
 bool tail_supports(const Params &p) {
-    return p.x2 && p.in_scale && !p.mask && !p.residual && !p.out_scale && !p.out_shift && !p.relu_out && !p.y32 && !p.os2 && !p.res_s2 &&
+    if (p.mask ? (p.stats != nullptr) : (p.residual != nullptr)) return false;      // data-gradient form: gate (+ residual) + BatchNorm-reverse sums, no statistics
+    return p.x2 && p.in_scale && !p.out_scale && !p.out_shift && !p.relu_out && !p.y32 && !p.os2 && !p.res_s2 &&
            p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.Kpad == p.Cin && p.Cin % TBK == 0 && p.Cin >= 2 * TBK && p.Cin <= TMAXK &&
            p.Cout % TBN == 0 && p.M % TBM == 0;
 }
 
 int launch_tail(const Params &p, hipStream_t s) {
     const int ntiles = (p.M / TBM) * (p.Cout / TBN);
-    hipLaunchKernelGGL(conv_tail_kernel, dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3(512), 0, s, p);
+    const dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256));
+    if (p.mask) hipLaunchKernelGGL(conv_tail_kernel<true>, grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL(conv_tail_kernel<false>, grid, dim3(512), 0, s, p);
     return check_launch("conv_tail_kernel");
 }
 

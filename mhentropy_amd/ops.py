@@ -53,7 +53,7 @@ def _conv_kernel_name(d, dt, mode):
     bke = 32 if dt == torch.float32 else 64
     tile = _lib.lib().mhe_conv_tile_mode(C.byref(d), mode)
     if tile == 10:
-        return "mhe::conv::conv_tail_kernel"
+        return "mhe::conv::conv_tail_kernel<false>"
     if tile == 9:
         return "mhe::conv::conv3x3_c64_stream_kernel<%s, false>" % ("true" if mode == 1 else "false")
     if tile == 8:

@@ -137,6 +137,7 @@ class TrainStep:
         self.fuse_bn_reduce = os.environ.get("MHE_BN_REDUCE_FUSED", "1") == "1"
         # the stem's BatchNorm + ReLU folded into its max pool, forward and reverse (ops.maxpool3x3s2_idx / maxpool3x3s2_bwd_bn)
         self.stem_pool_fused = os.environ.get("MHE_STEM_POOL_FUSED", "1") == "1"
+        self.bn_on_load_wide = os.environ.get("MHE_BN_BWD_ON_LOAD_WIDE", "1") == "1"
         self._bucket_bounds = self._gradient_buckets()
         self._works = []
         self.raw = torch.zeros(self._raw_n, device=self.dev, dtype=torch.float32)
@@ -562,7 +563,11 @@ class TrainStep:
             ul = us[-1]
             # bottleneck conv3 (1x1, stride 1): its BatchNorm reverse is applied in the operand load of its own data gradient
             # (ops.conv1x1_dgrad_bn_apply) instead of by a pass over three block-wide tensors
-            on_load = self.bn_apply_on_load and len(us) == 3 and ul.k == 1 and ul.stride == 1 and ul.cin <= self.bn_on_load_max_cin
+            # (the register-staged kernel pays for it up to 128 bottleneck channels; the wide layers take it where the transfer-wave
+            # kernel, csrc/conv_tail.hip, runs their data gradient)
+            on_load = self.bn_apply_on_load and len(us) == 3 and ul.k == 1 and ul.stride == 1 and (
+                ul.cin <= self.bn_on_load_max_cin or (self.bn_on_load_wide and ops.conv_tile_choice(
+                    g.shape[0], g.shape[1], g.shape[2], ul.cout, ul.cin, 1, 1, 0, g.dtype, 2) == 10))
             if on_load:
                 rs = getattr(ul, "rev_stats", None)
                 coef = ops.bn_backward(g, None, ul.y, ul.mi, ul.bn.weight.data, rs if rs is not None else pool.take(ul.cout), ul.dgamma,

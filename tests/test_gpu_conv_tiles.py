@@ -241,6 +241,39 @@ def test_dgrad_with_batchnorm_reverse_applied_on_load(gpu_lib, Cin, Cout, dt):
     assert ((s1 - s2).abs() <= (1e-4 if dt == torch.float32 else 3e-2) * scale).all(), "BatchNorm-reverse sums"
 
 
+@pytest.mark.parametrize("geom", [(8, 16, 1024, 256), (4, 16, 2048, 512), (24, 32, 256, 512)], ids=lambda g: "x".join(map(str, g)))
+def test_dgrad_with_batchnorm_reverse_on_load_transfer_wave_kernel(gpu_lib, geom):
+    """the data-gradient form of variant 10 (csrc/conv_tail.hip), as the train step uses it for conv3 of layer3 / layer4: against the 128x128
+    variant (operand written out: to the bit; gated gradient and BatchNorm-reverse sums: to accumulation order); the third geometry has more
+    tiles than persistent workgroups"""
+    from mhentropy_amd import ops
+    B, H, Cin, Cout = geom
+    dt = torch.bfloat16
+    assert ops.conv_tile_choice(B, H, H, Cin, Cout, 1, 1, 0, dt, 2) == 10
+    gen = torch.Generator().manual_seed(Cin + Cout)
+    rnd = lambda *s: torch.randn(*s, generator=gen)
+    g, y = rnd(B, H, H, Cin).to(dt).cuda(), (rnd(B, H, H, Cin) * 2 + 0.3).to(dt).cuda()
+    coef = torch.stack([torch.rand(Cin, generator=gen) + 0.5, rnd(Cin) * 0.2, rnd(Cin) * 0.1]).cuda().contiguous()
+    w = (rnd(Cout, Cin) / Cin ** 0.5).to(dt).cuda().contiguous()
+    mask = rnd(B, H, H, Cout).to(dt).cuda()
+    bn_y = rnd(B, H, H, Cout).to(dt).cuda()
+    mi = torch.stack([rnd(Cout) * 0.1, torch.rand(Cout, generator=gen) + 0.5]).cuda().contiguous()
+    res = {}
+    for tile in (11, 2):
+        st = torch.zeros(ops.stat_shards(), 2, Cout, device="cuda")
+        gy = torch.full_like(g, float("nan"))
+        out = ops.conv1x1_dgrad_bn_apply(g, y, coef, w, gy, mask, bn=[(bn_y, mi, st)], tile=tile)
+        res[tile] = (out, gy, st.sum(0).cpu())
+    out, gy, s1 = res[11]
+    assert torch.equal(gy, res[2][1]), "operand written out differs from the 128x128 variant's"
+    want = (gy.float() @ w.float().t()) * (mask.float() > 0)
+    assert_close(out.float().cpu(), want.cpu(), 8e-3, what="gated data gradient")
+    assert_close(out.float().cpu(), res[2][0].float().cpu(), 8e-3, what="vs the 128x128 variant")
+    s2 = res[2][2]
+    scale = s2.abs().max(1, keepdim=True)[0] + 1.0
+    assert ((s1 - s2).abs() <= 3e-2 * scale).all(), "BatchNorm-reverse sums"
+
+
 @pytest.mark.parametrize("tile", [0, 2, 8])
 @pytest.mark.parametrize("masked", [True, False])
 def test_half_resolution_residual(gpu_lib, tile, masked):
