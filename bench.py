@@ -308,7 +308,7 @@ def main():
                 import hashlib
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
                 cs = os.path.join(ROOT, "mhentropy_amd", "csrc")
-                sha = hashlib.sha1(b"".join(open(os.path.join(cs, f), "rb").read() for f in ("conv.hip", "conv_p8.hip", "conv_stream.hip", "conv_tail.hip", "conv_shared.h"))).hexdigest()
+                sha = hashlib.sha1(b"".join(open(os.path.join(cs, f), "rb").read() for f in ("conv.hip", "conv_p8.hip", "conv_stream.hip", "conv_tail.hip", "conv_wide.hip", "conv_shared.h"))).hexdigest()
                 if pmc.get("source_sha1") == sha:
                     traffic = pmc["kernels"].get(order[0], {}).get("hbm_bytes_per_launch")
                     tnote = "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r02_pmc_traffic.json, same kernel sources)"

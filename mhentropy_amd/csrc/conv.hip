@@ -636,6 +636,8 @@ bool stream_supports(const Params &p);         // conv_stream.hip: the streaming
 int launch_stream(const Params &p, hipStream_t s);
 bool stream3_supports(const Params &p);        // conv_stream.hip: the row-streaming 3x3 kernel for 64 -> 64 channels (variant 9)
 int launch_stream3(const Params &p, hipStream_t s);
+bool wide_supports(const Params &p);           // conv_wide.hip: resident weight slab + transfer waves for 256 / 512 -> many channels (variant 11)
+int launch_wide(const Params &p, hipStream_t s);
 bool tail_supports(const Params &p);           // conv_tail.hip: residual tail + conv1 on a 128 x 256 tile with transfer waves (variant 10)
 int launch_tail(const Params &p, hipStream_t s);
 
@@ -646,6 +648,10 @@ static int choose_tile(const Params &p, bool fast, bool bf16) {
     static const int env_stream = getenv("MHE_CONV_STREAM") ? atoi(getenv("MHE_CONV_STREAM")) : 1;
     if (bf16 && (force == 8 || (force < 0 && env_stream)) && stream_supports(p)) return 8;
     if (bf16 && (force == 9 || (force < 0 && env_stream)) && stream3_supports(p)) return 9;
+    static const int env_wide = getenv("MHE_CONV_WIDE") ? atoi(getenv("MHE_CONV_WIDE")) : 1;
+    // (selected by itself at 256 input channels only: at 512 the 64-channel slabs make 32 workgroups re-read every activation tile through
+    // one L2 - 62 us against the phase-pipelined kernel's 46 at layer4's conv3)
+    if (bf16 && (force == 11 || (force < 0 && env_wide && p.Cin == 256)) && wide_supports(p)) return 11;
     static const int env_tail = getenv("MHE_CONV_TAIL") ? atoi(getenv("MHE_CONV_TAIL")) : 1;
     if (bf16 && (force == 10 || (force < 0 && env_tail)) && tail_supports(p)) return 10;
     if ((force & 15) == 7 && bf16 && p8_supports(p)) return 7;      // (higher bits: ablation builds of tuning runs)
@@ -675,6 +681,7 @@ static int launch_conv(const Params &p, hipStream_t s) {
         if (t0 == 8) return launch_stream(p, s);
         if (t0 == 9) return launch_stream3(p, s);
         if (t0 == 10) return launch_tail(p, s);
+        if (t0 == 11) return launch_wide(p, s);
         if (t0 == 7) return launch_p8(p, s);
     }
     if (p.x2 && !fast) { set_error("residual-tail prologue needs Cin %% %d == 0", BKE); return MHE_ERR_ARG; }

@@ -52,6 +52,8 @@ def _conv_kernel_name(d, dt, mode):
     """the template instantiation the launcher will pick, spelled as rocprofv3 prints it"""
     bke = 32 if dt == torch.float32 else 64
     tile = _lib.lib().mhe_conv_tile_mode(C.byref(d), mode)
+    if tile == 11:
+        return "mhe::conv::conv_wide_kernel<%s, %s>" % ("128, 4" if d.Cin == 256 else "64, 8", "true" if mode == 1 else "false")
     if tile == 10:
         return "mhe::conv::conv_tail_kernel<false>"
     if tile == 9:

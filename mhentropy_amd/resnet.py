@@ -162,7 +162,9 @@ class ResNetTrunk(nn.Module):
                 ap2 = "load" if self.bn_apply_3x3 == "auto" and ops.conv_tile_choice(
                     y1.shape[0], y1.shape[1], y1.shape[2], y1.shape[3], blk.conv2.out_channels, 3, blk.stride, 1, y1.dtype, 1) == 9 else None
                 y2, a2 = self._conv_bn(y1, blk.conv2, blk.bn2, pool, a1, blk.stride, 1, 3, apply=ap2)
-                ap3 = self.bn_apply_1x1 if self.bn_apply_1x1 != "auto" else ("load" if blk.conv3.in_channels <= 128 else "pass")
+                # (... and where the resident-slab kernel runs conv3, layer3 at C2: its transfer waves normalise each K tile once)
+                ap3 = self.bn_apply_1x1 if self.bn_apply_1x1 != "auto" else ("load" if blk.conv3.in_channels <= 128 or ops.conv_tile_choice(
+                    y2.shape[0], y2.shape[1], y2.shape[2], y2.shape[3], blk.conv3.out_channels, 1, 1, 0, y2.dtype, 1) == 11 else "pass")
                 yl, al = self._conv_bn(y2, blk.conv3, blk.bn3, pool, a2, apply=ap3)
             else:
                 y1, a1 = self._conv_bn(a, blk.conv1, blk.bn1, pool, None, blk.stride, 1, 3)

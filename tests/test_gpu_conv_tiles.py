@@ -274,6 +274,39 @@ def test_dgrad_with_batchnorm_reverse_on_load_transfer_wave_kernel(gpu_lib, geom
     assert ((s1 - s2).abs() <= 3e-2 * scale).all(), "BatchNorm-reverse sums"
 
 
+@pytest.mark.parametrize("geom", [(64, 16, 256, 1024), (64, 8, 512, 2048), (128, 16, 512, 256)], ids=lambda g: "x".join(map(str, g)))
+@pytest.mark.parametrize("bn_load", [False, True], ids=["plain", "bn-on-load"])
+def test_resident_slab_kernel_with_transfer_waves(gpu_lib, geom, bn_load):
+    """variant 11 (csrc/conv_wide.hip): conv3 of layer3 / layer4 (and 512 -> 256, four slabs) with the weight slab resident in LDS and the
+    load / (BatchNorm +) store work in transfer waves; against matmul on the rounded operand, the phase-pipelined / register-staged variant,
+    and the batch statistics of the stored outputs"""
+    from mhentropy_amd import ops
+    B, H, Cin, Cout = geom
+    dt = torch.bfloat16
+    assert (ops.conv_tile_choice(B, H, H, Cin, Cout, 1, 1, 0, dt, int(bn_load)) == 11) == (Cin == 256)     # 512 input channels: on request only
+    gen = torch.Generator().manual_seed(Cin + Cout + bn_load)
+    x = torch.randn(B, H, H, Cin, generator=gen).to(dt).cuda()
+    w = (torch.randn(Cout, Cin, generator=gen) / Cin ** 0.5).to(dt).cuda().contiguous()
+    sc = (torch.rand(Cin, generator=gen) + 0.5).cuda() if bn_load else None
+    sh = (torch.randn(Cin, generator=gen) * 0.3).cuda() if bn_load else None
+    a = torch.relu(x.float() * sc + sh).to(dt).float() if bn_load else x.float()
+    want = a.reshape(-1, Cin) @ w.float().t()
+    res = {}
+    for tile in (12, 2):
+        st = torch.zeros(ops.stat_shards(), 2, Cout, device="cuda")
+        y = ops.conv2d_nhwc(x, w, 1, 1, 1, 0, in_scale=sc, in_shift=sh, relu_in=bn_load, stats=st, tile=tile)
+        res[tile] = (y, st.double().sum(0).cpu())
+    y, st = res[12]
+    assert_close(y.float().cpu().reshape(-1, Cout), want.cpu(), TOL, what="1x1 product")
+    assert_close(y.float().cpu(), res[2][0].float().cpu(), 8e-3, what="vs the 128x128 variant")
+    n = y.numel() / Cout
+    yd = y.double().cpu().reshape(-1, Cout)
+    assert_close(st[0] / n, yd.mean(0), 1e-5, 1e-5, what="batch mean (of the stored output)")
+    assert_close(st[1] / n, (yd * yd).mean(0), 1e-5, 1e-5, what="batch mean square (of the stored output)")
+    y2 = ops.conv2d_nhwc(x, w, 1, 1, 1, 0, in_scale=sc, in_shift=sh, relu_in=bn_load, tile=12)       # without statistics
+    assert torch.equal(y2, y)
+
+
 @pytest.mark.parametrize("tile", [0, 2, 8])
 @pytest.mark.parametrize("masked", [True, False])
 def test_half_resolution_residual(gpu_lib, tile, masked):

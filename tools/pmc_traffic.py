@@ -38,7 +38,7 @@ def main():
         res[k] = {"launches_profiled": nf, "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
                   "hbm_bytes_per_launch": round(rd + wr)}
     cs = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mhentropy_amd", "csrc")
-    sha = hashlib.sha1(b"".join(open(os.path.join(cs, f), "rb").read() for f in ("conv.hip", "conv_p8.hip", "conv_stream.hip", "conv_tail.hip", "conv_shared.h"))).hexdigest()
+    sha = hashlib.sha1(b"".join(open(os.path.join(cs, f), "rb").read() for f in ("conv.hip", "conv_p8.hip", "conv_stream.hip", "conv_tail.hip", "conv_wide.hip", "conv_shared.h"))).hexdigest()
     json.dump({"source_sha1": sha, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py "
                          "--steps 2 --warmup 1 --dtype bf16 --no-cpu-baseline --graph 0 --train-steps 0 --no-glow-variant",
                "correction": "FETCH_SIZE x2 (gfx950 wide coalesced reads), counters in KiB", "kernels": res},
