@@ -114,6 +114,26 @@ def test_state_dict_keys_match_reference_layout():
     assert all(k.startswith("mano_dec.") for k in missing)
 
 
+def test_launcher_picks_the_documented_kernel_variants_at_c2():
+    """host logic only (mhe_conv_tile_mode runs no kernel): the variant table of DESIGN.md section 4 at the bench workload's shapes
+    (B = 256, ResNet-50 at 256x256, bf16) - streaming kernels for the write-bound layers, transfer-wave kernels for the wide ones"""
+    import torch
+    from mhentropy_amd import ops
+    bf, B = torch.bfloat16, 256
+    pick = lambda H, cin, cout, k, stride=1, mode=0: ops.conv_tile_choice(B, H, H, cin, cout, k, stride, k // 2, bf, mode)
+    assert pick(64, 64, 64, 3) == 9 and pick(64, 64, 64, 3, mode=1) == 9          # layer1 conv2: row-streaming 3x3, also with BatchNorm on load
+    assert pick(64, 64, 256, 1) == 8 and pick(64, 64, 256, 1, mode=1) == 8        # layer1 conv3 / shortcut: streaming 1x1
+    assert pick(32, 128, 512, 1, mode=1) == 8                                     # layer2 conv3
+    assert pick(16, 256, 1024, 1) == 11 and pick(16, 256, 1024, 1, mode=1) == 11  # layer3 conv3: resident slab + transfer waves
+    assert pick(8, 512, 2048, 1) == 7                                             # layer4 conv3 stays on the phase-pipelined kernel
+    assert pick(16, 1024, 256, 1, mode=2) == 10 and pick(8, 2048, 512, 1, mode=2) == 10      # residual tails of layer3 / layer4
+    assert pick(32, 512, 256, 1, mode=2) == 10 and pick(16, 1024, 512, 1, mode=2) == 10      # ... and the transitions into them
+    assert pick(64, 256, 64, 1, mode=2) == 0 and pick(32, 512, 128, 1, mode=2) == 1          # layer1 / layer2 tails: register-staged tiles
+    assert pick(16, 256, 256, 3) == 7 and pick(32, 128, 128, 3) == 1              # 3x3: phase-pipelined from 256 channels, 128x128 below
+    # small batches fall back to the tiled kernels (the streaming / transfer-wave kernels want whole persistent workgroups)
+    assert ops.conv_tile_choice(4, 16, 16, 256, 1024, 1, 1, 0, bf, 0) not in (8, 9, 10, 11)
+
+
 def test_product_refuses_cpu_tensors():
     from mhentropy_amd import ops
     with pytest.raises(_lib.MheError):
