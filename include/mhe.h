@@ -301,6 +301,8 @@ int mhe_avgpool_nhwc(const void *x, float *y, int B, int HW, int C, int dtype, v
 
 /* NCHW f32 image -> NHWC (dtype), stem input layout change. */
 int mhe_nchw_to_nhwc(const float *x, void *y, int B, int C, int H, int W, int dtype, void *stream);
+/* ... with the channel padding given (Cp >= C; 3 -> 4 in bf16 = one 8-byte store per pixel: the operand of mhe_conv_wgrad_rect_nhwc for the stem) */
+int mhe_nchw_to_nhwc_pad(const float *x_nchw, void *y, int B, int C, int Cp, int H, int W, int dtype, void *stream);
 
 /* evaluation metrics ---------------------------------------------------------
  * MHEntLoss metrics (hand/criteria.py:91-168): xyz [N,B,63] normalised joints,
@@ -341,6 +343,14 @@ int mhe_conv_wgrad_nhwc(const mhe_conv_desc *d, const void *x, const void *gy, f
 size_t mhe_conv_wgrad_workspace_floats(const mhe_conv_desc *d);
 int mhe_conv_wgrad_ws_nhwc(const mhe_conv_desc *d, const void *x, const void *gy, float *dw, int ldw, float *workspace,
                            size_t workspace_floats, void *stream);
+/* Weight gradient of a convolution whose WIDTH direction has its own stride and left padding and whose output size is given instead of
+ * derived (d->stride / d->pad describe the height direction; d->KH x d->KW taps).  Use: the stem's 7x7 / stride-2 / pad-3 convolution
+ * (reference: torchvision ResNet.conv1 under hand/CrossModalHand.py:455-470's backward) read as a 7 x 4 / stride (2, 1) / pad (3, 2)
+ * convolution over PIXEL PAIRS - x [B, H, W/2, 8] = two neighbouring pixels x (3 channels padded to 4), Ho x Wo = H/2 x W/2 - so that
+ * dW' [Cout][7][4][8] has 224 columns instead of the 392 of 3 channels padded to 8; dW'[co][kh][kw'][4 par + c] = dW[co][c][kh][2 kw' + par - 1]. */
+size_t mhe_conv_wgrad_rect_workspace_floats(const mhe_conv_desc *d, int Ho, int Wo);
+int mhe_conv_wgrad_rect_nhwc(const mhe_conv_desc *d, int stride_w, int pad_w, int Ho, int Wo, const void *x, const void *gy, float *dw,
+                             int ldw, float *workspace, size_t workspace_floats, void *stream);
 /* out[c] += sum_r rows[r][c] (bias gradients; caller zeroes out); rows f32 or bf16, sums f32. */
 int mhe_colsum_f32(const void *rows, float *out, long R, int C, int dtype, void *stream);
 /* dst[i] = (idx[i] < 0 ? 0 : src[idx[i]]) + (idx2 != NULL && idx2[i] >= 0 ? src[idx2[i]] : 0) ; dst f32 or bf16.  Every weight re-layout of a train step (forward

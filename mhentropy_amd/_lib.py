@@ -38,6 +38,8 @@ SIGNATURES = {
     "mhe_conv_wgrad_nhwc": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _i, _p]),
     "mhe_conv_wgrad_workspace_floats": (_sz, [C.POINTER(ConvDesc)]),
     "mhe_conv_wgrad_ws_nhwc": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _i, _p, _sz, _p]),
+    "mhe_conv_wgrad_rect_workspace_floats": (_sz, [C.POINTER(ConvDesc), _i, _i]),
+    "mhe_conv_wgrad_rect_nhwc": (_i, [C.POINTER(ConvDesc), _i, _i, _i, _i, _p, _p, _p, _i, _p, _sz, _p]),
     "mhe_colsum_f32": (_i, [_p, _p, _l, _i, _i, _p]),
     "mhe_gather_f32": (_i, [_p, _p, _p, _p, _sz, _i, _p]),
     "mhe_flow_mask_pad_f32": (_i, [_p, _p, _p, _l, _i, _p]),
@@ -94,6 +96,7 @@ SIGNATURES = {
     "mhe_maxpool3x3s2_nhwc": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mhe_avgpool_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mhe_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "mhe_nchw_to_nhwc_pad": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mhe_rot6d_to_rotmat_f32": (_i, [_p, _p, _l, _i, _p]),
     "mhe_rot6d_to_rotmat_bwd_f32": (_i, [_p, _p, _p, _l, _p]),
     "mhe_lbs_workspace_floats": (_sz, [_i, _i, _i]),

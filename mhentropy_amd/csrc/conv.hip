@@ -612,6 +612,17 @@ __global__ void nchw_to_nhwc_kernel(const float *__restrict__ x, T *__restrict__
     }
 }
 
+// the same for 3 channels padded to 4 in bf16: one 8-byte store per pixel (the stem's weight gradient reads the image as pixel pairs)
+__global__ void nchw3_to_nhwc4_bf16_kernel(const float *__restrict__ x, uint2 *__restrict__ y, int B, int HW) {
+    const size_t n = (size_t)B * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / HW, p = i % HW;
+        const float *src = x + b * 3 * HW + p;
+        const float c0 = src[0], c1 = src[HW], c2 = src[2 * (size_t)HW];
+        y[i] = make_uint2((unsigned)f32_to_bf16(c0) | ((unsigned)f32_to_bf16(c1) << 16), (unsigned)f32_to_bf16(c2));
+    }
+}
+
 template <typename T, int BM, int BN, int WM, int WN, bool FAST>
 static void launch_mode(const Params &p, hipStream_t s) {
     const dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN), block(64 * WM * WN);
@@ -965,6 +976,19 @@ extern "C" int mhe_nchw_to_nhwc(const float *x, void *y, int B, int C, int H, in
     else
         hipLaunchKernelGGL(conv::nchw_to_nhwc_kernel<u16>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x,
                            (u16 *)y, B, C, H * W, Cp);
+    return check_launch("nchw_to_nhwc_kernel");
+}
+
+extern "C" int mhe_nchw_to_nhwc_pad(const float *x, void *y, int B, int C, int Cp, int H, int W, int dtype, void *stream) {
+    MHE_REQUIRE(x && y && B > 0 && C > 0 && Cp >= C && H > 0 && W > 0, "mhe_nchw_to_nhwc_pad: bad arguments");
+    MHE_REQUIRE(dtype == MHE_F32 || dtype == MHE_BF16, "mhe_nchw_to_nhwc_pad: dtype=%d", dtype);
+    const size_t n = (size_t)B * H * W;
+    if (dtype == MHE_BF16 && C == 3 && Cp == 4)
+        hipLaunchKernelGGL(conv::nchw3_to_nhwc4_bf16_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, (uint2 *)y, B, H * W);
+    else if (dtype == MHE_F32)
+        hipLaunchKernelGGL(conv::nchw_to_nhwc_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, (float *)y, B, C, H * W, Cp);
+    else
+        hipLaunchKernelGGL(conv::nchw_to_nhwc_kernel<u16>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, (u16 *)y, B, C, H * W, Cp);
     return check_launch("nchw_to_nhwc_kernel");
 }
 

@@ -20,6 +20,7 @@ struct Params {
     const void *x, *gy;
     float *dw;
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
+    int stride_w, pad_w;   // the width direction's own stride / left padding (= stride / pad except for mhe_conv_wgrad_rect_nhwc)
     int ldw;             // row pitch of dW (floats)
     int N;               // KH*KW*Cin
     long P;              // B*Ho*Wo
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const Params p) {
         b_ok[i] = n < p.N;
         const int tap = b_ok[i] ? n / p.Cin : 0;
         b_ci[i] = b_ok[i] ? n % p.Cin : 0;
-        b_dh[i] = tap / p.KW - p.pad; b_dw[i] = tap % p.KW - p.pad;
+        b_dh[i] = tap / p.KW - p.pad; b_dw[i] = tap % p.KW - p.pad_w;
     }
     v4f ra[A4], rb[B4];
     auto fetch = [&](long k0) {
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const Params p) {
                 const int wo = (int)(pix % p.Wo);
                 const long t = pix / p.Wo;
                 const int ho = (int)(t % p.Ho), b = (int)(t / p.Ho);
-                const int hi = ho * p.stride + b_dh[i], wi = wo * p.stride + b_dw[i];
+                const int hi = ho * p.stride + b_dh[i], wi = wo * p.stride_w + b_dw[i];
                 if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.W)
                     v = Vec4<T>::load(x + (((long)b * p.H + hi) * p.W + wi) * p.Cin + b_ci[i]);
             }
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const Params p) {
     const int nb = n0 + b_c;
     const bool b_ok = nb < p.N;
     const int tap = b_ok ? nb / p.Cin : 0, b_ci = b_ok ? nb % p.Cin : 0;
-    const int b_dh = tap / p.KW - p.pad, b_dw = tap % p.KW - p.pad;
+    const int b_dh = tap / p.KW - p.pad, b_dw = tap % p.KW - p.pad_w;
     uint4 ra[A4], rb[B4];
     auto fetch = [&](long k0) {
 #pragma unroll
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const Params p) {
                 const int wo = (int)(pix % p.Wo);
                 const long t = pix / p.Wo;
                 const int ho = (int)(t % p.Ho), b = (int)(t / p.Ho);
-                const int hi = ho * p.stride + b_dh, wi = wo * p.stride + b_dw;
+                const int hi = ho * p.stride + b_dh, wi = wo * p.stride_w + b_dw;
                 if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.W)
                     v = *reinterpret_cast<const uint4 *>(x + (((long)b * p.H + hi) * p.W + wi) * p.Cin + b_ci);
             }
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const DmaParams dp) {
         b_row[j] = row;
         const int tap = n < p.N ? n / p.Cin : 0;
         b_col[j] = n < p.N ? (unsigned)(n - tap * p.Cin) * 2u : OOB;
-        b_dh[j] = tap / p.KW - p.pad; b_dw[j] = tap % p.KW - p.pad;
+        b_dh[j] = tap / p.KW - p.pad; b_dw[j] = tap % p.KW - p.pad_w;
     }
     const u4v rs_g = {(unsigned)(size_t)p.gy, (unsigned)((size_t)p.gy >> 32) & 0xffffu, dp.gy_bytes, 0x00020000u};
     const u4v rs_x = {(unsigned)(size_t)p.x, (unsigned)((size_t)p.x >> 32) & 0xffffu, dp.x_bytes, 0x00020000u};
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const DmaParams dp) {
             else {
                 const unsigned t = __umulhi(pix, dp.rcp_wo), wo = pix - t * (unsigned)p.Wo;
                 const unsigned bi = __umulhi(t, dp.rcp_ho), ho = t - bi * (unsigned)p.Ho;
-                const unsigned hi = ho * (unsigned)p.stride + (unsigned)b_dh[j], wi = wo * (unsigned)p.stride + (unsigned)b_dw[j];
+                const unsigned hi = ho * (unsigned)p.stride + (unsigned)b_dh[j], wi = wo * (unsigned)p.stride_w + (unsigned)b_dw[j];
                 ok = ok && hi < (unsigned)p.H && wi < (unsigned)p.W;
                 v = ((bi * (unsigned)p.H + hi) * (unsigned)p.W + wi) * (unsigned)(p.Cin * 2) + b_col[j];
             }
@@ -528,9 +529,9 @@ using namespace mhe;
 
 // geometry of a launch: tile, grid and pixel chunk (shared by the launcher and the workspace query)
 struct WgradPlan { int BM, BN, gx, gy, gz; long chunk; bool bf16k, small, narrow; };
-static WgradPlan plan_wgrad(const mhe_conv_desc *d) {
+static WgradPlan plan_wgrad(const mhe_conv_desc *d, int Ho_ = 0, int Wo_ = 0) {
     WgradPlan w;
-    const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+    const int Ho = Ho_ > 0 ? Ho_ : (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = Wo_ > 0 ? Wo_ : (d->W + 2 * d->pad - d->KW) / d->stride + 1;
     const int N = d->KH * d->KW * d->Cin;
     const long P = (long)d->B * Ho * Wo;
     w.small = d->Cout <= 64;
@@ -561,7 +562,8 @@ extern "C" size_t mhe_conv_wgrad_workspace_floats(const mhe_conv_desc *d) {
     return (w.gz > 1 && w.gz <= 64) ? (size_t)w.gz * (w.gy * w.BM) * (size_t)(w.gx * w.BN) : 0;
 }
 
-static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, float *dw, int ldw, float *ws, size_t ws_floats, void *stream);
+static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, float *dw, int ldw, float *ws, size_t ws_floats, void *stream,
+                       int stride_w = 0, int pad_w = -1, int Ho_ = 0, int Wo_ = 0);
 
 extern "C" int mhe_conv_wgrad_nhwc(const mhe_conv_desc *d, const void *x, const void *gy, float *dw, int ldw, void *stream) {
     return wgrad_entry(d, x, gy, dw, ldw, nullptr, 0, stream);
@@ -572,7 +574,25 @@ extern "C" int mhe_conv_wgrad_ws_nhwc(const mhe_conv_desc *d, const void *x, con
     return wgrad_entry(d, x, gy, dw, ldw, workspace, workspace_floats, stream);
 }
 
-static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, float *dw, int ldw, float *ws, size_t ws_floats, void *stream) {
+// a convolution whose width direction has its own stride / left padding and whose output size is given (not derived): the stem's 7x7 /
+// stride-2 weight gradient over PIXEL PAIRS - two neighbouring pixels x 4 padded channels = one 8-channel "pixel", kernel 7 x 4, stride
+// (2, 1), padding (3, 2), output width W/2 exactly - which multiplies 224 columns instead of the 392 of 3 channels padded to 8
+extern "C" size_t mhe_conv_wgrad_rect_workspace_floats(const mhe_conv_desc *d, int Ho, int Wo) {
+    if (!d || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || Ho <= 0 || Wo <= 0) return 0;
+    const WgradPlan w = plan_wgrad(d, Ho, Wo);
+    if ((size_t)d->Cout * d->KH * d->KW * d->Cin < 131072) return 0;
+    return (w.gz > 1 && w.gz <= 64) ? (size_t)w.gz * (w.gy * w.BM) * (size_t)(w.gx * w.BN) : 0;
+}
+
+extern "C" int mhe_conv_wgrad_rect_nhwc(const mhe_conv_desc *d, int stride_w, int pad_w, int Ho, int Wo, const void *x, const void *gy, float *dw,
+                                        int ldw, float *workspace, size_t workspace_floats, void *stream) {
+    MHE_REQUIRE(stride_w > 0 && pad_w >= 0 && Ho > 0 && Wo > 0, "mhe_conv_wgrad_rect_nhwc: bad width geometry");
+    MHE_REQUIRE(d && (Ho - 1) * d->stride - d->pad < d->H && (Wo - 1) * stride_w - pad_w < d->W, "mhe_conv_wgrad_rect_nhwc: output larger than the input allows");
+    return wgrad_entry(d, x, gy, dw, ldw, workspace, workspace_floats, stream, stride_w, pad_w, Ho, Wo);
+}
+
+static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, float *dw, int ldw, float *ws, size_t ws_floats, void *stream,
+                       int stride_w, int pad_w, int Ho_, int Wo_) {
     MHE_REQUIRE(d && x && gy && dw, "mhe_conv_wgrad_nhwc: null pointer");
     MHE_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0,
                 "mhe_conv_wgrad_nhwc: bad geometry");
@@ -582,14 +602,15 @@ static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, fl
     p.x = x; p.gy = gy; p.dw = dw;
     p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
     p.stride = d->stride; p.pad = d->pad;
-    p.Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
-    p.Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+    p.stride_w = stride_w > 0 ? stride_w : d->stride; p.pad_w = pad_w >= 0 ? pad_w : d->pad;
+    p.Ho = Ho_ > 0 ? Ho_ : (d->H + 2 * d->pad - d->KH) / d->stride + 1;
+    p.Wo = Wo_ > 0 ? Wo_ : (d->W + 2 * d->pad - d->KW) / d->stride + 1;
     MHE_REQUIRE(p.Ho > 0 && p.Wo > 0, "mhe_conv_wgrad_nhwc: empty output");
     p.N = d->KH * d->KW * d->Cin;
     p.ldw = ldw > 0 ? ldw : p.N;
     MHE_REQUIRE(p.ldw >= p.N, "mhe_conv_wgrad_nhwc: ldw=%d < KH*KW*Cin=%d", ldw, p.N);
     p.P = (long)d->B * p.Ho * p.Wo;
-    const WgradPlan w = plan_wgrad(d);
+    const WgradPlan w = plan_wgrad(d, Ho_, Wo_);
     const bool small = w.small, bf16k = w.bf16k, narrow = w.narrow;
     const int gx = w.gx, gyy = w.gy, gz = w.gz;
     p.chunk = (int)w.chunk;
@@ -611,7 +632,7 @@ static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, fl
         dp.p = p;
         dp.rcp_wo = (unsigned)((0x100000000ull + p.Wo - 1) / p.Wo); dp.rcp_ho = (unsigned)((0x100000000ull + p.Ho - 1) / p.Ho);
         dp.x_bytes = (unsigned)xb; dp.gy_bytes = (unsigned)gb;
-        dp.plain = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0;
+        dp.plain = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && p.stride_w == 1 && p.pad_w == 0;
         if (narrow) {
             if (small) hipLaunchKernelGGL((wgrad::wgrad_dma_kernel<64, 64, 2, 2>), grid, block, 0, s, dp);
             else hipLaunchKernelGGL((wgrad::wgrad_dma_kernel<128, 64, 4, 1>), grid, block, 0, s, dp);

@@ -457,13 +457,17 @@ def avgpool(x):
     return y
 
 
-def nchw_to_nhwc(x, dtype=torch.float32):
+def nchw_to_nhwc(x, dtype=torch.float32, cpad=None):
+    """NCHW f32 -> NHWC `dtype`, channels zero-padded to a 16-byte chunk (or to cpad: mhe_nchw_to_nhwc_pad)"""
     B, Cn, H, W = x.shape
     _chk(x, torch.float32, "nchw_to_nhwc.x")
     ce = 4 if dtype == torch.float32 else 8
-    Cp = (Cn + ce - 1) // ce * ce
+    Cp = (Cn + ce - 1) // ce * ce if cpad is None else int(cpad)
     y = torch.empty(B, H, W, Cp, device=x.device, dtype=dtype)
-    check(_lib.lib().mhe_nchw_to_nhwc(_ptr(x), _ptr(y), B, Cn, H, W, dtype_code(dtype), _stream()), "mhe_nchw_to_nhwc")
+    if cpad is None:
+        check(_lib.lib().mhe_nchw_to_nhwc(_ptr(x), _ptr(y), B, Cn, H, W, dtype_code(dtype), _stream()), "mhe_nchw_to_nhwc")
+    else:
+        check(_lib.lib().mhe_nchw_to_nhwc_pad(_ptr(x), _ptr(y), B, Cn, Cp, H, W, dtype_code(dtype), _stream()), "mhe_nchw_to_nhwc_pad")
     return y
 
 
@@ -491,6 +495,28 @@ def conv_wgrad(x, gy, KH, KW, stride, pad, dw, ldw=0):
         check(L.mhe_conv_wgrad_ws_nhwc(C.byref(d), _ptr(x), _ptr(gy), _ptr(dw), int(ldw), _ptr(ws), ws.numel(), _stream()), "mhe_conv_wgrad_ws_nhwc")
     else:
         check(L.mhe_conv_wgrad_nhwc(C.byref(d), _ptr(x), _ptr(gy), _ptr(dw), int(ldw), _stream()), "mhe_conv_wgrad_nhwc")
+    return dw
+
+
+def conv_wgrad_rect(x, gy, KH, KW, stride_h, stride_w, pad_h, pad_w, dw):
+    """dw[Cout, KH*KW*Cin] += gy^T (*) x for a convolution with separate height / width stride and (top / left) padding whose output size is
+    gy's (mhe_conv_wgrad_rect_nhwc): the stem's weight gradient over pixel pairs (train.TrainStep)."""
+    B, H, W, Cin = x.shape
+    Ho, Wo, Cout = gy.shape[1], gy.shape[2], gy.shape[3]
+    dt = x.dtype
+    _chk(x, dt, "wgrad_rect.x"); _chk(gy, dt, "wgrad_rect.gy", (B, Ho, Wo, Cout)); _chk(dw, torch.float32, "wgrad_rect.dw")
+    if dw.numel() < Cout * KH * KW * Cin:
+        raise ValueError(f"wgrad_rect.dw: {dw.numel()} floats cannot hold [{Cout}, {KH * KW * Cin}]")
+    d = ConvDesc(B, H, W, Cin, Cout, KH, KW, stride_h, pad_h, dtype_code(dt), 0, 0)
+    L = _lib.lib()
+    need = L.mhe_conv_wgrad_rect_workspace_floats(C.byref(d), Ho, Wo) if WGRAD_SLABS else 0
+    ws = None
+    if need:
+        ws = _WGRAD_WS.get(x.device)
+        if ws is None or ws.numel() < need:
+            ws = _WGRAD_WS[x.device] = torch.empty(need, device=x.device, dtype=torch.float32)
+    check(L.mhe_conv_wgrad_rect_nhwc(C.byref(d), stride_w, pad_w, Ho, Wo, _ptr(x), _ptr(gy), _ptr(dw), 0, _ptr(ws), ws.numel() if ws is not None else 0,
+                                     _stream()), "mhe_conv_wgrad_rect_nhwc")
     return dw
 
 

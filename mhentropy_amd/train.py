@@ -273,6 +273,10 @@ class TrainStep:
                 wp[:, :7, :21] = idx.permute(0, 2, 3, 1).reshape(64, 7, 21)
                 u.w_fwd = self._derived(wp.reshape(64, 192), T)
                 u.cin_w = 4 if T == torch.float32 else 8              # channel padding of the NHWC image copy
+                # bf16: the weight gradient reads the image as PIXEL PAIRS (two neighbours x 3 channels padded to 4 = one 8-channel pixel):
+                # a 7 x 4 / stride (2, 1) / pad (3, 2) convolution with 224 weight columns instead of 7 x 7 x 8 = 392 of which 245 multiply
+                # zeros (ops.conv_wgrad_rect); raw gradient [64][7][4][2 x 4], column kw = 2 kw' + parity - 1
+                u.pairs = T != torch.float32 and os.environ.get("MHE_STEM_WGRAD_PAIRS", "1") == "1"
             else:
                 kk = KH * KW * Cin
                 f = torch.full((Cout, _ceil(kk, bke)), -1, dtype=torch.int64)
@@ -292,14 +296,22 @@ class TrainStep:
                         u.w_s2.append(self._derived(f2, T))
                 u.cin_w = Cin
             # raw weight gradient [Cout][KH*KW*cin_w]
-            u.raw_w = self._raw_slot((Cout, KH * KW * u.cin_w))
-            r = torch.arange(Cout * KH * KW * u.cin_w, dtype=torch.int64).view(Cout, KH, KW, u.cin_w)[..., :Cin] + u.raw_w
-            self._map_grad(w, r.permute(0, 3, 1, 2))
+            if stem and u.pairs:
+                u.raw_w = self._raw_slot((Cout, 7 * 4 * 8))
+                co, ci, kh, kw = torch.meshgrid(torch.arange(Cout), torch.arange(Cin), torch.arange(7), torch.arange(7), indexing="ij")
+                self._map_grad(w, ((co * 7 + kh) * 4 + (kw + 1) // 2) * 8 + ((kw + 1) % 2) * 4 + ci + u.raw_w)
+                wshape = (Cout, 7 * 4 * 8)
+            else:
+                u.pairs = False
+                u.raw_w = self._raw_slot((Cout, KH * KW * u.cin_w))
+                r = torch.arange(Cout * KH * KW * u.cin_w, dtype=torch.int64).view(Cout, KH, KW, u.cin_w)[..., :Cin] + u.raw_w
+                self._map_grad(w, r.permute(0, 3, 1, 2))
+                wshape = (Cout, KH * KW * u.cin_w)
             u.raw_g = self._raw_slot((Cout,)); u.raw_b = self._raw_slot((Cout,))
             self._map_grad(bn.weight, torch.arange(Cout) + u.raw_g)
             self._map_grad(bn.bias, torch.arange(Cout) + u.raw_b)
 
-            def views(u=u, shape=(Cout, KH * KW * u.cin_w)):
+            def views(u=u, shape=wshape):
                 u.dw = self._raw(u.raw_w, shape); u.dgamma = self._raw(u.raw_g, (u.cout,)); u.dbeta = self._raw(u.raw_b, (u.cout,))
             self._raw_views.append(views)
             self.units.append(u)
@@ -470,7 +482,12 @@ class TrainStep:
         pool = resnet._StatsPool(self.dev, channels=65536)
         self._bn_touched = []
         u = self.stem
-        self.x_nhwc = ops.nchw_to_nhwc(x, T)
+        if u.pairs:
+            if x.shape[3] % 2 or x.shape[2] % 2:
+                raise ValueError("TrainStep (bf16): the stem's weight gradient reads pixel pairs - even image sizes only (MHE_STEM_WGRAD_PAIRS=0 lifts this)")
+            self.x_nhwc = ops.nchw_to_nhwc(x, T, cpad=4).view(x.shape[0], x.shape[2], x.shape[3] // 2, 8)
+        else:
+            self.x_nhwc = ops.nchw_to_nhwc(x, T)
         st = pool.take(64)
         y0 = ops.stem_conv7x7s2(x, u.w_fwd, T, stats=st)
         self._bn_tape(u, self.x_nhwc, y0, st)
@@ -615,7 +632,10 @@ class TrainStep:
         else:
             g_r0 = ops.maxpool3x3s2_bwd(g, self.pool_idx, self.r0.shape[1], self.r0.shape[2])
             gy0 = self._bn_bwd(u, g_r0, self.r0, pool)
-        ops.conv_wgrad(self.x_nhwc, gy0, 7, 7, 2, 3, u.dw)
+        if u.pairs:
+            ops.conv_wgrad_rect(self.x_nhwc, gy0, 7, 4, 2, 1, 3, 2, u.dw)
+        else:
+            ops.conv_wgrad(self.x_nhwc, gy0, 7, 7, 2, 3, u.dw)
         self._grad_ready(0)
 
     # ------------------------------------------------------------------ flow reverse

@@ -220,6 +220,38 @@ def test_batchnorm_relu_backward(gpu_lib, C, P, dt):
     assert_close(gm.float().cpu().view(P, C), go * (a.detach() > 0), 1e-6, what="masked g")
 
 
+@pytest.mark.parametrize("B,S", [(2, 32), (3, 40)])
+def test_stem_weight_gradient_over_pixel_pairs(gpu_lib, B, S):
+    """mhe_conv_wgrad_rect_nhwc as the bf16 train step uses it: the 7x7 / stride-2 / pad-3 stem read as a 7 x 4 / stride (2, 1) / pad (3, 2)
+    convolution over pixel pairs (two neighbours x 3 channels padded to 4); un-mapped through dW[co][c][kh][2 kw' + par - 1] it must equal
+    torch's weight gradient of the stem on the same (bf16-rounded) operands, and the generic kernel's result on the 8-channel copy"""
+    from mhentropy_amd import ops
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(B * S)
+    bf = torch.bfloat16
+    x = torch.randn(B, 3, S, S, generator=g)
+    xr = x.to(bf).float()
+    gy = torch.randn(B, 64, S // 2, S // 2, generator=g).to(bf).float()
+    w = torch.zeros(64, 3, 7, 7, requires_grad=True)
+    F.conv2d(xr, w, stride=2, padding=3).backward(gy)
+    xd = x.cuda()
+    xp = ops.nchw_to_nhwc(xd, bf, cpad=4)
+    assert torch.equal(xp[..., :3].float().cpu(), xr.permute(0, 2, 3, 1)) and not xp[..., 3].any()
+    gyd = gy.permute(0, 2, 3, 1).contiguous().to(bf).cuda()
+    dw = torch.zeros(64, 7 * 4 * 8, device="cuda")
+    ops.conv_wgrad_rect(xp.view(B, S, S // 2, 8), gyd, 7, 4, 2, 1, 3, 2, dw)
+    d5 = dw.view(64, 7, 4, 2, 4).cpu()                      # [co][kh][kw'][parity][c]
+    got = torch.zeros(64, 3, 7, 7)
+    for kw in range(7):
+        got[:, :, :, kw] = d5[:, :, (kw + 1) // 2, (kw + 1) % 2, :3].permute(0, 2, 1)
+    assert_close(got, w.grad, 2e-5, what="stem weight gradient over pixel pairs")
+    # the columns that correspond to no tap (kw = -1) or to the padding channel: whatever the padding pixels / zero channel contribute
+    assert not d5[..., 3].any()
+    dw8 = torch.zeros(64, 7 * 7 * 8, device="cuda")
+    ops.conv_wgrad(ops.nchw_to_nhwc(xd, bf), gyd, 7, 7, 2, 3, dw8)
+    assert_close(got, dw8.view(64, 7, 7, 8)[..., :3].permute(0, 3, 1, 2).cpu(), 2e-5, what="vs the generic kernel on 8 padded channels")
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("H,W", [(18, 18), (19, 22)])
 def test_stem_pool_with_batchnorm_folded_in(gpu_lib, dt, H, W):
