@@ -138,6 +138,7 @@ class TrainStep:
         # the stem's BatchNorm + ReLU folded into its max pool, forward and reverse (ops.maxpool3x3s2_idx / maxpool3x3s2_bwd_bn)
         self.stem_pool_fused = os.environ.get("MHE_STEM_POOL_FUSED", "1") == "1"
         self.bn_on_load_wide = os.environ.get("MHE_BN_BWD_ON_LOAD_WIDE", "1") == "1"
+        self.cond_bwd_bf16 = os.environ.get("MHE_COND_BWD_BF16", "1") == "1"
         self._bucket_bounds = self._gradient_buckets()
         self._works = []
         self.raw = torch.zeros(self._raw_n, device=self.dev, dtype=torch.float32)
@@ -843,14 +844,24 @@ class TrainStep:
         ghd = ops.linear(gdet, self.d2["wT"]); ops.flow_lrelu_bwd(ghd, hd, slope=0.0)
         ops.linear_wgrad(feat, ghd, self.d0["dw"]); ops.colsum(ghd, self.d0["db"])
         if self.glow is None:       # conditioning projections of all nets in one pass
-            ops.linear_wgrad(feat, Gc, self.dwc); ops.colsum(Gc, self.dbc)
+            # bf16 mode: both products of the conditioning projections take bf16 operands like the rest of the flow's reverse pass (f32
+            # accumulation; the two f32 launches were 0.19 ms); the bias gradient sums the f32 Gc
+            cond_bf16 = self.flow_bf16 and self.f_wcb is not None and B % 8 == 0 and self.cond_bwd_bf16
+            if cond_bf16:
+                ops.linear_wgrad(feat.to(torch.bfloat16), Gc.to(torch.bfloat16), self.dwc)
+            else:
+                ops.linear_wgrad(feat, Gc, self.dwc)
+            ops.colsum(Gc, self.dbc)
             if self.flow_bf16 and B % 4 == 0:
                 # g_feat = Gc Wc is a (B x 24,576) x (24,576 x 512) product: 8 output tiles walking K serially as a plain GEMM
                 # (~0.75 ms); as a split-K reduction over the 24,576 columns ("pixels" of the weight-gradient kernel, operands
                 # GcT [k][b] and Wc [k][f] as they lie) it fills the chip
                 K_, F_ = self.f_wc.shape
                 g_feat = self._buf("g_feat_flow", (B, F_)); g_feat.zero_()
-                ops.conv_wgrad(self.f_wc.view(K_, 1, 1, F_), self._GcT.view(K_, 1, 1, B), 1, 1, 1, 0, g_feat)
+                if cond_bf16:
+                    ops.conv_wgrad(self.f_wcb.view(K_, 1, 1, F_), self._GcT.to(torch.bfloat16).view(K_, 1, 1, B), 1, 1, 1, 0, g_feat)
+                else:
+                    ops.conv_wgrad(self.f_wc.view(K_, 1, 1, F_), self._GcT.view(K_, 1, 1, B), 1, 1, 1, 0, g_feat)
             else:
                 g_feat = ops.linear(Gc, self.f_wcT)
         ops.add(g_feat, ops.linear(ghd, self.d0["wT"]))
