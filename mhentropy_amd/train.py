@@ -129,16 +129,16 @@ class TrainStep:
                        for dt in (torch.float32, torch.bfloat16)}
         self._raw_n = 0
         self._unpack = torch.full((self.n_params,), -1, dtype=torch.int64)
+        import os
+        self.cond_bwd_bf16 = os.environ.get("MHE_COND_BWD_BF16", "1") == "1"      # (read by _build_flow)
         self._build_trunk()
         self._build_heads()
         self._build_flow()
-        import os
         # BatchNorm-reverse sums accumulated by the data-gradient epilogues (no separate reduce pass); MHE_BN_REDUCE_FUSED=0: separate pass
         self.fuse_bn_reduce = os.environ.get("MHE_BN_REDUCE_FUSED", "1") == "1"
         # the stem's BatchNorm + ReLU folded into its max pool, forward and reverse (ops.maxpool3x3s2_idx / maxpool3x3s2_bwd_bn)
         self.stem_pool_fused = os.environ.get("MHE_STEM_POOL_FUSED", "1") == "1"
         self.bn_on_load_wide = os.environ.get("MHE_BN_BWD_ON_LOAD_WIDE", "1") == "1"
-        self.cond_bwd_bf16 = os.environ.get("MHE_COND_BWD_BF16", "1") == "1"
         self._bucket_bounds = self._gradient_buckets()
         self._works = []
         self.raw = torch.zeros(self._raw_n, device=self.dev, dtype=torch.float32)
@@ -417,10 +417,13 @@ class TrainStep:
                 self.fnets.append(d)
         self.f_stream = self._derived(torch.cat(streams), torch.bfloat16 if bf16 else torch.float32)
         self.f_b2 = self._derived(torch.stack(b2), torch.float32)
-        self.f_wc = self._derived(torch.cat(wc), torch.float32)                       # [2*ncoup*2*h, 512]
+        # bf16 mode with the conditioning products in bf16 (forward table, dWc, g_feat): the two f32 copies (2 x 12.6 M elements at C2) would
+        # only be gathered every step to be read by nobody
+        self.cond_f32 = not (bf16 and fl.tsfm_on % 64 == 0 and self.cond_bwd_bf16)
+        self.f_wc = self._derived(torch.cat(wc), torch.float32) if self.cond_f32 else None       # [2*ncoup*2*h, 512]
         self.f_wcb = self._derived(torch.cat(wc), torch.bfloat16) if bf16 and fl.tsfm_on % 64 == 0 else None      # forward operand in the bf16 mode
         self.f_bc = self._derived(torch.cat(bc1), torch.float32, torch.cat(bc2))       # c_j.bias + l_j.bias
-        self.f_wcT = self._derived(torch.cat(wc).t().contiguous(), torch.float32)     # [512, slots*h]
+        self.f_wcT = self._derived(torch.cat(wc).t().contiguous(), torch.float32) if self.cond_f32 else None     # [512, slots*h]
         slots = 4 * ncoup
         self.f_slots = slots
         raw_wc, raw_bc = self._raw_slot((slots * h, fl.tsfm_on)), self._raw_slot((slots * h,))
@@ -847,6 +850,9 @@ class TrainStep:
             # bf16 mode: both products of the conditioning projections take bf16 operands like the rest of the flow's reverse pass (f32
             # accumulation; the two f32 launches were 0.19 ms); the bias gradient sums the f32 Gc
             cond_bf16 = self.flow_bf16 and self.f_wcb is not None and B % 8 == 0 and self.cond_bwd_bf16
+            # (a batch that is not a multiple of 8 cannot feed the bf16 kernel's 16-byte rows: f32 operands, the weights widened from
+            # the bf16 copy for this call when the f32 copy is not kept)
+            wc32 = self.f_wc if (cond_bf16 or self.cond_f32) else self.f_wcb.float()
             if cond_bf16:
                 ops.linear_wgrad(feat.to(torch.bfloat16), Gc.to(torch.bfloat16), self.dwc)
             else:
@@ -856,14 +862,14 @@ class TrainStep:
                 # g_feat = Gc Wc is a (B x 24,576) x (24,576 x 512) product: 8 output tiles walking K serially as a plain GEMM
                 # (~0.75 ms); as a split-K reduction over the 24,576 columns ("pixels" of the weight-gradient kernel, operands
                 # GcT [k][b] and Wc [k][f] as they lie) it fills the chip
-                K_, F_ = self.f_wc.shape
+                K_, F_ = (self.f_wcb if self.f_wcb is not None else self.f_wc).shape
                 g_feat = self._buf("g_feat_flow", (B, F_)); g_feat.zero_()
                 if cond_bf16:
                     ops.conv_wgrad(self.f_wcb.view(K_, 1, 1, F_), self._GcT.to(torch.bfloat16).view(K_, 1, 1, B), 1, 1, 1, 0, g_feat)
                 else:
-                    ops.conv_wgrad(self.f_wc.view(K_, 1, 1, F_), self._GcT.view(K_, 1, 1, B), 1, 1, 1, 0, g_feat)
+                    ops.conv_wgrad(wc32.view(K_, 1, 1, F_), self._GcT.view(K_, 1, 1, B), 1, 1, 1, 0, g_feat)
             else:
-                g_feat = ops.linear(Gc, self.f_wcT)
+                g_feat = ops.linear(Gc, self.f_wcT if self.f_wcT is not None else wc32.t().contiguous())
         ops.add(g_feat, ops.linear(ghd, self.d0["wT"]))
         if hs is not None:          # partial over the local hypotheses, all images -> this rank's images, all hypotheses
             g_feat = hs.scatter_grad(g_feat)
