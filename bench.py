@@ -30,6 +30,7 @@ WORKLOADS = {
     # BASELINE.json configs[0] (CPU-runnable plumbing case)
     "c0": dict(B=2, K=4, backbone="resnet18", h=64, steps=2),
 }
+PMC_TRAFFIC = "r03_pmc_traffic.json"
 PEAK = {"f32": 157.3e12, "bf16": 2.5e15}      # dense MFMA peaks, MI355X_MICROARCH.md "Chip-level parameters"
 _T0 = time.time()
 
@@ -54,15 +55,15 @@ def build_model(cfg, dtype, seed, flow="realnvp"):
     return model, sd
 
 
-def cpu_baseline(cfg, sd, seed, budget_s=26.0):
-    """The oracle restatement (kind 'port') timed on this host's cores on a bounded
-    sample of the same workload: same networks, same K, fewer images."""
+def cpu_baseline(cfg, sd, seed, budget_s=75.0):
+    """The oracle restatement (kind 'port') timed on this host's cores on the SAME workload as the GPU line (same networks, same
+    B images x K hypotheses, train-mode BatchNorm over the whole batch): one warm-up pass + three timed ones (~15 s each at C2)."""
     from mhentropy_amd import synth
     from oracle import network_ref, mano_ref
     # the GPU box exposes every host CPU but a 1-GPU job owns a 16-core share: oversubscribing stalls torch's pool
     ncores = min(len(os.sched_getaffinity(0)), os.cpu_count() or 1, 16)
     torch.set_num_threads(ncores)
-    Bs, K = min(cfg["B"], 64), cfg["K"]
+    Bs, K = cfg["B"], cfg["K"]
     sdt = {k: torch.as_tensor(v) for k, v in sd.items()}
     tb = mano_ref.tables_from_numpy(synth.mano_tables(0))
     x, yn = synth.batch(seed + 1, Bs, image_size=256)
@@ -71,21 +72,21 @@ def cpu_baseline(cfg, sd, seed, budget_s=26.0):
     xt = torch.as_tensor(x)
     times = []
     t_start = time.time()
-    WARM = 2                                 # median of the timed runs after 2 warm-ups
+    WARM = 1                                 # like-for-like batch: 1 warm-up + 3 timed passes fit the default run's budget
     with torch.no_grad():
-        for i in range(WARM + 5):
+        for i in range(WARM + 3):
             t0 = time.time()
             network_ref.get_loss(sdt, tb, xt, y, z0, K, cfg["backbone"], True)
             times.append(time.time() - t0)
             log(f"cpu baseline pass {i}: {times[-1]:.2f}s")
-            if time.time() - t_start > budget_s and len(times) >= WARM + 3:
+            if time.time() - t_start > budget_s and len(times) >= WARM + 1:
                 break
     timed = times[WARM:] if len(times) > WARM else times[-1:]
     t = float(np.median(timed))
     return {"value": Bs * K / t, "unit": "hypotheses/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle get_loss (torch CPU fp32, train-mode BN) on B={Bs} of the GPU line's {cfg['B']} images x K={K} "
-                      f"hypotheses, 256x256 (same networks and seeds; a {cfg['B']}-image pass would take ~{cfg['B'] / Bs * t:.0f} s), "
-                      f"median of {len(timed)} runs after {min(WARM, len(times) - 1)} warm-ups, {t * 1e3:.0f} ms/pass"}
+            "sample": f"oracle get_loss (torch CPU fp32, train-mode BN) on the GPU line's own workload: B={Bs} images x K={K} "
+                      f"hypotheses, 256x256 (same networks and seeds), median of {len(timed)} passes after {min(WARM, len(times) - 1)} "
+                      f"warm-up, {t * 1e3:.0f} ms/pass"}
 
 
 def time_train_step(model, x, y, noise, B, K, args, dist, world, dev):
@@ -93,7 +94,7 @@ def time_train_step(model, x, y, noise, B, K, args, dist, world, dev):
     from mhentropy_amd import dist as mdist
     from mhentropy_amd.train import TrainStep
     ts = TrainStep(model, dist=dist)
-    tstep = lambda: ts.step(x, y, noise=noise, N=K)
+    tstep = lambda: ts.step(x, y, noise=noise, N=K)          # noise=None: drawn on the device inside the step (mhe_randn_f32)
     for i in range(2):
         tout = tstep()
         torch.cuda.synchronize()
@@ -143,6 +144,8 @@ def main():
                     help="also time this many full train steps (forward + reverse + all-reduce + clip + Adam) for the metric's "
                          "'img/s train step' part; 0 skips it")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured HIP graph (1) or launch eagerly (0)")
+    ap.add_argument("--resident-noise", type=int, default=0,
+                    help="1: feed a pre-drawn base-noise tensor (parity-style) instead of drawing z0 on the device inside every step")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
     if args.dtype is None:
@@ -198,7 +201,11 @@ def main():
     x, yn = synth.batch(args.seed + 17 * rank, B, image_size=256)
     x = torch.as_tensor(x).to(dev)
     y = {k: torch.as_tensor(v).to(dev) for k, v in yn.items()}
-    noise = torch.as_tensor(synth.noise(args.seed + 17 * rank, K * B)).to(dev)
+    # base noise z0 ~ N(0, I): drawn on the device INSIDE the timed step like the reference's per-call prior.sample (hand/flows.py:339);
+    # --resident-noise 1 feeds one pre-drawn tensor instead (what parity runs do)
+    torch.manual_seed(args.seed + 17 * rank)
+    ops.rng_state(dev, seed=args.seed + 17 * rank)
+    noise = torch.as_tensor(synth.noise(args.seed + 17 * rank, K * B)).to(dev) if args.resident_noise else None
 
     def step():
         return model.get_loss(x, y, mods=["uv"], N=K, noise=noise)
@@ -305,15 +312,13 @@ def main():
             # kernel sources are the ones that were profiled (sha1 of csrc/conv*.hip + conv_shared.h stored with the counters)
             traffic, tnote = None, "no PMC summary for this kernel"
             try:
-                import hashlib
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-                cs = os.path.join(ROOT, "mhentropy_amd", "csrc")
-                sha = hashlib.sha1(b"".join(open(os.path.join(cs, f), "rb").read() for f in ("conv.hip", "conv_p8.hip", "conv_stream.hip", "conv_tail.hip", "conv_wide.hip", "conv_shared.h"))).hexdigest()
-                if pmc.get("source_sha1") == sha:
+                from tools.pmc_traffic import kernel_sources_sha1
+                pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC)))
+                if pmc.get("source_sha1") == kernel_sources_sha1():          # every .hip / .h of csrc/, not the convolutions only
                     traffic = pmc["kernels"].get(order[0], {}).get("hbm_bytes_per_launch")
-                    tnote = "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r02_pmc_traffic.json, same kernel sources)"
+                    tnote = f"HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/{PMC_TRAFFIC}, same kernel sources)"
                 else:
-                    tnote = "profiles/r02_pmc_traffic.json was collected on other kernel sources: not reported"
+                    tnote = f"profiles/{PMC_TRAFFIC} was collected on other kernel sources: not reported"
             except Exception:
                 pass
             roof.update({"traffic": traffic, "traffic_note": tnote,
@@ -332,6 +337,7 @@ def main():
                                    f"{'4-layer ConditionalGlow h=512 (parity unpinned)' if args.flow == 'glow' else str(2 * cfg['steps']) + '-coupling RealNVP h=' + str(cfg['h'])}, MANO joints, B={B}/GPU, K={K}, 256x256",
                        "images_per_gpu": B, "hypotheses_per_image": K, "global_batch": world * B,
                        "launch": "hip-graph replay" if args.graph else "eager",
+                       "base_noise": "resident tensor" if args.resident_noise else "drawn on the device inside the step (Philox4x32-10, mhe_randn_f32)",
                        "img_per_s": round(world * B * args.steps / dt, 1), "glow_variant": glow_variant},
             "train_step": train, "roofline": roof, "cpu_baseline": cpu,
         }

@@ -39,6 +39,11 @@ enum { MHE_F32 = 0, MHE_BF16 = 1 };
 enum { MHE_FLOW_FORWARD = 0, MHE_FLOW_INVERSE = 1 };
 
 /* library ---------------------------------------------------------------- */
+/* MHE_ABI_VERSION changes whenever a struct layout or an existing signature changes (new entry points alone do not bump it).
+ *   1: round 1.   2: mhe_conv_desc gained `tile` and `res_half` (every convolution entry reads them), mhe_conv_wgrad_nhwc
+ *   takes the descriptor.  A caller compiled against another version must not call in: check
+ *   mhe_abi_version() == MHE_ABI_VERSION once after loading the library. */
+#define MHE_ABI_VERSION 2
 int         mhe_abi_version(void);
 const char *mhe_last_error(void);
 
@@ -55,6 +60,21 @@ int mhe_linear_f32(const float *X, const float *W, const float *bias, float *Y,
  * columns, K split over its 4 waves): the shapes of the per-image heads. */
 int mhe_linear_skinny_f32(const float *X, const float *W, const float *bias, float *Y,
                           int M, int N, int K, int act, void *stream);
+/* the same, also writing the result as bf16 (Y_bf16 [M,N]): BasicEnc.l1's feature (hand/network.py:121) feeds the flow's conditioning
+ * product, which takes bf16 operands in the bf16 mode - no separate cast launch in the step. */
+int mhe_linear_f32_bf16copy(const float *X, const float *W, const float *bias, float *Y, void *Y_bf16,
+                            int M, int N, int K, int act, void *stream);
+
+/* base noise -----------------------------------------------------------------
+ * out[n] ~ N(0, scale^2) i.i.d. (Philox4x32-10 + Box-Muller): the z0 = prior.sample((N*B,)) * temp of RealNVP.sample
+ * (hand/flows.py:339; hand/network.py:733-735), drawn on the device inside the step.  state = three uint64 in DEVICE memory
+ * {seed, next counter, 0}: the launch advances the counter itself, so a captured HIP graph draws fresh noise on every replay.
+ * A device generator cannot reproduce the reference's CPU stream: parity runs supply the noise instead. */
+int mhe_randn_f32(float *out, long n, unsigned long long *state, float scale, void *stream);
+/* BasicEnc's stochastic head (hand/network.py:121-138): sd = exp(l2/2) (sigmoid_act: sigmoid(l2)), z = mn + sd*eps (deterministic:
+ * z = mn; eps may then be NULL).  Dead for MHEnt, which keeps only mn (:779,862); built so BasicEnc returns the reference's (z, mn, sd). */
+int mhe_reparam_f32(const float *mn, const float *l2, const float *eps, float *sd, float *z, long n, int sigmoid_act,
+                    int deterministic, void *stream);
 
 /* conditional RealNVP ----------------------------------------------------- */
 
@@ -216,6 +236,24 @@ typedef struct mhe_conv_desc {
                     * into a full-resolution tensor first) */
 } mhe_conv_desc;
 
+/* Statistics-only form of a 1x1 / stride-1 bf16 convolution with 64 or 128 input channels: the batch statistics (stats, as above)
+ * of the output AS IT WOULD BE STORED, without storing it.  With mhe_bottleneck_tail_nhwc below this replaces "write conv3's raw output,
+ * read it back in the block tail" for layer1 / layer2 of ResNet-50 (torchvision Bottleneck, hand/network.py:54-61,110). */
+int mhe_conv1x1_stats_nhwc(const mhe_conv_desc *d, const void *x, const void *w, const float *in_scale, const float *in_shift,
+                           float *stats, void *stream);
+/* The tail of a bottleneck block with its conv3 re-evaluated, fused with the next block's conv1 (forward-only path; kernel variant 12):
+ *   T  = conv1x1(relu(y2 * bn2_scale + bn2_shift), w3)   rounded to the storage type like a stored conv3 output   [B,H,W,Cin]
+ *   a  = relu(T * bn3_scale + bn3_shift + (identity * id_scale + id_shift | identity))     -> a_out                 [B,H,W,Cin]
+ *   y1 = conv1x1(a, w1) -> y1 [B,H,W,Cout], stats (optional) as in mhe_conv2d_nhwc.
+ * d describes the second product (Cin = block width = 4 Cb, Cout = the next bottleneck width); y2 [B,H,W,Cb], w3 packed [Cin][Cb],
+ * w1 packed [Cout][Cin].  Results equal conv3 -> mhe_conv1x1_residual_in_nhwc bit for bit (same summation order).
+ * mhe_bottleneck_tail_supported: 1 when the geometry is taken (bf16, Cb 64 / 128, Cout 64 / 128, B*H*W % 128 == 0). */
+int mhe_bottleneck_tail_supported(const mhe_conv_desc *d, int Cb);
+int mhe_bottleneck_tail_nhwc(const mhe_conv_desc *d, int Cb, const void *y2, const float *bn2_scale, const float *bn2_shift,
+                             const void *w3, const float *bn3_scale, const float *bn3_shift, const void *identity,
+                             const float *id_scale, const float *id_shift, const void *w1, void *a_out, void *y1, float *stats,
+                             void *stream);
+
 int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y,
                     const float *in_scale, const float *in_shift,
                     const float *out_scale, const float *out_shift, const void *residual,
@@ -285,6 +323,11 @@ int mhe_stem_conv7x7s2(const float *x_nchw, const void *w, void *y, float *stats
 int mhe_bn_finalize(const float *stats, const float *gamma, const float *beta,
                     float *running_mean, float *running_var, float *scale, float *shift, float *mean_invstd,
                     int C, float count, float momentum, float eps, void *stream);
+/* the form the forward step uses: clear_stats != 0 zeroes the accumulators it has just read (the arena is clean for the next
+ * step without a memset launch), num_batches_tracked (optional, int64 on the device) is incremented like nn.BatchNorm2d does. */
+int mhe_bn_finalize_step(float *stats, const float *gamma, const float *beta,
+                         float *running_mean, float *running_var, float *scale, float *shift, float *mean_invstd,
+                         int C, float count, float momentum, float eps, int clear_stats, long long *num_batches_tracked, void *stream);
 
 /* y = relu?(x*scale+shift (+ r*r_scale+r_shift | + r)) elementwise over NHWC
  * [P,C]; the bottleneck tail bn3 + identity + relu (torchvision Bottleneck). */

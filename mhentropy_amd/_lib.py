@@ -22,6 +22,9 @@ SIGNATURES = {
     "mhe_last_error": (C.c_char_p, []),
     "mhe_linear_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mhe_linear_skinny_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "mhe_linear_f32_bf16copy": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "mhe_randn_f32": (_i, [_p, _l, _p, _f, _p]),
+    "mhe_reparam_f32": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _p]),
     "mhe_flow_packed_floats_per_net": (_sz, [_i, _i]),
     "mhe_flow_pack_net_host": (_i, [_p, _p, _p, _i, _i, _p]),
     "mhe_flow_couplings_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
@@ -91,7 +94,11 @@ SIGNATURES = {
     "mhe_conv_tile_mode": (_i, [C.POINTER(ConvDesc), _i]),
     "mhe_conv1x1_residual_in_nhwc": (_i, [C.POINTER(ConvDesc)] + [_p] * 11),
     "mhe_stem_conv7x7s2": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "mhe_conv1x1_stats_nhwc": (_i, [_p, _p, _p, _p, _p, _p, _p]),
+    "mhe_bottleneck_tail_supported": (_i, [_p, _i]),
+    "mhe_bottleneck_tail_nhwc": (_i, [_p, _i] + [_p] * 14),
     "mhe_bn_finalize": (_i, [_p] * 8 + [_i, _f, _f, _f, _p]),
+    "mhe_bn_finalize_step": (_i, [_p] * 8 + [_i, _f, _f, _f, _i, _p, _p]),
     "mhe_bn_act_nhwc": (_i, [_p] * 7 + [_l, _i, _i, _i, _p]),
     "mhe_maxpool3x3s2_nhwc": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mhe_avgpool_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
@@ -107,6 +114,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 2          # MHE_ABI_VERSION of include/mhe.h
 
 
 class MheError(RuntimeError):
@@ -128,6 +136,9 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the export is absent
             fn.restype, fn.argtypes = res, args
+        if L.mhe_abi_version() != ABI_VERSION:       # struct layouts (ConvDesc) below are this version's
+            raise MheError(f"{LIB_PATH} has ABI version {L.mhe_abi_version()}, these bindings are for {ABI_VERSION}: rebuild "
+                           "(`python -m mhentropy_amd.build`)")
         _lib = L
     return _lib
 

@@ -12,5 +12,6 @@ void set_error(const char *fmt, ...) {
 }
 }  // namespace mhe
 
-extern "C" int mhe_abi_version(void) { return 1; }
+// 2: mhe_conv_desc grew `tile` and `res_half` (read by every convolution entry) and mhe_conv_wgrad_nhwc takes the descriptor
+extern "C" int mhe_abi_version(void) { return 2; }
 extern "C" const char *mhe_last_error(void) { return mhe::g_err; }

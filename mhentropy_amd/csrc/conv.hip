@@ -450,13 +450,17 @@ __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ x, 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ stats, const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, float *__restrict__ rmean, float *__restrict__ rvar,
                                                           float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean_invstd, int C,
-                                                          float count, float momentum, float eps) {
+                                                          float count, float momentum, float eps, float *__restrict__ stats_clear,
+                                                          long long *__restrict__ num_batches_tracked) {
     static_assert(NSH == 64, "one lane per statistic shard");
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;      // nn.BatchNorm2d's counter (int64)
     if (c >= C) return;
     // shard sums are f32 (each shard holds <= M/(128*NSH) block partials); combine them in f64 so that
     // E[x^2] - E[x]^2 keeps fp32-level accuracy
     double s1 = (double)stats[((size_t)lane * 2) * C + c], s2 = (double)stats[((size_t)lane * 2 + 1) * C + c];
+    // self-cleaning accumulators: the arena is zero again when the next forward starts (no memset launch per step)
+    if (stats_clear) { stats_clear[((size_t)lane * 2) * C + c] = 0.f; stats_clear[((size_t)lane * 2 + 1) * C + c] = 0.f; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
     if (lane) return;
@@ -649,6 +653,8 @@ bool stream3_supports(const Params &p);        // conv_stream.hip: the row-strea
 int launch_stream3(const Params &p, hipStream_t s);
 bool wide_supports(const Params &p);           // conv_wide.hip: resident weight slab + transfer waves for 256 / 512 -> many channels (variant 11)
 int launch_wide(const Params &p, hipStream_t s);
+bool fuse_supports(const Params &p, int cb);   // conv_fuse.hip: bottleneck tail with conv3 re-evaluated + the next conv1 (variant 12)
+int launch_fuse(const Params &p, int cb, hipStream_t s);
 bool tail_supports(const Params &p);           // conv_tail.hip: residual tail + conv1 on a 128 x 256 tile with transfer waves (variant 10)
 int launch_tail(const Params &p, hipStream_t s);
 
@@ -666,9 +672,11 @@ static int choose_tile(const Params &p, bool fast, bool bf16) {
     static const int env_tail = getenv("MHE_CONV_TAIL") ? atoi(getenv("MHE_CONV_TAIL")) : 1;
     if (bf16 && (force == 10 || (force < 0 && env_tail)) && tail_supports(p)) return 10;
     if ((force & 15) == 7 && bf16 && p8_supports(p)) return 7;      // (higher bits: ablation builds of tuning runs)
+    // dual-input load + data-gradient epilogue: instantiated on the 128-row tiles only - a forced 256-row tile (descriptor or
+    // MHE_CONV_TILE) must not fall through to the plain dual-input kernel, which has no gate / BatchNorm-reverse sums
+    if (p.x2 && p.mask) return force == 0 ? 0 : 1;
     if (force >= 0 && force <= 4 && (force < 2 || (fast && bf16))) return force;
     if (p.Cout <= 64) return 0;
-    if (p.x2 && p.mask) return 1;             // dual-input load + data-gradient epilogue: instantiated on the 128-row tiles
     if (fast && bf16 && p.Cout >= 256) {      // (an f32 256x256 output tile would not fit the LDS staging buffers)
         const long tiles = (long)((p.M + 255) / 256) * ((p.Cout + 255) / 256);
         // plain operands go to the phase-pipelined kernel (conv_p8.hip: 0.85-1.0x the time of the register-staged 256x256
@@ -850,6 +858,55 @@ static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void
     return conv::launch_conv<u16>(p, (hipStream_t)stream);
 }
 
+// ---- the statistics-only pass and the fused bottleneck tail that re-evaluates conv3 (conv_fuse.hip)
+extern "C" int mhe_conv1x1_stats_nhwc(const mhe_conv_desc *d, const void *x, const void *w, const float *in_scale, const float *in_shift,
+                                      float *stats, void *stream) {
+    MHE_REQUIRE(d && x && w && stats, "mhe_conv1x1_stats_nhwc: null pointer");
+    MHE_REQUIRE(d->dtype == MHE_BF16 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && (d->Cin == 64 || d->Cin == 128) && d->Cout % 256 == 0,
+                "mhe_conv1x1_stats_nhwc: bf16 1x1 stride-1 with 64 / 128 input channels and a multiple of 256 output channels");
+    MHE_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "mhe_conv1x1_stats_nhwc: in_scale/in_shift must come together");
+    conv::Params p{};
+    p.x = x; p.w = w; p.y = nullptr; p.in_scale = in_scale; p.in_shift = in_shift; p.stats = stats;
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.Ho = d->H; p.Wo = d->W;
+    const long long M = (long long)d->B * d->H * d->W;
+    MHE_REQUIRE(M > 0 && M < (1ll << 31), "mhe_conv1x1_stats_nhwc: bad pixel count");
+    p.M = (int)M; p.Kpad = d->Cin; p.relu_in = d->relu_in; p.force = 8;
+    MHE_REQUIRE(conv::stream_supports(p), "mhe_conv1x1_stats_nhwc: geometry not taken by the streaming kernel");
+    return conv::launch_stream(p, (hipStream_t)stream);
+}
+
+extern "C" int mhe_bottleneck_tail_supported(const mhe_conv_desc *d, int Cb) {
+    if (!d || d->dtype != MHE_BF16) return 0;
+    static const float dummy = 0.f;
+    conv::Params p{};
+    p.x = p.x2 = p.w = p.w3 = p.y = p.a_out = (void *)&dummy; p.in_scale = p.in_shift = p.mid_scale = p.mid_shift = &dummy;
+    p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.Kpad = d->Cin;
+    const long long M = (long long)d->B * d->H * d->W;
+    if (M <= 0 || M >= (1ll << 31)) return 0;
+    p.M = (int)M;
+    return conv::fuse_supports(p, Cb) ? 1 : 0;
+}
+
+extern "C" int mhe_bottleneck_tail_nhwc(const mhe_conv_desc *d, int Cb, const void *y2, const float *bn2_scale, const float *bn2_shift,
+                                        const void *w3, const float *bn3_scale, const float *bn3_shift, const void *identity,
+                                        const float *id_scale, const float *id_shift, const void *w1, void *a_out, void *y1, float *stats,
+                                        void *stream) {
+    MHE_REQUIRE(d && y2 && bn2_scale && bn2_shift && w3 && bn3_scale && bn3_shift && identity && w1 && a_out && y1, "mhe_bottleneck_tail_nhwc: null pointer");
+    MHE_REQUIRE(d->dtype == MHE_BF16, "mhe_bottleneck_tail_nhwc: bf16 storage only");
+    MHE_REQUIRE((id_scale == nullptr) == (id_shift == nullptr), "mhe_bottleneck_tail_nhwc: id_scale/id_shift must come together");
+    conv::Params p{};
+    p.x = y2; p.in_scale = bn2_scale; p.in_shift = bn2_shift; p.w3 = w3; p.mid_scale = bn3_scale; p.mid_shift = bn3_shift;
+    p.x2 = identity; p.x2_scale = id_scale; p.x2_shift = id_shift; p.w = w1; p.a_out = a_out; p.y = y1; p.stats = stats;
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
+    p.Ho = d->H; p.Wo = d->W; p.Kpad = d->Cin; p.relu_in = 1; p.force = -1;
+    const long long M = (long long)d->B * d->H * d->W;
+    MHE_REQUIRE(M > 0 && M < (1ll << 31), "mhe_bottleneck_tail_nhwc: bad pixel count");
+    p.M = (int)M;
+    MHE_REQUIRE(conv::fuse_supports(p, Cb), "mhe_bottleneck_tail_nhwc: needs Cin = 4 Cb, Cb 64 / 128, Cout 64 / 128, pixels %% 128 == 0 (Cin=%d Cb=%d Cout=%d M=%lld)",
+                d->Cin, Cb, d->Cout, M);
+    return conv::launch_fuse(p, Cb, (hipStream_t)stream);
+}
+
 extern "C" int mhe_conv_stat_shards(void) { return conv::NSH; }
 
 // which kernel variant the launcher picks for a geometry with plain operands (see mhe_conv_desc.tile); with a producer-BatchNorm /
@@ -919,7 +976,17 @@ extern "C" int mhe_bn_finalize(const float *stats, const float *gamma, const flo
                                float momentum, float eps, void *stream) {
     MHE_REQUIRE(stats && gamma && beta && scale && shift && C > 0 && count > 1.f, "mhe_bn_finalize: bad arguments");
     hipLaunchKernelGGL(conv::bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, stats, gamma,
-                       beta, running_mean, running_var, scale, shift, mean_invstd, C, count, momentum, eps);
+                       beta, running_mean, running_var, scale, shift, mean_invstd, C, count, momentum, eps, (float *)nullptr, (long long *)nullptr);
+    return check_launch("bn_finalize_kernel");
+}
+
+extern "C" int mhe_bn_finalize_step(float *stats, const float *gamma, const float *beta, float *running_mean,
+                                    float *running_var, float *scale, float *shift, float *mean_invstd, int C, float count,
+                                    float momentum, float eps, int clear_stats, long long *num_batches_tracked, void *stream) {
+    MHE_REQUIRE(stats && gamma && beta && scale && shift && C > 0 && count > 1.f, "mhe_bn_finalize_step: bad arguments");
+    hipLaunchKernelGGL(conv::bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, stats, gamma,
+                       beta, running_mean, running_var, scale, shift, mean_invstd, C, count, momentum, eps, clear_stats ? stats : (float *)nullptr,
+                       num_batches_tracked);
     return check_launch("bn_finalize_kernel");
 }
 
@@ -1003,12 +1070,13 @@ namespace mhe { namespace conv {
 template <int MT>      // row tiles of 16 held per wave (M <= 16*MT)
 __global__ __launch_bounds__(256) void skinny_linear_kernel(const float *__restrict__ X, const float *__restrict__ W,
                                                             const float *__restrict__ bias, float *__restrict__ Y,
-                                                            int M, int N, int K, int relu) {
+                                                            int M, int N, int K, int relu, u16 *__restrict__ Yb) {
     __shared__ v4f red[3][MT][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, l15 = lane & 15;
     const int n0 = blockIdx.x * 16;
     // blockIdx.y: slice of 16*MT rows (few output columns, e.g. l1 with N = 512: 32 column groups alone would leave 7/8 of the CUs idle)
     X += (size_t)blockIdx.y * 16 * MT * K; Y += (size_t)blockIdx.y * 16 * MT * N; M -= blockIdx.y * 16 * MT;
+    if (Yb) Yb += (size_t)blockIdx.y * 16 * MT * N;
     const int kq = K / 4;                    // each wave reduces a quarter of K (K % 64 == 0)
     const int kbeg = wave * kq, kend = kbeg + kq;
     v4f acc[MT];
@@ -1050,26 +1118,45 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const float *__restr
             v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
             if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
             const int m = 16 * t + l15;
-            if (m < M && nb < N) *reinterpret_cast<float4 *>(Y + (size_t)m * N + nb) = make_float4(v[0], v[1], v[2], v[3]);
+            if (m < M && nb < N) {
+                *reinterpret_cast<float4 *>(Y + (size_t)m * N + nb) = make_float4(v[0], v[1], v[2], v[3]);
+                if (Yb) {                    // the same values as a bf16 operand for a following bf16 product (the flow's conditioning table)
+                    float t4[4] = {v[0], v[1], v[2], v[3]};
+                    store4<u16>(Yb + (size_t)m * N + nb, t4);
+                }
+            }
         }
     }
 }
 }}  // namespace mhe::conv
+
+static int skinny_launch(const float *X, const float *W, const float *bias, float *Y, mhe::u16 *Yb, int M, int N, int K, int act, void *stream) {
+    using namespace mhe;
+    const dim3 grid((N + 15) / 16), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const int relu = act == MHE_ACT_RELU;
+    if (M > 64 && (N + 15) / 16 < 512) {      // few column groups: also split the rows (64 per workgroup)
+        hipLaunchKernelGGL(conv::skinny_linear_kernel<4>, dim3((N + 15) / 16, (M + 63) / 64), block, 0, s, X, W, bias, Y, M, N, K, relu, Yb);
+        return check_launch("skinny_linear_kernel");
+    }
+    if (M <= 64) hipLaunchKernelGGL(conv::skinny_linear_kernel<4>, grid, block, 0, s, X, W, bias, Y, M, N, K, relu, Yb);
+    else if (M <= 128) hipLaunchKernelGGL(conv::skinny_linear_kernel<8>, grid, block, 0, s, X, W, bias, Y, M, N, K, relu, Yb);
+    else hipLaunchKernelGGL(conv::skinny_linear_kernel<16>, grid, block, 0, s, X, W, bias, Y, M, N, K, relu, Yb);
+    return check_launch("skinny_linear_kernel");
+}
 
 extern "C" int mhe_linear_skinny_f32(const float *X, const float *W, const float *bias, float *Y, int M, int N, int K,
                                      int act, void *stream) {
     using namespace mhe;
     MHE_REQUIRE(X && W && Y && M > 0 && M <= 256 && N > 0 && N % 4 == 0 && K > 0 && K % 64 == 0,
                 "mhe_linear_skinny_f32: need M <= 256, N %% 4 == 0, K %% 64 == 0 (M=%d N=%d K=%d)", M, N, K);
-    const dim3 grid((N + 15) / 16), block(256);
-    hipStream_t s = (hipStream_t)stream;
-    const int relu = act == MHE_ACT_RELU;
-    if (M > 64 && (N + 15) / 16 < 512) {      // few column groups: also split the rows (64 per workgroup)
-        hipLaunchKernelGGL(conv::skinny_linear_kernel<4>, dim3((N + 15) / 16, (M + 63) / 64), block, 0, s, X, W, bias, Y, M, N, K, relu);
-        return check_launch("skinny_linear_kernel");
-    }
-    if (M <= 64) hipLaunchKernelGGL(conv::skinny_linear_kernel<4>, grid, block, 0, s, X, W, bias, Y, M, N, K, relu);
-    else if (M <= 128) hipLaunchKernelGGL(conv::skinny_linear_kernel<8>, grid, block, 0, s, X, W, bias, Y, M, N, K, relu);
-    else hipLaunchKernelGGL(conv::skinny_linear_kernel<16>, grid, block, 0, s, X, W, bias, Y, M, N, K, relu);
-    return check_launch("skinny_linear_kernel");
+    return skinny_launch(X, W, bias, Y, nullptr, M, N, K, act, stream);
+}
+
+extern "C" int mhe_linear_f32_bf16copy(const float *X, const float *W, const float *bias, float *Y, void *Y_bf16, int M, int N, int K,
+                                       int act, void *stream) {
+    using namespace mhe;
+    MHE_REQUIRE(X && W && Y && Y_bf16 && M > 0 && M <= 256 && N > 0 && N % 4 == 0 && K > 0 && K % 64 == 0,
+                "mhe_linear_f32_bf16copy: need M <= 256, N %% 4 == 0, K %% 64 == 0 (M=%d N=%d K=%d)", M, N, K);
+    return skinny_launch(X, W, bias, Y, (u16 *)Y_bf16, M, N, K, act, stream);
 }

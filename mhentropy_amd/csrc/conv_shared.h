@@ -26,6 +26,8 @@ struct Params {
     // (b, 2i + os_py, 2j + os_px) of a [B, 2Ho, 2Wo] tensor (y, residual, mask and bn_y are all addressed there)
     int os2, os_py, os_px;
     int res_s2;            // residual at half resolution [B, ceil(Ho/2), ceil(Wo/2), Cout], added at even output positions only
+    // bottleneck tail with conv3 re-evaluated (conv_fuse.hip): w3 [Cin][Cin / 4] packed, mid_scale / mid_shift = bn3's affine [Cin]
+    const void *w3; const float *mid_scale, *mid_shift;
 };
 
 // tile row -> global output pixel index the epilogue addresses (or -1 outside the problem)

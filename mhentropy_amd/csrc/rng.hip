@@ -1,0 +1,94 @@
+// Base noise of the flow drawn on the device INSIDE the step: z0 ~ N(0, I) for the R = N*B hypothesis rows
+// (reference hand/flows.py:339 `prior.sample((N*B,))`, MultivariateNormal(0, I_45); hand/network.py:733-735).
+// Counter-based: Philox4x32-10 (Salmon et al., SC'11) keyed by a seed, four uniforms per call -> two Box-Muller pairs.  The
+// generator state lives in DEVICE memory and the launch that consumed it advances it (last workgroup to finish), so a HIP
+// graph that contains this launch draws fresh noise on every replay with no host involvement.  GPU draws can never equal the
+// reference's CPU generator stream - parity runs pass `noise=`; this is the product's default draw.
+#include "common.h"
+
+namespace mhe { namespace rng {
+
+__device__ __forceinline__ void philox_round(unsigned &c0, unsigned &c1, unsigned &c2, unsigned &c3, unsigned k0, unsigned k1) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+
+__device__ __forceinline__ void philox4x32_10(unsigned long long ctr, unsigned long long key, unsigned out[4]) {
+    unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0u, c3 = 0u, k0 = (unsigned)key, k1 = (unsigned)(key >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// state: [0] seed (key), [1] next counter, [2] workgroups finished in the running launch
+__global__ __launch_bounds__(256) void randn_kernel(float *__restrict__ out, long n, unsigned long long *__restrict__ state, float scale) {
+    const unsigned long long key = state[0], base = state[1];
+    const long n4 = (n + 3) / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        unsigned r[4];
+        philox4x32_10(base + (unsigned long long)i, key, r);
+        float v[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // u1 in (0, 1], u2 in [0, 1): 24 mantissa bits each
+            const float u1 = ((float)(r[2 * h] >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(r[2 * h + 1] >> 8) * (1.0f / 16777216.0f);
+            const float rad = sqrtf(-2.0f * logf(u1));
+            float sn, cs;
+            sincospif(2.0f * u2, &sn, &cs);
+            v[2 * h] = rad * cs * scale; v[2 * h + 1] = rad * sn * scale;
+        }
+        if (4 * i + 3 < n) *reinterpret_cast<float4 *>(out + 4 * i) = make_float4(v[0], v[1], v[2], v[3]);
+        else for (int e = 0; e < 4 && 4 * i + e < n; ++e) out[4 * i + e] = v[e];
+    }
+    // every workgroup has read `base` before it gets here; the last one to arrive moves the counter past this launch
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned long long done = atomicAdd(&state[2], 1ull);
+        if (done == (unsigned long long)gridDim.x - 1ull) {
+            state[2] = 0ull;
+            state[1] = base + (unsigned long long)n4;
+            __threadfence();
+        }
+    }
+}
+
+}}  // namespace mhe::rng
+
+extern "C" int mhe_randn_f32(float *out, long n, unsigned long long *state, float scale, void *stream) {
+    using namespace mhe;
+    MHE_REQUIRE(out && state && n > 0, "mhe_randn_f32: bad arguments");
+    MHE_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "mhe_randn_f32: out must be 16-byte aligned");
+    const long n4 = (n + 3) / 4;
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(rng::randn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, n, state, scale);
+    return check_launch("randn_kernel");
+}
+
+// ---- BasicEnc's stochastic head (reference hand/network.py:121-138): sd = exp(l2 / 2) | sigmoid(l2), z = mn + sd * eps.
+// Dead for MHEnt (it keeps only mn, :779,862) - built so that the exported class returns the reference's (z, mn, sd).
+namespace mhe { namespace rng {
+__global__ __launch_bounds__(256) void reparam_kernel(const float *__restrict__ mn, const float *__restrict__ l2, const float *__restrict__ eps,
+                                                      float *__restrict__ sd, float *__restrict__ z, long n, int sigmoid_act, int deterministic) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float s = sigmoid_act ? 1.f / (1.f + expf(-l2[i])) : expf(0.5f * l2[i]);
+        sd[i] = s;
+        z[i] = deterministic ? mn[i] : fmaf(s, eps[i], mn[i]);
+    }
+}
+}}  // namespace mhe::rng
+
+extern "C" int mhe_reparam_f32(const float *mn, const float *l2, const float *eps, float *sd, float *z, long n, int sigmoid_act,
+                               int deterministic, void *stream) {
+    using namespace mhe;
+    MHE_REQUIRE(mn && l2 && sd && z && n > 0 && (deterministic || eps), "mhe_reparam_f32: bad arguments");
+    long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(rng::reparam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mn, l2, eps, sd, z, n, sigmoid_act, deterministic);
+    return check_launch("reparam_kernel");
+}

@@ -87,7 +87,10 @@ class RealNVP(nn.Module):
         bf16 operands like the nets' own layers do (f32 accumulation and bias; 23 us against 117 us for the f32 form at C2)."""
         _, _, wc, bc, wcb = self._packed()
         if wcb is not None:
-            t = ops.linear_bf16_f32out(cond.to(torch.bfloat16).contiguous(), wcb, bc)
+            cb = getattr(cond, "_mhe_bf16", None)            # left by BasicEnc's l1 launch (same values, no cast launch)
+            if cb is None or cb.shape != cond.shape:
+                cb = cond.to(torch.bfloat16).contiguous()
+            t = ops.linear_bf16_f32out(cb, wcb, bc)
         else:
             t = ops.linear(cond.contiguous(), wc, bc)
         return t.view(cond.shape[0], 2 * len(self.mask), 2, self.hidden)
@@ -133,8 +136,9 @@ class RealNVP(nn.Module):
         is drawn on the device."""
         bs = batchSize          # == logvar.shape[0] in the reference's own call (network.py:733-735)
         if noise is None:
-            noise = torch.randn(batchSize, self.dim, device=logvar.device, dtype=torch.float32)
-        z0 = (noise * temp).contiguous()
+            z0 = ops.randn(batchSize, self.dim, logvar.device, scale=temp)       # drawn on the device (mhe_randn_f32)
+        else:
+            z0 = (noise * temp).contiguous()
         x = self.forward_p(z0, cond=self.make_cond(logvar)) * self.scale
         if return_z:
             return x.view(bs, -1), z0.view(bs, -1)

@@ -245,7 +245,7 @@ class ConditionalGlow(nn.Module):
         """samples (B,N,D), log_prob (B,N), noise - rows batch-major as nflows lays them out."""
         B = context.shape[0]
         if noise is None:
-            noise = torch.randn(B, num_samples, self.features, device=context.device)
+            noise = ops.randn(B * num_samples, self.features, context.device).view(B, num_samples, self.features)      # drawn on the device (mhe_randn_f32)
         x, lp = self._run(noise.reshape(B * num_samples, self.features).contiguous(), context.contiguous(), True, num_samples, B)
         return x.view(B, num_samples, -1), lp.view(B, num_samples), noise
 

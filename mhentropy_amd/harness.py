@@ -75,7 +75,11 @@ def multistep_lr(base_lr, epoch, milestones=(150, 250), gamma=0.1):
 # ---- configuration ingestion (reference hand/configs/config.py:13-93 defaults + merge_from_file; hand/configs/ho3d.yaml) -----
 class _Node(dict):
     """attribute access over nested dicts (what the reference gets from yacs' CfgNode / EasyDict)"""
-    __getattr__ = dict.__getitem__
+    def __getattr__(self, k):          # AttributeError like yacs' CfgNode / EasyDict: getattr(cfg.x, k, default), hasattr and copy.deepcopy rely on it
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k) from None
 
     def __setattr__(self, k, v):
         self[k] = v
@@ -87,14 +91,15 @@ def _node(d):
 
 # the defaults of the reference's config tree for the keys this path consumes (hand/configs/config.py:13-64)
 CONFIG_DEFAULTS = {
-    "info_interval": 200, "save_interval": 5, "eval_interval": 1,
+    "info_interval": 200, "save_interval": 5, "eval_interval": 1, "eval_mscoco": False,
+    "model_dir": "./model/", "pretrain_model": "./model/pretrain.pth", "final_model": "./model/final.pth",
     "dataset": {"dataset_name": "rhd", "image_size": [256, 256], "range_": [[-5., -5., -5.], [5., 5., 5.]], "pe": "3d", "jointN": 21},
     "training": {"mode": "pretrain", "seed": None, "view_correction": True, "batch_size": 32, "num_workers": 32, "pth": None,
                  "load_mod_names": None, "epochs": 80, "lr": 1e-4, "milestones": [30, 60], "warmups": 0, "criterion": "ELBOLoss"},
     "network": {"enc_type": "BasicEnc", "num_latent": 64, "nums_latent": None, "backbone": "resnet18", "resnet_pretrained": True,
                 "conditional_p": False, "conditional_i": False, "feat_dim": None, "acts": "exp", "deterministic": False,
                 "decoder_type": "mano", "pgm": None, "p_nf": None, "p_nf_dim": 3, "tsfm_on": None, "cond_mapping_dims": None,
-                "kemb": False, "h_dims": [64, 64], "num_steps": 3, "nf_res": None},
+                "iterative_refinement": False, "kemb": False, "h_dims": [64, 64], "num_steps": 3, "nf_res": None, "ddpm": False},
     "loss": {"kl": 0.0001},
 }
 
@@ -116,6 +121,8 @@ def load_config(path):
                     raise KeyError(f"config key {k}.{kk} does not exist in the reference's tree")
                 cfg[k][kk] = vv
         else:
+            if k not in cfg or isinstance(cfg[k], dict):       # merge_from_file rejects keys the tree does not declare
+                raise KeyError(f"config key {k!r} does not exist in the reference's tree")
             cfg[k] = v
     return _node(cfg)
 

@@ -29,12 +29,14 @@ from .glow import ConditionalGlow
 
 
 class BasicEnc(nn.Module):
-    """reference hand/network.py:27-140: ResNet trunk + two Linear heads; returns (z, mn, sd).
-    MHEnt consumes only `mn` (:779,862); l2 / exp / the epsilon draw are dead for it, so
-    by default they are skipped (`full_outputs=False` -> z = mn, sd = None)."""
+    """reference hand/network.py:27-140: ResNet trunk + two Linear heads; returns (z, mn, sd) with sd = exp(l2 / 2) (or
+    sigmoid, `sigma_act`) and z = mn + sd * eps, eps ~ N(0, I) (z = mn when deterministic) - `full_outputs=True`, the default
+    of the stand-alone class.  MHEnt consumes only `mn` (:779,862); l2 / exp / the epsilon draw are dead for it, so it
+    builds its encoder with `full_outputs=False` (-> (mn, mn, None), no l2 product, no draw).  `eps=` supplies the noise for
+    reproducible runs; otherwise it is drawn on the device (ops.randn) - a device generator cannot follow the reference's CPU stream."""
     def __init__(self, cfg=None, n_latent: Union[int, list] = 64, backbone="resnet18", pretrained=True,
                  conditional_p=False, K=21, D=3, feat_dim=None, sigma_act="exp", deterministic=False,
-                 compute_dtype=torch.float32, **kwargs):
+                 compute_dtype=torch.float32, full_outputs=True, **kwargs):
         super().__init__()
         if conditional_p:
             raise NotImplementedError("conditional_p is deprecated in the reference (network.py:63)")
@@ -45,14 +47,28 @@ class BasicEnc(nn.Module):
         feat_dim = feat_dim or resnet.CFG[backbone][2]
         self.l1 = nn.Sequential(nn.Linear(feat_dim, self.n_latent[0]))
         self.l2 = nn.Sequential(nn.Linear(feat_dim, self.n_latent[1]))
-        self.sigma_act, self.deterministic = sigma_act, deterministic
+        if sigma_act not in ("exp", "sigmoid"):
+            raise NotImplementedError(f"sigma_act={sigma_act!r}")
+        self.sigma_act, self.deterministic, self.full_outputs = sigma_act, deterministic, full_outputs
         self._feat = None
 
-    def forward(self, x, deterministic=False, p=None):
+    def forward(self, x, deterministic=False, p=None, eps=None):
         f = self.res(x)
         self._feat = f
-        mn = ops.linear(f, self.l1[0].weight.detach(), self.l1[0].bias.detach())
-        return mn, mn, None
+        # bf16 mode: the same launch also leaves mn as the bf16 operand of the flow's conditioning product (read by RealNVP._cond_table)
+        mn = ops.linear(f, self.l1[0].weight.detach(), self.l1[0].bias.detach(), want_bf16=self.res.compute_dtype == torch.bfloat16)
+        if isinstance(mn, tuple):
+            mn, mnb = mn
+            if mnb is not None:
+                mn._mhe_bf16 = mnb
+        if not self.full_outputs:
+            return mn, mn, None
+        l2 = ops.linear(f, self.l2[0].weight.detach(), self.l2[0].bias.detach())
+        det = bool(self.deterministic or deterministic or self.n_latent[0] != self.n_latent[1])      # hand/network.py:133-136
+        if not det and eps is None:
+            eps = ops.randn(mn.shape[0], mn.shape[1], mn.device)
+        sd, z = ops.reparam(mn, l2, None if det else eps.contiguous(), sigmoid_act=self.sigma_act == "sigmoid", deterministic=det)
+        return z, mn, sd
 
 
 class MHEnt(nn.Module):
@@ -61,7 +77,7 @@ class MHEnt(nn.Module):
         self.integrated = True
         if common_cfg["input"] != "image":
             raise NotImplementedError
-        self.feat_extractor = BasicEnc(**common_cfg)
+        self.feat_extractor = BasicEnc(**dict(common_cfg, full_outputs=False))      # only mn is consumed (hand/network.py:779,862)
         model = special_cfg["q_z_giv_i_model"]
         if model == "realnvp":
             self.q_z_giv_i = RealNVP(**special_cfg["q_z_giv_i_cfg"])
@@ -106,8 +122,10 @@ class MHEnt(nn.Module):
         return ops.linear(h, self.det_head[2].weight.detach(), self.det_head[2].bias.detach())
 
     def _noise(self, rows, temp, noise, device):
+        """z0 = prior.sample((N*B,)) * temp (hand/flows.py:339, hand/network.py:733-735): drawn on the device inside the step unless the
+        caller supplies `noise` (parity runs: a device generator cannot reproduce the reference's CPU stream)"""
         if noise is None:
-            noise = torch.randn(rows, 45, device=device, dtype=torch.float32)
+            return ops.randn(rows, 45, device, scale=temp)
         noise = noise.reshape(rows, 45)
         return (noise * temp).contiguous() if temp != 1.0 else noise.contiguous()
 

@@ -79,8 +79,9 @@ def conv_tile_choice(B, H, W, Cin, Cout, k, stride, pad, dt, mode=0):
     return _lib.lib().mhe_conv_tile_mode(C.byref(d), mode)
 
 
-def linear(x, w, bias=None, relu=False, out=None):
-    """act(x @ w.T + bias) in f32 (mhe_linear_f32)."""
+def linear(x, w, bias=None, relu=False, out=None, want_bf16=False):
+    """act(x @ w.T + bias) in f32 (mhe_linear_f32).  want_bf16: returns (y, y as bf16) from the same launch where the shape admits it
+    (mhe_linear_f32_bf16copy: M <= 256, K % 64 == 0), else (y, None)."""
     M, K = x.shape
     N = w.shape[0]
     _chk(x, torch.float32, "linear.x"); _chk(w, torch.float32, "linear.w", (N, K))
@@ -88,8 +89,47 @@ def linear(x, w, bias=None, relu=False, out=None):
         _chk(bias, torch.float32, "linear.bias", (N,))
     y = out if out is not None else torch.empty(M, N, device=x.device, dtype=torch.float32)
     _chk(y, torch.float32, "linear.out", (M, N))
+    if want_bf16:
+        if M <= 256 and K % 64 == 0 and N % 4 == 0:
+            yb = torch.empty(M, N, device=x.device, dtype=torch.bfloat16)
+            check(_lib.lib().mhe_linear_f32_bf16copy(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(yb), M, N, K, int(relu), _stream()), "mhe_linear_f32_bf16copy")
+            return y, yb
+        check(_lib.lib().mhe_linear_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), M, N, K, int(relu), _stream()), "mhe_linear_f32")
+        return y, None
     check(_lib.lib().mhe_linear_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), M, N, K, int(relu), _stream()), "mhe_linear_f32")
     return y
+
+
+_RNG_STATE = {}
+
+
+def rng_state(device, seed=None):
+    """the device-resident generator state {seed, next counter, 0} of mhe_randn_f32 for `device`; created on first use from torch's
+    seed (torch.manual_seed(s) before the first draw makes runs repeatable), or re-seeded explicitly with seed="""
+    st = _RNG_STATE.get(device)
+    if st is None or seed is not None:
+        s = torch.initial_seed() if seed is None else int(seed)
+        st = _RNG_STATE[device] = torch.tensor([s & 0x7FFFFFFFFFFFFFFF, 0, 0], dtype=torch.int64, device=device)
+    return st
+
+
+def randn(rows, cols, device, scale=1.0, state=None):
+    """[rows, cols] f32 ~ N(0, scale^2) drawn on the device by mhe_randn_f32 (graph-capturable: the launch advances its own counter)"""
+    out = torch.empty(rows, cols, device=device, dtype=torch.float32)
+    st = state if state is not None else rng_state(out.device)
+    check(_lib.lib().mhe_randn_f32(_ptr(out), out.numel(), _ptr(st), float(scale), _stream()), "mhe_randn_f32")
+    return out
+
+
+def reparam(mn, l2, eps=None, sigmoid_act=False, deterministic=False):
+    """(sd, z) of BasicEnc's stochastic head (mhe_reparam_f32)"""
+    _chk(mn, torch.float32, "reparam.mn"); _chk(l2, torch.float32, "reparam.l2", mn.shape)
+    if eps is not None:
+        _chk(eps, torch.float32, "reparam.eps", mn.shape)
+    sd, z = torch.empty_like(mn), torch.empty_like(mn)
+    check(_lib.lib().mhe_reparam_f32(_ptr(mn), _ptr(l2), _ptr(eps), _ptr(sd), _ptr(z), mn.numel(), int(sigmoid_act), int(deterministic or eps is None),
+                                     _stream()), "mhe_reparam_f32")
+    return sd, z
 
 
 def flow_pack_net(w0, w1, w2):
@@ -307,6 +347,57 @@ def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in
     return y
 
 
+def conv1x1_stats(x, w, in_scale, in_shift, stats):
+    """batch statistics of conv1x1(relu(x * in_scale + in_shift), w) as it would be stored, without storing it (mhe_conv1x1_stats_nhwc)"""
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    _chk(x, torch.bfloat16, "conv_stats.x"); _chk(w, torch.bfloat16, "conv_stats.w", (Cout, Cin))
+    _chk(in_scale, torch.float32, "conv_stats.in_scale", (Cin,)); _chk(in_shift, torch.float32, "conv_stats.in_shift", (Cin,))
+    _chk(stats, torch.float32, "conv_stats.stats", (stat_shards(), 2, Cout))
+    d = ConvDesc(B, H, W, Cin, Cout, 1, 1, 1, 0, BF16, 1, 0, 0, 0)
+    if TIMING:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(_lib.lib().mhe_conv1x1_stats_nhwc(C.byref(d), _ptr(x), _ptr(w), _ptr(in_scale), _ptr(in_shift), _ptr(stats), _stream()), "mhe_conv1x1_stats_nhwc")
+    if TIMING:
+        ev1.record()
+        KERNEL_TIMES.append(("mhe::conv::conv1x1_stream_kernel<%d, 256, true, false>" % (Cin // 64), 2.0 * B * H * W * Cout * Cin, ev0, ev1,
+                             2 * (x.numel() + w.numel())))
+    return stats
+
+
+def bottleneck_tail_supported(B, H, W, Cb, Cout):
+    d = ConvDesc(B, H, W, 4 * Cb, Cout, 1, 1, 1, 0, BF16, 1, 0, 0, 0)
+    return bool(_lib.lib().mhe_bottleneck_tail_supported(C.byref(d), int(Cb)))
+
+
+def bottleneck_tail(y2, bn2, w3, bn3, identity, id_aff, w1, stats=None):
+    """(a, y1) of mhe_bottleneck_tail_nhwc: a = relu(bn3(conv3(relu(bn2(y2)))) + identity) with conv3 re-evaluated in place of being read
+    back, y1 = the next block's conv1 of a (+ its batch statistics).  bn2 / bn3 / id_aff = (scale, shift) pairs (id_aff may be None)."""
+    B, H, W, Cb = y2.shape
+    Cw, Cout = w3.shape[0], w1.shape[0]
+    _chk(y2, torch.bfloat16, "tail.y2"); _chk(w3, torch.bfloat16, "tail.w3", (Cw, Cb)); _chk(w1, torch.bfloat16, "tail.w1", (Cout, Cw))
+    _chk(identity, torch.bfloat16, "tail.identity", (B, H, W, Cw))
+    for (sc, sh), n, c in ((bn2, "bn2", Cb), (bn3, "bn3", Cw)) + (((id_aff, "id", Cw),) if id_aff is not None else ()):
+        _chk(sc, torch.float32, f"tail.{n}_scale", (c,)); _chk(sh, torch.float32, f"tail.{n}_shift", (c,))
+    if stats is not None:
+        _chk(stats, torch.float32, "tail.stats", (stat_shards(), 2, Cout))
+    a = torch.empty(B, H, W, Cw, device=y2.device, dtype=torch.bfloat16)
+    y1 = torch.empty(B, H, W, Cout, device=y2.device, dtype=torch.bfloat16)
+    d = ConvDesc(B, H, W, Cw, Cout, 1, 1, 1, 0, BF16, 1, 0, 0, 0)
+    if TIMING:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(_lib.lib().mhe_bottleneck_tail_nhwc(C.byref(d), Cb, _ptr(y2), _ptr(bn2[0]), _ptr(bn2[1]), _ptr(w3), _ptr(bn3[0]), _ptr(bn3[1]), _ptr(identity),
+                                              _ptr(id_aff[0] if id_aff is not None else None), _ptr(id_aff[1] if id_aff is not None else None),
+                                              _ptr(w1), _ptr(a), _ptr(y1), _ptr(stats), _stream()), "mhe_bottleneck_tail_nhwc")
+    if TIMING:
+        ev1.record()
+        nbytes = 2 * (y2.numel() + identity.numel() + a.numel() + y1.numel() + w3.numel() + w1.numel())
+        KERNEL_TIMES.append(("mhe::conv::bottleneck_tail_kernel<%d, %d>" % (Cb, Cout), 2.0 * B * H * W * Cw * (Cb + Cout), ev0, ev1, nbytes))
+    return a, y1
+
+
 def linear_bf16_f32out(x, w, bias=None, out=None):
     """out[R,N] (f32) = x[R,K] (bf16) w[N,K]^T (bf16) + bias, f32 accumulation (mhe_conv2d_f32out_nhwc); K % 64 == 0, N % 4 == 0"""
     R, K = x.shape
@@ -421,14 +512,23 @@ def stem_conv7x7s2(x, w, dtype, stats=None):
     return y
 
 
-def bn_finalize(stats, gamma, beta, running_mean, running_var, count, momentum=0.1, eps=1e-5, want_mean_invstd=False):
+def bn_finalize(stats, gamma, beta, running_mean, running_var, count, momentum=0.1, eps=1e-5, want_mean_invstd=False, clear=False,
+                num_batches_tracked=None):
+    """clear: the accumulators are zeroed once read (self-cleaning arena); num_batches_tracked (int64 scalar on the device): += 1"""
     Cn = gamma.shape[0]
     scale = torch.empty(Cn, device=gamma.device, dtype=torch.float32)
     shift = torch.empty_like(scale)
     mi = torch.empty(2, Cn, device=gamma.device, dtype=torch.float32) if want_mean_invstd else None
-    check(_lib.lib().mhe_bn_finalize(_ptr(stats), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
-                                     _ptr(scale), _ptr(shift), _ptr(mi), Cn, float(count), float(momentum), float(eps), _stream()),
-          "mhe_bn_finalize")
+    if clear or num_batches_tracked is not None:
+        if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or not num_batches_tracked.is_cuda):
+            raise _lib.MheError("bn_finalize.num_batches_tracked: int64 device tensor expected")
+        check(_lib.lib().mhe_bn_finalize_step(_ptr(stats), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(scale), _ptr(shift),
+                                              _ptr(mi), Cn, float(count), float(momentum), float(eps), int(clear), _ptr(num_batches_tracked), _stream()),
+              "mhe_bn_finalize_step")
+    else:
+        check(_lib.lib().mhe_bn_finalize(_ptr(stats), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                         _ptr(scale), _ptr(shift), _ptr(mi), Cn, float(count), float(momentum), float(eps), _stream()),
+              "mhe_bn_finalize")
     return (scale, shift, mi) if want_mean_invstd else (scale, shift)
 
 
@@ -473,6 +573,16 @@ def nchw_to_nhwc(x, dtype=torch.float32, cpad=None):
 
 # ---- train-step (reverse) kernels ---------------------------------------------------------------------
 _WGRAD_WS = {}          # per device: one workspace for the partial slabs of the pixel-range split, grown to the largest layer
+_WGRAD_WS_RETIRED = []  # superseded workspaces stay alive: a captured HIP graph (train.GraphedStep) may have baked their address in
+
+
+def _wgrad_ws(device, need):
+    ws = _WGRAD_WS.get(device)
+    if ws is None or ws.numel() < need:
+        if ws is not None:
+            _WGRAD_WS_RETIRED.append(ws)
+        ws = _WGRAD_WS[device] = torch.empty(need, device=device, dtype=torch.float32)
+    return ws
 WGRAD_SLABS = True      # False: f32 atomics into dw (the form without a workspace)
 
 
@@ -489,9 +599,7 @@ def conv_wgrad(x, gy, KH, KW, stride, pad, dw, ldw=0):
     L = _lib.lib()
     need = L.mhe_conv_wgrad_workspace_floats(C.byref(d)) if WGRAD_SLABS else 0
     if need:
-        ws = _WGRAD_WS.get(x.device)
-        if ws is None or ws.numel() < need:
-            ws = _WGRAD_WS[x.device] = torch.empty(need, device=x.device, dtype=torch.float32)
+        ws = _wgrad_ws(x.device, need)
         check(L.mhe_conv_wgrad_ws_nhwc(C.byref(d), _ptr(x), _ptr(gy), _ptr(dw), int(ldw), _ptr(ws), ws.numel(), _stream()), "mhe_conv_wgrad_ws_nhwc")
     else:
         check(L.mhe_conv_wgrad_nhwc(C.byref(d), _ptr(x), _ptr(gy), _ptr(dw), int(ldw), _stream()), "mhe_conv_wgrad_nhwc")
@@ -512,9 +620,7 @@ def conv_wgrad_rect(x, gy, KH, KW, stride_h, stride_w, pad_h, pad_w, dw):
     need = L.mhe_conv_wgrad_rect_workspace_floats(C.byref(d), Ho, Wo) if WGRAD_SLABS else 0
     ws = None
     if need:
-        ws = _WGRAD_WS.get(x.device)
-        if ws is None or ws.numel() < need:
-            ws = _WGRAD_WS[x.device] = torch.empty(need, device=x.device, dtype=torch.float32)
+        ws = _wgrad_ws(x.device, need)
     check(L.mhe_conv_wgrad_rect_nhwc(C.byref(d), stride_w, pad_w, Ho, Wo, _ptr(x), _ptr(gy), _ptr(dw), 0, _ptr(ws), ws.numel() if ws is not None else 0,
                                      _stream()), "mhe_conv_wgrad_rect_nhwc")
     return dw

@@ -94,6 +94,10 @@ class ResNetTrunk(nn.Module):
         self.bn_apply_3x3 = os.environ.get("MHE_BN_APPLY_3X3", "auto")
         # evaluate relu(bn3(conv3) + identity) inside the next block's conv1 (one read of the block output saved)
         self.fuse_tail = os.environ.get("MHE_FUSE_TAIL", "1") == "1"
+        # ... and at 64 / 128 bottleneck channels (layer1 / layer2) do not write conv3's raw output at all: a statistics-only launch gives
+        # bn3's batch statistics, the tail kernel evaluates conv3 again on its way (csrc/conv_fuse.hip; bf16 storage, forward-only path -
+        # the train step keeps the raw outputs for its reverse pass)
+        self.fuse_recompute = os.environ.get("MHE_FUSE_RECOMPUTE", "1") == "1"
 
     # -- packed-weight cache keyed on the parameter's version counter
     def _w(self, conv, cin_pad=None, stem=False):
@@ -108,13 +112,13 @@ class ResNetTrunk(nn.Module):
             self._wcache[id(p)] = hit
         return hit[1]
 
-    def _bn_affine(self, y, bn, st):
+    def _bn_affine(self, y, bn, st, count=None):
         """this layer's BatchNorm folded to (scale, shift): batch statistics in training, running ones in eval"""
         if self.training:
-            count = y.numel() // y.shape[-1]
-            aff = ops.bn_finalize(st, bn.weight, bn.bias, bn.running_mean, bn.running_var, count, BN_MOMENTUM, BN_EPS)
-            self._bn_touched.append(bn.num_batches_tracked)
-            return aff
+            count = count if count is not None else y.numel() // y.shape[-1]
+            # the finalize launch also clears the accumulators it read (self-cleaning arena) and counts the batch
+            return ops.bn_finalize(st, bn.weight, bn.bias, bn.running_mean, bn.running_var, count, BN_MOMENTUM, BN_EPS, clear=True,
+                                   num_batches_tracked=bn.num_batches_tracked)
         sc = bn.weight.detach() / torch.sqrt(bn.running_var + BN_EPS)
         return sc.contiguous(), (bn.bias.detach() - bn.running_mean * sc).contiguous()
 
@@ -134,8 +138,7 @@ class ResNetTrunk(nn.Module):
         dt = self.compute_dtype
         if getattr(self, "_external_sync", None) is not None:
             self._external_sync()             # trainer-owned operand packs follow the parameters (optimizer.step, load_state_dict)
-        pool = _StatsPool(x.device)
-        self._bn_touched = []
+        pool = self._stats_pool(x.device) if self.training else None
         st = pool.take(64) if self.training else None
         y = ops.stem_conv7x7s2(x.contiguous(), self._w(self.conv1, stem=True), dt, stats=st)      # reads the NCHW image directly
         aff = self._bn_affine(y, self.bn1, st)
@@ -144,7 +147,14 @@ class ResNetTrunk(nn.Module):
         pending = None          # (raw conv3 output, bn3 affine, identity tensor, identity affine | None): an unevaluated block tail
         for bi, blk in enumerate(blocks):
             if blk.kind == "bottleneck":
-                if pending is not None:
+                if pending is not None and isinstance(pending[0], str):
+                    # ... with the previous block's conv3 evaluated again inside the same kernel (its raw output was never written)
+                    _, y2_p, a2_p, w3_p, al_p, idt_p, idaff_p = pending
+                    st = pool.take(blk.conv1.out_channels) if self.training else None
+                    a, y1 = ops.bottleneck_tail(y2_p, a2_p, w3_p, al_p, idt_p, idaff_p, self._w(blk.conv1), stats=st)
+                    a1 = self._bn_affine(y1, blk.bn1, st)
+                    pending = None
+                elif pending is not None:
                     # the previous block's relu(bn3(y3) + identity) is evaluated inside this conv1's operand load,
                     # which also writes it out once as this block's identity
                     yl_p, al_p, idt_p, idaff_p = pending
@@ -165,8 +175,21 @@ class ResNetTrunk(nn.Module):
                 # (... and where the resident-slab kernel runs conv3, layer3 at C2: its transfer waves normalise each K tile once)
                 ap3 = self.bn_apply_1x1 if self.bn_apply_1x1 != "auto" else ("load" if blk.conv3.in_channels <= 128 or ops.conv_tile_choice(
                     y2.shape[0], y2.shape[1], y2.shape[2], y2.shape[3], blk.conv3.out_channels, 1, 1, 0, y2.dtype, 1) == 11 else "pass")
-                yl, al = self._conv_bn(y2, blk.conv3, blk.bn3, pool, a2, apply=ap3)
+                nxt = blocks[bi + 1] if bi + 1 < len(blocks) else None
+                recompute = (self.fuse_recompute and self.fuse_tail and nxt is not None and nxt.kind == "bottleneck" and y2.dtype == torch.bfloat16
+                             and nxt.conv1.kernel_size == (1, 1) and nxt.conv1.stride == (1, 1)
+                             and ops.bottleneck_tail_supported(y2.shape[0], y2.shape[1], y2.shape[2], y2.shape[3], nxt.conv1.out_channels))
+                if recompute:
+                    w3 = self._w(blk.conv3)
+                    st3 = None
+                    if self.training:        # bn3's batch statistics from the products as they would be stored - nothing is stored
+                        st3 = pool.take(blk.conv3.out_channels)
+                        ops.conv1x1_stats(y2, w3, a2[0], a2[1], st3)
+                    yl, al = None, self._bn_affine(None, blk.bn3, st3, count=y2.numel() // y2.shape[-1])
+                else:
+                    yl, al = self._conv_bn(y2, blk.conv3, blk.bn3, pool, a2, apply=ap3)
             else:
+                recompute = False
                 y1, a1 = self._conv_bn(a, blk.conv1, blk.bn1, pool, None, blk.stride, 1, 3)
                 yl, al = self._conv_bn(y1, blk.conv2, blk.bn2, pool, a1, 1, 1, 3)
             if blk.downsample is not None:
@@ -174,27 +197,51 @@ class ResNetTrunk(nn.Module):
             else:
                 idt, idaff = a, None
             nxt = blocks[bi + 1] if bi + 1 < len(blocks) else None
-            if self.fuse_tail and nxt is not None and nxt.kind == "bottleneck":
+            if recompute:
+                pending = ("re", y2, a2, w3, al, idt, idaff)
+            elif self.fuse_tail and nxt is not None and nxt.kind == "bottleneck":
                 pending = (yl, al, idt, idaff)
             elif idaff is not None:
                 a = ops.bn_act(yl, al[0], al[1], idt, idaff[0], idaff[1], relu=True)
             else:
                 a = ops.bn_act(yl, al[0], al[1], idt, relu=True)
-        if self._bn_touched:
-            torch._foreach_add_(self._bn_touched, 1)      # one multi-tensor launch instead of one per BatchNorm
+        if pool is not None:
+            pool.done()
         return self.fc(ops.avgpool(a))
+
+    def _stats_pool(self, device):
+        """the trunk's statistics arena: allocated (zeroed) once; every slice handed out is cleared again by the bn_finalize launch
+        that consumes it, so a forward starts on zeros without a fill launch"""
+        p = getattr(self, "_pool", None)
+        if p is None or p.buf.device != device:
+            p = self._pool = _StatsPool(device, persistent=True)
+        p.begin()
+        return p
 
 
 class _StatsPool:
-    """one zeroed arena for all sharded per-channel (sum, sum^2) accumulators of a forward"""
-    def __init__(self, device, channels=32768):
+    """one zeroed arena for all sharded per-channel (sum, sum^2) accumulators of a pass.  persistent=True: kept across passes by its
+    owner - every slice must then be consumed by a launch that clears it (ops.bn_finalize(clear=True)); begin() / done() bracket a
+    pass, and a pass that did not finish (an exception in between) leaves the arena marked dirty: the next begin() zeroes it."""
+    def __init__(self, device, channels=32768, persistent=False):
         self.S = ops.stat_shards()
         self.buf = torch.zeros(self.S * 2 * channels, device=device, dtype=torch.float32)
         self.off = 0
+        self.persistent, self.clean = persistent, True
+
+    def begin(self):
+        if not self.clean:
+            self.buf.zero_()
+        self.off, self.clean = 0, False
+
+    def done(self):
+        self.clean = True
 
     def take(self, C):
         n = self.S * 2 * C
         if self.off + n > self.buf.numel():
+            if self.persistent:
+                raise RuntimeError("_StatsPool: persistent arena exhausted")
             self.buf = torch.zeros_like(self.buf)
             self.off = 0
         v = self.buf[self.off:self.off + n].view(self.S, 2, C)

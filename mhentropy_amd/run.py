@@ -87,6 +87,7 @@ def main(argv=None):
         for m in meters.values():
             m.reset()
         t0 = time.time()
+        it_losses = []
         for it in range(args.iters):
             if args.input_pipeline:
                 order = aug_rng.randint(0, len(pool), args.batch)
@@ -100,17 +101,22 @@ def main(argv=None):
                 from .train import GraphedStep
                 yk = {k: y[k].contiguous() for k in ("crop_uv", "vis")}          # what the loss consumes
                 if graphed is None or graphed_lr != trainer.lr:
+                    # (re-)capture: GraphedStep's warm-up pass is one real step on this batch - it IS this iteration (replaying the
+                    # same batch as well would apply two optimizer steps to it and advance Adam's count and the BatchNorm buffers twice)
                     sx, sy = x.clone(), {k: v.clone() for k, v in yk.items()}
-                    graphed, graphed_lr = GraphedStep(trainer, sx, sy, N=args.hyps), trainer.lr        # (its warm-up pass is one real step)
-                sx.copy_(x)
-                for k, v in yk.items():
-                    sy[k].copy_(v)
-                out = graphed.replay()
+                    graphed, graphed_lr = GraphedStep(trainer, sx, sy, N=args.hyps), trainer.lr
+                    out = graphed.warm_out
+                else:
+                    sx.copy_(x)
+                    for k, v in yk.items():
+                        sy[k].copy_(v)
+                    out = graphed.replay()
             else:
                 out = trainer.step(x, y, N=args.hyps, test_samples=args.test_samples)
             with torch.no_grad():
                 total, losses, metrics = criterion(dict(out), y)
             meters["loss"].update(float(total))
+            it_losses.append(float(total))
             if scalars is not None:
                 scalars.iteration(step, losses, metrics, out)
             if args.test_samples:
@@ -119,7 +125,8 @@ def main(argv=None):
             step += 1
         torch.cuda.synchronize()
         rec = mdist.reduce_mean_scalars({k: float(m.avg) for k, m in meters.items()}, dist, device=torch.device("cuda"))
-        rec.update(epoch=epoch, lr=trainer.lr, img_per_s=round(world * args.batch * args.iters / (time.time() - t0), 1))
+        rec.update(epoch=epoch, lr=trainer.lr, img_per_s=round(world * args.batch * args.iters / (time.time() - t0), 1),
+                   it_losses=[round(v, 4) for v in it_losses])          # this rank's per-iteration totals (the resume test reads the first)
         log.append(rec)
         if scalars is not None:
             scalars.epoch(step, rec["loss"], rec["epe3d"])
@@ -131,6 +138,7 @@ def main(argv=None):
         harness.save_model(args.save, model)
     if dist is not None:
         dist.destroy_process_group()
+    main.last_trainer = trainer           # (tests: optimizer step count, parameters)
     return log
 
 

@@ -476,15 +476,13 @@ class TrainStep:
         count = y.numel() // u.cout
         bn = u.bn
         u.scale, u.shift, u.mi = ops.bn_finalize(st, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, count, BN_MOMENTUM,
-                                                 BN_EPS, want_mean_invstd=True)
+                                                 BN_EPS, want_mean_invstd=True, clear=True, num_batches_tracked=bn.num_batches_tracked)
         u.x, u.y = x, y
-        self._bn_touched.append(bn.num_batches_tracked)
         return y
 
     def _trunk_forward(self, x):
         T = self.T
-        pool = resnet._StatsPool(self.dev, channels=65536)
-        self._bn_touched = []
+        pool = self.trunk._stats_pool(self.dev)       # self-cleaning arena shared with the module's own forward
         u = self.stem
         if u.pairs:
             if x.shape[3] % 2 or x.shape[2] % 2:
@@ -545,7 +543,7 @@ class TrainStep:
             else:
                 a = ops.bn_act(yl, ul.scale, ul.shift, b["a"], relu=True)
             b["out"] = a
-        torch._foreach_add_(self._bn_touched, 1)
+        pool.done()
         self.a_last = a
         return ops.avgpool(a)
 
@@ -762,7 +760,7 @@ class TrainStep:
         B = x.shape[0] if trunk_out is None else trunk_out.shape[0]
         self.sync()           # someone else (torch.optim, load_state_dict) may have written the parameters
         f = self._trunk_forward(x.contiguous()) if trunk_out is None else trunk_out.contiguous()
-        feat = ops.linear(f, self.l1["w"], self.l1["b"])
+        feat, feat_b = ops.linear(f, self.l1["w"], self.l1["b"], want_bf16=True) if self.flow_bf16 else (ops.linear(f, self.l1["w"], self.l1["b"]), None)
         hs, B_own, N_all, feat_own = None, B, N, feat
         if self.shard_hypotheses:
             if self.glow is not None:
@@ -770,6 +768,7 @@ class TrainStep:
             from .dist import HypothesisShards
             hs = HypothesisShards(self.dist, N)
             feat_own, feat = feat, hs.gather_rows(feat)                       # (world*B, 512): every image's conditioning feature
+            feat_b = None
             y = {"crop_uv": hs.gather_rows(y["crop_uv"]), "vis": hs.gather_rows(y["vis"])}
             if noise is not None:
                 noise = hs.gather_hypothesis_rows(noise.reshape(N * B, 45), B)
@@ -787,7 +786,9 @@ class TrainStep:
         else:
             h, ncoup = fl.hidden, len(fl.mask)
             if self.f_wcb is not None:
-                cond = ops.linear_bf16_f32out(feat.to(torch.bfloat16), self.f_wcb, self.f_bc).view(B, 2 * ncoup, 2, h)
+                if feat_b is None:
+                    feat_b = feat.to(torch.bfloat16)
+                cond = ops.linear_bf16_f32out(feat_b, self.f_wcb, self.f_bc).view(B, 2 * ncoup, 2, h)
             else:
                 cond = ops.linear(feat, self.f_wc, self.f_bc).view(B, 2 * ncoup, 2, h)
             z0 = m._noise(N * B, 1.0, noise, self.dev)
@@ -817,7 +818,7 @@ class TrainStep:
                "log_p": log_p if m.entropy else q_log_p}
         if m.entropy:
             out["h_q_z_giv_i"] = hq
-        self.tape = {"f": f, "feat": feat, "hd": hd, "det": det, "cond": cond, "th45": th45, "blob": blob, "cu": cu, "vis": vis,
+        self.tape = {"f": f, "feat": feat, "feat_b": feat_b, "hd": hd, "det": det, "cond": cond, "th45": th45, "blob": blob, "cu": cu, "vis": vis,
                      "N": N, "B": B, "trunk": trunk_out is None, "hs": hs, "B_own": B_own, "N_all": N_all, "feat_own": feat_own}
         return out
 
@@ -854,7 +855,8 @@ class TrainStep:
             # the bf16 copy for this call when the f32 copy is not kept)
             wc32 = self.f_wc if (cond_bf16 or self.cond_f32) else self.f_wcb.float()
             if cond_bf16:
-                ops.linear_wgrad(feat.to(torch.bfloat16), Gc.to(torch.bfloat16), self.dwc)
+                fb = t.get("feat_b")
+                ops.linear_wgrad(fb if fb is not None else feat.to(torch.bfloat16), Gc.to(torch.bfloat16), self.dwc)
             else:
                 ops.linear_wgrad(feat, Gc, self.dwc)
             ops.colsum(Gc, self.dbc)
@@ -973,7 +975,11 @@ class GraphedStep:
         side = torch.cuda.Stream()
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            ts.step(x, y, noise=noise, N=N)              # allocations and lazy initialisation happen here, not under capture
+            # allocations and lazy initialisation happen here, not under capture.  This warm-up IS one real optimizer step on the
+            # batch held by x / y: `warm_out` is that iteration's result, and a training loop must not replay() the same batch
+            # again (mhentropy_amd/run.py takes warm_out for the capture iteration; the reference steps once per iteration,
+            # hand/CrossModalHand.py:455-470)
+            self.warm_out = ts.step(x, y, noise=noise, N=N)
         cur.wait_stream(side)
         torch.cuda.synchronize()
         self._mode = "thread_local" if ts.world > 1 else "global"      # the communicator's watchdog thread may touch the device

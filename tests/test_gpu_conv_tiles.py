@@ -447,3 +447,52 @@ def test_row_streaming_3x3_kernel(gpu_lib, B, H, form):
         assert_close(stt[1] / n, (ys ** 2).mean((0, 2, 3)), 1e-5, what="batch E[x^2]")
     forced = ops.conv2d_nhwc(xd, wd, 3, 3, 1, 1, tile=1, **kw)
     assert_close(y.float().cpu(), forced.float().cpu(), 8e-3, what="vs the tiled kernel")
+
+
+@pytest.mark.parametrize("geom", [(4, 16, 16, 64, 64), (6, 16, 16, 64, 128), (3, 16, 16, 128, 128), (2, 8, 8, 128, 64), (40, 32, 32, 64, 64), (80, 16, 16, 128, 128)],
+                         ids=lambda g: "x".join(map(str, g)))
+@pytest.mark.parametrize("affine2", [False, True], ids=["identity", "downsample-bn"])
+def test_bottleneck_tail_with_conv3_reevaluated(gpu_lib, geom, affine2):
+    """variant 12 (csrc/conv_fuse.hip): statistics-only conv3 + the fused tail that evaluates conv3 again, against the path it replaces -
+    conv3 written out (mhe_conv2d_nhwc, BatchNorm on load) then read back by mhe_conv1x1_residual_in_nhwc.  Same products in the same
+    order: block output, next conv1 output bit-identical; statistics to the f32 atomics' order.  And against torch in f64 (bf16 tolerance).
+    The last two geometries give every workgroup several tiles (persistent loop, cross-tile prefetch)."""
+    from mhentropy_amd import ops, resnet
+    B, H, W, Cb, N2 = geom
+    C4 = 4 * Cb
+    g = torch.Generator().manual_seed(Cb + N2 + B)
+    y2 = torch.randn(B, Cb, H, W, generator=g).bfloat16().float()
+    idt = torch.randn(B, C4, H, W, generator=g).bfloat16().float()
+    w3 = (torch.randn(C4, Cb, 1, 1, generator=g) * (2.0 / Cb) ** 0.5).bfloat16().float()
+    w1 = (torch.randn(N2, C4, 1, 1, generator=g) * (2.0 / C4) ** 0.5).bfloat16().float()
+    s2, h2 = torch.rand(Cb, generator=g) + 0.5, torch.randn(Cb, generator=g) * 0.3
+    s3, h3 = torch.rand(C4, generator=g) + 0.5, torch.randn(C4, generator=g) * 0.3
+    si, hi = (torch.rand(C4, generator=g) + 0.5, torch.randn(C4, generator=g) * 0.3) if affine2 else (None, None)
+    cu = lambda t: None if t is None else t.cuda()
+    y2d, idd = _nhwc(y2), _nhwc(idt)
+    w3d, w1d = resnet.pack_conv_weight(w3, torch.bfloat16).cuda(), resnet.pack_conv_weight(w1, torch.bfloat16).cuda()
+    S = ops.stat_shards()
+    # the unfused path: conv3 with bn2 + relu on the operand load (+ statistics), then the MODE 2 tail
+    st3_ref, st1_ref = torch.zeros(S, 2, C4, device="cuda"), torch.zeros(S, 2, N2, device="cuda")
+    y3 = ops.conv2d_nhwc(y2d, w3d, 1, 1, 1, 0, in_scale=cu(s2), in_shift=cu(h2), relu_in=True, stats=st3_ref)
+    a_ref = torch.empty_like(y3)
+    y1_ref = ops.conv1x1_residual_in(y3, idd, w1d, cu(s3), cu(h3), cu(si), cu(hi), a_out=a_ref, stats=st1_ref)
+    # statistics-only conv3: same sums, nothing stored
+    st3 = torch.zeros(S, 2, C4, device="cuda")
+    ops.conv1x1_stats(y2d, w3d, cu(s2), cu(h2), st3)
+    assert_close(st3.double().sum(0).cpu(), st3_ref.double().sum(0).cpu(), 1e-6, what="conv3 statistics without the store")
+    # fused tail
+    assert ops.bottleneck_tail_supported(B, H, W, Cb, N2)
+    st1 = torch.zeros(S, 2, N2, device="cuda")
+    a, y1 = ops.bottleneck_tail(y2d, (cu(s2), cu(h2)), w3d, (cu(s3), cu(h3)), idd, (cu(si), cu(hi)) if affine2 else None, w1d, stats=st1)
+    torch.cuda.synchronize()
+    assert torch.equal(a, a_ref), f"block output differs on {(a != a_ref).float().mean().item():.2e} of the elements"
+    assert torch.equal(y1, y1_ref), f"conv1 output differs on {(y1 != y1_ref).float().mean().item():.2e} of the elements"
+    assert_close(st1.double().sum(0).cpu(), st1_ref.double().sum(0).cpu(), 1e-6, what="conv1 statistics")
+    # ... and against torch (f64) on the same bf16-rounded operands
+    a2 = F.relu(y2.double() * s2.double()[None, :, None, None] + h2.double()[None, :, None, None]).bfloat16().double()
+    t = F.conv2d(a2, w3.double()).bfloat16().double()
+    ident = idt.double() * si.double()[None, :, None, None] + hi.double()[None, :, None, None] if affine2 else idt.double()
+    aa = F.relu(t * s3.double()[None, :, None, None] + h3.double()[None, :, None, None] + ident)
+    assert_close(a.float().cpu().permute(0, 3, 1, 2), aa, TOL, what="block output vs torch")
+    assert_close(y1.float().cpu().permute(0, 3, 1, 2), F.conv2d(aa.bfloat16().double(), w1.double()), 2 * TOL, what="conv1 vs torch")

@@ -322,3 +322,99 @@ def test_flow_lrelu_bwd_sum(gpu_lib, H, N, B):
     assert_close(sums[:, H:2 * H].cpu(), want.cpu(), 1e-6, what="per-image sums")
     assert torch.equal(sums_t.t().contiguous(), sums[:, H:2 * H].contiguous())
     assert float(sums[:, :H].abs().max()) == 0 and float(sums[:, 2 * H:].abs().max()) == 0
+
+
+def test_device_base_noise_is_standard_normal_and_advances(gpu_lib):
+    """mhe_randn_f32 (the z0 = prior.sample((N*B,)) * temp of hand/flows.py:339 drawn inside the step): moments of N(0, 1), scale,
+    no repeats between launches, the same seed gives the same stream, the counter lives on the device so a HIP-graph replay draws
+    fresh numbers"""
+    from mhentropy_amd import ops
+    dev = torch.device("cuda", 0)
+    st = torch.tensor([1234, 0, 0], dtype=torch.int64, device=dev)
+    n_rows = 16384
+    a = ops.randn(n_rows, 45, dev, state=st)
+    b = ops.randn(n_rows, 45, dev, state=st)
+    n = a.numel()
+    assert st.tolist() == [1234, 2 * ((n + 3) // 4), 0]
+    x = a.double().flatten()
+    se = 1.0 / np.sqrt(n)
+    assert abs(x.mean().item()) < 5 * se and abs(x.var().item() - 1.0) < 5 * np.sqrt(2.0) * se
+    assert abs((x ** 3).mean().item()) < 5 * np.sqrt(15.0) * se and abs((x ** 4).mean().item() - 3.0) < 5 * np.sqrt(96.0) * se
+    assert x.abs().max().item() < 6.5 and torch.isfinite(a).all()
+    # independent of the previous launch and of the neighbouring element
+    assert abs((a.double() * b.double()).mean().item()) < 5 * se
+    assert abs((x[:-1] * x[1:]).mean().item()) < 5 * se
+    assert not torch.equal(a, b)
+    st2 = torch.tensor([1234, 0, 0], dtype=torch.int64, device=dev)
+    assert torch.equal(ops.randn(n_rows, 45, dev, state=st2), a)                       # same seed, same counter: same numbers
+    c = ops.randn(n_rows, 45, dev, scale=0.8, state=torch.tensor([1234, 0, 0], dtype=torch.int64, device=dev))
+    assert_close(c.cpu(), 0.8 * a.cpu(), 1e-6, what="scale = temp")
+    odd = ops.randn(7, 45, dev, state=torch.tensor([5, 0, 0], dtype=torch.int64, device=dev))          # n % 4 != 0: tail elements written
+    assert torch.isfinite(odd).all() and odd.abs().sum() > 0
+    # graph replay: the launch advances its own counter
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.randn(64, 45, dev, state=st)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = ops.randn(64, 45, dev, state=st)
+    g.replay(); r1 = out.clone()
+    g.replay(); r2 = out.clone()
+    assert not torch.equal(r1, r2)
+
+
+def test_bn_finalize_step_clears_its_accumulators_and_counts_the_batch(gpu_lib):
+    from mhentropy_amd import ops
+    C_, S = 96, ops.stat_shards()
+    rng = np.random.default_rng(3)
+    stats = _dev(rng.random((S, 2, C_)).astype(np.float32) * 10 + np.array([0.0, 400.0], np.float32)[None, :, None])
+    gamma, beta = _dev(rng.normal(1, 0.1, C_).astype(np.float32)), _dev(rng.normal(0, 0.1, C_).astype(np.float32))
+    rm, rv = torch.zeros(C_, device="cuda"), torch.ones(C_, device="cuda")
+    nbt = torch.tensor(7, dtype=torch.int64, device="cuda")
+    ref = ops.bn_finalize(stats.clone(), gamma, beta, rm.clone(), rv.clone(), 4096.0, want_mean_invstd=True)
+    got = ops.bn_finalize(stats, gamma, beta, rm, rv, 4096.0, want_mean_invstd=True, clear=True, num_batches_tracked=nbt)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    assert int(nbt) == 8 and not stats.any()
+
+
+def test_linear_with_bf16_copy_and_stochastic_head(gpu_lib):
+    """mhe_linear_f32_bf16copy = mhe_linear_f32 + the rounded copy; BasicEnc's (z, mn, sd) of hand/network.py:121-138"""
+    from mhentropy_amd import ops
+    rng = np.random.default_rng(4)
+    x, w, b = _dev(rng.normal(0, 1, (200, 2048)).astype(np.float32)), _dev(rng.normal(0, 0.03, (512, 2048)).astype(np.float32)), _dev(rng.normal(0, 1, 512).astype(np.float32))
+    y0 = ops.linear(x, w, b)
+    y1, yb = ops.linear(x, w, b, want_bf16=True)
+    assert torch.equal(y0, y1) and torch.equal(yb, y0.to(torch.bfloat16))
+    mn, l2, eps = y0, _dev(rng.normal(0, 1, (200, 512)).astype(np.float32)), _dev(rng.normal(0, 1, (200, 512)).astype(np.float32))
+    sd, z = ops.reparam(mn, l2, eps)
+    assert_close(sd.cpu(), torch.exp(0.5 * l2).cpu(), 1e-6, what="sd")
+    assert_close(z.cpu(), (mn + torch.exp(0.5 * l2) * eps).cpu(), 1e-6, what="z")
+    sd2, z2 = ops.reparam(mn, l2, None, sigmoid_act=True)
+    assert_close(sd2.cpu(), torch.sigmoid(l2).cpu(), 1e-6, what="sigmoid sd")
+    assert torch.equal(z2, mn)
+
+
+def test_basic_enc_returns_the_references_triple(gpu_lib):
+    """the exported class stand-alone: (z, mn, sd) like hand/network.py:96-140; MHEnt's own encoder skips the dead half"""
+    from mhentropy_amd.network import BasicEnc
+    from oracle import resnet_ref
+    torch.manual_seed(0)
+    enc = BasicEnc(n_latent=512, backbone="resnet18", pretrained=False).cuda().eval()
+    xn, _ = synth.batch(3, 4, image_size=64)
+    x = torch.as_tensor(xn).cuda()
+    eps = torch.randn(4, 512, device="cuda")
+    z, mn, sd = enc(x, eps=eps)
+    with torch.no_grad():
+        f = resnet_ref.forward({k: v.detach().cpu() for k, v in enc.res.state_dict().items()}, torch.as_tensor(xn), "resnet18", False)
+        mn_ref = torch.nn.functional.linear(f, enc.l1[0].weight.cpu(), enc.l1[0].bias.cpu())
+        sd_ref = torch.exp(0.5 * torch.nn.functional.linear(f, enc.l2[0].weight.cpu(), enc.l2[0].bias.cpu()))
+    assert_close(mn.cpu(), mn_ref, 2e-4, what="mn")
+    assert_close(sd.cpu(), sd_ref, 2e-4, what="sd")
+    assert_close(z.cpu(), mn_ref + sd_ref * eps.cpu(), 2e-4, what="z")
+    z2, _, _ = enc(x)                                    # epsilon drawn on the device
+    assert torch.isfinite(z2).all() and not torch.equal(z2, z)
+    zd, mnd, _ = enc(x, deterministic=True)
+    assert torch.equal(zd, mnd)

@@ -585,6 +585,20 @@ def test_run_entry_point(gpu_lib, tmp_path, monkeypatch):
                      "--scalars", str(sc)])
     assert len(log2) == 1 and np.isfinite(log2[0]["loss"])
     assert torch.equal(seen["w"], sd["encoderRGB"]["det_head.0.weight"].cpu())
+    # resumed, not re-initialised - on the loss this time: the FIRST resumed iteration's total is the checkpointed model's loss on
+    # that batch (batch 0, the run's own noise draw), i.e. the model the config path built + TrainStep's operand packs ARE the saved
+    # model.  (Round 2 compared the resumed epoch's mean with the untrained model's: 6,175 vs 3,133 "failed" - tools/resume_diag.py
+    # shows why that was the wrong expectation: after 8 steps on 8-image batches of random targets the checkpointed model scores 674 on
+    # the batch it saw last and 3,700 / 9,005 on batches 0 / 1, which the resumed run replays; both construction paths and the packs
+    # agree to 1e-6.  Adam's moments restart on resume as in the reference, hand/CrossModalHand.py:191-203,589-602.)
+    torch.manual_seed(0)                                      # run.main seeds the device generator the same way; the first draw is the loss noise
+    noise0 = torch.randn(6 * 8, 45, device="cuda")
+    xn, yn = synth.batch(0, 8, image_size=96)
+    fresh = fresh.cuda().train()
+    with torch.no_grad():
+        want = float(-fresh.get_loss(_dev(xn), {k: _dev(v) for k, v in yn.items()}, mods=["uv"], N=6, noise=noise0)["log_p"].mean())
+    got = log2[0]["it_losses"][0]
+    assert abs(got - want) <= 1e-3 * abs(want), (got, want)
     # ... and fed from decoded samples through the GPU input pipeline (row f4)
     log3 = run.main(["--backbone", "resnet18", "--batch", "4", "--hyps", "4", "--test-samples", "3", "--hidden", "64", "--flow-steps", "2",
                      "--dtype", "f32", "--epochs", "1", "--iters", "2", "--input-pipeline"])
@@ -593,8 +607,48 @@ def test_run_entry_point(gpu_lib, tmp_path, monkeypatch):
     log4 = run.main(["--backbone", "resnet18", "--batch", "4", "--hyps", "4", "--hidden", "64", "--flow-steps", "2", "--dtype", "f32", "--epochs", "2",
                      "--iters", "3", "--image-size", "96", "--milestones", "1", "--graph", "1"])
     assert len(log4) == 2 and all(np.isfinite(r["loss"]) for r in log4) and abs(log4[1]["lr"] - 2e-5) < 1e-12
+    # one optimizer step per iteration, capture iterations included (the warm-up pass of GraphedStep IS the iteration)
+    assert int(run.main.last_trainer.step_t.item()) == 6
+    assert int(run.main.last_trainer.model.feat_extractor.res.bn1.num_batches_tracked) == 6
     tags = {__import__("json").loads(l)["tag"] for l in open(sc)}
     assert {"loss_it/neg_log_p", "loss_avg/loss_total", "metric_train/eval_3d_rgb", "param/theta_norm", "param/beta_norm"} <= tags
+
+
+def test_graphed_loop_equals_eager_loop(gpu_lib):
+    """--graph 1 == --graph 0: a loop that takes GraphedStep's warm-up result for the capture iteration and replays the rest applies
+    exactly one optimizer step per batch - same step count, BatchNorm buffers and (to the f32 atomics' summation order) parameters
+    as the eager loop on the same batches and noise (hand/CrossModalHand.py:455-470: one step per iteration)"""
+    from mhentropy_amd import harness
+    from mhentropy_amd.train import TrainStep, GraphedStep
+    B, N, iters = 4, 4, 4
+    batches = []
+    for i in range(iters):
+        xn, yn = synth.batch(40 + i, B, image_size=96)
+        batches.append((_dev(xn), {k: _dev(yn[k]) for k in ("crop_uv", "vis")}, _dev(synth.noise(40 + i, N * B))))
+
+    def fresh():
+        torch.manual_seed(3)
+        m = harness.build_mhent(backbone="resnet18", h_dims=(64, 64), num_steps=2, tables=synth.mano_tables(0)).cuda().train()
+        return m, TrainStep(m, lr=2e-4)
+    m0, ts0 = fresh()
+    eager = [float(ts0.step(x, y, noise=z, N=N)["total"]) for x, y, z in batches]
+    m1, ts1 = fresh()
+    sx, sy, sz = batches[0][0].clone(), {k: v.clone() for k, v in batches[0][1].items()}, batches[0][2].clone()
+    g = GraphedStep(ts1, sx, sy, noise=sz, N=N)
+    graphed = [float(-g.warm_out["log_p"].mean())]
+    for x, y, z in batches[1:]:
+        sx.copy_(x); sz.copy_(z)
+        for k in sy:
+            sy[k].copy_(y[k])
+        graphed.append(float(-g.replay()["log_p"].mean()))
+    assert int(ts0.step_t.item()) == int(ts1.step_t.item()) == iters
+    assert int(m0.feat_extractor.res.bn1.num_batches_tracked) == int(m1.feat_extractor.res.bn1.num_batches_tracked) == iters
+    assert_close(graphed, eager, 1e-4, what="per-iteration loss, graphed vs eager loop")
+    # same kernels, same inputs: the two loops differ by the f32 atomics' summation order only; Adam turns a ~0 gradient whose sign
+    # flips into a +-lr difference, so bound the fraction of such elements instead of the maximum
+    d = (ts1.P - ts0.P).abs()
+    assert float((d > 2e-5).float().mean()) < 5e-3 and float(d.max()) <= 2 * iters * 2e-4, (float((d > 2e-5).float().mean()), float(d.max()))
+    assert torch.allclose(m1.feat_extractor.res.bn1.running_var, m0.feat_extractor.res.bn1.running_var, rtol=1e-5)
 
 
 def test_full_size_train_step_properties(gpu_lib):

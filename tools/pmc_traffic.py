@@ -28,6 +28,13 @@ def agg(d):
     return out
 
 
+def kernel_sources_sha1():
+    """sha1 over every kernel source of the library (csrc/*.hip, csrc/*.h, sorted by name): the counters describe THESE kernels"""
+    cs = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mhentropy_amd", "csrc")
+    names = sorted(f for f in os.listdir(cs) if f.endswith(".hip") or f.endswith(".h"))
+    return hashlib.sha1(b"".join(open(os.path.join(cs, f), "rb").read() for f in names)).hexdigest()
+
+
 def main():
     fetch, write, dst = agg(sys.argv[1]), agg(sys.argv[2]), sys.argv[3]
     res = {}
@@ -37,8 +44,7 @@ def main():
         wr = write[k][0] / nw * 1024
         res[k] = {"launches_profiled": nf, "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
                   "hbm_bytes_per_launch": round(rd + wr)}
-    cs = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mhentropy_amd", "csrc")
-    sha = hashlib.sha1(b"".join(open(os.path.join(cs, f), "rb").read() for f in ("conv.hip", "conv_p8.hip", "conv_stream.hip", "conv_tail.hip", "conv_wide.hip", "conv_shared.h"))).hexdigest()
+    sha = kernel_sources_sha1()
     json.dump({"source_sha1": sha, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py "
                          "--steps 2 --warmup 1 --dtype bf16 --no-cpu-baseline --graph 0 --train-steps 0 --no-glow-variant",
                "correction": "FETCH_SIZE x2 (gfx950 wide coalesced reads), counters in KiB", "kernels": res},
