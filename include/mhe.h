@@ -241,6 +241,19 @@ typedef struct mhe_conv_desc {
  * read it back in the block tail" for layer1 / layer2 of ResNet-50 (torchvision Bottleneck, hand/network.py:54-61,110). */
 int mhe_conv1x1_stats_nhwc(const mhe_conv_desc *d, const void *x, const void *w, const float *in_scale, const float *in_shift,
                            float *stats, void *stream);
+/* ... and cheaper still: the same batch statistics from the moments of the convolution's INPUT.  For y = W a:  sum_p y_c = w_c . m,
+ * sum_p y_c^2 = w_c^T G w_c  with m = sum_p a_p and G = sum_p a_p a_p^T (Cb x Cb) - 8x / 4x fewer multiply-adds than the product and no
+ * per-output-element work.  mhe_conv1x1_gram_nhwc accumulates G and m of a = relu?(x * in_scale + in_shift) (rounded to bf16, the operand
+ * conv3 multiplies) into `gram`, mhe_gram_stats_floats(Cb) floats (sharded; zeroed by the caller once - mhe_gram_bn_finalize clears what it
+ * read); mhe_gram_bn_finalize turns them into bn's affine like mhe_bn_finalize_step (w = the packed [C][Cb] bf16 weights; workspace =
+ * mhe_gram_stats_workspace_bytes(Cb) bytes).  Statistics of the f32 products (not of bf16-rounded outputs). */
+size_t mhe_gram_stats_floats(int Cb);
+size_t mhe_gram_stats_workspace_bytes(int Cb);
+int mhe_conv1x1_gram_nhwc(const void *x, const float *in_scale, const float *in_shift, int relu_in, float *gram, long pixels, int Cb,
+                          void *stream);
+int mhe_gram_bn_finalize(float *gram, void *workspace, const void *w, const float *gamma, const float *beta, float *running_mean,
+                         float *running_var, float *scale, float *shift, float *mean_invstd, int C, int Cb, float count,
+                         float momentum, float eps, long long *num_batches_tracked, void *stream);
 /* The tail of a bottleneck block with its conv3 re-evaluated, fused with the next block's conv1 (forward-only path; kernel variant 12):
  *   T  = conv1x1(relu(y2 * bn2_scale + bn2_shift), w3)   rounded to the storage type like a stored conv3 output   [B,H,W,Cin]
  *   a  = relu(T * bn3_scale + bn3_shift + (identity * id_scale + id_shift | identity))     -> a_out                 [B,H,W,Cin]

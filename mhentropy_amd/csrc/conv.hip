@@ -824,7 +824,7 @@ static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void
     MHE_REQUIRE(d->Cout % ce == 0, "mhe_conv2d_nhwc: Cout=%d must be a multiple of %d", d->Cout, ce);
     MHE_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "mhe_conv2d_nhwc: in_scale/in_shift must come together");
     MHE_REQUIRE(!in_scale || d->Cin <= conv::MAXC, "mhe_conv2d_nhwc: fused input affine supports Cin <= %d", conv::MAXC);
-    conv::Params p;
+    conv::Params p{};
     p.x = x; p.w = w; p.y = y; p.in_scale = in_scale; p.in_shift = in_shift; p.out_scale = out_scale;
     p.out_shift = out_shift; p.residual = residual; p.stats = stats; p.mask = mask;
     for (int u = 0; u < 2; ++u) { p.bn_y[u] = bn ? bn->y[u] : nullptr; p.bn_mi[u] = bn ? bn->mi[u] : nullptr; p.bn_stats[u] = bn ? bn->stats[u] : nullptr; }
@@ -870,7 +870,7 @@ extern "C" int mhe_conv1x1_stats_nhwc(const mhe_conv_desc *d, const void *x, con
     p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.Ho = d->H; p.Wo = d->W;
     const long long M = (long long)d->B * d->H * d->W;
     MHE_REQUIRE(M > 0 && M < (1ll << 31), "mhe_conv1x1_stats_nhwc: bad pixel count");
-    p.M = (int)M; p.Kpad = d->Cin; p.relu_in = d->relu_in; p.force = 8;
+    p.M = (int)M; p.Kpad = d->Cin; p.relu_in = d->relu_in; p.force = 8; p.stats_only = 1;
     MHE_REQUIRE(conv::stream_supports(p), "mhe_conv1x1_stats_nhwc: geometry not taken by the streaming kernel");
     return conv::launch_stream(p, (hipStream_t)stream);
 }

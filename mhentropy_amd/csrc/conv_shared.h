@@ -28,6 +28,7 @@ struct Params {
     int res_s2;            // residual at half resolution [B, ceil(Ho/2), ceil(Wo/2), Cout], added at even output positions only
     // bottleneck tail with conv3 re-evaluated (conv_fuse.hip): w3 [Cin][Cin / 4] packed, mid_scale / mid_shift = bn3's affine [Cin]
     const void *w3; const float *mid_scale, *mid_shift;
+    int stats_only;        // statistics-only launch of the streaming 1x1 kernel (y = NULL): any pixel count
 };
 
 // tile row -> global output pixel index the epilogue addresses (or -1 outside the problem)

@@ -580,7 +580,7 @@ static int stream_bn(const Params &p) { return p.Cin == 64 ? 256 : (p.Cin == 128
 
 bool stream_supports(const Params &p) {
     if (!(p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && (p.Cin == 64 || p.Cin == 128 || p.Cin == 256) && p.Kpad == p.Cin &&
-          !p.x2 && !p.out_scale && !p.out_shift && !p.relu_out && !p.y32 && !p.os2 && !p.a_out && (p.M >= 64 * 1024 || (!p.y && !p.mask))))
+          !p.x2 && !p.out_scale && !p.out_shift && !p.relu_out && !p.y32 && !p.os2 && !p.a_out && (p.M >= 64 * 1024 || (p.stats_only && !p.mask))))
         return false;
     if (p.Cout % stream_bn(p)) return false;
     if (p.Cin == 256 && !p.mask) return false;             // K = 256: only the data-gradient form gains (147 vs 158 us); plain 85 vs 63 us on the tiled kernel

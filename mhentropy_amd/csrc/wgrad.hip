@@ -312,16 +312,20 @@ struct DmaParams {
 };
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
+// <256, 256, 4, 2> (round 3): eight waves, a wave = 64 x 128 of the tile (TM = 2, TN = 4).  The 4-wave 128 x 128 tile reads (2 + 2) fragments
+// per 4 MFMAs - every staged byte twice, 128 B/clk/CU of transposing reads at the full MFMA rate, which the LDS does not deliver next to
+// the DMA writes (PMC: MFMA utilisation 0.20, 44 % issue-stalled); 64 x 128 per wave reads (2 + 4) per 8: 96 B/clk.  One workgroup per CU
+// (128 KiB ring), two waves per SIMD as before.
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void wgrad_dma_kernel(const DmaParams dp) {
+__global__ __launch_bounds__(64 * WM * WN) void wgrad_dma_kernel(const DmaParams dp) {
     const Params &p = dp.p;
-    constexpr int BKB = 32, NBUF = 4, DEPTH = 3;
-    constexpr int PA = BM * 2, PB = BN * 2;                       // row pitches in bytes (128 or 256)
+    constexpr int BKB = 32, NBUF = 4, DEPTH = 3, NW = WM * WN;
+    constexpr int PA = BM * 2, PB = BN * 2;                       // row pitches in bytes (128, 256 or 512)
     constexpr int STAGE = BKB * (PA + PB);
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int RA = 1024 / PA, RB = 1024 / PB;                 // rows per DMA wave-instruction
-    constexpr int IA = BKB / RA / 4, IB = BKB / RB / 4;           // DMA instructions per wave per stage
-    static_assert(WM * WN == 4 && (PA == 128 || PA == 256) && (PB == 128 || PB == 256) && IA >= 1 && IB >= 1, "tile");
+    constexpr int IA = BKB / RA / NW, IB = BKB / RB / NW;         // DMA instructions per wave per stage
+    static_assert((NW == 4 || NW == 8) && (PA == 128 || PA == 256 || PA == 512) && (PB == 128 || PB == 256 || PB == 512) && IA >= 1 && IB >= 1, "tile");
     __shared__ __attribute__((aligned(1024))) char ring[NBUF * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -329,7 +333,8 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const DmaParams dp) {
     const long k_begin = (long)blockIdx.z * p.chunk;
     const long k_end = k_begin + p.chunk < p.P ? k_begin + p.chunk : p.P;
     const unsigned OOB = 0x80000000u;
-    auto seg_swz = [](int pitch, int row) { return pitch == 256 ? (row & 3) : ((row >> 1) & 1); };
+    // (512-byte rows sit a multiple of 256 bytes apart like 256-byte ones: same remedy, the XOR stays inside the row's 256-byte half)
+    auto seg_swz = [](int pitch, int row) { return pitch >= 256 ? (row & 3) : ((row >> 1) & 1); };
 
     // ---- DMA role: per operand, instruction j of this wave fills rows R*(I*wave + j) .. +R-1 of the stage
     unsigned a_col[IA], b_col[IB];          // byte offset of this lane's 16 source bytes within a pixel's channel vector, or OOB
@@ -528,7 +533,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const float *__restrict__ s
 using namespace mhe;
 
 // geometry of a launch: tile, grid and pixel chunk (shared by the launcher and the workspace query)
-struct WgradPlan { int BM, BN, gx, gy, gz; long chunk; bool bf16k, small, narrow; };
+struct WgradPlan { int BM, BN, gx, gy, gz; long chunk; bool bf16k, small, narrow, dma, big; };
 static WgradPlan plan_wgrad(const mhe_conv_desc *d, int Ho_ = 0, int Wo_ = 0) {
     WgradPlan w;
     const int Ho = Ho_ > 0 ? Ho_ : (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = Wo_ > 0 ? Wo_ : (d->W + 2 * d->pad - d->KW) / d->stride + 1;
@@ -538,11 +543,21 @@ static WgradPlan plan_wgrad(const mhe_conv_desc *d, int Ho_ = 0, int Wo_ = 0) {
     w.bf16k = d->dtype == MHE_BF16 && d->Cin % 8 == 0 && d->Cout % 8 == 0 && !getenv("MHE_WGRAD_F32MFMA");
     w.narrow = w.bf16k && N <= 64;          // 1x1 layers with 64 input channels: a 128-wide N tile would be half empty
     w.BM = w.small ? 64 : 128; w.BN = w.narrow ? 64 : 128;
+    // LDS-DMA kernel: 32-bit byte offsets into x / gy, exact reciprocal quotients (pixel count < 2^32 / max(Wo, Ho))
+    const size_t xb = (size_t)d->B * d->H * d->W * d->Cin * 2, gb = (size_t)P * d->Cout * 2;
+    static const int dma_env = getenv("MHE_WGRAD_DMA") ? atoi(getenv("MHE_WGRAD_DMA")) : 1;
+    w.dma = w.bf16k && dma_env && xb < 0x7fff0000ull && gb < 0x7fff0000ull && P < (long)(0xffffffffull / (Wo > Ho ? Wo : Ho)) && d->KH * d->KW <= 64;
+    // 256 x 256 tile on eight waves (64 x 128 per wave) where both dimensions fill it: the layers from 256 output channels up
+    static const int big_env = getenv("MHE_WGRAD_BIG") ? atoi(getenv("MHE_WGRAD_BIG")) : 1;
+    // (measured, tools/wgrad_bench.py: -7 ... -26 % from 32k pixels up and on the 3x3 layers; the 16k-pixel 1x1 layers of layer4 and the
+    // flow's 512 x 512 products, a handful of tiles with short pixel slices each, lose 2 - 14 % and stay on the 128 x 128 tile)
+    w.big = w.dma && big_env && d->Cout % 256 == 0 && N >= 256 && (N % 256 == 0 || N >= 1024) && (P >= 32768 || N >= 2304);
+    if (w.big) w.BM = w.BN = 256;
     w.gx = (N + w.BN - 1) / w.BN; w.gy = (d->Cout + w.BM - 1) / w.BM;
     // split the pixel range: enough workgroups to fill 256 CUs a few times over; every split adds a full output tile of
     // partial sums - the bf16 kernel (4x faster mainloop) wants longer slices
     static const long target_wgs = getenv("MHE_WGRAD_WGS") ? atol(getenv("MHE_WGRAD_WGS")) : 512;      // 2 workgroups of the LDS-DMA kernel per CU: one resident wave of workgroups (measured 256-2048: 512 best)
-    long want = (w.bf16k ? target_wgs : 2048) / ((long)w.gx * w.gy);
+    long want = (w.big ? 256 : w.bf16k ? target_wgs : 2048) / ((long)w.gx * w.gy);      // (big tile: one workgroup per CU)
     if (want < 1) want = 1;
     long chunk = (P + want - 1) / want;
     static const long min_bf16 = getenv("MHE_WGRAD_MINCHUNK") ? atol(getenv("MHE_WGRAD_MINCHUNK")) : 512;
@@ -619,11 +634,8 @@ static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, fl
     p.ws = (ws && gz > 1 && gz <= 64 && need <= ws_floats && (size_t)d->Cout * p.N >= 131072) ? ws : nullptr;
     const dim3 grid(gx, gyy, gz), block(256);
     hipStream_t s = (hipStream_t)stream;
-    // LDS-DMA kernel: 32-bit byte offsets into x / gy, exact reciprocal quotients (pixel count < 2^32 / max(Wo, Ho))
     const size_t xb = (size_t)d->B * d->H * d->W * d->Cin * 2, gb = (size_t)p.P * d->Cout * 2;
-    static const int dma_env = getenv("MHE_WGRAD_DMA") ? atoi(getenv("MHE_WGRAD_DMA")) : 1;
-    const bool use_dma = dma_env && xb < 0x7fff0000ull && gb < 0x7fff0000ull && p.P < (long)(0xffffffffull / (p.Wo > p.Ho ? p.Wo : p.Ho)) &&
-                         d->KH * d->KW <= 64;
+    const bool use_dma = w.dma;
     if (d->dtype == MHE_F32) {
         if (small) hipLaunchKernelGGL((wgrad::wgrad_kernel<float, 64, 128>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((wgrad::wgrad_kernel<float, 128, 128>), grid, block, 0, s, p);
@@ -633,7 +645,8 @@ static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, fl
         dp.rcp_wo = (unsigned)((0x100000000ull + p.Wo - 1) / p.Wo); dp.rcp_ho = (unsigned)((0x100000000ull + p.Ho - 1) / p.Ho);
         dp.x_bytes = (unsigned)xb; dp.gy_bytes = (unsigned)gb;
         dp.plain = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && p.stride_w == 1 && p.pad_w == 0;
-        if (narrow) {
+        if (w.big) hipLaunchKernelGGL((wgrad::wgrad_dma_kernel<256, 256, 4, 2>), grid, dim3(512), 0, s, dp);
+        else if (narrow) {
             if (small) hipLaunchKernelGGL((wgrad::wgrad_dma_kernel<64, 64, 2, 2>), grid, block, 0, s, dp);
             else hipLaunchKernelGGL((wgrad::wgrad_dma_kernel<128, 64, 4, 1>), grid, block, 0, s, dp);
         } else {

@@ -366,6 +366,39 @@ def conv1x1_stats(x, w, in_scale, in_shift, stats):
     return stats
 
 
+def gram_buffers(Cb, device):
+    """(zeroed shard accumulators, f64 workspace) for conv1x1_gram_bn; the accumulators clean themselves (gram_bn_finalize)"""
+    L = _lib.lib()
+    return (torch.zeros(L.mhe_gram_stats_floats(Cb), device=device, dtype=torch.float32),
+            torch.empty(L.mhe_gram_stats_workspace_bytes(Cb) // 8, device=device, dtype=torch.float64))
+
+
+def conv1x1_gram_bn(x, in_scale, in_shift, w, bn_weight, bn_bias, running_mean, running_var, bufs, momentum=0.1, eps=1e-5, num_batches_tracked=None,
+                    want_mean_invstd=False):
+    """train-mode BatchNorm affine (scale, shift) of conv1x1(relu(x * in_scale + in_shift), w) from the Gram matrix of the convolution's
+    INPUT - the product itself is never evaluated (mhe_conv1x1_gram_nhwc + mhe_gram_bn_finalize; csrc/conv_gram.hip)"""
+    B, H, W, Cb = x.shape
+    Cn = w.shape[0]
+    _chk(x, torch.bfloat16, "gram.x"); _chk(w, torch.bfloat16, "gram.w", (Cn, Cb))
+    _chk(in_scale, torch.float32, "gram.in_scale", (Cb,)); _chk(in_shift, torch.float32, "gram.in_shift", (Cb,))
+    gram, ws = bufs
+    L = _lib.lib()
+    if TIMING:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(L.mhe_conv1x1_gram_nhwc(_ptr(x), _ptr(in_scale), _ptr(in_shift), 1, _ptr(gram), B * H * W, Cb, _stream()), "mhe_conv1x1_gram_nhwc")
+    if TIMING:
+        ev1.record()
+        KERNEL_TIMES.append(("mhe::conv::gram_kernel<%d>" % Cb, 2.0 * B * H * W * Cb * Cb, ev0, ev1, 2 * x.numel()))
+    scale = torch.empty(Cn, device=x.device, dtype=torch.float32)
+    shift = torch.empty_like(scale)
+    mi = torch.empty(2, Cn, device=x.device, dtype=torch.float32) if want_mean_invstd else None
+    check(L.mhe_gram_bn_finalize(_ptr(gram), _ptr(ws), _ptr(w), _ptr(bn_weight), _ptr(bn_bias), _ptr(running_mean), _ptr(running_var), _ptr(scale),
+                                 _ptr(shift), _ptr(mi), Cn, Cb, float(B * H * W), float(momentum), float(eps), _ptr(num_batches_tracked), _stream()),
+          "mhe_gram_bn_finalize")
+    return (scale, shift, mi) if want_mean_invstd else (scale, shift)
+
+
 def bottleneck_tail_supported(B, H, W, Cb, Cout):
     d = ConvDesc(B, H, W, 4 * Cb, Cout, 1, 1, 1, 0, BF16, 1, 0, 0, 0)
     return bool(_lib.lib().mhe_bottleneck_tail_supported(C.byref(d), int(Cb)))

@@ -98,6 +98,9 @@ class ResNetTrunk(nn.Module):
         # bn3's batch statistics, the tail kernel evaluates conv3 again on its way (csrc/conv_fuse.hip; bf16 storage, forward-only path -
         # the train step keeps the raw outputs for its reverse pass)
         self.fuse_recompute = os.environ.get("MHE_FUSE_RECOMPUTE", "1") == "1"
+        # bn3's batch statistics for those blocks: "gram" = from the Gram matrix of conv3's input (csrc/conv_gram.hip: the product is not
+        # evaluated at all), "stream" = the statistics-only launch of the streaming kernel (evaluates, rounds and sums the product)
+        self.recompute_stats = os.environ.get("MHE_RECOMPUTE_STATS", "gram")
 
     # -- packed-weight cache keyed on the parameter's version counter
     def _w(self, conv, cin_pad=None, stem=False):
@@ -182,10 +185,15 @@ class ResNetTrunk(nn.Module):
                 if recompute:
                     w3 = self._w(blk.conv3)
                     st3 = None
-                    if self.training:        # bn3's batch statistics from the products as they would be stored - nothing is stored
-                        st3 = pool.take(blk.conv3.out_channels)
-                        ops.conv1x1_stats(y2, w3, a2[0], a2[1], st3)
-                    yl, al = None, self._bn_affine(None, blk.bn3, st3, count=y2.numel() // y2.shape[-1])
+                    if self.training and self.recompute_stats == "gram":
+                        bn3 = blk.bn3
+                        yl, al = None, ops.conv1x1_gram_bn(y2, a2[0], a2[1], w3, bn3.weight, bn3.bias, bn3.running_mean, bn3.running_var,
+                                                           pool.gram(y2.shape[-1]), BN_MOMENTUM, BN_EPS, num_batches_tracked=bn3.num_batches_tracked)
+                    else:
+                        if self.training:    # bn3's batch statistics from the products as they would be stored - nothing is stored
+                            st3 = pool.take(blk.conv3.out_channels)
+                            ops.conv1x1_stats(y2, w3, a2[0], a2[1], st3)
+                        yl, al = None, self._bn_affine(None, blk.bn3, st3, count=y2.numel() // y2.shape[-1])
                 else:
                     yl, al = self._conv_bn(y2, blk.conv3, blk.bn3, pool, a2, apply=ap3)
             else:
@@ -228,10 +236,19 @@ class _StatsPool:
         self.buf = torch.zeros(self.S * 2 * channels, device=device, dtype=torch.float32)
         self.off = 0
         self.persistent, self.clean = persistent, True
+        self._gram = {}
+
+    def gram(self, Cb):
+        """the Gram accumulators + f64 workspace for bottleneck width Cb (ops.conv1x1_gram_bn; self-cleaning like the arena)"""
+        if Cb not in self._gram:
+            self._gram[Cb] = ops.gram_buffers(Cb, self.buf.device)
+        return self._gram[Cb]
 
     def begin(self):
         if not self.clean:
             self.buf.zero_()
+            for g, _ in self._gram.values():
+                g.zero_()
         self.off, self.clean = 0, False
 
     def done(self):

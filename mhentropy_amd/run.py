@@ -58,6 +58,8 @@ def main(argv=None):
         raise SystemExit("mhentropy_amd.run needs a HIP device (there is no CPU path)")
     torch.cuda.set_device(local_rank if world > 1 else 0)
     torch.manual_seed(args.seed)                      # same initial weights on every rank
+    from . import ops
+    ops.rng_state(torch.device("cuda", torch.cuda.current_device()), seed=args.seed + 7919 * rank)      # the device generator of the base noise
     cd = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     if cfg is not None:
         from .network import MHEnt

@@ -496,3 +496,44 @@ def test_bottleneck_tail_with_conv3_reevaluated(gpu_lib, geom, affine2):
     aa = F.relu(t * s3.double()[None, :, None, None] + h3.double()[None, :, None, None] + ident)
     assert_close(a.float().cpu().permute(0, 3, 1, 2), aa, TOL, what="block output vs torch")
     assert_close(y1.float().cpu().permute(0, 3, 1, 2), F.conv2d(aa.bfloat16().double(), w1.double()), 2 * TOL, what="conv1 vs torch")
+
+
+@pytest.mark.parametrize("geom", [(4, 16, 16, 64, 256), (2, 8, 8, 128, 512), (96, 32, 32, 64, 256), (40, 32, 32, 128, 512)], ids=lambda g: "x".join(map(str, g)))
+def test_gram_statistics_give_the_convolutions_batchnorm_affine(gpu_lib, geom):
+    """csrc/conv_gram.hip: train-mode BatchNorm (scale, shift, running statistics) of conv1x1(relu(bn(x)), w) from the Gram matrix of the
+    convolution's INPUT (sum y_c = w_c . m, sum y_c^2 = w_c^T G w_c) against torch in f64 on the same bf16-rounded operand, and against the
+    statistics-only launch it replaces (whose sums are of bf16-rounded outputs: agreement to that rounding's noise)"""
+    from mhentropy_amd import ops, resnet
+    B, H, W, Cb, C4 = geom
+    g = torch.Generator().manual_seed(Cb + B)
+    x = torch.randn(B, Cb, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(C4, Cb, 1, 1, generator=g) * (2.0 / Cb) ** 0.5).bfloat16().float()
+    s2, h2 = torch.rand(Cb, generator=g) + 0.5, torch.randn(Cb, generator=g) * 0.3
+    gamma, beta = torch.rand(C4, generator=g) + 0.5, torch.randn(C4, generator=g) * 0.2
+    xd, wd = _nhwc(x), resnet.pack_conv_weight(w, torch.bfloat16).cuda()
+    P = B * H * W
+    rm, rv = torch.zeros(C4, device="cuda"), torch.ones(C4, device="cuda")
+    nbt = torch.tensor(0, dtype=torch.int64, device="cuda")
+    bufs = ops.gram_buffers(Cb, torch.device("cuda"))
+    for rep in range(2):                                   # twice: the accumulators clean themselves
+        sc, sh, mi = ops.conv1x1_gram_bn(xd, s2.cuda(), h2.cuda(), wd, gamma.cuda(), beta.cuda(), rm, rv, bufs, num_batches_tracked=nbt,
+                                         want_mean_invstd=True)
+    assert int(nbt) == 2 and not bufs[0].any()
+    a = F.relu(x.double() * s2.double()[None, :, None, None] + h2.double()[None, :, None, None]).bfloat16().double()
+    y = F.conv2d(a, w.double())
+    mean, var = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
+    assert_close(mi[0].cpu(), mean, 2e-5, 1e-6, what="batch mean")
+    assert_close(1.0 / mi[1].double().cpu() ** 2 - 1e-5, var, 1e-4, what="batch variance")
+    sc_ref = gamma.double() / torch.sqrt(var + 1e-5)
+    assert_close(sc.cpu(), sc_ref, 1e-4, what="scale")
+    assert_close(sh.cpu(), beta.double() - mean * sc_ref, 1e-4, 1e-6, what="shift")
+    rm_ref = 0.1 * mean * (1 + 0.9)
+    assert_close(rm.cpu(), rm_ref, 1e-4, 1e-6, what="running_mean after two steps")
+    rv_ref = 0.9 * (0.9 * 1.0 + 0.1 * var * P / (P - 1)) + 0.1 * var * P / (P - 1)
+    assert_close(rv.cpu(), rv_ref, 1e-4, what="running_var after two steps")
+    # the statistics-only launch (bf16-rounded outputs) agrees to the rounding noise of its sums
+    st = torch.zeros(ops.stat_shards(), 2, C4, device="cuda")
+    ops.conv1x1_stats(xd, wd, s2.cuda(), h2.cuda(), st)
+    sc2, sh2 = ops.bn_finalize(st, gamma.cuda(), beta.cuda(), None, None, float(P))
+    assert_close(sc.cpu(), sc2.cpu(), 2e-3, what="scale vs statistics-only launch")
+    assert_close(sh.cpu(), sh2.cpu(), 2e-3, 1e-4, what="shift vs statistics-only launch")

@@ -591,8 +591,9 @@ def test_run_entry_point(gpu_lib, tmp_path, monkeypatch):
     # shows why that was the wrong expectation: after 8 steps on 8-image batches of random targets the checkpointed model scores 674 on
     # the batch it saw last and 3,700 / 9,005 on batches 0 / 1, which the resumed run replays; both construction paths and the packs
     # agree to 1e-6.  Adam's moments restart on resume as in the reference, hand/CrossModalHand.py:191-203,589-602.)
-    torch.manual_seed(0)                                      # run.main seeds the device generator the same way; the first draw is the loss noise
-    noise0 = torch.randn(6 * 8, 45, device="cuda")
+    from mhentropy_amd import ops
+    ops.rng_state(torch.device("cuda", torch.cuda.current_device()), seed=0)     # run.main seeds the device generator the same way; its first draw is the loss noise
+    noise0 = ops.randn(6 * 8, 45, torch.device("cuda", torch.cuda.current_device()))
     xn, yn = synth.batch(0, 8, image_size=96)
     fresh = fresh.cuda().train()
     with torch.no_grad():
