@@ -647,6 +647,7 @@ static void launch_mode(const Params &p, hipStream_t s) {
 
 bool p8_supports(const Params &p);             // conv_p8.hip: the phase-pipelined 256x256 bf16 kernel (variant 7)
 int launch_p8(const Params &p, hipStream_t s);
+int launch_p8h(const Params &p, hipStream_t s);   // ... on a 256 x 128 tile (variant 13)
 bool stream_supports(const Params &p);         // conv_stream.hip: the streaming 1x1 kernel for K = 64 / 128 (variant 8)
 int launch_stream(const Params &p, hipStream_t s);
 bool stream3_supports(const Params &p);        // conv_stream.hip: the row-streaming 3x3 kernel for 64 -> 64 channels (variant 9)
@@ -672,6 +673,7 @@ static int choose_tile(const Params &p, bool fast, bool bf16) {
     static const int env_tail = getenv("MHE_CONV_TAIL") ? atoi(getenv("MHE_CONV_TAIL")) : 1;
     if (bf16 && (force == 10 || (force < 0 && env_tail)) && tail_supports(p)) return 10;
     if ((force & 15) == 7 && bf16 && p8_supports(p)) return 7;      // (higher bits: ablation builds of tuning runs)
+    if (force == 13 && bf16 && p8_supports(p)) return 13;
     // dual-input load + data-gradient epilogue: instantiated on the 128-row tiles only - a forced 256-row tile (descriptor or
     // MHE_CONV_TILE) must not fall through to the plain dual-input kernel, which has no gate / BatchNorm-reverse sums
     if (p.x2 && p.mask) return force == 0 ? 0 : 1;
@@ -688,6 +690,14 @@ static int choose_tile(const Params &p, bool fast, bool bf16) {
         if (p.x2) return 1;
         if (tiles >= 192) return p8_supports(p) && force < 0 ? 7 : 2;
     }
+    // 3x3 layers with too few pixels for 256-channel tiles (layer4's conv2 and their data gradients: 16k pixels x 512 channels = 128 tiles
+    // of 256 x 256): the phase-pipelined kernel on a 256 x 128 tile, one per CU - 78 us against 93 on the 128 x 128 tile at C2.  Long
+    // K loops only: at 128 channels (layer2's conv2: 1024 tiles of 18 K tiles, one workgroup per CU) the tile's prologue and epilogue
+    // are not covered and the register-staged 128 x 128 tile with two workgroups per CU stays ahead (107 us against 117; tools/conv_variants.py)
+    static const int env_p8h = getenv("MHE_CONV_P8H") ? atoi(getenv("MHE_CONV_P8H")) : 1;
+    if (fast && bf16 && env_p8h && force < 0 && !p.x2 && p.KH * p.KW > 1 && p.KH * p.KW * p.Cin >= 2304 && p.Cout % 128 == 0 && p8_supports(p) &&
+        (long)((p.M + 255) / 256) * (p.Cout / 128) >= 192)
+        return 13;
     return 1;
 }
 
@@ -702,6 +712,7 @@ static int launch_conv(const Params &p, hipStream_t s) {
         if (t0 == 10) return launch_tail(p, s);
         if (t0 == 11) return launch_wide(p, s);
         if (t0 == 7) return launch_p8(p, s);
+        if (t0 == 13) return launch_p8h(p, s);
     }
     if (p.x2 && !fast) { set_error("residual-tail prologue needs Cin %% %d == 0", BKE); return MHE_ERR_ARG; }
     // the LDS-DMA kernel measures equal to the register-staged one (see its header): opt-in, bit 0 = 256x256, bit 1 = 128x128

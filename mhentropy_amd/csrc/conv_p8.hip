@@ -56,6 +56,19 @@ constexpr int P8_STAGE = 65536;      // per stage: A0 at 0, B0 at 16384, B1 at 3
     "ds_read_b128 %[a20], %[ra0] offset:53248\n\tds_read_b128 %[a30], %[ra0] offset:55296\n\t"         \
     "ds_read_b128 %[a01], %[ra1] offset:49152\n\tds_read_b128 %[a11], %[ra1] offset:51200\n\t"         \
     "ds_read_b128 %[a21], %[ra1] offset:53248\n\tds_read_b128 %[a31], %[ra1] offset:55296\n\t"
+// 256 x 128 form (NBH = 1): the wave columns are 32 channels wide, B0 holds all 128 channel rows, there is no B1: phase 1 reads A0 + B0
+// (12 fragments) for 16 MFMAs, phase 2 reads A1 (8) for 16; six 1 KiB DMA pieces per wave and K tile instead of eight -> vmcnt(6)
+#define P8_WAIT6 "s_waitcnt vmcnt(6) lgkmcnt(0)"
+#define P8_RD_1H                                                                                      \
+    "ds_read_b128 %[a00], %[ra0]\n\tds_read_b128 %[c00], %[rb0] offset:16384\n\t"                      \
+    "ds_read_b128 %[a10], %[ra0] offset:2048\n\tds_read_b128 %[c10], %[rb0] offset:18432\n\t"          \
+    "ds_read_b128 %[a20], %[ra0] offset:4096\n\tds_read_b128 %[a30], %[ra0] offset:6144\n\t"           \
+    "ds_read_b128 %[a01], %[ra1]\n\tds_read_b128 %[c01], %[rb1] offset:16384\n\t"                      \
+    "ds_read_b128 %[a11], %[ra1] offset:2048\n\tds_read_b128 %[c11], %[rb1] offset:18432\n\t"          \
+    "ds_read_b128 %[a21], %[ra1] offset:4096\n\tds_read_b128 %[a31], %[ra1] offset:6144\n\t"
+#define P8_DMA_2H "s_mov_b32 %[keep], m0\n\t" P8_PIECE(v0, rs, 0) P8_PIECE(v1, rs, 1024) P8_PIECE(v2, rw, 16384) P8_PIECE(v3, rw, 17408) \
+                  "s_mov_b32 m0, %[keep]\n\t"
+#define P8_OUT_BH [c00] "=&v"(fb0[0][0]), [c01] "=&v"(fb0[0][1]), [c10] "=&v"(fb0[1][0]), [c11] "=&v"(fb0[1][1])
 #define P8_DMA_1 "s_mov_b32 %[keep], m0\n\t" P8_PIECE(v0, rs, 49152) P8_PIECE(v1, rs, 50176) "s_mov_b32 m0, %[keep]\n\t"
 #define P8_DMA_2 "s_mov_b32 %[keep], m0\n\t" P8_PIECE(v0, rs, 0) P8_PIECE(v1, rs, 1024) P8_PIECE(v2, rw, 16384) P8_PIECE(v3, rw, 17408) \
                  P8_PIECE(v4, rw, 32768) P8_PIECE(v5, rw, 33792) "s_mov_b32 m0, %[keep]\n\t"
@@ -89,6 +102,45 @@ __device__ __forceinline__ void p8_load_2(u4 (&fa)[4][2], unsigned ra0, unsigned
     else asm volatile(P8_WAIT : P8_OUT_A, [keep] "=&s"(keep) : P8_INS : "memory");
 #undef P8_INS
 }
+// the 256 x 128 form's load parts
+__device__ __forceinline__ void p8h_load_1(u4 (&fa)[4][2], u4 (&fb0)[2][2], unsigned ra0, unsigned ra1, unsigned rb0, unsigned rb1, unsigned v0, unsigned v1,
+                                           u4 rs, unsigned lb) {
+    unsigned keep;
+    asm volatile(P8_RD_1H P8_DMA_1 P8_WAIT6 : P8_OUT_A, P8_OUT_BH, [keep] "=&s"(keep)
+                 : [ra0] "v"(ra0), [ra1] "v"(ra1), [rb0] "v"(rb0), [rb1] "v"(rb1), [v0] "v"(v0), [v1] "v"(v1), [rs] "s"(rs), [lb] "s"(lb) : "memory");
+}
+__device__ __forceinline__ void p8h_load_2(u4 (&fa)[4][2], unsigned ra0, unsigned ra1, unsigned v0, unsigned v1, unsigned v2, unsigned v3, u4 rs, u4 rw,
+                                           unsigned lb) {
+    unsigned keep;
+    asm volatile(P8_RD_2 P8_DMA_2H P8_WAIT6 : P8_OUT_A, [keep] "=&s"(keep)
+                 : [ra0] "v"(ra0), [ra1] "v"(ra1), [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3), [rs] "s"(rs), [rw] "s"(rw), [lb] "s"(lb) : "memory");
+}
+__device__ __forceinline__ void p8h_issue_2(unsigned v0, unsigned v1, unsigned v2, unsigned v3, u4 rs, u4 rw, unsigned lb) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\t" P8_DMA_2H "s_nop 0" : [keep] "=&s"(keep)
+                 : [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3), [rs] "s"(rs), [rw] "s"(rw), [lb] "s"(lb) : "memory");
+}
+// 16 MFMAs of one phase of the 256 x 128 form: pixel tiles 4*HA + {0..3} against this wave's two channel tiles, both k-steps
+template <int HA>
+__device__ __forceinline__ void p8h_mfma(v4f (&acc)[2][8], const u4 (&fa)[4][2], const u4 (&fb0)[2][2], int wr) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                acc[nt][4 * HA + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, fb0[nt][kk]), __builtin_bit_cast(bf8, fa[mt][kk]),
+                                                                               acc[nt][4 * HA + mt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!wr) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // prologue pieces: issue only
 __device__ __forceinline__ void p8_issue_1(unsigned v0, unsigned v1, u4 rs, unsigned lb) {
     unsigned keep;
@@ -150,7 +202,9 @@ struct P8Kpos {
     __device__ __forceinline__ unsigned aoff(const Params &p) const { return (unsigned)(((kh * p.W + kw) * p.Cin + c0) * 2); }
 };
 
-template <bool DG, bool TAPS, int ABL = 0>
+// NBH = B half-tiles per K tile: 2 = the 256 x 256 tile; 1 = a 256 x 128 tile (round 3: the 3x3 layers with 128 output channels and the
+// 512-channel ones of layer4, whose 16k pixels make only 128 tiles of 256 x 256 - see the macros above)
+template <bool DG, bool TAPS, int ABL = 0, int NBH = 2>
 __global__ __launch_bounds__(512) void conv_p8_kernel(const Params p) {
     using T = u16;
     __shared__ uint4 lds[2 * P8_STAGE / 16];          // 128 KiB: the two-stage ring, then the epilogue's staging
@@ -161,7 +215,7 @@ __global__ __launch_bounds__(512) void conv_p8_kernel(const Params p) {
     const int wr = wave >> 2, wc = wave & 3;
     int mtile, ntile;
     tile_of_block(mtile, ntile);
-    const int m0 = mtile * 256, n0 = ntile * 256;
+    const int m0 = mtile * 256, n0 = ntile * (128 * NBH);
     const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char *)lds);
 
     // ---- DMA role of this lane.  Wave-instruction i (0/1) of wave w fills the 1 KiB piece 2w+i of a half-tile: LDS rows
@@ -194,7 +248,7 @@ __global__ __launch_bounds__(512) void conv_p8_kernel(const Params p) {
             msk[h][i] = bits;
             const unsigned off = (unsigned)((((b * p.H + hi0) * p.W + wi0) * p.Cin) * 2) + lc * 16u;
             xo[h][i] = (TAPS || mv) ? off : P8_OOB;
-            const int n = n0 + (rho >> 5) * 64 + h * 32 + (rho & 31);
+            const int n = NBH == 2 ? n0 + (rho >> 5) * 64 + h * 32 + (rho & 31) : n0 + rho;      // (NBH = 1: B0 row = channel, h = 1 unused)
             wo[h][i] = n < p.Cout ? (unsigned)n * (unsigned)p.Kpad * 2u + lc * 16u : P8_OOB;
         }
     }
@@ -219,19 +273,20 @@ __global__ __launch_bounds__(512) void conv_p8_kernel(const Params p) {
         v0 = wo[h][0] + so; v1 = wo[h][1] + so;
     };
     auto stage_of = [&](int u) { return ldst + (unsigned)((u & 1) * P8_STAGE); };
-    auto issue_x = [&](int u, const P8Kpos &kp) {          // A0, B0, B1 of K tile u
+    auto issue_x = [&](int u, const P8Kpos &kp) {          // A0, B0 (, B1) of K tile u
         unsigned v0, v1, v2, v3, v4, v5;
-        a_offs(0, u, kp, v0, v1); b_offs(0, u, v2, v3); b_offs(1, u, v4, v5);
-        p8_issue_2(v0, v1, v2, v3, v4, v5, rsx, rsw, stage_of(u));
+        a_offs(0, u, kp, v0, v1); b_offs(0, u, v2, v3);
+        if constexpr (NBH == 2) { b_offs(1, u, v4, v5); p8_issue_2(v0, v1, v2, v3, v4, v5, rsx, rsw, stage_of(u)); }
+        else p8h_issue_2(v0, v1, v2, v3, rsx, rsw, stage_of(u));
     };
 
     // ---- fragment read addresses: tile row l15 of a 16-row tile, logical chunk 4kk+q -> physical (4kk+q) ^ (l15>>1)
     const unsigned sw0 = (unsigned)((q ^ (l15 >> 1)) * 16), sw1 = (unsigned)(((4 + q) ^ (l15 >> 1)) * 16);
     const unsigned fa_row = lds_base + (unsigned)(wr * 64 + l15) * 128u, fb_row = lds_base + (unsigned)(wc * 32 + l15) * 128u;
 
-    v4f acc[4][8];
+    v4f acc[2 * NBH][8];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 2 * NBH; ++a)
 #pragma unroll
         for (int b = 0; b < 8; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
     u4 fa[4][2], fb0[2][2], fb1[2][2];
@@ -248,24 +303,40 @@ __global__ __launch_bounds__(512) void conv_p8_kernel(const Params p) {
     issue_x(1, k1);
     P8Kpos k2 = k1;                   // position of K tile t+2
     k2.next(p);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (NBH == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // 4 + 2 + 4 pieces issued: K tile 0's A0 / B0 have landed
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
     for (int t = 0; t < nk; ++t) {
         const unsigned st = (unsigned)((t & 1) * P8_STAGE);
         const unsigned ra0 = fa_row + st + sw0, ra1 = fa_row + st + sw1, rb0 = fb_row + st + sw0, rb1 = fb_row + st + sw1;
-        {   // phase 1: quadrants (A0, B0), (A0, B1); prefetch A1 of tile t+1
-            unsigned v0, v1;
-            a_offs(1, t + 1, k1, v0, v1);
-            p8_load_1<ABL>(fa, fb0, fb1, ra0, ra1, rb0, rb1, v0, v1, rsx, stage_of(t + 1));
-            p8_mfma<0, ABL>(acc, fa, fb0, fb1, wr);
-        }
-        {   // phase 2: quadrants (A1, B1), (A1, B0); prefetch A0, B0, B1 of tile t+2
-            unsigned v0, v1, v2, v3, v4, v5;
-            a_offs(0, t + 2, k2, v0, v1); b_offs(0, t + 2, v2, v3); b_offs(1, t + 2, v4, v5);
-            p8_load_2<ABL>(fa, ra0, ra1, v0, v1, v2, v3, v4, v5, rsx, rsw, stage_of(t + 2));
-            p8_mfma<1, ABL>(acc, fa, fb0, fb1, wr);
+        if constexpr (NBH == 2) {
+            {   // phase 1: quadrants (A0, B0), (A0, B1); prefetch A1 of tile t+1
+                unsigned v0, v1;
+                a_offs(1, t + 1, k1, v0, v1);
+                p8_load_1<ABL>(fa, fb0, fb1, ra0, ra1, rb0, rb1, v0, v1, rsx, stage_of(t + 1));
+                p8_mfma<0, ABL>(acc, fa, fb0, fb1, wr);
+            }
+            {   // phase 2: quadrants (A1, B1), (A1, B0); prefetch A0, B0, B1 of tile t+2
+                unsigned v0, v1, v2, v3, v4, v5;
+                a_offs(0, t + 2, k2, v0, v1); b_offs(0, t + 2, v2, v3); b_offs(1, t + 2, v4, v5);
+                p8_load_2<ABL>(fa, ra0, ra1, v0, v1, v2, v3, v4, v5, rsx, rsw, stage_of(t + 2));
+                p8_mfma<1, ABL>(acc, fa, fb0, fb1, wr);
+            }
+        } else {
+            {   // phase 1: (A0, B0); prefetch A1 of tile t+1
+                unsigned v0, v1;
+                a_offs(1, t + 1, k1, v0, v1);
+                p8h_load_1(fa, fb0, ra0, ra1, rb0, rb1, v0, v1, rsx, stage_of(t + 1));
+                p8h_mfma<0>(acc, fa, fb0, wr);
+            }
+            {   // phase 2: (A1, B0); prefetch A0, B0 of tile t+2
+                unsigned v0, v1, v2, v3;
+                a_offs(0, t + 2, k2, v0, v1); b_offs(0, t + 2, v2, v3);
+                p8h_load_2(fa, ra0, ra1, v0, v1, v2, v3, rsx, rsw, stage_of(t + 2));
+                p8h_mfma<1>(acc, fa, fb0, wr);
+            }
         }
         k1 = k2;
         k2.next(p);
@@ -274,18 +345,32 @@ __global__ __launch_bounds__(512) void conv_p8_kernel(const Params p) {
     __syncthreads();
     if constexpr (ABL & 8) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 2 * NBH; ++a)
 #pragma unroll
             for (int b = 0; b < 8; ++b) asm volatile("" :: "v"(acc[a][b]));
         return;
     }
-    epilogue<T, 256, 256, 2, 4, DG>(p, acc, lds, mtile % NSH, n0, [&](int row) { return out_pixel(p, m0 + row); });
+    epilogue<T, 256, 128 * NBH, 2, 4, DG>(p, acc, lds, mtile % NSH, n0, [&](int row) { return out_pixel(p, m0 + row); });
 }
 
 // the geometry this kernel takes: bf16, Cin a multiple of the 64-deep K tile, at most 32 taps, operands below 2 GiB
 bool p8_supports(const Params &p) {
     return p.Cin % 64 == 0 && p.KH * p.KW <= 32 && !p.in_scale && !p.x2 &&
            (size_t)p.B * p.H * p.W * p.Cin * 2 < 0x7fff0000ull && (size_t)p.Cout * p.Kpad * 2 < 0x7fff0000ull;
+}
+
+// the 256 x 128 form (variant 13)
+int launch_p8h(const Params &p, hipStream_t s) {
+    const dim3 grid((p.M + 255) / 256, (p.Cout + 127) / 128), block(512);
+    const bool taps = !(p.KH == 1 && p.KW == 1 && p.pad == 0);
+    if (p.mask) {
+        if (taps) hipLaunchKernelGGL((conv_p8_kernel<true, true, 0, 1>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((conv_p8_kernel<true, false, 0, 1>), grid, block, 0, s, p);
+    } else {
+        if (taps) hipLaunchKernelGGL((conv_p8_kernel<false, true, 0, 1>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((conv_p8_kernel<false, false, 0, 1>), grid, block, 0, s, p);
+    }
+    return check_launch("conv_p8_kernel<256x128>");
 }
 
 int launch_p8(const Params &p, hipStream_t s) {

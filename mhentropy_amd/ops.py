@@ -60,8 +60,10 @@ def _conv_kernel_name(d, dt, mode):
         return "mhe::conv::conv3x3_c64_stream_kernel<%s, false>" % ("true" if mode == 1 else "false")
     if tile == 8:
         return "mhe::conv::conv1x1_stream_kernel<%d, %d, %s, false>" % (d.Cin // 64, 256 if d.Cin <= 128 else 128, "true" if mode == 1 else "false")
+    if tile == 13:
+        return "mhe::conv::conv_p8_kernel<false, %s, 0, 1>" % ("false" if d.KH == 1 and d.KW == 1 and d.pad == 0 else "true")
     if tile == 7:
-        return "mhe::conv::conv_p8_kernel<false, %s, 0>" % ("false" if d.KH == 1 and d.KW == 1 and d.pad == 0 else "true")
+        return "mhe::conv::conv_p8_kernel<false, %s, 0, 2>" % ("false" if d.KH == 1 and d.KW == 1 and d.pad == 0 else "true")
     return "mhe::conv::conv_kernel<%s, %s, %s, %d, false>" % ("float" if dt == torch.float32 else "unsigned short",
                                                              _TILES[tile],
                                                              "true" if d.Cin % bke == 0 else "false", mode)

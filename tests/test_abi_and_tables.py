@@ -129,7 +129,9 @@ def test_launcher_picks_the_documented_kernel_variants_at_c2():
     assert pick(16, 1024, 256, 1, mode=2) == 10 and pick(8, 2048, 512, 1, mode=2) == 10      # residual tails of layer3 / layer4
     assert pick(32, 512, 256, 1, mode=2) == 10 and pick(16, 1024, 512, 1, mode=2) == 10      # ... and the transitions into them
     assert pick(64, 256, 64, 1, mode=2) == 0 and pick(32, 512, 128, 1, mode=2) == 1          # layer1 / layer2 tails: register-staged tiles
-    assert pick(16, 256, 256, 3) == 7 and pick(32, 128, 128, 3) == 1              # 3x3: phase-pipelined from 256 channels, 128x128 below
+    assert pick(16, 256, 256, 3) == 7                                             # 3x3: phase-pipelined 256x256 where its tiles fill the chip
+    assert pick(8, 512, 512, 3) == 13 and pick(16, 512, 512, 3, stride=2) == 13   # ... layer4 (16k pixels): the same kernel on 256x128 tiles
+    assert pick(32, 128, 128, 3) == 1                                             # layer2 (K = 1152): register-staged 128x128, two workgroups per CU
     # small batches fall back to the tiled kernels (the streaming / transfer-wave kernels want whole persistent workgroups)
     assert ops.conv_tile_choice(4, 16, 16, 256, 1024, 1, 1, 0, bf, 0) not in (8, 9, 10, 11)
 

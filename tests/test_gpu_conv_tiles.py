@@ -18,7 +18,7 @@ TOL = 6e-3                       # bf16 output rounding (2^-9) relative to the t
 
 # variant id -> (name, supports the producer-BatchNorm / residual-tail operand loads)
 VARIANTS = {2: ("256x256", True), 3: ("256x128", True), 4: ("256x64", True), 5: ("dma 256x256", False),
-            6: ("dma 128x128", False), 7: ("8-phase 256x256", False)}
+            6: ("dma 128x128", False), 7: ("8-phase 256x256", False), 13: ("8-phase 256x128", False)}
 # B, H, W, Cin, Cout, k, stride, pad
 SHAPES = [
     (2, 24, 20, 64, 256, 1, 1, 0),      # K = a single 64-deep stage, partial M tile
@@ -80,7 +80,7 @@ def test_forced_variant_matches_torch(gpu_lib, variant, shape):
 
 @pytest.mark.parametrize("shape", [(2, 24, 20, 256, 256, 1, 1, 0), (3, 20, 20, 128, 320, 3, 1, 1), (5, 16, 16, 256, 256, 3, 1, 1)],
                          ids=lambda s: "x".join(map(str, s)))
-@pytest.mark.parametrize("variant", [1, 2, 7], ids=lambda v: {1: "128x128"}.get(v, VARIANTS.get(v, ("",))[0]).replace(" ", "-"))
+@pytest.mark.parametrize("variant", [1, 2, 7, 13], ids=lambda v: {1: "128x128"}.get(v, VARIANTS.get(v, ("",))[0]).replace(" ", "-"))
 def test_data_gradient_form_gate_and_bn_sums(gpu_lib, variant, shape):
     """y = (conv + residual) [mask > 0] and, for two BatchNorm units fed by y, sum y and sum y (bn_y - mean) invstd
     (mhe_conv2d_masked_nhwc) against the same quantities from torch; reference hand/CrossModalHand.py:455-470 (backward)."""
@@ -176,15 +176,18 @@ def test_residual_tail_kernel_with_transfer_waves(gpu_lib, geom, affine2):
     assert torch.equal(y2, y)
 
 
-@pytest.mark.parametrize("shape", [(12, 64, 64, 64, 256, 1, 1, 0), (192, 16, 16, 256, 256, 3, 1, 1), (48, 32, 32, 128, 512, 1, 1, 0)],
+@pytest.mark.parametrize("shape", [(12, 64, 64, 64, 256, 1, 1, 0), (192, 16, 16, 256, 256, 3, 1, 1), (48, 32, 32, 128, 512, 1, 1, 0),
+                                   (192, 8, 8, 512, 512, 3, 1, 1), (192, 16, 16, 512, 512, 3, 2, 1)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_launcher_selected_large_tile_matches_torch(gpu_lib, shape):
-    """shapes big enough (>= 192 output tiles) that the launcher itself takes a 256x256 variant, as at the bench batch"""
+    """shapes big enough (>= 192 output tiles) that the launcher itself takes a 256-row variant, as at the bench batch: 256x256 (2, 7) or,
+    for the 3x3 layers with 128 output channels / too few pixels for 256-channel tiles, the phase-pipelined kernel on 256x128 (13)"""
     from mhentropy_amd import ops, resnet, _lib
     import ctypes as C
     B, H, W, Cin, Cout, k, stride, pad = shape
     d = _lib.ConvDesc(B, H, W, Cin, Cout, k, k, stride, pad, ops.BF16, 0, 0, 0)
-    assert _lib.lib().mhe_conv_tile(C.byref(d)) in (2, 7), "expected one of the 256x256 variants for this geometry"
+    want = (13,) if (k == 3 and B * H * W // (stride * stride) < 49152) else (2, 7)
+    assert _lib.lib().mhe_conv_tile(C.byref(d)) in want, f"expected variant {want} for this geometry, got {_lib.lib().mhe_conv_tile(C.byref(d))}"
     g, x, w = _operands(Cin + Cout, B, H, W, Cin, Cout, k)
     ref = F.conv2d(x, w, None, stride, pad)              # f32 on the bf16-rounded operands (29 GMAC at the 3x3 shape)
     stats = torch.zeros(ops.stat_shards(), 2, Cout, device="cuda")
