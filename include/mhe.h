@@ -327,6 +327,15 @@ int mhe_conv1x1_residual_in_nhwc(const mhe_conv_desc *d, const void *x, const vo
 int mhe_stem_conv7x7s2(const float *x_nchw, const void *w, void *y, float *stats, int B, int H, int W, int dtype,
                        void *stream);
 
+/* The stem for the forward-only path (bf16, 256 x 256 images): conv1 + batch statistics + the 3x3 / stride-2 / pad-1 max pool in one kernel.
+ * pooled [B,64,64,64] receives, per channel, the window MAXIMUM (bn_gamma[c] >= 0) or MINIMUM (bn_gamma[c] < 0) of the raw bf16-rounded conv1
+ * outputs: relu(scale*y + shift) is monotone in y and sign(scale) = sign(gamma), so maxpool(relu(bn1(conv1(x)))) (torchvision ResNet's
+ * stem, hand/network.py:54-61,110) = relu(scale * pooled + shift), which the consumers apply on their operand load once the statistics
+ * (stats, as in mhe_stem_conv7x7s2) are finalised.  The full-resolution output is never written. */
+int mhe_stem_pool_supported(int B, int H, int W, int dtype);
+int mhe_stem_conv7x7s2_pool(const float *x_nchw, const void *w, const float *bn_gamma, void *pooled, float *stats, int B, int H, int W,
+                            void *stream);
+
 /* BatchNorm batch statistics (the sharded accumulators of mhe_conv2d_nhwc, summed in f64)
  * -> affine (train mode), torch semantics
  * (momentum 0.1, eps 1e-5, unbiased running_var):

@@ -101,6 +101,8 @@ SIGNATURES = {
     "mhe_gram_bn_finalize": (_i, [_p] * 10 + [_i, _i, _f, _f, _f, _p, _p]),
     "mhe_bottleneck_tail_supported": (_i, [_p, _i]),
     "mhe_bottleneck_tail_nhwc": (_i, [_p, _i] + [_p] * 14),
+    "mhe_stem_pool_supported": (_i, [_i, _i, _i, _i]),
+    "mhe_stem_conv7x7s2_pool": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "mhe_bn_finalize": (_i, [_p] * 8 + [_i, _f, _f, _f, _p]),
     "mhe_bn_finalize_step": (_i, [_p] * 8 + [_i, _f, _f, _f, _i, _p, _p]),
     "mhe_bn_act_nhwc": (_i, [_p] * 7 + [_l, _i, _i, _i, _p]),

@@ -547,6 +547,30 @@ def stem_conv7x7s2(x, w, dtype, stats=None):
     return y
 
 
+def stem_pool_supported(B, H, W, dtype):
+    return bool(_lib.lib().mhe_stem_pool_supported(B, H, W, dtype_code(dtype)))
+
+
+def stem_conv7x7s2_pool(x, w, bn_gamma, stats=None):
+    """x [B,3,256,256] f32 NCHW -> pooled [B,64,64,64] bf16: per channel the 3x3 / stride-2 window max (gamma >= 0) or min (gamma < 0) of the raw
+    conv1 output; relu(scale * pooled + shift) = maxpool(relu(bn1(conv1(x)))) (mhe_stem_conv7x7s2_pool).  stats: conv1's batch statistics."""
+    B, Cn, H, W = x.shape
+    _chk(x, torch.float32, "stem_pool.x"); _chk(w, torch.bfloat16, "stem_pool.w", (64, 192)); _chk(bn_gamma, torch.float32, "stem_pool.gamma", (64,))
+    if Cn != 3:
+        raise _lib.MheError("stem_pool.x: expected 3 input channels")
+    if stats is not None:
+        _chk(stats, torch.float32, "stem_pool.stats", (stat_shards(), 2, 64))
+    y = torch.empty(B, 64, 64, 64, device=x.device, dtype=torch.bfloat16)
+    if TIMING:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(_lib.lib().mhe_stem_conv7x7s2_pool(_ptr(x), _ptr(w), _ptr(bn_gamma), _ptr(y), _ptr(stats), B, H, W, _stream()), "mhe_stem_conv7x7s2_pool")
+    if TIMING:
+        ev1.record()
+        KERNEL_TIMES.append(("mhe::conv::stem_pool_kernel", 2.0 * B * 128 * 128 * 64 * 147, ev0, ev1, 4 * x.numel() + 2 * y.numel()))
+    return y
+
+
 def bn_finalize(stats, gamma, beta, running_mean, running_var, count, momentum=0.1, eps=1e-5, want_mean_invstd=False, clear=False,
                 num_batches_tracked=None):
     """clear: the accumulators are zeroed once read (self-cleaning arena); num_batches_tracked (int64 scalar on the device): += 1"""

@@ -101,6 +101,9 @@ class ResNetTrunk(nn.Module):
         # bn3's batch statistics for those blocks: "gram" = from the Gram matrix of conv3's input (csrc/conv_gram.hip: the product is not
         # evaluated at all), "stream" = the statistics-only launch of the streaming kernel (evaluates, rounds and sums the product)
         self.recompute_stats = os.environ.get("MHE_RECOMPUTE_STATS", "gram")
+        # the stem's max pool taken inside the conv1 kernel on the raw output (bf16, 256x256 images; csrc/stem_pool.hip): the
+        # full-resolution conv1 output is never written, layer1.0's conv1 / shortcut apply bn1 + ReLU on their operand load
+        self.stem_pool_fused = os.environ.get("MHE_STEM_POOL", "1") == "1"
 
     # -- packed-weight cache keyed on the parameter's version counter
     def _w(self, conv, cin_pad=None, stem=False):
@@ -143,10 +146,16 @@ class ResNetTrunk(nn.Module):
             self._external_sync()             # trainer-owned operand packs follow the parameters (optimizer.step, load_state_dict)
         pool = self._stats_pool(x.device) if self.training else None
         st = pool.take(64) if self.training else None
-        y = ops.stem_conv7x7s2(x.contiguous(), self._w(self.conv1, stem=True), dt, stats=st)      # reads the NCHW image directly
-        aff = self._bn_affine(y, self.bn1, st)
-        a = ops.maxpool3x3s2(y, aff[0], aff[1])
         blocks = [blk for li in range(4) for blk in getattr(self, f"layer{li + 1}")]
+        a_aff = None            # BatchNorm + ReLU still to be applied to `a` by its consumers (the fused stem leaves the pooled RAW output)
+        if (self.stem_pool_fused and blocks[0].kind == "bottleneck" and blocks[0].downsample is not None
+                and ops.stem_pool_supported(x.shape[0], x.shape[2], x.shape[3], dt)):
+            a = ops.stem_conv7x7s2_pool(x.contiguous(), self._w(self.conv1, stem=True), self.bn1.weight.detach(), stats=st)
+            a_aff = self._bn_affine(None, self.bn1, st, count=x.shape[0] * 128 * 128)
+        else:
+            y = ops.stem_conv7x7s2(x.contiguous(), self._w(self.conv1, stem=True), dt, stats=st)      # reads the NCHW image directly
+            aff = self._bn_affine(y, self.bn1, st)
+            a = ops.maxpool3x3s2(y, aff[0], aff[1])
         pending = None          # (raw conv3 output, bn3 affine, identity tensor, identity affine | None): an unevaluated block tail
         for bi, blk in enumerate(blocks):
             if blk.kind == "bottleneck":
@@ -169,7 +178,7 @@ class ResNetTrunk(nn.Module):
                     a1 = self._bn_affine(y1, blk.bn1, st)
                     pending = None
                 else:
-                    y1, a1 = self._conv_bn(a, blk.conv1, blk.bn1, pool)
+                    y1, a1 = self._conv_bn(a, blk.conv1, blk.bn1, pool, a_aff, apply="load")
                 # 3x3 consumer: in place, except where the row-streaming kernel runs (layer1 at C2) - it normalises each input row once on
                 # its way into LDS (95 us against 56 + 77 us for the pass and the plain form)
                 ap2 = "load" if self.bn_apply_3x3 == "auto" and ops.conv_tile_choice(
@@ -201,7 +210,8 @@ class ResNetTrunk(nn.Module):
                 y1, a1 = self._conv_bn(a, blk.conv1, blk.bn1, pool, None, blk.stride, 1, 3)
                 yl, al = self._conv_bn(y1, blk.conv2, blk.bn2, pool, a1, 1, 1, 3)
             if blk.downsample is not None:
-                idt, idaff = self._conv_bn(a, blk.downsample[0], blk.downsample[1], pool, None, blk.stride, 0, 1)
+                idt, idaff = self._conv_bn(a, blk.downsample[0], blk.downsample[1], pool, a_aff, blk.stride, 0, 1, apply="load")
+                a_aff = None        # (only the first block sees the un-normalised pooled stem output)
             else:
                 idt, idaff = a, None
             nxt = blocks[bi + 1] if bi + 1 < len(blocks) else None

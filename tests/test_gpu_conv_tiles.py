@@ -540,3 +540,35 @@ def test_gram_statistics_give_the_convolutions_batchnorm_affine(gpu_lib, geom):
     sc2, sh2 = ops.bn_finalize(st, gamma.cuda(), beta.cuda(), None, None, float(P))
     assert_close(sc.cpu(), sc2.cpu(), 2e-3, what="scale vs statistics-only launch")
     assert_close(sh.cpu(), sh2.cpu(), 2e-3, 1e-4, what="shift vs statistics-only launch")
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_stem_with_the_max_pool_inside(gpu_lib, B):
+    """csrc/stem_pool.hip: conv1 + batch statistics + 3x3 / stride-2 max pool of the RAW output in one kernel (per channel the window
+    maximum where gamma >= 0, the minimum where gamma < 0) against the two-kernel path's tensors: the raw conv1 output of
+    mhe_stem_conv7x7s2 pooled by torch (bit-identical values), its statistics, and maxpool(relu(bn(y))) = relu(scale * pooled + shift)"""
+    from mhentropy_amd import ops, resnet
+    g = torch.Generator().manual_seed(11 + B)
+    x = torch.randn(B, 3, 256, 256, generator=g).cuda()
+    w = (torch.randn(64, 3, 7, 7, generator=g) * 0.1)
+    wd = resnet.pack_stem_weight(w, torch.bfloat16).cuda()
+    gamma = torch.randn(64, generator=g)
+    gamma[::5] = -gamma[::5].abs()                                 # negative scales: window minimum
+    gamma[7] = 0.0
+    S = ops.stat_shards()
+    st_ref, st = torch.zeros(S, 2, 64, device="cuda"), torch.zeros(S, 2, 64, device="cuda")
+    y = ops.stem_conv7x7s2(x, wd, torch.bfloat16, stats=st_ref)           # [B,128,128,64] raw
+    assert ops.stem_pool_supported(B, 256, 256, torch.bfloat16) and not ops.stem_pool_supported(B, 128, 128, torch.bfloat16)
+    p = ops.stem_conv7x7s2_pool(x, wd, gamma.cuda(), stats=st)
+    torch.cuda.synchronize()
+    yn = y.float().permute(0, 3, 1, 2)
+    pmax = F.max_pool2d(yn, 3, 2, 1)
+    pmin = -F.max_pool2d(-yn, 3, 2, 1)
+    want = torch.where((gamma.cuda() >= 0)[None, :, None, None], pmax, pmin).permute(0, 2, 3, 1).contiguous().bfloat16()
+    assert torch.equal(p, want), f"pooled raw output differs on {(p != want).float().mean().item():.2e} of the elements"
+    assert_close(st.double().sum(0).cpu(), st_ref.double().sum(0).cpu(), 1e-6, what="conv1 batch statistics")
+    # ... and the identity the consumers rely on
+    sc, sh = gamma.cuda() * 0.7, torch.randn(64, generator=g).cuda()
+    a_ref = F.max_pool2d(F.relu(yn * sc[None, :, None, None] + sh[None, :, None, None]), 3, 2, 1)
+    a_new = F.relu(p.float().permute(0, 3, 1, 2) * sc[None, :, None, None] + sh[None, :, None, None])
+    assert torch.equal(a_new, a_ref)

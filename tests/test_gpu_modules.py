@@ -417,3 +417,28 @@ def test_trunk_with_conv3_reevaluated_equals_the_stored_form(gpu_lib, training, 
     tol = 1e-5 if stats == "stream" else 5e-4               # the first bn3 of the trunk: nothing upstream differs yet
     assert_close(rv1, rv0, tol, what="bn3 running_var")
     assert_close(rm1, rm0, tol, 1e-6, what="bn3 running_mean")
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_trunk_with_the_pool_inside_the_stem_equals_the_two_kernel_stem(gpu_lib, training):
+    """MHE_STEM_POOL (csrc/stem_pool.hip; bf16, 256x256 images): layer1.0's conv1 / shortcut read the pooled RAW conv1 output with bn1 + ReLU
+    on their operand load - the same values as stem -> bn1 -> relu -> maxpool (hand/network.py:54-61,110), so eval mode agrees to the last
+    bit of the feature and train mode to the noise of the statistics' atomics (see the recompute test above for its amplification)"""
+    from mhentropy_amd import resnet
+    sd = {k: torch.as_tensor(v) for k, v in synth.resnet_state(8, "resnet50").items()}
+    sd["bn1.weight"] = sd["bn1.weight"].clone()
+    sd["bn1.weight"][::4] *= -1.0                                   # negative BatchNorm scales: the window minimum is the one that matters
+    x = torch.as_tensor(synth.batch(8, 4, image_size=256)[0]).cuda()
+    outs = []
+    for fused in (True, False):
+        trunk = resnet.ResNetTrunk("resnet50", compute_dtype=torch.bfloat16)
+        trunk.load_state_dict(sd)
+        trunk = trunk.cuda().train(training)
+        trunk.stem_pool_fused = fused
+        outs.append((trunk(x).float().cpu(), trunk.bn1.running_var.cpu().clone(), trunk.layer1[0].bn1.running_mean.cpu().clone()))
+    (f1, rv1, rm1), (f0, rv0, rm0) = outs
+    d = ((f1 - f0).abs().mean() / f0.abs().mean()).item()
+    print(f"trunk feature, pool inside the stem vs two kernels (training={training}): mean-rel {d:.2e}")
+    assert d < (2e-1 if training else 1e-6), d
+    assert_close(rv1, rv0, 1e-5, what="bn1 running_var")
+    assert_close(rm1, rm0, 1e-4, 1e-6, what="layer1.0.bn1 running_mean (first consumer of the pooled output)")
