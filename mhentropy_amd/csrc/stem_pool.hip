@@ -30,6 +30,24 @@ constexpr int SP_PSI = 3 * SP_ICOLS + 1;       // 784 elements per interleaved p
 constexpr int SP_PROWS = SP_IROWS + 1;         // + one zero row: the k-slots of the K padding (kh = 7) of the last conv row land there
 constexpr int SP_NV = (3 * SP_IROWS * (2 * SP_W / 4) + 511) / 512;     // float4 loads per thread and strip (9): 69 input rows x 64 float4
 constexpr int SP_RING = 4;
+// The ring holds the conv outputs as SORTABLE KEYS: bf16 bits (sign-flipped first where gamma < 0, so that the window maximum is always
+// the value wanted) mapped so that unsigned 16-bit order = float order (negative: all bits inverted, else: sign bit set).  The 3 x 3
+// window maximum is then nine packed v_pk_max_u16 per register pair instead of unpack + nine f32 max per element: the pooling phase was
+// a third of the kernel's VALU time.
+typedef float f2v __attribute__((ext_vector_type(2)));          // statistics as packed-f32 pairs (v_pk_add_f32 / v_pk_fma_f32)
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+typedef short ss2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned to_key(unsigned x) {
+    const unsigned neg = __builtin_bit_cast(unsigned, __builtin_bit_cast(ss2, x) >> (ss2){15, 15});     // 0xffff per negative half
+    return x ^ (neg | 0x80008000u);
+}
+__device__ __forceinline__ unsigned from_key(unsigned k) {
+    const unsigned pos = __builtin_bit_cast(unsigned, __builtin_bit_cast(ss2, k) >> (ss2){15, 15});     // 0xffff where the value was >= 0
+    return k ^ (~pos | 0x80008000u);
+}
+__device__ __forceinline__ unsigned max_key(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+}
 }
 
 __global__ __launch_bounds__(512) void stem_pool_kernel(const float *__restrict__ x, const u16 *__restrict__ wg, const float *__restrict__ gamma,
@@ -61,11 +79,20 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(const float *__restrict_
         const int r = i >> 4, e = i & 15;                      // elements 0..8 (columns -3..-1) and 777..783 (columns 256, 257 and the pad)
         patch[r * SP_PSI + (e < 9 ? e : 768 + e)] = 0;
     }
-    float ss1[4][4], ss2[4][4];
+    // sign masks of the channels this lane holds in the accumulator layout (16 nt + 4 q .. + 3)
+    unsigned sgl[4][2];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c0 = nt * 16 + 4 * q + 2 * h;
+            sgl[nt][h] = (gamma[c0] < 0.f ? 0x8000u : 0u) | (gamma[c0 + 1] < 0.f ? 0x80000000u : 0u);
+        }
+    f2v ss1[4][2], ss2[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) ss1[a][c] = ss2[a][c] = 0.f;
+        for (int c = 0; c < 2; ++c) { ss1[a][c] = f2v{0.f, 0.f}; ss2[a][c] = f2v{0.f, 0.f}; }
 
     // the patch's 3 x 23 input rows are whole image rows (256 contiguous floats): float4 load L = tid + 512 j covers row L / 64 (channel
     // row / 23, patch row row % 23), columns 4 (L % 64) .. + 3
@@ -131,22 +158,19 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(const float *__restrict_
                 uint2 o;
                 o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
                 o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-                *reinterpret_cast<uint2 *>(rb + (size_t)swz(px, chunk) * 16 + (q & 1) * 8) = o;
+                *reinterpret_cast<uint2 *>(rb + (size_t)swz(px, chunk) * 16 + (q & 1) * 8) = make_uint2(to_key(o.x ^ sgl[nt][0]), to_key(o.y ^ sgl[nt][1]));
                 if (own) {
-                    const float f0 = __uint_as_float(o.x << 16), f1 = __uint_as_float(o.x & 0xffff0000u);
-                    const float f2 = __uint_as_float(o.y << 16), f3 = __uint_as_float(o.y & 0xffff0000u);
-                    ss1[nt][0] += f0; ss1[nt][1] += f1; ss1[nt][2] += f2; ss1[nt][3] += f3;
-                    ss2[nt][0] = fmaf(f0, f0, ss2[nt][0]); ss2[nt][1] = fmaf(f1, f1, ss2[nt][1]);
-                    ss2[nt][2] = fmaf(f2, f2, ss2[nt][2]); ss2[nt][3] = fmaf(f3, f3, ss2[nt][3]);
+                    const f2v fa2 = {__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u)};
+                    const f2v fb2 = {__uint_as_float(o.y << 16), __uint_as_float(o.y & 0xffff0000u)};
+                    ss1[nt][0] += fa2; ss1[nt][1] += fb2;
+                    ss2[nt][0] = __builtin_elementwise_fma(fa2, fa2, ss2[nt][0]); ss2[nt][1] = __builtin_elementwise_fma(fb2, fb2, ss2[nt][1]);
                 }
             }
             __syncthreads();                               // row rho is in the ring (and the slot written next was last read two steps ago)
             if (rho >= 2 && (rho & 1) == 0) {
                 // pooled row i0 + rho / 2 - 1 from conv rows rho - 2, rho - 1, rho: columns 2 j - 1, 2 j, 2 j + 1 (column -1 / row -1 = padding: skipped)
                 const bool top_ok = crow - 2 >= 0;
-                float best[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) best[i] = -__builtin_huge_valf();
+                uint4 best = make_uint4(0u, 0u, 0u, 0u);                              // key 0 sorts below every value
 #pragma unroll
                 for (int dr = 0; dr < 3; ++dr) {
                     if (dr == 0 && !top_ok) continue;
@@ -155,16 +179,11 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(const float *__restrict_
                     for (int dc = -1; dc <= 1; ++dc) {
                         const int col = 2 * pcol + dc;
                         if (col < 0) continue;
-                        uint4 v = rr[swz(col, pch)];
-                        v.x ^= sgn.x; v.y ^= sgn.y; v.z ^= sgn.z; v.w ^= sgn.w;        // gamma < 0: maximise -y
-                        float f[8];
-                        Chunk<u16>::unpack(v, f);
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) best[i] = fmaxf(best[i], f[i]);
+                        const uint4 v = rr[swz(col, pch)];
+                        best.x = max_key(best.x, v.x); best.y = max_key(best.y, v.y); best.z = max_key(best.z, v.z); best.w = max_key(best.w, v.w);
                     }
                 }
-                uint4 o = Chunk<u16>::pack(best);                                     // (exact: the values are bf16 already)
-                o.x ^= sgn.x; o.y ^= sgn.y; o.z ^= sgn.z; o.w ^= sgn.w;
+                uint4 o = make_uint4(from_key(best.x) ^ sgn.x, from_key(best.y) ^ sgn.y, from_key(best.z) ^ sgn.z, from_key(best.w) ^ sgn.w);
                 const int prow = i0 + rho / 2 - 1;
                 *reinterpret_cast<uint4 *>(pooled + (((size_t)b * SP_PW + prow) * SP_PW + pcol) * 64 + pch * 8) = o;
             }
@@ -178,7 +197,7 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(const float *__restrict_
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                float a = ss1[nt][c], s2 = ss2[nt][c];
+                float a = ss1[nt][c >> 1][c & 1], s2 = ss2[nt][c >> 1][c & 1];
 #pragma unroll
                 for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); s2 += __shfl_xor(s2, o, 64); }
                 if (l15 == 0) { red[(wave * 2) * 64 + nt * 16 + 4 * q + c] = a; red[(wave * 2 + 1) * 64 + nt * 16 + 4 * q + c] = s2; }
