@@ -408,6 +408,13 @@ int mhe_conv_wgrad_nhwc(const mhe_conv_desc *d, const void *x, const void *gy, f
 size_t mhe_conv_wgrad_workspace_floats(const mhe_conv_desc *d);
 int mhe_conv_wgrad_ws_nhwc(const mhe_conv_desc *d, const void *x, const void *gy, float *dw, int ldw, float *workspace,
                            size_t workspace_floats, void *stream);
+/* nbatch independent weight gradients of ONE geometry in one launch (grouped GEMM): problem b reads x + b * x_batch_stride and
+ * gy + b * gy_batch_stride (elements) and accumulates into dw + b * dw_batch_stride (floats).  bf16 operands only.  The RealNVP reverse
+ * pass uses it for the three products of its 24 coupling nets (hand/flows.py:105-122).  workspace as for mhe_conv_wgrad_ws_nhwc, sized by
+ * mhe_conv_wgrad_batched_workspace_floats (0 = not needed). */
+size_t mhe_conv_wgrad_batched_workspace_floats(const mhe_conv_desc *d, int nbatch);
+int mhe_conv_wgrad_batched_nhwc(const mhe_conv_desc *d, int nbatch, const void *x, long x_batch_stride, const void *gy, long gy_batch_stride,
+                                float *dw, long dw_batch_stride, int ldw, float *workspace, size_t workspace_floats, void *stream);
 /* Weight gradient of a convolution whose WIDTH direction has its own stride and left padding and whose output size is given instead of
  * derived (d->stride / d->pad describe the height direction; d->KH x d->KW taps).  Use: the stem's 7x7 / stride-2 / pad-3 convolution
  * (reference: torchvision ResNet.conv1 under hand/CrossModalHand.py:455-470's backward) read as a 7 x 4 / stride (2, 1) / pad (3, 2)

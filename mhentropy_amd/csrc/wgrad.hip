@@ -30,6 +30,10 @@ struct Params {
     // ~1000 slices of 64 KiB that was 10-35 % of a launch)
     float *ws;
     int Mp, Np;
+    // grouped launch (mhe_conv_wgrad_batched_nhwc, LDS-DMA kernel only): gridDim.z = nbatch * gz; problem b = blockIdx.z / gz reads
+    // x + b * x_bs, gy + b * gy_bs (elements) and adds into dw + b * dw_bs (floats); slabs lie [b][slice][Mp][Np].  gz = 0: not grouped
+    int gz;
+    long x_bs, gy_bs, dw_bs;
 };
 
 constexpr int BK = 16;
@@ -330,7 +334,8 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_dma_kernel(const DmaParams
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const long k_begin = (long)blockIdx.z * p.chunk;
+    const int bz = p.gz ? (int)blockIdx.z / p.gz : 0, zs = p.gz ? (int)blockIdx.z - bz * p.gz : (int)blockIdx.z;      // problem of a grouped launch, slice
+    const long k_begin = (long)zs * p.chunk;
     const long k_end = k_begin + p.chunk < p.P ? k_begin + p.chunk : p.P;
     const unsigned OOB = 0x80000000u;
     // (512-byte rows sit a multiple of 256 bytes apart like 256-byte ones: same remedy, the XOR stays inside the row's 256-byte half)
@@ -356,8 +361,9 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_dma_kernel(const DmaParams
         b_col[j] = n < p.N ? (unsigned)(n - tap * p.Cin) * 2u : OOB;
         b_dh[j] = tap / p.KW - p.pad; b_dw[j] = tap % p.KW - p.pad_w;
     }
-    const u4v rs_g = {(unsigned)(size_t)p.gy, (unsigned)((size_t)p.gy >> 32) & 0xffffu, dp.gy_bytes, 0x00020000u};
-    const u4v rs_x = {(unsigned)(size_t)p.x, (unsigned)((size_t)p.x >> 32) & 0xffffu, dp.x_bytes, 0x00020000u};
+    const size_t gy_base = (size_t)p.gy + (size_t)bz * p.gy_bs * 2, x_base = (size_t)p.x + (size_t)bz * p.x_bs * 2;
+    const u4v rs_g = {(unsigned)gy_base, (unsigned)(gy_base >> 32) & 0xffffu, dp.gy_bytes, 0x00020000u};
+    const u4v rs_x = {(unsigned)x_base, (unsigned)(x_base >> 32) & 0xffffu, dp.x_bytes, 0x00020000u};
     const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) char *)ring);
     const long nst = (k_end - k_begin + BKB - 1) / BKB;
 
@@ -462,14 +468,15 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_dma_kernel(const DmaParams
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (p.ws) p.ws[((size_t)blockIdx.z * p.Mp + m) * p.Np + n] = acc[i][j][r];
-                else if (m < p.Cout && n < p.N) atomicAdd(p.dw + (size_t)m * p.ldw + n, acc[i][j][r]);
+                else if (m < p.Cout && n < p.N) atomicAdd(p.dw + (size_t)bz * p.dw_bs + (size_t)m * p.ldw + n, acc[i][j][r]);
             }
         }
 }
 
 // dW[m][n..n+3] += sum_z ws[z][m][n..n+3]: the reducer of the partial-slab mode (one float4 per thread, slabs read coalesced)
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, int gz, int Mp, int Np,
-                                                          int M, int N, int ldw) {
+                                                          int M, int N, int ldw, long dw_bs) {
+    ws += (size_t)blockIdx.y * gz * Mp * Np; dw += (size_t)blockIdx.y * dw_bs;          // (grouped launch: one problem per blockIdx.y)
     const int n4 = N / 4;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)M * n4) return;
@@ -534,7 +541,7 @@ using namespace mhe;
 
 // geometry of a launch: tile, grid and pixel chunk (shared by the launcher and the workspace query)
 struct WgradPlan { int BM, BN, gx, gy, gz; long chunk; bool bf16k, small, narrow, dma, big; };
-static WgradPlan plan_wgrad(const mhe_conv_desc *d, int Ho_ = 0, int Wo_ = 0) {
+static WgradPlan plan_wgrad(const mhe_conv_desc *d, int Ho_ = 0, int Wo_ = 0, int nbatch = 1) {
     WgradPlan w;
     const int Ho = Ho_ > 0 ? Ho_ : (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = Wo_ > 0 ? Wo_ : (d->W + 2 * d->pad - d->KW) / d->stride + 1;
     const int N = d->KH * d->KW * d->Cin;
@@ -551,13 +558,14 @@ static WgradPlan plan_wgrad(const mhe_conv_desc *d, int Ho_ = 0, int Wo_ = 0) {
     static const int big_env = getenv("MHE_WGRAD_BIG") ? atoi(getenv("MHE_WGRAD_BIG")) : 1;
     // (measured, tools/wgrad_bench.py: -7 ... -26 % from 32k pixels up and on the 3x3 layers; the 16k-pixel 1x1 layers of layer4 and the
     // flow's 512 x 512 products, a handful of tiles with short pixel slices each, lose 2 - 14 % and stay on the 128 x 128 tile)
-    w.big = w.dma && big_env && d->Cout % 256 == 0 && N >= 256 && (N % 256 == 0 || N >= 1024) && (P >= 32768 || N >= 2304);
+    w.big = w.dma && big_env && d->Cout % 256 == 0 && N >= 256 && (N % 256 == 0 || N >= 1024) && (P >= 32768 || N >= 2304 || nbatch > 1);
     if (w.big) w.BM = w.BN = 256;
     w.gx = (N + w.BN - 1) / w.BN; w.gy = (d->Cout + w.BM - 1) / w.BM;
     // split the pixel range: enough workgroups to fill 256 CUs a few times over; every split adds a full output tile of
     // partial sums - the bf16 kernel (4x faster mainloop) wants longer slices
     static const long target_wgs = getenv("MHE_WGRAD_WGS") ? atol(getenv("MHE_WGRAD_WGS")) : 512;      // 2 workgroups of the LDS-DMA kernel per CU: one resident wave of workgroups (measured 256-2048: 512 best)
-    long want = (w.big ? 256 : w.bf16k ? target_wgs : 2048) / ((long)w.gx * w.gy);      // (big tile: one workgroup per CU)
+    // (big tile: one workgroup per CU; a grouped launch - nbatch problems side by side - aims at three resident rounds of workgroups)
+    long want = (nbatch > 1 ? (w.big ? 768 : 1536) : w.big ? 256 : w.bf16k ? target_wgs : 2048) / ((long)w.gx * w.gy * nbatch);
     if (want < 1) want = 1;
     long chunk = (P + want - 1) / want;
     static const long min_bf16 = getenv("MHE_WGRAD_MINCHUNK") ? atol(getenv("MHE_WGRAD_MINCHUNK")) : 512;
@@ -578,7 +586,25 @@ extern "C" size_t mhe_conv_wgrad_workspace_floats(const mhe_conv_desc *d) {
 }
 
 static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, float *dw, int ldw, float *ws, size_t ws_floats, void *stream,
-                       int stride_w = 0, int pad_w = -1, int Ho_ = 0, int Wo_ = 0);
+                       int stride_w = 0, int pad_w = -1, int Ho_ = 0, int Wo_ = 0, int nbatch = 1, long x_bs = 0, long gy_bs = 0, long dw_bs = 0);
+
+// nbatch independent weight gradients of one geometry in ONE launch (a grouped GEMM): problem b reads x + b * x_batch_stride and
+// gy + b * gy_batch_stride (elements) and accumulates into dw + b * dw_batch_stride (floats).  The 24 coupling nets of the RealNVP reverse
+// pass (hand/flows.py:105-122; three products per net over the same 16k hypothesis rows) ran as 72 launches of 4 - 16 output tiles each,
+// 30 - 55 us apiece at 150 TF; grouped, each of the three shapes fills the chip.  bf16 operands (the LDS-DMA kernel) only.
+extern "C" size_t mhe_conv_wgrad_batched_workspace_floats(const mhe_conv_desc *d, int nbatch) {
+    if (!d || nbatch < 1 || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0) return 0;
+    const WgradPlan w = plan_wgrad(d, 0, 0, nbatch);
+    if ((size_t)d->Cout * d->KH * d->KW * d->Cin < 131072) return 0;
+    return (w.gz > 1 && w.gz <= 64) ? (size_t)nbatch * w.gz * (w.gy * w.BM) * (size_t)(w.gx * w.BN) : 0;
+}
+
+extern "C" int mhe_conv_wgrad_batched_nhwc(const mhe_conv_desc *d, int nbatch, const void *x, long x_batch_stride, const void *gy, long gy_batch_stride,
+                                           float *dw, long dw_batch_stride, int ldw, float *workspace, size_t workspace_floats, void *stream) {
+    MHE_REQUIRE(d && nbatch >= 1 && x_batch_stride >= 0 && gy_batch_stride >= 0 && dw_batch_stride >= 0, "mhe_conv_wgrad_batched_nhwc: bad arguments");
+    MHE_REQUIRE(d->dtype == MHE_BF16 && d->Cin % 8 == 0 && d->Cout % 8 == 0, "mhe_conv_wgrad_batched_nhwc: bf16 operands with channel counts in multiples of 8");
+    return wgrad_entry(d, x, gy, dw, ldw, workspace, workspace_floats, stream, 0, -1, 0, 0, nbatch, x_batch_stride, gy_batch_stride, dw_batch_stride);
+}
 
 extern "C" int mhe_conv_wgrad_nhwc(const mhe_conv_desc *d, const void *x, const void *gy, float *dw, int ldw, void *stream) {
     return wgrad_entry(d, x, gy, dw, ldw, nullptr, 0, stream);
@@ -607,13 +633,13 @@ extern "C" int mhe_conv_wgrad_rect_nhwc(const mhe_conv_desc *d, int stride_w, in
 }
 
 static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, float *dw, int ldw, float *ws, size_t ws_floats, void *stream,
-                       int stride_w, int pad_w, int Ho_, int Wo_) {
+                       int stride_w, int pad_w, int Ho_, int Wo_, int nbatch, long x_bs, long gy_bs, long dw_bs) {
     MHE_REQUIRE(d && x && gy && dw, "mhe_conv_wgrad_nhwc: null pointer");
     MHE_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0,
                 "mhe_conv_wgrad_nhwc: bad geometry");
     MHE_REQUIRE(d->Cin % 4 == 0 && d->Cout % 4 == 0, "mhe_conv_wgrad_nhwc: Cin=%d and Cout=%d must be multiples of 4", d->Cin, d->Cout);
     MHE_REQUIRE(d->dtype == MHE_F32 || d->dtype == MHE_BF16, "mhe_conv_wgrad_nhwc: dtype=%d", d->dtype);
-    wgrad::Params p;
+    wgrad::Params p{};
     p.x = x; p.gy = gy; p.dw = dw;
     p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
     p.stride = d->stride; p.pad = d->pad;
@@ -625,14 +651,16 @@ static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, fl
     p.ldw = ldw > 0 ? ldw : p.N;
     MHE_REQUIRE(p.ldw >= p.N, "mhe_conv_wgrad_nhwc: ldw=%d < KH*KW*Cin=%d", ldw, p.N);
     p.P = (long)d->B * p.Ho * p.Wo;
-    const WgradPlan w = plan_wgrad(d, Ho_, Wo_);
+    const WgradPlan w = plan_wgrad(d, Ho_, Wo_, nbatch);
     const bool small = w.small, bf16k = w.bf16k, narrow = w.narrow;
     const int gx = w.gx, gyy = w.gy, gz = w.gz;
     p.chunk = (int)w.chunk;
     p.Mp = gyy * w.BM; p.Np = gx * w.BN;
-    const size_t need = (size_t)gz * p.Mp * p.Np;
+    const size_t need = (size_t)nbatch * gz * p.Mp * p.Np;
     p.ws = (ws && gz > 1 && gz <= 64 && need <= ws_floats && (size_t)d->Cout * p.N >= 131072) ? ws : nullptr;
-    const dim3 grid(gx, gyy, gz), block(256);
+    MHE_REQUIRE(nbatch == 1 || (w.dma && (long)gz * nbatch < 65536), "mhe_conv_wgrad_batched_nhwc: the grouped form runs on the LDS-DMA kernel (bf16, operands below 2 GiB)");
+    if (nbatch > 1) { p.gz = gz; p.x_bs = x_bs; p.gy_bs = gy_bs; p.dw_bs = dw_bs; }
+    const dim3 grid(gx, gyy, gz * nbatch), block(256);
     hipStream_t s = (hipStream_t)stream;
     const size_t xb = (size_t)d->B * d->H * d->W * d->Cin * 2, gb = (size_t)p.P * d->Cout * 2;
     const bool use_dma = w.dma;
@@ -666,7 +694,7 @@ static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, fl
     if (int rc = check_launch("wgrad_kernel")) return rc;
     if (p.ws) {
         const long n = (long)d->Cout * (p.N / 4);
-        hipLaunchKernelGGL(wgrad::slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), block, 0, s, p.ws, dw, gz, p.Mp, p.Np, d->Cout, p.N, p.ldw);
+        hipLaunchKernelGGL(wgrad::slab_reduce_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nbatch), block, 0, s, p.ws, dw, gz, p.Mp, p.Np, d->Cout, p.N, p.ldw, dw_bs);
         return check_launch("slab_reduce_kernel");
     }
     return MHE_OK;

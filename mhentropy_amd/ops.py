@@ -665,6 +665,25 @@ def conv_wgrad(x, gy, KH, KW, stride, pad, dw, ldw=0):
     return dw
 
 
+def conv_wgrad_batched(x, gy, dw, dw_batch_stride, nbatch, x_batch_stride=None, gy_batch_stride=None):
+    """nbatch dense weight gradients dw_b [N, K] += gy_b [R, N]^T x_b [R, K] in one grouped launch (mhe_conv_wgrad_batched_nhwc).  x / gy: bf16
+    tensors whose storage holds the problems at the given element strides (default: x [nbatch, R, K], gy [nbatch, R, N] contiguous); dw: the
+    f32 view of the FIRST problem's gradient, the others lie dw_batch_stride floats apart (the train step's raw gradient arena)."""
+    R, K = x.shape[-2], x.shape[-1]
+    N = gy.shape[-1]
+    if x.dtype != torch.bfloat16 or gy.dtype != torch.bfloat16 or not x.is_cuda or not gy.is_cuda or dw.dtype != torch.float32:
+        raise _lib.MheError("conv_wgrad_batched: bf16 device operands and an f32 gradient expected")
+    xs = R * K if x_batch_stride is None else int(x_batch_stride)
+    gs = R * N if gy_batch_stride is None else int(gy_batch_stride)
+    d = ConvDesc(R, 1, 1, K, N, 1, 1, 1, 0, BF16, 0, 0)
+    L = _lib.lib()
+    need = L.mhe_conv_wgrad_batched_workspace_floats(C.byref(d), nbatch) if WGRAD_SLABS else 0
+    ws = _wgrad_ws(x.device, need) if need else None
+    check(L.mhe_conv_wgrad_batched_nhwc(C.byref(d), nbatch, _ptr(x), xs, _ptr(gy), gs, _ptr(dw), int(dw_batch_stride), 0, _ptr(ws),
+                                        ws.numel() if ws is not None else 0, _stream()), "mhe_conv_wgrad_batched_nhwc")
+    return dw
+
+
 def conv_wgrad_rect(x, gy, KH, KW, stride_h, stride_w, pad_h, pad_w, dw):
     """dw[Cout, KH*KW*Cin] += gy^T (*) x for a convolution with separate height / width stride and (top / left) padding whose output size is
     gy's (mhe_conv_wgrad_rect_nhwc): the stem's weight gradient over pixel pairs (train.TrainStep)."""

@@ -680,8 +680,18 @@ class TrainStep:
             kept = getattr(self, "_flow_kept", None)
             if kept is not None and kept[0].shape[1] != R:
                 kept = None
+            # grouped weight gradients (ops.conv_wgrad_batched): with the forward's activations kept, every net's reverse operands are kept
+            # too (GO, G2, G1, the masked inputs: 0.9 GB at C2) and the 72 per-net weight-gradient launches (4 - 16 output tiles each,
+            # 30 - 55 us apiece) become four grouped ones after the chain - MHE_FLOW_WGRAD_GROUPED=0: per net, as the chain goes
+            grouped = kept is not None and os.environ.get("MHE_FLOW_WGRAD_GROUPED", "1") == "1"
+            if grouped:
+                GOb_all = self._buf("GOb_all", (2 * ncoup, R, 64), bf)
+                G2b_all, G1b_all = self._buf("G2b_all", (2 * ncoup, R, h), bf), self._buf("G1b_all", (2 * ncoup, R, h), bf)
+                XPb_all = self._buf("XPb_all", (ncoup, R, 64), bf)
             for i in range(ncoup - 1, -1, -1):
                 m = fl.mask[i]
+                if grouped:
+                    XPb, GOb, G2b_n, G1b_n = XPb_all[i], [GOb_all[2 * i], GOb_all[2 * i + 1]], [G2b_all[2 * i], G2b_all[2 * i + 1]], [G1b_all[2 * i], G1b_all[2 * i + 1]]
                 ops.flow_mask_pad_mixed(x_cur, m, out_bf16=XPb)
                 if kept is not None:                   # written out by the forward kernel (mhe_flow_couplings_bf16_emit)
                     H1b, H2b, O = [[k[2 * i + n] for n in range(2)] for k in kept]
@@ -697,16 +707,29 @@ class TrainStep:
                                     GOb[0], GOb[1], db_s=self.fnets[2 * i]["db2"], db_t=self.fnets[2 * i + 1]["db2"])
                 for n in range(2):
                     d, slot = self.fnets[2 * i + n], (2 * i + n) * 2
-                    ops.conv_wgrad(v4(H2b[n]), v4(GOb[n]), 1, 1, 1, 0, d["dw2"])
+                    if grouped:
+                        G2b, G1b = G2b_n[n], G1b_n[n]
+                    else:
+                        ops.conv_wgrad(v4(H2b[n]), v4(GOb[n]), 1, 1, 1, 0, d["dw2"])
                     ops.conv2d_nhwc(v4(GOb[n]), d["w2Tb"], 1, 1, 1, 0, out=v4(P2b))
                     ops.flow_lrelu_bwd_sum(P2b, H2b[n], N, B, Gc[:, (slot + 1) * h:], Gc.shape[1], out_bf16=G2b, sum_out_t=GcT[(slot + 1) * h:])
-                    ops.conv_wgrad(v4(H1b[n]), v4(G2b), 1, 1, 1, 0, d["dw1"])
+                    if not grouped:
+                        ops.conv_wgrad(v4(H1b[n]), v4(G2b), 1, 1, 1, 0, d["dw1"])
                     ops.conv2d_nhwc(v4(G2b), d["w1Tb"], 1, 1, 1, 0, out=v4(GH1b))
                     ops.flow_lrelu_bwd_sum(GH1b, H1b[n], N, B, Gc[:, slot * h:], Gc.shape[1], out_bf16=G1b, sum_out_t=GcT[slot * h:])
-                    ops.conv_wgrad(v4(XPb), v4(G1b), 1, 1, 1, 0, d["dw0"])
+                    if not grouped:
+                        ops.conv_wgrad(v4(XPb), v4(G1b), 1, 1, 1, 0, d["dw0"])
                     ops.linear_bf16_f32out(G1b, d["w0Tb"], out=GX[n])
                 ops.flow_couple_accum(gpart, GX[0], GX[1], m, g_in)
                 x_cur, g_cur = x_in, g_in
+            if grouped:
+                f0, nets = self.fnets[0], 2 * ncoup
+                stride = self.fnets[1]["r1"] - f0["r1"]                   # the nets' raw-gradient slots are laid out at one pitch
+                assert all(self.fnets[k][key] - f0[key] == k * stride for k in range(nets) for key in ("r0", "r1", "r2"))
+                ops.conv_wgrad_batched(kept[1], GOb_all, f0["dw2"], stride, nets)           # dW2 = GO^T H2   [64, h]  x 24
+                ops.conv_wgrad_batched(kept[0], G2b_all, f0["dw1"], stride, nets)           # dW1 = G2^T H1   [h, h]   x 24
+                for n in range(2):      # dW0 = G1^T XP [h, 64]: the s (t) nets of the 12 couplings share their coupling's masked input
+                    ops.conv_wgrad_batched(XPb_all, G1b_all[n], self.fnets[n]["dw0"], 2 * stride, ncoup, gy_batch_stride=2 * R * h)
             self.z0_recovered = x_cur
             return Gc
         for i in range(ncoup - 1, -1, -1):
