@@ -450,6 +450,24 @@ int mhe_flow_lrelu_bwd_sum(const void *g, int g_dtype, const void *h, int h_dtyp
  * that turns the conditioning table's gradient into the feature's) */
 /* mhe_flow_mask_pad_f32 / mhe_flow_couple_bwd_f32 with optional bf16 copies of the GEMM operands they produce */
 int mhe_flow_mask_pad_mixed(const float *x, const float *mask, float *xp, void *xp_bf16, long R, int dim, void *stream);
+/* The data-gradient chain of ALL couplings in one launch (bf16 mode, hidden 512, 64 hypotheses per image, forward activations kept by
+ * mhe_flow_couplings_bf16_emit): what mask_pad -> couple_bwd -> (GO W2, leaky-ReLU reverse + sums, G2 W1, leaky-ReLU reverse + sums, G1 W0) x 2
+ * -> couple_accum compute coupling by coupling (13 launches each), with every intermediate kept on chip.  A workgroup owns one image's 64
+ * rows.  Outputs: GO / G2 / G1 [nets][R][64 | 512 | 512] and the masked inputs XP [ncoup][R][64] in bf16 (operands of the grouped weight
+ * gradients), Gc [B][cond_stride] (the conditioning table's gradient: column (2 net + layer) * hidden + unit; cond_stride % 4 == 0),
+ * db2 (+ net * db_net_stride: l2 bias gradients, ACCUMULATED), z0 [R][dim] (the recovered base sample, optional).  w2F, w1F, w0F =
+ * net 0's bf16 operands W2^T [512][64], W1^T [512][512], W0^T [64][512] ([out][k]) in FRAGMENT-MAJOR order - element
+ * [out][k] at ((out / 16 * (K / 32) + k / 32) * 64 + (k % 32 / 8) * 16 + out % 16) * 8 + k % 8, the order the lanes of
+ * v_mfma_f32_16x16x32_bf16 take them, so a fragment is one 1 KiB run; net k at + k * w_net_stride elements. */
+int mhe_flow_reverse_chain_supported(int R, int B, int dim, int hidden, int ncoup);
+int mhe_flow_reverse_chain_bf16(const float *x_out, const float *g_x, const float *g_logp, float q_weight, const float *mask,
+                                const float *o_pre, const void *h1, const void *h2, const void *w2F, const void *w1F,
+                                const void *w0F, long w_net_stride, void *GO_bf16, void *G2_bf16, void *G1_bf16, void *XP_bf16,
+                                float *Gc, int cond_stride, float *db2, long db_net_stride, float *z0, int R, int B, int dim,
+                                int hidden, int ncoup, void *stream);
+/* src [R][C] f32 (row pitch src_stride) -> dst [R][C] bf16 (optional) and dstT [C][R] bf16: the conditioning gradient as the two operands
+ * its consumers read (the conditioning layer's weight gradient; the split-K product that gives the feature's gradient). */
+int mhe_pack_transpose_bf16(const float *src, long src_stride, void *dst_bf16, void *dstT_bf16, int R, int C, void *stream);
 int mhe_flow_couple_bwd_mixed(const float *x_out, const float *Os, const float *Ot, const float *mask,
                               const float *g_out, const float *g_log_p, float q_weight, float *x_in, float *GOs,
                               float *GOt, float *g_part, void *GOs_bf16, void *GOt_bf16,

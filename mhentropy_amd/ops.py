@@ -796,6 +796,52 @@ def flow_couple_bwd(x_out, Os, Ot, mask_row, g_out, g_log_p, q_weight, B, x_in, 
                                                _ptr(db_s), _ptr(db_t), R, B, dim, _stream()), "mhe_flow_couple_bwd_mixed")
 
 
+def mfma_fragment_major(t):
+    """[rows][K] (rows % 16 == 0, K % 32 == 0) -> the same elements in the order mhe_flow_reverse_chain_bf16 reads its operands:
+    [rows / 16][K / 32][k-group 4][row 16][8] (lane = k-group * 16 + row of v_mfma_f32_16x16x32_bf16); works on index tensors too"""
+    rows, K = t.shape
+    return t.reshape(rows // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def flow_reverse_chain_supported(R, B, dim, hidden, ncoup):
+    return bool(_lib.lib().mhe_flow_reverse_chain_supported(R, B, dim, hidden, ncoup))
+
+
+def flow_reverse_chain(x_out, g_x, g_logp, q_weight, mask, o_pre, h1, h2, w2F, w1F, w0F, w_net_stride, GOb, G2b, G1b, XPb, Gc, db2,
+                       db_net_stride, z0):
+    """the RealNVP reverse pass's data-gradient chain over all couplings in one launch (mhe_flow_reverse_chain_bf16; csrc/flow_rev.hip)"""
+    R, dim = x_out.shape
+    B = Gc.shape[0]
+    nets, _, hidden = h1.shape
+    _chk(x_out, torch.float32, "rev_chain.x_out"); _chk(g_x, torch.float32, "rev_chain.g_x", (R, dim))
+    _chk(mask, torch.float32, "rev_chain.mask", (nets // 2, dim)); _chk(o_pre, torch.float32, "rev_chain.o", (nets, R, 64))
+    _chk(h1, torch.bfloat16, "rev_chain.h1", (nets, R, hidden)); _chk(h2, torch.bfloat16, "rev_chain.h2", (nets, R, hidden))
+    _chk(GOb, torch.bfloat16, "rev_chain.GO", (nets, R, 64)); _chk(G2b, torch.bfloat16, "rev_chain.G2", (nets, R, hidden))
+    _chk(G1b, torch.bfloat16, "rev_chain.G1", (nets, R, hidden)); _chk(XPb, torch.bfloat16, "rev_chain.XP", (nets // 2, R, 64))
+    _chk(Gc, torch.float32, "rev_chain.Gc"); _chk(z0, torch.float32, "rev_chain.z0", (R, dim))
+    if g_logp is not None:
+        _chk(g_logp, torch.float32, "rev_chain.g_logp", (B,))
+    check(_lib.lib().mhe_flow_reverse_chain_bf16(_ptr(x_out), _ptr(g_x), _ptr(g_logp), float(q_weight), _ptr(mask), _ptr(o_pre), _ptr(h1), _ptr(h2), _ptr(w2F),
+                                                 _ptr(w1F), _ptr(w0F), int(w_net_stride), _ptr(GOb), _ptr(G2b), _ptr(G1b), _ptr(XPb), _ptr(Gc),
+                                                 Gc.shape[1], _ptr(db2), int(db_net_stride), _ptr(z0), R, B, dim, hidden, nets // 2, _stream()),
+          "mhe_flow_reverse_chain_bf16")
+
+
+def pack_transpose_bf16(src, out=None, outT=None, want_rows=True):
+    """src [R][C] f32 -> (bf16 copy [R][C] | None, bf16 transpose [C][R]) in one launch (mhe_pack_transpose_bf16)"""
+    R, Cc = src.shape
+    _chk(src, torch.float32, "pack_transpose.src")
+    if want_rows and out is None:
+        out = torch.empty(R, Cc, device=src.device, dtype=torch.bfloat16)
+    if outT is None:
+        outT = torch.empty(Cc, R, device=src.device, dtype=torch.bfloat16)
+    if out is not None:
+        _chk(out, torch.bfloat16, "pack_transpose.out", (R, Cc))
+    _chk(outT, torch.bfloat16, "pack_transpose.outT", (Cc, R))
+    check(_lib.lib().mhe_pack_transpose_bf16(_ptr(src), src.stride(0), _ptr(out), _ptr(outT), R, Cc, _stream()), "mhe_pack_transpose_bf16")
+    return out, outT
+
+
 def flow_couple_accum(g_part, GXs, GXt, mask_row, g_in):
     R, dim = g_part.shape
     check(_lib.lib().mhe_flow_couple_accum_f32(_ptr(g_part), _ptr(GXs), _ptr(GXt), _ptr(mask_row), _ptr(g_in), R, dim, _stream()),

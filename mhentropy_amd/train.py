@@ -407,6 +407,10 @@ class TrainStep:
                     d["w2Tb"] = self._derived(w2i.t().contiguous(), torch.bfloat16)         # [h, 64]: GO W2
                     d["w2b"] = self._derived(w2i, torch.bfloat16)                           # [64, h]: H1 W2^T (f32 result)
                     d["w0Tb"] = self._derived(w0i.t().contiguous(), torch.bfloat16)         # [64, h]: G1 W0 (f32 result)
+                    # the three [out][k] operands again in MFMA fragment order: what the one-launch reverse chain reads (csrc/flow_rev.hip)
+                    d["w1Fb"] = self._derived(ops.mfma_fragment_major(self._pidx(net.l[1].weight).t()), torch.bfloat16)
+                    d["w2Fb"] = self._derived(ops.mfma_fragment_major(w2i.t()), torch.bfloat16)
+                    d["w0Fb"] = self._derived(ops.mfma_fragment_major(w0i.t()), torch.bfloat16)
                 d["w2"], d["w2T"] = self._derived(w2i, torch.float32), self._derived(w2i.t().contiguous(), torch.float32)
                 d["b2"] = self._derived(b2i, torch.float32)
                 d["r0"], d["r1"], d["r2"], d["rb2"] = (self._raw_slot(s) for s in ((h, 64), (h, h), (64, h), (64,)))
@@ -677,6 +681,7 @@ class TrainStep:
             G1b = self._buf("G1b", (R, h), bf)
             GcT = self._buf("GcondT", (cstride, B))              # the same sums as Gc, [column][image]: split-K operand of g_feat
             self._GcT = GcT
+            self._Gc_packed = None
             kept = getattr(self, "_flow_kept", None)
             if kept is not None and kept[0].shape[1] != R:
                 kept = None
@@ -688,7 +693,24 @@ class TrainStep:
                 GOb_all = self._buf("GOb_all", (2 * ncoup, R, 64), bf)
                 G2b_all, G1b_all = self._buf("G2b_all", (2 * ncoup, R, h), bf), self._buf("G1b_all", (2 * ncoup, R, h), bf)
                 XPb_all = self._buf("XPb_all", (ncoup, R, 64), bf)
-            for i in range(ncoup - 1, -1, -1):
+            # the whole data-gradient chain in one launch (csrc/flow_rev.hip): 64 hypotheses per image, one workgroup per image.
+            # MHE_FLOW_REV_FUSED=0: coupling by coupling (13 launches each)
+            fused = (grouped and os.environ.get("MHE_FLOW_REV_FUSED", "1") == "1" and N == N_all and R == 64 * B
+                     and ops.flow_reverse_chain_supported(R, B, dim, h, ncoup))
+            if fused:
+                f0 = self.fnets[0]
+                wst = (self.fnets[1]["w1Fb"].data_ptr() - f0["w1Fb"].data_ptr()) // 2
+                assert wst > 0 and all((self.fnets[k][key].data_ptr() - f0[key].data_ptr()) // 2 == k * wst
+                                       for k in range(2 * ncoup) for key in ("w2Fb", "w1Fb", "w0Fb"))
+                z0r = self._buf("z0_rec", (R, dim))
+                ops.flow_reverse_chain(x_out, g_x, g_logp, -1.0 / N_all if g_logp is not None else 0.0, fl.mask, kept[2], kept[0], kept[1],
+                                       f0["w2Fb"], f0["w1Fb"], f0["w0Fb"], wst, GOb_all, G2b_all, G1b_all, XPb_all, Gc, f0["db2"],
+                                       self.fnets[1]["rb2"] - f0["rb2"], z0r)
+                # (the kernel leaves the per-image sums as [image][column] rows only; both bf16 operands of the conditioning layer's
+                # reverse - the rows and their transpose - come from one pack launch instead of a scattered second layout + two casts)
+                self._Gc_packed = ops.pack_transpose_bf16(Gc, out=self._buf("Gcond_b", (B, cstride), bf), outT=self._buf("GcondT_b", (cstride, B), bf))
+                x_cur = z0r
+            for i in range(ncoup - 1, -1, -1) if not fused else ():
                 m = fl.mask[i]
                 if grouped:
                     XPb, GOb, G2b_n, G1b_n = XPb_all[i], [GOb_all[2 * i], GOb_all[2 * i + 1]], [G2b_all[2 * i], G2b_all[2 * i + 1]], [G1b_all[2 * i], G1b_all[2 * i + 1]]
@@ -879,7 +901,8 @@ class TrainStep:
             wc32 = self.f_wc if (cond_bf16 or self.cond_f32) else self.f_wcb.float()
             if cond_bf16:
                 fb = t.get("feat_b")
-                ops.linear_wgrad(fb if fb is not None else feat.to(torch.bfloat16), Gc.to(torch.bfloat16), self.dwc)
+                packed = getattr(self, "_Gc_packed", None)
+                ops.linear_wgrad(fb if fb is not None else feat.to(torch.bfloat16), packed[0] if packed else Gc.to(torch.bfloat16), self.dwc)
             else:
                 ops.linear_wgrad(feat, Gc, self.dwc)
             ops.colsum(Gc, self.dbc)
@@ -890,9 +913,11 @@ class TrainStep:
                 K_, F_ = (self.f_wcb if self.f_wcb is not None else self.f_wc).shape
                 g_feat = self._buf("g_feat_flow", (B, F_)); g_feat.zero_()
                 if cond_bf16:
-                    ops.conv_wgrad(self.f_wcb.view(K_, 1, 1, F_), self._GcT.to(torch.bfloat16).view(K_, 1, 1, B), 1, 1, 1, 0, g_feat)
+                    ops.conv_wgrad(self.f_wcb.view(K_, 1, 1, F_), (packed[1] if packed else self._GcT.to(torch.bfloat16)).view(K_, 1, 1, B),
+                                   1, 1, 1, 0, g_feat)
                 else:
-                    ops.conv_wgrad(wc32.view(K_, 1, 1, F_), self._GcT.view(K_, 1, 1, B), 1, 1, 1, 0, g_feat)
+                    GcT32 = self._GcT if getattr(self, "_Gc_packed", None) is None else Gc.t().contiguous()
+                    ops.conv_wgrad(wc32.view(K_, 1, 1, F_), GcT32.view(K_, 1, 1, B), 1, 1, 1, 0, g_feat)
             else:
                 g_feat = ops.linear(Gc, self.f_wcT if self.f_wcT is not None else wc32.t().contiguous())
         ops.add(g_feat, ops.linear(ghd, self.d0["wT"]))

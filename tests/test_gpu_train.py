@@ -644,7 +644,10 @@ def test_graphed_loop_equals_eager_loop(gpu_lib):
         graphed.append(float(-g.replay()["log_p"].mean()))
     assert int(ts0.step_t.item()) == int(ts1.step_t.item()) == iters
     assert int(m0.feat_extractor.res.bn1.num_batches_tracked) == int(m1.feat_extractor.res.bn1.num_batches_tracked) == iters
-    assert_close(graphed, eager, 1e-4, what="per-iteration loss, graphed vs eager loop")
+    assert abs(graphed[0] - eager[0]) <= 1e-6 * abs(eager[0])          # same model, same batch: the capture iteration IS the first step
+    # later iterations: the f32 atomics' summation order differs between the loops, and Adam turns the sign of a ~0 gradient into a
+    # +-lr parameter difference - measured drift 2e-6 -> 5e-4 over four iterations
+    assert_close(graphed, eager, 3e-3, what="per-iteration loss, graphed vs eager loop")
     # same kernels, same inputs: the two loops differ by the f32 atomics' summation order only; Adam turns a ~0 gradient whose sign
     # flips into a +-lr difference, so bound the fraction of such elements instead of the maximum
     d = (ts1.P - ts0.P).abs()
@@ -697,6 +700,7 @@ def test_grouped_flow_weight_gradients_equal_the_per_net_launches(gpu_lib, monke
     ts = TrainStep(model)
     assert ts.flow_bf16
     grads = {}
+    monkeypatch.setenv("MHE_FLOW_REV_FUSED", "0")
     for mode in ("1", "0"):
         monkeypatch.setenv("MHE_FLOW_WGRAD_GROUPED", mode)
         ts.forward_backward(x, y, noise=z0, N=N)
@@ -707,3 +711,34 @@ def test_grouped_flow_weight_gradients_equal_the_per_net_launches(gpu_lib, monke
         g0 = grads["0"][n]
         assert g0.abs().max() > 0, n
         assert_close(g1.cpu(), g0.cpu(), 2e-5, what="grouped vs per-net " + n)
+
+
+def test_fused_reverse_chain_of_the_flow_equals_the_coupling_by_coupling_pass(gpu_lib, monkeypatch):
+    """csrc/flow_rev.hip (bf16 mode, h = 512, 64 hypotheses per image): the data-gradient chain of all couplings in one launch against
+    the 13-launches-per-coupling pass - the same operands and products; the fused kernel applies the leaky-ReLU reverse to the f32
+    accumulator where the launch-by-launch pass first rounds the product to bf16, so the two agree to bf16 rounding of the 512-wide
+    gradients (norm-wise, like test_bf16_flow_reverse_close_to_fp32_autograd), the recovered base sample and everything f32 to 1e-5"""
+    from mhentropy_amd import harness
+    from mhentropy_amd.train import TrainStep
+    torch.manual_seed(4)
+    model = harness.build_mhent(backbone="resnet18", h_dims=(512, 512), num_steps=2, tables=synth.mano_tables(0), compute_dtype=torch.bfloat16).cuda().train()
+    B, N = 6, 64
+    xn, yn = synth.batch(6, B, image_size=96)
+    x, y = _dev(xn), {k: _dev(v) for k, v in yn.items()}
+    z0 = _dev(synth.noise(6, N * B))
+    ts = TrainStep(model)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MHE_FLOW_REV_FUSED", mode)
+        out = ts.forward_backward(x, y, noise=z0, N=N)
+        res[mode] = ({n: ts.grad_of(p).clone() for n, p in model.named_parameters()}, ts.z0_recovered.clone(), ts.tape["g_feat"].clone(), float(out["total"]))
+    (g0, z_0, gf0, l0), (g1, z_1, gf1, l1) = res["0"], res["1"]
+    assert l0 == l1
+    assert_close(z_1.cpu(), z_0.cpu(), 1e-5, what="recovered base sample")
+    assert_close(z_1.cpu(), z0.cpu(), 2e-2, what="recovered base sample vs the noise that went in (bf16 nets)")
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+    assert rel(gf1, gf0) < 1e-2, rel(gf1, gf0)
+    worst = max((rel(g1[n], g0[n]), n) for n in g0 if g0[n].abs().max() > 0)
+    assert worst[0] < 5e-2, worst
+    flow = [rel(g1[n], g0[n]) for n in g0 if n.startswith("q_z_giv_i") and g0[n].abs().max() > 0]
+    assert len(flow) == 4 * 2 * 10 and sorted(flow)[len(flow) // 2] < 5e-3, sorted(flow)[len(flow) // 2]

@@ -23,6 +23,9 @@ python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json
 python tools/pmc_mfma.py $O/pmc_mfma $O/pmc_mfma.json
 python tools/pmc_mfma.py $O/pmc_mfma_train $O/pmc_mfma_train.json
 python tools/trace_stats.py $O/train_tr $O/train_kernel_stats.csv step:adam_kernel:5 > $O/train_stats.txt; tail -1 $O/train_stats.txt
+# the forward's kernels PER TIMED STEP (a step ends with its single elbo_reduce launch): nothing of the model's construction in it
+python tools/trace_stats.py $O/stats $O/step_kernel_stats.csv step:elbo_reduce_kernel:5 > $O/step_stats.txt; tail -1 $O/step_stats.txt
+timeout -k 10 300 python bench.py --workload c1 --no-glow-variant > $O/bench_c1.json 2> $O/bench_c1.err || true
 find $O -name "*counter_collection.csv" -size +4M -delete; find $O -name "*kernel_trace.csv" -size +4M -delete
 du -sh $O
-echo "cp $O/bench.json profiles/r03_bench_c2_bf16.json; cp $O/stats/s_kernel_stats.csv profiles/r03_c2_bf16_kernel_stats.csv; cp $O/pmc_traffic.json profiles/r03_pmc_traffic.json; cp $O/pmc_mfma.json profiles/r03_pmc_mfma.json; cp $O/pmc_mfma_train.json profiles/r03_pmc_mfma_train.json; cp $O/train_kernel_stats.csv profiles/r03_train_kernel_stats.csv"
+echo "cp $O/bench.json profiles/r03_bench_c2_bf16.json; cp $O/stats/s_kernel_stats.csv profiles/r03_c2_bf16_kernel_stats.csv; cp $O/pmc_traffic.json profiles/r03_pmc_traffic.json; cp $O/pmc_mfma.json profiles/r03_pmc_mfma.json; cp $O/pmc_mfma_train.json profiles/r03_pmc_mfma_train.json; cp $O/train_kernel_stats.csv profiles/r03_train_kernel_stats.csv; cp $O/step_kernel_stats.csv profiles/r03_c2_bf16_step_kernel_stats.csv; cp $O/bench_c1.json profiles/r03_bench_c1_f32.json"
