@@ -140,3 +140,16 @@ def test_product_refuses_cpu_tensors():
     from mhentropy_amd import ops
     with pytest.raises(_lib.MheError):
         ops.linear(torch.zeros(4, 32), torch.zeros(8, 32))
+
+
+def test_fragment_major_order_is_the_headers_formula():
+    """include/mhe.h (mhe_flow_reverse_chain_bf16): element [out][k] of an operand lies at
+    ((out / 16 * (K / 32) + k / 32) * 64 + (k % 32 / 8) * 16 + out % 16) * 8 + k % 8"""
+    import torch
+    from mhentropy_amd import ops
+    rows, K = 64, 128
+    idx = torch.arange(rows * K).view(rows, K)
+    flat = ops.mfma_fragment_major(idx).reshape(-1)
+    o, k = torch.meshgrid(torch.arange(rows), torch.arange(K), indexing="ij")
+    pos = ((o // 16 * (K // 32) + k // 32) * 64 + (k % 32 // 8) * 16 + o % 16) * 8 + k % 8
+    assert torch.equal(flat[pos.reshape(-1)], idx.reshape(-1))

@@ -418,3 +418,83 @@ def test_basic_enc_returns_the_references_triple(gpu_lib):
     assert torch.isfinite(z2).all() and not torch.equal(z2, z)
     zd, mnd, _ = enc(x, deterministic=True)
     assert torch.equal(zd, mnd)
+
+
+def test_pack_transpose_bf16(gpu_lib):
+    """f32 [R][C] -> bf16 rows and bf16 transpose in one launch (ragged edges: neither side a multiple of the 64 x 64 tile)"""
+    from mhentropy_amd import ops
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    wide = torch.randn(70, 300, device="cuda", generator=gen)
+    src = wide[:, :200]                                    # a row pitch larger than the row
+    src_c = src.contiguous()
+    rows, cols = ops.pack_transpose_bf16(src_c)
+    assert torch.equal(rows, src_c.to(torch.bfloat16)) and torch.equal(cols, src_c.t().contiguous().to(torch.bfloat16))
+    _, cols2 = ops.pack_transpose_bf16(src_c, want_rows=False)
+    assert torch.equal(cols2, cols)
+
+
+@pytest.mark.parametrize("B,ncoup,entropy", [(3, 4, True), (2, 3, False)])
+def test_flow_reverse_chain_against_a_plain_torch_reverse_pass(gpu_lib, B, ncoup, entropy):
+    """mhe_flow_reverse_chain_bf16 (all couplings' data-gradient chain in one launch, one workgroup per image) against the same chain in
+    plain torch: f32 math, the operands the kernel rounds to bf16 rounded at the same places (hand/flows.py:97-122,210-217 reversed).
+    Tolerance: bf16 operands -> 1e-2 of the tensor's scale for what passes through a 512-deep bf16 product, 2e-5 for the recovered sample."""
+    from mhentropy_amd import ops
+    N, h, dim = 64, 512, 45
+    R, nets = N * B, 2 * ncoup
+    gen = torch.Generator(device="cuda").manual_seed(17 + B)
+    rn = lambda *s, sc=1.0: torch.randn(*s, device="cuda", generator=gen) * sc
+    bf = lambda t: t.to(torch.bfloat16)
+    x_out, g_x = rn(R, dim), rn(R, dim, sc=0.1)
+    g_logp = rn(B, sc=0.1) if entropy else None
+    qw = -1.0 / N if entropy else 0.0
+    mask = torch.zeros(ncoup, dim, device="cuda"); mask[0::2, :22] = 1; mask[1::2, 22:] = 1
+    o_pre = torch.zeros(nets, R, 64, device="cuda"); o_pre[:, :, :dim] = rn(nets, R, dim, sc=0.5)
+    h1, h2 = bf(rn(nets, R, h)), bf(rn(nets, R, h))
+    w2T, w1T, w0T = bf(rn(nets, h, 64, sc=0.05)), bf(rn(nets, h, h, sc=0.05)), bf(rn(nets, 64, h, sc=0.05))
+    w2T[:, :, dim:] = 0; w0T[:, dim:, :] = 0                # the padded dims carry zeros, as in the train step's packs
+    # fragment-major operands, one pitch apart
+    wst = h * h + 2 * 64 * h
+    wbuf = torch.zeros(nets * wst, device="cuda", dtype=torch.bfloat16)
+    for k in range(nets):
+        wbuf[k * wst:k * wst + h * h] = ops.mfma_fragment_major(w1T[k]).reshape(-1)
+        wbuf[k * wst + h * h:k * wst + h * h + 64 * h] = ops.mfma_fragment_major(w2T[k]).reshape(-1)
+        wbuf[k * wst + h * h + 64 * h:(k + 1) * wst] = ops.mfma_fragment_major(w0T[k]).reshape(-1)
+    GOb, XPb = torch.zeros(nets, R, 64, device="cuda", dtype=torch.bfloat16), torch.zeros(ncoup, R, 64, device="cuda", dtype=torch.bfloat16)
+    G2b, G1b = torch.zeros(nets, R, h, device="cuda", dtype=torch.bfloat16), torch.zeros(nets, R, h, device="cuda", dtype=torch.bfloat16)
+    cs = 4 * ncoup * h + 8
+    Gc, db2, z0 = torch.zeros(B, cs, device="cuda"), torch.zeros(nets, 64, device="cuda"), torch.zeros(R, dim, device="cuda")
+    assert ops.flow_reverse_chain_supported(R, B, dim, h, ncoup) and not ops.flow_reverse_chain_supported(R + B, B, dim, h, ncoup)
+    ops.flow_reverse_chain(x_out, g_x, g_logp, qw, mask, o_pre, h1, h2, wbuf[h * h:], wbuf, wbuf[h * h + 64 * h:], wst, GOb, G2b, G1b, XPb, Gc,
+                           db2, 64, z0)
+    torch.cuda.synchronize()
+    # ---- the same in torch
+    lre = lambda g, hk: torch.where(hk.float() > 0, g, 0.01 * g)
+    img = lambda t: t.view(N, B, -1).sum(0)
+    x, g = x_out.clone(), g_x.clone()
+    aq = (g_logp * qw).repeat(N)[:, None] if entropy else 0.0               # row r = n B + b
+    for ci in range(ncoup - 1, -1, -1):
+        m = mask[ci]
+        s, t = torch.tanh(o_pre[2 * ci, :, :dim]), o_pre[2 * ci + 1, :, :dim]
+        es = torch.exp(s)
+        xi = torch.where(m == 0, (x - t) / es, x)
+        vs = torch.where(m == 0, (g * xi * es - aq) * (1 - s * s), torch.zeros_like(g))
+        vt = torch.where(m == 0, g, torch.zeros_like(g))
+        gp = torch.where(m == 0, g * es, g)
+        assert_close(XPb[ci, :, :dim].float().cpu(), bf(x * m).float().cpu(), 1e-2, what=f"masked input {ci}")
+        gx = torch.zeros(R, dim, device="cuda")
+        for n, v in enumerate((vs, vt)):
+            k = 2 * ci + n
+            assert_close(GOb[k, :, :dim].float().cpu(), bf(v).float().cpu(), 1e-2, what=f"GO {k}")
+            assert_close(db2[k, :dim].cpu(), v.sum(0).cpu(), 1e-3, what=f"l2 bias gradient {k}")
+            GO = torch.zeros(R, 64, device="cuda"); GO[:, :dim] = bf(v).float()
+            G2 = lre(GO @ w2T[k].float().t(), h2[k])
+            assert_close(G2b[k].float().cpu(), bf(G2).float().cpu(), 1e-2, what=f"G2 {k}")
+            assert_close(Gc[:, (2 * k + 1) * h:(2 * k + 2) * h].cpu(), img(G2).cpu(), 1e-2, what=f"cond gradient, layer 1 of net {k}")
+            G1 = lre(bf(G2).float() @ w1T[k].float().t(), h1[k])
+            assert_close(G1b[k].float().cpu(), bf(G1).float().cpu(), 1e-2, what=f"G1 {k}")
+            assert_close(Gc[:, 2 * k * h:(2 * k + 1) * h].cpu(), img(G1).cpu(), 1e-2, what=f"cond gradient, layer 0 of net {k}")
+            gx += (bf(G1).float() @ w0T[k].float().t())[:, :dim]
+        g = gp + m * gx
+        x = xi
+    assert_close(z0.cpu(), x.cpu(), 2e-5, what="recovered base sample")
+    assert float(Gc[:, 4 * ncoup * h:].abs().max()) == 0
