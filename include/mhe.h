@@ -460,6 +460,17 @@ int mhe_flow_mask_pad_mixed(const float *x, const float *mask, float *xp, void *
  * [out][k] at ((out / 16 * (K / 32) + k / 32) * 64 + (k % 32 / 8) * 16 + out % 16) * 8 + k % 8, the order the lanes of
  * v_mfma_f32_16x16x32_bf16 take them, so a fragment is one 1 KiB run; net k at + k * w_net_stride elements. */
 int mhe_flow_reverse_chain_supported(int R, int B, int dim, int hidden, int ncoup);
+/* mhe_flow_couplings_bf16 / _emit on the fragment-streaming skeleton (csrc/flow_fwd.hip): hidden 512, a multiple of 64 hypotheses per
+ * image (R % (64 B) == 0; a workgroup = 64 rows of one image), at most 32 couplings.  Same results as mhe_flow_couplings_bf16 up to the
+ * order of the f32 accumulation.  w0F, w1F, w2F = net 0's W0 [512][64 (dim zero-padded)], W1 [512][512], W2 [64 (padded)][512] as bf16 in
+ * FRAGMENT-MAJOR order (see mhe_flow_reverse_chain_bf16), net k at + k * w_net_stride elements; cond [B][cond_stride] with column
+ * (2 net + layer) * 512 + unit; bias2 [nets][64].  h1, h2, o: all three or none - the activations the reverse pass reads
+ * (bf16 [nets][R][512] x 2, f32 [nets][R][64]). */
+int mhe_flow_couplings_frag_supported(int R, int B, int dim, int hidden, int ncoup);
+int mhe_flow_couplings_frag_bf16(const float *in, float *out, const float *cond, int cond_stride, const void *w0F, const void *w1F,
+                                 const void *w2F, long w_net_stride, const float *bias2, const float *mask, float *sum_s,
+                                 float *log_prob, void *h1, void *h2, float *o, int R, int B, int dim, int hidden, int ncoup,
+                                 int direction, void *stream);
 int mhe_flow_reverse_chain_bf16(const float *x_out, const float *g_x, const float *g_logp, float q_weight, const float *mask,
                                 const float *o_pre, const void *h1, const void *h2, const void *w2F, const void *w1F,
                                 const void *w0F, long w_net_stride, void *GO_bf16, void *G2_bf16, void *G1_bf16, void *XP_bf16,

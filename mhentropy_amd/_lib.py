@@ -98,6 +98,8 @@ SIGNATURES = {
     "mhe_conv_wgrad_batched_workspace_floats": (_sz, [_p, _i]),
     "mhe_conv_wgrad_batched_nhwc": (_i, [_p, _i, _p, _l, _p, _l, _p, _l, _i, _p, _sz, _p]),
     "mhe_flow_reverse_chain_supported": (_i, [_i, _i, _i, _i, _i]),
+    "mhe_flow_couplings_frag_supported": (_i, [_i, _i, _i, _i, _i]),
+    "mhe_flow_couplings_frag_bf16": (_i, [_p, _p, _p, _i, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mhe_flow_reverse_chain_bf16": (_i, [_p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _i, _p, _l, _p, _i, _i, _i, _i, _i, _p]),
     "mhe_pack_transpose_bf16": (_i, [_p, _l, _p, _p, _i, _i, _p]),
     "mhe_gram_stats_floats": (_sz, [_i]),

@@ -19,29 +19,14 @@
 // change to / from the accumulator layout through the wave's own k-tile; the weight operands are FRAGMENT-MAJOR copies of the train step's
 // bf16 packs (w2F from W2^T [512][64], w1F from W1^T [512][512], w0F from W0^T [64][512]; see frag()), one pitch apart from net to net.
 // The kernel is bound by the L2 -> register weight stream (640 KiB per net and workgroup, as the forward kernel's), not by its 0.5 TFLOP.
-#include "common.h"
+#include "flow_frag.h"
 #include "../../include/mhe.h"
 
 namespace mhe { namespace flowrev {
 
-constexpr int H = 512, ROWS = 64, XP = 64, XG = 68, KT = H / 64;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
+using namespace flowfrag;
 
-__device__ __forceinline__ int swz(int row, int slot) { return row * 8 + (slot ^ ((row >> 1) & 7)); }
-__device__ __forceinline__ v4f mfma(const uint4 &a, const uint4 &b, v4f c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
-}
-// sum over the 16 lanes of a DPP row (the lanes that share q): quad butterflies, then the row rotated by 4 and by 8 - four v_add_f32_dpp,
-// where __shfl_xor lowered to four dependent ds_bpermute round trips per value (64 per epilogue; 0.5 ms of the first version's 2.4)
-template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
-    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float row16_sum(float v) {
-    v = dpp_add<0xB1>(v);                                 // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E>(v);                                 // quad_perm [2,3,0,1]
-    v = dpp_add<0x124>(v);                                // row_ror:4
-    return dpp_add<0x128>(v);                             // row_ror:8
-}
+constexpr int H = 512, ROWS = 64, XP = 64, XG = 68, KT = H / 64;
 struct Args {
     const float *x_out, *g_x, *g_logp, *mask, *oe;       // [R][dim], [R][dim], [B] | NULL, [ncoup][dim], [nets][R][64]
     const u16 *h1e, *h2e;                                 // [nets][R][512]
@@ -53,27 +38,6 @@ struct Args {
     int R, B, dim, ncoup, cstride;
     float q_weight;
 };
-
-// fragment-major operand: the 16-byte piece lane (q, l15) feeds to the MFMA of (row tile t, k step ks) lies at ((t * KS + ks) * 64 + lane) * 8,
-// so one wave-instruction reads 1 KiB in a row (from plain [row][k] storage the 64 lanes of a fragment load are 64 separate 16-byte requests
-// to 16 rows: the weight stream of the first version of this kernel ran at 30 GB/s per CU)
-// Global traffic goes through buffer instructions: one lane-dependent VGPR byte offset per access shape, everything else (net, row piece,
-// fragment) a scalar offset - as flat addresses hipcc built a 64-bit VGPR pair per access, hoisted them out of the coupling loop and spilled
-// over three hundred registers.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-__device__ __forceinline__ rsrc_t rsrc_of(const void *p, size_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)(bytes > 0xffffffffu ? 0xffffffffu : bytes), 0x00020000);
-}
-__device__ __forceinline__ uint4 bld(rsrc_t r, unsigned voff, unsigned soff) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
-    return make_uint4(v[0], v[1], v[2], v[3]);
-}
-__device__ __forceinline__ void bst(rsrc_t r, unsigned voff, unsigned soff, const uint4 &v) {
-    const u32x4 t = {v.x, v.y, v.z, v.w};
-    __builtin_amdgcn_raw_buffer_store_b128(t, r, (int)voff, (int)soff, 0);
-}
-__device__ __forceinline__ uint4 frag(rsrc_t r, unsigned lane16, int t, int KS, int ks) { return bld(r, lane16, (unsigned)(t * KS + ks) * 1024u); }
 
 __global__ __launch_bounds__(512) void chain_kernel(const Args a) {
     __shared__ uint4 act[KT * ROWS * 8];                  // 64 KiB: G2, then G1, as eight [64 rows][64 units] k-tiles (16-byte chunks swizzled)

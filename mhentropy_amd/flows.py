@@ -13,6 +13,8 @@ sample-major rows (row r uses cond[r % B]); with R rows of cond it is exactly
 the reference's call (`feat.repeat(N,1)`, hand/network.py:734).  The
 conditioning projections c0/c1 are then evaluated once per image.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -78,14 +80,23 @@ class RealNVP(nn.Module):
             if bf16:                      # the bf16 kernel wants l2.bias zero-padded to 64 per net
                 b2 = torch.nn.functional.pad(b2, (0, 64 - b2.shape[1]))
             wc = torch.cat(wc).contiguous()
+            fragp = None
+            if bf16 and self.hidden == 512:       # the same weights in MFMA fragment order: operands of the fragment-streaming kernel
+                per = []
+                for i in range(len(self.mask)):
+                    for net in (self.s[i], self.t[i]):
+                        per.append(torch.cat([f.reshape(-1) for f in ops.flow_frag_pack(*(l.weight.detach() for l in net.l))]))
+                fp = torch.stack(per).to(torch.bfloat16).to(dev).contiguous()              # [nets][W1 | W0 | W2 fragments]
+                hh = self.hidden
+                fragp = (fp[0, hh * hh:], fp[0], fp[0, hh * hh + 64 * hh:], fp.shape[1], fp)   # net 0's w0F, w1F, w2F, the net pitch (+ owner)
             self._pack = (ver, torch.from_numpy(stream).to(dev), b2.contiguous(), wc, torch.cat(bc).contiguous(),
-                          wc.to(torch.bfloat16) if bf16 and wc.shape[1] % 64 == 0 else None)
+                          wc.to(torch.bfloat16) if bf16 and wc.shape[1] % 64 == 0 else None, fragp)
         return self._pack[1:]
 
     def _cond_table(self, cond):
         """(B, F) features -> (B, 2*ncoup, 2, hidden): c_j(feat) + c_j.bias + l_j.bias per net.  In the bf16 mode the product takes
         bf16 operands like the nets' own layers do (f32 accumulation and bias; 23 us against 117 us for the f32 form at C2)."""
-        _, _, wc, bc, wcb = self._packed()
+        _, _, wc, bc, wcb = self._packed()[:5]
         if wcb is not None:
             cb = getattr(cond, "_mhe_bf16", None)            # left by BasicEnc's l1 launch (same values, no cast launch)
             if cb is None or cb.shape != cond.shape:
@@ -101,7 +112,13 @@ class RealNVP(nn.Module):
         R, B = v.shape[0], cond.shape[0]
         if R % B:
             raise ValueError(f"flow rows ({R}) must be a multiple of conditioning rows ({B})")
-        wstream, b2 = self._packed()[:2]
+        pk = self._packed()
+        wstream, b2 = pk[:2]
+        fragp = pk[5] if len(pk) > 5 else None
+        if (fragp is not None and os.environ.get("MHE_FLOW_FRAG", "1") == "1"
+                and ops.flow_couplings_frag_supported(R, B, v.shape[1], self.hidden, len(self.mask))):
+            return ops.flow_couplings_frag(v.contiguous(), self._cond_table(cond), fragp[0], fragp[1], fragp[2], fragp[3], b2, self.mask, B,
+                                           self.hidden, direction)
         return ops.flow_couplings(v.contiguous(), self._cond_table(cond), wstream, b2, self.mask, B, self.hidden, direction)
 
     # ---- reference call surface ------------------------------------------------

@@ -203,6 +203,42 @@ def flow_couplings_emit(x_in, cond, wstream, bias2, mask, B, hidden, direction, 
     return out, sum_s, logp
 
 
+def flow_couplings_frag_supported(R, B, dim, hidden, ncoup):
+    return bool(_lib.lib().mhe_flow_couplings_frag_supported(R, B, dim, hidden, ncoup))
+
+
+def flow_frag_pack(w0, w1, w2):
+    """one net's layer weights (torch [h, dim], [h, h], [dim, h]; or index tensors of those shapes) -> (w1F, w0F, w2F) in MFMA fragment order,
+    dim zero-padded (index tensors: -1) to 64 - the operands of mhe_flow_couplings_frag_bf16"""
+    h, dim = w0.shape
+    fill = -1 if not w0.is_floating_point() else 0
+    w0p = torch.full((h, 64), fill, dtype=w0.dtype, device=w0.device); w0p[:, :dim] = w0
+    w2p = torch.full((64, h), fill, dtype=w2.dtype, device=w2.device); w2p[:dim] = w2
+    return mfma_fragment_major(w1), mfma_fragment_major(w0p), mfma_fragment_major(w2p)
+
+
+def flow_couplings_frag(x_in, cond, w0F, w1F, w2F, w_net_stride, bias2, mask, B, hidden, direction, want_log_prob=True, emit=None):
+    """flow_couplings / flow_couplings_emit (emit = (h1, h2, o)) on the fragment-streaming kernel (mhe_flow_couplings_frag_bf16)"""
+    R, dim = x_in.shape
+    ncoup = mask.shape[0]
+    _chk(x_in, torch.float32, "flow.in"); _chk(cond, torch.float32, "flow.cond", (B, 2 * ncoup, 2, hidden))
+    _chk(bias2, torch.float32, "flow.bias2", (2 * ncoup, 64)); _chk(mask, torch.float32, "flow.mask", (ncoup, dim))
+    for t, nm in ((w0F, "w0F"), (w1F, "w1F"), (w2F, "w2F")):
+        _chk(t, torch.bfloat16, "flow." + nm)
+    h1 = h2 = o = None
+    if emit is not None:
+        h1, h2, o = emit
+        _chk(h1, torch.bfloat16, "flow.h1", (2 * ncoup, R, hidden)); _chk(h2, torch.bfloat16, "flow.h2", (2 * ncoup, R, hidden))
+        _chk(o, torch.float32, "flow.o", (2 * ncoup, R, 64))
+    out = torch.empty_like(x_in)
+    sum_s = torch.empty(R, device=x_in.device, dtype=torch.float32)
+    logp = torch.empty(R, device=x_in.device, dtype=torch.float32) if want_log_prob else None
+    check(_lib.lib().mhe_flow_couplings_frag_bf16(_ptr(x_in), _ptr(out), _ptr(cond), 4 * ncoup * hidden, _ptr(w0F), _ptr(w1F), _ptr(w2F),
+                                                  int(w_net_stride), _ptr(bias2), _ptr(mask), _ptr(sum_s), _ptr(logp), _ptr(h1), _ptr(h2), _ptr(o),
+                                                  R, B, dim, hidden, ncoup, direction, _stream()), "mhe_flow_couplings_frag_bf16")
+    return out, sum_s, logp
+
+
 def mano_joints(th45, det, tables, crop_uv=None, vis=None, laplace_b=0.03, th45_alpha=50.0, inv_norm=False,
                 image_size=256.0, want=("z", "xyz", "uv", "terms", "log_p", "norms")):
     """want may also include "joints_mm"."""

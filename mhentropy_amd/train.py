@@ -159,7 +159,10 @@ class TrainStep:
         # optimizer step - no host re-pack, never stale
         self.repack()
         if self.glow is None:
-            self.flow._external_pack = (self.f_stream, self.f_b2, self.f_wc, self.f_bc, self.f_wcb)
+            f0 = self.fnets[0]
+            fragp = ((f0["f0F"], f0["f1F"], f0["f2F"], (self.fnets[1]["f1F"].data_ptr() - f0["f1F"].data_ptr()) // 2)
+                     if "f1F" in f0 and len(self.fnets) > 1 else None)
+            self.flow._external_pack = (self.f_stream, self.f_b2, self.f_wc, self.f_bc, self.f_wcb, fragp)
             self.flow._external_sync = self.sync
         self.trunk._external_w = {id(u.conv.weight): u.w_fwd for u in self.units}
         self.trunk._external_sync = self.sync
@@ -411,6 +414,10 @@ class TrainStep:
                     d["w1Fb"] = self._derived(ops.mfma_fragment_major(self._pidx(net.l[1].weight).t()), torch.bfloat16)
                     d["w2Fb"] = self._derived(ops.mfma_fragment_major(w2i.t()), torch.bfloat16)
                     d["w0Fb"] = self._derived(ops.mfma_fragment_major(w0i.t()), torch.bfloat16)
+                    # ... and the forward's own operands W1 [out][in], W0 (padded) [h][64], W2 (padded) [64][h] (csrc/flow_fwd.hip)
+                    d["f1F"] = self._derived(ops.mfma_fragment_major(self._pidx(net.l[1].weight)), torch.bfloat16)
+                    d["f0F"] = self._derived(ops.mfma_fragment_major(w0i), torch.bfloat16)
+                    d["f2F"] = self._derived(ops.mfma_fragment_major(w2i), torch.bfloat16)
                 d["w2"], d["w2T"] = self._derived(w2i, torch.float32), self._derived(w2i.t().contiguous(), torch.float32)
                 d["b2"] = self._derived(b2i, torch.float32)
                 d["r0"], d["r1"], d["r2"], d["rb2"] = (self._raw_slot(s) for s in ((h, 64), (h, h), (64, h), (64,)))
@@ -844,7 +851,13 @@ class TrainStep:
                 Rr = N * B
                 kept = (self._buf("fl_h1", (2 * ncoup, Rr, h), torch.bfloat16), self._buf("fl_h2", (2 * ncoup, Rr, h), torch.bfloat16),
                         self._buf("fl_o", (2 * ncoup, Rr, 64)))
-                th45, _, log_q = ops.flow_couplings_emit(z0, cond, self.f_stream, self.f_b2, fl.mask, B, h, ops.FLOW_FORWARD, *kept)
+                f0 = self.fnets[0]
+                if (os.environ.get("MHE_FLOW_FRAG", "1") == "1" and "f1F" in f0 and ops.flow_couplings_frag_supported(Rr, B, z0.shape[1], h, ncoup)):
+                    wst = (self.fnets[1]["f1F"].data_ptr() - f0["f1F"].data_ptr()) // 2
+                    th45, _, log_q = ops.flow_couplings_frag(z0, cond, f0["f0F"], f0["f1F"], f0["f2F"], wst, self.f_b2, fl.mask, B, h,
+                                                             ops.FLOW_FORWARD, emit=kept)
+                else:
+                    th45, _, log_q = ops.flow_couplings_emit(z0, cond, self.f_stream, self.f_b2, fl.mask, B, h, ops.FLOW_FORWARD, *kept)
                 self._flow_kept = kept
             else:
                 th45, _, log_q = ops.flow_couplings(z0, cond, self.f_stream, self.f_b2, fl.mask, B, h, ops.FLOW_FORWARD)

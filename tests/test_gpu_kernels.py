@@ -498,3 +498,71 @@ def test_flow_reverse_chain_against_a_plain_torch_reverse_pass(gpu_lib, B, ncoup
         x = xi
     assert_close(z0.cpu(), x.cpu(), 2e-5, what="recovered base sample")
     assert float(Gc[:, 4 * ncoup * h:].abs().max()) == 0
+
+
+def _frag_state(sd, steps, h=512):
+    """numpy state_dict -> (w0F, w1F, w2F, pitch, bias2 [nets][64], Wc, bc) as mhe_flow_couplings_frag_bf16 wants them"""
+    from mhentropy_amd import ops
+    per, b2, wc, bc = [], [], [], []
+    for i in range(2 * steps):
+        for net in ("s", "t"):
+            p = f"{net}.{i}."
+            f1, f0, f2 = ops.flow_frag_pack(*(torch.as_tensor(sd[p + f"l.{j}.weight"]) for j in range(3)))
+            per.append(torch.cat([f1.reshape(-1), f0.reshape(-1), f2.reshape(-1)]))
+            b2.append(sd[p + "l.2.bias"])
+            for j in range(2):
+                wc.append(sd[p + f"c.{j}.weight"]); bc.append(sd[p + f"c.{j}.bias"] + sd[p + f"l.{j}.bias"])
+    fp = torch.stack(per).to(torch.bfloat16).cuda().contiguous()
+    return (fp[0, h * h:], fp[0], fp[0, h * h + 64 * h:], fp.shape[1], _dev(np.pad(np.stack(b2), ((0, 0), (0, 64 - 45)))),
+            _dev(np.concatenate(wc)), _dev(np.concatenate(bc)), fp)
+
+
+@pytest.mark.parametrize("steps,B,N", [(6, 3, 64), (2, 5, 128), (1, 2, 64)])
+def test_flow_fragment_streaming_kernel_vs_bf16_rounding_oracle(gpu_lib, steps, B, N):
+    """mhe_flow_couplings_frag_bf16 (csrc/flow_fwd.hip; hidden 512, 64 rows of one image per workgroup) against the oracle with the same
+    rounding points, against the second-generation kernel, both directions, run-to-run identical.  Tolerance as for that kernel: a
+    flipped bf16 rounding of one hidden unit moves an output by ~1e-3 of its scale -> 1e-2."""
+    from mhentropy_amd import ops
+    from oracle import flows_ref
+    h = 512
+    sd = synth.flow_state(9, 45, 512, (h, h), steps)
+    ncoup = 2 * steps
+    w0F, w1F, w2F, pitch, b2d, wc, bc, _own = _frag_state(sd, steps)
+    rng = np.random.default_rng(2)
+    feat = rng.normal(0, 1, (B, 512)).astype(np.float32)
+    z0 = rng.normal(0, 1, (N * B, 45)).astype(np.float32)
+    R = N * B
+    assert ops.flow_couplings_frag_supported(R, B, 45, h, ncoup) and not ops.flow_couplings_frag_supported(R + B, B, 45, h, ncoup)
+    cond = ops.linear(_dev(feat), wc, bc).view(B, 2 * ncoup, 2, h)
+    mask = _dev(sd["mask"])
+    x, sum_s, logq = ops.flow_couplings_frag(_dev(z0), cond, w0F, w1F, w2F, pitch, b2d, mask, B, h, ops.FLOW_FORWARD)
+    sdt = {k: torch.as_tensor(v) for k, v in sd.items()}
+    with torch.no_grad():
+        xr, tot = flows_ref.forward_p_logdet_bf16(sdt, torch.as_tensor(z0), torch.as_tensor(feat).repeat(N, 1))
+    assert_close(x.cpu(), xr, 1e-2, what="x")
+    assert_close(sum_s.cpu(), tot, 1e-2, 1e-2, what="sum s")
+    assert_close(logq.cpu(), flows_ref.std_normal_logprob(torch.as_tensor(z0)) - tot, 1e-2, what="log q")
+    zb, sum_s2, _ = ops.flow_couplings_frag(x, cond, w0F, w1F, w2F, pitch, b2d, mask, B, h, ops.FLOW_INVERSE)
+    assert_close(zb.cpu(), z0, 1e-2, what="inverse(forward(z)) == z")
+    assert_close(sum_s2.cpu(), sum_s.cpu(), 1e-2, 1e-2, what="same log-det both ways")
+    x2, s2, l2 = ops.flow_couplings_frag(_dev(z0), cond, w0F, w1F, w2F, pitch, b2d, mask, B, h, ops.FLOW_FORWARD)
+    assert torch.equal(x, x2) and torch.equal(sum_s, s2) and torch.equal(logq, l2), "run-to-run identical"
+    # the second-generation kernel on the same weights
+    packs = [ops.flow_pack_net_bf16(sd[f"{net}.{i}.l.0.weight"], sd[f"{net}.{i}.l.1.weight"], sd[f"{net}.{i}.l.2.weight"])
+             for i in range(ncoup) for net in ("s", "t")]
+    xo, so, lo = ops.flow_couplings(_dev(z0), cond, _dev(np.concatenate(packs).view(np.int16)), b2d, mask, B, h, ops.FLOW_FORWARD)
+    assert_close(x.cpu(), xo.cpu(), 1e-2, what="x vs mhe_flow_couplings_bf16")
+    assert_close(logq.cpu(), lo.cpu(), 1e-2, what="log q vs mhe_flow_couplings_bf16")
+    # the activations it writes out for the reverse pass: same results with them, and those of mhe_flow_couplings_bf16_emit
+    mk = lambda: (torch.zeros(2 * ncoup, R, h, device="cuda", dtype=torch.bfloat16), torch.zeros(2 * ncoup, R, h, device="cuda", dtype=torch.bfloat16),
+                  torch.zeros(2 * ncoup, R, 64, device="cuda"))
+    e1, e0 = mk(), mk()
+    xe, se, le = ops.flow_couplings_frag(_dev(z0), cond, w0F, w1F, w2F, pitch, b2d, mask, B, h, ops.FLOW_FORWARD, emit=e1)
+    assert torch.equal(xe, x) and torch.equal(se, sum_s) and torch.equal(le, logq)
+    ops.flow_couplings_emit(_dev(z0), cond, _dev(np.concatenate(packs).view(np.int16)), b2d, mask, B, h, ops.FLOW_FORWARD, *e0)
+    # (first coupling: identical inputs -> agreement to a bf16 ulp where a rounding flips; the whole chain to the kernel tolerance)
+    for net in range(2):
+        assert_close(e1[0][net].float().cpu(), e0[0][net].float().cpu(), 8e-3, what=f"h1 net {net}")
+        assert_close(e1[1][net].float().cpu(), e0[1][net].float().cpu(), 8e-3, what=f"h2 net {net}")
+    assert_close(e1[2][:, :, :45].cpu(), e0[2][:, :, :45].cpu(), 1e-2, what="s / t pre-activations, all nets")
+    assert float(e1[2][:, :, 45:].abs().max()) == 0
