@@ -663,6 +663,8 @@ int launch_tail(const Params &p, hipStream_t s);
 static int choose_tile(const Params &p, bool fast, bool bf16) {
     static const int env_force = getenv("MHE_CONV_TILE") ? atoi(getenv("MHE_CONV_TILE")) : -1;    // tuning knob
     const int force = p.force >= 0 ? p.force : env_force;
+    // data-gradient form with a per-channel constant (mhe_conv2d_masked_bias_nhwc): the kernels with the shared epilogue only
+    if (p.mask && p.out_shift) return force == 0 || (force < 0 && p.Cout <= 64) ? 0 : 1;
     static const int env_stream = getenv("MHE_CONV_STREAM") ? atoi(getenv("MHE_CONV_STREAM")) : 1;
     if (bf16 && (force == 8 || (force < 0 && env_stream)) && stream_supports(p)) return 8;
     if (bf16 && (force == 9 || (force < 0 && env_stream)) && stream3_supports(p)) return 9;
@@ -800,6 +802,16 @@ extern "C" int mhe_conv2d_masked_nhwc(const mhe_conv_desc *d, const void *x, con
                 "mhe_conv2d_masked_nhwc: each bn_y needs its mean_invstd and stats (and bn_y1 needs bn_y0)");
     const BnRev bn = {{bn_y0, bn_y1}, {bn_mean_invstd0, bn_mean_invstd1}, {bn_stats0, bn_stats1}};
     return conv_entry(d, x, w, y, nullptr, nullptr, nullptr, nullptr, residual, nullptr, nullptr, nullptr, nullptr, nullptr, stream, mask, &bn);
+}
+
+extern "C" int mhe_conv2d_masked_bias_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const void *residual,
+                                           const void *mask, const float *bias, const void *bn_y0, const float *bn_mean_invstd0,
+                                           float *bn_stats0, void *stream) {
+    MHE_REQUIRE(mask && bias, "mhe_conv2d_masked_bias_nhwc: mask and bias are required");
+    MHE_REQUIRE(!bn_y0 || (bn_mean_invstd0 && bn_stats0), "mhe_conv2d_masked_bias_nhwc: bn_y needs its mean_invstd and stats");
+    MHE_REQUIRE(d && (d->tile == 0 || d->tile == 1 || d->tile == 2), "mhe_conv2d_masked_bias_nhwc: 128-row register-staged tiles only (tile 0, 1 or 2)");
+    const BnRev bn = {{bn_y0, nullptr}, {bn_mean_invstd0, nullptr}, {bn_stats0, nullptr}};
+    return conv_entry(d, x, w, y, nullptr, nullptr, nullptr, bias, residual, nullptr, nullptr, nullptr, nullptr, nullptr, stream, mask, &bn);
 }
 
 extern "C" int mhe_conv3x3s2_dgrad_nhwc(int B, int Ho, int Wo, int Cout, int Cin, int dtype, const void *gy, const void *const *w4,

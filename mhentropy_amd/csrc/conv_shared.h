@@ -210,6 +210,12 @@ __device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, 
         static_assert(NTH % CPR == 0, "a thread keeps one 16-byte column chunk across its rows");
         float bs1[DG ? 2 : 1][EPC], bs2[DG ? 2 : 1][EPC], bmu[DG ? 2 : 1][EPC], biv[DG ? 2 : 1][EPC];
         const int cfix = tid % CPR;
+        // per-channel constant of the data-gradient form (out_shift without out_scale: mhe_conv2d_masked_bias_nhwc), added before the gate
+        float bsh[DG ? EPC : 1];
+        if constexpr (DG) {
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) bsh[i] = p.out_shift && n0 + cfix * EPC + i < p.Cout ? p.out_shift[n0 + cfix * EPC + i] : 0.f;
+        }
         if constexpr (DG) if (bnr) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
@@ -236,7 +242,7 @@ __device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, 
         for (int i = 0; i < EPC; ++i) ss1[i] = ss2[i] = 0.f;
         bool done = false;
         if constexpr (DG) {
-            if (mk && pix(0) >= 0 && pix(BM - 1) >= 0 && n0 + BN <= p.Cout && !p.out_scale && !p.out_shift && !p.relu_out) {
+            if (mk && pix(0) >= 0 && pix(BM - 1) >= 0 && n0 + BN <= p.Cout && !p.out_scale && !p.relu_out) {
                 done = true;
                 const int nbn = bnr ? (p.bn_y[1] ? 2 : 1) : 0;
                 const T *y0g = reinterpret_cast<const T *>(p.bn_y[0]), *y1g = reinterpret_cast<const T *>(p.bn_y[1]);
@@ -271,6 +277,8 @@ __device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, 
                         for (int g = 0; g < G; ++g) {
                             float v[EPC], t[EPC];
                             Chunk<T>::unpack(raw[g], v);
+#pragma unroll
+                            for (int i = 0; i < EPC; ++i) v[i] += bsh[i];
                             if constexpr (HAS_RES) {
                                 Chunk<T>::unpack(rr[g], t);
 #pragma unroll

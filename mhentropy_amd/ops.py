@@ -356,9 +356,19 @@ def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in
         _chk(stats, torch.float32, "conv.stats", (stat_shards(), 2, Cout))
     d = ConvDesc(B, H, W, Cin, Cout, KH, KW, stride, pad, dtype_code(dt), int(relu_in), int(relu_out), int(tile), int(res_half))
     if mask is not None:
-        if in_scale is not None or out_scale is not None or out_shift is not None or stats is not None or relu_in or relu_out:
-            raise ValueError("conv2d_nhwc: mask= is the plain data-gradient form (no affine / statistics / relu)")
+        if in_scale is not None or out_scale is not None or stats is not None or relu_in or relu_out:
+            raise ValueError("conv2d_nhwc: mask= is the plain data-gradient form (no affine / statistics / relu; out_shift = a per-channel constant)")
         _chk(mask, dt, "conv.mask", (B, Ho, Wo, Cout))
+        if out_shift is not None:        # y = (conv + out_shift + residual) [mask > 0], one consumer's sums at most
+            if bn is not None and len(bn) > 1:
+                raise ValueError("conv2d_nhwc: out_shift= with mask= takes one bn consumer")
+            by, bmi, bst = (list(bn or []) + [(None, None, None)])[0]
+            if by is not None:
+                _chk(by, dt, "conv.bn_y", (B, Ho, Wo, Cout)); _chk(bmi, torch.float32, "conv.bn_mean_invstd", (2, Cout))
+                _chk(bst, torch.float32, "conv.bn_stats", (stat_shards(), 2, Cout))
+            check(_lib.lib().mhe_conv2d_masked_bias_nhwc(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _ptr(residual), _ptr(mask), _ptr(out_shift), _ptr(by),
+                                                         _ptr(bmi), _ptr(bst), _stream()), "mhe_conv2d_masked_bias_nhwc")
+            return y
         ext = []
         for by, bmi, bst in (list(bn or []) + [(None, None, None)] * 2)[:2]:
             if by is not None:
@@ -435,6 +445,26 @@ def conv1x1_gram_bn(x, in_scale, in_shift, w, bn_weight, bn_bias, running_mean, 
                                  _ptr(shift), _ptr(mi), Cn, Cb, float(B * H * W), float(momentum), float(eps), _ptr(num_batches_tracked), _stream()),
           "mhe_gram_bn_finalize")
     return (scale, shift, mi) if want_mean_invstd else (scale, shift)
+
+
+def gram_workspace(Cb, device):
+    """an f64 workspace of conv1x1_gram_bn of one's own (its totals - Gram matrix [Cb][Cb], then column sums [Cb] - stay valid until reused)"""
+    return torch.empty(_lib.lib().mhe_gram_stats_workspace_bytes(Cb) // 8, device=device, dtype=torch.float64)
+
+
+def conv3_bn_fold(D, w, gram_totals, rev_stats, gamma, mean_invstd, count, dgamma, dbeta, dW, w_dg, S, c0, coef_ws):
+    """reverse of conv3 + train-mode BatchNorm from D = g^T A and the forward's Gram statistics (mhe_conv3_bn_fold; csrc/conv_fold.hip)"""
+    Cn, Cb = w.shape
+    _chk(D, torch.float32, "fold.D", (Cn, Cb)); _chk(w, torch.bfloat16, "fold.w", (Cn, Cb)); _chk(gram_totals, torch.float64, "fold.gram")
+    _chk(rev_stats, torch.float32, "fold.rev_stats", (stat_shards(), 2, Cn)); _chk(gamma, torch.float32, "fold.gamma", (Cn,))
+    _chk(mean_invstd, torch.float32, "fold.mean_invstd", (2, Cn)); _chk(dgamma, torch.float32, "fold.dgamma", (Cn,)); _chk(dbeta, torch.float32, "fold.dbeta", (Cn,))
+    _chk(dW, torch.float32, "fold.dW"); _chk(w_dg, torch.bfloat16, "fold.w_dg"); _chk(S, torch.bfloat16, "fold.S", (Cb, Cb))
+    _chk(c0, torch.float32, "fold.c0", (Cb,)); _chk(coef_ws, torch.float32, "fold.coef_ws")
+    if gram_totals.numel() < Cb * Cb + Cb or dW.numel() < Cn * Cb or w_dg.shape[0] != Cb or w_dg.shape[1] < Cn or coef_ws.numel() < 2 * Cn:
+        raise ValueError("conv3_bn_fold: operand sizes")
+    check(_lib.lib().mhe_conv3_bn_fold(_ptr(D), _ptr(w), _ptr(gram_totals), _ptr(rev_stats), _ptr(gamma), _ptr(mean_invstd), float(count), _ptr(dgamma),
+                                       _ptr(dbeta), _ptr(dW), _ptr(w_dg), int(w_dg.shape[1]), _ptr(S), _ptr(c0), _ptr(coef_ws), Cn, Cb, _stream()),
+          "mhe_conv3_bn_fold")
 
 
 def bottleneck_tail_supported(B, H, W, Cb, Cout):

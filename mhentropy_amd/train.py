@@ -136,6 +136,8 @@ class TrainStep:
         self._build_flow()
         # BatchNorm-reverse sums accumulated by the data-gradient epilogues (no separate reduce pass); MHE_BN_REDUCE_FUSED=0: separate pass
         self.fuse_bn_reduce = os.environ.get("MHE_BN_REDUCE_FUSED", "1") == "1"
+        self.train_recompute = os.environ.get("MHE_TRAIN_RECOMPUTE", "1") == "1"
+        self.conv3_fold = os.environ.get("MHE_CONV3_FOLD", "1") == "1"
         # the stem's BatchNorm + ReLU folded into its max pool, forward and reverse (ops.maxpool3x3s2_idx / maxpool3x3s2_bwd_bn)
         self.stem_pool_fused = os.environ.get("MHE_STEM_POOL_FUSED", "1") == "1"
         self.bn_on_load_wide = os.environ.get("MHE_BN_BWD_ON_LOAD_WIDE", "1") == "1"
@@ -515,7 +517,22 @@ class TrainStep:
         fuse = self.trunk.fuse_tail
         for bi, b in enumerate(self.blocks):
             us = b["u"]
-            if pending is not None:
+            if pending is not None and isinstance(pending[0], str):
+                # ... with the previous block's conv3 evaluated again inside the same kernel: its raw output was never written (the reverse
+                # pass evaluates it once more when it gets there, _ensure_y)
+                _, y2_p, bn2_p, ul_p, idt_p, ud_p = pending
+                u0 = us[0]
+                st = pool.take(u0.cout)
+                a, y = ops.bottleneck_tail(y2_p, bn2_p, ul_p.w_fwd, (ul_p.scale, ul_p.shift), idt_p,
+                                           None if ud_p is None else (ud_p.scale, ud_p.shift), u0.w_fwd, stats=st)
+                self._bn_tape(u0, a, y, st)
+                self.blocks[bi - 1]["out"] = a
+                pending = None
+                b["a"] = a
+                h = ops.bn_act(y, u0.scale, u0.shift, relu=True)
+                b["acts"] = [h]
+                rest = us[1:-1]
+            elif pending is not None:
                 # relu(bn3(y3) + identity) of the previous block is evaluated inside this conv1's operand load, which also
                 # writes it out once (this block's input / identity and the reverse pass's ReLU mask): one read of the widest
                 # tensor of the block saved, as in the inference path (resnet.py)
@@ -542,10 +559,37 @@ class TrainStep:
                 h = ops.bn_act(y, u.scale, u.shift, relu=True)
                 b["acts"].append(h)
             ul = us[-1]
-            yl = self._unit_fwd(ul, h, pool)
+            nxt = self.blocks[bi + 1] if bi + 1 < len(self.blocks) else None
+            # layer1 / layer2 bottlenecks (bf16, 64 / 128 bottleneck channels): conv3 is not run here at all - bn3's batch statistics come
+            # from the Gram matrix of its input, the tail kernel of the next block evaluates it on the fly (as the module's own forward
+            # does, resnet.py), and the reverse pass evaluates it once when it needs it: a write + a read of the block's widest tensor
+            # traded for one plain 1x1 launch in the reverse pass (MHE_TRAIN_RECOMPUTE=0: conv3 written in the forward pass)
+            recompute = (self.train_recompute and fuse and nxt is not None and nxt["kind"] == "bottleneck" and b["kind"] == "bottleneck"
+                         and len(us) == 3 and ul.k == 1 and ul.stride == 1 and h.dtype == torch.bfloat16 and us[-2].y is not None
+                         and nxt["u"][0].k == 1 and nxt["u"][0].stride == 1
+                         and ops.bottleneck_tail_supported(h.shape[0], h.shape[1], h.shape[2], h.shape[3], nxt["u"][0].cout))
+            if recompute:
+                u2, bn3 = us[-2], ul.bn
+                gbufs = pool.gram(ul.cin)
+                if self.conv3_fold:      # the Gram totals of THIS block stay for the reverse pass (csrc/conv_fold.hip)
+                    tot = self._ws.get(("gram_tot", bi))
+                    if tot is None:
+                        tot = self._ws[("gram_tot", bi)] = ops.gram_workspace(ul.cin, self.dev)
+                    gbufs, ul.gram_tot = (gbufs[0], tot), tot
+                else:
+                    ul.gram_tot = None
+                ul.scale, ul.shift, ul.mi = ops.conv1x1_gram_bn(u2.y, u2.scale, u2.shift, ul.w_fwd, bn3.weight.data, bn3.bias.data, bn3.running_mean,
+                                                                bn3.running_var, gbufs, BN_MOMENTUM, BN_EPS,
+                                                                num_batches_tracked=bn3.num_batches_tracked, want_mean_invstd=True)
+                ul.x, ul.y = h, None
+                yl = None
+            else:
+                yl = self._unit_fwd(ul, h, pool)
             ud = b["ud"]
             yd = self._unit_fwd(ud, b["a"], pool) if ud is not None else None
-            nxt = self.blocks[bi + 1] if bi + 1 < len(self.blocks) else None
+            if recompute:
+                pending = ("re", us[-2].y, (us[-2].scale, us[-2].shift), ul, yd if ud is not None else b["a"], ud)
+                continue
             if fuse and nxt is not None and nxt["kind"] == "bottleneck" and b["kind"] == "bottleneck":
                 pending = (yl, ul, yd if ud is not None else b["a"], ud)
                 continue
@@ -564,6 +608,14 @@ class TrainStep:
         return ops.bn_backward(g, a, u.y, u.mi, u.bn.weight.data, stats if stats is not None else pool.take(u.cout), u.dgamma, u.dbeta,
                                reduced=stats is not None)
 
+    def _ensure_y(self, u):
+        """the raw output of a unit whose forward launch was skipped (conv3 of a layer1 / layer2 bottleneck): evaluated now, bit-identical
+        to what the fused tail kernel worked with"""
+        if u.y is None:
+            u.y = ops.conv2d_nhwc(u.x, u.w_fwd, u.k, u.k, u.stride, u.pad)
+            u.y_recomputed = True
+        return u.y
+
     def _wgrad(self, u, gy):
         ops.conv_wgrad(u.x, gy, u.k, u.k, u.stride, u.pad, u.dw)
 
@@ -574,14 +626,18 @@ class TrainStep:
         bn = None
         if gate and consumers and self.fuse_bn_reduce:
             # the BatchNorm units that consume this gradient: their reverse sums are accumulated by this kernel's epilogue
-            bn = [(c.y, c.mi, pool.take(c.cout)) for c in consumers]
+            # (a unit whose raw output was never written and whose reverse runs on the Gram statistics, csrc/conv_fold.hip, needs sum g only:
+            # the gate tensor - same shape, read by this epilogue anyway - stands in for its output; the second sum is not used)
+            bn = [(c.y if c.y is not None else u.x, c.mi, pool.take(c.cout)) for c in consumers]
             for c, (_, _, st) in zip(consumers, bn):
                 c.rev_stats = st
+                c.rev_dummy = c.y is None
         return conv_dgrad(gy, u.w_dg, u.k, u.stride, u.pad, u.x.shape[1], u.x.shape[2], residual, u.x if gate else None, bn,
                           w_s2=getattr(u, "w_s2", None), res_half=res_half, coarse=coarse)
 
     def _trunk_backward(self, g_f):
         pool = resnet._StatsPool(self.dev, channels=65536)
+        self.n_fold = 0                 # blocks whose conv3 + bn3 were reversed on the Gram statistics in this pass
         B, Hh, Ww, Cc = self.a_last.shape
         # g is always the gradient w.r.t. the block output's PRE-ReLU value: the gate is applied where g is produced
         g = ops.avgpool_bwd(g_f, Hh * Ww, self.T, mask=self.a_last.view(B, Hh * Ww, Cc)).view(B, Hh, Ww, Cc)
@@ -591,6 +647,11 @@ class TrainStep:
                 self._grad_ready(self.blocks[bi + 1]["layer"] - 2)      # layer4 complete -> bucket 2, layer3 -> bucket 1
             us, ud = b["u"], b["ud"]
             ul = us[-1]
+            # conv3 + bn3 reversed on the forward's Gram statistics (layer1 / layer2, csrc/conv_fold.hip): neither y3 nor gy3 exists
+            fold = (ul.y is None and getattr(ul, "gram_tot", None) is not None and getattr(ul, "rev_stats", None) is not None
+                    and getattr(ul, "rev_dummy", False) and self.fuse_bn_reduce)
+            if not fold:
+                self._ensure_y(ul)
             # bottleneck conv3 (1x1, stride 1): its BatchNorm reverse is applied in the operand load of its own data gradient
             # (ops.conv1x1_dgrad_bn_apply) instead of by a pass over three block-wide tensors
             # (the register-staged kernel pays for it up to 128 bottleneck channels; the wide layers take it where the transfer-wave
@@ -598,7 +659,19 @@ class TrainStep:
             on_load = self.bn_apply_on_load and len(us) == 3 and ul.k == 1 and ul.stride == 1 and (
                 ul.cin <= self.bn_on_load_max_cin or (self.bn_on_load_wide and ops.conv_tile_choice(
                     g.shape[0], g.shape[1], g.shape[2], ul.cout, ul.cin, 1, 1, 0, g.dtype, 2) == 10))
-            if on_load:
+            if fold:
+                self.n_fold += 1
+                Cn, Cb = ul.cout, ul.cin
+                D = self._ws.get(("foldD", Cn, Cb))
+                if D is None:
+                    D = self._ws[("foldD", Cn, Cb)] = torch.zeros(Cn, Cb, device=self.dev)      # cleared by the fold kernel on its way out
+                ops.conv_wgrad(ul.x, g, 1, 1, 1, 0, D)
+                fw = (self._buf(f"fold_wdg{Cn}", (Cb, Cn), torch.bfloat16), self._buf(f"fold_S{Cb}", (Cb, Cb), torch.bfloat16),
+                      self._buf(f"fold_c0{Cb}", (Cb,)))
+                ops.conv3_bn_fold(D, ul.w_fwd, ul.gram_tot, ul.rev_stats, ul.bn.weight.data, ul.mi, g.numel() // Cn, ul.dgamma, ul.dbeta, ul.dw,
+                                  fw[0], fw[1], fw[2], self._buf(f"fold_coef{Cn}", (2 * Cn,)))
+                gy = None
+            elif on_load:
                 rs = getattr(ul, "rev_stats", None)
                 coef = ops.bn_backward(g, None, ul.y, ul.mi, ul.bn.weight.data, rs if rs is not None else pool.take(ul.cout), ul.dgamma,
                                        ul.dbeta, reduced=rs is not None, coef_only=True)
@@ -622,9 +695,15 @@ class TrainStep:
                     if self.fuse_bn_reduce:
                         cons.rev_stats = pool.take(cons.cout)
                         bn = [(cons.y, cons.mi, cons.rev_stats)]
-                    gy = torch.empty_like(g)
-                    ga = ops.conv1x1_dgrad_bn_apply(g, u.y, coef, u.w_dg, gy, u.x, bn, zeros=self._zeros_c[:u.cout])
-                    self._wgrad(u, gy)
+                    if fold:
+                        # gy3 W = g (k2 W) + A (W^T diag(k1) W) + k0^T W: the Cb x Cb product on conv3's input as the residual, the constant
+                        # as the bias of ONE data-gradient launch on g; the weight gradient came out of the fold
+                        t_res = ops.conv2d_nhwc(u.x, fw[1], 1, 1, 1, 0)
+                        ga = ops.conv2d_nhwc(g, fw[0], 1, 1, 1, 0, residual=t_res, mask=u.x, bn=bn, out_shift=fw[2])
+                    else:
+                        gy = torch.empty_like(g)
+                        ga = ops.conv1x1_dgrad_bn_apply(g, u.y, coef, u.w_dg, gy, u.x, bn, zeros=self._zeros_c[:u.cout])
+                        self._wgrad(u, gy)
                 else:
                     self._wgrad(u, gy)
                     ga = self._dgrad(u, gy, consumers=(us[j - 1],), pool=pool)
@@ -632,10 +711,14 @@ class TrainStep:
             self._wgrad(us[0], gy)
             first = bi == 0            # the first block's input is the max-pooled stem output (>= 0; the pool's reverse gates it)
             prev = self.blocks[bi - 1] if bi else None
+            if prev is not None and not (self.conv3_fold and self.fuse_bn_reduce and getattr(prev["u"][-1], "gram_tot", None) is not None):
+                self._ensure_y(prev["u"][-1])
             cons = () if first else tuple(x for x in (prev["u"][-1], prev["ud"]) if x is not None)
             g = self._dgrad(us[0], gy, residual=skip, gate=not first, consumers=cons, pool=pool, res_half=ud is not None and half_skip)
         for u in self.units:
-            u.rev_stats = None
+            u.rev_stats, u.rev_dummy = None, False
+            if getattr(u, "y_recomputed", False):
+                u.y, u.y_recomputed = None, False
         u = self.stem
         if self.stem_pool_fused:
             # pool scatter + ReLU gate (recomputed from the raw output) + the BatchNorm-reverse sums in one pass

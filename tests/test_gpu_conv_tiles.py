@@ -572,3 +572,56 @@ def test_stem_with_the_max_pool_inside(gpu_lib, B):
     a_ref = F.max_pool2d(F.relu(yn * sc[None, :, None, None] + sh[None, :, None, None]), 3, 2, 1)
     a_new = F.relu(p.float().permute(0, 3, 1, 2) * sc[None, :, None, None] + sh[None, :, None, None])
     assert torch.equal(a_new, a_ref)
+
+
+@pytest.mark.parametrize("geom", [(4, 16, 16, 64), (3, 32, 16, 128)], ids=lambda g: "x".join(map(str, g)))
+def test_conv3_batchnorm_reverse_from_gram_statistics_against_autograd(gpu_lib, geom):
+    """csrc/conv_fold.hip: reverse of z = BatchNorm_train(conv1x1(A, W)) for a given gradient g at z, computed WITHOUT y3 = conv(A, W) and
+    without gy3: D = g^T A (one weight-gradient launch), the forward's Gram totals of A, sum_p g -> dgamma, dbeta, dW and the three
+    operands (k2 W, W^T diag(k1) W, k0^T W) of the data-gradient launch; against torch autograd in f64 on the same bf16-rounded tensors.
+    Tolerances: dW / dgamma / dbeta are f32 sums of bf16 products: 2e-3 of the tensor's scale; the data gradient passes through bf16 weights
+    (k2 W and S rounded to bf16) and a bf16 residual: 2e-2."""
+    from mhentropy_amd import ops, resnet
+    B, H, W_, Cb = geom
+    C4, P = 4 * Cb, B * H * W_
+    gen = torch.Generator().manual_seed(Cb + B)
+    A = (torch.rand(B, Cb, H, W_, generator=gen) + 0.0625).bfloat16().float()         # post-ReLU, all positive: the gate is open everywhere
+    Wt = (torch.randn(C4, Cb, 1, 1, generator=gen) * (2.0 / Cb) ** 0.5).bfloat16().float()
+    g = (torch.randn(B, C4, H, W_, generator=gen) * 0.1 + 0.03).bfloat16().float()
+    gamma, beta = torch.rand(C4, generator=gen) + 0.5, torch.randn(C4, generator=gen) * 0.2
+    # ---- autograd, f64
+    Ad, Wd = A.double().requires_grad_(True), Wt.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    z = F.batch_norm(F.conv2d(Ad, Wd), None, None, gd, bd, True, 0.1, 1e-5)
+    (z * g.double()).sum().backward()
+    # ---- the fold
+    Ax, gx = _nhwc(A), _nhwc(g)
+    wd = resnet.pack_conv_weight(Wt, torch.bfloat16).cuda()
+    ones, zeros = torch.ones(Cb, device="cuda"), torch.zeros(Cb, device="cuda")
+    gbuf = (ops.gram_buffers(Cb, torch.device("cuda"))[0], ops.gram_workspace(Cb, torch.device("cuda")))
+    rm, rv = torch.zeros(C4, device="cuda"), torch.ones(C4, device="cuda")
+    _, _, mi = ops.conv1x1_gram_bn(Ax, ones, zeros, wd, gamma.cuda(), beta.cuda(), rm, rv, gbuf, want_mean_invstd=True)
+    D = torch.zeros(C4, Cb, device="cuda")
+    ops.conv_wgrad(Ax, gx, 1, 1, 1, 0, D)
+    rev = torch.zeros(ops.stat_shards(), 2, C4, device="cuda")
+    rev[3, 0] = g.sum((0, 2, 3)).cuda(); rev[:, 1] = 123.0                              # the second sum is not read
+    dgamma, dbeta, dW = torch.zeros(C4, device="cuda"), torch.zeros(C4, device="cuda"), torch.zeros(C4, Cb, device="cuda")
+    w_dg, S, c0 = torch.zeros(Cb, C4, device="cuda", dtype=torch.bfloat16), torch.zeros(Cb, Cb, device="cuda", dtype=torch.bfloat16), torch.zeros(Cb, device="cuda")
+    ops.conv3_bn_fold(D, wd, gbuf[1], rev, gamma.cuda(), mi, P, dgamma, dbeta, dW, w_dg, S, c0, torch.zeros(2 * C4, device="cuda"))
+    torch.cuda.synchronize()
+    assert not D.any(), "the accumulator is left clean"
+    assert_close(dbeta.cpu(), bd.grad, 2e-3, what="dbeta")
+    assert_close(dgamma.cpu(), gd.grad, 2e-3, what="dgamma")
+    assert_close(dW.cpu(), Wd.grad[:, :, 0, 0], 2e-3, what="dW")
+    # data gradient: g (k2 W) + A S + c0, gated by [A > 0] (open everywhere here)
+    t_res = ops.conv2d_nhwc(Ax, S, 1, 1, 1, 0)
+    gA = ops.conv2d_nhwc(gx, w_dg, 1, 1, 1, 0, residual=t_res, mask=Ax, out_shift=c0)
+    assert_close(gA.float().cpu().permute(0, 3, 1, 2), Ad.grad, 2e-2, what="data gradient")
+    # ... and the same launch with the consumer's BatchNorm-reverse sums (one bn triple) leaves the same tensor
+    st = torch.zeros(ops.stat_shards(), 2, Cb, device="cuda")
+    mi2 = torch.stack([torch.zeros(Cb), torch.ones(Cb)]).cuda()
+    gA2 = ops.conv2d_nhwc(gx, w_dg, 1, 1, 1, 0, residual=t_res, mask=Ax, out_shift=c0, bn=[(Ax, mi2, st)])
+    assert torch.equal(gA2, gA)
+    # (sum_p of a train-mode BatchNorm's input gradient is zero: the sums are rounding noise - compared on the scale of sum |g|)
+    err = (st.double().sum(0)[0] - gA.double().sum((0, 1, 2))).abs() / gA.double().abs().sum((0, 1, 2))
+    assert float(err.max()) < 4e-3, float(err.max())
