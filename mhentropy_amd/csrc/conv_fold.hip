@@ -17,8 +17,6 @@
 
 namespace mhe { namespace fold {
 
-constexpr int NSH = 64;
-
 // one wave per output channel c of conv3
 template <int CB>
 __global__ __launch_bounds__(256) void channel_kernel(float *__restrict__ D, const u16 *__restrict__ w, const double *__restrict__ tot,
@@ -70,25 +68,35 @@ __global__ __launch_bounds__(256) void channel_kernel(float *__restrict__ D, con
     }
 }
 
-// S = W^T diag(k1) W [Cb][Cb] (row j per wave) and c0 = k0^T W [Cb] (one more wave)
+// S = W^T diag(k1) W [Cb][Cb] (row j per workgroup) and c0 = k0^T W [Cb] (one more workgroup).  256 threads = 256 / CB channel groups x CB
+// columns: a thread walks its group's channels (rows of W: coalesced), the groups are folded through LDS.  (One wave per row walking all C
+// channels with a strided scalar per step took 174 us at Cb = 128: eight times the rest of the fold.)
 template <int CB>
 __global__ __launch_bounds__(256) void gram_side_kernel(const u16 *__restrict__ w, const float *__restrict__ coef, u16 *__restrict__ S,
                                                         float *__restrict__ c0, int C) {
-    constexpr int NC = CB / 64;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, j = blockIdx.x * 4 + wv;
-    if (j > CB) return;
-    float acc[NC];
-#pragma unroll
-    for (int k = 0; k < NC; ++k) acc[k] = 0.f;
-    for (int c = 0; c < C; ++c) {
-        const float f = j < CB ? coef[c] * bf16_to_f32(w[(size_t)c * CB + j]) : coef[C + c];
-#pragma unroll
-        for (int k = 0; k < NC; ++k) acc[k] = fmaf(f, bf16_to_f32(w[(size_t)c * CB + lane + 64 * k]), acc[k]);
+    constexpr int NG = 256 / CB;
+    __shared__ float red[NG][CB];
+    const int j = blockIdx.x, k = threadIdx.x % CB, grp = threadIdx.x / CB;
+    float acc0 = 0.f, acc1 = 0.f;
+    int c = grp;
+    for (; c + NG < C; c += 2 * NG) {
+        const float f0 = j < CB ? coef[c] * bf16_to_f32(w[(size_t)c * CB + j]) : coef[C + c];
+        const float f1 = j < CB ? coef[c + NG] * bf16_to_f32(w[(size_t)(c + NG) * CB + j]) : coef[C + c + NG];
+        acc0 = fmaf(f0, bf16_to_f32(w[(size_t)c * CB + k]), acc0);
+        acc1 = fmaf(f1, bf16_to_f32(w[(size_t)(c + NG) * CB + k]), acc1);
     }
+    for (; c < C; c += NG) {
+        const float f0 = j < CB ? coef[c] * bf16_to_f32(w[(size_t)c * CB + j]) : coef[C + c];
+        acc0 = fmaf(f0, bf16_to_f32(w[(size_t)c * CB + k]), acc0);
+    }
+    red[grp][k] = acc0 + acc1;
+    __syncthreads();
+    if (grp == 0) {
+        float v = 0.f;
 #pragma unroll
-    for (int k = 0; k < NC; ++k) {
-        if (j < CB) S[(size_t)j * CB + lane + 64 * k] = f32_to_bf16(acc[k]);
-        else c0[lane + 64 * k] = acc[k];
+        for (int g = 0; g < NG; ++g) v += red[g][k];
+        if (j < CB) S[(size_t)j * CB + k] = f32_to_bf16(v);
+        else c0[k] = v;
     }
 }
 
@@ -107,12 +115,12 @@ extern "C" int mhe_conv3_bn_fold(float *D, const void *w_bf16, const double *gra
         hipLaunchKernelGGL(fold::channel_kernel<64>, dim3((C + 3) / 4), dim3(256), 0, s, D, (const u16 *)w_bf16, gram_totals, rev_stats, gamma,
                            mean_invstd, dgamma, dbeta, dW, (u16 *)w_dg_bf16, coef_ws, C, ld_dg, (double)count);
         if (int rc = check_launch("fold::channel_kernel")) return rc;
-        hipLaunchKernelGGL(fold::gram_side_kernel<64>, dim3((Cb + 1 + 3) / 4), dim3(256), 0, s, (const u16 *)w_bf16, coef_ws, (u16 *)S_bf16, c0, C);
+        hipLaunchKernelGGL(fold::gram_side_kernel<64>, dim3(Cb + 1), dim3(256), 0, s, (const u16 *)w_bf16, coef_ws, (u16 *)S_bf16, c0, C);
     } else {
         hipLaunchKernelGGL(fold::channel_kernel<128>, dim3((C + 3) / 4), dim3(256), 0, s, D, (const u16 *)w_bf16, gram_totals, rev_stats, gamma,
                            mean_invstd, dgamma, dbeta, dW, (u16 *)w_dg_bf16, coef_ws, C, ld_dg, (double)count);
         if (int rc = check_launch("fold::channel_kernel")) return rc;
-        hipLaunchKernelGGL(fold::gram_side_kernel<128>, dim3((Cb + 1 + 3) / 4), dim3(256), 0, s, (const u16 *)w_bf16, coef_ws, (u16 *)S_bf16, c0, C);
+        hipLaunchKernelGGL(fold::gram_side_kernel<128>, dim3(Cb + 1), dim3(256), 0, s, (const u16 *)w_bf16, coef_ws, (u16 *)S_bf16, c0, C);
     }
     return check_launch("fold::gram_side_kernel");
 }
