@@ -460,19 +460,21 @@ int mhe_flow_mask_pad_mixed(const float *x, const float *mask, float *xp, void *
  * [out][k] at ((out / 16 * (K / 32) + k / 32) * 64 + (k % 32 / 8) * 16 + out % 16) * 8 + k % 8, the order the lanes of
  * v_mfma_f32_16x16x32_bf16 take them, so a fragment is one 1 KiB run; net k at + k * w_net_stride elements. */
 /* mhe_conv2d_masked_nhwc with a per-channel constant: y = (conv(x, w) + bias + residual) * [mask > 0] (+ the BatchNorm-reverse sums of one
- * consumer).  Register-staged 128-row tiles only. */
-int mhe_conv2d_masked_bias_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const void *residual,
-                                const void *mask, const float *bias, const void *bn_y0, const float *bn_mean_invstd0,
-                                float *bn_stats0, void *stream);
+ * consumer).  Register-staged 128-row tiles only.  xcat (optional, bf16 1x1 stride-1 launches): the operand's K range continues on a second
+ * tensor - y = [x | xcat] w^T with w [Cout][Cin + cin2] and xcat [pixels][cin2]. */
+int mhe_conv2d_masked_bias_nhwc(const mhe_conv_desc *d, const void *x, const void *xcat, int cin2, const void *w, void *y,
+                                const void *residual, const void *mask, const float *bias, const void *bn_y0,
+                                const float *bn_mean_invstd0, float *bn_stats0, void *stream);
 /* Reverse of conv3 (1x1, C outputs, Cb = 64 | 128 inputs) + train-mode BatchNorm without the convolution's raw output (csrc/conv_fold.hip).
  * In: D [C][Cb] = g^T A accumulated by a weight-gradient launch on the gated gradient g itself (cleared on the way out), w_bf16 [C][Cb] the
  * forward's weights, gram_totals = the f64 totals of mhe_conv1x1_gram_nhwc on conv3's input ([Cb][Cb] Gram matrix, then [Cb] column sums),
  * rev_stats [64][2][C] whose [.][0][c] shards hold sum_p g, gamma, mean_invstd [2][C], count = pixels.  Out: dgamma, dbeta [C]; dW [C][Cb]
- * ACCUMULATED; w_dg_bf16 [Cb][ld_dg] = (k2 W)^T, the data-gradient weights for g; S_bf16 [Cb][Cb] = W^T diag(k1) W, the 1x1 weights that
- * turn conv3's input into the residual of that launch; c0 [Cb] its per-channel constant.  coef_ws: 2 C floats of scratch. */
+ * ACCUMULATED; w_dg_bf16 [Cb][ld_dg] = (k2 W)^T, the data-gradient weights for g; S_bf16 [Cb][ld_S] = W^T diag(k1) W, the 1x1 weights for
+ * conv3's input (as the residual of that launch, or - S_bf16 = w_dg_bf16 + C, ld_S = ld_dg = C + Cb - as the second part of ONE
+ * K-concatenated launch, mhe_conv2d_masked_bias_nhwc); c0 [Cb] the per-channel constant.  coef_ws: 2 C floats of scratch. */
 int mhe_conv3_bn_fold(float *D, const void *w_bf16, const double *gram_totals, const float *rev_stats, const float *gamma,
                       const float *mean_invstd, float count, float *dgamma, float *dbeta, float *dW, void *w_dg_bf16, int ld_dg,
-                      void *S_bf16, float *c0, float *coef_ws, int C, int Cb, void *stream);
+                      void *S_bf16, int ld_S, float *c0, float *coef_ws, int C, int Cb, void *stream);
 int mhe_flow_reverse_chain_supported(int R, int B, int dim, int hidden, int ncoup);
 /* mhe_flow_couplings_bf16 / _emit on the fragment-streaming skeleton (csrc/flow_fwd.hip): hidden 512, a multiple of 64 hypotheses per
  * image (R % (64 B) == 0; a workgroup = 64 rows of one image), at most 32 couplings.  Same results as mhe_flow_couplings_bf16 up to the

@@ -22,7 +22,8 @@
 
 namespace mhe { namespace conv {
 
-// MODE 0: plain operand load; 1: producer BatchNorm(+ReLU) applied to the operand; 2: residual-tail (dual input)
+// MODE 0: plain operand load; 1: producer BatchNorm(+ReLU) applied to the operand; 2: residual-tail (dual input);
+// 3: plain, the K range continued on a second tensor (1x1 only: p.xcat, p.Cin2 - the data-gradient launch of csrc/conv_fold.hip)
 // Tile BM x BN computed by WM x WN wavefronts (64 * WM * WN threads); each wave owns (BM/WM) x (BN/WN).
 // Shipped shapes: 128x64 and 128x128 on 2x2 waves (2 workgroups per CU), 256x256 on 2x4 waves (one per CU,
 // half the L2->LDS bytes per MAC of 128x128 - the 128-tiles measure L2-fill-bound at ~11 TB/s).
@@ -34,7 +35,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_kerne
     constexpr int NJ_A = BM / RSTEP, NJ_B = BN / RSTEP;
     constexpr int MTW = BM / WM / 16, NTW = BN / WN / 16;     // 16x16 tiles per wave
     __shared__ uint4 lds[2][(BM + BN) * 8];
-    __shared__ __attribute__((aligned(16))) float aff[2][MODE ? MAXC : 4];     // producer BatchNorm scale / shift
+    constexpr bool AFFM = MODE == 1 || MODE == 2;
+    __shared__ __attribute__((aligned(16))) float aff[2][AFFM ? MAXC : 4];     // producer BatchNorm scale / shift
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int q = lane >> 4, l15 = lane & 15;
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_kerne
         wi0[j] = wo * p.stride - p.pad;
         xb[j] = (size_t)b * p.H * p.W;
     }
-    if constexpr (MODE != 0) {
+    if constexpr (AFFM) {
         for (int i = tid; i < p.Cin; i += NTH) { aff[0][i] = p.in_scale[i]; aff[1][i] = p.in_shift[i]; }
         __syncthreads();
     }
@@ -80,6 +82,12 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_kerne
         int tap, c;
         if constexpr (FAST) { tap = (ks * BKE) / p.Cin; c = kc - tap * p.Cin; }
         else                { tap = kc / p.Cin; c = kc - tap * p.Cin; }
+        const T *src = xg;
+        int pitch = p.Cin;
+        if constexpr (MODE == 3) {                        // (uniform per K stage)
+            if (ks * BKE >= p.Cin) { src = reinterpret_cast<const T *>(p.xcat); pitch = p.Cin2; c = kc - p.Cin; }
+            tap = 0;
+        }
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
         const bool tv = tap < ntaps;
         c_ld = c;
@@ -91,10 +99,10 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_kerne
             uint4 v = make_uint4(0, 0, 0, 0);
             if constexpr (dual) ra2[j] = v;
             if (ok) {
-                const size_t off = (xb[j] + (size_t)hi * p.W + wi) * p.Cin + c;
-                v = *reinterpret_cast<const uint4 *>(xg + off);
+                const size_t off = (xb[j] + (size_t)hi * p.W + wi) * pitch + c;
+                v = *reinterpret_cast<const uint4 *>(src + off);
                 if constexpr (dual) { ra2[j] = *reinterpret_cast<const uint4 *>(x2g + off); aoff[j] = off; }
-                if constexpr (MODE != 0) okbits |= 1u << j;
+                if constexpr (AFFM) okbits |= 1u << j;
             }
             ra[j] = v;
         }
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_kerne
 #pragma unroll
         for (int j = 0; j < NJ_A; ++j) {
             uint4 v = ra[j];
-            if constexpr (MODE != 0) {
+            if constexpr (AFFM) {
                 if ((okbits >> j) & 1u) {          // padding stays zero
                     v = in_transform<T>(v, aff[0], aff[1], c_ld, p.relu_in, dual, ra2[dual ? j : 0], p.x2_scale, p.x2_shift);
                     if constexpr (dual) {
@@ -638,6 +646,8 @@ static void launch_mode(const Params &p, hipStream_t s) {
         }
     } else if (p.in_scale) {
         hipLaunchKernelGGL((conv_kernel<T, BM, BN, WM, WN, FAST, 1>), grid, block, 0, s, p);
+    } else if (p.mask && p.xcat) {
+        if constexpr (FAST && BM == 128 && sizeof(T) == 2) hipLaunchKernelGGL((conv_kernel<T, BM, BN, WM, WN, true, 3, true>), grid, block, 0, s, p);
     } else if (p.mask) {
         hipLaunchKernelGGL((conv_kernel<T, BM, BN, WM, WN, FAST, 0, true>), grid, block, 0, s, p);
     } else {
@@ -755,7 +765,8 @@ static inline int elem_chunk(int dtype) { return dtype == MHE_F32 ? 4 : 8; }
 static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
                       const float *in_shift, const float *out_scale, const float *out_shift, const void *residual,
                       float *stats, const void *x2, const float *x2_scale, const float *x2_shift, void *a_out, void *stream,
-                      const void *mask = nullptr, const struct BnRev *bn = nullptr, float *y32 = nullptr, const int *scatter = nullptr);
+                      const void *mask = nullptr, const struct BnRev *bn = nullptr, float *y32 = nullptr, const int *scatter = nullptr,
+                      const void *xcat = nullptr, int cin2 = 0);
 struct BnRev { const void *y[2]; const float *mi[2]; float *stats[2]; };
 
 extern "C" int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
@@ -804,14 +815,17 @@ extern "C" int mhe_conv2d_masked_nhwc(const mhe_conv_desc *d, const void *x, con
     return conv_entry(d, x, w, y, nullptr, nullptr, nullptr, nullptr, residual, nullptr, nullptr, nullptr, nullptr, nullptr, stream, mask, &bn);
 }
 
-extern "C" int mhe_conv2d_masked_bias_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const void *residual,
-                                           const void *mask, const float *bias, const void *bn_y0, const float *bn_mean_invstd0,
-                                           float *bn_stats0, void *stream) {
+extern "C" int mhe_conv2d_masked_bias_nhwc(const mhe_conv_desc *d, const void *x, const void *xcat, int cin2, const void *w, void *y,
+                                           const void *residual, const void *mask, const float *bias, const void *bn_y0,
+                                           const float *bn_mean_invstd0, float *bn_stats0, void *stream) {
     MHE_REQUIRE(mask && bias, "mhe_conv2d_masked_bias_nhwc: mask and bias are required");
+    MHE_REQUIRE(!xcat || (d && d->dtype == MHE_BF16 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && cin2 > 0 && cin2 % 64 == 0 && d->Cin % 64 == 0),
+                "mhe_conv2d_masked_bias_nhwc: a concatenated operand needs a bf16 1x1 stride-1 launch with Cin and cin2 multiples of 64");
     MHE_REQUIRE(!bn_y0 || (bn_mean_invstd0 && bn_stats0), "mhe_conv2d_masked_bias_nhwc: bn_y needs its mean_invstd and stats");
     MHE_REQUIRE(d && (d->tile == 0 || d->tile == 1 || d->tile == 2), "mhe_conv2d_masked_bias_nhwc: 128-row register-staged tiles only (tile 0, 1 or 2)");
     const BnRev bn = {{bn_y0, nullptr}, {bn_mean_invstd0, nullptr}, {bn_stats0, nullptr}};
-    return conv_entry(d, x, w, y, nullptr, nullptr, nullptr, bias, residual, nullptr, nullptr, nullptr, nullptr, nullptr, stream, mask, &bn);
+    return conv_entry(d, x, w, y, nullptr, nullptr, nullptr, bias, residual, nullptr, nullptr, nullptr, nullptr, nullptr, stream, mask, &bn, nullptr,
+                      nullptr, xcat, xcat ? cin2 : 0);
 }
 
 extern "C" int mhe_conv3x3s2_dgrad_nhwc(int B, int Ho, int Wo, int Cout, int Cin, int dtype, const void *gy, const void *const *w4,
@@ -837,7 +851,7 @@ extern "C" int mhe_conv3x3s2_dgrad_nhwc(int B, int Ho, int Wo, int Cout, int Cin
 static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
                       const float *in_shift, const float *out_scale, const float *out_shift, const void *residual,
                       float *stats, const void *x2, const float *x2_scale, const float *x2_shift, void *a_out, void *stream,
-                      const void *mask, const BnRev *bn, float *y32, const int *scatter) {
+                      const void *mask, const BnRev *bn, float *y32, const int *scatter, const void *xcat, int cin2) {
     MHE_REQUIRE(d && x && w && (y || y32), "mhe_conv2d_nhwc: null pointer");
     MHE_REQUIRE(d->dtype == MHE_F32 || d->dtype == MHE_BF16, "mhe_conv2d_nhwc: dtype=%d", d->dtype);
     const int ce = elem_chunk(d->dtype), bke = 8 * ce;
@@ -866,7 +880,8 @@ static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void
     const long long M = (long long)p.B * p.Ho * p.Wo;
     MHE_REQUIRE(M < (1ll << 31), "mhe_conv2d_nhwc: too many output pixels");
     p.M = (int)M;
-    const int ktot = d->KH * d->KW * d->Cin;
+    p.xcat = xcat; p.Cin2 = cin2;
+    const int ktot = d->KH * d->KW * d->Cin + cin2;
     p.Kpad = (ktot + bke - 1) / bke * bke;       // weight rows are zero-padded to this length by the packer
     p.relu_in = d->relu_in; p.relu_out = d->relu_out;
     p.force = d->tile - 1;

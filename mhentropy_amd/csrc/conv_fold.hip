@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void channel_kernel(float *__restrict__ D, con
 // channels with a strided scalar per step took 174 us at Cb = 128: eight times the rest of the fold.)
 template <int CB>
 __global__ __launch_bounds__(256) void gram_side_kernel(const u16 *__restrict__ w, const float *__restrict__ coef, u16 *__restrict__ S,
-                                                        float *__restrict__ c0, int C) {
+                                                        float *__restrict__ c0, int C, int ldS) {
     constexpr int NG = 256 / CB;
     __shared__ float red[NG][CB];
     const int j = blockIdx.x, k = threadIdx.x % CB, grp = threadIdx.x / CB;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void gram_side_kernel(const u16 *__restrict__ 
         float v = 0.f;
 #pragma unroll
         for (int g = 0; g < NG; ++g) v += red[g][k];
-        if (j < CB) S[(size_t)j * CB + k] = f32_to_bf16(v);
+        if (j < CB) S[(size_t)j * ldS + k] = f32_to_bf16(v);
         else c0[k] = v;
     }
 }
@@ -106,21 +106,21 @@ using namespace mhe;
 
 extern "C" int mhe_conv3_bn_fold(float *D, const void *w_bf16, const double *gram_totals, const float *rev_stats, const float *gamma,
                                  const float *mean_invstd, float count, float *dgamma, float *dbeta, float *dW, void *w_dg_bf16, int ld_dg,
-                                 void *S_bf16, float *c0, float *coef_ws, int C, int Cb, void *stream) {
+                                 void *S_bf16, int ld_S, float *c0, float *coef_ws, int C, int Cb, void *stream) {
     MHE_REQUIRE(D && w_bf16 && gram_totals && rev_stats && gamma && mean_invstd && dgamma && dbeta && dW && w_dg_bf16 && S_bf16 && c0 && coef_ws,
                 "mhe_conv3_bn_fold: null pointer");
-    MHE_REQUIRE((Cb == 64 || Cb == 128) && C > 0 && ld_dg >= C && count > 1.f, "mhe_conv3_bn_fold: Cb=%d (64 | 128), C=%d, ld_dg=%d", Cb, C, ld_dg);
+    MHE_REQUIRE((Cb == 64 || Cb == 128) && C > 0 && ld_dg >= C && ld_S >= Cb && count > 1.f, "mhe_conv3_bn_fold: Cb=%d (64 | 128), C=%d, ld_dg=%d, ld_S=%d", Cb, C, ld_dg, ld_S);
     hipStream_t s = (hipStream_t)stream;
     if (Cb == 64) {
         hipLaunchKernelGGL(fold::channel_kernel<64>, dim3((C + 3) / 4), dim3(256), 0, s, D, (const u16 *)w_bf16, gram_totals, rev_stats, gamma,
                            mean_invstd, dgamma, dbeta, dW, (u16 *)w_dg_bf16, coef_ws, C, ld_dg, (double)count);
         if (int rc = check_launch("fold::channel_kernel")) return rc;
-        hipLaunchKernelGGL(fold::gram_side_kernel<64>, dim3(Cb + 1), dim3(256), 0, s, (const u16 *)w_bf16, coef_ws, (u16 *)S_bf16, c0, C);
+        hipLaunchKernelGGL(fold::gram_side_kernel<64>, dim3(Cb + 1), dim3(256), 0, s, (const u16 *)w_bf16, coef_ws, (u16 *)S_bf16, c0, C, ld_S);
     } else {
         hipLaunchKernelGGL(fold::channel_kernel<128>, dim3((C + 3) / 4), dim3(256), 0, s, D, (const u16 *)w_bf16, gram_totals, rev_stats, gamma,
                            mean_invstd, dgamma, dbeta, dW, (u16 *)w_dg_bf16, coef_ws, C, ld_dg, (double)count);
         if (int rc = check_launch("fold::channel_kernel")) return rc;
-        hipLaunchKernelGGL(fold::gram_side_kernel<128>, dim3(Cb + 1), dim3(256), 0, s, (const u16 *)w_bf16, coef_ws, (u16 *)S_bf16, c0, C);
+        hipLaunchKernelGGL(fold::gram_side_kernel<128>, dim3(Cb + 1), dim3(256), 0, s, (const u16 *)w_bf16, coef_ws, (u16 *)S_bf16, c0, C, ld_S);
     }
     return check_launch("fold::gram_side_kernel");
 }

@@ -29,6 +29,9 @@ struct Params {
     // bottleneck tail with conv3 re-evaluated (conv_fuse.hip): w3 [Cin][Cin / 4] packed, mid_scale / mid_shift = bn3's affine [Cin]
     const void *w3; const float *mid_scale, *mid_shift;
     int stats_only;        // statistics-only launch of the streaming 1x1 kernel (y = NULL): any pixel count
+    // K-concatenated operand of a 1x1 data-gradient launch (MODE 3, conv.hip): channels Cin .. Cin + Cin2 - 1 of a pixel come from xcat
+    // [M][Cin2]; the weight rows are [Cout][Cin + Cin2]
+    const void *xcat; int Cin2;
 };
 
 // tile row -> global output pixel index the epilogue addresses (or -1 outside the problem)

@@ -334,7 +334,7 @@ def metrics(xyz, uv, pose3d, scale, crop_uv, vis):
 
 
 def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in=False, out_scale=None,
-                out_shift=None, residual=None, relu_out=False, stats=None, out=None, mask=None, bn=None, tile=0, res_half=False):
+                out_shift=None, residual=None, relu_out=False, stats=None, out=None, mask=None, bn=None, tile=0, res_half=False, xcat=None):
     """x [B,H,W,Cin], w packed [Cout, Kpad]; returns y [B,Ho,Wo,Cout] of x.dtype.  mask (shaped like y, data-gradient
     form only): y = (conv + residual) * [mask > 0]; bn = up to two (bn_y, mean_invstd [2,C], stats [S,2,C]) triples: the epilogue
     also accumulates the BatchNorm-reverse sums of y for those units (see mhe_conv2d_masked_nhwc).  tile > 0 forces kernel
@@ -366,9 +366,17 @@ def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in
             if by is not None:
                 _chk(by, dt, "conv.bn_y", (B, Ho, Wo, Cout)); _chk(bmi, torch.float32, "conv.bn_mean_invstd", (2, Cout))
                 _chk(bst, torch.float32, "conv.bn_stats", (stat_shards(), 2, Cout))
-            check(_lib.lib().mhe_conv2d_masked_bias_nhwc(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _ptr(residual), _ptr(mask), _ptr(out_shift), _ptr(by),
-                                                         _ptr(bmi), _ptr(bst), _stream()), "mhe_conv2d_masked_bias_nhwc")
+            cin2 = 0
+            if xcat is not None:         # the operand's K range continued on a second tensor: w is [Cout][Cin + cin2]
+                cin2 = xcat.shape[-1]
+                _chk(xcat, dt, "conv.xcat", (B, H, W, cin2))
+                if tuple(w.shape) != (Cout, Cin + cin2):
+                    raise ValueError(f"conv2d_nhwc: xcat= needs w [{Cout}, {Cin + cin2}], got {tuple(w.shape)}")
+            check(_lib.lib().mhe_conv2d_masked_bias_nhwc(C.byref(d), _ptr(x), _ptr(xcat), int(cin2), _ptr(w), _ptr(y), _ptr(residual), _ptr(mask),
+                                                         _ptr(out_shift), _ptr(by), _ptr(bmi), _ptr(bst), _stream()), "mhe_conv2d_masked_bias_nhwc")
             return y
+        if xcat is not None:
+            raise ValueError("conv2d_nhwc: xcat= comes with mask= and out_shift=")
         ext = []
         for by, bmi, bst in (list(bn or []) + [(None, None, None)] * 2)[:2]:
             if by is not None:
@@ -453,17 +461,24 @@ def gram_workspace(Cb, device):
 
 
 def conv3_bn_fold(D, w, gram_totals, rev_stats, gamma, mean_invstd, count, dgamma, dbeta, dW, w_dg, S, c0, coef_ws):
-    """reverse of conv3 + train-mode BatchNorm from D = g^T A and the forward's Gram statistics (mhe_conv3_bn_fold; csrc/conv_fold.hip)"""
+    """reverse of conv3 + train-mode BatchNorm from D = g^T A and the forward's Gram statistics (mhe_conv3_bn_fold; csrc/conv_fold.hip).
+    S=None: w_dg is [Cb][C + Cb] and receives [(k2 W)^T | S] - the weights of ONE K-concatenated data-gradient launch (conv2d_nhwc xcat=)"""
     Cn, Cb = w.shape
+    if S is None:
+        _chk(w_dg, torch.bfloat16, "fold.w_cat", (Cb, Cn + Cb))
+        s_ptr, ld_s = C.c_void_p(w_dg.data_ptr() + 2 * Cn), Cn + Cb
+    else:
+        _chk(S, torch.bfloat16, "fold.S", (Cb, Cb))
+        s_ptr, ld_s = _ptr(S), Cb
     _chk(D, torch.float32, "fold.D", (Cn, Cb)); _chk(w, torch.bfloat16, "fold.w", (Cn, Cb)); _chk(gram_totals, torch.float64, "fold.gram")
     _chk(rev_stats, torch.float32, "fold.rev_stats", (stat_shards(), 2, Cn)); _chk(gamma, torch.float32, "fold.gamma", (Cn,))
     _chk(mean_invstd, torch.float32, "fold.mean_invstd", (2, Cn)); _chk(dgamma, torch.float32, "fold.dgamma", (Cn,)); _chk(dbeta, torch.float32, "fold.dbeta", (Cn,))
-    _chk(dW, torch.float32, "fold.dW"); _chk(w_dg, torch.bfloat16, "fold.w_dg"); _chk(S, torch.bfloat16, "fold.S", (Cb, Cb))
+    _chk(dW, torch.float32, "fold.dW"); _chk(w_dg, torch.bfloat16, "fold.w_dg")
     _chk(c0, torch.float32, "fold.c0", (Cb,)); _chk(coef_ws, torch.float32, "fold.coef_ws")
     if gram_totals.numel() < Cb * Cb + Cb or dW.numel() < Cn * Cb or w_dg.shape[0] != Cb or w_dg.shape[1] < Cn or coef_ws.numel() < 2 * Cn:
         raise ValueError("conv3_bn_fold: operand sizes")
     check(_lib.lib().mhe_conv3_bn_fold(_ptr(D), _ptr(w), _ptr(gram_totals), _ptr(rev_stats), _ptr(gamma), _ptr(mean_invstd), float(count), _ptr(dgamma),
-                                       _ptr(dbeta), _ptr(dW), _ptr(w_dg), int(w_dg.shape[1]), _ptr(S), _ptr(c0), _ptr(coef_ws), Cn, Cb, _stream()),
+                                       _ptr(dbeta), _ptr(dW), _ptr(w_dg), int(w_dg.shape[1]), s_ptr, int(ld_s), _ptr(c0), _ptr(coef_ws), Cn, Cb, _stream()),
           "mhe_conv3_bn_fold")
 
 

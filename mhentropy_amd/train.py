@@ -138,6 +138,7 @@ class TrainStep:
         self.fuse_bn_reduce = os.environ.get("MHE_BN_REDUCE_FUSED", "1") == "1"
         self.train_recompute = os.environ.get("MHE_TRAIN_RECOMPUTE", "1") == "1"
         self.conv3_fold = os.environ.get("MHE_CONV3_FOLD", "1") == "1"
+        self.conv3_fold_cat = os.environ.get("MHE_CONV3_FOLD_CAT", "1") == "1"
         # the stem's BatchNorm + ReLU folded into its max pool, forward and reverse (ops.maxpool3x3s2_idx / maxpool3x3s2_bwd_bn)
         self.stem_pool_fused = os.environ.get("MHE_STEM_POOL_FUSED", "1") == "1"
         self.bn_on_load_wide = os.environ.get("MHE_BN_BWD_ON_LOAD_WIDE", "1") == "1"
@@ -666,8 +667,11 @@ class TrainStep:
                 if D is None:
                     D = self._ws[("foldD", Cn, Cb)] = torch.zeros(Cn, Cb, device=self.dev)      # cleared by the fold kernel on its way out
                 ops.conv_wgrad(ul.x, g, 1, 1, 1, 0, D)
-                fw = (self._buf(f"fold_wdg{Cn}", (Cb, Cn), torch.bfloat16), self._buf(f"fold_S{Cb}", (Cb, Cb), torch.bfloat16),
-                      self._buf(f"fold_c0{Cb}", (Cb,)))
+                # [(k2 W)^T | W^T diag(k1) W]: the weights of one data-gradient launch on [g | A] (MHE_CONV3_FOLD_CAT=0: two launches, the
+                # Cb x Cb product on A as the residual of the one on g)
+                cat = self.conv3_fold_cat
+                fw = (self._buf(f"fold_wcat{Cn}", (Cb, Cn + Cb), torch.bfloat16) if cat else self._buf(f"fold_wdg{Cn}", (Cb, Cn), torch.bfloat16),
+                      None if cat else self._buf(f"fold_S{Cb}", (Cb, Cb), torch.bfloat16), self._buf(f"fold_c0{Cb}", (Cb,)))
                 ops.conv3_bn_fold(D, ul.w_fwd, ul.gram_tot, ul.rev_stats, ul.bn.weight.data, ul.mi, g.numel() // Cn, ul.dgamma, ul.dbeta, ul.dw,
                                   fw[0], fw[1], fw[2], self._buf(f"fold_coef{Cn}", (2 * Cn,)))
                 gy = None
@@ -698,8 +702,11 @@ class TrainStep:
                     if fold:
                         # gy3 W = g (k2 W) + A (W^T diag(k1) W) + k0^T W: the Cb x Cb product on conv3's input as the residual, the constant
                         # as the bias of ONE data-gradient launch on g; the weight gradient came out of the fold
-                        t_res = ops.conv2d_nhwc(u.x, fw[1], 1, 1, 1, 0)
-                        ga = ops.conv2d_nhwc(g, fw[0], 1, 1, 1, 0, residual=t_res, mask=u.x, bn=bn, out_shift=fw[2])
+                        if fw[1] is None:
+                            ga = ops.conv2d_nhwc(g, fw[0], 1, 1, 1, 0, mask=u.x, bn=bn, out_shift=fw[2], xcat=u.x)
+                        else:
+                            t_res = ops.conv2d_nhwc(u.x, fw[1], 1, 1, 1, 0)
+                            ga = ops.conv2d_nhwc(g, fw[0], 1, 1, 1, 0, residual=t_res, mask=u.x, bn=bn, out_shift=fw[2])
                     else:
                         gy = torch.empty_like(g)
                         ga = ops.conv1x1_dgrad_bn_apply(g, u.y, coef, u.w_dg, gy, u.x, bn, zeros=self._zeros_c[:u.cout])

@@ -617,6 +617,19 @@ def test_conv3_batchnorm_reverse_from_gram_statistics_against_autograd(gpu_lib, 
     t_res = ops.conv2d_nhwc(Ax, S, 1, 1, 1, 0)
     gA = ops.conv2d_nhwc(gx, w_dg, 1, 1, 1, 0, residual=t_res, mask=Ax, out_shift=c0)
     assert_close(gA.float().cpu().permute(0, 3, 1, 2), Ad.grad, 2e-2, what="data gradient")
+    # ... as ONE launch on the K-concatenated operand [g | A] with weights [(k2 W)^T | S] (what the train step runs)
+    D2 = torch.zeros(C4, Cb, device="cuda")
+    ops.conv_wgrad(Ax, gx, 1, 1, 1, 0, D2)
+    w_cat, c0b = torch.zeros(Cb, C4 + Cb, device="cuda", dtype=torch.bfloat16), torch.zeros(Cb, device="cuda")
+    ops.conv3_bn_fold(D2, wd, gbuf[1], rev, gamma.cuda(), mi, P, torch.zeros(C4, device="cuda"), torch.zeros(C4, device="cuda"),
+                      torch.zeros(C4, Cb, device="cuda"), w_cat, None, c0b, torch.zeros(2 * C4, device="cuda"))
+    # (D comes out of a split-K launch with f32 atomics: a second evaluation may differ in the last bit, and so a bf16 rounding of S)
+    assert_close(w_cat[:, :C4].float().cpu(), w_dg.float().cpu(), 4e-3, what="(k2 W)^T in the concatenated weights")
+    assert_close(w_cat[:, C4:].float().cpu(), S.float().cpu(), 4e-3, what="S in the concatenated weights")
+    assert_close(c0b.cpu(), c0.cpu(), 1e-4, what="c0")
+    gAc = ops.conv2d_nhwc(gx, w_cat, 1, 1, 1, 0, mask=Ax, out_shift=c0, xcat=Ax)
+    assert_close(gAc.float().cpu().permute(0, 3, 1, 2), Ad.grad, 2e-2, what="data gradient, one concatenated launch")
+    assert_close(gAc.float().cpu(), gA.float().cpu(), 1e-2, what="concatenated launch vs residual form")     # (the residual form rounds A S to bf16)
     # ... and the same launch with the consumer's BatchNorm-reverse sums (one bn triple) leaves the same tensor
     st = torch.zeros(ops.stat_shards(), 2, Cb, device="cuda")
     mi2 = torch.stack([torch.zeros(Cb), torch.ones(Cb)]).cuda()

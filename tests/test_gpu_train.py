@@ -779,8 +779,8 @@ def test_conv3_reverse_on_gram_statistics_equals_the_pass_that_reads_y3(gpu_lib)
     for n in ("layer4.0.conv1.weight", "layer3.0.conv1.weight", "layer2.3.conv2.weight", "layer2.3.bn1.weight"):
         assert torch.equal(gC[pre + n], gB[pre + n]), n
     # the first folded block: what the fold writes, and what its data gradient feeds - bf16 rounding of gy3 (B) against exact algebra (C)
-    for n, tol in (("layer2.2.bn3.bias", 1e-6), ("layer2.2.conv3.weight", 5e-3), ("layer2.2.bn3.weight", 8e-3), ("layer2.2.conv2.weight", 1e-2),
-                   ("layer2.2.conv1.weight", 1.5e-2)):
+    for n, tol in (("layer2.2.bn3.bias", 1e-6), ("layer2.2.conv3.weight", 5e-3), ("layer2.2.bn3.weight", 8e-3), ("layer2.2.conv2.weight", 1.5e-2),
+                   ("layer2.2.conv1.weight", 2e-2)):
         assert rel(gC[pre + n], gB[pre + n]) <= tol, (n, rel(gC[pre + n], gB[pre + n]))
     # through the five further folds the difference stays at the bf16 level in the residual layers (it grows by ~1.5e-3 per block here), and
     # so does the run-to-run spread of C itself (the f32 atomics of D's split-K change a last bit of the bf16-rounded S / k2 W); the stem's
