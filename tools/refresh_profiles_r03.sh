@@ -6,8 +6,6 @@ set -e
 O=gpurun_out/r3p
 mkdir -p $O
 R=$PWD
-timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err
-tail -2 $O/bench.err
 cd /tmp && export TMPDIR=/tmp
 FW="--steps 5 --warmup 2 --no-cpu-baseline --graph 0 --train-steps 0 --no-glow-variant"
 PM="--steps 2 --warmup 1 --no-cpu-baseline --graph 0 --train-steps 0 --no-glow-variant"
@@ -20,6 +18,10 @@ ITERS=5 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $R/$O/
 ITERS=1 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/$O/pmc_mfma_train -- python3 $R/tools/train_bench.py > $R/$O/pmt.log 2>&1
 cd $R
 python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json
+# the headline line last: it reads profiles/r03_pmc_traffic.json for roofline.traffic, which must come from these very sources
+cp $O/pmc_traffic.json profiles/r03_pmc_traffic.json
+timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err
+tail -2 $O/bench.err
 python tools/pmc_mfma.py $O/pmc_mfma $O/pmc_mfma.json
 python tools/pmc_mfma.py $O/pmc_mfma_train $O/pmc_mfma_train.json
 python tools/trace_stats.py $O/train_tr $O/train_kernel_stats.csv step:adam_kernel:5 > $O/train_stats.txt; tail -1 $O/train_stats.txt
