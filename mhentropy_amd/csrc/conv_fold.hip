@@ -68,34 +68,40 @@ __global__ __launch_bounds__(256) void channel_kernel(float *__restrict__ D, con
     }
 }
 
-// S = W^T diag(k1) W [Cb][Cb] (row j per workgroup) and c0 = k0^T W [Cb] (one more workgroup).  256 threads = 256 / CB channel groups x CB
+// S = W^T diag(k1) W [Cb][Cb] (row j per workgroup) and c0 = k0^T W [Cb] (one more workgroup).  1,024 threads = 1,024 / CB channel groups x CB
 // columns: a thread walks its group's channels (rows of W: coalesced), the groups are folded through LDS.  (One wave per row walking all C
 // channels with a strided scalar per step took 174 us at Cb = 128: eight times the rest of the fold.)
 template <int CB>
-__global__ __launch_bounds__(256) void gram_side_kernel(const u16 *__restrict__ w, const float *__restrict__ coef, u16 *__restrict__ S,
-                                                        float *__restrict__ c0, int C, int ldS) {
-    constexpr int NG = 256 / CB;
+__global__ __launch_bounds__(1024) void gram_side_kernel(const u16 *__restrict__ w, const float *__restrict__ coef, u16 *__restrict__ S,
+                                                         float *__restrict__ c0, int C, int ldS) {
+    constexpr int NG = 1024 / CB;
     __shared__ float red[NG][CB];
     const int j = blockIdx.x, k = threadIdx.x % CB, grp = threadIdx.x / CB;
-    float acc0 = 0.f, acc1 = 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool row = j < CB;
     int c = grp;
-    for (; c + NG < C; c += 2 * NG) {
-        const float f0 = j < CB ? coef[c] * bf16_to_f32(w[(size_t)c * CB + j]) : coef[C + c];
-        const float f1 = j < CB ? coef[c + NG] * bf16_to_f32(w[(size_t)(c + NG) * CB + j]) : coef[C + c + NG];
-        acc0 = fmaf(f0, bf16_to_f32(w[(size_t)c * CB + k]), acc0);
-        acc1 = fmaf(f1, bf16_to_f32(w[(size_t)(c + NG) * CB + k]), acc1);
+    for (; c + 3 * NG < C; c += 4 * NG) {                    // four channels in flight per thread (the loads are what the loop waits for)
+        float f[4], x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cc = c + u * NG;
+            f[u] = row ? coef[cc] * bf16_to_f32(w[(size_t)cc * CB + j]) : coef[C + cc];
+            x[u] = bf16_to_f32(w[(size_t)cc * CB + k]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = fmaf(f[u], x[u], acc[u]);
     }
     for (; c < C; c += NG) {
-        const float f0 = j < CB ? coef[c] * bf16_to_f32(w[(size_t)c * CB + j]) : coef[C + c];
-        acc0 = fmaf(f0, bf16_to_f32(w[(size_t)c * CB + k]), acc0);
+        const float f0 = row ? coef[c] * bf16_to_f32(w[(size_t)c * CB + j]) : coef[C + c];
+        acc[0] = fmaf(f0, bf16_to_f32(w[(size_t)c * CB + k]), acc[0]);
     }
-    red[grp][k] = acc0 + acc1;
+    red[grp][k] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     __syncthreads();
     if (grp == 0) {
         float v = 0.f;
 #pragma unroll
         for (int g = 0; g < NG; ++g) v += red[g][k];
-        if (j < CB) S[(size_t)j * ldS + k] = f32_to_bf16(v);
+        if (row) S[(size_t)j * ldS + k] = f32_to_bf16(v);
         else c0[k] = v;
     }
 }
@@ -115,12 +121,12 @@ extern "C" int mhe_conv3_bn_fold(float *D, const void *w_bf16, const double *gra
         hipLaunchKernelGGL(fold::channel_kernel<64>, dim3((C + 3) / 4), dim3(256), 0, s, D, (const u16 *)w_bf16, gram_totals, rev_stats, gamma,
                            mean_invstd, dgamma, dbeta, dW, (u16 *)w_dg_bf16, coef_ws, C, ld_dg, (double)count);
         if (int rc = check_launch("fold::channel_kernel")) return rc;
-        hipLaunchKernelGGL(fold::gram_side_kernel<64>, dim3(Cb + 1), dim3(256), 0, s, (const u16 *)w_bf16, coef_ws, (u16 *)S_bf16, c0, C, ld_S);
+        hipLaunchKernelGGL(fold::gram_side_kernel<64>, dim3(Cb + 1), dim3(1024), 0, s, (const u16 *)w_bf16, coef_ws, (u16 *)S_bf16, c0, C, ld_S);
     } else {
         hipLaunchKernelGGL(fold::channel_kernel<128>, dim3((C + 3) / 4), dim3(256), 0, s, D, (const u16 *)w_bf16, gram_totals, rev_stats, gamma,
                            mean_invstd, dgamma, dbeta, dW, (u16 *)w_dg_bf16, coef_ws, C, ld_dg, (double)count);
         if (int rc = check_launch("fold::channel_kernel")) return rc;
-        hipLaunchKernelGGL(fold::gram_side_kernel<128>, dim3(Cb + 1), dim3(256), 0, s, (const u16 *)w_bf16, coef_ws, (u16 *)S_bf16, c0, C, ld_S);
+        hipLaunchKernelGGL(fold::gram_side_kernel<128>, dim3(Cb + 1), dim3(1024), 0, s, (const u16 *)w_bf16, coef_ws, (u16 *)S_bf16, c0, C, ld_S);
     }
     return check_launch("fold::gram_side_kernel");
 }
