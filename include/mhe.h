@@ -552,6 +552,11 @@ int mhe_maxpool3x3s2_idx_affine_nhwc(const void *x, const float *scale, const fl
                                      int C, int dtype, void *stream);
 int mhe_maxpool3x3s2_bwd_bn_nhwc(const void *gy, const unsigned char *idx, const void *y, const float *scale, const float *shift,
                                  const float *mean_invstd, float *stats, void *gx, int B, int H, int W, int C, int dtype, void *stream);
+/* (gx may be NULL: the sums only.)  The same walk with the finished BatchNorm-reverse coefficients coef = k2 | k1 | k0 [3][C] (mhe_bn_bwd_finalize):
+ * gy_out = k2 (scattered, gated gradient) + k1 y + k0 - mhe_bn_bwd_apply_nhwc's result without the scattered gradient ever being stored. */
+int mhe_maxpool3x3s2_bwd_bn_apply_nhwc(const void *gy, const unsigned char *idx, const void *y, const float *scale, const float *shift,
+                                       const float *mean_invstd, const float *coef, void *gy_out, int B, int H, int W, int C, int dtype,
+                                       void *stream);
 /* gx[b,p,c] = g[b,c] / HW, zeroed where mask[b,p,c] <= 0 (mask optional: ReLU gate of the pooled tensor). */
 int mhe_avgpool_bwd_nhwc(const float *g, const void *mask, void *gx, int B, int HW, int C, int dtype, void *stream);
 /* out[b,2i,2j,c] = g[b,i,j,c] (+ base), 0 (+ base) elsewhere; out is [B,H,W,C], g is [B,ceil(H/2),ceil(W/2),C]:

@@ -274,11 +274,14 @@ __global__ __launch_bounds__(256) void maxpool_idx_affine_kernel(const T *__rest
 // gx = (scatter of gy to the recorded winners) [relu(y * scale + shift) > 0], written as T, and the BatchNorm-reverse sums of the stored gx:
 // stats[shard][0][c] += sum gx, [1][c] += sum gx * (y - mean) * invstd.  blockDim * gridDim is a multiple of the chunks per pixel, so a thread
 // keeps one channel chunk for its whole walk: sums in registers, folded through LDS at the end.
+// Two further forms of the same walk, so that the scattered gradient never exists in memory (it is as large as the stem's output):
+// stats only (gx = NULL), and - coef = the BatchNorm reverse's k2 | k1 | k0 - gx = k2 (scattered, gated, rounded gradient) + k1 y + k0, i.e.
+// bn_bwd_apply_kernel's result in its arithmetic, without the sums.
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_bn_kernel(const T *__restrict__ gy, const unsigned char *__restrict__ idx, const T *__restrict__ y,
                                                              const float *__restrict__ scale, const float *__restrict__ shift,
                                                              const float *__restrict__ mean_invstd, float *__restrict__ stats, T *__restrict__ gx,
-                                                             int B, int H, int W, int C, int Ho, int Wo) {
+                                                             int B, int H, int W, int C, int Ho, int Wo, const float *__restrict__ coef = nullptr) {
     constexpr int E = Lane<T>::E;
     __shared__ float red[256 * 2 * E];
     const int cpp = C / E;
@@ -288,6 +291,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_bn_kernel(const T *__restrict
     float sc[E], sf[E], mu[E], iv[E], s1[E], s2[E];
 #pragma unroll
     for (int k = 0; k < E; ++k) { sc[k] = scale[c + k]; sf[k] = shift[c + k]; mu[k] = mean_invstd[c + k]; iv[k] = mean_invstd[C + c + k]; s1[k] = s2[k] = 0.f; }
+    float k2[E], k1[E], k0[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) { k2[k] = coef ? coef[c + k] : 0.f; k1[k] = coef ? coef[C + c + k] : 0.f; k0[k] = coef ? coef[2 * C + c + k] : 0.f; }
     for (unsigned i = blockIdx.x * blockDim.x + tid; i < n; i += gridDim.x * blockDim.x) {
         unsigned t = i / cpp;
         const int w = (int)(t % W); t /= W;
@@ -328,9 +334,11 @@ __global__ __launch_bounds__(256) void maxpool_bwd_bn_kernel(const T *__restrict
             acc[k] = on ? Lane<T>::stored(acc[k]) : 0.f;
             s1[k] += acc[k];
             s2[k] = fmaf(acc[k], (yv[k] - mu[k]) * iv[k], s2[k]);
+            if (coef) acc[k] = fmaf(k2[k], acc[k], fmaf(k1[k], yv[k], k0[k]));
         }
-        Lane<T>::put(gx + e, acc);
+        if (gx) Lane<T>::put(gx + e, acc);
     }
+    if (!stats) return;
     // threads tid, tid + cpp, ... of a block share a channel chunk
 #pragma unroll
     for (int k = 0; k < E; ++k) { red[tid * 2 * E + k] = s1[k]; red[tid * 2 * E + E + k] = s2[k]; }
@@ -534,7 +542,7 @@ extern "C" int mhe_maxpool3x3s2_idx_affine_nhwc(const void *x, const float *scal
 
 extern "C" int mhe_maxpool3x3s2_bwd_bn_nhwc(const void *gy, const unsigned char *idx, const void *y, const float *scale, const float *shift,
                                             const float *mean_invstd, float *stats, void *gx, int B, int H, int W, int C, int dtype, void *stream) {
-    MHE_REQUIRE(gy && idx && y && scale && shift && mean_invstd && stats && gx && B > 0 && H > 0 && W > 0, "mhe_maxpool3x3s2_bwd_bn_nhwc: bad arguments");
+    MHE_REQUIRE(gy && idx && y && scale && shift && mean_invstd && (stats || gx) && B > 0 && H > 0 && W > 0, "mhe_maxpool3x3s2_bwd_bn_nhwc: bad arguments");
     MHE_REQUIRE(dtype == MHE_F32 || dtype == MHE_BF16, "mhe_maxpool3x3s2_bwd_bn_nhwc: dtype=%d", dtype);
     const int E = dtype == MHE_F32 ? 4 : 8;
     MHE_REQUIRE(C > 0 && C % E == 0 && 256 % (C / E) == 0 && (size_t)B * H * W * (C / E) < (1ull << 31),
@@ -543,10 +551,29 @@ extern "C" int mhe_maxpool3x3s2_bwd_bn_nhwc(const void *gy, const unsigned char 
     const size_t n = (size_t)B * H * W * (C / E);
     if (dtype == MHE_F32)
         hipLaunchKernelGGL(tb::maxpool_bwd_bn_kernel<float>, dim3(ewg(n)), dim3(256), 0, (hipStream_t)stream, (const float *)gy, idx, (const float *)y, scale, shift,
-                           mean_invstd, stats, (float *)gx, B, H, W, C, Ho, Wo);
+                           mean_invstd, stats, (float *)gx, B, H, W, C, Ho, Wo, (const float *)nullptr);
     else
         hipLaunchKernelGGL(tb::maxpool_bwd_bn_kernel<u16>, dim3(ewg(n)), dim3(256), 0, (hipStream_t)stream, (const u16 *)gy, idx, (const u16 *)y, scale, shift,
-                           mean_invstd, stats, (u16 *)gx, B, H, W, C, Ho, Wo);
+                           mean_invstd, stats, (u16 *)gx, B, H, W, C, Ho, Wo, (const float *)nullptr);
+    return check_launch("maxpool_bwd_bn_kernel");
+}
+
+extern "C" int mhe_maxpool3x3s2_bwd_bn_apply_nhwc(const void *gy, const unsigned char *idx, const void *y, const float *scale, const float *shift,
+                                                  const float *mean_invstd, const float *coef, void *gy_out, int B, int H, int W, int C, int dtype,
+                                                  void *stream) {
+    MHE_REQUIRE(gy && idx && y && scale && shift && mean_invstd && coef && gy_out && B > 0 && H > 0 && W > 0, "mhe_maxpool3x3s2_bwd_bn_apply_nhwc: bad arguments");
+    MHE_REQUIRE(dtype == MHE_F32 || dtype == MHE_BF16, "mhe_maxpool3x3s2_bwd_bn_apply_nhwc: dtype=%d", dtype);
+    const int E = dtype == MHE_F32 ? 4 : 8;
+    MHE_REQUIRE(C > 0 && C % E == 0 && 256 % (C / E) == 0 && (size_t)B * H * W * (C / E) < (1ull << 31),
+                "mhe_maxpool3x3s2_bwd_bn_apply_nhwc: C=%d: C / %d must divide 256 (a thread keeps one channel chunk)", C, E);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const size_t n = (size_t)B * H * W * (C / E);
+    if (dtype == MHE_F32)
+        hipLaunchKernelGGL(tb::maxpool_bwd_bn_kernel<float>, dim3(ewg(n)), dim3(256), 0, (hipStream_t)stream, (const float *)gy, idx, (const float *)y, scale, shift,
+                           mean_invstd, (float *)nullptr, (float *)gy_out, B, H, W, C, Ho, Wo, coef);
+    else
+        hipLaunchKernelGGL(tb::maxpool_bwd_bn_kernel<u16>, dim3(ewg(n)), dim3(256), 0, (hipStream_t)stream, (const u16 *)gy, idx, (const u16 *)y, scale, shift,
+                           mean_invstd, (float *)nullptr, (u16 *)gy_out, B, H, W, C, Ho, Wo, coef);
     return check_launch("maxpool_bwd_bn_kernel");
 }
 

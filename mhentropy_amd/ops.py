@@ -961,6 +961,17 @@ def bn_backward(g, a, y, mean_invstd, gamma, stats, dgamma, dbeta, want_masked=F
     return (gy, gm) if want_masked else gy
 
 
+def bn_bwd_coef(stats, gamma, mean_invstd, dgamma, dbeta, count):
+    """finish a BatchNorm reverse whose sums are in `stats`: writes dgamma / dbeta, returns coef = k2 | k1 | k0 [3, C] of gy = k2 g + k1 y + k0"""
+    Cc = gamma.shape[0]
+    _chk(stats, torch.float32, "bn_bwd.stats", (stat_shards(), 2, Cc)); _chk(mean_invstd, torch.float32, "bn_bwd.mean_invstd", (2, Cc))
+    _chk(gamma, torch.float32, "bn_bwd.gamma", (Cc,)); _chk(dgamma, torch.float32, "bn_bwd.dgamma", (Cc,)); _chk(dbeta, torch.float32, "bn_bwd.dbeta", (Cc,))
+    coef = torch.empty(3, Cc, device=stats.device, dtype=torch.float32)
+    check(_lib.lib().mhe_bn_bwd_finalize(_ptr(stats), _ptr(gamma), _ptr(mean_invstd), _ptr(dgamma), _ptr(dbeta), _ptr(coef), Cc, float(count), _stream()),
+          "mhe_bn_bwd_finalize")
+    return coef
+
+
 def maxpool3x3s2_idx(x, scale=None, shift=None):
     """(pooled, winning taps) of a 3x3 / stride-2 / pad-1 max pool; with scale / shift: of relu(x * scale + shift), evaluated on the load
     (mhe_maxpool3x3s2_idx_affine_nhwc: the normalised activation is never materialised)"""
@@ -978,7 +989,7 @@ def maxpool3x3s2_idx(x, scale=None, shift=None):
     return y, idx
 
 
-def maxpool3x3s2_bwd_bn(gy, idx, y, scale, shift, mean_invstd, stats):
+def maxpool3x3s2_bwd_bn(gy, idx, y, scale, shift, mean_invstd, stats, want_gx=True):
     """reverse of maxpool(relu(bn(y))) up to the BatchNorm's sums: returns gx = scatter(gy, idx) [relu(y * scale + shift) > 0] and adds
     sum gx, sum gx * xhat per channel to `stats` (then bn_backward(gx, None, y, ..., stats, reduced=True) finishes the BatchNorm reverse)"""
     B, Ho, Wo, Cc = gy.shape
@@ -990,10 +1001,25 @@ def maxpool3x3s2_bwd_bn(gy, idx, y, scale, shift, mean_invstd, stats):
         raise ValueError(f"maxpool_bwd_bn: y {tuple(y.shape)} does not pool to gy {tuple(gy.shape)}")
     _chk(scale, torch.float32, "maxpool_bwd_bn.scale", (Cc,)); _chk(shift, torch.float32, "maxpool_bwd_bn.shift", (Cc,))
     _chk(mean_invstd, torch.float32, "maxpool_bwd_bn.mean_invstd", (2, Cc)); _chk(stats, torch.float32, "maxpool_bwd_bn.stats", (stat_shards(), 2, Cc))
-    gx = torch.empty_like(y)
+    gx = torch.empty_like(y) if want_gx else None
     check(_lib.lib().mhe_maxpool3x3s2_bwd_bn_nhwc(_ptr(gy), _ptr(idx), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean_invstd), _ptr(stats), _ptr(gx),
                                                   B, H, W, Cc, dtype_code(dt), _stream()), "mhe_maxpool3x3s2_bwd_bn_nhwc")
     return gx
+
+
+def maxpool3x3s2_bwd_bn_apply(gy, idx, y, scale, shift, mean_invstd, coef):
+    """the BatchNorm reverse's result k2 gx + k1 y + k0 for gx = scatter(gy, idx) [relu(y * scale + shift) > 0], gx itself never stored
+    (mhe_maxpool3x3s2_bwd_bn_apply_nhwc; coef from bn_backward(..., coef_only=True) on the sums of maxpool3x3s2_bwd_bn(want_gx=False))"""
+    B, Ho, Wo, Cc = gy.shape
+    dt = gy.dtype
+    _chk(gy, dt, "maxpool_bwd_apply.gy"); _chk(idx, torch.uint8, "maxpool_bwd_apply.idx", gy.shape); _chk(y, dt, "maxpool_bwd_apply.y")
+    H, W = y.shape[1], y.shape[2]
+    _chk(scale, torch.float32, "maxpool_bwd_apply.scale", (Cc,)); _chk(shift, torch.float32, "maxpool_bwd_apply.shift", (Cc,))
+    _chk(mean_invstd, torch.float32, "maxpool_bwd_apply.mean_invstd", (2, Cc)); _chk(coef, torch.float32, "maxpool_bwd_apply.coef", (3, Cc))
+    out = torch.empty_like(y)
+    check(_lib.lib().mhe_maxpool3x3s2_bwd_bn_apply_nhwc(_ptr(gy), _ptr(idx), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean_invstd), _ptr(coef), _ptr(out),
+                                                        B, H, W, Cc, dtype_code(dt), _stream()), "mhe_maxpool3x3s2_bwd_bn_apply_nhwc")
+    return out
 
 
 def maxpool3x3s2_bwd(gy, idx, H, W):

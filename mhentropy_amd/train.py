@@ -139,6 +139,7 @@ class TrainStep:
         self.train_recompute = os.environ.get("MHE_TRAIN_RECOMPUTE", "1") == "1"
         self.conv3_fold = os.environ.get("MHE_CONV3_FOLD", "1") == "1"
         self.conv3_fold_cat = os.environ.get("MHE_CONV3_FOLD_CAT", "1") == "1"
+        self.stem_bwd_two_pass = os.environ.get("MHE_STEM_BWD_TWO_PASS", "1") == "1"
         # the stem's BatchNorm + ReLU folded into its max pool, forward and reverse (ops.maxpool3x3s2_idx / maxpool3x3s2_bwd_bn)
         self.stem_pool_fused = os.environ.get("MHE_STEM_POOL_FUSED", "1") == "1"
         self.bn_on_load_wide = os.environ.get("MHE_BN_BWD_ON_LOAD_WIDE", "1") == "1"
@@ -730,8 +731,15 @@ class TrainStep:
         if self.stem_pool_fused:
             # pool scatter + ReLU gate (recomputed from the raw output) + the BatchNorm-reverse sums in one pass
             st = pool.take(u.cout)
-            g_r0 = ops.maxpool3x3s2_bwd_bn(g, self.pool_idx, u.y, u.scale, u.shift, u.mi, st)
-            gy0 = self._bn_bwd(u, g_r0, None, pool, stats=st)
+            if self.stem_bwd_two_pass:
+                # the same walk twice - sums, then the BatchNorm reverse applied where the scattered gradient is formed: that gradient (as
+                # large as the stem's output: 0.54 GB at C2) is never written or read back (MHE_STEM_BWD_TWO_PASS=0: one walk + an apply pass)
+                ops.maxpool3x3s2_bwd_bn(g, self.pool_idx, u.y, u.scale, u.shift, u.mi, st, want_gx=False)
+                coef = ops.bn_bwd_coef(st, u.bn.weight.data, u.mi, u.dgamma, u.dbeta, u.y.numel() // u.cout)
+                gy0 = ops.maxpool3x3s2_bwd_bn_apply(g, self.pool_idx, u.y, u.scale, u.shift, u.mi, coef)
+            else:
+                g_r0 = ops.maxpool3x3s2_bwd_bn(g, self.pool_idx, u.y, u.scale, u.shift, u.mi, st)
+                gy0 = self._bn_bwd(u, g_r0, None, pool, stats=st)
         else:
             g_r0 = ops.maxpool3x3s2_bwd(g, self.pool_idx, self.r0.shape[1], self.r0.shape[2])
             gy0 = self._bn_bwd(u, g_r0, self.r0, pool)

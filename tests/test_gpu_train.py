@@ -282,6 +282,18 @@ def test_stem_pool_with_batchnorm_folded_in(gpu_lib, dt, H, W):
     ops.check(_lib.lib().mhe_bn_bwd_reduce_nhwc(ops._ptr(g_sep), ops._ptr(r0), ops._ptr(y0d), ops._ptr(mi), ops._ptr(st_ref), B * H * W, C,
                                                 ops.dtype_code(dt), ops._stream()), "mhe_bn_bwd_reduce_nhwc")
     assert_close(st.sum(0).cpu(), st_ref.sum(0).cpu(), 1e-5, what="BatchNorm-reverse sums")
+    # the two-walk form of the train step: sums without the scattered gradient, then the BatchNorm reverse applied where it is formed -
+    # to the bit what the apply pass makes of the stored gradient
+    st2 = torch.zeros_like(st)
+    assert ops.maxpool3x3s2_bwd_bn(gy, idx, y0d, sc, sh, mi, st2, want_gx=False) is None
+    assert_close(st2.sum(0).cpu(), st.sum(0).cpu(), 1e-6, what="sums of the walk that stores nothing")
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda()
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    coef = ops.bn_bwd_coef(st, gamma, mi, dg, db, B * H * W)
+    dg1, db1 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    gy_ref = ops.bn_backward(gx, None, y0d, mi, gamma, st, dg1, db1, reduced=True)
+    gy_two = ops.maxpool3x3s2_bwd_bn_apply(gy, idx, y0d, sc, sh, mi, coef)
+    assert torch.equal(gy_two, gy_ref) and torch.equal(dg, dg1) and torch.equal(db, db1)
     # torch autograd through the same composition (f32): values up to the storage rounding of dt
     yt = y0.clone().requires_grad_(True)
     rt = torch.relu(yt * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
