@@ -153,3 +153,24 @@ def test_fragment_major_order_is_the_headers_formula():
     o, k = torch.meshgrid(torch.arange(rows), torch.arange(K), indexing="ij")
     pos = ((o // 16 * (K // 32) + k // 32) * 64 + (k % 32 // 8) * 16 + o % 16) * 8 + k % 8
     assert torch.equal(flat[pos.reshape(-1)], idx.reshape(-1))
+
+
+def test_round3_entries_refuse_what_they_do_not_support():
+    """argument checks of the round-3 C entries run before anything touches the GPU: unsupported geometries and null operands come back
+    as MHE_ERR_ARG with a message, never as a launch"""
+    L = _lib.lib()
+    # hidden 512, a multiple of 64 hypotheses per image
+    assert L.mhe_flow_couplings_frag_supported(64 * 3, 3, 45, 512, 12) == 1
+    assert L.mhe_flow_couplings_frag_supported(40 * 3, 3, 45, 512, 12) == 0 and L.mhe_flow_couplings_frag_supported(64 * 3, 3, 45, 256, 12) == 0
+    assert L.mhe_flow_couplings_frag_supported(64 * 3, 3, 45, 512, 40) == 0
+    assert L.mhe_flow_reverse_chain_supported(64 * 3, 3, 45, 512, 12) == 1 and L.mhe_flow_reverse_chain_supported(128 * 3, 3, 45, 512, 12) == 0
+    null = None
+    rc = L.mhe_flow_couplings_frag_bf16(null, null, null, 0, null, null, null, 0, null, null, null, null, null, null, null, 192, 3, 45, 512, 12, 0, null)
+    assert rc != 0 and b"null pointer" in L.mhe_last_error()
+    rc = L.mhe_flow_reverse_chain_bf16(null, null, null, 0.0, null, null, null, null, null, null, null, 0, null, null, null, null, null, 0, null, 0, null,
+                                       192, 3, 45, 512, 12, null)
+    assert rc != 0 and b"null pointer" in L.mhe_last_error()
+    rc = L.mhe_conv3_bn_fold(null, null, null, null, null, null, 1024.0, null, null, null, null, 256, null, 64, null, null, 256, 64, null)
+    assert rc != 0 and b"null pointer" in L.mhe_last_error()
+    rc = L.mhe_pack_transpose_bf16(null, 0, null, null, 4, 4, null)
+    assert rc != 0 and b"bad arguments" in L.mhe_last_error()
