@@ -313,6 +313,11 @@ struct DmaParams {
     unsigned rcp_wo, rcp_ho;          // ceil(2^32 / Wo), ceil(2^32 / Ho): exact quotients for pixel counts < 2^32 / max(Wo, Ho)
     unsigned x_bytes, gy_bytes;
     int plain;                        // 1x1, stride 1, pad 0: the operand row is the pixel's own channel vector
+    // XCD-aware order: the output tiles of ONE pixel slice read the same pixels (3x3: each of its column tiles another tap pair) - dispatched
+    // in grid order they land on eight different XCDs and every L2 fetches the slice for itself (counters: 1,080 MB per launch for the
+    // 268 MB of layer1's 3x3 layer).  xcd = 1: workgroup L (hardware order, XCD L % 8) takes tile (L / 8) % tiles of slice 8 (L / 8 / tiles)
+    // + L % 8 - a slice's tiles run on one XCD, next to each other in time; nzt = slices that exist (gridDim.z is rounded up to 8)
+    int xcd, nzt;
 };
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
@@ -333,8 +338,15 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_dma_kernel(const DmaParams
     __shared__ __attribute__((aligned(1024))) char ring[NBUF * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int bz = p.gz ? (int)blockIdx.z / p.gz : 0, zs = p.gz ? (int)blockIdx.z - bz * p.gz : (int)blockIdx.z;      // problem of a grouped launch, slice
+    int bx = blockIdx.x, by = blockIdx.y, bzl = blockIdx.z;
+    if (dp.xcd) {
+        const int S = gridDim.x * gridDim.y, L = bx + gridDim.x * (by + gridDim.y * bzl), j = L >> 3;
+        const int sl = j / S, t = j - sl * S;
+        bzl = sl * 8 + (L & 7); bx = t % (int)gridDim.x; by = t / (int)gridDim.x;
+        if (bzl >= dp.nzt) return;
+    }
+    const int m0 = by * BM, n0 = bx * BN;
+    const int bz = p.gz ? bzl / p.gz : 0, zs = p.gz ? bzl - bz * p.gz : bzl;      // problem of a grouped launch, slice
     const long k_begin = (long)zs * p.chunk;
     const long k_end = k_begin + p.chunk < p.P ? k_begin + p.chunk : p.P;
     const unsigned OOB = 0x80000000u;
@@ -467,7 +479,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_dma_kernel(const DmaParams
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (p.ws) p.ws[((size_t)blockIdx.z * p.Mp + m) * p.Np + n] = acc[i][j][r];
+                if (p.ws) p.ws[((size_t)bzl * p.Mp + m) * p.Np + n] = acc[i][j][r];
                 else if (m < p.Cout && n < p.N) atomicAdd(p.dw + (size_t)bz * p.dw_bs + (size_t)m * p.ldw + n, acc[i][j][r]);
             }
         }
@@ -540,7 +552,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const float *__restrict__ s
 using namespace mhe;
 
 // geometry of a launch: tile, grid and pixel chunk (shared by the launcher and the workspace query)
-struct WgradPlan { int BM, BN, gx, gy, gz; long chunk; bool bf16k, small, narrow, dma, big; };
+struct WgradPlan { int BM, BN, gx, gy, gz; long chunk; bool bf16k, small, narrow, dma, big, xcd; };
 static WgradPlan plan_wgrad(const mhe_conv_desc *d, int Ho_ = 0, int Wo_ = 0, int nbatch = 1) {
     WgradPlan w;
     const int Ho = Ho_ > 0 ? Ho_ : (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = Wo_ > 0 ? Wo_ : (d->W + 2 * d->pad - d->KW) / d->stride + 1;
@@ -567,6 +579,12 @@ static WgradPlan plan_wgrad(const mhe_conv_desc *d, int Ho_ = 0, int Wo_ = 0, in
     // (big tile: one workgroup per CU; a grouped launch - nbatch problems side by side - aims at three resident rounds of workgroups)
     long want = (nbatch > 1 ? (w.big ? 768 : 1536) : w.big ? 256 : w.bf16k ? target_wgs : 2048) / ((long)w.gx * w.gy * nbatch);
     if (want < 1) want = 1;
+    // XCD-aware order (DmaParams::xcd): the launch rounds the slice count UP to a multiple of 8 with empty slices - aim at a multiple of 8 from
+    // below, or the big tile's one-workgroup-per-CU launch grows a second round (28 slices x 9 tiles -> 32 x 9 = 288 workgroups: +65 %)
+    // (the big tile keeps its slice count - and the grid order - where that is not a multiple of 8 already: 24 x 9 = 216 workgroups on 256 CUs
+    // cost the 3x3 layers of 256 channels more than the shared L2 gave them)
+    w.xcd = w.dma && (long)w.gx * w.gy > 1 && want >= 8 && (!w.big || want % 8 == 0);
+    if (w.xcd) want = want / 8 * 8;
     long chunk = (P + want - 1) / want;
     static const long min_bf16 = getenv("MHE_WGRAD_MINCHUNK") ? atol(getenv("MHE_WGRAD_MINCHUNK")) : 512;
     const long min_chunk = w.bf16k ? min_bf16 : 64;
@@ -660,7 +678,8 @@ static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, fl
     p.ws = (ws && gz > 1 && gz <= 64 && need <= ws_floats && (size_t)d->Cout * p.N >= 131072) ? ws : nullptr;
     MHE_REQUIRE(nbatch == 1 || (w.dma && (long)gz * nbatch < 65536), "mhe_conv_wgrad_batched_nhwc: the grouped form runs on the LDS-DMA kernel (bf16, operands below 2 GiB)");
     if (nbatch > 1) { p.gz = gz; p.x_bs = x_bs; p.gy_bs = gy_bs; p.dw_bs = dw_bs; }
-    const dim3 grid(gx, gyy, gz * nbatch), block(256);
+    dim3 grid(gx, gyy, gz * nbatch);
+    const dim3 block(256);
     hipStream_t s = (hipStream_t)stream;
     const size_t xb = (size_t)d->B * d->H * d->W * d->Cin * 2, gb = (size_t)p.P * d->Cout * 2;
     const bool use_dma = w.dma;
@@ -673,6 +692,10 @@ static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, fl
         dp.rcp_wo = (unsigned)((0x100000000ull + p.Wo - 1) / p.Wo); dp.rcp_ho = (unsigned)((0x100000000ull + p.Ho - 1) / p.Ho);
         dp.x_bytes = (unsigned)xb; dp.gy_bytes = (unsigned)gb;
         dp.plain = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && p.stride_w == 1 && p.pad_w == 0;
+        static const int xcd_env = getenv("MHE_WGRAD_XCD") ? atoi(getenv("MHE_WGRAD_XCD")) : 1;
+        dp.nzt = gz * nbatch;
+        dp.xcd = xcd_env && w.xcd && dp.nzt >= 8;
+        if (dp.xcd) grid.z = (unsigned)((dp.nzt + 7) / 8 * 8);
         if (w.big) hipLaunchKernelGGL((wgrad::wgrad_dma_kernel<256, 256, 4, 2>), grid, dim3(512), 0, s, dp);
         else if (narrow) {
             if (small) hipLaunchKernelGGL((wgrad::wgrad_dma_kernel<64, 64, 2, 2>), grid, block, 0, s, dp);
