@@ -451,7 +451,7 @@ int mhe_flow_lrelu_bwd_sum(const void *g, int g_dtype, const void *h, int h_dtyp
 /* mhe_flow_mask_pad_f32 / mhe_flow_couple_bwd_f32 with optional bf16 copies of the GEMM operands they produce */
 int mhe_flow_mask_pad_mixed(const float *x, const float *mask, float *xp, void *xp_bf16, long R, int dim, void *stream);
 /* The data-gradient chain of ALL couplings in one launch (bf16 mode, hidden 512, 64 hypotheses per image, forward activations kept by
- * mhe_flow_couplings_bf16_emit): what mask_pad -> couple_bwd -> (GO W2, leaky-ReLU reverse + sums, G2 W1, leaky-ReLU reverse + sums, G1 W0) x 2
+ * mhe_flow_couplings_frag_bf16, which also leaves their signs as sign_bits): what mask_pad -> couple_bwd -> (GO W2, leaky-ReLU reverse + sums, G2 W1, leaky-ReLU reverse + sums, G1 W0) x 2
  * -> couple_accum compute coupling by coupling (13 launches each), with every intermediate kept on chip.  A workgroup owns one image's 64
  * rows.  Outputs: GO / G2 / G1 [nets][R][64 | 512 | 512] and the masked inputs XP [ncoup][R][64] in bf16 (operands of the grouped weight
  * gradients), Gc [B][cond_stride] (the conditioning table's gradient: column (2 net + layer) * hidden + unit; cond_stride % 4 == 0),
@@ -481,14 +481,15 @@ int mhe_flow_reverse_chain_supported(int R, int B, int dim, int hidden, int ncou
  * order of the f32 accumulation.  w0F, w1F, w2F = net 0's W0 [512][64 (dim zero-padded)], W1 [512][512], W2 [64 (padded)][512] as bf16 in
  * FRAGMENT-MAJOR order (see mhe_flow_reverse_chain_bf16), net k at + k * w_net_stride elements; cond [B][cond_stride] with column
  * (2 net + layer) * 512 + unit; bias2 [nets][64].  h1, h2, o: all three or none - the activations the reverse pass reads
- * (bf16 [nets][R][512] x 2, f32 [nets][R][64]). */
+ * (bf16 [nets][R][512] x 2, f32 [nets][R][64]); sign_bits (optional, with them): the signs of h1 / h2 as mhe_flow_reverse_chain_bf16
+ * reads them - u64 [nets][R / 64][2 layers][8 waves][64 lanes], bit (unit tile * 4 + row tile) * 4 + e of the MFMA accumulator layout. */
 int mhe_flow_couplings_frag_supported(int R, int B, int dim, int hidden, int ncoup);
 int mhe_flow_couplings_frag_bf16(const float *in, float *out, const float *cond, int cond_stride, const void *w0F, const void *w1F,
                                  const void *w2F, long w_net_stride, const float *bias2, const float *mask, float *sum_s,
-                                 float *log_prob, void *h1, void *h2, float *o, int R, int B, int dim, int hidden, int ncoup,
-                                 int direction, void *stream);
+                                 float *log_prob, void *h1, void *h2, float *o, void *sign_bits, int R, int B, int dim, int hidden,
+                                 int ncoup, int direction, void *stream);
 int mhe_flow_reverse_chain_bf16(const float *x_out, const float *g_x, const float *g_logp, float q_weight, const float *mask,
-                                const float *o_pre, const void *h1, const void *h2, const void *w2F, const void *w1F,
+                                const float *o_pre, const void *sign_bits, const void *w2F, const void *w1F,
                                 const void *w0F, long w_net_stride, void *GO_bf16, void *G2_bf16, void *G1_bf16, void *XP_bf16,
                                 float *Gc, int cond_stride, float *db2, long db_net_stride, float *z0, int R, int B, int dim,
                                 int hidden, int ncoup, void *stream);

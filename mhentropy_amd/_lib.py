@@ -102,8 +102,8 @@ SIGNATURES = {
     "mhe_conv3_bn_fold": (_i, [_p] * 6 + [_f] + [_p] * 4 + [_i, _p, _i] + [_p] * 2 + [_i, _i, _p]),
     "mhe_flow_reverse_chain_supported": (_i, [_i, _i, _i, _i, _i]),
     "mhe_flow_couplings_frag_supported": (_i, [_i, _i, _i, _i, _i]),
-    "mhe_flow_couplings_frag_bf16": (_i, [_p, _p, _p, _i, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
-    "mhe_flow_reverse_chain_bf16": (_i, [_p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _i, _p, _l, _p, _i, _i, _i, _i, _i, _p]),
+    "mhe_flow_couplings_frag_bf16": (_i, [_p, _p, _p, _i, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "mhe_flow_reverse_chain_bf16": (_i, [_p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _i, _p, _l, _p, _i, _i, _i, _i, _i, _p]),
     "mhe_pack_transpose_bf16": (_i, [_p, _l, _p, _p, _i, _i, _p]),
     "mhe_gram_stats_floats": (_sz, [_i]),
     "mhe_gram_stats_workspace_bytes": (_sz, [_i]),

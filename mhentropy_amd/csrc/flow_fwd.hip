@@ -31,6 +31,8 @@ struct Args {
     long w_stride;                                        // net k lies k * w_stride elements further
     u16 *h1e, *h2e;                                       // EMIT: [nets][R][512]
     float *oe;                                            // EMIT: [nets][R][64]
+    uint2 *hbits;                                         // EMIT (optional): signs of H1 / H2 in the accumulator layout, [nets][R / 64][layer 2][wave 8][lane 64]
+                                                          //   bit (unit tile nt * 4 + row tile mt) * 4 + e - what the reverse chain masks with (flow_rev.hip)
     int R, B, dim, ncoup, cstride, inverse;
 };
 
@@ -119,7 +121,8 @@ __global__ __launch_bounds__(512) void couplings_frag_kernel(const Args a) {
             v4f acc[4][4];                                // [unit tile of the wave's 64][row tile]
             // + conditioning row, leaky-ReLU, bf16 -> the wave's k-tile (accumulator layout: 8 bytes per (unit tile, row tile)); EMIT: the
             // finished tile out as whole 128-byte rows
-            auto finish = [&](const float4 (&c)[4], u16 *he) __attribute__((always_inline)) {
+            auto finish = [&](const float4 (&c)[4], u16 *he, int layer) __attribute__((always_inline)) {
+                uint2 sg = make_uint2(0u, 0u);
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -129,8 +132,15 @@ __global__ __launch_bounds__(512) void couplings_frag_kernel(const Args a) {
                         o.x = (unsigned)f32_to_bf16(leaky(g[0] + c[nt].x)) | ((unsigned)f32_to_bf16(leaky(g[1] + c[nt].y)) << 16);
                         o.y = (unsigned)f32_to_bf16(leaky(g[2] + c[nt].z)) | ((unsigned)f32_to_bf16(leaky(g[3] + c[nt].w)) << 16);
                         *reinterpret_cast<uint2 *>(tile + ac_off[nt] + 2048 * mt) = o;
+                        if constexpr (EMIT) {             // sign of the STORED value (bf16: sign bit clear and not zero)
+                            const unsigned b4 = (unsigned)((o.x & 0x8000u) == 0 && (o.x & 0x7fffu) != 0) | ((unsigned)((o.x & 0x80000000u) == 0 && (o.x & 0x7fff0000u) != 0) << 1) |
+                                                ((unsigned)((o.y & 0x8000u) == 0 && (o.y & 0x7fffu) != 0) << 2) | ((unsigned)((o.y & 0x80000000u) == 0 && (o.y & 0x7fff0000u) != 0) << 3);
+                            if (nt * 4 + mt < 8) sg.x |= b4 << ((nt * 4 + mt) * 4);
+                            else sg.y |= b4 << (((nt * 4 + mt) & 7) * 4);
+                        }
                     }
                 if constexpr (EMIT) {
+                    if (a.hbits) a.hbits[(((size_t)net * gridDim.x + blockIdx.x) * 2 + layer) * 512 + wave * 64 + lane] = sg;
                     const rsrc_t hr = rsrc_of(he + (size_t)net * R * H, hbytes);
                     wave_sync();                          // the tile is this wave's own: wave-local ordering suffices
 #pragma unroll
@@ -166,7 +176,7 @@ __global__ __launch_bounds__(512) void couplings_frag_kernel(const Args a) {
             fetch_w(fA, 0);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();                              // (B0) every wave is through the layer 2 before: act is free
-            finish(c0, a.h1e);
+            finish(c0, a.h1e, 0);
             __syncthreads();                              // (B1) H1 complete in act
             // ================= layer 1 (K = 512): W1 fragments into two register sets, k-tile kt + 1's in flight under k-tile kt's 32 MFMAs
 #pragma unroll
@@ -207,7 +217,7 @@ __global__ __launch_bounds__(512) void couplings_frag_kernel(const Args a) {
                 fetch_net(n == 0 ? net + 1 : 2 * coupling_at(nstep));
             }
             __builtin_amdgcn_sched_barrier(0);
-            finish(c1, a.h2e);
+            finish(c1, a.h2e, 1);
             __syncthreads();                              // (B3) H2 complete in act
             // ================= layer 2 (K = 512) + the coupling
             v4f o[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
@@ -278,8 +288,8 @@ extern "C" int mhe_flow_couplings_frag_supported(int R, int B, int dim, int hidd
 
 extern "C" int mhe_flow_couplings_frag_bf16(const float *in, float *out, const float *cond, int cond_stride, const void *w0F, const void *w1F,
                                             const void *w2F, long w_net_stride, const float *bias2, const float *mask, float *sum_s,
-                                            float *log_prob, void *h1, void *h2, float *o, int R, int B, int dim, int hidden, int ncoup,
-                                            int direction, void *stream) {
+                                            float *log_prob, void *h1, void *h2, float *o, void *sign_bits, int R, int B, int dim, int hidden,
+                                            int ncoup, int direction, void *stream) {
     MHE_REQUIRE(in && out && cond && w0F && w1F && w2F && bias2 && mask, "mhe_flow_couplings_frag_bf16: null pointer");
     MHE_REQUIRE(mhe_flow_couplings_frag_supported(R, B, dim, hidden, ncoup),
                 "mhe_flow_couplings_frag_bf16: needs hidden 512, a multiple of 64 hypotheses per image, at most %d couplings (R=%d B=%d)", flowfwd::MAXC, R, B);
@@ -288,10 +298,11 @@ extern "C" int mhe_flow_couplings_frag_bf16(const float *in, float *out, const f
     MHE_REQUIRE((long)R * hidden < (1L << 31), "mhe_flow_couplings_frag_bf16: R x hidden beyond the 32-bit row offsets");
     const bool emit = h1 || h2 || o;
     MHE_REQUIRE(!emit || (h1 && h2 && o), "mhe_flow_couplings_frag_bf16: h1, h2 and o come together");
+    MHE_REQUIRE(!sign_bits || emit, "mhe_flow_couplings_frag_bf16: sign_bits come with h1, h2 and o");
     flowfwd::Args a;
     a.in = in; a.cond = cond; a.bias2 = bias2; a.mask = mask; a.out = out; a.sum_s = sum_s; a.logp = log_prob;
     a.w0F = (const u16 *)w0F; a.w1F = (const u16 *)w1F; a.w2F = (const u16 *)w2F; a.w_stride = w_net_stride;
-    a.h1e = (u16 *)h1; a.h2e = (u16 *)h2; a.oe = o;
+    a.h1e = (u16 *)h1; a.h2e = (u16 *)h2; a.oe = o; a.hbits = (uint2 *)sign_bits;
     a.R = R; a.B = B; a.dim = dim; a.ncoup = ncoup; a.cstride = cond_stride; a.inverse = direction == MHE_FLOW_INVERSE;
     if (emit) hipLaunchKernelGGL(flowfwd::couplings_frag_kernel<true>, dim3(R / 64), dim3(512), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(flowfwd::couplings_frag_kernel<false>, dim3(R / 64), dim3(512), 0, (hipStream_t)stream, a);

@@ -15,8 +15,8 @@
 //            G1 = GH1 * lrelu'(H1) -> bf16 -> LDS k-tile `wave` (+ global G1, + sums -> d cond[b][layer 0])
 //   phase 3  GX += G1 W0       K = 512   a wave = one 16-dim tile x two row tiles, both nets accumulated in registers
 //   then the coupling's element-wise reverse (tanh / exp, hand/flows.py:213-216) on the 64 x 45 flow variable held in LDS.
-// Every global access is whole 128-byte rows or 1 KiB runs: the kept activations and the outgoing G2 / G1 move as [8 rows][128 B] pieces and
-// change to / from the accumulator layout through the wave's own k-tile; the weight operands are FRAGMENT-MAJOR copies of the train step's
+// Every global access is whole 128-byte rows or 1 KiB runs: the outgoing G2 / G1 move as [8 rows][128 B] pieces out of the wave's own k-tile;
+// of the kept activations only the SIGNS are read (64 bits per lane and epilogue, laid down by the forward kernel in the accumulator layout); the weight operands are FRAGMENT-MAJOR copies of the train step's
 // bf16 packs (w2F from W2^T [512][64], w1F from W1^T [512][512], w0F from W0^T [64][512]; see frag()), one pitch apart from net to net.
 // The kernel is bound by the L2 -> register weight stream (640 KiB per net and workgroup, as the forward kernel's), not by its 0.5 TFLOP.
 #include "flow_frag.h"
@@ -29,7 +29,7 @@ using namespace flowfrag;
 constexpr int H = 512, ROWS = 64, XP = 64, XG = 68, KT = H / 64;
 struct Args {
     const float *x_out, *g_x, *g_logp, *mask, *oe;       // [R][dim], [R][dim], [B] | NULL, [ncoup][dim], [nets][R][64]
-    const u16 *h1e, *h2e;                                 // [nets][R][512]
+    const uint2 *hbits;                                   // signs of the kept H1 / H2: [nets][B][layer 2][wave 8][lane 64] x 64 bits (flow_fwd.hip)
     const u16 *w2F, *w1F, *w0F;                           // net 0's fragment-major operands; net k lies k * w_stride elements further
     long w_stride;
     u16 *GOb, *G2b, *G1b, *XPb;                           // [nets][R][64], [nets][R][512] x 2, [ncoup][R][64]
@@ -82,15 +82,20 @@ __global__ __launch_bounds__(512) void chain_kernel(const Args a) {
     const int nt3 = wave >> 1, mt3 = 2 * (wave & 1);      // phase 3: this wave's dim tile and pair of row tiles of GX
     v4f a3[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
     // fetched a net ahead, under phase 3: phase 1's W2^T fragments and the kept H2 rows of its epilogue
-    uint4 w2f[2][4], hc2[8];
+    uint4 w2f[2][4];
+    uint2 hc2;
+    // the signs of the kept activations under this lane's accumulators: bit (unit tile nt * 4 + row tile mt) * 4 + e, written by the forward
+    // kernel in this very layout - 8 bytes per lane and epilogue where the bf16 rows were 32 VGPRs and 16 KiB of HBM per wave
+    auto fetch_bits = [&](int net, int layer) __attribute__((always_inline)) {
+        return a.hbits[(((size_t)net * B + b) * 2 + layer) * 512 + wave * 64 + lane];
+    };
     auto fetch_net = [&](int net) __attribute__((always_inline)) {
-        const rsrc_t w2 = rsrc_of(a.w2F + (size_t)net * a.w_stride, (size_t)H * 64 * 2), h2 = rsrc_of(a.h2e + (size_t)net * R * H, hbytes);
+        const rsrc_t w2 = rsrc_of(a.w2F + (size_t)net * a.w_stride, (size_t)H * 64 * 2);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) w2f[kk][nt] = frag(w2, lane16, 4 * wave + nt, 2, kk);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) hc2[i] = bld(h2, co, i * cstep);
+        hc2 = fetch_bits(net, 1);
     };
     // the coupling's kept s / t pre-activations of this thread's eight elements, requested at the end of the coupling before: read where
     // they are used - inside the branch on the mask - they were eight dependent HBM round trips per coupling
@@ -154,16 +159,12 @@ __global__ __launch_bounds__(512) void chain_kernel(const Args a) {
         for (int n = 0; n < 2; ++n) {
             const int net = 2 * ci + n, slot = net * 2;
             const rsrc_t w1 = rsrc_of(a.w1F + (size_t)net * a.w_stride, (size_t)H * H * 2), w0 = rsrc_of(a.w0F + (size_t)net * a.w_stride, (size_t)64 * H * 2);
-            const rsrc_t h1 = rsrc_of(a.h1e + (size_t)net * R * H, hbytes);
             const rsrc_t G2o = rsrc_of(a.G2b + (size_t)net * R * H, hbytes), G1o = rsrc_of(a.G1b + (size_t)net * R * H, hbytes);
             v4f acc[4][4];                                // [unit tile of the wave's 64][row tile]
-            uint4 hc1[8];
-            // leaky-ReLU reverse of the accumulators against the kept activation (staged through the wave's k-tile to reach the accumulator
-            // layout), bf16 result into the k-tile, column sums over the 64 rows -> conditioning gradient, the finished tile out to Go
-            auto epilogue = [&](const uint4 (&hc)[8], rsrc_t Go, int cslot) __attribute__((always_inline)) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4 *>(tile + pc_off[i & 1] + 1024 * i) = hc[i];
-                wave_sync();                              // the tile is this wave's own: wave-local ordering suffices
+            uint2 hc1;
+            // leaky-ReLU reverse of the accumulators against the kept activation's sign, bf16 result into the k-tile, column sums over the 64
+            // rows -> conditioning gradient, the finished tile out to Go
+            auto epilogue = [&](const uint2 hc, rsrc_t Go, int cslot) __attribute__((always_inline)) {
                 float csum[4][4];
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
@@ -174,17 +175,15 @@ __global__ __launch_bounds__(512) void chain_kernel(const Args a) {
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt) {
                         uint2 *pc = reinterpret_cast<uint2 *>(tile + ac_off[nt] + 2048 * mt);
-                        const uint2 h = *pc;
-                        const float h0 = __uint_as_float(h.x << 16), h1v = __uint_as_float(h.x & 0xffff0000u);
-                        const float h2v = __uint_as_float(h.y << 16), h3 = __uint_as_float(h.y & 0xffff0000u);
+                        const unsigned sg = ((nt * 4 + mt) < 8 ? hc.x : hc.y) >> (((nt * 4 + mt) & 7) * 4);
                         v4f g = acc[nt][mt];
-                        g[0] = h0 > 0.f ? g[0] : 0.01f * g[0]; g[1] = h1v > 0.f ? g[1] : 0.01f * g[1];
-                        g[2] = h2v > 0.f ? g[2] : 0.01f * g[2]; g[3] = h3 > 0.f ? g[3] : 0.01f * g[3];
+                        g[0] = (sg & 1u) ? g[0] : 0.01f * g[0]; g[1] = (sg & 2u) ? g[1] : 0.01f * g[1];
+                        g[2] = (sg & 4u) ? g[2] : 0.01f * g[2]; g[3] = (sg & 8u) ? g[3] : 0.01f * g[3];
                         csum[nt][0] += g[0]; csum[nt][1] += g[1]; csum[nt][2] += g[2]; csum[nt][3] += g[3];
                         uint2 o;
                         o.x = (unsigned)f32_to_bf16(g[0]) | ((unsigned)f32_to_bf16(g[1]) << 16);
                         o.y = (unsigned)f32_to_bf16(g[2]) | ((unsigned)f32_to_bf16(g[3]) << 16);
-                        *pc = o;                          // (the 8 bytes this lane alone reads and writes)
+                        *pc = o;
                     }
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
@@ -211,12 +210,10 @@ __global__ __launch_bounds__(512) void chain_kernel(const Args a) {
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mfma(w2f[kk][nt], fa[mt], acc[nt][mt]);
             }
-            // the kept H1 rows of phase 2's epilogue: requested here, under phase 1's epilogue, so that they are older than every W1 fragment
-            // of phase 2 (loads return in order: asked for later they would hold k-tiles up behind an HBM round trip; asked for before
-            // phase 1 they did not fit the register file beside its operands and were spilled as they arrived)
+            // the signs of H1 for phase 2's epilogue: requested here, under phase 1's epilogue, so that the load is older than every W1
+            // fragment of phase 2 (loads return in order: asked for later it would hold k-tiles up behind an HBM round trip)
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) hc1[i] = bld(h1, co, i * cstep);
+            hc1 = fetch_bits(net, 0);
             if (n == 1) __syncthreads();                  // (B0) every wave is through net 0's phase 3: act is free (net 0: the barriers above)
             epilogue(hc2, G2o, slot + 1);
             __syncthreads();                              // (B1) G2 complete in act
@@ -324,18 +321,18 @@ extern "C" int mhe_flow_reverse_chain_supported(int R, int B, int dim, int hidde
 }
 
 extern "C" int mhe_flow_reverse_chain_bf16(const float *x_out, const float *g_x, const float *g_logp, float q_weight, const float *mask,
-                                           const float *o_pre, const void *h1, const void *h2, const void *w2F, const void *w1F,
+                                           const float *o_pre, const void *sign_bits, const void *w2F, const void *w1F,
                                            const void *w0F, long w_net_stride, void *GO_bf16, void *G2_bf16, void *G1_bf16, void *XP_bf16,
                                            float *Gc, int cond_stride, float *db2, long db_net_stride, float *z0, int R, int B, int dim,
                                            int hidden, int ncoup, void *stream) {
-    MHE_REQUIRE(x_out && g_x && mask && o_pre && h1 && h2 && w2F && w1F && w0F && GO_bf16 && G2_bf16 && G1_bf16 && XP_bf16 && Gc && db2,
+    MHE_REQUIRE(x_out && g_x && mask && o_pre && sign_bits && w2F && w1F && w0F && GO_bf16 && G2_bf16 && G1_bf16 && XP_bf16 && Gc && db2,
                 "mhe_flow_reverse_chain_bf16: null pointer");
     MHE_REQUIRE(mhe_flow_reverse_chain_supported(R, B, dim, hidden, ncoup), "mhe_flow_reverse_chain_bf16: needs hidden 512 and 64 hypotheses per image (R=%d B=%d)", R, B);
     MHE_REQUIRE((long)R * hidden < (1L << 31), "mhe_flow_reverse_chain_bf16: R x hidden beyond the 32-bit row offsets");
     MHE_REQUIRE(cond_stride % 4 == 0 && cond_stride >= 4 * ncoup * hidden && w_net_stride > 0 && db_net_stride >= 0, "mhe_flow_reverse_chain_bf16: bad strides");
     flowrev::Args a;
     a.x_out = x_out; a.g_x = g_x; a.g_logp = g_logp; a.mask = mask; a.oe = o_pre;
-    a.h1e = (const u16 *)h1; a.h2e = (const u16 *)h2; a.w2F = (const u16 *)w2F; a.w1F = (const u16 *)w1F; a.w0F = (const u16 *)w0F;
+    a.hbits = (const uint2 *)sign_bits; a.w2F = (const u16 *)w2F; a.w1F = (const u16 *)w1F; a.w0F = (const u16 *)w0F;
     a.w_stride = w_net_stride;
     a.GOb = (u16 *)GO_bf16; a.G2b = (u16 *)G2_bf16; a.G1b = (u16 *)G1_bf16; a.XPb = (u16 *)XP_bf16;
     a.Gc = Gc; a.db2 = db2; a.z0 = z0; a.db_stride = db_net_stride;

@@ -217,8 +217,9 @@ def flow_frag_pack(w0, w1, w2):
     return mfma_fragment_major(w1), mfma_fragment_major(w0p), mfma_fragment_major(w2p)
 
 
-def flow_couplings_frag(x_in, cond, w0F, w1F, w2F, w_net_stride, bias2, mask, B, hidden, direction, want_log_prob=True, emit=None):
-    """flow_couplings / flow_couplings_emit (emit = (h1, h2, o)) on the fragment-streaming kernel (mhe_flow_couplings_frag_bf16)"""
+def flow_couplings_frag(x_in, cond, w0F, w1F, w2F, w_net_stride, bias2, mask, B, hidden, direction, want_log_prob=True, emit=None, sign_bits=None):
+    """flow_couplings / flow_couplings_emit (emit = (h1, h2, o)) on the fragment-streaming kernel (mhe_flow_couplings_frag_bf16);
+    sign_bits (with emit, int32 [nets, R / 64, 2, 8, 64, 2]): also the signs of h1 / h2 as the reverse chain reads them"""
     R, dim = x_in.shape
     ncoup = mask.shape[0]
     _chk(x_in, torch.float32, "flow.in"); _chk(cond, torch.float32, "flow.cond", (B, 2 * ncoup, 2, hidden))
@@ -230,12 +231,14 @@ def flow_couplings_frag(x_in, cond, w0F, w1F, w2F, w_net_stride, bias2, mask, B,
         h1, h2, o = emit
         _chk(h1, torch.bfloat16, "flow.h1", (2 * ncoup, R, hidden)); _chk(h2, torch.bfloat16, "flow.h2", (2 * ncoup, R, hidden))
         _chk(o, torch.float32, "flow.o", (2 * ncoup, R, 64))
+    if sign_bits is not None:
+        _chk(sign_bits, torch.int32, "flow.sign_bits", (2 * ncoup, R // 64, 2, 8, 64, 2))
     out = torch.empty_like(x_in)
     sum_s = torch.empty(R, device=x_in.device, dtype=torch.float32)
     logp = torch.empty(R, device=x_in.device, dtype=torch.float32) if want_log_prob else None
     check(_lib.lib().mhe_flow_couplings_frag_bf16(_ptr(x_in), _ptr(out), _ptr(cond), 4 * ncoup * hidden, _ptr(w0F), _ptr(w1F), _ptr(w2F),
                                                   int(w_net_stride), _ptr(bias2), _ptr(mask), _ptr(sum_s), _ptr(logp), _ptr(h1), _ptr(h2), _ptr(o),
-                                                  R, B, dim, hidden, ncoup, direction, _stream()), "mhe_flow_couplings_frag_bf16")
+                                                  _ptr(sign_bits), R, B, dim, hidden, ncoup, direction, _stream()), "mhe_flow_couplings_frag_bf16")
     return out, sum_s, logp
 
 
@@ -888,21 +891,37 @@ def flow_reverse_chain_supported(R, B, dim, hidden, ncoup):
     return bool(_lib.lib().mhe_flow_reverse_chain_supported(R, B, dim, hidden, ncoup))
 
 
-def flow_reverse_chain(x_out, g_x, g_logp, q_weight, mask, o_pre, h1, h2, w2F, w1F, w0F, w_net_stride, GOb, G2b, G1b, XPb, Gc, db2,
+def flow_sign_bits(h1, h2, B):
+    """the signs of the kept activations h1, h2 (bf16 [nets, 64 B, 512], rows n B + b) in the layout mhe_flow_reverse_chain_bf16 reads and
+    mhe_flow_couplings_frag_bf16 writes: int32 [nets, B, 2 layers, 8 waves, 64 lanes, 2] - lane (q, l15) of wave w holds bit
+    (nt * 4 + mt) * 4 + e = [h[row mt * 16 + l15 of image b][unit 64 w + 16 nt + 4 q + e] > 0] (low word: nt < 2)"""
+    nets = h1.shape[0]
+    out = []
+    for h in (h1, h2):
+        t = (h.float() > 0).view(nets, 4, 16, B, 8, 4, 4, 4)                  # [net, mt, l15, b, w, nt, q, e]
+        t = t.permute(0, 3, 4, 6, 2, 5, 1, 7).reshape(nets, B, 8, 64, 2, 32).to(torch.int64)      # [net, b, w, lane = q * 16 + l15, half, bit (nt % 2, mt, e)]
+        wts = (1 << torch.arange(32, device=h.device, dtype=torch.int64))
+        words = (t * wts).sum(-1)                                              # < 2^32
+        out.append(torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32))
+    return torch.stack(out, 2).contiguous()                                    # [net, b, layer, w, lane, 2]
+
+
+def flow_reverse_chain(x_out, g_x, g_logp, q_weight, mask, o_pre, sign_bits, w2F, w1F, w0F, w_net_stride, GOb, G2b, G1b, XPb, Gc, db2,
                        db_net_stride, z0):
-    """the RealNVP reverse pass's data-gradient chain over all couplings in one launch (mhe_flow_reverse_chain_bf16; csrc/flow_rev.hip)"""
+    """the RealNVP reverse pass's data-gradient chain over all couplings in one launch (mhe_flow_reverse_chain_bf16; csrc/flow_rev.hip);
+    sign_bits: flow_couplings_frag(..., sign_bits=) / flow_sign_bits"""
     R, dim = x_out.shape
     B = Gc.shape[0]
-    nets, _, hidden = h1.shape
+    nets, hidden = o_pre.shape[0], 512
     _chk(x_out, torch.float32, "rev_chain.x_out"); _chk(g_x, torch.float32, "rev_chain.g_x", (R, dim))
     _chk(mask, torch.float32, "rev_chain.mask", (nets // 2, dim)); _chk(o_pre, torch.float32, "rev_chain.o", (nets, R, 64))
-    _chk(h1, torch.bfloat16, "rev_chain.h1", (nets, R, hidden)); _chk(h2, torch.bfloat16, "rev_chain.h2", (nets, R, hidden))
+    _chk(sign_bits, torch.int32, "rev_chain.sign_bits", (nets, B, 2, 8, 64, 2))
     _chk(GOb, torch.bfloat16, "rev_chain.GO", (nets, R, 64)); _chk(G2b, torch.bfloat16, "rev_chain.G2", (nets, R, hidden))
     _chk(G1b, torch.bfloat16, "rev_chain.G1", (nets, R, hidden)); _chk(XPb, torch.bfloat16, "rev_chain.XP", (nets // 2, R, 64))
     _chk(Gc, torch.float32, "rev_chain.Gc"); _chk(z0, torch.float32, "rev_chain.z0", (R, dim))
     if g_logp is not None:
         _chk(g_logp, torch.float32, "rev_chain.g_logp", (B,))
-    check(_lib.lib().mhe_flow_reverse_chain_bf16(_ptr(x_out), _ptr(g_x), _ptr(g_logp), float(q_weight), _ptr(mask), _ptr(o_pre), _ptr(h1), _ptr(h2), _ptr(w2F),
+    check(_lib.lib().mhe_flow_reverse_chain_bf16(_ptr(x_out), _ptr(g_x), _ptr(g_logp), float(q_weight), _ptr(mask), _ptr(o_pre), _ptr(sign_bits), _ptr(w2F),
                                                  _ptr(w1F), _ptr(w0F), int(w_net_stride), _ptr(GOb), _ptr(G2b), _ptr(G1b), _ptr(XPb), _ptr(Gc),
                                                  Gc.shape[1], _ptr(db2), int(db_net_stride), _ptr(z0), R, B, dim, hidden, nets // 2, _stream()),
           "mhe_flow_reverse_chain_bf16")

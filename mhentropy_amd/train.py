@@ -808,7 +808,10 @@ class TrainStep:
                 assert wst > 0 and all((self.fnets[k][key].data_ptr() - f0[key].data_ptr()) // 2 == k * wst
                                        for k in range(2 * ncoup) for key in ("w2Fb", "w1Fb", "w0Fb"))
                 z0r = self._buf("z0_rec", (R, dim))
-                ops.flow_reverse_chain(x_out, g_x, g_logp, -1.0 / N_all if g_logp is not None else 0.0, fl.mask, kept[2], kept[0], kept[1],
+                sg = getattr(self, "_flow_sign", None)
+                if sg is None or sg.shape[1] != B:      # (activations kept by the second-generation kernel: signs from the tensors themselves)
+                    sg = ops.flow_sign_bits(kept[0], kept[1], B)
+                ops.flow_reverse_chain(x_out, g_x, g_logp, -1.0 / N_all if g_logp is not None else 0.0, fl.mask, kept[2], sg,
                                        f0["w2Fb"], f0["w1Fb"], f0["w0Fb"], wst, GOb_all, G2b_all, G1b_all, XPb_all, Gc, f0["db2"],
                                        self.fnets[1]["rb2"] - f0["rb2"], z0r)
                 # (the kernel leaves the per-image sums as [image][column] rows only; both bf16 operands of the conditioning layer's
@@ -942,7 +945,7 @@ class TrainStep:
             else:
                 cond = ops.linear(feat, self.f_wc, self.f_bc).view(B, 2 * ncoup, 2, h)
             z0 = m._noise(N * B, 1.0, noise, self.dev)
-            self._flow_kept = None
+            self._flow_kept, self._flow_sign = None, None
             if self.flow_bf16 and h == 512 and os.environ.get("MHE_FLOW_RECOMPUTE") != "1":
                 # the 512-wide kernel writes the nets' activations out on the way: the reverse pass reads them instead of re-evaluating
                 # the nets coupling by coupling (what autograd would have kept)
@@ -952,8 +955,10 @@ class TrainStep:
                 f0 = self.fnets[0]
                 if (os.environ.get("MHE_FLOW_FRAG", "1") == "1" and "f1F" in f0 and ops.flow_couplings_frag_supported(Rr, B, z0.shape[1], h, ncoup)):
                     wst = (self.fnets[1]["f1F"].data_ptr() - f0["f1F"].data_ptr()) // 2
+                    sg = self._buf("fl_sign", (2 * ncoup, Rr // 64, 2, 8, 64, 2), torch.int32)
                     th45, _, log_q = ops.flow_couplings_frag(z0, cond, f0["f0F"], f0["f1F"], f0["f2F"], wst, self.f_b2, fl.mask, B, h,
-                                                             ops.FLOW_FORWARD, emit=kept)
+                                                             ops.FLOW_FORWARD, emit=kept, sign_bits=sg)
+                    self._flow_sign = sg
                 else:
                     th45, _, log_q = ops.flow_couplings_emit(z0, cond, self.f_stream, self.f_b2, fl.mask, B, h, ops.FLOW_FORWARD, *kept)
                 self._flow_kept = kept

@@ -464,7 +464,7 @@ def test_flow_reverse_chain_against_a_plain_torch_reverse_pass(gpu_lib, B, ncoup
     cs = 4 * ncoup * h + 8
     Gc, db2, z0 = torch.zeros(B, cs, device="cuda"), torch.zeros(nets, 64, device="cuda"), torch.zeros(R, dim, device="cuda")
     assert ops.flow_reverse_chain_supported(R, B, dim, h, ncoup) and not ops.flow_reverse_chain_supported(R + B, B, dim, h, ncoup)
-    ops.flow_reverse_chain(x_out, g_x, g_logp, qw, mask, o_pre, h1, h2, wbuf[h * h:], wbuf, wbuf[h * h + 64 * h:], wst, GOb, G2b, G1b, XPb, Gc,
+    ops.flow_reverse_chain(x_out, g_x, g_logp, qw, mask, o_pre, ops.flow_sign_bits(h1, h2, B), wbuf[h * h:], wbuf, wbuf[h * h + 64 * h:], wst, GOb, G2b, G1b, XPb, Gc,
                            db2, 64, z0)
     torch.cuda.synchronize()
     # ---- the same in torch
@@ -557,8 +557,11 @@ def test_flow_fragment_streaming_kernel_vs_bf16_rounding_oracle(gpu_lib, steps, 
     mk = lambda: (torch.zeros(2 * ncoup, R, h, device="cuda", dtype=torch.bfloat16), torch.zeros(2 * ncoup, R, h, device="cuda", dtype=torch.bfloat16),
                   torch.zeros(2 * ncoup, R, 64, device="cuda"))
     e1, e0 = mk(), mk()
-    xe, se, le = ops.flow_couplings_frag(_dev(z0), cond, w0F, w1F, w2F, pitch, b2d, mask, B, h, ops.FLOW_FORWARD, emit=e1)
+    sg = torch.zeros(2 * ncoup, R // 64, 2, 8, 64, 2, device="cuda", dtype=torch.int32)
+    xe, se, le = ops.flow_couplings_frag(_dev(z0), cond, w0F, w1F, w2F, pitch, b2d, mask, B, h, ops.FLOW_FORWARD, emit=e1, sign_bits=sg)
     assert torch.equal(xe, x) and torch.equal(se, sum_s) and torch.equal(le, logq)
+    if N == 64:      # the signs of the activations it wrote, in the reverse chain's layout (64 hypotheses per image: a workgroup = an image)
+        assert torch.equal(sg, ops.flow_sign_bits(e1[0], e1[1], B))
     ops.flow_couplings_emit(_dev(z0), cond, _dev(np.concatenate(packs).view(np.int16)), b2d, mask, B, h, ops.FLOW_FORWARD, *e0)
     # (first coupling: identical inputs -> agreement to a bf16 ulp where a rounding flips; the whole chain to the kernel tolerance)
     for net in range(2):

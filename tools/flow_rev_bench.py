@@ -20,7 +20,8 @@ GOb, XPb = torch.empty(nets, R, 64, device="cuda", dtype=torch.bfloat16), torch.
 G2b, G1b = torch.empty(nets, R, h, device="cuda", dtype=torch.bfloat16), torch.empty(nets, R, h, device="cuda", dtype=torch.bfloat16)
 cs = 4 * ncoup * h
 Gc, db2, z0 = torch.zeros(B, cs, device="cuda"), torch.zeros(nets * 64, device="cuda"), torch.empty(R, dim, device="cuda")
-run = lambda: ops.flow_reverse_chain(x_out, g_x, g_logp, -1.0 / N, mask, o_pre, h1, h2, w2T, w1T, w0T, wst, GOb, G2b, G1b, XPb, Gc, db2, 64, z0)
+sg = ops.flow_sign_bits(h1, h2, B)
+run = lambda: ops.flow_reverse_chain(x_out, g_x, g_logp, -1.0 / N, mask, o_pre, sg, w2T, w1T, w0T, wst, GOb, G2b, G1b, XPb, Gc, db2, 64, z0)
 for _ in range(2): run()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
