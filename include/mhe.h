@@ -459,6 +459,17 @@ int mhe_flow_mask_pad_mixed(const float *x, const float *mask, float *xp, void *
  * net 0's bf16 operands W2^T [512][64], W1^T [512][512], W0^T [64][512] ([out][k]) in FRAGMENT-MAJOR order - element
  * [out][k] at ((out / 16 * (K / 32) + k / 32) * 64 + (k % 32 / 8) * 16 + out % 16) * 8 + k % 8, the order the lanes of
  * v_mfma_f32_16x16x32_bf16 take them, so a fragment is one 1 KiB run; net k at + k * w_net_stride elements. */
+/* mhe_conv2d_masked_nhwc with the gate also as bits: mask_bits [pixels][Cout / 8] bytes, bit i of byte j = (mask value of channel 8 j + i) > 0
+ * (written by mhe_bottleneck_tail_bits_nhwc).  The streaming 1x1 data-gradient kernel reads the bits instead of the tensor; every other kernel
+ * reads mask.  A bn_y equal to mask asks for sum g only (its second sum is then undefined). */
+int mhe_conv2d_masked_bits_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const void *residual,
+                                const void *mask, const void *mask_bits, const void *bn_y0, const float *bn_mean_invstd0, float *bn_stats0,
+                                const void *bn_y1, const float *bn_mean_invstd1, float *bn_stats1, void *stream);
+/* mhe_bottleneck_tail_nhwc that also writes the gate bits of its block output (a_bits [pixels][Cin / 8] bytes, optional). */
+int mhe_bottleneck_tail_bits_nhwc(const mhe_conv_desc *d, int Cb, const void *y2, const float *bn2_scale, const float *bn2_shift,
+                                  const void *w3, const float *bn3_scale, const float *bn3_shift, const void *identity,
+                                  const float *id_scale, const float *id_shift, const void *w1, void *a_out, void *a_bits, void *y1,
+                                  float *stats, void *stream);
 /* mhe_conv2d_masked_nhwc with a per-channel constant: y = (conv(x, w) + bias + residual) * [mask > 0] (+ the BatchNorm-reverse sums of one
  * consumer).  Register-staged 128-row tiles only.  xcat (optional, bf16 1x1 stride-1 launches): the operand's K range continues on a second
  * tensor - y = [x | xcat] w^T with w [Cout][Cin + cin2] and xcat [pixels][cin2]. */

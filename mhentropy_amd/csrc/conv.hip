@@ -766,7 +766,7 @@ static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void
                       const float *in_shift, const float *out_scale, const float *out_shift, const void *residual,
                       float *stats, const void *x2, const float *x2_scale, const float *x2_shift, void *a_out, void *stream,
                       const void *mask = nullptr, const struct BnRev *bn = nullptr, float *y32 = nullptr, const int *scatter = nullptr,
-                      const void *xcat = nullptr, int cin2 = 0);
+                      const void *xcat = nullptr, int cin2 = 0, const void *mask_bits = nullptr);
 struct BnRev { const void *y[2]; const float *mi[2]; float *stats[2]; };
 
 extern "C" int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
@@ -815,6 +815,18 @@ extern "C" int mhe_conv2d_masked_nhwc(const mhe_conv_desc *d, const void *x, con
     return conv_entry(d, x, w, y, nullptr, nullptr, nullptr, nullptr, residual, nullptr, nullptr, nullptr, nullptr, nullptr, stream, mask, &bn);
 }
 
+extern "C" int mhe_conv2d_masked_bits_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const void *residual,
+                                           const void *mask, const void *mask_bits, const void *bn_y0, const float *bn_mean_invstd0, float *bn_stats0,
+                                           const void *bn_y1, const float *bn_mean_invstd1, float *bn_stats1, void *stream) {
+    MHE_REQUIRE(mask, "mhe_conv2d_masked_bits_nhwc: mask is required (kernels without the bit path read it)");
+    MHE_REQUIRE((!bn_y0 || (bn_mean_invstd0 && bn_stats0)) && (!bn_y1 || (bn_y0 && bn_mean_invstd1 && bn_stats1)),
+                "mhe_conv2d_masked_bits_nhwc: each bn_y needs its mean_invstd and stats (and bn_y1 needs bn_y0)");
+    MHE_REQUIRE(!mask_bits || (d && d->Cout % 8 == 0), "mhe_conv2d_masked_bits_nhwc: Cout must be a multiple of 8");
+    const BnRev bn = {{bn_y0, bn_y1}, {bn_mean_invstd0, bn_mean_invstd1}, {bn_stats0, bn_stats1}};
+    return conv_entry(d, x, w, y, nullptr, nullptr, nullptr, nullptr, residual, nullptr, nullptr, nullptr, nullptr, nullptr, stream, mask, &bn, nullptr,
+                      nullptr, nullptr, 0, mask_bits);
+}
+
 extern "C" int mhe_conv2d_masked_bias_nhwc(const mhe_conv_desc *d, const void *x, const void *xcat, int cin2, const void *w, void *y,
                                            const void *residual, const void *mask, const float *bias, const void *bn_y0,
                                            const float *bn_mean_invstd0, float *bn_stats0, void *stream) {
@@ -851,7 +863,7 @@ extern "C" int mhe_conv3x3s2_dgrad_nhwc(int B, int Ho, int Wo, int Cout, int Cin
 static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
                       const float *in_shift, const float *out_scale, const float *out_shift, const void *residual,
                       float *stats, const void *x2, const float *x2_scale, const float *x2_shift, void *a_out, void *stream,
-                      const void *mask, const BnRev *bn, float *y32, const int *scatter, const void *xcat, int cin2) {
+                      const void *mask, const BnRev *bn, float *y32, const int *scatter, const void *xcat, int cin2, const void *mask_bits) {
     MHE_REQUIRE(d && x && w && (y || y32), "mhe_conv2d_nhwc: null pointer");
     MHE_REQUIRE(d->dtype == MHE_F32 || d->dtype == MHE_BF16, "mhe_conv2d_nhwc: dtype=%d", d->dtype);
     const int ce = elem_chunk(d->dtype), bke = 8 * ce;
@@ -880,7 +892,7 @@ static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void
     const long long M = (long long)p.B * p.Ho * p.Wo;
     MHE_REQUIRE(M < (1ll << 31), "mhe_conv2d_nhwc: too many output pixels");
     p.M = (int)M;
-    p.xcat = xcat; p.Cin2 = cin2;
+    p.xcat = xcat; p.Cin2 = cin2; p.mask_bits = (const unsigned char *)mask_bits;
     const int ktot = d->KH * d->KW * d->Cin + cin2;
     p.Kpad = (ktot + bke - 1) / bke * bke;       // weight rows are zero-padded to this length by the packer
     p.relu_in = d->relu_in; p.relu_out = d->relu_out;
@@ -929,12 +941,20 @@ extern "C" int mhe_bottleneck_tail_nhwc(const mhe_conv_desc *d, int Cb, const vo
                                         const void *w3, const float *bn3_scale, const float *bn3_shift, const void *identity,
                                         const float *id_scale, const float *id_shift, const void *w1, void *a_out, void *y1, float *stats,
                                         void *stream) {
+    return mhe_bottleneck_tail_bits_nhwc(d, Cb, y2, bn2_scale, bn2_shift, w3, bn3_scale, bn3_shift, identity, id_scale, id_shift, w1, a_out, nullptr, y1, stats, stream);
+}
+
+extern "C" int mhe_bottleneck_tail_bits_nhwc(const mhe_conv_desc *d, int Cb, const void *y2, const float *bn2_scale, const float *bn2_shift,
+                                             const void *w3, const float *bn3_scale, const float *bn3_shift, const void *identity,
+                                             const float *id_scale, const float *id_shift, const void *w1, void *a_out, void *a_bits, void *y1,
+                                             float *stats, void *stream) {
     MHE_REQUIRE(d && y2 && bn2_scale && bn2_shift && w3 && bn3_scale && bn3_shift && identity && w1 && a_out && y1, "mhe_bottleneck_tail_nhwc: null pointer");
     MHE_REQUIRE(d->dtype == MHE_BF16, "mhe_bottleneck_tail_nhwc: bf16 storage only");
     MHE_REQUIRE((id_scale == nullptr) == (id_shift == nullptr), "mhe_bottleneck_tail_nhwc: id_scale/id_shift must come together");
     conv::Params p{};
     p.x = y2; p.in_scale = bn2_scale; p.in_shift = bn2_shift; p.w3 = w3; p.mid_scale = bn3_scale; p.mid_shift = bn3_shift;
     p.x2 = identity; p.x2_scale = id_scale; p.x2_shift = id_shift; p.w = w1; p.a_out = a_out; p.y = y1; p.stats = stats;
+    p.a_bits = (unsigned char *)a_bits;
     p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
     p.Ho = d->H; p.Wo = d->W; p.Kpad = d->Cin; p.relu_in = 1; p.force = -1;
     const long long M = (long long)d->B * d->H * d->W;

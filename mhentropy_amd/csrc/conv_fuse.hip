@@ -76,6 +76,7 @@ __global__ __launch_bounds__(512) void bottleneck_tail_kernel(const Params p) {
     const __amdgpu_buffer_rsrc_t y2g = rsrc_of(p.x, (size_t)p.M * CB * 2), idg = rsrc_of(p.x2, (size_t)p.M * C * 2);
     const __amdgpu_buffer_rsrc_t w3g = rsrc_of(p.w3, (size_t)C * CB * 2), w1g = rsrc_of(p.w, (size_t)N2 * C * 2);
     const __amdgpu_buffer_rsrc_t ag = rsrc_of(p.a_out, (size_t)p.M * C * 2), yg = rsrc_of(p.y, (size_t)p.M * N2 * 2);
+    const __amdgpu_buffer_rsrc_t abg = rsrc_of(p.a_bits, (size_t)p.M * (C / 8));
     // output epilogue (the four transfer waves; the multiply waves go on to the next tile's top barrier): staged 128 x N2 tile -> 16-byte
     // stores + per-thread partial statistics of the stored values
     const int cc = t2 % CPR2, r0 = t2 / CPR2;
@@ -254,6 +255,14 @@ __global__ __launch_bounds__(512) void bottleneck_tail_kernel(const Params p) {
                 const uint4 o = Chunk<T>::pack(v);
                 As[swz(row, s8)] = o;
                 bst(ag, toffC, (unsigned)(m0 + 32 * j) * (C * 2) + t * 128, o);
+                // the gate of the reverse pass, one bit per stored value (bf16: sign clear and not zero)
+                const unsigned wds[4] = {o.x, o.y, o.z, o.w};
+                unsigned gb = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    gb |= ((unsigned)((wds[i] & 0x8000u) == 0 && (wds[i] & 0x7fffu) != 0) << (2 * i)) |
+                          ((unsigned)((wds[i] & 0x80000000u) == 0 && (wds[i] & 0x7fff0000u) != 0) << (2 * i + 1));
+                if (p.a_bits) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)gb, abg, (int)((rbase * (C / 8)) + s8), (int)((unsigned)(m0 + 32 * j) * (C / 8) + t * 8), 0);
             }
         };
         auto stage_a2 = [&]() __attribute__((always_inline)) {                 // relu(bn2(y2)) tile -> LDS (over Abuf)

@@ -32,6 +32,10 @@ struct Params {
     // K-concatenated operand of a 1x1 data-gradient launch (MODE 3, conv.hip): channels Cin .. Cin + Cin2 - 1 of a pixel come from xcat
     // [M][Cin2]; the weight rows are [Cout][Cin + Cin2]
     const void *xcat; int Cin2;
+    // the ReLU gate as bits: byte [pixel][channel / 8], bit i = (value of channel 8 j + i) > 0.  a_bits: written next to a_out by the fused
+    // bottleneck tail (conv_fuse.hip); mask_bits: read INSTEAD of mask by the streaming 1x1 data-gradient kernel (conv_stream.hip) - a
+    // sixteenth of the block-wide tensor's bytes; every other kernel reads mask
+    unsigned char *a_bits; const unsigned char *mask_bits;
 };
 
 // tile row -> global output pixel index the epilogue addresses (or -1 outside the problem)

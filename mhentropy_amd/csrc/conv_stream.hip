@@ -91,6 +91,10 @@ void conv1x1_stream_kernel(const Params p, int nchunks, int ntiles_n) {
     const int ccol = n0 + (tid % CPR) * 8;
     const T *mk = reinterpret_cast<const T *>(p.mask), *rg = reinterpret_cast<const T *>(p.residual);
     const T *y0g = reinterpret_cast<const T *>(p.bn_y[0]), *y1g = reinterpret_cast<const T *>(p.bn_y[1]);
+    // gate bits instead of the gate tensor (p.mask_bits); a consumer handed the gate tensor as its raw output wants sum g only (train step:
+    // conv3 + bn3 reversed on Gram statistics) - its second sum is not taken and the tensor is not read for it
+    const unsigned char *mkb = DG ? p.mask_bits : nullptr;
+    const bool y0sum = DG && y0g != nullptr && y0g == mk, y1sum = DG && y1g != nullptr && y1g == mk;
     float bs1[DG ? 2 : 1][8], bs2[DG ? 2 : 1][8], bmu[DG ? 2 : 1][8], biv[DG ? 2 : 1][8];
     if constexpr (DG) {
 #pragma unroll
@@ -156,6 +160,7 @@ void conv1x1_stream_kernel(const Params p, int nchunks, int ntiles_n) {
 #pragma unroll 1
                 for (int j0 = 0; j0 < NJ; j0 += 4) {                 // 4 rows at a time: their operand loads are issued together
                     uint4 raw[4], gm[4], rr[4], ya[4], yb[4];
+                    unsigned gmb[4];
                     size_t off[4];
                     bool okr[4];
 #pragma unroll
@@ -165,7 +170,8 @@ void conv1x1_stream_kernel(const Params p, int nchunks, int ntiles_n) {
                         okr[g] = m < p.M && ccol < p.Cout;
                         const long mc = okr[g] ? m : 0;
                         off[g] = (size_t)mc * p.Cout + ccol;
-                        gm[g] = *reinterpret_cast<const uint4 *>(mk + off[g]);
+                        if (mkb) gmb[g] = mkb[(size_t)mc * (p.Cout / 8) + (ccol >> 3)];
+                        else gm[g] = *reinterpret_cast<const uint4 *>(mk + off[g]);
                         rr[g] = make_uint4(0u, 0u, 0u, 0u);
                         if (rg) {
                             if (p.res_s2) {
@@ -173,8 +179,8 @@ void conv1x1_stream_kernel(const Params p, int nchunks, int ntiles_n) {
                                 if (hr >= 0) rr[g] = *reinterpret_cast<const uint4 *>(rg + (size_t)hr * p.Cout + ccol);
                             } else rr[g] = *reinterpret_cast<const uint4 *>(rg + off[g]);
                         }
-                        if (y0g) ya[g] = *reinterpret_cast<const uint4 *>(y0g + off[g]);
-                        if (y1g) yb[g] = *reinterpret_cast<const uint4 *>(y1g + off[g]);
+                        if (y0g && !y0sum) ya[g] = *reinterpret_cast<const uint4 *>(y0g + off[g]);
+                        if (y1g && !y1sum) yb[g] = *reinterpret_cast<const uint4 *>(y1g + off[g]);
                         raw[g] = *reinterpret_cast<const uint4 *>(ot + ((size_t)row * CPR + (cc ^ (row & 15))) * 16);
                     }
 #pragma unroll
@@ -187,15 +193,26 @@ void conv1x1_stream_kernel(const Params p, int nchunks, int ntiles_n) {
 #pragma unroll
                             for (int i = 0; i < 8; ++i) v[i] += t[i];
                         }
-                        Chunk<T>::unpack(gm[g], t);
+                        if (mkb) {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) v[i] = t[i] > 0.f ? v[i] : 0.f;
-                        if (y0g) {
+                            for (int i = 0; i < 8; ++i) v[i] = ((gmb[g] >> i) & 1u) ? v[i] : 0.f;
+                        } else {
+                            Chunk<T>::unpack(gm[g], t);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) v[i] = t[i] > 0.f ? v[i] : 0.f;
+                        }
+                        if (y0sum) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) bs1[0][i] += v[i];
+                        } else if (y0g) {
                             Chunk<T>::unpack(ya[g], t);
 #pragma unroll
                             for (int i = 0; i < 8; ++i) { bs1[0][i] += v[i]; bs2[0][i] = fmaf(v[i], (t[i] - bmu[0][i]) * biv[0][i], bs2[0][i]); }
                         }
-                        if (y1g) {
+                        if (y1sum) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) bs1[1][i] += v[i];
+                        } else if (y1g) {
                             Chunk<T>::unpack(yb[g], t);
 #pragma unroll
                             for (int i = 0; i < 8; ++i) { bs1[1][i] += v[i]; bs2[1][i] = fmaf(v[i], (t[i] - bmu[1][i]) * biv[1][i], bs2[1][i]); }

@@ -337,7 +337,8 @@ def metrics(xyz, uv, pose3d, scale, crop_uv, vis):
 
 
 def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in=False, out_scale=None,
-                out_shift=None, residual=None, relu_out=False, stats=None, out=None, mask=None, bn=None, tile=0, res_half=False, xcat=None):
+                out_shift=None, residual=None, relu_out=False, stats=None, out=None, mask=None, bn=None, tile=0, res_half=False, xcat=None,
+                mask_bits=None):
     """x [B,H,W,Cin], w packed [Cout, Kpad]; returns y [B,Ho,Wo,Cout] of x.dtype.  mask (shaped like y, data-gradient
     form only): y = (conv + residual) * [mask > 0]; bn = up to two (bn_y, mean_invstd [2,C], stats [S,2,C]) triples: the epilogue
     also accumulates the BatchNorm-reverse sums of y for those units (see mhe_conv2d_masked_nhwc).  tile > 0 forces kernel
@@ -386,6 +387,11 @@ def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in
                 _chk(by, dt, "conv.bn_y", (B, Ho, Wo, Cout)); _chk(bmi, torch.float32, "conv.bn_mean_invstd", (2, Cout))
                 _chk(bst, torch.float32, "conv.bn_stats", (stat_shards(), 2, Cout))
             ext += [_ptr(by), _ptr(bmi), _ptr(bst)]
+        if mask_bits is not None:        # the gate also as bits [pixel][Cout / 8] (bottleneck_tail want_bits=): read instead of `mask` where the kernel can
+            _chk(mask_bits, torch.uint8, "conv.mask_bits", (B, Ho, Wo, Cout // 8))
+            check(_lib.lib().mhe_conv2d_masked_bits_nhwc(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _ptr(residual), _ptr(mask), _ptr(mask_bits), *ext, _stream()),
+                  "mhe_conv2d_masked_bits_nhwc")
+            return y
         check(_lib.lib().mhe_conv2d_masked_nhwc(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _ptr(residual), _ptr(mask), *ext, _stream()),
               "mhe_conv2d_masked_nhwc")
         return y
@@ -490,7 +496,7 @@ def bottleneck_tail_supported(B, H, W, Cb, Cout):
     return bool(_lib.lib().mhe_bottleneck_tail_supported(C.byref(d), int(Cb)))
 
 
-def bottleneck_tail(y2, bn2, w3, bn3, identity, id_aff, w1, stats=None):
+def bottleneck_tail(y2, bn2, w3, bn3, identity, id_aff, w1, stats=None, want_bits=False):
     """(a, y1) of mhe_bottleneck_tail_nhwc: a = relu(bn3(conv3(relu(bn2(y2)))) + identity) with conv3 re-evaluated in place of being read
     back, y1 = the next block's conv1 of a (+ its batch statistics).  bn2 / bn3 / id_aff = (scale, shift) pairs (id_aff may be None)."""
     B, H, W, Cb = y2.shape
@@ -503,18 +509,20 @@ def bottleneck_tail(y2, bn2, w3, bn3, identity, id_aff, w1, stats=None):
         _chk(stats, torch.float32, "tail.stats", (stat_shards(), 2, Cout))
     a = torch.empty(B, H, W, Cw, device=y2.device, dtype=torch.bfloat16)
     y1 = torch.empty(B, H, W, Cout, device=y2.device, dtype=torch.bfloat16)
+    # want_bits: also [a > 0] as bits, byte [pixel][channel / 8] - the gate the reverse pass reads instead of `a` (conv2d_nhwc mask_bits=)
+    bits = torch.empty(B, H, W, Cw // 8, device=y2.device, dtype=torch.uint8) if want_bits else None
     d = ConvDesc(B, H, W, Cw, Cout, 1, 1, 1, 0, BF16, 1, 0, 0, 0)
     if TIMING:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    check(_lib.lib().mhe_bottleneck_tail_nhwc(C.byref(d), Cb, _ptr(y2), _ptr(bn2[0]), _ptr(bn2[1]), _ptr(w3), _ptr(bn3[0]), _ptr(bn3[1]), _ptr(identity),
-                                              _ptr(id_aff[0] if id_aff is not None else None), _ptr(id_aff[1] if id_aff is not None else None),
-                                              _ptr(w1), _ptr(a), _ptr(y1), _ptr(stats), _stream()), "mhe_bottleneck_tail_nhwc")
+    check(_lib.lib().mhe_bottleneck_tail_bits_nhwc(C.byref(d), Cb, _ptr(y2), _ptr(bn2[0]), _ptr(bn2[1]), _ptr(w3), _ptr(bn3[0]), _ptr(bn3[1]), _ptr(identity),
+                                                   _ptr(id_aff[0] if id_aff is not None else None), _ptr(id_aff[1] if id_aff is not None else None),
+                                                   _ptr(w1), _ptr(a), _ptr(bits), _ptr(y1), _ptr(stats), _stream()), "mhe_bottleneck_tail_bits_nhwc")
     if TIMING:
         ev1.record()
         nbytes = 2 * (y2.numel() + identity.numel() + a.numel() + y1.numel() + w3.numel() + w1.numel())
         KERNEL_TIMES.append(("mhe::conv::bottleneck_tail_kernel<%d, %d>" % (Cb, Cout), 2.0 * B * H * W * Cw * (Cb + Cout), ev0, ev1, nbytes))
-    return a, y1
+    return (a, y1, bits) if want_bits else (a, y1)
 
 
 def linear_bf16_f32out(x, w, bias=None, out=None):

@@ -58,14 +58,15 @@ def dgrad_s2_operand_indices(idx):
     return out
 
 
-def conv_dgrad(gy, w_dg, k, stride, pad, H, W, residual=None, mask=None, bn=None, w_s2=None, res_half=False, coarse=False):
+def conv_dgrad(gy, w_dg, k, stride, pad, H, W, residual=None, mask=None, bn=None, w_s2=None, res_half=False, coarse=False, mask_bits=None):
     """gradient of a k x k / stride / pad convolution w.r.t. its [B,H,W,Cin] input (+ residual), through the
     FORWARD implicit-GEMM kernel: stride 1 is a convolution of gy with the transposed, tap-flipped weights at
     padding k-1-pad; a stride-2 3x3 runs the same on the zero-dilated gy; a stride-2 1x1 is computed on the
     coarse grid and scattered to the even positions.  mask (the convolution's own post-ReLU input): the result is
     gated by [mask > 0] in the kernel's epilogue, i.e. it leaves as the gradient w.r.t. the PRE-activation."""
     if stride == 1:
-        return ops.conv2d_nhwc(gy, w_dg, k, k, 1, k - 1 - pad, residual=residual, mask=mask, bn=bn, res_half=res_half)
+        return ops.conv2d_nhwc(gy, w_dg, k, k, 1, k - 1 - pad, residual=residual, mask=mask, bn=bn, res_half=res_half,
+                               mask_bits=mask_bits if mask is not None else None)
     if stride != 2 or k not in (1, 3):
         raise NotImplementedError(f"conv_dgrad: k={k} stride={stride}")
     if k == 3 and w_s2 is not None and pad == 1 and H == 2 * gy.shape[1] and W == 2 * gy.shape[2]:
@@ -140,6 +141,7 @@ class TrainStep:
         self.conv3_fold = os.environ.get("MHE_CONV3_FOLD", "1") == "1"
         self.conv3_fold_cat = os.environ.get("MHE_CONV3_FOLD_CAT", "1") == "1"
         self.stem_bwd_two_pass = os.environ.get("MHE_STEM_BWD_TWO_PASS", "1") == "1"
+        self.gate_bits = os.environ.get("MHE_GATE_BITS", "1") == "1"
         # the stem's BatchNorm + ReLU folded into its max pool, forward and reverse (ops.maxpool3x3s2_idx / maxpool3x3s2_bwd_bn)
         self.stem_pool_fused = os.environ.get("MHE_STEM_POOL_FUSED", "1") == "1"
         self.bn_on_load_wide = os.environ.get("MHE_BN_BWD_ON_LOAD_WIDE", "1") == "1"
@@ -525,8 +527,10 @@ class TrainStep:
                 _, y2_p, bn2_p, ul_p, idt_p, ud_p = pending
                 u0 = us[0]
                 st = pool.take(u0.cout)
-                a, y = ops.bottleneck_tail(y2_p, bn2_p, ul_p.w_fwd, (ul_p.scale, ul_p.shift), idt_p,
-                                           None if ud_p is None else (ud_p.scale, ud_p.shift), u0.w_fwd, stats=st)
+                # (+ [a > 0] as bits: the reverse pass's gate at a sixteenth of a's bytes, MHE_GATE_BITS=0: it reads a)
+                a, y, abits = ops.bottleneck_tail(y2_p, bn2_p, ul_p.w_fwd, (ul_p.scale, ul_p.shift), idt_p,
+                                                  None if ud_p is None else (ud_p.scale, ud_p.shift), u0.w_fwd, stats=st, want_bits=True)
+                b["a_bits"] = abits if self.gate_bits else None
                 self._bn_tape(u0, a, y, st)
                 self.blocks[bi - 1]["out"] = a
                 pending = None
@@ -547,12 +551,12 @@ class TrainStep:
                 self._bn_tape(u0, a, y, st)
                 self.blocks[bi - 1]["out"] = a
                 pending = None
-                b["a"] = a
+                b["a"], b["a_bits"] = a, None
                 h = ops.bn_act(y, u0.scale, u0.shift, relu=True)
                 b["acts"] = [h]
                 rest = us[1:-1]
             else:
-                b["a"] = a
+                b["a"], b["a_bits"] = a, None
                 h = a
                 b["acts"] = []
                 rest = us[:-1]
@@ -621,7 +625,7 @@ class TrainStep:
     def _wgrad(self, u, gy):
         ops.conv_wgrad(u.x, gy, u.k, u.k, u.stride, u.pad, u.dw)
 
-    def _dgrad(self, u, gy, residual=None, gate=True, consumers=(), pool=None, res_half=False, coarse=False):
+    def _dgrad(self, u, gy, residual=None, gate=True, consumers=(), pool=None, res_half=False, coarse=False, mask_bits=None):
         """gradient w.r.t. the pre-activation of the unit's input (+ residual): every unit input in the trunk is a post-ReLU
         tensor, so the ReLU gate [x > 0] is applied in the producing kernel's epilogue and the BatchNorm reverse passes
         downstream read one tensor less"""
@@ -635,7 +639,7 @@ class TrainStep:
                 c.rev_stats = st
                 c.rev_dummy = c.y is None
         return conv_dgrad(gy, u.w_dg, u.k, u.stride, u.pad, u.x.shape[1], u.x.shape[2], residual, u.x if gate else None, bn,
-                          w_s2=getattr(u, "w_s2", None), res_half=res_half, coarse=coarse)
+                          w_s2=getattr(u, "w_s2", None), res_half=res_half, coarse=coarse, mask_bits=mask_bits)
 
     def _trunk_backward(self, g_f):
         pool = resnet._StatsPool(self.dev, channels=65536)
@@ -722,7 +726,8 @@ class TrainStep:
             if prev is not None and not (self.conv3_fold and self.fuse_bn_reduce and getattr(prev["u"][-1], "gram_tot", None) is not None):
                 self._ensure_y(prev["u"][-1])
             cons = () if first else tuple(x for x in (prev["u"][-1], prev["ud"]) if x is not None)
-            g = self._dgrad(us[0], gy, residual=skip, gate=not first, consumers=cons, pool=pool, res_half=ud is not None and half_skip)
+            g = self._dgrad(us[0], gy, residual=skip, gate=not first, consumers=cons, pool=pool, res_half=ud is not None and half_skip,
+                            mask_bits=b.get("a_bits"))
         for u in self.units:
             u.rev_stats, u.rev_dummy = None, False
             if getattr(u, "y_recomputed", False):

@@ -638,3 +638,45 @@ def test_conv3_batchnorm_reverse_from_gram_statistics_against_autograd(gpu_lib, 
     # (sum_p of a train-mode BatchNorm's input gradient is zero: the sums are rounding noise - compared on the scale of sum |g|)
     err = (st.double().sum(0)[0] - gA.double().sum((0, 1, 2))).abs() / gA.double().abs().sum((0, 1, 2))
     assert float(err.max()) < 4e-3, float(err.max())
+
+
+def test_relu_gate_as_bits_for_the_streaming_data_gradient(gpu_lib):
+    """the block output's ReLU gate as bits (mhe_bottleneck_tail_bits_nhwc writes [a > 0], byte [pixel][channel / 8]) read by the streaming
+    1x1 data-gradient kernel instead of the block-wide tensor (mhe_conv2d_masked_bits_nhwc): bits exactly [a > 0]; outputs and
+    BatchNorm-reverse sums identical to the launch that reads the tensor; a consumer handed the gate tensor as its raw output gets sum g
+    (and no second sum)."""
+    from mhentropy_amd import ops, resnet
+    B, H, W, Cb, N2 = 4, 32, 32, 64, 64
+    C4 = 4 * Cb
+    g = torch.Generator().manual_seed(5)
+    y2 = torch.randn(B, Cb, H, W, generator=g).bfloat16().float()
+    idt = torch.randn(B, C4, H, W, generator=g).bfloat16().float()
+    w3 = (torch.randn(C4, Cb, 1, 1, generator=g) * (2.0 / Cb) ** 0.5).bfloat16().float()
+    w1 = (torch.randn(N2, C4, 1, 1, generator=g) * (2.0 / C4) ** 0.5).bfloat16().float()
+    s2, h2 = (torch.rand(Cb, generator=g) + 0.5).cuda(), (torch.randn(Cb, generator=g) * 0.3).cuda()
+    s3, h3 = (torch.rand(C4, generator=g) + 0.5).cuda(), (torch.randn(C4, generator=g) * 0.3).cuda()
+    w3d, w1d = resnet.pack_conv_weight(w3, torch.bfloat16).cuda(), resnet.pack_conv_weight(w1, torch.bfloat16).cuda()
+    a, y1, bits = ops.bottleneck_tail(_nhwc(y2), (s2, h2), w3d, (s3, h3), _nhwc(idt), None, w1d, want_bits=True)
+    a0, y10 = ops.bottleneck_tail(_nhwc(y2), (s2, h2), w3d, (s3, h3), _nhwc(idt), None, w1d)
+    assert torch.equal(a, a0) and torch.equal(y1, y10)
+    want = ((a.float() > 0).view(B, H, W, C4 // 8, 8).to(torch.int32) * (1 << torch.arange(8, device="cuda", dtype=torch.int32))).sum(-1).to(torch.uint8)
+    assert torch.equal(bits, want)
+    assert 0.2 < float((a.float() > 0).float().mean()) < 0.8
+    # conv1's data gradient (64 -> 256 channels: the streaming kernel), gated by [a > 0], residual, two consumers' sums
+    gy = torch.randn(B, H, W, N2, generator=g).bfloat16().cuda()
+    res = torch.randn(B, H, W, C4, generator=g).bfloat16().cuda()
+    ybn = torch.randn(B, H, W, C4, generator=g).bfloat16().cuda()
+    wdg = resnet.pack_conv_weight(w1.permute(1, 0, 2, 3).contiguous(), torch.bfloat16).cuda()          # [C4][N2]
+    assert ops.conv_tile_choice(B, H, W, N2, C4, 1, 1, 0, torch.bfloat16, 0) in (8, 1, 2, 7, 0)
+    mi = torch.stack([torch.randn(C4, generator=g) * 0.1, torch.rand(C4, generator=g) + 0.5]).cuda().contiguous()
+    S = ops.stat_shards()
+    outs = []
+    for mb in (None, bits):
+        st0, st1 = torch.zeros(S, 2, C4, device="cuda"), torch.zeros(S, 2, C4, device="cuda")
+        o = ops.conv2d_nhwc(gy, wdg, 1, 1, 1, 0, residual=res, mask=a, bn=[(ybn, mi, st0), (a, mi, st1)], mask_bits=mb)
+        outs.append((o, st0.sum(0), st1.sum(0)))
+    (o0, s00, s01), (o1, s10, s11) = outs
+    assert torch.equal(o0, o1)
+    assert_close(s10.cpu(), s00.cpu(), 1e-5, what="sums of the consumer with a raw output")
+    assert_close(s11[0].cpu(), s01[0].cpu(), 1e-5, what="sum g of the consumer handed the gate tensor")
+    assert_close(s11[0].cpu(), o1.float().sum((0, 1, 2)).cpu(), 2e-3, 1e-2, what="sum g against the stored gradient")
