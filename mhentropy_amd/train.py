@@ -570,11 +570,14 @@ class TrainStep:
             # from the Gram matrix of its input, the tail kernel of the next block evaluates it on the fly (as the module's own forward
             # does, resnet.py), and the reverse pass evaluates it once when it needs it: a write + a read of the block's widest tensor
             # traded for one plain 1x1 launch in the reverse pass (MHE_TRAIN_RECOMPUTE=0: conv3 written in the forward pass)
-            recompute = (self.train_recompute and fuse and nxt is not None and nxt["kind"] == "bottleneck" and b["kind"] == "bottleneck"
-                         and len(us) == 3 and ul.k == 1 and ul.stride == 1 and h.dtype == torch.bfloat16 and us[-2].y is not None
-                         and nxt["u"][0].k == 1 and nxt["u"][0].stride == 1
-                         and ops.bottleneck_tail_supported(h.shape[0], h.shape[1], h.shape[2], h.shape[3], nxt["u"][0].cout))
-            if recompute:
+            foldable = (self.train_recompute and fuse and nxt is not None and nxt["kind"] == "bottleneck" and b["kind"] == "bottleneck"
+                        and len(us) == 3 and ul.k == 1 and ul.stride == 1 and h.dtype == torch.bfloat16 and us[-2].y is not None
+                        and nxt["u"][0].k == 1 and nxt["u"][0].stride == 1 and ul.cin in (64, 128) and (h.numel() // ul.cin) % 128 == 0)
+            recompute = foldable and ops.bottleneck_tail_supported(h.shape[0], h.shape[1], h.shape[2], h.shape[3], nxt["u"][0].cout)
+            # (a block whose tail the fused kernel cannot take - layer2's last, which feeds layer3 - still runs conv3 for the forward's sake,
+            # but on the Gram statistics as well, so that the REVERSE pass can do without y3: it is dropped from the tape)
+            semi = foldable and not recompute and self.conv3_fold and self.fuse_bn_reduce
+            if recompute or semi:
                 u2, bn3 = us[-2], ul.bn
                 gbufs = pool.gram(ul.cin)
                 if self.conv3_fold:      # the Gram totals of THIS block stay for the reverse pass (csrc/conv_fold.hip)
@@ -588,7 +591,7 @@ class TrainStep:
                                                                 bn3.running_var, gbufs, BN_MOMENTUM, BN_EPS,
                                                                 num_batches_tracked=bn3.num_batches_tracked, want_mean_invstd=True)
                 ul.x, ul.y = h, None
-                yl = None
+                yl = ops.conv2d_nhwc(h, ul.w_fwd, 1, 1, 1, 0) if semi else None
             else:
                 yl = self._unit_fwd(ul, h, pool)
             ud = b["ud"]
