@@ -251,6 +251,10 @@ size_t mhe_gram_stats_floats(int Cb);
 size_t mhe_gram_stats_workspace_bytes(int Cb);
 int mhe_conv1x1_gram_nhwc(const void *x, const float *in_scale, const float *in_shift, int relu_in, float *gram, long pixels, int Cb,
                           void *stream);
+/* ... that also writes the operand it multiplies, relu(x * in_scale + in_shift) as bf16 [pixels][Cb] (a_out, optional): the train step keeps it
+ * for the reverse pass instead of making it in a pass of its own */
+int mhe_conv1x1_gram_store_nhwc(const void *x, const float *in_scale, const float *in_shift, int relu_in, float *gram, void *a_out,
+                                long pixels, int Cb, void *stream);
 int mhe_gram_bn_finalize(float *gram, void *workspace, const void *w, const float *gamma, const float *beta, float *running_mean,
                          float *running_var, float *scale, float *shift, float *mean_invstd, int C, int Cb, float count,
                          float momentum, float eps, long long *num_batches_tracked, void *stream);

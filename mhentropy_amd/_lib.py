@@ -110,6 +110,7 @@ SIGNATURES = {
     "mhe_gram_stats_floats": (_sz, [_i]),
     "mhe_gram_stats_workspace_bytes": (_sz, [_i]),
     "mhe_conv1x1_gram_nhwc": (_i, [_p, _p, _p, _i, _p, _l, _i, _p]),
+    "mhe_conv1x1_gram_store_nhwc": (_i, [_p, _p, _p, _i, _p, _p, _l, _i, _p]),
     "mhe_gram_bn_finalize": (_i, [_p] * 10 + [_i, _i, _f, _f, _f, _p, _p]),
     "mhe_bottleneck_tail_supported": (_i, [_p, _i]),
     "mhe_bottleneck_tail_nhwc": (_i, [_p, _i] + [_p] * 14),

@@ -31,7 +31,7 @@ __device__ __forceinline__ int gseg_swz(int pitch, int row) { return pitch >= 25
 
 template <int CB>
 __global__ __launch_bounds__(256) void gram_kernel(const u16 *__restrict__ x, const float *__restrict__ in_scale, const float *__restrict__ in_shift,
-                                                   float *__restrict__ gram, int M, int relu) {
+                                                   float *__restrict__ gram, int M, int relu, u16 *__restrict__ a_out) {
     constexpr int PA = CB * 2, CPR = CB / 8, RPP = 256 / CPR, NJ = GPX / RPP;      // row pitch (bytes), 16-byte chunks per row, rows per pass, passes
     constexpr int TW = CB / 64;                                                    // 32 x 32 tiles per wave and dimension (waves 2 x 2)
     constexpr int GE = CB * CB + CB;                                               // floats per shard: G then m
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const u16 *__restrict__ x, co
 #pragma unroll
         for (int j = 0; j < NJ; ++j) ra[j] = *reinterpret_cast<const uint4 *>(x + ((size_t)Lc * GPX + r0 + RPP * j) * CB + cch * 8);
     };
-    auto store_tile = [&](int buf) __attribute__((always_inline)) {
+    auto store_tile = [&](int buf, int L) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int row = r0 + RPP * j;
@@ -66,6 +66,8 @@ __global__ __launch_bounds__(256) void gram_kernel(const u16 *__restrict__ x, co
             for (int i = 0; i < 8; ++i) cs[i] += f[i];
             const int pc = (((cch >> 2) ^ gseg_swz(PA, row)) << 2) | (cch & 3);
             *reinterpret_cast<uint4 *>(tile[buf] + row * PA + pc * 16) = o;
+            // (train step: the normalised operand itself, which the reverse pass multiplies again - one pass over the raw tensor instead of two)
+            if (a_out) *reinterpret_cast<uint4 *>(a_out + ((size_t)L * GPX + row) * CB + cch * 8) = o;
         }
     };
     // transposing-read geometry (wgrad.hip): 16-lane group g reads pixels 8 (g >> 1) + q (+ 4), channels 16 (g & 1) + 4 pq of a 32-channel block
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const u16 *__restrict__ x, co
     int it = 0;
     for (int L = blockIdx.x; L < ntiles; L += (int)gridDim.x, ++it) {
         const int buf = it & 1;
-        store_tile(buf);
+        store_tile(buf, L);
         load_tile(L + (int)gridDim.x);                           // in flight during this tile's products
         __syncthreads();                                         // (also: every wave is done reading the buffer written two tiles ago)
         const char *base = tile[buf];
@@ -195,14 +197,19 @@ extern "C" size_t mhe_gram_stats_workspace_bytes(int Cb) { return (Cb == 64 || C
 
 extern "C" int mhe_conv1x1_gram_nhwc(const void *x, const float *in_scale, const float *in_shift, int relu_in, float *gram, long pixels, int Cb,
                                      void *stream) {
+    return mhe_conv1x1_gram_store_nhwc(x, in_scale, in_shift, relu_in, gram, nullptr, pixels, Cb, stream);
+}
+
+extern "C" int mhe_conv1x1_gram_store_nhwc(const void *x, const float *in_scale, const float *in_shift, int relu_in, float *gram, void *a_out,
+                                           long pixels, int Cb, void *stream) {
     MHE_REQUIRE(x && gram && pixels > 0 && pixels % conv::GPX == 0 && pixels < (1l << 31) && (Cb == 64 || Cb == 128),
                 "mhe_conv1x1_gram_nhwc: bf16 rows of 64 / 128 channels, pixel count a multiple of %d (pixels=%ld Cb=%d)", conv::GPX, pixels, Cb);
     MHE_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "mhe_conv1x1_gram_nhwc: in_scale/in_shift must come together");
     const int ntiles = (int)(pixels / conv::GPX);
     const int per_cu = Cb == 64 ? 3 : 2;                         // 40 / 72 KiB of LDS per workgroup
     const dim3 grid((unsigned)(ntiles < 256 * per_cu ? ntiles : 256 * per_cu));
-    if (Cb == 64) hipLaunchKernelGGL(conv::gram_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, (const u16 *)x, in_scale, in_shift, gram, (int)pixels, relu_in);
-    else hipLaunchKernelGGL(conv::gram_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, (const u16 *)x, in_scale, in_shift, gram, (int)pixels, relu_in);
+    if (Cb == 64) hipLaunchKernelGGL(conv::gram_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, (const u16 *)x, in_scale, in_shift, gram, (int)pixels, relu_in, (u16 *)a_out);
+    else hipLaunchKernelGGL(conv::gram_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, (const u16 *)x, in_scale, in_shift, gram, (int)pixels, relu_in, (u16 *)a_out);
     return check_launch("gram_kernel");
 }
 

@@ -439,7 +439,7 @@ def gram_buffers(Cb, device):
 
 
 def conv1x1_gram_bn(x, in_scale, in_shift, w, bn_weight, bn_bias, running_mean, running_var, bufs, momentum=0.1, eps=1e-5, num_batches_tracked=None,
-                    want_mean_invstd=False):
+                    want_mean_invstd=False, a_out=None):
     """train-mode BatchNorm affine (scale, shift) of conv1x1(relu(x * in_scale + in_shift), w) from the Gram matrix of the convolution's
     INPUT - the product itself is never evaluated (mhe_conv1x1_gram_nhwc + mhe_gram_bn_finalize; csrc/conv_gram.hip)"""
     B, H, W, Cb = x.shape
@@ -451,7 +451,9 @@ def conv1x1_gram_bn(x, in_scale, in_shift, w, bn_weight, bn_bias, running_mean, 
     if TIMING:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    check(L.mhe_conv1x1_gram_nhwc(_ptr(x), _ptr(in_scale), _ptr(in_shift), 1, _ptr(gram), B * H * W, Cb, _stream()), "mhe_conv1x1_gram_nhwc")
+    if a_out is not None:        # also relu(x * in_scale + in_shift) itself, as the matrix cores multiplied it
+        _chk(a_out, torch.bfloat16, "gram.a_out", (B, H, W, Cb))
+    check(L.mhe_conv1x1_gram_store_nhwc(_ptr(x), _ptr(in_scale), _ptr(in_shift), 1, _ptr(gram), _ptr(a_out), B * H * W, Cb, _stream()), "mhe_conv1x1_gram_store_nhwc")
     if TIMING:
         ev1.record()
         KERNEL_TIMES.append(("mhe::conv::gram_kernel<%d>" % Cb, 2.0 * B * H * W * Cb * Cb, ev0, ev1, 2 * x.numel()))

@@ -560,19 +560,22 @@ class TrainStep:
                 h = a
                 b["acts"] = []
                 rest = us[:-1]
-            for u in rest:
-                y = self._unit_fwd(u, h, pool)
-                h = ops.bn_act(y, u.scale, u.shift, relu=True)
-                b["acts"].append(h)
             ul = us[-1]
             nxt = self.blocks[bi + 1] if bi + 1 < len(self.blocks) else None
+            h_by_gram = False
+            for u in rest:
+                y = self._unit_fwd(u, h, pool)
+                # conv2's output of a block whose conv3 runs on Gram statistics: the Gram launch below reads it raw anyway and writes the
+                # normalised tensor on the way (no bn_act pass of its own)
+                h_by_gram = (u is us[-2] and self._foldable(b, nxt, us, y) and (self.conv3_fold and self.fuse_bn_reduce or
+                             ops.bottleneck_tail_supported(y.shape[0], y.shape[1], y.shape[2], y.shape[3], nxt["u"][0].cout)))
+                h = torch.empty_like(y) if h_by_gram else ops.bn_act(y, u.scale, u.shift, relu=True)
+                b["acts"].append(h)
             # layer1 / layer2 bottlenecks (bf16, 64 / 128 bottleneck channels): conv3 is not run here at all - bn3's batch statistics come
             # from the Gram matrix of its input, the tail kernel of the next block evaluates it on the fly (as the module's own forward
             # does, resnet.py), and the reverse pass evaluates it once when it needs it: a write + a read of the block's widest tensor
             # traded for one plain 1x1 launch in the reverse pass (MHE_TRAIN_RECOMPUTE=0: conv3 written in the forward pass)
-            foldable = (self.train_recompute and fuse and nxt is not None and nxt["kind"] == "bottleneck" and b["kind"] == "bottleneck"
-                        and len(us) == 3 and ul.k == 1 and ul.stride == 1 and h.dtype == torch.bfloat16 and us[-2].y is not None
-                        and nxt["u"][0].k == 1 and nxt["u"][0].stride == 1 and ul.cin in (64, 128) and (h.numel() // ul.cin) % 128 == 0)
+            foldable = self._foldable(b, nxt, us, h)
             recompute = foldable and ops.bottleneck_tail_supported(h.shape[0], h.shape[1], h.shape[2], h.shape[3], nxt["u"][0].cout)
             # (a block whose tail the fused kernel cannot take - layer2's last, which feeds layer3 - still runs conv3 for the forward's sake,
             # but on the Gram statistics as well, so that the REVERSE pass can do without y3: it is dropped from the tape)
@@ -589,7 +592,8 @@ class TrainStep:
                     ul.gram_tot = None
                 ul.scale, ul.shift, ul.mi = ops.conv1x1_gram_bn(u2.y, u2.scale, u2.shift, ul.w_fwd, bn3.weight.data, bn3.bias.data, bn3.running_mean,
                                                                 bn3.running_var, gbufs, BN_MOMENTUM, BN_EPS,
-                                                                num_batches_tracked=bn3.num_batches_tracked, want_mean_invstd=True)
+                                                                num_batches_tracked=bn3.num_batches_tracked, want_mean_invstd=True,
+                                                                a_out=h if h_by_gram else None)
                 ul.x, ul.y = h, None
                 yl = ops.conv2d_nhwc(h, ul.w_fwd, 1, 1, 1, 0) if semi else None
             else:
@@ -616,6 +620,14 @@ class TrainStep:
         reverse sums already accumulated by the producer's epilogue (then only finalize + apply run here)."""
         return ops.bn_backward(g, a, u.y, u.mi, u.bn.weight.data, stats if stats is not None else pool.take(u.cout), u.dgamma, u.dbeta,
                                reduced=stats is not None)
+
+    def _foldable(self, b, nxt, us, h):
+        """a bottleneck of layer1 / layer2 whose conv3 + bn3 can run on the Gram statistics of conv3's input (h: that input, or conv2's raw
+        output - same shape)"""
+        ul = us[-1]
+        return (self.train_recompute and self.trunk.fuse_tail and nxt is not None and nxt["kind"] == "bottleneck" and b["kind"] == "bottleneck"
+                and len(us) == 3 and ul.k == 1 and ul.stride == 1 and h.dtype == torch.bfloat16 and us[-2].y is not None
+                and nxt["u"][0].k == 1 and nxt["u"][0].stride == 1 and ul.cin in (64, 128) and (h.numel() // ul.cin) % 128 == 0)
 
     def _ensure_y(self, u):
         """the raw output of a unit whose forward launch was skipped (conv3 of a layer1 / layer2 bottleneck): evaluated now, bit-identical
