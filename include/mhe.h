@@ -469,11 +469,6 @@ int mhe_flow_mask_pad_mixed(const float *x, const float *mask, float *xp, void *
 int mhe_conv2d_masked_bits_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const void *residual,
                                 const void *mask, const void *mask_bits, const void *bn_y0, const float *bn_mean_invstd0, float *bn_stats0,
                                 const void *bn_y1, const float *bn_mean_invstd1, float *bn_stats1, void *stream);
-/* mhe_conv1x1_residual_in_nhwc that also writes [a_out > 0] as bits (a_bits [pixels][Cin / 8] bytes); only where the launcher picks the
- * transfer-wave tail kernel (mhe_conv_tile_mode(d, 2) == 10) - refused otherwise. */
-int mhe_conv1x1_residual_in_bits_nhwc(const mhe_conv_desc *d, const void *x, const void *x2, const void *w, void *y,
-                                      const float *in_scale, const float *in_shift, const float *x2_scale,
-                                      const float *x2_shift, void *a_out, void *a_bits, float *stats, void *stream);
 /* mhe_bottleneck_tail_nhwc that also writes the gate bits of its block output (a_bits [pixels][Cin / 8] bytes, optional). */
 int mhe_bottleneck_tail_bits_nhwc(const mhe_conv_desc *d, int Cb, const void *y2, const float *bn2_scale, const float *bn2_shift,
                                   const void *w3, const float *bn3_scale, const float *bn3_shift, const void *identity,

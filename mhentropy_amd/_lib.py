@@ -99,7 +99,6 @@ SIGNATURES = {
     "mhe_conv_wgrad_batched_workspace_floats": (_sz, [_p, _i]),
     "mhe_conv_wgrad_batched_nhwc": (_i, [_p, _i, _p, _l, _p, _l, _p, _l, _i, _p, _sz, _p]),
     "mhe_conv2d_masked_bits_nhwc": (_i, [_p] * 14),
-    "mhe_conv1x1_residual_in_bits_nhwc": (_i, [_p] * 13),
     "mhe_bottleneck_tail_bits_nhwc": (_i, [_p, _i] + [_p] * 15),
     "mhe_conv2d_masked_bias_nhwc": (_i, [_p, _p, _p, _i] + [_p] * 9),
     "mhe_conv3_bn_fold": (_i, [_p] * 6 + [_f] + [_p] * 4 + [_i, _p, _i] + [_p] * 2 + [_i, _i, _p]),

@@ -766,7 +766,7 @@ static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void
                       const float *in_shift, const float *out_scale, const float *out_shift, const void *residual,
                       float *stats, const void *x2, const float *x2_scale, const float *x2_shift, void *a_out, void *stream,
                       const void *mask = nullptr, const struct BnRev *bn = nullptr, float *y32 = nullptr, const int *scatter = nullptr,
-                      const void *xcat = nullptr, int cin2 = 0, const void *mask_bits = nullptr, void *a_bits = nullptr);
+                      const void *xcat = nullptr, int cin2 = 0, const void *mask_bits = nullptr);
 struct BnRev { const void *y[2]; const float *mi[2]; float *stats[2]; };
 
 extern "C" int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
@@ -789,17 +789,6 @@ extern "C" int mhe_conv1x1_residual_in_nhwc(const mhe_conv_desc *d, const void *
     MHE_REQUIRE(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0, "mhe_conv1x1_residual_in_nhwc: 1x1 stride-1 only");
     MHE_REQUIRE((x2_scale == nullptr) == (x2_shift == nullptr), "mhe_conv1x1_residual_in_nhwc: x2_scale/x2_shift must come together");
     return conv_entry(d, x, w, y, in_scale, in_shift, nullptr, nullptr, nullptr, stats, x2, x2_scale, x2_shift, a_out, stream);
-}
-
-extern "C" int mhe_conv1x1_residual_in_bits_nhwc(const mhe_conv_desc *d, const void *x, const void *x2, const void *w, void *y,
-                                                 const float *in_scale, const float *in_shift, const float *x2_scale,
-                                                 const float *x2_shift, void *a_out, void *a_bits, float *stats, void *stream) {
-    MHE_REQUIRE(d && x2 && in_scale && in_shift && a_out && a_bits, "mhe_conv1x1_residual_in_bits_nhwc: x2, in_scale, in_shift, a_out and a_bits are required");
-    MHE_REQUIRE(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0, "mhe_conv1x1_residual_in_bits_nhwc: 1x1 stride-1 only");
-    MHE_REQUIRE((x2_scale == nullptr) == (x2_shift == nullptr), "mhe_conv1x1_residual_in_bits_nhwc: x2_scale/x2_shift must come together");
-    MHE_REQUIRE(mhe_conv_tile_mode(d, 2) == 10, "mhe_conv1x1_residual_in_bits_nhwc: only the transfer-wave tail kernel (variant 10) writes the gate bits");
-    return conv_entry(d, x, w, y, in_scale, in_shift, nullptr, nullptr, nullptr, stats, x2, x2_scale, x2_shift, a_out, stream, nullptr, nullptr, nullptr,
-                      nullptr, nullptr, 0, nullptr, a_bits);
 }
 
 extern "C" int mhe_conv1x1_residual_in_masked_nhwc(const mhe_conv_desc *d, const void *x, const void *x2, const void *w, void *y,
@@ -874,7 +863,7 @@ extern "C" int mhe_conv3x3s2_dgrad_nhwc(int B, int Ho, int Wo, int Cout, int Cin
 static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
                       const float *in_shift, const float *out_scale, const float *out_shift, const void *residual,
                       float *stats, const void *x2, const float *x2_scale, const float *x2_shift, void *a_out, void *stream,
-                      const void *mask, const BnRev *bn, float *y32, const int *scatter, const void *xcat, int cin2, const void *mask_bits, void *a_bits) {
+                      const void *mask, const BnRev *bn, float *y32, const int *scatter, const void *xcat, int cin2, const void *mask_bits) {
     MHE_REQUIRE(d && x && w && (y || y32), "mhe_conv2d_nhwc: null pointer");
     MHE_REQUIRE(d->dtype == MHE_F32 || d->dtype == MHE_BF16, "mhe_conv2d_nhwc: dtype=%d", d->dtype);
     const int ce = elem_chunk(d->dtype), bke = 8 * ce;
@@ -903,7 +892,7 @@ static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void
     const long long M = (long long)p.B * p.Ho * p.Wo;
     MHE_REQUIRE(M < (1ll << 31), "mhe_conv2d_nhwc: too many output pixels");
     p.M = (int)M;
-    p.xcat = xcat; p.Cin2 = cin2; p.mask_bits = (const unsigned char *)mask_bits; p.a_bits = (unsigned char *)a_bits;
+    p.xcat = xcat; p.Cin2 = cin2; p.mask_bits = (const unsigned char *)mask_bits;
     const int ktot = d->KH * d->KW * d->Cin + cin2;
     p.Kpad = (ktot + bke - 1) / bke * bke;       // weight rows are zero-padded to this length by the packer
     p.relu_in = d->relu_in; p.relu_out = d->relu_out;

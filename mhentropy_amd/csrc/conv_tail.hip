@@ -67,7 +67,7 @@ __global__ __launch_bounds__(512) void conv_tail_kernel(const Params p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) st.w[j] = *reinterpret_cast<const uint4 *>(wg + (size_t)(n0 + rbase + 32 * j) * p.Kpad + kc);
     };
-    auto store_tile = [&](int t, const Set &st, int m0, T *ag, unsigned char *ab) __attribute__((always_inline)) {
+    auto store_tile = [&](int t, const Set &st, int m0, T *ag) __attribute__((always_inline)) {
         uint4 *At = lds + (t & 1) * T_STAGE, *Wt = At + T_A;
         const int kc = t * TBK + s * 8;
         float sc[8], sh[8], s2[8], h2[8];
@@ -96,15 +96,6 @@ __global__ __launch_bounds__(512) void conv_tail_kernel(const Params p) {
             const uint4 o = Chunk<T>::pack(v);
             At[swz(rbase + 32 * j, s)] = o;
             if (ag) *reinterpret_cast<uint4 *>(ag + (size_t)(m0 + rbase + 32 * j) * K + kc) = o;
-            if (ab) {                                                    // [a > 0] of the eight stored values: the reverse pass's gate as bits
-                const unsigned wds[4] = {o.x, o.y, o.z, o.w};
-                unsigned gb = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    gb |= ((unsigned)((wds[i] & 0x8000u) == 0 && (wds[i] & 0x7fffu) != 0) << (2 * i)) |
-                          ((unsigned)((wds[i] & 0x80000000u) == 0 && (wds[i] & 0x7fff0000u) != 0) << (2 * i + 1));
-                ab[(size_t)(m0 + rbase + 32 * j) * (K / 8) + (kc >> 3)] = (unsigned char)gb;
-            }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) Wt[swz(rbase + 32 * j, s)] = st.w[j];
@@ -269,15 +260,14 @@ __global__ __launch_bounds__(512) void conv_tail_kernel(const Params p) {
             tile_at(L, mt, ntile);
             const int m0 = mt * TBM, n0 = ntile * TBN;
             T *ag = p.a_out && ntile == 0 ? reinterpret_cast<T *>(p.a_out) : nullptr;
-            unsigned char *ab = !DG && p.a_bits && ntile == 0 ? p.a_bits : nullptr;
             __syncthreads();
             // K tile u lives in set u & 1; tiles 0 and 1 are in flight (loaded during the previous pixel tile's epilogue)
-            store_tile(0, st0, m0, ag, ab);
+            store_tile(0, st0, m0, ag);
             if (2 < nk) load_tile(2, st0, m0, n0);
             // tick t: write tile t + 1 (set (t + 1) & 1) into the stage the multiply waves are not reading, then reload that set with tile t + 3
             auto tick = [&](int t, Set &st) __attribute__((always_inline)) {
                 __syncthreads();                                          // stage (t + 1) & 1 was last read during tick t - 1
-                if (t + 1 < nk) store_tile(t + 1, st, m0, ag, ab);            // first everything that consumes loaded registers ...
+                if (t + 1 < nk) store_tile(t + 1, st, m0, ag);            // first everything that consumes loaded registers ...
                 if (t + 3 < nk) load_tile(t + 3, st, m0, n0);             // ... then this tick's loads
             };
             for (int t = 0; t < nk; t += 2) {

@@ -566,9 +566,8 @@ def conv3x3s2_dgrad(gy, w4, residual=None, mask=None, bn=None, tile=0):
     return dx
 
 
-def conv1x1_residual_in(x, x2, w, in_scale, in_shift, x2_scale=None, x2_shift=None, a_out=None, stats=None, tile=0, a_bits=None):
-    """y = conv1x1(relu(x*in_scale+in_shift + (x2*x2_scale+x2_shift | x2))); optionally writes that operand to a_out (and, a_bits: [a_out > 0]
-    as bits [pixel][Cin / 8] - only where conv_tile_choice(..., mode 2) == 10; check before asking)."""
+def conv1x1_residual_in(x, x2, w, in_scale, in_shift, x2_scale=None, x2_shift=None, a_out=None, stats=None, tile=0):
+    """y = conv1x1(relu(x*in_scale+in_shift + (x2*x2_scale+x2_shift | x2))); optionally writes that operand to a_out."""
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
     dt = x.dtype
@@ -585,15 +584,9 @@ def conv1x1_residual_in(x, x2, w, in_scale, in_shift, x2_scale=None, x2_shift=No
     if TIMING:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    if a_bits is not None:
-        _chk(a_bits, torch.uint8, "conv_res.a_bits", (B, H, W, Cin // 8))
-        check(_lib.lib().mhe_conv1x1_residual_in_bits_nhwc(C.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(y), _ptr(in_scale), _ptr(in_shift),
-                                                           _ptr(x2_scale), _ptr(x2_shift), _ptr(a_out), _ptr(a_bits), _ptr(stats), _stream()),
-              "mhe_conv1x1_residual_in_bits_nhwc")
-    else:
-        check(_lib.lib().mhe_conv1x1_residual_in_nhwc(C.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(y), _ptr(in_scale), _ptr(in_shift),
-                                                      _ptr(x2_scale), _ptr(x2_shift), _ptr(a_out), _ptr(stats), _stream()),
-              "mhe_conv1x1_residual_in_nhwc")
+    check(_lib.lib().mhe_conv1x1_residual_in_nhwc(C.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(y), _ptr(in_scale), _ptr(in_shift),
+                                                  _ptr(x2_scale), _ptr(x2_shift), _ptr(a_out), _ptr(stats), _stream()),
+          "mhe_conv1x1_residual_in_nhwc")
     if TIMING:
         ev1.record()
         es = x.element_size()

@@ -142,8 +142,6 @@ class TrainStep:
         self.conv3_fold_cat = os.environ.get("MHE_CONV3_FOLD_CAT", "1") == "1"
         self.stem_bwd_two_pass = os.environ.get("MHE_STEM_BWD_TWO_PASS", "1") == "1"
         self.gate_bits = os.environ.get("MHE_GATE_BITS", "1") == "1"
-        # (the transfer-wave tail kernel writing them for layer3's blocks: measured +0.4 ms - its transfer waves are what bounds it; off)
-        self.gate_bits_tail = os.environ.get("MHE_GATE_BITS_TAIL", "0") == "1"
         # the stem's BatchNorm + ReLU folded into its max pool, forward and reverse (ops.maxpool3x3s2_idx / maxpool3x3s2_bwd_bn)
         self.stem_pool_fused = os.environ.get("MHE_STEM_POOL_FUSED", "1") == "1"
         self.bn_on_load_wide = os.environ.get("MHE_BN_BWD_ON_LOAD_WIDE", "1") == "1"
@@ -548,18 +546,12 @@ class TrainStep:
                 a = torch.empty_like(yl_p)
                 u0 = us[0]
                 st = pool.take(u0.cout)
-                # (the gate bits of this block's input where the transfer-wave tail kernel runs and the streaming data-gradient kernel will
-                # read them: conv1 of layer3's blocks)
-                abits = None
-                if (self.gate_bits and self.gate_bits_tail and a.dtype == torch.bfloat16 and a.shape[3] % 8 == 0
-                        and ops.conv_tile_choice(a.shape[0], a.shape[1], a.shape[2], a.shape[3], u0.cout, 1, 1, 0, a.dtype, 2) == 10):
-                    abits = torch.empty(a.shape[0], a.shape[1], a.shape[2], a.shape[3] // 8, device=self.dev, dtype=torch.uint8)
                 y = ops.conv1x1_residual_in(yl_p, idt_p, u0.w_fwd, ul_p.scale, ul_p.shift, None if ud_p is None else ud_p.scale,
-                                            None if ud_p is None else ud_p.shift, a_out=a, stats=st, a_bits=abits)
+                                            None if ud_p is None else ud_p.shift, a_out=a, stats=st)
                 self._bn_tape(u0, a, y, st)
                 self.blocks[bi - 1]["out"] = a
                 pending = None
-                b["a"], b["a_bits"] = a, abits
+                b["a"], b["a_bits"] = a, None
                 h = ops.bn_act(y, u0.scale, u0.shift, relu=True)
                 b["acts"] = [h]
                 rest = us[1:-1]

@@ -680,21 +680,3 @@ def test_relu_gate_as_bits_for_the_streaming_data_gradient(gpu_lib):
     assert_close(s10.cpu(), s00.cpu(), 1e-5, what="sums of the consumer with a raw output")
     assert_close(s11[0].cpu(), s01[0].cpu(), 1e-5, what="sum g of the consumer handed the gate tensor")
     assert_close(s11[0].cpu(), o1.float().sum((0, 1, 2)).cpu(), 2e-3, 1e-2, what="sum g against the stored gradient")
-
-
-def test_residual_tail_kernel_writes_the_gate_bits(gpu_lib):
-    """mhe_conv1x1_residual_in_bits_nhwc (variant 10): the block output's [a > 0] as bits next to a_out, nothing else changed"""
-    from mhentropy_amd import ops, resnet
-    B, H, W, Cin, Cout = 4, 16, 16, 1024, 256
-    assert ops.conv_tile_choice(B, H, W, Cin, Cout, 1, 1, 0, torch.bfloat16, 2) == 10
-    g, x, w = _operands(7, B, H, W, Cin, Cout, 1)
-    x2 = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
-    sc, sh = (torch.rand(Cin, generator=g) + 0.5).cuda(), (torch.randn(Cin, generator=g) * 0.3).cuda()
-    wp = resnet.pack_conv_weight(w, torch.bfloat16).cuda()
-    a0 = torch.empty(B, H, W, Cin, device="cuda", dtype=torch.bfloat16)
-    y0 = ops.conv1x1_residual_in(_nhwc(x), _nhwc(x2), wp, sc, sh, a_out=a0)
-    a1, bits = torch.empty_like(a0), torch.zeros(B, H, W, Cin // 8, device="cuda", dtype=torch.uint8)
-    y1 = ops.conv1x1_residual_in(_nhwc(x), _nhwc(x2), wp, sc, sh, a_out=a1, a_bits=bits)
-    assert torch.equal(a1, a0) and torch.equal(y1, y0)
-    want = ((a0.float() > 0).view(B, H, W, Cin // 8, 8).to(torch.int32) * (1 << torch.arange(8, device="cuda", dtype=torch.int32))).sum(-1).to(torch.uint8)
-    assert torch.equal(bits, want)
