@@ -490,6 +490,17 @@ int mhe_conv2d_masked_bias_nhwc(const mhe_conv_desc *d, const void *x, const voi
 int mhe_conv3_bn_fold(float *D, const void *w_bf16, const double *gram_totals, const float *rev_stats, const float *gamma,
                       const float *mean_invstd, float count, float *dgamma, float *dbeta, float *dW, void *w_dg_bf16, int ld_dg,
                       void *S_bf16, int ld_S, float *c0, float *coef_ws, int C, int Cb, void *stream);
+/* 3x3 / stride-1 / pad-1 bf16 convolution with the input tile resident in LDS (csrc/conv_halo.hip; conv2 of a torchvision Bottleneck,
+ * hand/network.py:54-61,110, and its data gradient): W = 32 or 16, H a multiple of 256 / W, Cin a multiple of 64 (<= 512), Cout of 128.
+ * w_halo = mhe_conv3x3_halo_pack_bf16 of the standard pack [Cout][9 Cin] (same byte count).  in_scale / in_shift (+ relu_in): the producer's
+ * BatchNorm (+ ReLU) applied once per element on its way into LDS (zero padding stays zero); a_out (optional, with them): the normalised
+ * operand [B][H][W][Cin] written once.  Forward form: stats as mhe_conv2d_nhwc.  Data-gradient form (mask given): outputs (+ residual) gated
+ * by mask > 0, BatchNorm-reverse sums of one consumer as mhe_conv2d_masked_nhwc. */
+int mhe_conv3x3_halo_supported(int B, int H, int W, int Cin, int Cout);
+int mhe_conv3x3_halo_pack_bf16(const void *w, void *w_halo, int Cout, int Cin, void *stream);
+int mhe_conv3x3_halo_nhwc(int B, int H, int W, int Cin, int Cout, const void *x, const void *w_halo, void *y, const float *in_scale,
+                          const float *in_shift, int relu_in, void *a_out, float *stats, const void *residual, const void *mask,
+                          const void *bn_y0, const float *bn_mean_invstd0, float *bn_stats0, void *stream);
 int mhe_flow_reverse_chain_supported(int R, int B, int dim, int hidden, int ncoup);
 /* mhe_flow_couplings_bf16 / _emit on the fragment-streaming skeleton (csrc/flow_fwd.hip): hidden 512, a multiple of 64 hypotheses per
  * image (R % (64 B) == 0; a workgroup = 64 rows of one image), at most 32 couplings.  Same results as mhe_flow_couplings_bf16 up to the

@@ -152,63 +152,17 @@ __device__ __forceinline__ long res_half_row(const Params &p, long m) {
 // index (or -1 when the row is outside the image / batch).
 // DG: data-gradient form - ReLU gate by p.mask and (optionally) BatchNorm-reverse sums; compiled out of the forward kernels
 // (with the code present behind run-time flags the forward step was 1.5 % slower: register pressure in the store loop).
-template <typename T, int BM, int BN, int WM, int WN, bool DG, typename LdsT, typename AccT, typename PixF>
-__device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, int shard, int n0, PixF pix) {
-    constexpr int NTH = 64 * WM * WN;
-    constexpr int MTW = BM / WM / 16, NTW = BN / WN / 16;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int q = lane >> 4, l15 = lane & 15;
-    const int wr = wave / WN, wc = wave % WN;
-    // ---- epilogue.  The accumulator holds y^T: lane (l15, q) owns channels 4q..4q+3 of tile nt
-    // for pixel 16mt + l15.  (1) batch statistics: per-thread partials -> LDS -> one thread per
-    // (statistic, channel) -> ONE coalesced f32 atomic per thread into this block's shard.
-    // (2) the tile is transposed through LDS (16-byte chunks XOR-swizzled by row) so that global
-    // stores are whole 16-byte pieces of contiguous channel rows instead of 8-byte row-strided ones.
+// the store half of the epilogue: the BM x BN tile lies staged in `ot` (row = pixel, 16-byte chunks XOR-swizzled by row); NTH threads
+// (tid 0 .. NTH - 1, all of them and only them) walk it.  Takes 2 workgroup barriers when p.stats is set, 2 more per BatchNorm unit of the
+// data-gradient form: waves of the workgroup that do not take part in the walk must execute as many (conv_halo.hip).
+template <typename T, int BM, int BN, int NTH, bool DG, int GROWS = (NTH >= 512 ? 4 : 2), typename PixF>
+__device__ __forceinline__ void epilogue_store(const Params &p, unsigned char *ot, int shard, int n0, PixF pix) {
+    const int tid = threadIdx.x;
     constexpr int CPR = BN * (int)sizeof(T) / 16;          // 16-byte chunks per output row
     constexpr int CMASK = (CPR - 1) & 15;
     constexpr int EPC = 16 / (int)sizeof(T);               // elements per chunk
-    static_assert((size_t)BM * BN * sizeof(T) <= sizeof(lds), "output tile must fit the staging buffers");
-    if constexpr (sizeof(T) == 2 && !DG) {
-        // f32 result from bf16 operands (mhe_conv2d_f32out_nhwc): the accumulator's own layout gives every lane 4 consecutive
-        // channels of one pixel = one 16-byte store; used by the narrow (<= 64 output channels) products of the flow's reverse
-        // pass whose results feed exp / tanh or the flow variable's gradient chain
-        if (p.y32) {
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < MTW; ++mt) {
-                    const long m = pix(wr * (BM / WM) + mt * 16 + l15);
-                    const int n = n0 + wc * (BN / WN) + nt * 16 + 4 * q;
-                    if (m < 0 || n >= p.Cout) continue;
-                    v4f v = acc[nt][mt];
-                    if (p.out_shift) { const float4 b = *reinterpret_cast<const float4 *>(p.out_shift + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-                    *reinterpret_cast<float4 *>(p.y32 + (size_t)m * p.Cout + n) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-            return;
-        }
-    }
+    float *const lds = reinterpret_cast<float *>(ot);
     {
-        unsigned char *ot = reinterpret_cast<unsigned char *>(lds);
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) {
-                const int row = wr * (BM / WM) + mt * 16 + l15;
-                const int e0 = wc * (BN / WN) + nt * 16 + 4 * q;             // first of 4 channels within the tile
-                const int boff = e0 * (int)sizeof(T);
-                const int chunk = (boff >> 4) ^ (row & CMASK);
-                unsigned char *dst = ot + ((size_t)row * CPR + chunk) * 16 + (boff & 15);
-                const v4f v = acc[nt][mt];
-                if constexpr (sizeof(T) == 4) {
-                    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    uint2 o;
-                    o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-                    o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-                    *reinterpret_cast<uint2 *>(dst) = o;
-                }
-            }
-        __syncthreads();
         T *yg = reinterpret_cast<T *>(p.y);
         const T *rg = reinterpret_cast<const T *>(p.residual);
         const T *mk = DG ? reinterpret_cast<const T *>(p.mask) : nullptr;
@@ -258,7 +212,7 @@ __device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, 
                     constexpr int NBN = decltype(NB)::value, NJ = BM * CPR / NTH;
                     // rows in flight per thread: 4 on the one-workgroup-per-CU 256x256 tiles; 2 on the 256-thread tiles, which must
                     // stay within 256 registers to keep two workgroups per CU (4 took 128x128 to one wave per SIMD: 166 -> 210 us)
-                    constexpr int G = NTH >= 512 ? 4 : 2;
+                    constexpr int G = GROWS;
                     static_assert(NJ % G == 0, "rows per thread");
 #pragma unroll 1                  // one group of G rows at a time: fully unrolled, hipcc hoists the next groups' loads and spills (179 VGPRs on the 256x256 tile)
                     for (int j0 = 0; j0 < NJ; j0 += G) {
@@ -422,6 +376,67 @@ __device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, 
             }
         }
     }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool DG, typename LdsT, typename AccT, typename PixF>
+__device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, int shard, int n0, PixF pix) {
+    constexpr int NTH = 64 * WM * WN;
+    constexpr int MTW = BM / WM / 16, NTW = BN / WN / 16;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int q = lane >> 4, l15 = lane & 15;
+    const int wr = wave / WN, wc = wave % WN;
+    // ---- epilogue.  The accumulator holds y^T: lane (l15, q) owns channels 4q..4q+3 of tile nt
+    // for pixel 16mt + l15.  (1) batch statistics: per-thread partials -> LDS -> one thread per
+    // (statistic, channel) -> ONE coalesced f32 atomic per thread into this block's shard.
+    // (2) the tile is transposed through LDS (16-byte chunks XOR-swizzled by row) so that global
+    // stores are whole 16-byte pieces of contiguous channel rows instead of 8-byte row-strided ones.
+    constexpr int CPR = BN * (int)sizeof(T) / 16;          // 16-byte chunks per output row
+    constexpr int CMASK = (CPR - 1) & 15;
+    constexpr int EPC = 16 / (int)sizeof(T);               // elements per chunk
+    static_assert((size_t)BM * BN * sizeof(T) <= sizeof(lds), "output tile must fit the staging buffers");
+    if constexpr (sizeof(T) == 2 && !DG) {
+        // f32 result from bf16 operands (mhe_conv2d_f32out_nhwc): the accumulator's own layout gives every lane 4 consecutive
+        // channels of one pixel = one 16-byte store; used by the narrow (<= 64 output channels) products of the flow's reverse
+        // pass whose results feed exp / tanh or the flow variable's gradient chain
+        if (p.y32) {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) {
+                    const long m = pix(wr * (BM / WM) + mt * 16 + l15);
+                    const int n = n0 + wc * (BN / WN) + nt * 16 + 4 * q;
+                    if (m < 0 || n >= p.Cout) continue;
+                    v4f v = acc[nt][mt];
+                    if (p.out_shift) { const float4 b = *reinterpret_cast<const float4 *>(p.out_shift + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                    *reinterpret_cast<float4 *>(p.y32 + (size_t)m * p.Cout + n) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            return;
+        }
+    }
+    unsigned char *ot = reinterpret_cast<unsigned char *>(lds);
+    {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+                const int row = wr * (BM / WM) + mt * 16 + l15;
+                const int e0 = wc * (BN / WN) + nt * 16 + 4 * q;             // first of 4 channels within the tile
+                const int boff = e0 * (int)sizeof(T);
+                const int chunk = (boff >> 4) ^ (row & CMASK);
+                unsigned char *dst = ot + ((size_t)row * CPR + chunk) * 16 + (boff & 15);
+                const v4f v = acc[nt][mt];
+                if constexpr (sizeof(T) == 4) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    uint2 o;
+                    o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                    o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                    *reinterpret_cast<uint2 *>(dst) = o;
+                }
+            }
+    }
+    __syncthreads();
+    epilogue_store<T, BM, BN, NTH, DG>(p, ot, shard, n0, pix);
 }
 
 }}  // namespace mhe::conv

@@ -493,6 +493,43 @@ def conv3_bn_fold(D, w, gram_totals, rev_stats, gamma, mean_invstd, count, dgamm
           "mhe_conv3_bn_fold")
 
 
+def conv3x3_halo_supported(B, H, W, Cin, Cout):
+    return bool(_lib.lib().mhe_conv3x3_halo_supported(int(B), int(H), int(W), int(Cin), int(Cout)))
+
+
+def conv3x3_halo_pack(w):
+    """standard bf16 pack [Cout][9 Cin] -> the fragment-major 16 KiB stages csrc/conv_halo.hip streams (same byte count)"""
+    _chk(w, torch.bfloat16, "halo_pack.w")
+    Cout, K = w.shape
+    if K % 9 or (K // 9) % 64 or Cout % 128:
+        raise ValueError(f"conv3x3_halo_pack: weight rows [{Cout}][{K}] are not 9 x (a multiple of 64) wide / a multiple of 128 many")
+    out = torch.empty_like(w)
+    check(_lib.lib().mhe_conv3x3_halo_pack_bf16(_ptr(w), _ptr(out), int(Cout), int(K // 9), _stream()), "mhe_conv3x3_halo_pack_bf16")
+    return out
+
+
+def conv3x3_halo(x, w_halo, in_scale=None, in_shift=None, relu_in=False, a_out=None, stats=None, residual=None, mask=None, bn=None):
+    """3x3 / stride 1 / pad 1 with the input tile resident in LDS (mhe_conv3x3_halo_nhwc).  in_scale / in_shift: the producer's BatchNorm on
+    the way in; a_out: that operand written once; mask (+ residual, bn = (raw output, mean_invstd, stats) of ONE consumer): data-gradient form."""
+    B, H, W, Cin = x.shape
+    Cout = w_halo.shape[0]
+    _chk(x, torch.bfloat16, "halo.x"); _chk(w_halo, torch.bfloat16, "halo.w", (Cout, 9 * Cin))
+    y = torch.empty(B, H, W, Cout, device=x.device, dtype=torch.bfloat16)
+    for t, name, shape in ((in_scale, "in_scale", (Cin,)), (in_shift, "in_shift", (Cin,)), (stats, "stats", (stat_shards(), 2, Cout))):
+        if t is not None:
+            _chk(t, torch.float32, "halo." + name, shape)
+    for t, name, shape in ((a_out, "a_out", tuple(x.shape)), (residual, "residual", tuple(y.shape)), (mask, "mask", tuple(y.shape))):
+        if t is not None:
+            _chk(t, torch.bfloat16, "halo." + name, shape)
+    by, bmi, bst = (None, None, None) if bn is None else bn
+    if by is not None:
+        _chk(by, torch.bfloat16, "halo.bn_y", tuple(y.shape)); _chk(bmi, torch.float32, "halo.bn_mi", (2, Cout)); _chk(bst, torch.float32, "halo.bn_stats", (stat_shards(), 2, Cout))
+    check(_lib.lib().mhe_conv3x3_halo_nhwc(B, H, W, Cin, Cout, _ptr(x), _ptr(w_halo), _ptr(y), _ptr(in_scale), _ptr(in_shift), int(bool(relu_in)),
+                                           _ptr(a_out), _ptr(stats), _ptr(residual), _ptr(mask), _ptr(by), _ptr(bmi), _ptr(bst), _stream()),
+          "mhe_conv3x3_halo_nhwc")
+    return y
+
+
 def bottleneck_tail_supported(B, H, W, Cb, Cout):
     d = ConvDesc(B, H, W, 4 * Cb, Cout, 1, 1, 1, 0, BF16, 1, 0, 0, 0)
     return bool(_lib.lib().mhe_bottleneck_tail_supported(C.byref(d), int(Cb)))

@@ -92,6 +92,11 @@ class ResNetTrunk(nn.Module):
         # wide (layer1, layer2), in place on layer3 / layer4 (C2 bf16 forward 9.19 ms all in place, 9.02 all on load)
         self.bn_apply_1x1 = os.environ.get("MHE_BN_APPLY_1X1", "auto")
         self.bn_apply_3x3 = os.environ.get("MHE_BN_APPLY_3X3", "auto")
+        # (stride-2 3x3 consumers: each input element is used by 2.25 taps on average instead of 9: on load, -0.06 ms at C2)
+        self.bn_load_s2 = os.environ.get("MHE_BN_LOAD_S2", "1") == "1"
+        # stride-1 3x3 consumers on 32 x 32 / 16 x 16 images (conv2 of layer2 / layer3 at C2): the kernel that keeps the input tile in LDS
+        # and normalises every element once on its way in (csrc/conv_halo.hip) - no pass, no im2col re-reads
+        self.conv_halo = os.environ.get("MHE_CONV_HALO", "1") == "1"
         # evaluate relu(bn3(conv3) + identity) inside the next block's conv1 (one read of the block output saved)
         self.fuse_tail = os.environ.get("MHE_FUSE_TAIL", "1") == "1"
         # ... and at 64 / 128 bottleneck channels (layer1 / layer2) do not write conv3's raw output at all: a statistics-only launch gives
@@ -116,6 +121,18 @@ class ResNetTrunk(nn.Module):
         if hit is None or hit[0] != key:
             hit = (key, pack_stem_weight(p, self.compute_dtype) if stem else pack_conv_weight(p, self.compute_dtype, cin_pad))
             self._wcache[id(p)] = hit
+        return hit[1]
+
+    def _w_halo(self, conv):
+        """the 3x3 weights as csrc/conv_halo.hip streams them (cached like _w; None while a trainer owns the packs: they change every step)"""
+        if getattr(self, "_external_w", None) is not None:
+            return None
+        p = conv.weight
+        key = (id(p), p._version, "halo", p.device)
+        hit = self._wcache.get(("halo", id(p)))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.conv3x3_halo_pack(self._w(conv)))
+            self._wcache[("halo", id(p))] = hit
         return hit[1]
 
     def _bn_affine(self, y, bn, st, count=None):
@@ -181,9 +198,19 @@ class ResNetTrunk(nn.Module):
                     y1, a1 = self._conv_bn(a, blk.conv1, blk.bn1, pool, a_aff, apply="load")
                 # 3x3 consumer: in place, except where the row-streaming kernel runs (layer1 at C2) - it normalises each input row once on
                 # its way into LDS (95 us against 56 + 77 us for the pass and the plain form)
-                ap2 = "load" if self.bn_apply_3x3 == "auto" and ops.conv_tile_choice(
-                    y1.shape[0], y1.shape[1], y1.shape[2], y1.shape[3], blk.conv2.out_channels, 3, blk.stride, 1, y1.dtype, 1) == 9 else None
-                y2, a2 = self._conv_bn(y1, blk.conv2, blk.bn2, pool, a1, blk.stride, 1, 3, apply=ap2)
+                ap2 = "load" if self.bn_apply_3x3 == "auto" and (ops.conv_tile_choice(
+                    y1.shape[0], y1.shape[1], y1.shape[2], y1.shape[3], blk.conv2.out_channels, 3, blk.stride, 1, y1.dtype, 1) == 9
+                    or (blk.stride == 2 and self.bn_load_s2)) else None
+                wh = None
+                if (self.conv_halo and blk.stride == 1 and y1.dtype == torch.bfloat16 and self.bn_apply_3x3 == "auto"
+                        and ops.conv3x3_halo_supported(y1.shape[0], y1.shape[1], y1.shape[2], y1.shape[3], blk.conv2.out_channels)):
+                    wh = self._w_halo(blk.conv2)
+                if wh is not None:
+                    st2 = pool.take(blk.conv2.out_channels) if self.training else None
+                    y2 = ops.conv3x3_halo(y1, wh, a1[0], a1[1], relu_in=True, stats=st2)
+                    a2 = self._bn_affine(y2, blk.bn2, st2)
+                else:
+                    y2, a2 = self._conv_bn(y1, blk.conv2, blk.bn2, pool, a1, blk.stride, 1, 3, apply=ap2)
                 # (... and where the resident-slab kernel runs conv3, layer3 at C2: its transfer waves normalise each K tile once)
                 ap3 = self.bn_apply_1x1 if self.bn_apply_1x1 != "auto" else ("load" if blk.conv3.in_channels <= 128 or ops.conv_tile_choice(
                     y2.shape[0], y2.shape[1], y2.shape[2], y2.shape[3], blk.conv3.out_channels, 1, 1, 0, y2.dtype, 1) == 11 else "pass")

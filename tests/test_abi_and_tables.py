@@ -172,5 +172,10 @@ def test_round3_entries_refuse_what_they_do_not_support():
     assert rc != 0 and b"null pointer" in L.mhe_last_error()
     rc = L.mhe_conv3_bn_fold(null, null, null, null, null, null, 1024.0, null, null, null, null, 256, null, 64, null, null, 256, 64, null)
     assert rc != 0 and b"null pointer" in L.mhe_last_error()
+    rc = L.mhe_conv3x3_halo_nhwc(256, 32, 32, 128, 128, null, null, null, null, null, 0, null, null, null, null, null, null, null, null)
+    assert rc != 0 and b"null pointer" in L.mhe_last_error()
+    rc = L.mhe_conv3x3_halo_pack_bf16(null, null, 128, 128, null)
+    assert rc != 0 and b"null pointer" in L.mhe_last_error()
+    assert L.mhe_conv3x3_halo_supported(256, 32, 32, 128, 128) == 1 and L.mhe_conv3x3_halo_supported(256, 8, 8, 512, 512) == 0
     rc = L.mhe_pack_transpose_bf16(null, 0, null, null, 4, 4, null)
     assert rc != 0 and b"bad arguments" in L.mhe_last_error()

@@ -680,3 +680,71 @@ def test_relu_gate_as_bits_for_the_streaming_data_gradient(gpu_lib):
     assert_close(s10.cpu(), s00.cpu(), 1e-5, what="sums of the consumer with a raw output")
     assert_close(s11[0].cpu(), s01[0].cpu(), 1e-5, what="sum g of the consumer handed the gate tensor")
     assert_close(s11[0].cpu(), o1.float().sum((0, 1, 2)).cpu(), 2e-3, 1e-2, what="sum g against the stored gradient")
+
+
+# B, H (= W), Cin, Cout: one tile per workgroup; an odd number of 64-channel chunks (the halo buffers change parity from tile to tile);
+# two column tiles; more tiles than workgroups (the persistent loop: next tile staged during this one's last chunk) on both map sizes
+HALO_GEOMS = [(4, 32, 128, 128), (3, 16, 192, 128), (5, 16, 256, 256), (80, 32, 64, 128), (136, 16, 192, 256)]
+
+
+@pytest.mark.parametrize("form", ["plain", "bn-on-load", "data-gradient"])
+@pytest.mark.parametrize("geom", HALO_GEOMS, ids=lambda g: "x".join(map(str, g)))
+def test_3x3_kernel_with_the_input_tile_resident_in_lds(gpu_lib, geom, form):
+    """conv_halo_kernel (csrc/conv_halo.hip: 3x3 / stride 1 / pad 1 on 32 x 32 and 16 x 16 maps; halo of 256 output pixels in LDS, weights
+    streamed fragment-major): against conv2d on the bf16-rounded operands - producer BatchNorm + ReLU applied in f32 once per element and
+    rounded, zero padding AFTER it, the normalised operand written out once and equal to the in-place pass's; statistics of the stored
+    output; data-gradient form against the register-staged kernel"""
+    from mhentropy_amd import ops, resnet
+    B, H, Cin, Cout = geom
+    W = H
+    assert ops.conv3x3_halo_supported(B, H, W, Cin, Cout)
+    g, x, w = _operands(B + Cin, B, H, W, Cin, Cout, 3)
+    if B > 16:
+        x = x.cuda(); w = w.cuda()
+    xd = x.permute(0, 2, 3, 1).contiguous().bfloat16().cuda()
+    wd = resnet.pack_conv_weight(w, torch.bfloat16).cuda()
+    wh = ops.conv3x3_halo_pack(wd)
+    if form == "data-gradient":
+        rnd = lambda *s: torch.randn(*s, generator=g).bfloat16().cuda()
+        mask, res, by = rnd(B, H, W, Cout), rnd(B, H, W, Cout), rnd(B, H, W, Cout)
+        mi = torch.stack([torch.randn(Cout, generator=g) * 0.1, torch.rand(Cout, generator=g) + 0.5]).cuda().contiguous()
+        st = [torch.zeros(ops.stat_shards(), 2, Cout, device="cuda") for _ in range(2)]
+        got = ops.conv3x3_halo(xd, wh, residual=res, mask=mask, bn=(by, mi, st[0]))
+        want = ops.conv2d_nhwc(xd, wd, 3, 3, 1, 1, residual=res, mask=mask, bn=[(by, mi, st[1])], tile=2)
+        assert_close(got.float().cpu(), want.float().cpu(), 8e-3, what="gated data gradient")
+        a, b = st[0].sum(0).cpu(), st[1].sum(0).cpu()
+        assert ((a - b).abs() <= 2e-2 * (b.abs().max(1, keepdim=True)[0] + 1.0)).all(), "BatchNorm-reverse sums"
+        return
+    kw, xin = {}, x
+    a_out = None
+    if form == "bn-on-load":
+        sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.2
+        a_out = torch.empty_like(xd)
+        kw = dict(in_scale=sc.cuda(), in_shift=sh.cuda(), relu_in=True, a_out=a_out)
+        xin = torch.relu(x * sc.to(x.device).view(1, -1, 1, 1) + sh.to(x.device).view(1, -1, 1, 1)).bfloat16().float()
+    ref = F.conv2d(xin.double() if B <= 16 else xin, w.double() if B <= 16 else w, None, 1, 1)
+    stats = torch.zeros(ops.stat_shards(), 2, Cout, device="cuda")
+    y = ops.conv3x3_halo(xd, wh, stats=stats, **kw)
+    assert_close(y.float().cpu().permute(0, 3, 1, 2), ref.cpu(), TOL, what="raw conv")
+    n = ref.numel() / Cout
+    stt = stats.double().sum(0).cpu()
+    ys = y.double().cpu().permute(0, 3, 1, 2)
+    assert_close(stt[0] / n, ys.mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean")
+    assert_close(stt[1] / n, (ys ** 2).mean((0, 2, 3)), 1e-5, what="batch E[x^2]")
+    if a_out is not None:
+        assert torch.equal(a_out, ops.bn_act(xd.clone(), kw["in_scale"], kw["in_shift"], relu=True)), "the normalised operand is the in-place pass's"
+        assert_close(a_out.float().cpu(), xin.permute(0, 2, 3, 1).cpu(), 8e-3, what="normalised operand")      # (the kernels fuse the multiply-add)
+    old = ops.conv2d_nhwc(xd, wd, 3, 3, 1, 1, in_scale=kw.get("in_scale"), in_shift=kw.get("in_shift"), relu_in=form == "bn-on-load", tile=2)
+    assert_close(y.float().cpu(), old.float().cpu(), 8e-3, what="vs the tiled kernel")
+
+
+def test_3x3_resident_tile_kernel_refuses_what_it_does_not_take(gpu_lib):
+    from mhentropy_amd import ops, _lib
+    assert not ops.conv3x3_halo_supported(4, 64, 64, 64, 64)        # 64-pixel rows: the row-streaming kernel's
+    assert not ops.conv3x3_halo_supported(4, 8, 8, 512, 512)
+    assert not ops.conv3x3_halo_supported(4, 24, 16, 128, 128)      # rows per tile do not divide the image
+    assert not ops.conv3x3_halo_supported(4, 16, 16, 128, 64)
+    x = torch.zeros(4, 8, 8, 512, device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros(512, 9 * 512, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(_lib.MheError):
+        ops.conv3x3_halo(x, w)
