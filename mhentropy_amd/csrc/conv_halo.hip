@@ -13,7 +13,9 @@
 //                         to a_out once (the train step's weight-gradient operand).
 // Workgroups are persistent (one per CU, XCD-aware tile order): the next tile's first chunk is staged while this tile's last chunk multiplies.
 // One barrier per step.  32 x 32 MFMAs because their operand lanes of one LDS lane group all read the same 16-byte slot of 16 different
-// pixels: with the slot XOR-swizzled by the pixel index the shifted (tap) reads stay conflict-free for any shift.
+// pixels - 16 different image columns mod 16, on one row or two: with the slot XOR-swizzled by the halo COLUMN (pitch W + 2 is even, so the
+// column's parity is the pixel's) the shifted (tap) reads are conflict-free for any shift (keyed by the pixel index the two-row fragments
+// of the 16-wide maps were 2-way on 2 of 16 banks: 34 % of the LDS cycles).
 // Epilogue: the shared one (conv_shared.h), staged through the weight ring; statistics / gate / BatchNorm-reverse sums as everywhere.
 #include "conv_shared.h"
 
@@ -85,18 +87,19 @@ __global__ __launch_bounds__(768) void conv_halo_kernel(const Params p) {
     const bool bn = p.in_scale != nullptr;
     constexpr int abl = MHE_HALO_ABL; // tuning builds (tools/halo_abl.sh): 1 no MFMA, 2 no fragment reads, 4 no weight DMA, 8 no halo staging, 16 no output walk
     if (bn) for (int i = tid; i < C; i += 768) { aff[i] = p.in_scale[i]; aff[H_MAXC + i] = p.in_shift[i]; }
-    const int nbar_epi = (MHE_HALO_ABL & 16) ? 3 : 3 + (!DG && p.stats ? 2 : 0) + (DG && BN_EPILOGUE && p.bn_y[0] ? (p.bn_y[1] ? 4 : 2) : 0);
+    const int nbar_epi = (MHE_HALO_ABL & 16) ? 3 : 3 + (!DG && p.stats ? 2 : 0) + (DG && BN_EPILOGUE && p.bn_y[0] ? 2 : 0);
     __syncthreads();
 
     if (wave < 8) {
         // ------------------------------------------------------------------ multiply role
         const int l31 = lane & 31, kg = lane >> 5;
         const int wm = wave >> 1, wn = wave & 1;
-        int hpb[2];
+        int hpb[2], xcb[2];                            // halo pixel index / halo column of this lane's pixel of row tile mt (tap 0, 0)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int pm = wm * 64 + mt * 32 + l31;
             hpb[mt] = (pm / W + 1) * PW + (pm % W) + 1;
+            xcb[mt] = (pm % W) + 1;
         }
         const size_t wbytes = (size_t)gn * Tn * H_STAGE;
         const u4 rsw = {(unsigned)(size_t)p.w, (unsigned)((size_t)p.w >> 32) & 0xffffu, (unsigned)wbytes, 0x00020000u};
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(768) void conv_halo_kernel(const Params p) {
                         if (MHE_HALO_NOHOIST) asm volatile("" : "+v"(hp0));      // (keeps hipcc from hoisting the 18 tap addresses out of the chunk loop - and spilling them)
                         const int hp = hp0 + toff;
                         ha[mt] = hb + hp * 128;
-                        fx[mt] = (kg ^ ((hp >> 1) & 7)) << 4;
+                        fx[mt] = (kg ^ (((xcb[mt] + (tap % 3 - 1)) >> 1) & 7)) << 4;
                     }
                     auto rd = [&](int ks) __attribute__((always_inline)) {
 #pragma unroll
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(768) void conv_halo_kernel(const Params p) {
                     }
             __syncthreads();
             const int m0 = mtile * HBM;
-            if constexpr (!(abl & 16)) epilogue_store<T, HBM, HBN, 512, DG, 2>(p, ring, mtile % NSH, ntile * HBN, [&](int row) { return (long)(m0 + row); });
+            if constexpr (!(abl & 16)) epilogue_store<T, HBM, HBN, 512, DG, 2, 1>(p, ring, mtile % NSH, ntile * HBN, [&](int row) { return (long)(m0 + row); });
             __syncthreads();                                                  // the fold's reads of the ring are done: the next tile's weights may land
         }
     } else {
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(768) void conv_halo_kernel(const Params p) {
             if (e >= NP) { goff = -2; lo = 0; inner = false; return; }
             const int hp = e >> 3, slot = e & 7, hr = hp / PW, hc = hp - hr * PW;
             const int col = hc - 1;
-            lo = hp * 128 + ((slot ^ ((hp >> 1) & 7)) << 4);
+            lo = hp * 128 + ((slot ^ ((hc >> 1) & 7)) << 4);
             const bool ok = (unsigned)(r1 + hr) < (unsigned)p.H && (unsigned)col < (unsigned)W;
             goff = ok ? ((long)(rb + hr) * W + col) * C + cc * 64 + slot * 8 : -1l;
             inner = ok && hr >= 1 && hr <= R;

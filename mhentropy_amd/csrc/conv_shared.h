@@ -155,7 +155,7 @@ __device__ __forceinline__ long res_half_row(const Params &p, long m) {
 // the store half of the epilogue: the BM x BN tile lies staged in `ot` (row = pixel, 16-byte chunks XOR-swizzled by row); NTH threads
 // (tid 0 .. NTH - 1, all of them and only them) walk it.  Takes 2 workgroup barriers when p.stats is set, 2 more per BatchNorm unit of the
 // data-gradient form: waves of the workgroup that do not take part in the walk must execute as many (conv_halo.hip).
-template <typename T, int BM, int BN, int NTH, bool DG, int GROWS = (NTH >= 512 ? 4 : 2), typename PixF>
+template <typename T, int BM, int BN, int NTH, bool DG, int GROWS = (NTH >= 512 ? 4 : 2), int MAXU = 2, typename PixF>
 __device__ __forceinline__ void epilogue_store(const Params &p, unsigned char *ot, int shard, int n0, PixF pix) {
     const int tid = threadIdx.x;
     constexpr int CPR = BN * (int)sizeof(T) / 16;          // 16-byte chunks per output row
@@ -169,7 +169,7 @@ __device__ __forceinline__ void epilogue_store(const Params &p, unsigned char *o
         const bool bnr = DG && BN_EPILOGUE && p.bn_y[0] != nullptr;
         const bool plain = !p.out_scale && !p.out_shift && !rg && !p.relu_out && !mk && !bnr;
         static_assert(NTH % CPR == 0, "a thread keeps one 16-byte column chunk across its rows");
-        float bs1[DG ? 2 : 1][EPC], bs2[DG ? 2 : 1][EPC], bmu[DG ? 2 : 1][EPC], biv[DG ? 2 : 1][EPC];
+        float bs1[DG ? MAXU : 1][EPC], bs2[DG ? MAXU : 1][EPC], bmu[DG ? MAXU : 1][EPC], biv[DG ? MAXU : 1][EPC];      // (MAXU: BatchNorm units the caller can pass)
         const int cfix = tid % CPR;
         // per-channel constant of the data-gradient form (out_shift without out_scale: mhe_conv2d_masked_bias_nhwc), added before the gate
         float bsh[DG ? EPC : 1];
@@ -179,7 +179,7 @@ __device__ __forceinline__ void epilogue_store(const Params &p, unsigned char *o
         }
         if constexpr (DG) if (bnr) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < MAXU; ++u)
 #pragma unroll
                 for (int i = 0; i < EPC; ++i) {
                     const int n = n0 + cfix * EPC + i;
@@ -205,8 +205,8 @@ __device__ __forceinline__ void epilogue_store(const Params &p, unsigned char *o
         if constexpr (DG) {
             if (mk && pix(0) >= 0 && pix(BM - 1) >= 0 && n0 + BN <= p.Cout && !p.out_scale && !p.relu_out) {
                 done = true;
-                const int nbn = bnr ? (p.bn_y[1] ? 2 : 1) : 0;
-                const T *y0g = reinterpret_cast<const T *>(p.bn_y[0]), *y1g = reinterpret_cast<const T *>(p.bn_y[1]);
+                const int nbn = bnr ? (MAXU == 2 && p.bn_y[1] ? 2 : 1) : 0;
+                const T *y0g = reinterpret_cast<const T *>(p.bn_y[0]), *y1g = reinterpret_cast<const T *>(MAXU == 2 ? p.bn_y[1] : nullptr);
                 auto run = [&](auto RES, auto NB) {
                     constexpr bool HAS_RES = decltype(RES)::value;
                     constexpr int NBN = decltype(NB)::value, NJ = BM * CPR / NTH;
@@ -264,11 +264,11 @@ __device__ __forceinline__ void epilogue_store(const Params &p, unsigned char *o
                 };
                 using std::integral_constant;
                 if (rg) {
-                    if (nbn == 2) run(integral_constant<bool, true>{}, integral_constant<int, 2>{});
+                    if (nbn == 2) { if constexpr (MAXU == 2) run(integral_constant<bool, true>{}, integral_constant<int, 2>{}); }
                     else if (nbn == 1) run(integral_constant<bool, true>{}, integral_constant<int, 1>{});
                     else run(integral_constant<bool, true>{}, integral_constant<int, 0>{});
                 } else {
-                    if (nbn == 2) run(integral_constant<bool, false>{}, integral_constant<int, 2>{});
+                    if (nbn == 2) { if constexpr (MAXU == 2) run(integral_constant<bool, false>{}, integral_constant<int, 2>{}); }
                     else if (nbn == 1) run(integral_constant<bool, false>{}, integral_constant<int, 1>{});
                     else run(integral_constant<bool, false>{}, integral_constant<int, 0>{});
                 }
@@ -319,7 +319,7 @@ __device__ __forceinline__ void epilogue_store(const Params &p, unsigned char *o
                 }
                 if constexpr (DG) if (bnr) {
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
+                    for (int u = 0; u < MAXU; ++u) {
                         if (!p.bn_y[u]) continue;
                         float yv[EPC];
                         Chunk<T>::unpack(*reinterpret_cast<const uint4 *>(reinterpret_cast<const T *>(p.bn_y[u]) + off), yv);
@@ -357,7 +357,7 @@ __device__ __forceinline__ void epilogue_store(const Params &p, unsigned char *o
             // the tile's two sums to this block's statistic shard
             float *red = reinterpret_cast<float *>(lds);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < MAXU; ++u) {
                 if (!p.bn_y[u]) continue;
                 __syncthreads();
 #pragma unroll

@@ -81,6 +81,15 @@ def conv_dgrad(gy, w_dg, k, stride, pad, H, W, residual=None, mask=None, bn=None
     return ops.upsample2(half, H, W, base=residual)
 
 
+def halo_operand_index(f):
+    """standard 3x3 pack [Cout][9 Cin] (index table) -> the fragment-major stages of csrc/conv_halo.hip (ops.conv3x3_halo_pack on indices):
+    [Cout / 128][Cin / 64][9][4 channel tiles x 4 k-steps][2 k halves x 32 rows][8]"""
+    Cout, K = f.shape
+    Cin = K // 9
+    v = f.view(Cout // 128, 4, 32, 9, Cin // 64, 4, 2, 8)          # ntile, nt32, row, tap, chunk, ks, kg, e
+    return v.permute(0, 4, 3, 1, 5, 6, 2, 7).reshape(Cout, K).contiguous()
+
+
 def flow_stream_table(dim, h, bf16):
     """gather table of ONE net's fragment-ordered weight stream, as local indices into [W0 | W1 | W2]
     (obtained by running the host packer on index-valued weights)"""
@@ -126,7 +135,7 @@ class TrainStep:
         self._flatten_params()
         # derived operand layouts: two arenas (f32 / bf16), each refreshed by ONE gather per step over one concatenated index
         # table (a gather per tensor was ~340 launches of ~5 us)
-        self._arena = {dt: {"buf": torch.zeros(3 * self.n_params, device=self.dev, dtype=dt), "used": 0, "idx": [], "idx2": []}
+        self._arena = {dt: {"buf": torch.zeros(4 * self.n_params, device=self.dev, dtype=dt), "used": 0, "idx": [], "idx2": []}
                        for dt in (torch.float32, torch.bfloat16)}
         self._raw_n = 0
         self._unpack = torch.full((self.n_params,), -1, dtype=torch.int64)
@@ -142,6 +151,10 @@ class TrainStep:
         self.conv3_fold_cat = os.environ.get("MHE_CONV3_FOLD_CAT", "1") == "1"
         self.stem_bwd_two_pass = os.environ.get("MHE_STEM_BWD_TWO_PASS", "1") == "1"
         self.gate_bits = os.environ.get("MHE_GATE_BITS", "1") == "1"
+        # 3x3 / stride-1 units of layer2 / layer3: the resident-tile kernel (csrc/conv_halo.hip) - forward with conv1's BatchNorm + ReLU on its
+        # load (the normalised tensor written once on the way, no bn_act pass); their data gradients too (MHE_CONV_HALO_DG=0: the im2col kernels)
+        self.conv_halo = os.environ.get("MHE_CONV_HALO", "1") == "1"
+        self.conv_halo_dg = os.environ.get("MHE_CONV_HALO_DG", "1") == "1"
         # the stem's BatchNorm + ReLU folded into its max pool, forward and reverse (ops.maxpool3x3s2_idx / maxpool3x3s2_bwd_bn)
         self.stem_pool_fused = os.environ.get("MHE_STEM_POOL_FUSED", "1") == "1"
         self.bn_on_load_wide = os.environ.get("MHE_BN_BWD_ON_LOAD_WIDE", "1") == "1"
@@ -297,6 +310,12 @@ class TrainStep:
                 d = torch.full((Cin, _ceil(kd, bke)), -1, dtype=torch.int64)
                 d[:, :kd] = dgrad_operand_index(idx)
                 u.w_dg = self._derived(d, T)
+                # the 3x3 / stride-1 units also in the layout of the resident-tile kernel (csrc/conv_halo.hip), forward and data gradient
+                u.w_halo = u.w_dg_halo = None
+                if (KH == 3 and stride == 1 and pad == 1 and T == torch.bfloat16 and Cin % 128 == 0 and Cout % 128 == 0 and Cin <= 512 and Cout <= 512
+                        and os.environ.get("MHE_CONV_HALO", "1") == "1"):
+                    u.w_halo = self._derived(halo_operand_index(f[:, :kk]), T)
+                    u.w_dg_halo = self._derived(halo_operand_index(d[:, :kd]), T)
                 u.w_s2 = None
                 if KH == 3 and stride == 2 and pad == 1:
                     u.w_s2 = []
@@ -518,6 +537,7 @@ class TrainStep:
             self.r0 = ops.bn_act(y0, u.scale, u.shift, relu=True)
             a, self.pool_idx = ops.maxpool3x3s2_idx(self.r0)
         pending = None          # (raw conv3 output, its unit, identity tensor, downsample unit | None): a block tail not yet evaluated
+        raw_prev = None         # (conv1's raw output, its unit): normalisation left to conv2's operand load
         fuse = self.trunk.fuse_tail
         for bi, b in enumerate(self.blocks):
             us = b["u"]
@@ -535,8 +555,12 @@ class TrainStep:
                 self.blocks[bi - 1]["out"] = a
                 pending = None
                 b["a"] = a
-                h = ops.bn_act(y, u0.scale, u0.shift, relu=True)
-                b["acts"] = [h]
+                if self._halo_ok(us[1], y):      # conv2 normalises its operand on its own load and writes it out on the way
+                    h, raw_prev = None, (y, u0)
+                    b["acts"] = []
+                else:
+                    h = ops.bn_act(y, u0.scale, u0.shift, relu=True)
+                    b["acts"] = [h]
                 rest = us[1:-1]
             elif pending is not None:
                 # relu(bn3(y3) + identity) of the previous block is evaluated inside this conv1's operand load, which also
@@ -552,8 +576,12 @@ class TrainStep:
                 self.blocks[bi - 1]["out"] = a
                 pending = None
                 b["a"], b["a_bits"] = a, None
-                h = ops.bn_act(y, u0.scale, u0.shift, relu=True)
-                b["acts"] = [h]
+                if self._halo_ok(us[1], y):      # conv2 normalises its operand on its own load and writes it out on the way
+                    h, raw_prev = None, (y, u0)
+                    b["acts"] = []
+                else:
+                    h = ops.bn_act(y, u0.scale, u0.shift, relu=True)
+                    b["acts"] = [h]
                 rest = us[1:-1]
             else:
                 b["a"], b["a_bits"] = a, None
@@ -564,7 +592,16 @@ class TrainStep:
             nxt = self.blocks[bi + 1] if bi + 1 < len(self.blocks) else None
             h_by_gram = False
             for u in rest:
-                y = self._unit_fwd(u, h, pool)
+                if raw_prev is not None:
+                    y1, up = raw_prev
+                    raw_prev = None
+                    h = torch.empty_like(y1)
+                    st = pool.take(u.cout)
+                    y = ops.conv3x3_halo(y1, u.w_halo, up.scale, up.shift, relu_in=True, a_out=h, stats=st)
+                    self._bn_tape(u, h, y, st)
+                    b["acts"].append(h)
+                else:
+                    y = self._unit_fwd(u, h, pool)
                 # conv2's output of a block whose conv3 runs on Gram statistics: the Gram launch below reads it raw anyway and writes the
                 # normalised tensor on the way (no bn_act pass of its own)
                 h_by_gram = (u is us[-2] and self._foldable(b, nxt, us, y) and (self.conv3_fold and self.fuse_bn_reduce or
@@ -621,6 +658,10 @@ class TrainStep:
         return ops.bn_backward(g, a, u.y, u.mi, u.bn.weight.data, stats if stats is not None else pool.take(u.cout), u.dgamma, u.dbeta,
                                reduced=stats is not None)
 
+    def _halo_ok(self, u, x):
+        return (self.conv_halo and getattr(u, "w_halo", None) is not None and u.k == 3 and u.stride == 1 and x.dtype == torch.bfloat16
+                and ops.conv3x3_halo_supported(x.shape[0], x.shape[1], x.shape[2], u.cin, u.cout))
+
     def _foldable(self, b, nxt, us, h):
         """a bottleneck of layer1 / layer2 whose conv3 + bn3 can run on the Gram statistics of conv3's input (h: that input, or conv2's raw
         output - same shape)"""
@@ -653,6 +694,10 @@ class TrainStep:
             for c, (_, _, st) in zip(consumers, bn):
                 c.rev_stats = st
                 c.rev_dummy = c.y is None
+        if (self.conv_halo_dg and gate and residual is None and mask_bits is None and len(consumers) <= 1 and getattr(u, "w_dg_halo", None) is not None
+                and u.k == 3 and u.stride == 1 and gy.dtype == torch.bfloat16
+                and ops.conv3x3_halo_supported(gy.shape[0], gy.shape[1], gy.shape[2], u.cout, u.cin)):
+            return ops.conv3x3_halo(gy, u.w_dg_halo, mask=u.x, bn=None if bn is None else bn[0])
         return conv_dgrad(gy, u.w_dg, u.k, u.stride, u.pad, u.x.shape[1], u.x.shape[2], residual, u.x if gate else None, bn,
                           w_s2=getattr(u, "w_s2", None), res_half=res_half, coarse=coarse, mask_bits=mask_bits)
 
