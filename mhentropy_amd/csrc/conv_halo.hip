@@ -8,9 +8,10 @@
 //   multiply waves 0-7  : 64 pixels x 64 output channels each (2 x 2 v_mfma_f32_32x32x16_bf16 tiles); a STEP = one tap of one 64-channel
 //                         chunk = 16 MFMAs per wave.  They also stream the weights: fragment-major 16 KiB stages (mhe_conv3x3_halo_pack_bf16)
 //                         by LDS-DMA into a 4-stage ring, three steps ahead, behind a counted vmcnt (they issue no other VMEM in the loop);
-//   transfer waves 8-11 : the NEXT chunk's halo from global memory through registers (BatchNorm + ReLU of the producer applied on the way,
-//                         zeros at the image border), two steps in flight, into the other halo buffer; optionally the normalised tensor out
-//                         to a_out once (the train step's weight-gradient operand).
+//   transfer waves 8-11 : the NEXT chunk's halo from global memory through registers - all of a chunk's pieces in flight from the first step
+//                         of the chunk before, written from its fourth step on (BatchNorm + ReLU of the producer applied on the way, zeros at
+//                         the image border) into the other halo buffer; optionally the normalised tensor out to a_out once (the train
+//                         step's weight-gradient operand).
 // Workgroups are persistent (one per CU, XCD-aware tile order): the next tile's first chunk is staged while this tile's last chunk multiplies.
 // One barrier per step.  32 x 32 MFMAs because their operand lanes of one LDS lane group all read the same 16-byte slot of 16 different
 // pixels - 16 different image columns mod 16, on one row or two: with the slot XOR-swizzled by the halo COLUMN (pitch W + 2 is even, so the
@@ -21,24 +22,6 @@
 
 #ifndef MHE_HALO_ABL
 #define MHE_HALO_ABL 0
-#endif
-#ifndef MHE_HALO_STAGGER
-#define MHE_HALO_STAGGER 0
-#endif
-#ifndef MHE_HALO_PRIO
-#define MHE_HALO_PRIO 0
-#endif
-#ifndef MHE_HALO_FENCE
-#define MHE_HALO_FENCE 1
-#endif
-#ifndef MHE_HALO_NOHOIST
-#define MHE_HALO_NOHOIST 1
-#endif
-#ifndef MHE_HALO_TTOP
-#define MHE_HALO_TTOP 0
-#endif
-#ifndef MHE_HALO_FORM
-#define MHE_HALO_FORM 0      // 0: fragments read k-step by k-step (4 at a time), 1: all 16 of a step up front, 2: k-step by k-step, one ahead
 #endif
 
 namespace mhe { namespace conv {
@@ -125,27 +108,24 @@ __global__ __launch_bounds__(768) void conv_halo_kernel(const Params p) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
             if constexpr (!(abl & 4)) { issue(0); issue(1); issue(2); }
-            if (MHE_HALO_STAGGER) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // this wave's share of stage 0 has landed
-            if (!MHE_HALO_TTOP) __builtin_amdgcn_s_barrier();                 // ... everyone's, and the first chunk's halo
+            __builtin_amdgcn_s_barrier();                                     // (pairs with the transfer waves' first barrier of the tile)
             __builtin_amdgcn_sched_barrier(0);
-            // A step, as in conv_p8.hip: LOAD part = the 16 fragments of step tau (stage and halo published by the barrier before), the DMA of
-            // stage tau + 3 (its buffer was read during step tau - 1, i.e. before that barrier), the counted wait for this wave's share of stage
-            // tau + 1; then 16 MFMAs.  Waves 0-3 run  load, MFMA, barrier;  waves 4-7  load, barrier, MFMA: on every SIMD one wave multiplies
-            // while its partner loads (same order for both: 88 us; the compiler's own interleaving of reads and MFMAs waited on every read)
+            // A step: this wave's share of stage tau has landed (issued three steps ago; tau + 1, tau + 2 stay in flight); barrier (everyone's
+            // share, and at a chunk's first step its halo); DMA of stage tau + 3 into the buffer read during step tau - 1; then the 16 fragment
+            // reads and 16 MFMAs, k-step by k-step, interleaved by the compiler.  Measured alternatives, all slower (EXPERIMENTS.md): all 16
+            // reads up front behind counted waits (+10 %: the eight waves' reads arrive at the LDS together and nothing multiplies meanwhile);
+            // conv_p8.hip's staggered phases (waves 0-3 load, MFMA, barrier; waves 4-7 load, barrier, MFMA: +5 % - reading before the barrier
+            // shortens the DMA's lead from three steps to two); s_setprio around the MFMAs (equal).
             for (int c = 0; c < nC; ++c) {
                 const unsigned char *hb = halo0 + ((gc + c) & 1) * HALO;
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const int tau = c * 9 + tap;
-                    if (!MHE_HALO_STAGGER) {
-                        // plain order: this wave's share of stage tau has landed (issued three steps ago; tau + 1, tau + 2 in flight); barrier;
-                        // DMA of stage tau + 3 into the buffer read during step tau - 1; reads; MFMAs
-                        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                        __builtin_amdgcn_s_barrier();
-                        __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (!(abl & 4)) issue(tau + 3);
-                    }
-                    uint4 fb[4][2], fa[4][2];
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (!(abl & 4)) issue(tau + 3);
+                    if constexpr (abl & 2) continue;
                     const unsigned char *ws = ring + ((c + tap) & 3) * H_STAGE + (wn * 8) * 1024 + lane * 16;
                     const int toff = (tap / 3 - 1) * PW + (tap % 3 - 1);
                     const unsigned char *ha[2];
@@ -153,70 +133,26 @@ __global__ __launch_bounds__(768) void conv_halo_kernel(const Params p) {
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
                         int hp0 = hpb[mt];
-                        if (MHE_HALO_NOHOIST) asm volatile("" : "+v"(hp0));      // (keeps hipcc from hoisting the 18 tap addresses out of the chunk loop - and spilling them)
+                        asm volatile("" : "+v"(hp0));          // (keeps hipcc from hoisting the 18 tap addresses out of the chunk loop - and spilling them)
                         const int hp = hp0 + toff;
                         ha[mt] = hb + hp * 128;
                         fx[mt] = (kg ^ (((xcb[mt] + (tap % 3 - 1)) >> 1) & 7)) << 4;
                     }
-                    auto rd = [&](int ks) __attribute__((always_inline)) {
 #pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) fb[ks][nt] = *reinterpret_cast<const uint4 *>(ws + (nt * 4 + ks) * 1024);
+                    for (int ks = 0; ks < 4; ++ks) {
+                        uint4 fb[2], fa[2];
 #pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) fa[ks][mt] = *reinterpret_cast<const uint4 *>(ha[mt] + (fx[mt] ^ (ks << 5)));
-                    };
-                    auto mm = [&](int ks) __attribute__((always_inline)) {
+                        for (int nt = 0; nt < 2; ++nt) fb[nt] = *reinterpret_cast<const uint4 *>(ws + (nt * 4 + ks) * 1024);
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) fa[mt] = *reinterpret_cast<const uint4 *>(ha[mt] + (fx[mt] ^ (ks << 5)));
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                             for (int mt = 0; mt < 2; ++mt)
-                                if constexpr (abl & 1) acc[nt][mt][0] += __uint_as_float((fb[ks][nt].x ^ fa[ks][mt].x) + (fb[ks][nt].w ^ fa[ks][mt].w));
-                                else acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, fb[ks][nt]),
-                                                                                           __builtin_bit_cast(bf8, fa[ks][mt]), acc[nt][mt], 0, 0, 0);
-                    };
-                    if constexpr (MHE_HALO_FORM == 0 && !MHE_HALO_STAGGER) {
-                        if constexpr (!(abl & 2)) {
-#pragma unroll
-                            for (int ks = 0; ks < 4; ++ks) { rd(ks); mm(ks); }
-                        }
-                        continue;
+                                if constexpr (abl & 1) acc[nt][mt][0] += __uint_as_float((fb[nt].x ^ fa[mt].x) + (fb[nt].w ^ fa[mt].w));
+                                else acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, fb[nt]), __builtin_bit_cast(bf8, fa[mt]),
+                                                                                           acc[nt][mt], 0, 0, 0);
                     }
-                    if constexpr (MHE_HALO_FORM == 2 && !MHE_HALO_STAGGER) {
-                        if constexpr (!(abl & 2)) {
-                            rd(0);
-#pragma unroll
-                            for (int ks = 0; ks < 4; ++ks) {
-                                if (ks < 3) rd(ks + 1);
-                                __builtin_amdgcn_sched_barrier(0);
-                                mm(ks);
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
-                        }
-                        continue;
-                    }
-                    if constexpr (!(abl & 2)) {
-#pragma unroll
-                        for (int ks = 0; ks < 4; ++ks) rd(ks);
-                    }
-                    if (MHE_HALO_FENCE) __builtin_amdgcn_sched_barrier(0);
-                    if (MHE_HALO_STAGGER) {
-                        if constexpr (!(abl & 4)) issue(tau + 3);
-                        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (wave >= 4) {
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            __builtin_amdgcn_s_barrier();
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (!(abl & 2)) {
-                        if (MHE_HALO_PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                        for (int ks = 0; ks < 4; ++ks) mm(ks);
-                        if (MHE_HALO_PRIO) __builtin_amdgcn_s_setprio(0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (MHE_HALO_STAGGER && wave < 4) __builtin_amdgcn_s_barrier();
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             gc += nC;
@@ -249,7 +185,9 @@ __global__ __launch_bounds__(768) void conv_halo_kernel(const Params p) {
         // piece j of this lane: halo pixel / slot -> global element offset (or -1: border zeros; -2: no such piece), LDS byte offset
         // (rb = (image * H + first halo row), r1 = that halo row within the image: both may be -1 at the top of an image)
         auto locate = [&](int j, int rb, int r1, int cc, long &goff, int &lo, bool &inner) __attribute__((always_inline)) {
-            const int e = tr + 256 * j;
+            int trv = tr;
+            asm volatile("" : "+v"(trv));              // (recomputed where it is used: hoisted out of the tile loop these 11 x 4 values spill)
+            const int e = trv + 256 * j;
             if (e >= NP) { goff = -2; lo = 0; inner = false; return; }
             const int hp = e >> 3, slot = e & 7, hr = hp / PW, hc = hp - hr * PW;
             const int col = hc - 1;
@@ -322,31 +260,26 @@ __global__ __launch_bounds__(768) void conv_halo_kernel(const Params p) {
                 unsigned char *hb = halo0 + ((gc + c + 1) & 1) * HALO;
                 T *ag = p.a_out && nt2 == 0 ? reinterpret_cast<T *>(p.a_out) : nullptr;
                 const int r1 = (mt2 % TPI) * R - 1, rb = (mt2 / TPI) * p.H + r1;
-                if (c == 0 && !MHE_HALO_TTOP) {                               // the tile's first barrier: stage 0 and this chunk's halo are published
+                if (c == 0) {                                                 // the tile's first barrier
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int s = 0; s < 9; ++s) {
-                    if (MHE_HALO_TTOP) {
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (step 0: the chunk about to be multiplied is written)
-                        __builtin_amdgcn_s_barrier();
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
                     if (have && !(abl & 8)) {
                         if (s == 0) { load_all(rb, r1, c2); if (bn) affine_of(c2); }
                         if (s >= 3) store2(s - 3, rb, r1, c2, hb, ag);
                     }
-                    if (!MHE_HALO_TTOP) {
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (step 8: the next chunk is written)
-                        __builtin_amdgcn_s_barrier();
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (step 8: the next chunk is written - the barrier publishes it)
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             gc += nC;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // (the output walk by THIS role from registers while the next tile multiplies - the walk is 13 us of write-rate-bound time in which
+            // no CU multiplies - was slower: 111 against 101 us; these waves then arrive late at the next tile's first barriers.  EXPERIMENTS.md)
             for (int i = 0; i < nbar_epi; ++i) __builtin_amdgcn_s_barrier();
         }
     }

@@ -2,7 +2,7 @@
 # 8 no halo staging, 16 no output walk) as stand-alone libraries under mhentropy_amd/csrc/_abl/ (git-ignored; they travel with gpurun):
 #   bash tools/halo_abl_build.sh "0 2 6 10 18 30"
 mkdir -p mhentropy_amd/csrc/_abl
-# a variant may carry other switches: "0,-DMHE_HALO_STAGGER=1,-DMHE_HALO_PRIO=1" (the library is named after the whole string)
+# a variant may carry other -D switches after commas: "0,-DNAME=1" (the library is named after the whole string)
 for v in $1; do
   a=${v%%,*}; rest=${v#$a}; rest=${rest//,/ }
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Iinclude -Imhentropy_amd/csrc -DMHE_HALO_ABL=$a $rest \
