@@ -480,6 +480,11 @@ int mhe_bottleneck_tail_bits_nhwc(const mhe_conv_desc *d, int Cb, const void *y2
 int mhe_conv2d_masked_bias_nhwc(const mhe_conv_desc *d, const void *x, const void *xcat, int cin2, const void *w, void *y,
                                 const void *residual, const void *mask, const float *bias, const void *bn_y0,
                                 const float *bn_mean_invstd0, float *bn_stats0, void *stream);
+/* y = [x | xcat] w^T + bias (+ residual): a bf16 1x1 / stride-1 product whose K range continues on a second tensor (w [Cout][Cin + cin2]),
+ * ungated - the data gradient of a shortcut convolution whose BatchNorm reverse runs on Gram statistics (mhe_conv3_bn_fold below; torchvision
+ * Bottleneck.downsample, hand/network.py:54-61).  bias, residual optional. */
+int mhe_conv1x1_cat_bias_nhwc(const mhe_conv_desc *d, const void *x, const void *xcat, int cin2, const void *w, void *y, const void *residual,
+                              const float *bias, void *stream);
 /* Reverse of conv3 (1x1, C outputs, Cb = 64 | 128 inputs) + train-mode BatchNorm without the convolution's raw output (csrc/conv_fold.hip).
  * In: D [C][Cb] = g^T A accumulated by a weight-gradient launch on the gated gradient g itself (cleared on the way out), w_bf16 [C][Cb] the
  * forward's weights, gram_totals = the f64 totals of mhe_conv1x1_gram_nhwc on conv3's input ([Cb][Cb] Gram matrix, then [Cb] column sums),

@@ -646,8 +646,11 @@ static void launch_mode(const Params &p, hipStream_t s) {
         }
     } else if (p.in_scale) {
         hipLaunchKernelGGL((conv_kernel<T, BM, BN, WM, WN, FAST, 1>), grid, block, 0, s, p);
-    } else if (p.mask && p.xcat) {
-        if constexpr (FAST && BM == 128 && sizeof(T) == 2) hipLaunchKernelGGL((conv_kernel<T, BM, BN, WM, WN, true, 3, true>), grid, block, 0, s, p);
+    } else if (p.xcat) {
+        if constexpr (FAST && BM == 128 && sizeof(T) == 2) {
+            if (p.mask) hipLaunchKernelGGL((conv_kernel<T, BM, BN, WM, WN, true, 3, true>), grid, block, 0, s, p);
+            else hipLaunchKernelGGL((conv_kernel<T, BM, BN, WM, WN, true, 3>), grid, block, 0, s, p);       // (ungated: a shortcut's data gradient)
+        }
     } else if (p.mask) {
         hipLaunchKernelGGL((conv_kernel<T, BM, BN, WM, WN, FAST, 0, true>), grid, block, 0, s, p);
     } else {
@@ -674,7 +677,7 @@ static int choose_tile(const Params &p, bool fast, bool bf16) {
     static const int env_force = getenv("MHE_CONV_TILE") ? atoi(getenv("MHE_CONV_TILE")) : -1;    // tuning knob
     const int force = p.force >= 0 ? p.force : env_force;
     // data-gradient form with a per-channel constant (mhe_conv2d_masked_bias_nhwc): the kernels with the shared epilogue only
-    if (p.mask && p.out_shift) return force == 0 || (force < 0 && p.Cout <= 64) ? 0 : 1;
+    if ((p.mask && p.out_shift) || p.xcat) return force == 0 || (force < 0 && p.Cout <= 64) ? 0 : 1;
     static const int env_stream = getenv("MHE_CONV_STREAM") ? atoi(getenv("MHE_CONV_STREAM")) : 1;
     if (bf16 && (force == 8 || (force < 0 && env_stream)) && stream_supports(p)) return 8;
     if (bf16 && (force == 9 || (force < 0 && env_stream)) && stream3_supports(p)) return 9;
@@ -789,6 +792,15 @@ extern "C" int mhe_conv1x1_residual_in_nhwc(const mhe_conv_desc *d, const void *
     MHE_REQUIRE(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0, "mhe_conv1x1_residual_in_nhwc: 1x1 stride-1 only");
     MHE_REQUIRE((x2_scale == nullptr) == (x2_shift == nullptr), "mhe_conv1x1_residual_in_nhwc: x2_scale/x2_shift must come together");
     return conv_entry(d, x, w, y, in_scale, in_shift, nullptr, nullptr, nullptr, stats, x2, x2_scale, x2_shift, a_out, stream);
+}
+
+extern "C" int mhe_conv1x1_cat_bias_nhwc(const mhe_conv_desc *d, const void *x, const void *xcat, int cin2, const void *w, void *y, const void *residual,
+                                         const float *bias, void *stream) {
+    MHE_REQUIRE(d && xcat && d->dtype == MHE_BF16 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && cin2 > 0 && cin2 % 64 == 0 && d->Cin % 64 == 0,
+                "mhe_conv1x1_cat_bias_nhwc: a bf16 1x1 stride-1 launch on two operand tensors with Cin and cin2 multiples of 64");
+    MHE_REQUIRE(d->tile == 0 || d->tile == 1 || d->tile == 2, "mhe_conv1x1_cat_bias_nhwc: 128-row register-staged tiles only (tile 0, 1 or 2)");
+    return conv_entry(d, x, w, y, nullptr, nullptr, nullptr, bias, residual, nullptr, nullptr, nullptr, nullptr, nullptr, stream, nullptr, nullptr, nullptr,
+                      nullptr, xcat, cin2);
 }
 
 extern "C" int mhe_conv1x1_residual_in_masked_nhwc(const mhe_conv_desc *d, const void *x, const void *x2, const void *w, void *y,

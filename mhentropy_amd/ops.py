@@ -397,6 +397,16 @@ def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in
         return y
     if bn:
         raise ValueError("conv2d_nhwc: bn= needs mask= (data-gradient form)")
+    if xcat is not None:                 # ungated product on two operand tensors (+ out_shift as a per-channel constant, + residual)
+        if in_scale is not None or out_scale is not None or stats is not None or relu_in or relu_out:
+            raise ValueError("conv2d_nhwc: xcat= without mask= takes out_shift and residual only")
+        cin2 = xcat.shape[-1]
+        _chk(xcat, dt, "conv.xcat", (B, H, W, cin2))
+        if tuple(w.shape) != (Cout, Cin + cin2):
+            raise ValueError(f"conv2d_nhwc: xcat= needs w [{Cout}, {Cin + cin2}], got {tuple(w.shape)}")
+        check(_lib.lib().mhe_conv1x1_cat_bias_nhwc(C.byref(d), _ptr(x), _ptr(xcat), int(cin2), _ptr(w), _ptr(y), _ptr(residual), _ptr(out_shift), _stream()),
+              "mhe_conv1x1_cat_bias_nhwc")
+        return y
     if TIMING:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()

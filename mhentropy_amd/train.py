@@ -153,6 +153,7 @@ class TrainStep:
         self.gate_bits = os.environ.get("MHE_GATE_BITS", "1") == "1"
         # 3x3 / stride-1 units of layer2 / layer3: the resident-tile kernel (csrc/conv_halo.hip) - forward with conv1's BatchNorm + ReLU on its
         # load (the normalised tensor written once on the way, no bn_act pass); their data gradients too (MHE_CONV_HALO_DG=0: the im2col kernels)
+        self.shortcut_fold = os.environ.get("MHE_SHORTCUT_FOLD", "1") == "1"
         self.conv_halo = os.environ.get("MHE_CONV_HALO", "1") == "1"
         self.conv_halo_dg = os.environ.get("MHE_CONV_HALO_DG", "1") == "1"
         # the stem's BatchNorm + ReLU folded into its max pool, forward and reverse (ops.maxpool3x3s2_idx / maxpool3x3s2_bwd_bn)
@@ -636,7 +637,7 @@ class TrainStep:
             else:
                 yl = self._unit_fwd(ul, h, pool)
             ud = b["ud"]
-            yd = self._unit_fwd(ud, b["a"], pool) if ud is not None else None
+            yd = self._shortcut_fwd(bi, b, ud, pool) if ud is not None else None
             if recompute:
                 pending = ("re", us[-2].y, (us[-2].scale, us[-2].shift), ul, yd if ud is not None else b["a"], ud)
                 continue
@@ -657,6 +658,29 @@ class TrainStep:
         reverse sums already accumulated by the producer's epilogue (then only finalize + apply run here)."""
         return ops.bn_backward(g, a, u.y, u.mi, u.bn.weight.data, stats if stats is not None else pool.take(u.cout), u.dgamma, u.dbeta,
                                reduced=stats is not None)
+
+    def _shortcut_fwd(self, bi, b, ud, pool):
+        """the block's shortcut convolution + its BatchNorm's batch statistics.  Layer1's (1x1, stride 1, 64 input channels): the statistics
+        from the Gram matrix of the block's input, whose totals stay for the reverse pass - there the BatchNorm reverse then needs neither the
+        shortcut's raw output nor a pass of its own over three block-wide tensors (csrc/conv_fold.hip, as for conv3; MHE_SHORTCUT_FOLD=0: as the others)"""
+        a = b["a"]
+        ud.fold_rev = False
+        if not (self.shortcut_fold and self.conv3_fold and self.fuse_bn_reduce and ud.k == 1 and ud.stride == 1 and ud.cin in (64, 128)
+                and a.dtype == torch.bfloat16 and (a.numel() // ud.cin) % 128 == 0 and bi + 1 < len(self.blocks) and self.blocks[bi + 1]["ud"] is None
+                and self.blocks[bi + 1]["u"][0].k == 1):
+            return self._unit_fwd(ud, a, pool)
+        tot = self._ws.get(("gram_tot_ds", bi))
+        if tot is None:
+            tot = self._ws[("gram_tot_ds", bi)] = ops.gram_workspace(ud.cin, self.dev)
+            self._ws["ones_c"] = torch.ones(4096, device=self.dev)
+        bn = ud.bn
+        ud.scale, ud.shift, ud.mi = ops.conv1x1_gram_bn(a, self._ws["ones_c"][:ud.cin], self._zeros_c[:ud.cin], ud.w_fwd, bn.weight.data, bn.bias.data,
+                                                        bn.running_mean, bn.running_var, (pool.gram(ud.cin)[0], tot), BN_MOMENTUM, BN_EPS,
+                                                        num_batches_tracked=bn.num_batches_tracked, want_mean_invstd=True)
+        ud.gram_tot, ud.fold_rev = tot, True
+        ud.x = a
+        ud.y = ops.conv2d_nhwc(a, ud.w_fwd, 1, 1, 1, 0)
+        return ud.y
 
     def _halo_ok(self, u, x):
         return (self.conv_halo and getattr(u, "w_halo", None) is not None and u.k == 3 and u.stride == 1 and x.dtype == torch.bfloat16
@@ -690,10 +714,11 @@ class TrainStep:
             # the BatchNorm units that consume this gradient: their reverse sums are accumulated by this kernel's epilogue
             # (a unit whose raw output was never written and whose reverse runs on the Gram statistics, csrc/conv_fold.hip, needs sum g only:
             # the gate tensor - same shape, read by this epilogue anyway - stands in for its output; the second sum is not used)
-            bn = [(c.y if c.y is not None else u.x, c.mi, pool.take(c.cout)) for c in consumers]
-            for c, (_, _, st) in zip(consumers, bn):
+            dummy = [c.y is None or getattr(c, "fold_rev", False) for c in consumers]
+            bn = [(u.x if dm else c.y, c.mi, pool.take(c.cout)) for c, dm in zip(consumers, dummy)]
+            for c, (_, _, st), dm in zip(consumers, bn, dummy):
                 c.rev_stats = st
-                c.rev_dummy = c.y is None
+                c.rev_dummy = dm
         if (self.conv_halo_dg and gate and residual is None and mask_bits is None and len(consumers) <= 1 and getattr(u, "w_dg_halo", None) is not None
                 and u.k == 3 and u.stride == 1 and gy.dtype == torch.bfloat16
                 and ops.conv3x3_halo_supported(gy.shape[0], gy.shape[1], gy.shape[2], u.cout, u.cin)):
@@ -704,6 +729,7 @@ class TrainStep:
     def _trunk_backward(self, g_f):
         pool = resnet._StatsPool(self.dev, channels=65536)
         self.n_fold = 0                 # blocks whose conv3 + bn3 were reversed on the Gram statistics in this pass
+        self.n_fold_ds = 0              # ... and shortcuts
         B, Hh, Ww, Cc = self.a_last.shape
         # g is always the gradient w.r.t. the block output's PRE-ReLU value: the gate is applied where g is produced
         g = ops.avgpool_bwd(g_f, Hh * Ww, self.T, mask=self.a_last.view(B, Hh * Ww, Cc)).view(B, Hh, Ww, Cc)
@@ -747,7 +773,24 @@ class TrainStep:
                 gy = None
             else:
                 gy = self._bn_bwd(ul, g, None, pool, stats=getattr(ul, "rev_stats", None))
-            if ud is not None:
+            ud_fold = (ud is not None and getattr(ud, "fold_rev", False) and getattr(ud, "rev_stats", None) is not None
+                       and getattr(ud, "rev_dummy", False))
+            if ud_fold:
+                # the shortcut's BatchNorm reverse on the Gram statistics of the block's input: D = g^T a by a weight-gradient launch on g itself,
+                # dW / dgamma / dbeta and the weights [(k2 W)^T | W^T diag(k1) W] of ONE ungated data-gradient launch on [g | a] out of the fold
+                Cn, Cb = ud.cout, ud.cin
+                D = self._ws.get(("foldD", Cn, Cb))
+                if D is None:
+                    D = self._ws[("foldD", Cn, Cb)] = torch.zeros(Cn, Cb, device=self.dev)
+                ops.conv_wgrad(ud.x, g, 1, 1, 1, 0, D)
+                # (buffers of its own: conv3's fold of this block has run already, its data-gradient launch - further down - has not)
+                wcat, c0 = self._buf(f"fold_ds_wcat{Cn}", (Cb, Cn + Cb), torch.bfloat16), self._buf(f"fold_ds_c0{Cb}", (Cb,))
+                ops.conv3_bn_fold(D, ud.w_fwd, ud.gram_tot, ud.rev_stats, ud.bn.weight.data, ud.mi, g.numel() // Cn, ud.dgamma, ud.dbeta, ud.dw,
+                                  wcat, None, c0, self._buf(f"fold_ds_coef{Cn}", (2 * Cn,)))
+                self.n_fold_ds += 1
+                skip = ops.conv2d_nhwc(g, wcat, 1, 1, 1, 0, xcat=ud.x, out_shift=c0)
+                half_skip = False
+            elif ud is not None:
                 gyd = self._bn_bwd(ud, g, None, pool, stats=getattr(ud, "rev_stats", None))
                 self._wgrad(ud, gyd)
                 # summed with the main branch before the gate; a stride-2 shortcut's gradient stays on its coarse grid and the main

@@ -775,6 +775,7 @@ def test_conv3_reverse_on_gram_statistics_equals_the_pass_that_reads_y3(gpu_lib)
     z0 = _dev(synth.noise(9, N * B))
     ts = TrainStep(model)
     ts.train_recompute, ts.conv3_fold = True, True
+    ts.shortcut_fold = False        # (layer1's shortcut on Gram statistics has a test of its own below; its run-to-run spread reaches the stem undamped)
     ts.forward(x, y, noise=z0, N=N)
     res = {}
     for mode, fold in (("B", False), ("C", True), ("C2", True)):
@@ -804,3 +805,50 @@ def test_conv3_reverse_on_gram_statistics_equals_the_pass_that_reads_y3(gpu_lib)
     assert again[0] < 8e-2, again
     assert max(rel(gC[n], gB[n]) for n in trunk) < 2e-1
     assert rel(gC2[pre + "layer2.3.conv3.weight"], gC[pre + "layer2.3.conv3.weight"]) < 1e-5          # the fold's accumulator cleans itself
+
+
+def test_shortcut_reverse_on_gram_statistics_equals_the_pass_over_its_output(gpu_lib):
+    """layer1's shortcut (1x1, 64 -> 256, stride 1) in the bf16 train step: its BatchNorm's batch statistics come from the Gram matrix of the
+    block's input, and the reverse pass runs conv + BatchNorm on those statistics (csrc/conv_fold.hip) - no apply pass over the gradient,
+    the shortcut's raw output and the result, one ungated data-gradient launch on [g | a].  Two reverse passes over ONE forward tape, the
+    second with the fold switched off for that unit (its raw output exists: the forward's tail reads it)."""
+    from mhentropy_amd import harness
+    from mhentropy_amd.train import TrainStep
+    torch.manual_seed(5)
+    model = harness.build_mhent(backbone="resnet50", h_dims=(64, 64), num_steps=1, tables=synth.mano_tables(0), compute_dtype=torch.bfloat16).cuda().train()
+    B, N = 8, 4
+    xn, yn = synth.batch(11, B, image_size=128)
+    x, y = _dev(xn), {k: _dev(v) for k, v in yn.items()}
+    z0 = _dev(synth.noise(11, N * B))
+    ts = TrainStep(model)
+    assert ts.shortcut_fold
+    ts.forward(x, y, noise=z0, N=N)
+    ud = ts.blocks[0]["ud"]
+    assert ud.fold_rev and ud.y is not None
+    res = {}
+    for mode, fold in (("pass", False), ("fold", True), ("fold again", True)):
+        ud.fold_rev = fold
+        ts.backward()
+        res[mode] = ({n: ts.grad_of(p).clone() for n, p in model.named_parameters()}, ts.n_fold_ds)
+    assert [res[m][1] for m in ("pass", "fold", "fold again")] == [0, 1, 1]
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+    gP, gF, gF2 = res["pass"][0], res["fold"][0], res["fold again"][0]
+    pre = "feat_extractor.res."
+    # upstream of the shortcut nothing changes but the run-to-run spread of the reverse pass itself (f32 atomics of the small weight gradients,
+    # amplified by the train-mode BatchNorm layers in between: measured below as fold against fold)
+    for n in ("layer2.0.downsample.0.weight", "layer1.1.conv1.weight", "layer1.0.conv3.weight"):
+        spread = rel(gF2[pre + n], gF[pre + n])
+        print(f"upstream {n}: fold vs pass {rel(gF[pre + n], gP[pre + n]):.2e}, fold vs fold {spread:.2e}")
+        assert rel(gF[pre + n], gP[pre + n]) <= 3 * spread + 1e-3, (n, rel(gF[pre + n], gP[pre + n]), spread)
+    for n, tol in (("layer1.0.downsample.1.bias", 1e-3), ("layer1.0.downsample.0.weight", 5e-3), ("layer1.0.downsample.1.weight", 8e-3)):
+        spread = rel(gF2[pre + n], gF[pre + n])
+        print(f"shortcut {n}: fold vs pass {rel(gF[pre + n], gP[pre + n]):.2e}, fold vs fold {spread:.2e}")
+        assert rel(gF[pre + n], gP[pre + n]) <= tol + 3 * spread, (n, rel(gF[pre + n], gP[pre + n]), spread)
+    # behind it: the stem (through the max pool's reverse) - the band of the other whole-trunk comparisons
+    # (the fold's weights [(k2 W)^T | S] are rounded to bf16 from sums whose split-K atomics change a last bit from run to run: the whole
+    # shortcut gradient moves by a bf16 ulp, and the stem's train-mode BatchNorm on 8 images amplifies that - the fold against itself
+    # spreads as far as the fold against the pass)
+    for n in ("conv1.weight", "bn1.weight", "bn1.bias"):
+        spread = rel(gF2[pre + n], gF[pre + n])
+        print(f"stem {n}: fold vs pass {rel(gF[pre + n], gP[pre + n]):.2e}, fold vs fold {spread:.2e}")
+        assert rel(gF[pre + n], gP[pre + n]) < max(2e-1, 3 * spread), (n, rel(gF[pre + n], gP[pre + n]), spread)
