@@ -506,6 +506,12 @@ int mhe_conv3x3_halo_pack_bf16(const void *w, void *w_halo, int Cout, int Cin, v
 int mhe_conv3x3_halo_nhwc(int B, int H, int W, int Cin, int Cout, const void *x, const void *w_halo, void *y, const float *in_scale,
                           const float *in_shift, int relu_in, void *a_out, float *stats, const void *residual, const void *mask,
                           const void *bn_y0, const float *bn_mean_invstd0, float *bn_stats0, void *stream);
+/* Data-gradient form of mhe_conv3x3_halo_nhwc with the BatchNorm reverse of the convolution's own output gradient on the operand load:
+ * operand = k2 g + k1 y_raw + k0 per channel (coef = k2 | k1 | k0 [3][Cin], mhe_bn_bwd_finalize; the arithmetic of mhe_bn_bwd_apply_nhwc), written
+ * once to gy_out (optional) for the weight gradient; gx = (conv(operand, w_halo) + residual) [mask > 0], BatchNorm-reverse sums of one consumer. */
+int mhe_conv3x3_halo_dgrad_bn_nhwc(int B, int H, int W, int Cin, int Cout, const void *g, const void *y_raw, const float *coef, const void *w_halo,
+                                   void *gx, void *gy_out, const void *residual, const void *mask, const void *bn_y0,
+                                   const float *bn_mean_invstd0, float *bn_stats0, void *stream);
 int mhe_flow_reverse_chain_supported(int R, int B, int dim, int hidden, int ncoup);
 /* mhe_flow_couplings_bf16 / _emit on the fragment-streaming skeleton (csrc/flow_fwd.hip): hidden 512, a multiple of 64 hypotheses per
  * image (R % (64 B) == 0; a workgroup = 64 rows of one image), at most 32 couplings.  Same results as mhe_flow_couplings_bf16 up to the

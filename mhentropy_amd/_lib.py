@@ -103,6 +103,7 @@ SIGNATURES = {
     "mhe_conv2d_masked_bias_nhwc": (_i, [_p, _p, _p, _i] + [_p] * 9),
     "mhe_conv3x3_halo_supported": (_i, [_i] * 5),
     "mhe_conv3x3_halo_pack_bf16": (_i, [_p, _p, _i, _i, _p]),
+    "mhe_conv3x3_halo_dgrad_bn_nhwc": (_i, [_i] * 5 + [_p] * 12),
     "mhe_conv3x3_halo_nhwc": (_i, [_i] * 5 + [_p] * 5 + [_i] + [_p] * 8),
     "mhe_conv1x1_cat_bias_nhwc": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p]),
     "mhe_conv3_bn_fold": (_i, [_p] * 6 + [_f] + [_p] * 4 + [_i, _p, _i] + [_p] * 2 + [_i, _i, _p]),

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(768) void conv_halo_kernel(const Params p) {
     constexpr int R = G::R, PW = G::PW, HALO = G::HALO, NP = G::NP, NJ = G::NJ;
     static_assert(NJ <= 12, "six load steps of two pieces");
     __shared__ uint4 lds[(H_RING * H_STAGE + 2 * HALO) / 16];
-    __shared__ float aff[2 * H_MAXC];
+    __shared__ float aff[3 * H_MAXC];                  // scale | shift of the producer's BatchNorm, or k2 | k1 | k0 of the BatchNorm reverse on the load
     unsigned char *const ring = reinterpret_cast<unsigned char *>(lds), *const halo0 = ring + H_RING * H_STAGE;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int C = p.Cin, nC = C / 64, Tn = nC * 9;
@@ -68,6 +68,8 @@ __global__ __launch_bounds__(768) void conv_halo_kernel(const Params p) {
         } else { mt = L % gm; nt = L / gm; }
     };
     const bool bn = p.in_scale != nullptr;
+    const bool rev = DG && p.rev_coef != nullptr;      // operand = k2 x + k1 x2 + k0 (bn_bwd_apply_kernel's arithmetic, trunk_bwd.hip)
+    if (rev) for (int i = tid; i < C; i += 768) { aff[i] = p.rev_coef[i]; aff[H_MAXC + i] = p.rev_coef[C + i]; aff[2 * H_MAXC + i] = p.rev_coef[2 * C + i]; }
     constexpr int abl = MHE_HALO_ABL; // tuning builds (tools/halo_abl.sh): 1 no MFMA, 2 no fragment reads, 4 no weight DMA, 8 no halo staging, 16 no output walk
     if (bn) for (int i = tid; i < C; i += 768) { aff[i] = p.in_scale[i]; aff[H_MAXC + i] = p.in_shift[i]; }
     const int nbar_epi = (MHE_HALO_ABL & 16) ? 3 : 3 + (!DG && p.stats ? 2 : 0) + (DG && BN_EPILOGUE && p.bn_y[0] ? 2 : 0);
@@ -199,12 +201,17 @@ __global__ __launch_bounds__(768) void conv_halo_kernel(const Params p) {
         // a chunk's pieces are all loaded at step 0 of the chunk before (NJ x 16 B per lane in flight) and written, two per step, from step 3 on:
         // three steps cover the load latency (with two pieces loaded per step and written two steps later the transfer waves set the pace:
         // 85 us against 51 without any multiply work - tools/halo_abl.sh)
-        uint4 regs[NJ];
+        uint4 regs[NJ], regs2[DG ? NJ : 1];
+        const T *x2g = reinterpret_cast<const T *>(p.x2);
         const int slot8 = (tr & 7) * 8;                // every piece of this lane is the same 16-byte slot of its pixel (256 % 8 == 0)
-        float sc[8], sh[8];
+        float sc[8], sh[8], k0[DG ? 8 : 1];
         auto affine_of = [&](int cc) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) { sc[i] = aff[cc * 64 + slot8 + i]; sh[i] = aff[H_MAXC + cc * 64 + slot8 + i]; }
+            if constexpr (DG) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) k0[i] = aff[2 * H_MAXC + cc * 64 + slot8 + i];
+            }
         };
         auto load_all = [&](int rb, int r1, int cc) __attribute__((always_inline)) {
 #pragma unroll
@@ -212,6 +219,7 @@ __global__ __launch_bounds__(768) void conv_halo_kernel(const Params p) {
                 long goff; int lo; bool inner;
                 locate(j, rb, r1, cc, goff, lo, inner);
                 regs[j] = goff >= 0 ? *reinterpret_cast<const uint4 *>(xg + goff) : make_uint4(0u, 0u, 0u, 0u);
+                if constexpr (DG) { if (rev) regs2[j] = goff >= 0 ? *reinterpret_cast<const uint4 *>(x2g + goff) : make_uint4(0u, 0u, 0u, 0u); }
             }
         };
         auto store2 = [&](int s, int rb, int r1, int cc, unsigned char *hb, T *ag) __attribute__((always_inline)) {
@@ -230,6 +238,16 @@ __global__ __launch_bounds__(768) void conv_halo_kernel(const Params p) {
                     for (int k = 0; k < 8; ++k) { f[k] = fmaf(f[k], sc[k], sh[k]); if (p.relu_in) f[k] = fmaxf(f[k], 0.f); }
                     v = Chunk<T>::pack(f);
                 }
+                if constexpr (DG) {
+                    if (rev && goff >= 0) {
+                        float f[8], y[8];
+                        Chunk<T>::unpack(v, f);
+                        Chunk<T>::unpack(regs2[j], y);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) f[k] = fmaf(sc[k], f[k], fmaf(sh[k], y[k], k0[k]));
+                        v = Chunk<T>::pack(f);
+                    }
+                }
                 *reinterpret_cast<uint4 *>(hb + lo) = v;
                 if (ag && inner) *reinterpret_cast<uint4 *>(ag + goff) = v;
             }
@@ -240,7 +258,7 @@ __global__ __launch_bounds__(768) void conv_halo_kernel(const Params p) {
             tile_at(blockIdx.x, mt0, nt0);
             T *ag = p.a_out && nt0 == 0 ? reinterpret_cast<T *>(p.a_out) : nullptr;
             const int r1 = (mt0 % TPI) * R - 1, rb = (mt0 / TPI) * p.H + r1;
-            if (bn) affine_of(0);
+            if (bn || rev) affine_of(0);
             load_all(rb, r1, 0);
 #pragma unroll
             for (int s = 0; s < 6; ++s) store2(s, rb, r1, 0, halo0, ag);
@@ -268,7 +286,7 @@ __global__ __launch_bounds__(768) void conv_halo_kernel(const Params p) {
 #pragma unroll
                 for (int s = 0; s < 9; ++s) {
                     if (have && !(abl & 8)) {
-                        if (s == 0) { load_all(rb, r1, c2); if (bn) affine_of(c2); }
+                        if (s == 0) { load_all(rb, r1, c2); if (bn || rev) affine_of(c2); }
                         if (s >= 3) store2(s - 3, rb, r1, c2, hb, ag);
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (step 8: the next chunk is written - the barrier publishes it)
@@ -287,7 +305,7 @@ __global__ __launch_bounds__(768) void conv_halo_kernel(const Params p) {
 
 bool halo_supports(const Params &p) {
     return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && (p.W == 32 || p.W == 16) && p.H % (HBM / p.W) == 0 && p.Cin % 64 == 0 &&
-           p.Cin >= 64 && p.Cin <= H_MAXC && p.Cout % HBN == 0 && p.M % HBM == 0 && !p.x2 && !p.os2 && !p.res_s2 && !p.y32 && !p.xcat &&
+           p.Cin >= 64 && p.Cin <= H_MAXC && p.Cout % HBN == 0 && p.M % HBM == 0 && (!p.x2 || (p.mask && p.rev_coef && !p.in_scale)) && !p.os2 && !p.res_s2 && !p.y32 && !p.xcat &&
            !(p.mask && p.stats) && (size_t)(p.Cout / HBN) * (p.Cin / 64) * 9 * H_STAGE < 0x7fff0000ull;
 }
 
@@ -356,5 +374,21 @@ extern "C" int mhe_conv3x3_halo_nhwc(int B, int H, int W, int Cin, int Cout, con
     p.M = (int)M; p.Kpad = 9 * Cin;
     p.force = -1;
     MHE_REQUIRE(conv::halo_supports(p), "mhe_conv3x3_halo_nhwc: geometry not taken (3x3 stride 1 pad 1, W 32 / 16, Cin %% 64, Cin <= 512, Cout %% 128)");
+    return conv::launch_halo(p, (hipStream_t)stream);
+}
+
+extern "C" int mhe_conv3x3_halo_dgrad_bn_nhwc(int B, int H, int W, int Cin, int Cout, const void *g, const void *y_raw, const float *coef, const void *w_halo,
+                                              void *gx, void *gy_out, const void *residual, const void *mask, const void *bn_y0,
+                                              const float *bn_mean_invstd0, float *bn_stats0, void *stream) {
+    MHE_REQUIRE(g && y_raw && coef && w_halo && gx && mask, "mhe_conv3x3_halo_dgrad_bn_nhwc: null pointer");
+    MHE_REQUIRE(!bn_y0 || (bn_mean_invstd0 && bn_stats0), "mhe_conv3x3_halo_dgrad_bn_nhwc: bn_y needs its mean_invstd and stats");
+    conv::Params p{};
+    p.x = g; p.x2 = y_raw; p.rev_coef = coef; p.w = w_halo; p.y = gx; p.a_out = gy_out;
+    p.residual = residual; p.mask = mask; p.bn_y[0] = bn_y0; p.bn_mi[0] = bn_mean_invstd0; p.bn_stats[0] = bn_stats0;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = p.KW = 3; p.stride = 1; p.pad = 1; p.Ho = H; p.Wo = W;
+    const long long M = (long long)B * H * W;
+    MHE_REQUIRE(B > 0 && H > 0 && W > 0 && M < (1ll << 31), "mhe_conv3x3_halo_dgrad_bn_nhwc: bad geometry");
+    p.M = (int)M; p.Kpad = 9 * Cin; p.force = -1;
+    MHE_REQUIRE(conv::halo_supports(p), "mhe_conv3x3_halo_dgrad_bn_nhwc: geometry not taken (see mhe_conv3x3_halo_nhwc)");
     return conv::launch_halo(p, (hipStream_t)stream);
 }

@@ -36,6 +36,9 @@ struct Params {
     // bottleneck tail (conv_fuse.hip); mask_bits: read INSTEAD of mask by the streaming 1x1 data-gradient kernel (conv_stream.hip) - a
     // sixteenth of the block-wide tensor's bytes; every other kernel reads mask
     unsigned char *a_bits; const unsigned char *mask_bits;
+    // conv_halo.hip, data-gradient form with the BatchNorm reverse of the convolution's own output gradient on the operand load:
+    // operand = k2 x + k1 x2 + k0 per channel (rev_coef = k2 | k1 | k0, [3][Cin]; x2 = the raw output that BatchNorm normalised), written to a_out
+    const float *rev_coef;
 };
 
 // tile row -> global output pixel index the epilogue addresses (or -1 outside the problem)

@@ -540,6 +540,26 @@ def conv3x3_halo(x, w_halo, in_scale=None, in_shift=None, relu_in=False, a_out=N
     return y
 
 
+def conv3x3_halo_dgrad_bn(g, y_raw, coef, w_halo, mask, gy_out=None, residual=None, bn=None):
+    """data gradient of a 3x3 / stride-1 unit with the BatchNorm reverse of its own output gradient on the operand load: operand = k2 g + k1 y_raw
+    + k0 (coef [3, C] of bn_backward(coef_only=True)), written to gy_out for the weight gradient (mhe_conv3x3_halo_dgrad_bn_nhwc)"""
+    B, H, W, Cin = g.shape
+    Cout = w_halo.shape[0]
+    _chk(g, torch.bfloat16, "halo_dg.g"); _chk(y_raw, torch.bfloat16, "halo_dg.y", tuple(g.shape)); _chk(coef, torch.float32, "halo_dg.coef", (3, Cin))
+    _chk(w_halo, torch.bfloat16, "halo_dg.w", (Cout, 9 * Cin)); _chk(mask, torch.bfloat16, "halo_dg.mask", (B, H, W, Cout))
+    gx = torch.empty(B, H, W, Cout, device=g.device, dtype=torch.bfloat16)
+    if gy_out is not None:
+        _chk(gy_out, torch.bfloat16, "halo_dg.gy_out", tuple(g.shape))
+    if residual is not None:
+        _chk(residual, torch.bfloat16, "halo_dg.residual", tuple(gx.shape))
+    by, bmi, bst = (None, None, None) if bn is None else bn
+    if by is not None:
+        _chk(by, torch.bfloat16, "halo_dg.bn_y", tuple(gx.shape)); _chk(bmi, torch.float32, "halo_dg.bn_mi", (2, Cout)); _chk(bst, torch.float32, "halo_dg.bn_stats", (stat_shards(), 2, Cout))
+    check(_lib.lib().mhe_conv3x3_halo_dgrad_bn_nhwc(B, H, W, Cin, Cout, _ptr(g), _ptr(y_raw), _ptr(coef), _ptr(w_halo), _ptr(gx), _ptr(gy_out), _ptr(residual),
+                                                    _ptr(mask), _ptr(by), _ptr(bmi), _ptr(bst), _stream()), "mhe_conv3x3_halo_dgrad_bn_nhwc")
+    return gx
+
+
 def bottleneck_tail_supported(B, H, W, Cb, Cout):
     d = ConvDesc(B, H, W, 4 * Cb, Cout, 1, 1, 1, 0, BF16, 1, 0, 0, 0)
     return bool(_lib.lib().mhe_bottleneck_tail_supported(C.byref(d), int(Cb)))

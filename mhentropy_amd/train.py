@@ -156,6 +156,9 @@ class TrainStep:
         self.shortcut_fold = os.environ.get("MHE_SHORTCUT_FOLD", "1") == "1"
         self.conv_halo = os.environ.get("MHE_CONV_HALO", "1") == "1"
         self.conv_halo_dg = os.environ.get("MHE_CONV_HALO_DG", "1") == "1"
+        # (... with their own BatchNorm reverse on that launch's operand load, MHE_HALO_BN_ON_LOAD=1: built, equal - 26.35 / 26.38 ms: the transfer
+        # waves' second operand stream and arithmetic cost the launch what the apply pass cost)
+        self.halo_bn_on_load = os.environ.get("MHE_HALO_BN_ON_LOAD", "0") == "1"
         # the stem's BatchNorm + ReLU folded into its max pool, forward and reverse (ops.maxpool3x3s2_idx / maxpool3x3s2_bwd_bn)
         self.stem_pool_fused = os.environ.get("MHE_STEM_POOL_FUSED", "1") == "1"
         self.bn_on_load_wide = os.environ.get("MHE_BN_BWD_ON_LOAD_WIDE", "1") == "1"
@@ -801,7 +804,19 @@ class TrainStep:
                 skip = g
             for j in range(len(us) - 1, 0, -1):
                 u = us[j]
-                if gy is None:                               # conv3 with its BatchNorm reverse on load
+                if isinstance(gy, tuple):
+                    # a 3x3 unit of layer2 / layer3: its BatchNorm reverse applied on the operand load of its own data gradient (the
+                    # resident-tile kernel's transfer waves, csrc/conv_halo.hip), gy written on the way for the weight gradient
+                    graw, coef = gy
+                    cons = us[j - 1]
+                    bn = None
+                    if self.fuse_bn_reduce:
+                        cons.rev_stats = pool.take(cons.cout)
+                        bn = (cons.y, cons.mi, cons.rev_stats)
+                    gy = torch.empty_like(graw)
+                    ga = ops.conv3x3_halo_dgrad_bn(graw, u.y, coef, u.w_dg_halo, u.x, gy_out=gy, bn=bn)
+                    self._wgrad(u, gy)
+                elif gy is None:                             # conv3 with its BatchNorm reverse on load
                     cons = us[j - 1]
                     bn = None
                     if self.fuse_bn_reduce:
@@ -822,7 +837,15 @@ class TrainStep:
                 else:
                     self._wgrad(u, gy)
                     ga = self._dgrad(u, gy, consumers=(us[j - 1],), pool=pool)
-                gy = self._bn_bwd(us[j - 1], ga, None, pool, stats=getattr(us[j - 1], "rev_stats", None))
+                nu = us[j - 1]
+                if (j - 1 >= 1 and self.conv_halo_dg and self.halo_bn_on_load and getattr(nu, "w_dg_halo", None) is not None and nu.k == 3
+                        and nu.stride == 1 and ga.dtype == torch.bfloat16
+                        and ops.conv3x3_halo_supported(ga.shape[0], ga.shape[1], ga.shape[2], nu.cout, nu.cin)):
+                    rs = getattr(nu, "rev_stats", None)
+                    gy = (ga, ops.bn_backward(ga, None, nu.y, nu.mi, nu.bn.weight.data, rs if rs is not None else pool.take(nu.cout), nu.dgamma,
+                                              nu.dbeta, reduced=rs is not None, coef_only=True))
+                else:
+                    gy = self._bn_bwd(nu, ga, None, pool, stats=getattr(nu, "rev_stats", None))
             self._wgrad(us[0], gy)
             first = bi == 0            # the first block's input is the max-pooled stem output (>= 0; the pool's reverse gates it)
             prev = self.blocks[bi - 1] if bi else None

@@ -748,3 +748,33 @@ def test_3x3_resident_tile_kernel_refuses_what_it_does_not_take(gpu_lib):
     w = torch.zeros(512, 9 * 512, device="cuda", dtype=torch.bfloat16)
     with pytest.raises(_lib.MheError):
         ops.conv3x3_halo(x, w)
+
+
+@pytest.mark.parametrize("geom", [(4, 32, 128, 128), (5, 16, 256, 256), (80, 32, 128, 128)], ids=lambda g: "x".join(map(str, g)))
+def test_3x3_resident_tile_data_gradient_with_batchnorm_reverse_on_its_load(gpu_lib, geom):
+    """mhe_conv3x3_halo_dgrad_bn_nhwc: operand = k2 g + k1 y + k0 formed by the transfer waves (the arithmetic of the apply pass, so the
+    tensor written out for the weight gradient is the pass's to the bit) - and then the same launch as on that tensor"""
+    from mhentropy_amd import ops, resnet
+    B, H, Cin, Cout = geom
+    W = H
+    g0, x, w = _operands(B + Cin + 1, B, H, W, Cin, Cout, 3)
+    rnd = lambda *s: torch.randn(*s, generator=g0).bfloat16().cuda()
+    g, y = x.permute(0, 2, 3, 1).contiguous().bfloat16().cuda(), rnd(B, H, W, Cin)
+    wh = ops.conv3x3_halo_pack(resnet.pack_conv_weight(w, torch.bfloat16).cuda())
+    mask, by = rnd(B, H, W, Cout), rnd(B, H, W, Cout)
+    mi_in = torch.stack([torch.randn(Cin, generator=g0) * 0.1, torch.rand(Cin, generator=g0) + 0.5]).cuda().contiguous()
+    mi_out = torch.stack([torch.randn(Cout, generator=g0) * 0.1, torch.rand(Cout, generator=g0) + 0.5]).cuda().contiguous()
+    gamma = (torch.rand(Cin, generator=g0) + 0.5).cuda()
+    S = ops.stat_shards()
+    dg, db = torch.zeros(Cin, device="cuda"), torch.zeros(Cin, device="cuda")
+    sums = torch.zeros(S, 2, Cin, device="cuda")
+    coef = ops.bn_backward(g, None, y, mi_in, gamma, sums, dg, db, coef_only=True)
+    gy_ref = ops.bn_backward(g, None, y, mi_in, gamma, sums, dg, db, reduced=True)        # (the same sums: the same coefficients to the bit)
+    st = [torch.zeros(S, 2, Cout, device="cuda") for _ in range(2)]
+    gy = torch.empty_like(g)
+    got = ops.conv3x3_halo_dgrad_bn(g, y, coef, wh, mask, gy_out=gy, bn=(by, mi_out, st[0]))
+    want = ops.conv3x3_halo(gy_ref, wh, mask=mask, bn=(by, mi_out, st[1]))
+    assert torch.equal(gy, gy_ref), (gy.float() - gy_ref.float()).abs().max().item()
+    assert torch.equal(got, want)
+    a, b = st[0].sum(0).cpu(), st[1].sum(0).cpu()
+    assert ((a - b).abs() <= 1e-3 * (b.abs().max(1, keepdim=True)[0] + 1.0)).all(), "BatchNorm-reverse sums"
