@@ -93,7 +93,8 @@ class ResNetTrunk(nn.Module):
         self.bn_apply_1x1 = os.environ.get("MHE_BN_APPLY_1X1", "auto")
         self.bn_apply_3x3 = os.environ.get("MHE_BN_APPLY_3X3", "auto")
         # (stride-2 3x3 consumers: each input element is used by 2.25 taps on average instead of 9: on load, -0.06 ms at C2)
-        self.bn_load_s2 = os.environ.get("MHE_BN_LOAD_S2", "1") == "1"
+        # up to this many channels (0 = never): at layer4.0's 512 the in-place pass + phase-pipelined kernel stay ahead (113 against 166 us)
+        self.bn_load_s2 = int(os.environ.get("MHE_BN_LOAD_S2", "256"))
         # stride-1 3x3 consumers on 32 x 32 / 16 x 16 images (conv2 of layer2 / layer3 at C2): the kernel that keeps the input tile in LDS
         # and normalises every element once on its way in (csrc/conv_halo.hip) - no pass, no im2col re-reads
         self.conv_halo = os.environ.get("MHE_CONV_HALO", "1") == "1"
@@ -200,7 +201,7 @@ class ResNetTrunk(nn.Module):
                 # its way into LDS (95 us against 56 + 77 us for the pass and the plain form)
                 ap2 = "load" if self.bn_apply_3x3 == "auto" and (ops.conv_tile_choice(
                     y1.shape[0], y1.shape[1], y1.shape[2], y1.shape[3], blk.conv2.out_channels, 3, blk.stride, 1, y1.dtype, 1) == 9
-                    or (blk.stride == 2 and self.bn_load_s2)) else None
+                    or (blk.stride == 2 and blk.conv2.in_channels <= self.bn_load_s2)) else None
                 wh = None
                 if (self.conv_halo and blk.stride == 1 and y1.dtype == torch.bfloat16 and self.bn_apply_3x3 == "auto"
                         and ops.conv3x3_halo_supported(y1.shape[0], y1.shape[1], y1.shape[2], y1.shape[3], blk.conv2.out_channels)):
