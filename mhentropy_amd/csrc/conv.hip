@@ -679,7 +679,9 @@ static int choose_tile(const Params &p, bool fast, bool bf16) {
     // data-gradient form with a per-channel constant (mhe_conv2d_masked_bias_nhwc): the kernels with the shared epilogue only
     if ((p.mask && p.out_shift) || p.xcat) return force == 0 || (force < 0 && p.Cout <= 64) ? 0 : 1;
     static const int env_stream = getenv("MHE_CONV_STREAM") ? atoi(getenv("MHE_CONV_STREAM")) : 1;
-    if (bf16 && (force == 8 || (force < 0 && env_stream)) && stream_supports(p)) return 8;
+    // (not chosen for the data-gradient form at 256 input channels - layer3's conv1 reverse, 256 -> 1024: 178 us there against 157 on the
+    // phase-pipelined kernel, 220 with the gate as bits; at 64 / 128 it leads by 10-25 %: tools/dg_l3.py)
+    if (bf16 && (force == 8 || (force < 0 && env_stream && !(p.mask && p.Cin == 256))) && stream_supports(p)) return 8;
     if (bf16 && (force == 9 || (force < 0 && env_stream)) && stream3_supports(p)) return 9;
     static const int env_wide = getenv("MHE_CONV_WIDE") ? atoi(getenv("MHE_CONV_WIDE")) : 1;
     // (selected by itself at 256 input channels only: at 512 the 64-channel slabs make 32 workgroups re-read every activation tile through

@@ -569,3 +569,21 @@ def test_flow_fragment_streaming_kernel_vs_bf16_rounding_oracle(gpu_lib, steps, 
         assert_close(e1[1][net].float().cpu(), e0[1][net].float().cpu(), 8e-3, what=f"h2 net {net}")
     assert_close(e1[2][:, :, :45].cpu(), e0[2][:, :, :45].cpu(), 1e-2, what="s / t pre-activations, all nets")
     assert float(e1[2][:, :, 45:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("n", [8 * 1000, 8 * 1000 + 3, 1 << 20])
+def test_operand_gather_matches_torch_indexing(gpu_lib, n):
+    """mhe_gather_f32: dst[i] = src[idx[i]] (0 where idx < 0) (+ src[idx2[i]]), f32 and bf16 destinations - the scalar kernel and the
+    eight-per-thread bf16 form the train step's operand arena goes through (n a multiple of 8, no second index)"""
+    from mhentropy_amd import ops
+    g = torch.Generator().manual_seed(n)
+    src = torch.randn(50000, generator=g).cuda()
+    idx = torch.randint(-1, 50000, (n,), generator=g, dtype=torch.int32).cuda()
+    idx2 = torch.randint(-1, 50000, (n,), generator=g, dtype=torch.int32).cuda()
+    pick = lambda ix: torch.where(ix >= 0, src[ix.clamp(min=0).long()], torch.zeros((), device="cuda"))
+    for dt in (torch.float32, torch.bfloat16):
+        out = torch.empty(n, device="cuda", dtype=dt)
+        ops.gather(src, idx, out)
+        assert torch.equal(out, pick(idx).to(dt))
+        ops.gather(src, idx, out, idx2)
+        assert torch.equal(out, (pick(idx) + pick(idx2)).to(dt))
