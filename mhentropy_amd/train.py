@@ -315,8 +315,9 @@ class TrainStep:
                 d[:, :kd] = dgrad_operand_index(idx)
                 u.w_dg = self._derived(d, T)
                 # the 3x3 / stride-1 units also in the layout of the resident-tile kernel (csrc/conv_halo.hip), forward and data gradient
+                # (layer2 / layer3: layer4's 8 x 8 maps are not taken by it, and every table here is gathered every step)
                 u.w_halo = u.w_dg_halo = None
-                if (KH == 3 and stride == 1 and pad == 1 and T == torch.bfloat16 and Cin % 128 == 0 and Cout % 128 == 0 and Cin <= 512 and Cout <= 512
+                if (KH == 3 and stride == 1 and pad == 1 and T == torch.bfloat16 and Cin % 128 == 0 and Cout % 128 == 0 and Cin <= 256 and Cout <= 256
                         and os.environ.get("MHE_CONV_HALO", "1") == "1"):
                     u.w_halo = self._derived(halo_operand_index(f[:, :kk]), T)
                     u.w_dg_halo = self._derived(halo_operand_index(d[:, :kd]), T)
