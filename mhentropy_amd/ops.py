@@ -534,9 +534,16 @@ def conv3x3_halo(x, w_halo, in_scale=None, in_shift=None, relu_in=False, a_out=N
     by, bmi, bst = (None, None, None) if bn is None else bn
     if by is not None:
         _chk(by, torch.bfloat16, "halo.bn_y", tuple(y.shape)); _chk(bmi, torch.float32, "halo.bn_mi", (2, Cout)); _chk(bst, torch.float32, "halo.bn_stats", (stat_shards(), 2, Cout))
+    if TIMING:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     check(_lib.lib().mhe_conv3x3_halo_nhwc(B, H, W, Cin, Cout, _ptr(x), _ptr(w_halo), _ptr(y), _ptr(in_scale), _ptr(in_shift), int(bool(relu_in)),
                                            _ptr(a_out), _ptr(stats), _ptr(residual), _ptr(mask), _ptr(by), _ptr(bmi), _ptr(bst), _stream()),
           "mhe_conv3x3_halo_nhwc")
+    if TIMING:
+        ev1.record()
+        KERNEL_TIMES.append(("mhe::conv::conv_halo_kernel<%d, %s>" % (W, "true" if mask is not None else "false"), 2.0 * B * H * W * Cout * 9 * Cin, ev0, ev1,
+                             2 * (x.numel() + y.numel() + w_halo.numel())))
     return y
 
 
