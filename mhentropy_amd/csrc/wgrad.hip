@@ -562,6 +562,24 @@ __global__ __launch_bounds__(256) void gather8_bf16_kernel(const float *__restri
         reinterpret_cast<uint4 *>(dst)[i] = o;
     }
 }
+// ... and four f32 destinations per thread (the f32 arena: 11 M elements, a second index for a handful of them)
+__global__ __launch_bounds__(256) void gather4_f32_kernel(const float *__restrict__ src, const int *__restrict__ idx, const int *__restrict__ idx2,
+                                                          float *__restrict__ dst, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const int4 a = reinterpret_cast<const int4 *>(idx)[i];
+        const int j[4] = {a.x, a.y, a.z, a.w};
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = j[k] < 0 ? 0.f : src[j[k]];
+        if (idx2) {
+            const int4 b = reinterpret_cast<const int4 *>(idx2)[i];
+            const int j2[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (j2[k] >= 0) v[k] += src[j2[k]];
+        }
+        reinterpret_cast<float4 *>(dst)[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
 }}  // namespace mhe::wgrad
 
 using namespace mhe;
@@ -761,6 +779,12 @@ extern "C" int mhe_gather_f32(const float *src, const int *idx, const int *idx2,
         if (b8 > 16384) b8 = 16384;
         hipLaunchKernelGGL(wgrad::gather8_bf16_kernel, dim3((unsigned)b8), dim3(256), 0, (hipStream_t)stream, src, idx, (u16 *)dst, n / 8);
         return check_launch("gather8_bf16_kernel");
+    }
+    if (dst_dtype == MHE_F32 && n % 4 == 0 && ((size_t)idx & 15) == 0 && ((size_t)dst & 15) == 0 && (!idx2 || ((size_t)idx2 & 15) == 0)) {
+        size_t b4 = (n / 4 + 255) / 256;
+        if (b4 > 16384) b4 = 16384;
+        hipLaunchKernelGGL(wgrad::gather4_f32_kernel, dim3((unsigned)b4), dim3(256), 0, (hipStream_t)stream, src, idx, idx2, (float *)dst, n / 4);
+        return check_launch("gather4_f32_kernel");
     }
     if (dst_dtype == MHE_F32)
         hipLaunchKernelGGL(wgrad::gather_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, idx, idx2, (float *)dst, n);
