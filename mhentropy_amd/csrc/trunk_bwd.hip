@@ -33,7 +33,26 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict_
             const float4 mu = *reinterpret_cast<const float4 *>(mean_invstd + c);
             const float4 is = *reinterpret_cast<const float4 *>(mean_invstd + C + c);
             const float m[4] = {mu.x, mu.y, mu.z, mu.w}, iv[4] = {is.x, is.y, is.z, is.w};
-            for (long r = r0 + rl; r < r1; r += rl_n) {
+            // four rows' loads in flight per thread (one row at a time ran at 1.5 TB/s: 89 us for the 134 MB of layer4's last block)
+            long r = r0 + rl;
+            for (; r + 3 * rl_n < r1; r += 4 * rl_n) {
+                float gv[4][4], yv[4][4], av[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    load4<T>(g + (r + u * rl_n) * C + c, gv[u]);
+                    load4<T>(y + (r + u * rl_n) * C + c, yv[u]);
+                    if (a) load4<T>(a + (r + u * rl_n) * C + c, av[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float gg = (!a || av[u][k] > 0.f) ? gv[u][k] : 0.f;
+                        s1[k] += gg;
+                        s2[k] = fmaf(gg, (yv[u][k] - m[k]) * iv[k], s2[k]);
+                    }
+            }
+            for (; r < r1; r += rl_n) {
                 float gv[4], yv[4], av[4];
                 load4<T>(g + r * C + c, gv);
                 load4<T>(y + r * C + c, yv);
