@@ -41,10 +41,19 @@ enum { MHE_FLOW_FORWARD = 0, MHE_FLOW_INVERSE = 1 };
 /* library ---------------------------------------------------------------- */
 /* MHE_ABI_VERSION changes whenever a struct layout or an existing signature changes (new entry points alone do not bump it).
  *   1: round 1.   2: mhe_conv_desc gained `tile` and `res_half` (every convolution entry reads them), mhe_conv_wgrad_nhwc
- *   takes the descriptor.  A caller compiled against another version must not call in: check
+ *   takes the descriptor.   3: statistic accumulators are fixed-point mhe_stat_t words (below) instead of f32; pixel counts are double.  A caller compiled against another version must not call in: check
  *   mhe_abi_version() == MHE_ABI_VERSION once after loading the library. */
-#define MHE_ABI_VERSION 2
+#define MHE_ABI_VERSION 3
 int         mhe_abi_version(void);
+
+/* Sharded per-channel accumulators (BatchNorm batch statistics, BatchNorm-reverse sums): 64-bit FIXED-POINT words added with integer
+ * atomics, so that a total does not depend on the order in which workgroups arrive (bit-identical runs, eager or graph replay).
+ * One unit of C channels = [2 planes][S shards][2 statistics][C] words, S = mhe_conv_stat_shards() = 64:
+ *   value = sum_shards (plane0 word * 2^-16 + plane1 word * 2^-56)          (mhe_stat_words(C) words in all)
+ * A NaN / Inf / out-of-range partial plants a marker the finalize kernels turn into NaN.  Zeroed by the caller once; the
+ * finalize entry points with a clear flag re-zero what they read.  (ABI 3: these were f32 [S,2,C] up to ABI 2.) */
+typedef long long mhe_stat_t;
+size_t mhe_stat_words(int C);
 const char *mhe_last_error(void);
 
 /* dense layers ------------------------------------------------------------
@@ -214,7 +223,7 @@ int mhe_elbo_reduce_f32(const float *log_p_rows, const float *log_q_rows,
  *       relu(x*scale+shift) applied while loading (padding stays zero)
  *   out_scale/out_shift [Cout] (optional, eval-mode BN), residual (optional,
  *       [B,Ho,Wo,Cout]), relu flag: y = act(conv*scale+shift + residual)
- *   stats [S,2,Cout] f32 (optional), S = mhe_conv_stat_shards(): per-channel sum and
+ *   stats (optional): one mhe_stat_t unit of Cout channels (above): per-channel sum and
  *       sum of squares of the raw conv output (train-mode BatchNorm batch
  *       statistics).  Each workgroup reduces its tile in LDS and adds one value
  *       per channel into shard (workgroup % S); must be zeroed by the caller.
@@ -240,23 +249,23 @@ typedef struct mhe_conv_desc {
  * of the output AS IT WOULD BE STORED, without storing it.  With mhe_bottleneck_tail_nhwc below this replaces "write conv3's raw output,
  * read it back in the block tail" for layer1 / layer2 of ResNet-50 (torchvision Bottleneck, hand/network.py:54-61,110). */
 int mhe_conv1x1_stats_nhwc(const mhe_conv_desc *d, const void *x, const void *w, const float *in_scale, const float *in_shift,
-                           float *stats, void *stream);
+                           mhe_stat_t *stats, void *stream);
 /* ... and cheaper still: the same batch statistics from the moments of the convolution's INPUT.  For y = W a:  sum_p y_c = w_c . m,
  * sum_p y_c^2 = w_c^T G w_c  with m = sum_p a_p and G = sum_p a_p a_p^T (Cb x Cb) - 8x / 4x fewer multiply-adds than the product and no
  * per-output-element work.  mhe_conv1x1_gram_nhwc accumulates G and m of a = relu?(x * in_scale + in_shift) (rounded to bf16, the operand
- * conv3 multiplies) into `gram`, mhe_gram_stats_floats(Cb) floats (sharded; zeroed by the caller once - mhe_gram_bn_finalize clears what it
+ * conv3 multiplies) into `gram`, mhe_gram_stats_words(Cb) fixed-point words (one-word form, quantum 2^-20) (sharded; zeroed by the caller once - mhe_gram_bn_finalize clears what it
  * read); mhe_gram_bn_finalize turns them into bn's affine like mhe_bn_finalize_step (w = the packed [C][Cb] bf16 weights; workspace =
  * mhe_gram_stats_workspace_bytes(Cb) bytes).  Statistics of the f32 products (not of bf16-rounded outputs). */
-size_t mhe_gram_stats_floats(int Cb);
+size_t mhe_gram_stats_words(int Cb);
 size_t mhe_gram_stats_workspace_bytes(int Cb);
-int mhe_conv1x1_gram_nhwc(const void *x, const float *in_scale, const float *in_shift, int relu_in, float *gram, long pixels, int Cb,
+int mhe_conv1x1_gram_nhwc(const void *x, const float *in_scale, const float *in_shift, int relu_in, mhe_stat_t *gram, long pixels, int Cb,
                           void *stream);
 /* ... that also writes the operand it multiplies, relu(x * in_scale + in_shift) as bf16 [pixels][Cb] (a_out, optional): the train step keeps it
  * for the reverse pass instead of making it in a pass of its own */
-int mhe_conv1x1_gram_store_nhwc(const void *x, const float *in_scale, const float *in_shift, int relu_in, float *gram, void *a_out,
+int mhe_conv1x1_gram_store_nhwc(const void *x, const float *in_scale, const float *in_shift, int relu_in, mhe_stat_t *gram, void *a_out,
                                 long pixels, int Cb, void *stream);
-int mhe_gram_bn_finalize(float *gram, void *workspace, const void *w, const float *gamma, const float *beta, float *running_mean,
-                         float *running_var, float *scale, float *shift, float *mean_invstd, int C, int Cb, float count,
+int mhe_gram_bn_finalize(mhe_stat_t *gram, void *workspace, const void *w, const float *gamma, const float *beta, float *running_mean,
+                         float *running_var, float *scale, float *shift, float *mean_invstd, int C, int Cb, double count,
                          float momentum, float eps, long long *num_batches_tracked, void *stream);
 /* The tail of a bottleneck block with its conv3 re-evaluated, fused with the next block's conv1 (forward-only path; kernel variant 12):
  *   T  = conv1x1(relu(y2 * bn2_scale + bn2_shift), w3)   rounded to the storage type like a stored conv3 output   [B,H,W,Cin]
@@ -268,13 +277,13 @@ int mhe_gram_bn_finalize(float *gram, void *workspace, const void *w, const floa
 int mhe_bottleneck_tail_supported(const mhe_conv_desc *d, int Cb);
 int mhe_bottleneck_tail_nhwc(const mhe_conv_desc *d, int Cb, const void *y2, const float *bn2_scale, const float *bn2_shift,
                              const void *w3, const float *bn3_scale, const float *bn3_shift, const void *identity,
-                             const float *id_scale, const float *id_shift, const void *w1, void *a_out, void *y1, float *stats,
+                             const float *id_scale, const float *id_shift, const void *w1, void *a_out, void *y1, mhe_stat_t *stats,
                              void *stream);
 
 int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y,
                     const float *in_scale, const float *in_shift,
                     const float *out_scale, const float *out_shift, const void *residual,
-                    float *stats, void *stream);
+                    mhe_stat_t *stats, void *stream);
 /* bf16 operands, f32 accumulation, F32 RESULT y_f32 [B,Ho,Wo,Cout] (+ out_shift per channel, optional): products whose result
  * feeds exp / tanh or a long f32 gradient chain (the 64-wide layers of the flow's reverse pass) at the bf16 MFMA rate. */
 int mhe_conv2d_f32out_nhwc(const mhe_conv_desc *d, const void *x, const void *w, float *y_f32, const float *out_shift, void *stream);
@@ -284,8 +293,8 @@ int mhe_conv2d_f32out_nhwc(const mhe_conv_desc *d, const void *x, const void *w,
  * like y (the tail of a residual block feeds bn3 and the downsample's BN): bn_stats*[shard][0][c] += sum y,
  * [1][c] += sum y (bn_y - mean) invstd, exactly what mhe_bn_bwd_reduce_nhwc would compute in a separate pass. */
 int mhe_conv2d_masked_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const void *residual,
-                           const void *mask, const void *bn_y0, const float *bn_mean_invstd0, float *bn_stats0,
-                           const void *bn_y1, const float *bn_mean_invstd1, float *bn_stats1, void *stream);
+                           const void *mask, const void *bn_y0, const float *bn_mean_invstd0, mhe_stat_t *bn_stats0,
+                           const void *bn_y1, const float *bn_mean_invstd1, mhe_stat_t *bn_stats1, void *stream);
 int mhe_conv_stat_shards(void);
 /* kernel variant the launcher picks for a geometry with plain operands (numbering of mhe_conv_desc.tile, minus 1) */
 /* mhe_conv1x1_residual_in_nhwc's dual-input operand load (operand = [relu](x*in_scale+in_shift + x2*x2_scale+x2_shift), d->relu_in
@@ -297,7 +306,7 @@ int mhe_conv_stat_shards(void);
 int mhe_conv1x1_residual_in_masked_nhwc(const mhe_conv_desc *d, const void *x, const void *x2, const void *w, void *y,
                                         const float *in_scale, const float *in_shift, const float *x2_scale, const float *x2_shift,
                                         void *a_out, const void *residual, const void *mask, const void *bn_y0,
-                                        const float *bn_mean_invstd0, float *bn_stats0, void *stream);
+                                        const float *bn_mean_invstd0, mhe_stat_t *bn_stats0, void *stream);
 
 /* Data gradient of a 3x3 / stride 2 / pad 1 convolution (reference: torchvision Bottleneck.conv2 of layer2-4's first block, reached
  * through hand/network.py:54-61) WITHOUT zero-dilating gy: the four output parity classes (2i+py, 2j+px) are four small
@@ -307,8 +316,8 @@ int mhe_conv1x1_residual_in_masked_nhwc(const mhe_conv_desc *d, const void *x, c
  * (mask may be NULL: no gate, no BatchNorm-reverse sums). */
 int mhe_conv3x3s2_dgrad_nhwc(int B, int Ho, int Wo, int Cout, int Cin, int dtype, const void *gy, const void *const *w4,
                              void *dx, const void *residual, const void *mask, const void *bn_y0,
-                             const float *bn_mean_invstd0, float *bn_stats0, const void *bn_y1,
-                             const float *bn_mean_invstd1, float *bn_stats1, int tile /* mhe_conv_desc.tile */, void *stream);
+                             const float *bn_mean_invstd0, mhe_stat_t *bn_stats0, const void *bn_y1,
+                             const float *bn_mean_invstd1, mhe_stat_t *bn_stats1, int tile /* mhe_conv_desc.tile */, void *stream);
 int mhe_conv_tile(const mhe_conv_desc *d);
 /* the same for an operand-load form: mode 1 = producer BatchNorm on load, 2 = residual-block tail, 0 = plain operands */
 int mhe_conv_tile_mode(const mhe_conv_desc *d, int mode);
@@ -321,14 +330,14 @@ int mhe_conv_tile_mode(const mhe_conv_desc *d, int mode);
  * full read of the block output compared with mhe_bn_act_nhwc followed by mhe_conv2d_nhwc. */
 int mhe_conv1x1_residual_in_nhwc(const mhe_conv_desc *d, const void *x, const void *x2, const void *w, void *y,
                                  const float *in_scale, const float *in_shift, const float *x2_scale,
-                                 const float *x2_shift, void *a_out, float *stats, void *stream);
+                                 const float *x2_shift, void *a_out, mhe_stat_t *stats, void *stream);
 
 /* ResNet stem: 7x7 stride-2 pad-3 convolution 3 -> 64 (torchvision `conv1`, reference hand/network.py:54-61)
  * read straight from the NCHW f32 image x [B,3,H,W]; w [64][192] with k = 24*kh + 3*kw + c (each kh row of
  * 21 taps zero-padded to 24, then to 192; mhentropy_amd/resnet.py:pack_stem_weight); y [B,Ho,Wo,64] raw
  * conv output (dtype);
  * stats [S,2,64] as in mhe_conv2d_nhwc (optional). */
-int mhe_stem_conv7x7s2(const float *x_nchw, const void *w, void *y, float *stats, int B, int H, int W, int dtype,
+int mhe_stem_conv7x7s2(const float *x_nchw, const void *w, void *y, mhe_stat_t *stats, int B, int H, int W, int dtype,
                        void *stream);
 
 /* The stem for the forward-only path (bf16, 256 x 256 images): conv1 + batch statistics + the 3x3 / stride-2 / pad-1 max pool in one kernel.
@@ -337,7 +346,7 @@ int mhe_stem_conv7x7s2(const float *x_nchw, const void *w, void *y, float *stats
  * stem, hand/network.py:54-61,110) = relu(scale * pooled + shift), which the consumers apply on their operand load once the statistics
  * (stats, as in mhe_stem_conv7x7s2) are finalised.  The full-resolution output is never written. */
 int mhe_stem_pool_supported(int B, int H, int W, int dtype);
-int mhe_stem_conv7x7s2_pool(const float *x_nchw, const void *w, const float *bn_gamma, void *pooled, float *stats, int B, int H, int W,
+int mhe_stem_conv7x7s2_pool(const float *x_nchw, const void *w, const float *bn_gamma, void *pooled, mhe_stat_t *stats, int B, int H, int W,
                             void *stream);
 
 /* BatchNorm batch statistics (the sharded accumulators of mhe_conv2d_nhwc, summed in f64)
@@ -346,14 +355,14 @@ int mhe_stem_conv7x7s2_pool(const float *x_nchw, const void *w, const float *bn_
  *   mean = sum/n, var = sumsq/n - mean^2; scale = gamma/sqrt(var+eps);
  *   shift = beta - mean*scale; running stats updated in place when non-NULL;
  *   mean_invstd [2,C] (optional) receives mean and 1/sqrt(var+eps) for the reverse pass. */
-int mhe_bn_finalize(const float *stats, const float *gamma, const float *beta,
+int mhe_bn_finalize(const mhe_stat_t *stats, const float *gamma, const float *beta,
                     float *running_mean, float *running_var, float *scale, float *shift, float *mean_invstd,
-                    int C, float count, float momentum, float eps, void *stream);
+                    int C, double count, float momentum, float eps, void *stream);
 /* the form the forward step uses: clear_stats != 0 zeroes the accumulators it has just read (the arena is clean for the next
  * step without a memset launch), num_batches_tracked (optional, int64 on the device) is incremented like nn.BatchNorm2d does. */
-int mhe_bn_finalize_step(float *stats, const float *gamma, const float *beta,
+int mhe_bn_finalize_step(mhe_stat_t *stats, const float *gamma, const float *beta,
                          float *running_mean, float *running_var, float *scale, float *shift, float *mean_invstd,
-                         int C, float count, float momentum, float eps, int clear_stats, long long *num_batches_tracked, void *stream);
+                         int C, double count, float momentum, float eps, int clear_stats, long long *num_batches_tracked, void *stream);
 
 /* y = relu?(x*scale+shift (+ r*r_scale+r_shift | + r)) elementwise over NHWC
  * [P,C]; the bottleneck tail bn3 + identity + relu (torchvision Bottleneck). */
@@ -467,19 +476,19 @@ int mhe_flow_mask_pad_mixed(const float *x, const float *mask, float *xp, void *
  * (written by mhe_bottleneck_tail_bits_nhwc).  The streaming 1x1 data-gradient kernel reads the bits instead of the tensor; every other kernel
  * reads mask.  A bn_y equal to mask asks for sum g only (its second sum is then undefined). */
 int mhe_conv2d_masked_bits_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const void *residual,
-                                const void *mask, const void *mask_bits, const void *bn_y0, const float *bn_mean_invstd0, float *bn_stats0,
-                                const void *bn_y1, const float *bn_mean_invstd1, float *bn_stats1, void *stream);
+                                const void *mask, const void *mask_bits, const void *bn_y0, const float *bn_mean_invstd0, mhe_stat_t *bn_stats0,
+                                const void *bn_y1, const float *bn_mean_invstd1, mhe_stat_t *bn_stats1, void *stream);
 /* mhe_bottleneck_tail_nhwc that also writes the gate bits of its block output (a_bits [pixels][Cin / 8] bytes, optional). */
 int mhe_bottleneck_tail_bits_nhwc(const mhe_conv_desc *d, int Cb, const void *y2, const float *bn2_scale, const float *bn2_shift,
                                   const void *w3, const float *bn3_scale, const float *bn3_shift, const void *identity,
                                   const float *id_scale, const float *id_shift, const void *w1, void *a_out, void *a_bits, void *y1,
-                                  float *stats, void *stream);
+                                  mhe_stat_t *stats, void *stream);
 /* mhe_conv2d_masked_nhwc with a per-channel constant: y = (conv(x, w) + bias + residual) * [mask > 0] (+ the BatchNorm-reverse sums of one
  * consumer).  Register-staged 128-row tiles only.  xcat (optional, bf16 1x1 stride-1 launches): the operand's K range continues on a second
  * tensor - y = [x | xcat] w^T with w [Cout][Cin + cin2] and xcat [pixels][cin2]. */
 int mhe_conv2d_masked_bias_nhwc(const mhe_conv_desc *d, const void *x, const void *xcat, int cin2, const void *w, void *y,
                                 const void *residual, const void *mask, const float *bias, const void *bn_y0,
-                                const float *bn_mean_invstd0, float *bn_stats0, void *stream);
+                                const float *bn_mean_invstd0, mhe_stat_t *bn_stats0, void *stream);
 /* y = [x | xcat] w^T + bias (+ residual): a bf16 1x1 / stride-1 product whose K range continues on a second tensor (w [Cout][Cin + cin2]),
  * ungated - the data gradient of a shortcut convolution whose BatchNorm reverse runs on Gram statistics (mhe_conv3_bn_fold below; torchvision
  * Bottleneck.downsample, hand/network.py:54-61).  bias, residual optional. */
@@ -492,8 +501,8 @@ int mhe_conv1x1_cat_bias_nhwc(const mhe_conv_desc *d, const void *x, const void 
  * ACCUMULATED; w_dg_bf16 [Cb][ld_dg] = (k2 W)^T, the data-gradient weights for g; S_bf16 [Cb][ld_S] = W^T diag(k1) W, the 1x1 weights for
  * conv3's input (as the residual of that launch, or - S_bf16 = w_dg_bf16 + C, ld_S = ld_dg = C + Cb - as the second part of ONE
  * K-concatenated launch, mhe_conv2d_masked_bias_nhwc); c0 [Cb] the per-channel constant.  coef_ws: 2 C floats of scratch. */
-int mhe_conv3_bn_fold(float *D, const void *w_bf16, const double *gram_totals, const float *rev_stats, const float *gamma,
-                      const float *mean_invstd, float count, float *dgamma, float *dbeta, float *dW, void *w_dg_bf16, int ld_dg,
+int mhe_conv3_bn_fold(float *D, const void *w_bf16, const double *gram_totals, const mhe_stat_t *rev_stats, const float *gamma,
+                      const float *mean_invstd, double count, float *dgamma, float *dbeta, float *dW, void *w_dg_bf16, int ld_dg,
                       void *S_bf16, int ld_S, float *c0, float *coef_ws, int C, int Cb, void *stream);
 /* 3x3 / stride-1 / pad-1 bf16 convolution with the input tile resident in LDS (csrc/conv_halo.hip; conv2 of a torchvision Bottleneck,
  * hand/network.py:54-61,110, and its data gradient): W = 32 or 16, H a multiple of 256 / W, Cin a multiple of 64 (<= 512), Cout of 128.
@@ -504,14 +513,14 @@ int mhe_conv3_bn_fold(float *D, const void *w_bf16, const double *gram_totals, c
 int mhe_conv3x3_halo_supported(int B, int H, int W, int Cin, int Cout);
 int mhe_conv3x3_halo_pack_bf16(const void *w, void *w_halo, int Cout, int Cin, void *stream);
 int mhe_conv3x3_halo_nhwc(int B, int H, int W, int Cin, int Cout, const void *x, const void *w_halo, void *y, const float *in_scale,
-                          const float *in_shift, int relu_in, void *a_out, float *stats, const void *residual, const void *mask,
-                          const void *bn_y0, const float *bn_mean_invstd0, float *bn_stats0, void *stream);
+                          const float *in_shift, int relu_in, void *a_out, mhe_stat_t *stats, const void *residual, const void *mask,
+                          const void *bn_y0, const float *bn_mean_invstd0, mhe_stat_t *bn_stats0, void *stream);
 /* Data-gradient form of mhe_conv3x3_halo_nhwc with the BatchNorm reverse of the convolution's own output gradient on the operand load:
  * operand = k2 g + k1 y_raw + k0 per channel (coef = k2 | k1 | k0 [3][Cin], mhe_bn_bwd_finalize; the arithmetic of mhe_bn_bwd_apply_nhwc), written
  * once to gy_out (optional) for the weight gradient; gx = (conv(operand, w_halo) + residual) [mask > 0], BatchNorm-reverse sums of one consumer. */
 int mhe_conv3x3_halo_dgrad_bn_nhwc(int B, int H, int W, int Cin, int Cout, const void *g, const void *y_raw, const float *coef, const void *w_halo,
                                    void *gx, void *gy_out, const void *residual, const void *mask, const void *bn_y0,
-                                   const float *bn_mean_invstd0, float *bn_stats0, void *stream);
+                                   const float *bn_mean_invstd0, mhe_stat_t *bn_stats0, void *stream);
 int mhe_flow_reverse_chain_supported(int R, int B, int dim, int hidden, int ncoup);
 /* mhe_flow_couplings_bf16 / _emit on the fragment-streaming skeleton (csrc/flow_fwd.hip): hidden 512, a multiple of 64 hypotheses per
  * image (R % (64 B) == 0; a workgroup = 64 rows of one image), at most 32 couplings.  Same results as mhe_flow_couplings_bf16 up to the
@@ -571,11 +580,11 @@ int mhe_lbs_skin_f32(const float *workspace, const float *v_template, const floa
  *   finalize: dbeta, dgamma and coef [3,C] with  gy = coef0 g' + coef1 y + coef2  (= gamma invstd (g' - dbeta/M - xhat dgamma/M))
  *   apply:    gy (and optionally g' itself, the identity branch's gradient of a residual block)
  * mhe_bn_mean_invstd recovers mean / invstd [2,C] from the forward's statistic shards. */
-int mhe_bn_mean_invstd(const float *stats, float *mean_invstd, int C, float count, float eps, void *stream);
-int mhe_bn_bwd_reduce_nhwc(const void *g, const void *a, const void *y, const float *mean_invstd, float *stats,
+int mhe_bn_mean_invstd(const mhe_stat_t *stats, float *mean_invstd, int C, double count, float eps, void *stream);
+int mhe_bn_bwd_reduce_nhwc(const void *g, const void *a, const void *y, const float *mean_invstd, mhe_stat_t *stats,
                            long P, int C, int dtype, void *stream);
-int mhe_bn_bwd_finalize(const float *stats, const float *gamma, const float *mean_invstd, float *dgamma,
-                        float *dbeta, float *coef, int C, float count, void *stream);
+int mhe_bn_bwd_finalize(const mhe_stat_t *stats, const float *gamma, const float *mean_invstd, float *dgamma,
+                        float *dbeta, float *coef, int C, double count, void *stream);
 int mhe_bn_bwd_apply_nhwc(const void *g, const void *a, const void *y, const float *coef, void *gy, void *g_masked,
                           long P, int C, int dtype, void *stream);
 /* 3x3/s2/p1 max pool recording the winning tap (first maximum, as torch), and its reverse gather. */
@@ -589,7 +598,7 @@ int mhe_maxpool3x3s2_bwd_nhwc(const void *gy, const unsigned char *idx, void *gx
 int mhe_maxpool3x3s2_idx_affine_nhwc(const void *x, const float *scale, const float *shift, void *y, unsigned char *idx, int B, int H, int W,
                                      int C, int dtype, void *stream);
 int mhe_maxpool3x3s2_bwd_bn_nhwc(const void *gy, const unsigned char *idx, const void *y, const float *scale, const float *shift,
-                                 const float *mean_invstd, float *stats, void *gx, int B, int H, int W, int C, int dtype, void *stream);
+                                 const float *mean_invstd, mhe_stat_t *stats, void *gx, int B, int H, int W, int C, int dtype, void *stream);
 /* (gx may be NULL: the sums only.)  The same walk with the finished BatchNorm-reverse coefficients coef = k2 | k1 | k0 [3][C] (mhe_bn_bwd_finalize):
  * gy_out = k2 (scattered, gated gradient) + k1 y + k0 - mhe_bn_bwd_apply_nhwc's result without the scattered gradient ever being stored. */
 int mhe_maxpool3x3s2_bwd_bn_apply_nhwc(const void *gy, const unsigned char *idx, const void *y, const float *scale, const float *shift,

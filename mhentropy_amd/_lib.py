@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmhe_hip.so")
 
-_p, _i, _f, _sz, _l = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_long
+_p, _i, _f, _sz, _l, _d = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_long, C.c_double
 
 
 class ConvDesc(C.Structure):
@@ -56,9 +56,9 @@ SIGNATURES = {
     "mhe_flow_mask_pad_mixed": (_i, [_p, _p, _p, _p, _l, _i, _p]),
     "mhe_flow_couple_bwd_mixed": (_i, [_p] * 6 + [_f] + [_p] * 8 + [_l, _i, _i, _p]),
     "mhe_flow_couple_accum_f32": (_i, [_p] * 5 + [_l, _i, _p]),
-    "mhe_bn_mean_invstd": (_i, [_p, _p, _i, _f, _f, _p]),
+    "mhe_bn_mean_invstd": (_i, [_p, _p, _i, _d, _f, _p]),
     "mhe_bn_bwd_reduce_nhwc": (_i, [_p] * 5 + [_l, _i, _i, _p]),
-    "mhe_bn_bwd_finalize": (_i, [_p] * 6 + [_i, _f, _p]),
+    "mhe_bn_bwd_finalize": (_i, [_p] * 6 + [_i, _d, _p]),
     "mhe_bn_bwd_apply_nhwc": (_i, [_p] * 6 + [_l, _i, _i, _p]),
     "mhe_maxpool3x3s2_idx_nhwc": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mhe_maxpool3x3s2_bwd_nhwc": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
@@ -106,23 +106,24 @@ SIGNATURES = {
     "mhe_conv3x3_halo_dgrad_bn_nhwc": (_i, [_i] * 5 + [_p] * 12),
     "mhe_conv3x3_halo_nhwc": (_i, [_i] * 5 + [_p] * 5 + [_i] + [_p] * 8),
     "mhe_conv1x1_cat_bias_nhwc": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p]),
-    "mhe_conv3_bn_fold": (_i, [_p] * 6 + [_f] + [_p] * 4 + [_i, _p, _i] + [_p] * 2 + [_i, _i, _p]),
+    "mhe_conv3_bn_fold": (_i, [_p] * 6 + [_d] + [_p] * 4 + [_i, _p, _i] + [_p] * 2 + [_i, _i, _p]),
     "mhe_flow_reverse_chain_supported": (_i, [_i, _i, _i, _i, _i]),
     "mhe_flow_couplings_frag_supported": (_i, [_i, _i, _i, _i, _i]),
     "mhe_flow_couplings_frag_bf16": (_i, [_p, _p, _p, _i, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mhe_flow_reverse_chain_bf16": (_i, [_p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _i, _p, _l, _p, _i, _i, _i, _i, _i, _p]),
     "mhe_pack_transpose_bf16": (_i, [_p, _l, _p, _p, _i, _i, _p]),
-    "mhe_gram_stats_floats": (_sz, [_i]),
+    "mhe_gram_stats_words": (_sz, [_i]),
+    "mhe_stat_words": (_sz, [_i]),
     "mhe_gram_stats_workspace_bytes": (_sz, [_i]),
     "mhe_conv1x1_gram_nhwc": (_i, [_p, _p, _p, _i, _p, _l, _i, _p]),
     "mhe_conv1x1_gram_store_nhwc": (_i, [_p, _p, _p, _i, _p, _p, _l, _i, _p]),
-    "mhe_gram_bn_finalize": (_i, [_p] * 10 + [_i, _i, _f, _f, _f, _p, _p]),
+    "mhe_gram_bn_finalize": (_i, [_p] * 10 + [_i, _i, _d, _f, _f, _p, _p]),
     "mhe_bottleneck_tail_supported": (_i, [_p, _i]),
     "mhe_bottleneck_tail_nhwc": (_i, [_p, _i] + [_p] * 14),
     "mhe_stem_pool_supported": (_i, [_i, _i, _i, _i]),
     "mhe_stem_conv7x7s2_pool": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
-    "mhe_bn_finalize": (_i, [_p] * 8 + [_i, _f, _f, _f, _p]),
-    "mhe_bn_finalize_step": (_i, [_p] * 8 + [_i, _f, _f, _f, _i, _p, _p]),
+    "mhe_bn_finalize": (_i, [_p] * 8 + [_i, _d, _f, _f, _p]),
+    "mhe_bn_finalize_step": (_i, [_p] * 8 + [_i, _d, _f, _f, _i, _p, _p]),
     "mhe_bn_act_nhwc": (_i, [_p] * 7 + [_l, _i, _i, _i, _p]),
     "mhe_maxpool3x3s2_nhwc": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mhe_avgpool_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
@@ -138,7 +139,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 2          # MHE_ABI_VERSION of include/mhe.h
+ABI_VERSION = 3          # MHE_ABI_VERSION of include/mhe.h
 
 
 class MheError(RuntimeError):

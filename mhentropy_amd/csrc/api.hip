@@ -13,5 +13,6 @@ void set_error(const char *fmt, ...) {
 }  // namespace mhe
 
 // 2: mhe_conv_desc grew `tile` and `res_half` (read by every convolution entry) and mhe_conv_wgrad_nhwc takes the descriptor
-extern "C" int mhe_abi_version(void) { return 2; }
+// 3: statistic accumulators are fixed-point mhe_stat_t words (order-independent integer atomics); pixel counts are double
+extern "C" int mhe_abi_version(void) { return 3; }
 extern "C" const char *mhe_last_error(void) { return mhe::g_err; }

@@ -54,6 +54,65 @@ __device__ __forceinline__ u16 f32_to_bf16(float f) {
     return __builtin_bit_cast(u16, b);
 }
 
+// ---- order-independent statistic accumulators ----------------------------------------------------------------------------------
+// Every per-channel sum that many workgroups contribute to (BatchNorm batch statistics, Gram matrices, BatchNorm-reverse sums, bias
+// gradients) is accumulated in 64-bit FIXED POINT with integer atomics: integer addition is associative, so the total does not depend
+// on the order in which workgroups arrive - two runs of one launch, eager or replayed from a HIP graph, give the same bits (the f32
+// atomics of rounds 1-3 did not: one flipped bf16 rounding after 53 train-mode BatchNorm layers moved the C2 loss by 3e-3 ... 2e-2).
+//   two-word form (BatchNorm sums):  v = W0 * 2^-16 + W1 * 2^-56, W0 = rint(v 2^16), W1 = rint((v 2^16 - W0) 2^40): an f32 partial whose
+//       lowest bit is >= 2^-56 is represented EXACTLY (|v| >= 2^-32 for a full 24-bit mantissa); |partial| < 2^32, |shard total| < 2^39;
+//   one-word form (Gram matrices of normalised activations): quantum 2^-20.
+// A partial that is NaN / Inf / out of range plants a sticky marker (atomicMax to 2^62; legitimate shard totals stay below 2^55, so the
+// marker survives later adds): the finalize kernels turn it into NaN, as the f32 sum would have become.
+namespace fx {
+typedef long long acc_t;
+constexpr int NSH = 64;                                   // shards per unit: workgroup b adds into shard b % NSH
+constexpr long long MARK = 1ll << 62, LIMIT = 1ll << 61;
+__device__ __forceinline__ void add_word(acc_t *p, float x) {
+    if (x != 0.f) atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)(long long)x);
+}
+// one-word form, quantum 2^-20
+__device__ __forceinline__ void add1(acc_t *p, float v) {
+    const float s = v * 0x1p20f;
+    if (fabsf(s) < 0x1p48f) add_word(p, rintf(s));
+    else atomicMax(p, MARK);
+}
+__device__ __forceinline__ bool marked(acc_t w) { return w >= LIMIT || w <= -LIMIT; }
+__host__ __device__ __forceinline__ double value1(acc_t w) { return (double)w * 0x1p-20; }
+// two-word form: plane 0 = [NSH][2][C] words of quantum 2^-16, plane 1 (at + NSH * 2 * C) the remainders of quantum 2^-56
+__device__ __forceinline__ size_t plane(int C) { return (size_t)NSH * 2 * C; }
+__device__ __forceinline__ void add2(acc_t *p, size_t lo_off, float v) {
+    const float s = v * 0x1p16f;
+    if (fabsf(s) < 0x1p48f) {
+        const float h = rintf(s);
+        add_word(p, h);
+        add_word(p + lo_off, rintf((s - h) * 0x1p40f));
+    } else atomicMax(p, MARK);
+}
+// unit = the accumulators of one BatchNorm unit, [2 planes][NSH][2 statistics][C]
+__device__ __forceinline__ void add(acc_t *unit, int shard, int stat, int C, int c, float v) {
+    add2(unit + ((size_t)shard * 2 + stat) * C + c, plane(C), v);
+}
+__host__ __device__ __forceinline__ double value2(acc_t hi, acc_t lo) { return (double)hi * 0x1p-16 + (double)lo * 0x1p-56; }
+// lane = shard: the unit's total of (stat, c) over the 64 shards, exact (integer wave reduction), NaN if any shard carries the marker.
+// clear: the words are zeroed on the way (self-cleaning arena)
+__device__ __forceinline__ double wave_total(acc_t *unit, int stat, int C, int c, int lane, bool clear) {
+    acc_t *p = unit + ((size_t)lane * 2 + stat) * C + c;
+    acc_t hi = p[0], lo = p[plane(C)];
+    if (clear) { p[0] = 0; p[plane(C)] = 0; }
+    const bool bad = __any(marked(hi));
+    if (__any(hi >= (1ll << 55) || hi <= -(1ll << 55))) {       // (the integer sum of 64 such words could wrap: fixed-order sum of doubles)
+        double d = value2(hi, lo);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+        return bad ? __builtin_nan("") : d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { hi += __shfl_xor(hi, o, 64); lo += __shfl_xor(lo, o, 64); }
+    return bad ? __builtin_nan("") : value2(hi, lo);
+}
+}  // namespace fx
+
 // 4 consecutive elements of f32 or bf16 storage <-> 4 floats (8/16-byte accesses)
 template <typename T> __device__ __forceinline__ void load4(const T *p, float *v);
 template <> __device__ __forceinline__ void load4<float>(const float *p, float *v) {

@@ -453,34 +453,30 @@ __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ x, 
 }
 
 // ---------------------------------------------------------------------------
-// one wavefront per channel: lane = statistic shard (NSH == 64), sums combined in f64 by a wave reduction (the serial walk over
-// the 64 shards made this ~6 us latency-bound kernel, launched once per BatchNorm, 3 % of the forward step)
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ stats, const float *__restrict__ gamma,
+// one wavefront per channel: lane = statistic shard (NSH == 64); the shard words are summed as INTEGERS (exact, order-free) and
+// decoded to f64 once (the serial walk over the 64 shards made this ~6 us latency-bound kernel, launched once per BatchNorm, 3 % of
+// the forward step).  `stats` is read and - clear != 0 - zeroed through the SAME pointer (loads first, then the zero stores).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(mhe_stat_t *stats, const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, float *__restrict__ rmean, float *__restrict__ rvar,
                                                           float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean_invstd, int C,
-                                                          float count, float momentum, float eps, float *__restrict__ stats_clear,
+                                                          double count, float momentum, float eps, int clear,
                                                           long long *__restrict__ num_batches_tracked) {
     static_assert(NSH == 64, "one lane per statistic shard");
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;      // nn.BatchNorm2d's counter (int64)
     if (c >= C) return;
-    // shard sums are f32 (each shard holds <= M/(128*NSH) block partials); combine them in f64 so that
-    // E[x^2] - E[x]^2 keeps fp32-level accuracy
-    double s1 = (double)stats[((size_t)lane * 2) * C + c], s2 = (double)stats[((size_t)lane * 2 + 1) * C + c];
     // self-cleaning accumulators: the arena is zero again when the next forward starts (no memset launch per step)
-    if (stats_clear) { stats_clear[((size_t)lane * 2) * C + c] = 0.f; stats_clear[((size_t)lane * 2 + 1) * C + c] = 0.f; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    const double s1 = fx::wave_total(stats, 0, C, c, lane, clear != 0), s2 = fx::wave_total(stats, 1, C, c, lane, clear != 0);
     if (lane) return;
-    const double dmean = s1 / (double)count;
-    const double dvar = fmax(s2 / (double)count - dmean * dmean, 0.0);   // biased, as F.batch_norm normalises with
+    const double dmean = s1 / count;
+    const double dvar = fmax(s2 / count - dmean * dmean, 0.0);   // biased, as F.batch_norm normalises with
     const float mean = (float)dmean, var = (float)dvar;
     const float sc = gamma[c] / sqrtf(var + eps);
     scale[c] = sc;
     shift[c] = beta[c] - mean * sc;
     if (mean_invstd) { mean_invstd[c] = mean; mean_invstd[C + c] = 1.f / sqrtf(var + eps); }     // kept for the reverse pass
     if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
-    if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * var * (count / (count - 1.f));
+    if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * var * (float)(count / (count - 1.0));
 }
 
 // y = relu?(x*scale+shift + (res*rscale+rshift | res))   4 channels per thread
@@ -769,14 +765,14 @@ static inline int elem_chunk(int dtype) { return dtype == MHE_F32 ? 4 : 8; }
 
 static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
                       const float *in_shift, const float *out_scale, const float *out_shift, const void *residual,
-                      float *stats, const void *x2, const float *x2_scale, const float *x2_shift, void *a_out, void *stream,
+                      mhe_stat_t *stats, const void *x2, const float *x2_scale, const float *x2_shift, void *a_out, void *stream,
                       const void *mask = nullptr, const struct BnRev *bn = nullptr, float *y32 = nullptr, const int *scatter = nullptr,
                       const void *xcat = nullptr, int cin2 = 0, const void *mask_bits = nullptr);
-struct BnRev { const void *y[2]; const float *mi[2]; float *stats[2]; };
+struct BnRev { const void *y[2]; const float *mi[2]; mhe_stat_t *stats[2]; };
 
 extern "C" int mhe_conv2d_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
                                const float *in_shift, const float *out_scale, const float *out_shift,
-                               const void *residual, float *stats, void *stream) {
+                               const void *residual, mhe_stat_t *stats, void *stream) {
     return conv_entry(d, x, w, y, in_scale, in_shift, out_scale, out_shift, residual, stats, nullptr, nullptr, nullptr,
                       nullptr, stream);
 }
@@ -789,7 +785,7 @@ extern "C" int mhe_conv2d_f32out_nhwc(const mhe_conv_desc *d, const void *x, con
 
 extern "C" int mhe_conv1x1_residual_in_nhwc(const mhe_conv_desc *d, const void *x, const void *x2, const void *w, void *y,
                                             const float *in_scale, const float *in_shift, const float *x2_scale,
-                                            const float *x2_shift, void *a_out, float *stats, void *stream) {
+                                            const float *x2_shift, void *a_out, mhe_stat_t *stats, void *stream) {
     MHE_REQUIRE(d && x2 && in_scale && in_shift, "mhe_conv1x1_residual_in_nhwc: x2, in_scale and in_shift are required");
     MHE_REQUIRE(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0, "mhe_conv1x1_residual_in_nhwc: 1x1 stride-1 only");
     MHE_REQUIRE((x2_scale == nullptr) == (x2_shift == nullptr), "mhe_conv1x1_residual_in_nhwc: x2_scale/x2_shift must come together");
@@ -808,7 +804,7 @@ extern "C" int mhe_conv1x1_cat_bias_nhwc(const mhe_conv_desc *d, const void *x, 
 extern "C" int mhe_conv1x1_residual_in_masked_nhwc(const mhe_conv_desc *d, const void *x, const void *x2, const void *w, void *y,
                                                    const float *in_scale, const float *in_shift, const float *x2_scale,
                                                    const float *x2_shift, void *a_out, const void *residual, const void *mask,
-                                                   const void *bn_y0, const float *bn_mean_invstd0, float *bn_stats0, void *stream) {
+                                                   const void *bn_y0, const float *bn_mean_invstd0, mhe_stat_t *bn_stats0, void *stream) {
     MHE_REQUIRE(d && x2 && in_scale && in_shift && mask, "mhe_conv1x1_residual_in_masked_nhwc: x2, in_scale, in_shift and mask are required");
     MHE_REQUIRE(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0, "mhe_conv1x1_residual_in_masked_nhwc: 1x1 stride-1 only");
     MHE_REQUIRE((x2_scale == nullptr) == (x2_shift == nullptr), "mhe_conv1x1_residual_in_masked_nhwc: x2_scale/x2_shift must come together");
@@ -820,8 +816,8 @@ extern "C" int mhe_conv1x1_residual_in_masked_nhwc(const mhe_conv_desc *d, const
 }
 
 extern "C" int mhe_conv2d_masked_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const void *residual,
-                                      const void *mask, const void *bn_y0, const float *bn_mean_invstd0, float *bn_stats0,
-                                      const void *bn_y1, const float *bn_mean_invstd1, float *bn_stats1, void *stream) {
+                                      const void *mask, const void *bn_y0, const float *bn_mean_invstd0, mhe_stat_t *bn_stats0,
+                                      const void *bn_y1, const float *bn_mean_invstd1, mhe_stat_t *bn_stats1, void *stream) {
     MHE_REQUIRE(mask, "mhe_conv2d_masked_nhwc: mask is required");
     MHE_REQUIRE((!bn_y0 || (bn_mean_invstd0 && bn_stats0)) && (!bn_y1 || (bn_y0 && bn_mean_invstd1 && bn_stats1)),
                 "mhe_conv2d_masked_nhwc: each bn_y needs its mean_invstd and stats (and bn_y1 needs bn_y0)");
@@ -830,8 +826,8 @@ extern "C" int mhe_conv2d_masked_nhwc(const mhe_conv_desc *d, const void *x, con
 }
 
 extern "C" int mhe_conv2d_masked_bits_nhwc(const mhe_conv_desc *d, const void *x, const void *w, void *y, const void *residual,
-                                           const void *mask, const void *mask_bits, const void *bn_y0, const float *bn_mean_invstd0, float *bn_stats0,
-                                           const void *bn_y1, const float *bn_mean_invstd1, float *bn_stats1, void *stream) {
+                                           const void *mask, const void *mask_bits, const void *bn_y0, const float *bn_mean_invstd0, mhe_stat_t *bn_stats0,
+                                           const void *bn_y1, const float *bn_mean_invstd1, mhe_stat_t *bn_stats1, void *stream) {
     MHE_REQUIRE(mask, "mhe_conv2d_masked_bits_nhwc: mask is required (kernels without the bit path read it)");
     MHE_REQUIRE((!bn_y0 || (bn_mean_invstd0 && bn_stats0)) && (!bn_y1 || (bn_y0 && bn_mean_invstd1 && bn_stats1)),
                 "mhe_conv2d_masked_bits_nhwc: each bn_y needs its mean_invstd and stats (and bn_y1 needs bn_y0)");
@@ -843,7 +839,7 @@ extern "C" int mhe_conv2d_masked_bits_nhwc(const mhe_conv_desc *d, const void *x
 
 extern "C" int mhe_conv2d_masked_bias_nhwc(const mhe_conv_desc *d, const void *x, const void *xcat, int cin2, const void *w, void *y,
                                            const void *residual, const void *mask, const float *bias, const void *bn_y0,
-                                           const float *bn_mean_invstd0, float *bn_stats0, void *stream) {
+                                           const float *bn_mean_invstd0, mhe_stat_t *bn_stats0, void *stream) {
     MHE_REQUIRE(mask && bias, "mhe_conv2d_masked_bias_nhwc: mask and bias are required");
     MHE_REQUIRE(!xcat || (d && d->dtype == MHE_BF16 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && cin2 > 0 && cin2 % 64 == 0 && d->Cin % 64 == 0),
                 "mhe_conv2d_masked_bias_nhwc: a concatenated operand needs a bf16 1x1 stride-1 launch with Cin and cin2 multiples of 64");
@@ -856,8 +852,8 @@ extern "C" int mhe_conv2d_masked_bias_nhwc(const mhe_conv_desc *d, const void *x
 
 extern "C" int mhe_conv3x3s2_dgrad_nhwc(int B, int Ho, int Wo, int Cout, int Cin, int dtype, const void *gy, const void *const *w4,
                                         void *dx, const void *residual, const void *mask, const void *bn_y0,
-                                        const float *bn_mean_invstd0, float *bn_stats0, const void *bn_y1,
-                                        const float *bn_mean_invstd1, float *bn_stats1, int tile, void *stream) {
+                                        const float *bn_mean_invstd0, mhe_stat_t *bn_stats0, const void *bn_y1,
+                                        const float *bn_mean_invstd1, mhe_stat_t *bn_stats1, int tile, void *stream) {
     MHE_REQUIRE(gy && w4 && dx && w4[0] && w4[1] && w4[2] && w4[3], "mhe_conv3x3s2_dgrad_nhwc: null pointer");
     MHE_REQUIRE((!bn_y0 || (bn_mean_invstd0 && bn_stats0 && mask)) && (!bn_y1 || (bn_y0 && bn_mean_invstd1 && bn_stats1)),
                 "mhe_conv3x3s2_dgrad_nhwc: each bn_y needs its mean_invstd and stats (and the gate)");
@@ -876,7 +872,7 @@ extern "C" int mhe_conv3x3s2_dgrad_nhwc(int B, int Ho, int Wo, int Cout, int Cin
 
 static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void *y, const float *in_scale,
                       const float *in_shift, const float *out_scale, const float *out_shift, const void *residual,
-                      float *stats, const void *x2, const float *x2_scale, const float *x2_shift, void *a_out, void *stream,
+                      mhe_stat_t *stats, const void *x2, const float *x2_scale, const float *x2_shift, void *a_out, void *stream,
                       const void *mask, const BnRev *bn, float *y32, const int *scatter, const void *xcat, int cin2, const void *mask_bits) {
     MHE_REQUIRE(d && x && w && (y || y32), "mhe_conv2d_nhwc: null pointer");
     MHE_REQUIRE(d->dtype == MHE_F32 || d->dtype == MHE_BF16, "mhe_conv2d_nhwc: dtype=%d", d->dtype);
@@ -924,7 +920,7 @@ static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void
 
 // ---- the statistics-only pass and the fused bottleneck tail that re-evaluates conv3 (conv_fuse.hip)
 extern "C" int mhe_conv1x1_stats_nhwc(const mhe_conv_desc *d, const void *x, const void *w, const float *in_scale, const float *in_shift,
-                                      float *stats, void *stream) {
+                                      mhe_stat_t *stats, void *stream) {
     MHE_REQUIRE(d && x && w && stats, "mhe_conv1x1_stats_nhwc: null pointer");
     MHE_REQUIRE(d->dtype == MHE_BF16 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && (d->Cin == 64 || d->Cin == 128) && d->Cout % 256 == 0,
                 "mhe_conv1x1_stats_nhwc: bf16 1x1 stride-1 with 64 / 128 input channels and a multiple of 256 output channels");
@@ -953,7 +949,7 @@ extern "C" int mhe_bottleneck_tail_supported(const mhe_conv_desc *d, int Cb) {
 
 extern "C" int mhe_bottleneck_tail_nhwc(const mhe_conv_desc *d, int Cb, const void *y2, const float *bn2_scale, const float *bn2_shift,
                                         const void *w3, const float *bn3_scale, const float *bn3_shift, const void *identity,
-                                        const float *id_scale, const float *id_shift, const void *w1, void *a_out, void *y1, float *stats,
+                                        const float *id_scale, const float *id_shift, const void *w1, void *a_out, void *y1, mhe_stat_t *stats,
                                         void *stream) {
     return mhe_bottleneck_tail_bits_nhwc(d, Cb, y2, bn2_scale, bn2_shift, w3, bn3_scale, bn3_shift, identity, id_scale, id_shift, w1, a_out, nullptr, y1, stats, stream);
 }
@@ -961,7 +957,7 @@ extern "C" int mhe_bottleneck_tail_nhwc(const mhe_conv_desc *d, int Cb, const vo
 extern "C" int mhe_bottleneck_tail_bits_nhwc(const mhe_conv_desc *d, int Cb, const void *y2, const float *bn2_scale, const float *bn2_shift,
                                              const void *w3, const float *bn3_scale, const float *bn3_shift, const void *identity,
                                              const float *id_scale, const float *id_shift, const void *w1, void *a_out, void *a_bits, void *y1,
-                                             float *stats, void *stream) {
+                                             mhe_stat_t *stats, void *stream) {
     MHE_REQUIRE(d && y2 && bn2_scale && bn2_shift && w3 && bn3_scale && bn3_shift && identity && w1 && a_out && y1, "mhe_bottleneck_tail_nhwc: null pointer");
     MHE_REQUIRE(d->dtype == MHE_BF16, "mhe_bottleneck_tail_nhwc: bf16 storage only");
     MHE_REQUIRE((id_scale == nullptr) == (id_shift == nullptr), "mhe_bottleneck_tail_nhwc: id_scale/id_shift must come together");
@@ -980,6 +976,7 @@ extern "C" int mhe_bottleneck_tail_bits_nhwc(const mhe_conv_desc *d, int Cb, con
 }
 
 extern "C" int mhe_conv_stat_shards(void) { return conv::NSH; }
+extern "C" size_t mhe_stat_words(int C) { return C > 0 ? (size_t)2 * conv::NSH * 2 * (size_t)C : 0; }
 
 // which kernel variant the launcher picks for a geometry with plain operands (see mhe_conv_desc.tile); with a producer-BatchNorm /
 // residual-tail operand load variant 7 becomes 2
@@ -1012,7 +1009,7 @@ extern "C" int mhe_conv_tile_mode(const mhe_conv_desc *d, int mode) {
     return conv::choose_tile(p, d->Cin % bke == 0, d->dtype == MHE_BF16);
 }
 
-extern "C" int mhe_stem_conv7x7s2(const float *x_nchw, const void *w, void *y, float *stats, int B, int H, int W, int dtype,
+extern "C" int mhe_stem_conv7x7s2(const float *x_nchw, const void *w, void *y, mhe_stat_t *stats, int B, int H, int W, int dtype,
                                   void *stream) {
     MHE_REQUIRE(x_nchw && w && y, "mhe_stem_conv7x7s2: null pointer");
     MHE_REQUIRE(B > 0 && H > 0 && W > 0, "mhe_stem_conv7x7s2: bad geometry");
@@ -1043,21 +1040,21 @@ extern "C" int mhe_linear_f32(const float *X, const float *W, const float *bias,
     return mhe_conv2d_nhwc(&d, X, W, Y, nullptr, nullptr, nullptr, bias, nullptr, nullptr, stream);
 }
 
-extern "C" int mhe_bn_finalize(const float *stats, const float *gamma, const float *beta, float *running_mean,
-                               float *running_var, float *scale, float *shift, float *mean_invstd, int C, float count,
+extern "C" int mhe_bn_finalize(const mhe_stat_t *stats, const float *gamma, const float *beta, float *running_mean,
+                               float *running_var, float *scale, float *shift, float *mean_invstd, int C, double count,
                                float momentum, float eps, void *stream) {
     MHE_REQUIRE(stats && gamma && beta && scale && shift && C > 0 && count > 1.f, "mhe_bn_finalize: bad arguments");
-    hipLaunchKernelGGL(conv::bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, stats, gamma,
-                       beta, running_mean, running_var, scale, shift, mean_invstd, C, count, momentum, eps, (float *)nullptr, (long long *)nullptr);
+    hipLaunchKernelGGL(conv::bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, const_cast<mhe_stat_t *>(stats), gamma,
+                       beta, running_mean, running_var, scale, shift, mean_invstd, C, count, momentum, eps, 0, (long long *)nullptr);
     return check_launch("bn_finalize_kernel");
 }
 
-extern "C" int mhe_bn_finalize_step(float *stats, const float *gamma, const float *beta, float *running_mean,
-                                    float *running_var, float *scale, float *shift, float *mean_invstd, int C, float count,
+extern "C" int mhe_bn_finalize_step(mhe_stat_t *stats, const float *gamma, const float *beta, float *running_mean,
+                                    float *running_var, float *scale, float *shift, float *mean_invstd, int C, double count,
                                     float momentum, float eps, int clear_stats, long long *num_batches_tracked, void *stream) {
     MHE_REQUIRE(stats && gamma && beta && scale && shift && C > 0 && count > 1.f, "mhe_bn_finalize_step: bad arguments");
     hipLaunchKernelGGL(conv::bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, stats, gamma,
-                       beta, running_mean, running_var, scale, shift, mean_invstd, C, count, momentum, eps, clear_stats ? stats : (float *)nullptr,
+                       beta, running_mean, running_var, scale, shift, mean_invstd, C, count, momentum, eps, clear_stats,
                        num_batches_tracked);
     return check_launch("bn_finalize_kernel");
 }

@@ -20,7 +20,7 @@ namespace mhe { namespace fold {
 // one wave per output channel c of conv3
 template <int CB>
 __global__ __launch_bounds__(256) void channel_kernel(float *__restrict__ D, const u16 *__restrict__ w, const double *__restrict__ tot,
-                                                      const float *__restrict__ stats, const float *__restrict__ gamma,
+                                                      const mhe_stat_t *__restrict__ stats, const float *__restrict__ gamma,
                                                       const float *__restrict__ mean_invstd, float *__restrict__ dgamma, float *__restrict__ dbeta,
                                                       float *__restrict__ dW, u16 *__restrict__ w_dg, float *__restrict__ coef, int C, int ldg,
                                                       double count) {
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void channel_kernel(float *__restrict__ D, con
     __shared__ double wl[4][CB];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, c = blockIdx.x * 4 + wv;
     if (c >= C) return;                                          // (whole waves leave together: the LDS exchange below is wave-local)
-    double s1 = (double)stats[((size_t)lane * 2) * C + c];       // lane = statistic shard
+    const double s1 = fx::wave_total(const_cast<mhe_stat_t *>(stats), 0, C, c, lane, false);       // lane = statistic shard
     double wk[NC], dk[NC], sw = 0.0;
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void channel_kernel(float *__restrict__ D, con
         sw = fma(wk[k], dk[k], sw);
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); sw += __shfl_xor(sw, o, 64); }
+    for (int o = 32; o > 0; o >>= 1) sw += __shfl_xor(sw, o, 64);
     wave_sync();
     const double mean = (double)mean_invstd[c], invstd = (double)mean_invstd[C + c];
     const double s2 = invstd * (sw - mean * s1);                 // sum g xhat
@@ -110,8 +110,8 @@ __global__ __launch_bounds__(1024) void gram_side_kernel(const u16 *__restrict__
 
 using namespace mhe;
 
-extern "C" int mhe_conv3_bn_fold(float *D, const void *w_bf16, const double *gram_totals, const float *rev_stats, const float *gamma,
-                                 const float *mean_invstd, float count, float *dgamma, float *dbeta, float *dW, void *w_dg_bf16, int ld_dg,
+extern "C" int mhe_conv3_bn_fold(float *D, const void *w_bf16, const double *gram_totals, const mhe_stat_t *rev_stats, const float *gamma,
+                                 const float *mean_invstd, double count, float *dgamma, float *dbeta, float *dW, void *w_dg_bf16, int ld_dg,
                                  void *S_bf16, int ld_S, float *c0, float *coef_ws, int C, int Cb, void *stream) {
     MHE_REQUIRE(D && w_bf16 && gram_totals && rev_stats && gamma && mean_invstd && dgamma && dbeta && dW && w_dg_bf16 && S_bf16 && c0 && coef_ws,
                 "mhe_conv3_bn_fold: null pointer");

@@ -336,9 +336,8 @@ __global__ __launch_bounds__(512) void bottleneck_tail_kernel(const Params p) {
             const int ch = tid >> 3, e = tid & 7;
             float a = 0.f, b = 0.f;
             for (int k = 0; k < RPP; ++k) { a += red[(ch + CPR2 * k) * 16 + e]; b += red[(ch + CPR2 * k) * 16 + 8 + e]; }
-            float *st = p.stats + (size_t)((int)blockIdx.x % NSH) * 2 * N2;
-            atomicAdd(st + tid, a);
-            atomicAdd(st + N2 + tid, b);
+            fx::add(p.stats, (int)blockIdx.x % NSH, 0, N2, tid, a);
+            fx::add(p.stats, (int)blockIdx.x % NSH, 1, N2, tid, b);
         }
     }
 }

@@ -12,7 +12,8 @@
 // reference's f32 arithmetic, different from the unfused path by the rounding noise of the sums (~1e-4 of the variance).
 //   gram_kernel     : persistent workgroups, 128-pixel tiles register-staged into a double-buffered LDS image ([pixel][channel] rows, 64-byte
 //                     segments XOR-swizzled as in wgrad.hip), G accumulated on v_mfma_f32_32x32x16_bf16 from transposing reads
-//                     (ds_read_b64_tr_b16) over the workgroup's whole life, one round of f32 atomics into a shard at the end;
+//                     (ds_read_b64_tr_b16) over the workgroup's whole life, one round of fixed-point integer atomics (common.h, fx::add1: the totals
+//                     do not depend on the order the workgroups arrive in) into a shard at the end;
 //   gram_combine    : shards -> f64 totals (and clears the shards: the arena is clean for the next step);
 //   gram_finalize   : one wave per output channel: w^T G w and w . m in f64 -> mean, variance -> scale / shift (+ running statistics).
 #include "conv_shared.h"
@@ -31,7 +32,7 @@ __device__ __forceinline__ int gseg_swz(int pitch, int row) { return pitch >= 25
 
 template <int CB>
 __global__ __launch_bounds__(256) void gram_kernel(const u16 *__restrict__ x, const float *__restrict__ in_scale, const float *__restrict__ in_shift,
-                                                   float *__restrict__ gram, int M, int relu, u16 *__restrict__ a_out) {
+                                                   fx::acc_t *__restrict__ gram, int M, int relu, u16 *__restrict__ a_out) {
     constexpr int PA = CB * 2, CPR = CB / 8, RPP = 256 / CPR, NJ = GPX / RPP;      // row pitch (bytes), 16-byte chunks per row, rows per pass, passes
     constexpr int TW = CB / 64;                                                    // 32 x 32 tiles per wave and dimension (waves 2 x 2)
     constexpr int GE = CB * CB + CB;                                               // floats per shard: G then m
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const u16 *__restrict__ x, co
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8g, fa[i]), __builtin_bit_cast(bf8g, fb[j]), acc[i][j], 0, 0, 0);
         }
     }
-    float *dst = gram + (size_t)((int)blockIdx.x % GSH) * GE;
+    fx::acc_t *dst = gram + (size_t)((int)blockIdx.x % GSH) * GE;
 #pragma unroll
     for (int i = 0; i < TW; ++i)
 #pragma unroll
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const u16 *__restrict__ x, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = (wm * TW + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                atomicAdd(dst + m * CB + n, acc[i][j][r]);
+                fx::add1(dst + m * CB + n, acc[i][j][r]);
             }
         }
     // column sums: RPP threads share a channel chunk
@@ -136,18 +137,19 @@ __global__ __launch_bounds__(256) void gram_kernel(const u16 *__restrict__ x, co
         const int c8 = tid >> 3, e = tid & 7;
         float a = 0.f;
         for (int k = 0; k < RPP; ++k) a += red[(c8 + CPR * k) * 8 + e];
-        atomicAdd(dst + CB * CB + tid, a);
+        fx::add1(dst + CB * CB + tid, a);
     }
 }
 
 // totals in f64; the shards are cleared on the way (self-cleaning accumulators)
-__global__ __launch_bounds__(256) void gram_combine_kernel(float *__restrict__ gram, double *__restrict__ tot, int ge) {
+__global__ __launch_bounds__(256) void gram_combine_kernel(fx::acc_t *__restrict__ gram, double *__restrict__ tot, int ge) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= ge) return;
-    double a = 0.0;
+    fx::acc_t a = 0;
+    bool bad = false;
 #pragma unroll
-    for (int s = 0; s < GSH; ++s) { a += (double)gram[(size_t)s * ge + e]; gram[(size_t)s * ge + e] = 0.f; }
-    tot[e] = a;
+    for (int s = 0; s < GSH; ++s) { const fx::acc_t w = gram[(size_t)s * ge + e]; bad |= fx::marked(w); a += w; gram[(size_t)s * ge + e] = 0; }
+    tot[e] = bad ? __builtin_nan("") : fx::value1(a);
 }
 
 // one wave per output channel c: q = w^T G w, s = w . m in f64 -> the BatchNorm affine (torch semantics, as bn_finalize_kernel)
@@ -192,15 +194,15 @@ __global__ __launch_bounds__(256) void gram_finalize_kernel(const double *__rest
 
 using namespace mhe;
 
-extern "C" size_t mhe_gram_stats_floats(int Cb) { return (Cb == 64 || Cb == 128) ? (size_t)conv::GSH * ((size_t)Cb * Cb + Cb) : 0; }
+extern "C" size_t mhe_gram_stats_words(int Cb) { return (Cb == 64 || Cb == 128) ? (size_t)conv::GSH * ((size_t)Cb * Cb + Cb) : 0; }
 extern "C" size_t mhe_gram_stats_workspace_bytes(int Cb) { return (Cb == 64 || Cb == 128) ? ((size_t)Cb * Cb + Cb) * sizeof(double) : 0; }
 
-extern "C" int mhe_conv1x1_gram_nhwc(const void *x, const float *in_scale, const float *in_shift, int relu_in, float *gram, long pixels, int Cb,
+extern "C" int mhe_conv1x1_gram_nhwc(const void *x, const float *in_scale, const float *in_shift, int relu_in, mhe_stat_t *gram, long pixels, int Cb,
                                      void *stream) {
     return mhe_conv1x1_gram_store_nhwc(x, in_scale, in_shift, relu_in, gram, nullptr, pixels, Cb, stream);
 }
 
-extern "C" int mhe_conv1x1_gram_store_nhwc(const void *x, const float *in_scale, const float *in_shift, int relu_in, float *gram, void *a_out,
+extern "C" int mhe_conv1x1_gram_store_nhwc(const void *x, const float *in_scale, const float *in_shift, int relu_in, mhe_stat_t *gram, void *a_out,
                                            long pixels, int Cb, void *stream) {
     MHE_REQUIRE(x && gram && pixels > 0 && pixels % conv::GPX == 0 && pixels < (1l << 31) && (Cb == 64 || Cb == 128),
                 "mhe_conv1x1_gram_nhwc: bf16 rows of 64 / 128 channels, pixel count a multiple of %d (pixels=%ld Cb=%d)", conv::GPX, pixels, Cb);
@@ -213,8 +215,8 @@ extern "C" int mhe_conv1x1_gram_store_nhwc(const void *x, const float *in_scale,
     return check_launch("gram_kernel");
 }
 
-extern "C" int mhe_gram_bn_finalize(float *gram, void *workspace, const void *w, const float *gamma, const float *beta, float *running_mean,
-                                    float *running_var, float *scale, float *shift, float *mean_invstd, int C, int Cb, float count,
+extern "C" int mhe_gram_bn_finalize(mhe_stat_t *gram, void *workspace, const void *w, const float *gamma, const float *beta, float *running_mean,
+                                    float *running_var, float *scale, float *shift, float *mean_invstd, int C, int Cb, double count,
                                     float momentum, float eps, long long *num_batches_tracked, void *stream) {
     MHE_REQUIRE(gram && workspace && w && gamma && beta && scale && shift && C > 0 && (Cb == 64 || Cb == 128) && count > 1.f,
                 "mhe_gram_bn_finalize: bad arguments");

@@ -358,8 +358,8 @@ extern "C" int mhe_conv3x3_halo_pack_bf16(const void *w, void *w_halo, int Cout,
 }
 
 extern "C" int mhe_conv3x3_halo_nhwc(int B, int H, int W, int Cin, int Cout, const void *x, const void *w_halo, void *y, const float *in_scale,
-                                     const float *in_shift, int relu_in, void *a_out, float *stats, const void *residual, const void *mask,
-                                     const void *bn_y0, const float *bn_mean_invstd0, float *bn_stats0, void *stream) {
+                                     const float *in_shift, int relu_in, void *a_out, mhe_stat_t *stats, const void *residual, const void *mask,
+                                     const void *bn_y0, const float *bn_mean_invstd0, mhe_stat_t *bn_stats0, void *stream) {
     MHE_REQUIRE(x && w_halo && y, "mhe_conv3x3_halo_nhwc: null pointer");
     MHE_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "mhe_conv3x3_halo_nhwc: in_scale/in_shift must come together");
     MHE_REQUIRE(!a_out || in_scale, "mhe_conv3x3_halo_nhwc: a_out is the normalised operand: it needs in_scale / in_shift");
@@ -379,7 +379,7 @@ extern "C" int mhe_conv3x3_halo_nhwc(int B, int H, int W, int Cin, int Cout, con
 
 extern "C" int mhe_conv3x3_halo_dgrad_bn_nhwc(int B, int H, int W, int Cin, int Cout, const void *g, const void *y_raw, const float *coef, const void *w_halo,
                                               void *gx, void *gy_out, const void *residual, const void *mask, const void *bn_y0,
-                                              const float *bn_mean_invstd0, float *bn_stats0, void *stream) {
+                                              const float *bn_mean_invstd0, mhe_stat_t *bn_stats0, void *stream) {
     MHE_REQUIRE(g && y_raw && coef && w_halo && gx && mask, "mhe_conv3x3_halo_dgrad_bn_nhwc: null pointer");
     MHE_REQUIRE(!bn_y0 || (bn_mean_invstd0 && bn_stats0), "mhe_conv3x3_halo_dgrad_bn_nhwc: bn_y needs its mean_invstd and stats");
     conv::Params p{};

@@ -14,8 +14,8 @@ struct Params {
     const void *mask;      // optional, shaped like y: outputs are zeroed where mask <= 0 (ReLU gate of a data gradient)
     // optional BatchNorm-reverse statistics of the (gated) outputs g: for up to two BN units whose raw outputs bn_y[u] are shaped like y,
     // bn_stats[u][shard][0][c] += sum g, [1][c] += sum g * (bn_y - mean) * invstd   (bn_mi[u] = [mean | invstd])
-    const void *bn_y[2]; const float *bn_mi[2]; float *bn_stats[2];
-    float *stats;          // [NSH][2][Cout] sharded accumulators
+    const void *bn_y[2]; const float *bn_mi[2]; fx::acc_t *bn_stats[2];
+    fx::acc_t *stats;      // [2][NSH][2][Cout] sharded fixed-point accumulators (common.h, namespace fx)
     // dual-input prologue (1x1, stride 1): operand = relu(x*in_scale+in_shift + (x2*x2_scale+x2_shift | x2)),
     // i.e. the tail of the previous residual block evaluated on load; a_out (optional) receives it once
     const void *x2; const float *x2_scale, *x2_shift; void *a_out;
@@ -49,7 +49,7 @@ __device__ __forceinline__ long out_pixel(const Params &p, int m) {
     return ((long)(b * 2 * p.Ho + 2 * i + p.os_py)) * (2 * p.Wo) + 2 * j + p.os_px;
 }
 
-constexpr int NSH = 64;          // statistic shards: block b adds into shard b % NSH
+constexpr int NSH = fx::NSH;     // statistic shards: block b adds into shard b % NSH
 constexpr int MAXC = 2048;       // largest Cin whose BatchNorm affine is staged in LDS
 
 template <typename T> struct El;
@@ -350,8 +350,8 @@ __device__ __forceinline__ void epilogue_store(const Params &p, unsigned char *o
                 float a = 0.f, b = 0.f;
                 for (int k = 0; k < NTH / CPR; ++k) { a += red[(c + CPR * k) * (2 * EPC) + e]; b += red[(c + CPR * k) * (2 * EPC) + EPC + e]; }
                 if (n < p.Cout) {
-                    atomicAdd(p.stats + ((size_t)shard * 2) * p.Cout + n, a);
-                    atomicAdd(p.stats + ((size_t)shard * 2 + 1) * p.Cout + n, b);
+                    fx::add(p.stats, shard, 0, p.Cout, n, a);
+                    fx::add(p.stats, shard, 1, p.Cout, n, b);
                 }
             }
         }
@@ -371,9 +371,8 @@ __device__ __forceinline__ void epilogue_store(const Params &p, unsigned char *o
                     float a = 0.f, b = 0.f;
                     for (int k = 0; k < NTH / CPR; ++k) { a += red[(c + CPR * k) * (2 * EPC) + e]; b += red[(c + CPR * k) * (2 * EPC) + EPC + e]; }
                     if (n < p.Cout) {
-                        float *st = p.bn_stats[u] + (size_t)shard * 2 * p.Cout;
-                        atomicAdd(st + n, a);
-                        atomicAdd(st + p.Cout + n, b);
+                        fx::add(p.bn_stats[u], shard, 0, p.Cout, n, a);
+                        fx::add(p.bn_stats[u], shard, 1, p.Cout, n, b);
                     }
                 }
             }

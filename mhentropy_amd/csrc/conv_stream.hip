@@ -260,9 +260,8 @@ void conv1x1_stream_kernel(const Params p, int nchunks, int ntiles_n) {
             if (tid < ST_BN)
                 for (int k = 0; k < NTH / CPR; ++k) { a += red[(cch + CPR * k) * 16 + e]; b += red[(cch + CPR * k) * 16 + 8 + e]; }
             if (tid < ST_BN && n < p.Cout) {
-                float *st = p.bn_stats[u] + (size_t)(wg % NSH) * 2 * p.Cout;
-                atomicAdd(st + n, a);
-                atomicAdd(st + p.Cout + n, b);
+                fx::add(p.bn_stats[u], wg % NSH, 0, p.Cout, n, a);
+                fx::add(p.bn_stats[u], wg % NSH, 1, p.Cout, n, b);
             }
         }
     }
@@ -278,8 +277,8 @@ void conv1x1_stream_kernel(const Params p, int nchunks, int ntiles_n) {
             for (int k = 0; k < NTH / CPR; ++k) { a += red[(cch + CPR * k) * 16 + e]; b += red[(cch + CPR * k) * 16 + 8 + e]; }
         if (tid < ST_BN && n < p.Cout) {
             const int shard = wg % NSH;
-            atomicAdd(p.stats + ((size_t)shard * 2) * p.Cout + n, a);
-            atomicAdd(p.stats + ((size_t)shard * 2 + 1) * p.Cout + n, b);
+            fx::add(p.stats, shard, 0, p.Cout, n, a);
+            fx::add(p.stats, shard, 1, p.Cout, n, b);
         }
     }
 }
@@ -552,7 +551,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_stream_kernel(const Params p)
     }
     // fold the transfer threads' partial sums (threads sharing a column chunk: 32 of them) and add them to this workgroup's shard
     float *red = reinterpret_cast<float *>(Ol[0]);
-    auto fold = [&](const float *a8, const float *b8, float *dst) __attribute__((always_inline)) {
+    auto fold = [&](const float *a8, const float *b8, fx::acc_t *dst) __attribute__((always_inline)) {
         __syncthreads();
         if (!mult) {
 #pragma unroll
@@ -563,9 +562,8 @@ __global__ __launch_bounds__(512) void conv3x3_c64_stream_kernel(const Params p)
             const int cch = t2 / 8, e = t2 % 8;
             float a = 0.f, b = 0.f;
             for (int k = 0; k < NT2 / CPR; ++k) { a += red[(cch + CPR * k) * 16 + e]; b += red[(cch + CPR * k) * 16 + 8 + e]; }
-            float *st = dst + (size_t)(blockIdx.x % NSH) * 2 * 64;
-            atomicAdd(st + t2, a);
-            atomicAdd(st + 64 + t2, b);
+            fx::add(dst, (int)(blockIdx.x % NSH), 0, 64, t2, a);
+            fx::add(dst, (int)(blockIdx.x % NSH), 1, 64, t2, b);
         }
     };
     if constexpr (DG) {

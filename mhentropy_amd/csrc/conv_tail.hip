@@ -107,7 +107,7 @@ __global__ __launch_bounds__(512) void conv_tail_kernel(const Params p) {
         const int cc = tid & 31, r0 = tid >> 5;
         float *red = reinterpret_cast<float *>(lds);
         // fold 16 threads' partial sums per column chunk and add them to this pixel tile's shard of dst
-        auto fold = [&](const float *a8, const float *b8, float *dst) __attribute__((always_inline)) {
+        auto fold = [&](const float *a8, const float *b8, fx::acc_t *dst) __attribute__((always_inline)) {
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < 8; ++i) { red[tid * 16 + i] = a8[i]; red[tid * 16 + 8 + i] = b8[i]; }
@@ -116,9 +116,8 @@ __global__ __launch_bounds__(512) void conv_tail_kernel(const Params p) {
                 const int ch = tid >> 3, e = tid & 7;
                 float a = 0.f, b = 0.f;
                 for (int k = 0; k < 16; ++k) { a += red[(ch + 32 * k) * 16 + e]; b += red[(ch + 32 * k) * 16 + 8 + e]; }
-                float *st = dst + (size_t)(mt % NSH) * 2 * p.Cout;
-                atomicAdd(st + n0 + tid, a);
-                atomicAdd(st + p.Cout + n0 + tid, b);
+                fx::add(dst, mt % NSH, 0, p.Cout, n0 + tid, a);
+                fx::add(dst, mt % NSH, 1, p.Cout, n0 + tid, b);
             }
         };
         if constexpr (DG) {

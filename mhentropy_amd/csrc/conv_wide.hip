@@ -220,9 +220,8 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(const Params p, int nsla
             const int ch = t2 >> 3, e = t2 & 7;
             float a1 = 0.f, b1 = 0.f;
             for (int k = 0; k < RSTEP; ++k) { a1 += red[(ch + CPR * k) * 16 + e]; b1 += red[(ch + CPR * k) * 16 + 8 + e]; }
-            float *stp = p.stats + (size_t)(blockIdx.x % NSH) * 2 * p.Cout;
-            atomicAdd(stp + n0 + t2, a1);
-            atomicAdd(stp + p.Cout + n0 + t2, b1);
+            fx::add(p.stats, (int)(blockIdx.x % NSH), 0, p.Cout, n0 + t2, a1);
+            fx::add(p.stats, (int)(blockIdx.x % NSH), 1, p.Cout, n0 + t2, b1);
         }
     }
 }

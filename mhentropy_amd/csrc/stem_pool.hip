@@ -51,7 +51,7 @@ __device__ __forceinline__ unsigned max_key(unsigned a, unsigned b) {
 }
 
 __global__ __launch_bounds__(512) void stem_pool_kernel(const float *__restrict__ x, const u16 *__restrict__ wg, const float *__restrict__ gamma,
-                                                        u16 *__restrict__ pooled, float *__restrict__ stats, int B, int H, int W) {
+                                                        u16 *__restrict__ pooled, mhe_stat_t *__restrict__ stats, int B, int H, int W) {
     __shared__ __attribute__((aligned(16))) u16 patch[SP_PROWS * SP_PSI + 8];      // 37.6 KiB (+ the zero-weight k-slots past the last row's end)
     __shared__ uint4 ring[SP_RING][SP_W * 8];                                      // 4 x 16 KiB: conv rows as [pixel][64 channels], chunks swizzled
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, q = lane >> 4, l15 = lane & 15;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(const float *__restrict_
             float a = 0.f;
 #pragma unroll
             for (int w2 = 0; w2 < 8; ++w2) a += red[(w2 * 2 + which) * 64 + ch];
-            atomicAdd(stats + ((size_t)((int)blockIdx.x % NSH) * 2 + which) * 64 + ch, a);
+            fx::add(stats, (int)blockIdx.x % NSH, which, 64, ch, a);
         }
     }
 }
@@ -219,7 +219,7 @@ using namespace mhe;
 
 extern "C" int mhe_stem_pool_supported(int B, int H, int W, int dtype) { return dtype == MHE_BF16 && B > 0 && H == 256 && W == 256; }
 
-extern "C" int mhe_stem_conv7x7s2_pool(const float *x_nchw, const void *w, const float *bn_gamma, void *pooled, float *stats, int B, int H, int W,
+extern "C" int mhe_stem_conv7x7s2_pool(const float *x_nchw, const void *w, const float *bn_gamma, void *pooled, mhe_stat_t *stats, int B, int H, int W,
                                        void *stream) {
     MHE_REQUIRE(x_nchw && w && bn_gamma && pooled, "mhe_stem_conv7x7s2_pool: null pointer");
     MHE_REQUIRE(mhe_stem_pool_supported(B, H, W, MHE_BF16), "mhe_stem_conv7x7s2_pool: bf16, 256 x 256 images (B=%d H=%d W=%d)", B, H, W);

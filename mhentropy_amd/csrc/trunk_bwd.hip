@@ -8,14 +8,14 @@
 #include "common.h"
 
 namespace mhe { namespace tb {
-constexpr int NSH = 64;       // statistic shards, as the forward's (conv.hip)
+constexpr int NSH = fx::NSH;  // statistic shards, as the forward's (conv.hip)
 
 // Per-channel sums of g' = g [a > 0] and g' * xhat, xhat = (y - mean) invstd, over a slab of pixels per block.
 // Threads: (C/4 channel quads, capped at 256) x row lanes; LDS reduce over row lanes; one sharded atomic per value.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict__ g, const T *__restrict__ a,
                                                             const T *__restrict__ y, const float *__restrict__ mean_invstd,
-                                                            float *__restrict__ stats, long P, int C, long rows_per_block) {
+                                                            mhe_stat_t *__restrict__ stats, long P, int C, long rows_per_block) {
     __shared__ float red[256 * 8];
     const int Q = C / 4;
     const int qpb = Q < 256 ? Q : 256;          // quads handled at once
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict_
     const int ql = tid % qpb, rl = tid / qpb;
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = r0 + rows_per_block < P ? r0 + rows_per_block : P;
-    float *sh = stats + (size_t)(blockIdx.x % NSH) * 2 * C;
+    const int shard = (int)(blockIdx.x % NSH);
     for (int q0 = 0; q0 < Q; q0 += qpb) {
         const int q = q0 + ql;
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict_
         }
         if (rl == 0 && q < Q) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { atomicAdd(sh + q * 4 + k, s1[k]); atomicAdd(sh + C + q * 4 + k, s2[k]); }
+            for (int k = 0; k < 4; ++k) { fx::add(stats, shard, 0, C, q * 4 + k, s1[k]); fx::add(stats, shard, 1, C, q * 4 + k, s2[k]); }
         }
     }
 }
@@ -86,25 +86,24 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict_
 // dbeta = sum g', dgamma = sum g' xhat; coefficients of gy = k2 g' + k1 y + k0 with
 //   gy = gamma invstd (g' - dbeta/M - xhat dgamma/M)       (F.batch_norm backward, training mode)
 // (one wavefront per channel, lane = statistic shard: see bn_finalize_kernel in conv.hip)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__restrict__ stats, const float *__restrict__ gamma,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const mhe_stat_t *__restrict__ stats, const float *__restrict__ gamma,
                                                               const float *__restrict__ mean_invstd, float *__restrict__ dgamma,
-                                                              float *__restrict__ dbeta, float *__restrict__ coef, int C, float count) {
+                                                              float *__restrict__ dbeta, float *__restrict__ coef, int C, double count) {
     static_assert(NSH == 64, "one lane per statistic shard");
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
-    double s1 = (double)stats[((size_t)lane * 2) * C + c], s2 = (double)stats[((size_t)lane * 2 + 1) * C + c];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    const double s1 = fx::wave_total(const_cast<mhe_stat_t *>(stats), 0, C, c, lane, false);
+    const double s2 = fx::wave_total(const_cast<mhe_stat_t *>(stats), 1, C, c, lane, false);
     if (lane) return;
     const float db = (float)s1, dg = (float)s2;
     dbeta[c] = db;
     dgamma[c] = dg;
     const float mean = mean_invstd[c], invstd = mean_invstd[C + c];
     const float k2 = gamma[c] * invstd;
-    const float k1 = -k2 * invstd * dg / count;
+    const float k1 = -k2 * invstd * dg / (float)count;
     coef[c] = k2;
     coef[C + c] = k1;
-    coef[2 * C + c] = -k2 * db / count - k1 * mean;
+    coef[2 * C + c] = -k2 * db / (float)count - k1 * mean;
 }
 
 template <typename T>
@@ -132,15 +131,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
 }
 
 // mean / invstd of the batch statistics the forward accumulated (same shards, same f64 combine as bn_finalize)
-__global__ void bn_mean_invstd_kernel(const float *__restrict__ stats, float *__restrict__ mean_invstd, int C, float count, float eps) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void bn_mean_invstd_kernel(const mhe_stat_t *__restrict__ stats, float *__restrict__ mean_invstd, int C, double count, float eps) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-#pragma unroll 8
-    for (int sh = 0; sh < NSH; ++sh) {
-        s1 += (double)stats[((size_t)sh * 2) * C + c];
-        s2 += (double)stats[((size_t)sh * 2 + 1) * C + c];
-    }
+    const double s1 = fx::wave_total(const_cast<mhe_stat_t *>(stats), 0, C, c, lane, false);
+    const double s2 = fx::wave_total(const_cast<mhe_stat_t *>(stats), 1, C, c, lane, false);
+    if (lane) return;
     const double dmean = s1 / (double)count;
     const double dvar = fmax(s2 / (double)count - dmean * dmean, 0.0);
     mean_invstd[c] = (float)dmean;
@@ -299,7 +295,7 @@ __global__ __launch_bounds__(256) void maxpool_idx_affine_kernel(const T *__rest
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_bn_kernel(const T *__restrict__ gy, const unsigned char *__restrict__ idx, const T *__restrict__ y,
                                                              const float *__restrict__ scale, const float *__restrict__ shift,
-                                                             const float *__restrict__ mean_invstd, float *__restrict__ stats, T *__restrict__ gx,
+                                                             const float *__restrict__ mean_invstd, mhe_stat_t *__restrict__ stats, T *__restrict__ gx,
                                                              int B, int H, int W, int C, int Ho, int Wo, const float *__restrict__ coef = nullptr) {
     constexpr int E = Lane<T>::E;
     __shared__ float red[256 * 2 * E];
@@ -363,12 +359,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_bn_kernel(const T *__restrict
     for (int k = 0; k < E; ++k) { red[tid * 2 * E + k] = s1[k]; red[tid * 2 * E + E + k] = s2[k]; }
     __syncthreads();
     if (tid < cpp) {
-        float *sh = stats + (size_t)(blockIdx.x % NSH) * 2 * C;
+        const int shard = (int)(blockIdx.x % NSH);
         for (int k = 0; k < E; ++k) {
             float a = 0.f, b2 = 0.f;
             for (int o = tid; o < 256; o += cpp) { a += red[o * 2 * E + k]; b2 += red[o * 2 * E + E + k]; }
-            atomicAdd(sh + c + k, a);
-            atomicAdd(sh + C + c + k, b2);
+            fx::add(stats, shard, 0, C, c + k, a);
+            fx::add(stats, shard, 1, C, c + k, b2);
         }
     }
 }
@@ -478,13 +474,13 @@ static inline unsigned ewg(size_t n) { size_t b = (n + 255) / 256; return (unsig
         else hipLaunchKernelGGL(KERNEL<u16>, grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);                      \
     } while (0)
 
-extern "C" int mhe_bn_mean_invstd(const float *stats, float *mean_invstd, int C, float count, float eps, void *stream) {
+extern "C" int mhe_bn_mean_invstd(const mhe_stat_t *stats, float *mean_invstd, int C, double count, float eps, void *stream) {
     MHE_REQUIRE(stats && mean_invstd && C > 0 && count > 0.f, "mhe_bn_mean_invstd: bad arguments");
-    hipLaunchKernelGGL(tb::bn_mean_invstd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, mean_invstd, C, count, eps);
+    hipLaunchKernelGGL(tb::bn_mean_invstd_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, stats, mean_invstd, C, count, eps);
     return check_launch("bn_mean_invstd_kernel");
 }
 
-extern "C" int mhe_bn_bwd_reduce_nhwc(const void *g, const void *a, const void *y, const float *mean_invstd, float *stats,
+extern "C" int mhe_bn_bwd_reduce_nhwc(const void *g, const void *a, const void *y, const float *mean_invstd, mhe_stat_t *stats,
                                       long P, int C, int dtype, void *stream) {
     MHE_REQUIRE(g && y && mean_invstd && stats && P > 0 && C > 0 && C % 4 == 0, "mhe_bn_bwd_reduce_nhwc: bad arguments");
     long blocks = P / 64;
@@ -501,8 +497,8 @@ extern "C" int mhe_bn_bwd_reduce_nhwc(const void *g, const void *a, const void *
     return check_launch("bn_bwd_reduce_kernel");
 }
 
-extern "C" int mhe_bn_bwd_finalize(const float *stats, const float *gamma, const float *mean_invstd, float *dgamma,
-                                   float *dbeta, float *coef, int C, float count, void *stream) {
+extern "C" int mhe_bn_bwd_finalize(const mhe_stat_t *stats, const float *gamma, const float *mean_invstd, float *dgamma,
+                                   float *dbeta, float *coef, int C, double count, void *stream) {
     MHE_REQUIRE(stats && gamma && mean_invstd && dgamma && dbeta && coef && C > 0 && count > 0.f, "mhe_bn_bwd_finalize: bad arguments");
     hipLaunchKernelGGL(tb::bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, stats, gamma,
                        mean_invstd, dgamma, dbeta, coef, C, count);
@@ -560,7 +556,7 @@ extern "C" int mhe_maxpool3x3s2_idx_affine_nhwc(const void *x, const float *scal
 }
 
 extern "C" int mhe_maxpool3x3s2_bwd_bn_nhwc(const void *gy, const unsigned char *idx, const void *y, const float *scale, const float *shift,
-                                            const float *mean_invstd, float *stats, void *gx, int B, int H, int W, int C, int dtype, void *stream) {
+                                            const float *mean_invstd, mhe_stat_t *stats, void *gx, int B, int H, int W, int C, int dtype, void *stream) {
     MHE_REQUIRE(gy && idx && y && scale && shift && mean_invstd && (stats || gx) && B > 0 && H > 0 && W > 0, "mhe_maxpool3x3s2_bwd_bn_nhwc: bad arguments");
     MHE_REQUIRE(dtype == MHE_F32 || dtype == MHE_BF16, "mhe_maxpool3x3s2_bwd_bn_nhwc: dtype=%d", dtype);
     const int E = dtype == MHE_F32 ? 4 : 8;
@@ -589,10 +585,10 @@ extern "C" int mhe_maxpool3x3s2_bwd_bn_apply_nhwc(const void *gy, const unsigned
     const size_t n = (size_t)B * H * W * (C / E);
     if (dtype == MHE_F32)
         hipLaunchKernelGGL(tb::maxpool_bwd_bn_kernel<float>, dim3(ewg(n)), dim3(256), 0, (hipStream_t)stream, (const float *)gy, idx, (const float *)y, scale, shift,
-                           mean_invstd, (float *)nullptr, (float *)gy_out, B, H, W, C, Ho, Wo, coef);
+                           mean_invstd, (mhe_stat_t *)nullptr, (float *)gy_out, B, H, W, C, Ho, Wo, coef);
     else
         hipLaunchKernelGGL(tb::maxpool_bwd_bn_kernel<u16>, dim3(ewg(n)), dim3(256), 0, (hipStream_t)stream, (const u16 *)gy, idx, (const u16 *)y, scale, shift,
-                           mean_invstd, (float *)nullptr, (u16 *)gy_out, B, H, W, C, Ho, Wo, coef);
+                           mean_invstd, (mhe_stat_t *)nullptr, (u16 *)gy_out, B, H, W, C, Ho, Wo, coef);
     return check_launch("maxpool_bwd_bn_kernel");
 }
 

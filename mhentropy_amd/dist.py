@@ -12,10 +12,16 @@ def env_rank():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def forced():
+    """MHE_DIST_FORCE=1: run every collective even in a group of ONE rank (the one-GPU rehearsal of the RCCL code path:
+    communicator set-up, stream ordering against the compute / capture streams, reduce_scatter_tensor; tests/test_gpu_rccl.py)"""
+    return os.environ.get("MHE_DIST_FORCE", "0") == "1"
+
+
 def init(backend=None):
     """Initialise torch.distributed from the launcher's environment; returns (rank, local_rank, world, dist|None)."""
     rank, local_rank, world = env_rank()
-    if world == 1:
+    if world == 1 and not forced():
         return rank, local_rank, world, None
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -72,7 +78,7 @@ def allreduce_gradients(flat, dist=None, bucket_elems=16 << 20):
     as a few large buckets issued back to back (64 MB of f32 each: large enough to run every xGMI link at its
     ring bandwidth, small enough that a later bucket's reduce-scatter overlaps an earlier one's all-gather).
     The mean (DDP semantics) is taken by the optimizer kernel's grad_scale = 1/world."""
-    if dist is None or dist.get_world_size() == 1:
+    if dist is None or (dist.get_world_size() == 1 and not forced()):
         return flat
     works = []
     for lo in range(0, flat.numel(), bucket_elems):
@@ -102,13 +108,14 @@ class HypothesisShards:
         self.dist, self.K = dist, K
         self.world = dist.get_world_size() if dist is not None else 1
         self.rank = dist.get_rank() if dist is not None else 0
+        self.active = dist is not None and (self.world > 1 or forced())       # collectives are issued (a forced group of one included)
 
     def hypotheses(self):
         return shard_range(self.K, self.rank, self.world)
 
     def gather_rows(self, t):
         """(B, ...) per rank -> (world*B, ...) on every rank, rank-major"""
-        if self.world == 1:
+        if not self.active:
             return t
         t = t.contiguous()
         out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
@@ -119,7 +126,7 @@ class HypothesisShards:
         """sample-major rows (K*B, ...) of the rank's own images -> this rank's hypotheses of ALL images, sample-major over the
         gathered batch: ((hi-lo) * world*B, ...).  (Only parity runs ship host noise this way; a production run draws the
         slice's base noise on the device.)"""
-        if self.world == 1:
+        if not self.active:
             return t
         K = self.K
         full = self.gather_rows(t.reshape(K, B, *t.shape[1:]).transpose(0, 1).contiguous())        # (world*B, K, ...)
@@ -128,13 +135,13 @@ class HypothesisShards:
 
     def reduce_images(self, t):
         """sum over ranks of a per-image tensor (in place)"""
-        if self.world > 1:
+        if self.active:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t
 
     def scatter_grad(self, g_all):
         """(world*B, F) partial gradients -> (B, F): the sum over ranks of the rows of this rank's own images"""
-        if self.world == 1:
+        if not self.active:
             return g_all
         B = g_all.shape[0] // self.world
         g_all = g_all.contiguous()

@@ -48,11 +48,16 @@ class AverageMeter:
         self.avg = self.sum / self.count if self.count != 0 else 0
 
 
-def save_model(path, model):
+def save_model(path, model, rng_words=None):
     """checkpoint in the reference's format (hand/CrossModalHand.py:573-587): {'decoderPose': ..., 'encoderRGB': state_dict}.
-    The reference builds `decoderPose` as an empty nn.Sequential for MHEnt (its state_dict is empty)."""
+    The reference builds `decoderPose` as an empty nn.Sequential for MHEnt (its state_dict is empty).  rng_words (optional, an extra
+    key the reference's loader ignores): the device generator's {seed, counter, draws} (ops.rng_get_state) so that a resumed run
+    continues the base-noise stream instead of replaying it from counter 0."""
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    torch.save({"decoderPose": {}, "encoderRGB": sd}, path)
+    ck = {"decoderPose": {}, "encoderRGB": sd}
+    if rng_words is not None:
+        ck["mhe_rng_state"] = torch.as_tensor(rng_words, dtype=torch.int64).cpu().clone()
+    torch.save(ck, path)
 
 
 def load_model(path, model, map_location=None):

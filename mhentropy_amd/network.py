@@ -64,7 +64,12 @@ class BasicEnc(nn.Module):
         if not self.full_outputs:
             return mn, mn, None
         l2 = ops.linear(f, self.l2[0].weight.detach(), self.l2[0].bias.detach())
-        det = bool(self.deterministic or deterministic or self.n_latent[0] != self.n_latent[1])      # hand/network.py:133-136
+        if mn.shape != l2.shape:
+            # list-valued n_latent: the reference returns z = mn with sd in l2's OWN shape (hand/network.py:133-136); the fused launch
+            # wants one shape, so sd comes from a deterministic launch on l2 alone (its z output, a copy of l2, is dropped)
+            sd, _ = ops.reparam(l2, l2, None, sigmoid_act=self.sigma_act == "sigmoid", deterministic=True)
+            return mn, mn, sd
+        det = bool(self.deterministic or deterministic)      # hand/network.py:133-136
         if not det and eps is None:
             eps = ops.randn(mn.shape[0], mn.shape[1], mn.device)
         sd, z = ops.reparam(mn, l2, None if det else eps.contiguous(), sigmoid_act=self.sigma_act == "sigmoid", deterministic=det)

@@ -45,6 +45,37 @@ def stat_shards():
     return _lib.lib().mhe_conv_stat_shards()
 
 
+STAT_DTYPE = torch.int64
+
+
+def stat_shape(C):
+    """one unit of sharded fixed-point accumulators for C channels (include/mhe.h, mhe_stat_t): [2 planes][S shards][2 statistics][C]"""
+    return (2, stat_shards(), 2, C)
+
+
+def stat_unit(C, device):
+    return torch.zeros(stat_shape(C), device=device, dtype=STAT_DTYPE)
+
+
+def stat_totals(st):
+    """[2, C] float64 totals of a unit: sum over shards of plane0 * 2^-16 + plane1 * 2^-56 (what the finalize kernels compute; the
+    marker of a non-finite partial is not decoded here - tests and diagnostics only)"""
+    t = st.sum(1)                                     # integer sums: exact
+    return t[0].double() * 2.0 ** -16 + t[1].double() * 2.0 ** -56
+
+
+def stat_from_float(t):
+    """[S, 2, C] float shard values -> a unit holding them (the encoding fx::add2 of csrc/common.h applies to one partial; tests)"""
+    d = t.double() * 2.0 ** 16
+    hi = torch.round(d)
+    lo = torch.round((d - hi) * 2.0 ** 40)
+    return torch.stack([hi.to(torch.int64), lo.to(torch.int64)]).contiguous()
+
+
+def _chk_stats(t, name, C):
+    _chk(t, STAT_DTYPE, name, stat_shape(C))
+
+
 _TILES = {0: "128, 64, 2, 2", 1: "128, 128, 2, 2", 2: "256, 256, 2, 4", 3: "256, 128, 4, 2", 4: "256, 64, 4, 2"}
 
 
@@ -108,10 +139,28 @@ _RNG_STATE = {}
 def rng_state(device, seed=None):
     """the device-resident generator state {seed, next counter, 0} of mhe_randn_f32 for `device`; created on first use from torch's
     seed (torch.manual_seed(s) before the first draw makes runs repeatable), or re-seeded explicitly with seed="""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
     st = _RNG_STATE.get(device)
-    if st is None or seed is not None:
+    if st is None:
         s = torch.initial_seed() if seed is None else int(seed)
         st = _RNG_STATE[device] = torch.tensor([s & 0x7FFFFFFFFFFFFFFF, 0, 0], dtype=torch.int64, device=device)
+    elif seed is not None:
+        # re-seed IN PLACE: a captured HIP graph has this tensor's address baked into its randn_kernel node
+        st.copy_(torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0], dtype=torch.int64))
+    return st
+
+
+def rng_get_state(device):
+    """the three int64 words {seed, next counter, draws} of the device generator, on the host (for checkpoints)"""
+    return rng_state(device).cpu().clone()
+
+
+def rng_set_state(device, words):
+    """restore rng_get_state()'s words in place (a resumed run continues the base-noise stream instead of replaying it)"""
+    st = rng_state(device)
+    st.copy_(torch.as_tensor(words, dtype=torch.int64).reshape(3))
     return st
 
 
@@ -357,7 +406,7 @@ def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in
     if residual is not None:
         _chk(residual, dt, "conv.residual", (B, (Ho + 1) // 2, (Wo + 1) // 2, Cout) if res_half else (B, Ho, Wo, Cout))
     if stats is not None:
-        _chk(stats, torch.float32, "conv.stats", (stat_shards(), 2, Cout))
+        _chk_stats(stats, "conv.stats", Cout)
     d = ConvDesc(B, H, W, Cin, Cout, KH, KW, stride, pad, dtype_code(dt), int(relu_in), int(relu_out), int(tile), int(res_half))
     if mask is not None:
         if in_scale is not None or out_scale is not None or stats is not None or relu_in or relu_out:
@@ -369,7 +418,7 @@ def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in
             by, bmi, bst = (list(bn or []) + [(None, None, None)])[0]
             if by is not None:
                 _chk(by, dt, "conv.bn_y", (B, Ho, Wo, Cout)); _chk(bmi, torch.float32, "conv.bn_mean_invstd", (2, Cout))
-                _chk(bst, torch.float32, "conv.bn_stats", (stat_shards(), 2, Cout))
+                _chk_stats(bst, "conv.bn_stats", Cout)
             cin2 = 0
             if xcat is not None:         # the operand's K range continued on a second tensor: w is [Cout][Cin + cin2]
                 cin2 = xcat.shape[-1]
@@ -385,7 +434,7 @@ def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in
         for by, bmi, bst in (list(bn or []) + [(None, None, None)] * 2)[:2]:
             if by is not None:
                 _chk(by, dt, "conv.bn_y", (B, Ho, Wo, Cout)); _chk(bmi, torch.float32, "conv.bn_mean_invstd", (2, Cout))
-                _chk(bst, torch.float32, "conv.bn_stats", (stat_shards(), 2, Cout))
+                _chk_stats(bst, "conv.bn_stats", Cout)
             ext += [_ptr(by), _ptr(bmi), _ptr(bst)]
         if mask_bits is not None:        # the gate also as bits [pixel][Cout / 8] (bottleneck_tail want_bits=): read instead of `mask` where the kernel can
             _chk(mask_bits, torch.uint8, "conv.mask_bits", (B, Ho, Wo, Cout // 8))
@@ -428,7 +477,7 @@ def conv1x1_stats(x, w, in_scale, in_shift, stats):
     Cout = w.shape[0]
     _chk(x, torch.bfloat16, "conv_stats.x"); _chk(w, torch.bfloat16, "conv_stats.w", (Cout, Cin))
     _chk(in_scale, torch.float32, "conv_stats.in_scale", (Cin,)); _chk(in_shift, torch.float32, "conv_stats.in_shift", (Cin,))
-    _chk(stats, torch.float32, "conv_stats.stats", (stat_shards(), 2, Cout))
+    _chk_stats(stats, "conv_stats.stats", Cout)
     d = ConvDesc(B, H, W, Cin, Cout, 1, 1, 1, 0, BF16, 1, 0, 0, 0)
     if TIMING:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -444,7 +493,7 @@ def conv1x1_stats(x, w, in_scale, in_shift, stats):
 def gram_buffers(Cb, device):
     """(zeroed shard accumulators, f64 workspace) for conv1x1_gram_bn; the accumulators clean themselves (gram_bn_finalize)"""
     L = _lib.lib()
-    return (torch.zeros(L.mhe_gram_stats_floats(Cb), device=device, dtype=torch.float32),
+    return (torch.zeros(L.mhe_gram_stats_words(Cb), device=device, dtype=STAT_DTYPE),
             torch.empty(L.mhe_gram_stats_workspace_bytes(Cb) // 8, device=device, dtype=torch.float64))
 
 
@@ -458,6 +507,7 @@ def conv1x1_gram_bn(x, in_scale, in_shift, w, bn_weight, bn_bias, running_mean, 
     _chk(in_scale, torch.float32, "gram.in_scale", (Cb,)); _chk(in_shift, torch.float32, "gram.in_shift", (Cb,))
     gram, ws = bufs
     L = _lib.lib()
+    _chk(gram, STAT_DTYPE, "gram.accumulators", (L.mhe_gram_stats_words(Cb),))
     if TIMING:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -492,7 +542,7 @@ def conv3_bn_fold(D, w, gram_totals, rev_stats, gamma, mean_invstd, count, dgamm
         _chk(S, torch.bfloat16, "fold.S", (Cb, Cb))
         s_ptr, ld_s = _ptr(S), Cb
     _chk(D, torch.float32, "fold.D", (Cn, Cb)); _chk(w, torch.bfloat16, "fold.w", (Cn, Cb)); _chk(gram_totals, torch.float64, "fold.gram")
-    _chk(rev_stats, torch.float32, "fold.rev_stats", (stat_shards(), 2, Cn)); _chk(gamma, torch.float32, "fold.gamma", (Cn,))
+    _chk_stats(rev_stats, "fold.rev_stats", Cn); _chk(gamma, torch.float32, "fold.gamma", (Cn,))
     _chk(mean_invstd, torch.float32, "fold.mean_invstd", (2, Cn)); _chk(dgamma, torch.float32, "fold.dgamma", (Cn,)); _chk(dbeta, torch.float32, "fold.dbeta", (Cn,))
     _chk(dW, torch.float32, "fold.dW"); _chk(w_dg, torch.bfloat16, "fold.w_dg")
     _chk(c0, torch.float32, "fold.c0", (Cb,)); _chk(coef_ws, torch.float32, "fold.coef_ws")
@@ -525,15 +575,17 @@ def conv3x3_halo(x, w_halo, in_scale=None, in_shift=None, relu_in=False, a_out=N
     Cout = w_halo.shape[0]
     _chk(x, torch.bfloat16, "halo.x"); _chk(w_halo, torch.bfloat16, "halo.w", (Cout, 9 * Cin))
     y = torch.empty(B, H, W, Cout, device=x.device, dtype=torch.bfloat16)
-    for t, name, shape in ((in_scale, "in_scale", (Cin,)), (in_shift, "in_shift", (Cin,)), (stats, "stats", (stat_shards(), 2, Cout))):
+    for t, name, shape in ((in_scale, "in_scale", (Cin,)), (in_shift, "in_shift", (Cin,))):
         if t is not None:
             _chk(t, torch.float32, "halo." + name, shape)
+    if stats is not None:
+        _chk_stats(stats, "halo.stats", Cout)
     for t, name, shape in ((a_out, "a_out", tuple(x.shape)), (residual, "residual", tuple(y.shape)), (mask, "mask", tuple(y.shape))):
         if t is not None:
             _chk(t, torch.bfloat16, "halo." + name, shape)
     by, bmi, bst = (None, None, None) if bn is None else bn
     if by is not None:
-        _chk(by, torch.bfloat16, "halo.bn_y", tuple(y.shape)); _chk(bmi, torch.float32, "halo.bn_mi", (2, Cout)); _chk(bst, torch.float32, "halo.bn_stats", (stat_shards(), 2, Cout))
+        _chk(by, torch.bfloat16, "halo.bn_y", tuple(y.shape)); _chk(bmi, torch.float32, "halo.bn_mi", (2, Cout)); _chk_stats(bst, "halo.bn_stats", Cout)
     if TIMING:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -561,7 +613,7 @@ def conv3x3_halo_dgrad_bn(g, y_raw, coef, w_halo, mask, gy_out=None, residual=No
         _chk(residual, torch.bfloat16, "halo_dg.residual", tuple(gx.shape))
     by, bmi, bst = (None, None, None) if bn is None else bn
     if by is not None:
-        _chk(by, torch.bfloat16, "halo_dg.bn_y", tuple(gx.shape)); _chk(bmi, torch.float32, "halo_dg.bn_mi", (2, Cout)); _chk(bst, torch.float32, "halo_dg.bn_stats", (stat_shards(), 2, Cout))
+        _chk(by, torch.bfloat16, "halo_dg.bn_y", tuple(gx.shape)); _chk(bmi, torch.float32, "halo_dg.bn_mi", (2, Cout)); _chk_stats(bst, "halo_dg.bn_stats", Cout)
     check(_lib.lib().mhe_conv3x3_halo_dgrad_bn_nhwc(B, H, W, Cin, Cout, _ptr(g), _ptr(y_raw), _ptr(coef), _ptr(w_halo), _ptr(gx), _ptr(gy_out), _ptr(residual),
                                                     _ptr(mask), _ptr(by), _ptr(bmi), _ptr(bst), _stream()), "mhe_conv3x3_halo_dgrad_bn_nhwc")
     return gx
@@ -582,7 +634,7 @@ def bottleneck_tail(y2, bn2, w3, bn3, identity, id_aff, w1, stats=None, want_bit
     for (sc, sh), n, c in ((bn2, "bn2", Cb), (bn3, "bn3", Cw)) + (((id_aff, "id", Cw),) if id_aff is not None else ()):
         _chk(sc, torch.float32, f"tail.{n}_scale", (c,)); _chk(sh, torch.float32, f"tail.{n}_shift", (c,))
     if stats is not None:
-        _chk(stats, torch.float32, "tail.stats", (stat_shards(), 2, Cout))
+        _chk_stats(stats, "tail.stats", Cout)
     a = torch.empty(B, H, W, Cw, device=y2.device, dtype=torch.bfloat16)
     y1 = torch.empty(B, H, W, Cout, device=y2.device, dtype=torch.bfloat16)
     # want_bits: also [a > 0] as bits, byte [pixel][channel / 8] - the gate the reverse pass reads instead of `a` (conv2d_nhwc mask_bits=)
@@ -632,7 +684,7 @@ def conv3x3s2_dgrad(gy, w4, residual=None, mask=None, bn=None, tile=0):
     for by, bmi, bst in (list(bn or []) + [(None, None, None)] * 2)[:2]:
         if by is not None:
             _chk(by, dt, "dgrad_s2.bn_y", dx.shape); _chk(bmi, torch.float32, "dgrad_s2.bn_mean_invstd", (2, Cin))
-            _chk(bst, torch.float32, "dgrad_s2.bn_stats", (stat_shards(), 2, Cin))
+            _chk_stats(bst, "dgrad_s2.bn_stats", Cin)
         ext += [_ptr(by), _ptr(bmi), _ptr(bst)]
     wp = (C.c_void_p * 4)(*[w.data_ptr() for w in w4])
     check(_lib.lib().mhe_conv3x3s2_dgrad_nhwc(B, Ho, Wo, Cout, Cin, dtype_code(dt), _ptr(gy), wp, _ptr(dx), _ptr(residual), _ptr(mask), *ext, int(tile), _stream()),
@@ -652,7 +704,7 @@ def conv1x1_residual_in(x, x2, w, in_scale, in_shift, x2_scale=None, x2_shift=No
     if a_out is not None:
         _chk(a_out, dt, "conv_res.a_out", x.shape)
     if stats is not None:
-        _chk(stats, torch.float32, "conv_res.stats", (stat_shards(), 2, Cout))
+        _chk_stats(stats, "conv_res.stats", Cout)
     y = torch.empty(B, H, W, Cout, device=x.device, dtype=dt)
     d = ConvDesc(B, H, W, Cin, Cout, 1, 1, 1, 0, dtype_code(dt), 1, 0, int(tile))
     if TIMING:
@@ -685,7 +737,7 @@ def conv1x1_dgrad_bn_apply(g, y_raw, coef, w_dg, a_out, mask, bn=None, zeros=Non
     by, bmi, bst = bn[0] if bn else (None, None, None)
     if by is not None:
         _chk(by, dt, "dgrad_apply.bn_y", out.shape); _chk(bmi, torch.float32, "dgrad_apply.bn_mean_invstd", (2, Cout))
-        _chk(bst, torch.float32, "dgrad_apply.bn_stats", (stat_shards(), 2, Cout))
+        _chk_stats(bst, "dgrad_apply.bn_stats", Cout)
     d = ConvDesc(B, H, W, Cin, Cout, 1, 1, 1, 0, dtype_code(dt), 0, 0, int(tile))
     check(_lib.lib().mhe_conv1x1_residual_in_masked_nhwc(C.byref(d), _ptr(g), _ptr(y_raw), _ptr(w_dg), _ptr(out), _ptr(coef[0]), _ptr(coef[2]),
                                                          _ptr(coef[1]), _ptr(zeros), _ptr(a_out), None, _ptr(mask), _ptr(by), _ptr(bmi), _ptr(bst),
@@ -702,7 +754,7 @@ def stem_conv7x7s2(x, w, dtype, stats=None):
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     y = torch.empty(B, Ho, Wo, 64, device=x.device, dtype=dtype)
     if stats is not None:
-        _chk(stats, torch.float32, "stem.stats", (stat_shards(), 2, 64))
+        _chk_stats(stats, "stem.stats", 64)
     if TIMING:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -727,7 +779,7 @@ def stem_conv7x7s2_pool(x, w, bn_gamma, stats=None):
     if Cn != 3:
         raise _lib.MheError("stem_pool.x: expected 3 input channels")
     if stats is not None:
-        _chk(stats, torch.float32, "stem_pool.stats", (stat_shards(), 2, 64))
+        _chk_stats(stats, "stem_pool.stats", 64)
     y = torch.empty(B, 64, 64, 64, device=x.device, dtype=torch.bfloat16)
     if TIMING:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -743,6 +795,7 @@ def bn_finalize(stats, gamma, beta, running_mean, running_var, count, momentum=0
                 num_batches_tracked=None):
     """clear: the accumulators are zeroed once read (self-cleaning arena); num_batches_tracked (int64 scalar on the device): += 1"""
     Cn = gamma.shape[0]
+    _chk_stats(stats, "bn_finalize.stats", Cn)
     scale = torch.empty(Cn, device=gamma.device, dtype=torch.float32)
     shift = torch.empty_like(scale)
     mi = torch.empty(2, Cn, device=gamma.device, dtype=torch.float32) if want_mean_invstd else None
@@ -1035,6 +1088,7 @@ def flow_couple_accum(g_part, GXs, GXt, mask_row, g_in):
 
 def bn_mean_invstd(stats, count, eps=1e-5):
     Cc = stats.shape[-1]
+    _chk_stats(stats, "bn_mean_invstd.stats", Cc)
     mi = torch.empty(2, Cc, device=stats.device, dtype=torch.float32)
     check(_lib.lib().mhe_bn_mean_invstd(_ptr(stats), _ptr(mi), Cc, float(count), float(eps), _stream()), "mhe_bn_mean_invstd")
     return mi
@@ -1049,7 +1103,7 @@ def bn_backward(g, a, y, mean_invstd, gamma, stats, dgamma, dbeta, want_masked=F
     _chk(g, dt, "bn_bwd.g", y.shape); _chk(y, dt, "bn_bwd.y")
     if a is not None:
         _chk(a, dt, "bn_bwd.a", y.shape)
-    _chk(stats, torch.float32, "bn_bwd.stats", (stat_shards(), 2, Cc)); _chk(mean_invstd, torch.float32, "bn_bwd.mean_invstd", (2, Cc))
+    _chk_stats(stats, "bn_bwd.stats", Cc); _chk(mean_invstd, torch.float32, "bn_bwd.mean_invstd", (2, Cc))
     _chk(gamma, torch.float32, "bn_bwd.gamma", (Cc,)); _chk(dgamma, torch.float32, "bn_bwd.dgamma", (Cc,)); _chk(dbeta, torch.float32, "bn_bwd.dbeta", (Cc,))
     L = _lib.lib()
     if not reduced:
@@ -1067,7 +1121,7 @@ def bn_backward(g, a, y, mean_invstd, gamma, stats, dgamma, dbeta, want_masked=F
 def bn_bwd_coef(stats, gamma, mean_invstd, dgamma, dbeta, count):
     """finish a BatchNorm reverse whose sums are in `stats`: writes dgamma / dbeta, returns coef = k2 | k1 | k0 [3, C] of gy = k2 g + k1 y + k0"""
     Cc = gamma.shape[0]
-    _chk(stats, torch.float32, "bn_bwd.stats", (stat_shards(), 2, Cc)); _chk(mean_invstd, torch.float32, "bn_bwd.mean_invstd", (2, Cc))
+    _chk_stats(stats, "bn_bwd.stats", Cc); _chk(mean_invstd, torch.float32, "bn_bwd.mean_invstd", (2, Cc))
     _chk(gamma, torch.float32, "bn_bwd.gamma", (Cc,)); _chk(dgamma, torch.float32, "bn_bwd.dgamma", (Cc,)); _chk(dbeta, torch.float32, "bn_bwd.dbeta", (Cc,))
     coef = torch.empty(3, Cc, device=stats.device, dtype=torch.float32)
     check(_lib.lib().mhe_bn_bwd_finalize(_ptr(stats), _ptr(gamma), _ptr(mean_invstd), _ptr(dgamma), _ptr(dbeta), _ptr(coef), Cc, float(count), _stream()),
@@ -1103,7 +1157,7 @@ def maxpool3x3s2_bwd_bn(gy, idx, y, scale, shift, mean_invstd, stats, want_gx=Tr
     if y.shape[0] != B or y.shape[3] != Cc or ((H - 1) // 2 + 1, (W - 1) // 2 + 1) != (Ho, Wo):
         raise ValueError(f"maxpool_bwd_bn: y {tuple(y.shape)} does not pool to gy {tuple(gy.shape)}")
     _chk(scale, torch.float32, "maxpool_bwd_bn.scale", (Cc,)); _chk(shift, torch.float32, "maxpool_bwd_bn.shift", (Cc,))
-    _chk(mean_invstd, torch.float32, "maxpool_bwd_bn.mean_invstd", (2, Cc)); _chk(stats, torch.float32, "maxpool_bwd_bn.stats", (stat_shards(), 2, Cc))
+    _chk(mean_invstd, torch.float32, "maxpool_bwd_bn.mean_invstd", (2, Cc)); _chk_stats(stats, "maxpool_bwd_bn.stats", Cc)
     gx = torch.empty_like(y) if want_gx else None
     check(_lib.lib().mhe_maxpool3x3s2_bwd_bn_nhwc(_ptr(gy), _ptr(idx), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean_invstd), _ptr(stats), _ptr(gx),
                                                   B, H, W, Cc, dtype_code(dt), _stream()), "mhe_maxpool3x3s2_bwd_bn_nhwc")

@@ -271,7 +271,7 @@ class _StatsPool:
     pass, and a pass that did not finish (an exception in between) leaves the arena marked dirty: the next begin() zeroes it."""
     def __init__(self, device, channels=32768, persistent=False):
         self.S = ops.stat_shards()
-        self.buf = torch.zeros(self.S * 2 * channels, device=device, dtype=torch.float32)
+        self.buf = torch.zeros(2 * self.S * 2 * channels, device=device, dtype=ops.STAT_DTYPE)      # fixed-point words (include/mhe.h: mhe_stat_t)
         self.off = 0
         self.persistent, self.clean = persistent, True
         self._gram = {}
@@ -293,13 +293,13 @@ class _StatsPool:
         self.clean = True
 
     def take(self, C):
-        n = self.S * 2 * C
+        n = 2 * self.S * 2 * C
         if self.off + n > self.buf.numel():
             if self.persistent:
                 raise RuntimeError("_StatsPool: persistent arena exhausted")
             self.buf = torch.zeros_like(self.buf)
             self.off = 0
-        v = self.buf[self.off:self.off + n].view(self.S, 2, C)
+        v = self.buf[self.off:self.off + n].view(2, self.S, 2, C)
         self.off += n
         return v
 

@@ -71,7 +71,10 @@ def main(argv=None):
         model = harness.build_mhent(backbone=args.backbone, h_dims=(args.hidden, args.hidden), num_steps=args.flow_steps,
                                     tables=synth.mano_tables(0), compute_dtype=cd).cuda().train()
     if args.load:
-        harness.load_model(args.load, model, map_location="cuda")
+        ck = harness.load_model(args.load, model, map_location="cuda")
+        if isinstance(ck, dict) and ck.get("mhe_rng_state") is not None and rank == 0 and world == 1:
+            # continue the checkpointed run's base-noise stream (single process; under data parallelism every rank keeps its own seed)
+            ops.rng_set_state(torch.device("cuda", torch.cuda.current_device()), ck["mhe_rng_state"])
     scalars = harness.ScalarLog(args.scalars) if (args.scalars and rank == 0) else None
     trainer = TrainStep(model, lr=args.lr, max_norm=1.0, dist=dist)
     criterion = MHEntLoss()
@@ -137,7 +140,7 @@ def main(argv=None):
     if scalars is not None:
         scalars.close()
     if args.save and rank == 0:
-        harness.save_model(args.save, model)
+        harness.save_model(args.save, model, rng_words=ops.rng_get_state(torch.device("cuda", torch.cuda.current_device())))
     if dist is not None:
         dist.destroy_process_group()
     main.last_trainer = trainer           # (tests: optimizer step count, parameters)

@@ -123,9 +123,12 @@ class TrainStep:
     def __init__(self, model, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, dist=None, shard_hypotheses=False):
         self.model, self.lr, self.betas, self.eps, self.max_norm, self.dist = model, lr, betas, eps, max_norm, dist
         self.world = dist.get_world_size() if dist is not None else 1
+        from .dist import forced
+        # collectives are issued: more than one rank, or a forced group of ONE (the one-GPU rehearsal of the RCCL path, MHE_DIST_FORCE=1)
+        self.comm = dist is not None and (self.world > 1 or forced())
         # hypothesis-sharded exchange (dist.HypothesisShards): images stay sharded for the encoder, every rank evaluates its
         # slice of the K hypotheses for ALL images from the gathered conditioning features
-        self.shard_hypotheses = bool(shard_hypotheses) and self.world > 1
+        self.shard_hypotheses = bool(shard_hypotheses) and self.comm
         trunk = model.feat_extractor.res
         self.trunk = trunk
         self.T = trunk.compute_dtype
@@ -224,7 +227,7 @@ class TrainStep:
     def _grad_ready(self, i):
         lo, hi = self._bucket_bounds[i]
         ops.gather(self.raw, self._unpack_idx[lo:hi], self.G[lo:hi])
-        if self.dist is not None and self.world > 1:
+        if self.comm:
             cap = getattr(self, "_capture", None)
             if cap is not None:              # GraphedStep: the graph ends here, the collective is issued between two graph launches
                 cap.cut(("allreduce", i))
@@ -238,7 +241,7 @@ class TrainStep:
     def finish_allreduce(self):
         """wait for the gradient buckets' all-reduces (sum over ranks; the mean is taken by grad_scale = 1/world)"""
         cap = getattr(self, "_capture", None)
-        if cap is not None and self.dist is not None and self.world > 1:
+        if cap is not None and self.comm:
             cap.cut(("wait",))
             return
         for w in self._works:
@@ -1278,7 +1281,7 @@ class GraphedStep:
             self.warm_out = ts.step(x, y, noise=noise, N=N)
         cur.wait_stream(side)
         torch.cuda.synchronize()
-        self._mode = "thread_local" if ts.world > 1 else "global"      # the communicator's watchdog thread may touch the device
+        self._mode = "thread_local" if ts.comm else "global"           # the communicator's watchdog thread may touch the device
         with torch.cuda.stream(side):
             self._cur = torch.cuda.CUDAGraph()
             self._cur.capture_begin(capture_error_mode=self._mode)

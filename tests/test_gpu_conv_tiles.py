@@ -50,15 +50,15 @@ def test_forced_variant_matches_torch(gpu_lib, variant, shape):
     xd = _nhwc(x)
     wd = resnet.pack_conv_weight(w, torch.bfloat16).cuda()
     tile = variant + 1
-    stats = torch.zeros(ops.stat_shards(), 2, Cout, device="cuda")
+    stats = ops.stat_unit(Cout, "cuda")
     y = ops.conv2d_nhwc(xd, wd, k, k, stride, pad, stats=stats, tile=tile)
     assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, TOL, what="raw conv")
     n = ref.numel() / Cout
-    st = stats.double().sum(0).cpu()
+    st = ops.stat_totals(stats).cpu()
     ys = y.double().cpu().permute(0, 3, 1, 2)           # the statistics are those of the output AS STORED (what the consumer normalises)
     assert_close(st[0] / n, ys.mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean")
     assert_close(st[1] / n, (ys ** 2).mean((0, 2, 3)), 1e-5, what="batch E[x^2]")
-    assert (stats.abs().sum((1, 2)) > 0).sum().item() >= min(ops.stat_shards(), (ref.numel() // Cout + 255) // 256), \
+    assert (stats[0].abs().sum((1, 2)) > 0).sum().item() >= min(ops.stat_shards(), (ref.numel() // Cout + 255) // 256), \
         "statistics must be spread over the shards"
     # fused eval-mode epilogue: relu(conv*scale+shift + residual)
     osc = torch.rand(Cout, generator=g) + 0.5
@@ -93,7 +93,7 @@ def test_data_gradient_form_gate_and_bn_sums(gpu_lib, variant, shape):
     bny = [(torch.randn(conv.shape, generator=g) * 1.5 + 0.3).bfloat16().float() for _ in range(2)]
     mi = [torch.stack([torch.randn(Cout, generator=g) * 0.2, torch.rand(Cout, generator=g) + 0.5]) for _ in range(2)]
     want = (conv + res) * (mask > 0)
-    st = [torch.zeros(ops.stat_shards(), 2, Cout, device="cuda") for _ in range(2)]
+    st = [ops.stat_unit(Cout, "cuda") for _ in range(2)]
     y = ops.conv2d_nhwc(_nhwc(x), resnet.pack_conv_weight(w, torch.bfloat16).cuda(), k, k, stride, pad, residual=_nhwc(res),
                         mask=_nhwc(mask), bn=[(_nhwc(bny[u]), mi[u].cuda().contiguous(), st[u]) for u in range(2)], tile=variant + 1)
     assert_close(y.float().cpu().permute(0, 3, 1, 2), want, TOL, what="gated data gradient")
@@ -101,7 +101,7 @@ def test_data_gradient_form_gate_and_bn_sums(gpu_lib, variant, shape):
     # what the separate reduce pass would read back: each term carries a rounding error of <= 2^-9 of its value, so a
     # channel's sum may differ from the exact one by a few 2^-9 sqrt(sum of squares)
     for u in range(2):
-        s = st[u].double().sum(0).cpu()
+        s = ops.stat_totals(st[u]).cpu()
         xhat = (bny[u].double() - mi[u][0].view(1, -1, 1, 1)) * mi[u][1].view(1, -1, 1, 1)
         for name, got, terms in (("sum g", s[0], conv * (mask > 0)), ("sum g xhat", s[1], conv * (mask > 0) * xhat)):
             exact = (want if name == "sum g" else want * xhat).sum((0, 2, 3))
@@ -124,14 +124,14 @@ def test_residual_tail_operand_load(gpu_lib, variant, affine2):
     a = torch.relu(a).bfloat16().float()
     ref = F.conv2d(a.double(), w.double())
     a_out = torch.empty(B, H, W, Cin, device="cuda", dtype=torch.bfloat16)
-    stats = torch.zeros(ops.stat_shards(), 2, Cout, device="cuda")
+    stats = ops.stat_unit(Cout, "cuda")
     y = ops.conv1x1_residual_in(_nhwc(x), _nhwc(x2), resnet.pack_conv_weight(w, torch.bfloat16).cuda(), sc.cuda(), sh.cuda(),
                                 sc2.cuda() if affine2 else None, sh2.cuda() if affine2 else None, a_out=a_out, stats=stats,
                                 tile=variant + 1)
     assert_close(a_out.float().cpu().permute(0, 3, 1, 2), a, 4e-3, what="block output written by the operand load")
     assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, TOL, what="conv1x1 of the fused tail")
     n = ref.numel() / Cout
-    assert_close(stats.double().sum(0).cpu()[0] / n, y.double().cpu().permute(0, 3, 1, 2).mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean (of the stored output)")
+    assert_close(ops.stat_totals(stats).cpu()[0] / n, y.double().cpu().permute(0, 3, 1, 2).mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean (of the stored output)")
 
 
 # the last three: more tiles than the 256 persistent workgroups (a second tile per workgroup, its first K tiles loaded during the first one's
@@ -157,7 +157,7 @@ def test_residual_tail_kernel_with_transfer_waves(gpu_lib, geom, affine2):
     out = {}
     for tile in (11, 2):
         a_out = torch.full((B, H, W, Cin), float("nan"), device="cuda", dtype=torch.bfloat16)
-        stats = torch.zeros(ops.stat_shards(), 2, Cout, device="cuda")
+        stats = ops.stat_unit(Cout, "cuda")
         y = ops.conv1x1_residual_in(_nhwc(x), _nhwc(x2), wp, sc.cuda(), sh.cuda(), sc2.cuda() if affine2 else None,
                                     sh2.cuda() if affine2 else None, a_out=a_out, stats=stats, tile=tile)
         out[tile] = (y, a_out, stats)
@@ -168,8 +168,8 @@ def test_residual_tail_kernel_with_transfer_waves(gpu_lib, geom, affine2):
     assert_close(y.float().cpu(), out[2][0].float().cpu(), 8e-3, what="against the 128x128 variant")
     n = ref.numel() / Cout
     yd = y.double().cpu().permute(0, 3, 1, 2)
-    assert_close(stats.double().sum(0).cpu()[0] / n, yd.mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean (of the stored output)")
-    assert_close(stats.double().sum(0).cpu()[1] / n, (yd * yd).mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean square (of the stored output)")
+    assert_close(ops.stat_totals(stats).cpu()[0] / n, yd.mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean (of the stored output)")
+    assert_close(ops.stat_totals(stats).cpu()[1] / n, (yd * yd).mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean square (of the stored output)")
     # without a_out / statistics
     y2 = ops.conv1x1_residual_in(_nhwc(x), _nhwc(x2), wp, sc.cuda(), sh.cuda(), sc2.cuda() if affine2 else None,
                                  sh2.cuda() if affine2 else None, tile=11)
@@ -190,15 +190,15 @@ def test_launcher_selected_large_tile_matches_torch(gpu_lib, shape):
     assert _lib.lib().mhe_conv_tile(C.byref(d)) in want, f"expected variant {want} for this geometry, got {_lib.lib().mhe_conv_tile(C.byref(d))}"
     g, x, w = _operands(Cin + Cout, B, H, W, Cin, Cout, k)
     ref = F.conv2d(x, w, None, stride, pad)              # f32 on the bf16-rounded operands (29 GMAC at the 3x3 shape)
-    stats = torch.zeros(ops.stat_shards(), 2, Cout, device="cuda")
+    stats = ops.stat_unit(Cout, "cuda")
     y = ops.conv2d_nhwc(_nhwc(x), resnet.pack_conv_weight(w, torch.bfloat16).cuda(), k, k, stride, pad, stats=stats)
     assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, TOL, what="raw conv")
     n = ref.numel() / Cout
-    st = stats.double().sum(0).cpu()
+    st = ops.stat_totals(stats).cpu()
     ys = y.double().cpu().permute(0, 3, 1, 2)           # statistics of the output as stored
     assert_close(st[0] / n, ys.mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean")
     assert_close(st[1] / n, (ys ** 2).mean((0, 2, 3)), 1e-5, what="batch E[x^2]")
-    assert (stats.abs().sum((1, 2)) > 0).sum().item() > 1, "statistics must be spread over more than one shard"
+    assert (stats[0].abs().sum((1, 2)) > 0).sum().item() > 1, "statistics must be spread over more than one shard"
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -208,9 +208,9 @@ def test_stem_statistics_use_every_shard(gpu_lib, dtype):
     g = torch.Generator().manual_seed(0)
     x = torch.randn(4, 3, 128, 128, generator=g)
     w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
-    stats = torch.zeros(ops.stat_shards(), 2, 64, device="cuda")
+    stats = ops.stat_unit(64, "cuda")
     ops.stem_conv7x7s2(x.cuda(), resnet.pack_stem_weight(w, dtype).cuda(), dtype, stats=stats)
-    assert (stats.abs().sum((1, 2)) > 0).all(), "every statistic shard should receive workgroups"
+    assert (stats[0].abs().sum((1, 2)) > 0).all(), "every statistic shard should receive workgroups"
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
@@ -229,7 +229,7 @@ def test_dgrad_with_batchnorm_reverse_applied_on_load(gpu_lib, Cin, Cout, dt):
     mask = rnd(B, H, H, Cout).to(dt).cuda()
     bn_y = rnd(B, H, H, Cout).to(dt).cuda()
     mi = torch.stack([rnd(Cout) * 0.1, torch.rand(Cout, generator=gen) + 0.5]).cuda().contiguous()
-    st1, st2 = (torch.zeros(ops.stat_shards(), 2, Cout, device="cuda") for _ in range(2))
+    st1, st2 = (ops.stat_unit(Cout, "cuda") for _ in range(2))
     gy = torch.empty_like(g)
     out = ops.conv1x1_dgrad_bn_apply(g, y, coef, w, gy, mask, bn=[(bn_y, mi, st1)])
     gy_ref = (coef[0] * g.float() + coef[1] * y.float() + coef[2])
@@ -239,7 +239,7 @@ def test_dgrad_with_batchnorm_reverse_applied_on_load(gpu_lib, Cin, Cout, dt):
     assert_close(out.float().cpu(), want.cpu(), 2e-5 if dt == torch.float32 else 8e-3, what="gated data gradient")
     ref = ops.conv2d_nhwc(gy, w, 1, 1, 1, 0, mask=mask, bn=[(bn_y, mi, st2)])
     assert_close(out.float().cpu(), ref.float().cpu(), 2e-5 if dt == torch.float32 else 8e-3, what="vs the two-pass form")
-    s1, s2 = st1.sum(0).cpu(), st2.sum(0).cpu()
+    s1, s2 = ops.stat_totals(st1).cpu(), ops.stat_totals(st2).cpu()
     scale = s2.abs().max(1, keepdim=True)[0] + 1.0
     assert ((s1 - s2).abs() <= (1e-4 if dt == torch.float32 else 3e-2) * scale).all(), "BatchNorm-reverse sums"
 
@@ -263,10 +263,10 @@ def test_dgrad_with_batchnorm_reverse_on_load_transfer_wave_kernel(gpu_lib, geom
     mi = torch.stack([rnd(Cout) * 0.1, torch.rand(Cout, generator=gen) + 0.5]).cuda().contiguous()
     res = {}
     for tile in (11, 2):
-        st = torch.zeros(ops.stat_shards(), 2, Cout, device="cuda")
+        st = ops.stat_unit(Cout, "cuda")
         gy = torch.full_like(g, float("nan"))
         out = ops.conv1x1_dgrad_bn_apply(g, y, coef, w, gy, mask, bn=[(bn_y, mi, st)], tile=tile)
-        res[tile] = (out, gy, st.sum(0).cpu())
+        res[tile] = (out, gy, ops.stat_totals(st).cpu())
     out, gy, s1 = res[11]
     assert torch.equal(gy, res[2][1]), "operand written out differs from the 128x128 variant's"
     want = (gy.float() @ w.float().t()) * (mask.float() > 0)
@@ -296,9 +296,9 @@ def test_resident_slab_kernel_with_transfer_waves(gpu_lib, geom, bn_load):
     want = a.reshape(-1, Cin) @ w.float().t()
     res = {}
     for tile in (12, 2):
-        st = torch.zeros(ops.stat_shards(), 2, Cout, device="cuda")
+        st = ops.stat_unit(Cout, "cuda")
         y = ops.conv2d_nhwc(x, w, 1, 1, 1, 0, in_scale=sc, in_shift=sh, relu_in=bn_load, stats=st, tile=tile)
-        res[tile] = (y, st.double().sum(0).cpu())
+        res[tile] = (y, ops.stat_totals(st).cpu())
     y, st = res[12]
     assert_close(y.float().cpu().reshape(-1, Cout), want.cpu(), TOL, what="1x1 product")
     assert_close(y.float().cpu(), res[2][0].float().cpu(), 8e-3, what="vs the 128x128 variant")
@@ -328,13 +328,13 @@ def test_half_resolution_residual(gpu_lib, tile, masked):
     if masked:
         bn_y = torch.randn(B, H, W, Cout, generator=gen).to(bf).cuda()
         mi = torch.stack([torch.randn(Cout, generator=gen) * 0.1, torch.rand(Cout, generator=gen) + 0.5]).cuda().contiguous()
-        st1, st2 = (torch.zeros(ops.stat_shards(), 2, Cout, device="cuda") for _ in range(2))
+        st1, st2 = (ops.stat_unit(Cout, "cuda") for _ in range(2))
         bn1, bn2 = [(bn_y, mi, st1)], [(bn_y, mi, st2)]
     got = ops.conv2d_nhwc(x, w, 1, 1, 1, 0, residual=half, mask=mask, bn=bn1, tile=tile, res_half=True)
     want = ops.conv2d_nhwc(x, w, 1, 1, 1, 0, residual=full, mask=mask, bn=bn2, tile=tile)
     assert torch.equal(got, want)
     if masked:
-        assert_close(st1.sum(0).cpu(), st2.sum(0).cpu(), 1e-6, 1e-5, what="BatchNorm-reverse sums")
+        assert_close(ops.stat_totals(st1).cpu(), ops.stat_totals(st2).cpu(), 1e-6, 1e-5, what="BatchNorm-reverse sums")
 
 
 @pytest.mark.parametrize("bn_load", [False, True], ids=["plain", "bn-on-load"])
@@ -363,15 +363,15 @@ def test_streaming_1x1_kernel(gpu_lib, shape, bn_load):
     d = _lib.ConvDesc(B, H, W, Cin, Cout, 1, 1, 1, 0, ops.BF16, 0, 0, 0)
     assert _lib.lib().mhe_conv_tile_mode(C.byref(d), 1 if bn_load else 0) == 8, "the launcher should pick the streaming kernel here"
     for tile in (0, 9):
-        stats = torch.zeros(ops.stat_shards(), 2, Cout, device="cuda")
+        stats = ops.stat_unit(Cout, "cuda")
         y = ops.conv2d_nhwc(xd, wd, 1, 1, 1, 0, stats=stats, tile=tile, **kw)
         assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, TOL, what="raw conv")
         n = ref.numel() / Cout
-        st = stats.double().sum(0).cpu()
+        st = ops.stat_totals(stats).cpu()
         ys = y.double().cpu().permute(0, 3, 1, 2)
         assert_close(st[0] / n, ys.mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean")
         assert_close(st[1] / n, (ys ** 2).mean((0, 2, 3)), 1e-5, what="batch E[x^2]")
-        assert (stats.abs().sum((1, 2)) > 0).sum().item() > 8, "statistics must be spread over the shards"
+        assert (stats[0].abs().sum((1, 2)) > 0).sum().item() > 8, "statistics must be spread over the shards"
     y2 = ops.conv2d_nhwc(xd, wd, 1, 1, 1, 0, tile=9, **kw)                  # without statistics
     assert torch.equal(y2, y)
 
@@ -394,7 +394,7 @@ def test_streaming_1x1_kernel_data_gradient_form(gpu_lib, shape, nbn, res):
         for u in range(nbn):
             by = rnd(B, H, W, Cout) if k == 0 else bns[0][u][0]
             mi = (torch.stack([torch.randn(Cout, generator=g) * 0.1, torch.rand(Cout, generator=g) + 0.5]).cuda().contiguous() if k == 0 else bns[0][u][1])
-            bns[k].append((by, mi, torch.zeros(ops.stat_shards(), 2, Cout, device="cuda")))
+            bns[k].append((by, mi, ops.stat_unit(Cout, "cuda")))
     kw = dict(residual=residual, mask=mask, res_half=res == "half")
     got = ops.conv2d_nhwc(xd, wd, 1, 1, 1, 0, bn=bns[0] or None, tile=9, **kw)
     auto = ops.conv2d_nhwc(xd, wd, 1, 1, 1, 0, tile=0, **kw)
@@ -402,7 +402,7 @@ def test_streaming_1x1_kernel_data_gradient_form(gpu_lib, shape, nbn, res):
     assert torch.equal(got, auto), "the launcher picks the streaming kernel for this shape"
     assert_close(got.float().cpu(), want.float().cpu(), 8e-3, what="gated data gradient")        # different summation order before the bf16 rounding
     for u in range(nbn):
-        a, b = bns[0][u][2].sum(0).cpu(), bns[1][u][2].sum(0).cpu()
+        a, b = ops.stat_totals(bns[0][u][2]).cpu(), ops.stat_totals(bns[1][u][2]).cpu()
         scale = b.abs().max(1, keepdim=True)[0] + 1.0
         assert ((a - b).abs() <= 2e-2 * scale).all(), f"BatchNorm-reverse sums of unit {u}"
 
@@ -424,13 +424,13 @@ def test_row_streaming_3x3_kernel(gpu_lib, B, H, form):
         rnd = lambda *s: torch.randn(*s, generator=g).bfloat16().cuda()
         mask, res, by = rnd(B, H, W, C), rnd(B, H, W, C), rnd(B, H, W, C)
         mi = torch.stack([torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5]).cuda().contiguous()
-        st = [torch.zeros(ops.stat_shards(), 2, C, device="cuda") for _ in range(2)]
+        st = [ops.stat_unit(C, "cuda") for _ in range(2)]
         got = ops.conv2d_nhwc(xd, wd, 3, 3, 1, 1, residual=res, mask=mask, bn=[(by, mi, st[0])], tile=10)
         auto = ops.conv2d_nhwc(xd, wd, 3, 3, 1, 1, residual=res, mask=mask, tile=0)
         want = ops.conv2d_nhwc(xd, wd, 3, 3, 1, 1, residual=res, mask=mask, bn=[(by, mi, st[1])], tile=1)
         assert torch.equal(got, auto)
         assert_close(got.float().cpu(), want.float().cpu(), 8e-3, what="gated data gradient")
-        a, b = st[0].sum(0).cpu(), st[1].sum(0).cpu()
+        a, b = ops.stat_totals(st[0]).cpu(), ops.stat_totals(st[1]).cpu()
         assert ((a - b).abs() <= 2e-2 * (b.abs().max(1, keepdim=True)[0] + 1.0)).all(), "BatchNorm-reverse sums"
         return
     kw, xin = {}, x
@@ -440,11 +440,11 @@ def test_row_streaming_3x3_kernel(gpu_lib, B, H, form):
         xin = torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).bfloat16().float()
     ref = F.conv2d(xin.double(), w.double(), None, 1, 1)
     for tile in (0, 10):
-        stats = torch.zeros(ops.stat_shards(), 2, C, device="cuda")
+        stats = ops.stat_unit(C, "cuda")
         y = ops.conv2d_nhwc(xd, wd, 3, 3, 1, 1, stats=stats, tile=tile, **kw)
         assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, TOL, what="raw conv")
         n = ref.numel() / C
-        stt = stats.double().sum(0).cpu()
+        stt = ops.stat_totals(stats).cpu()
         ys = y.double().cpu().permute(0, 3, 1, 2)
         assert_close(stt[0] / n, ys.mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean")
         assert_close(stt[1] / n, (ys ** 2).mean((0, 2, 3)), 1e-5, what="batch E[x^2]")
@@ -476,22 +476,22 @@ def test_bottleneck_tail_with_conv3_reevaluated(gpu_lib, geom, affine2):
     w3d, w1d = resnet.pack_conv_weight(w3, torch.bfloat16).cuda(), resnet.pack_conv_weight(w1, torch.bfloat16).cuda()
     S = ops.stat_shards()
     # the unfused path: conv3 with bn2 + relu on the operand load (+ statistics), then the MODE 2 tail
-    st3_ref, st1_ref = torch.zeros(S, 2, C4, device="cuda"), torch.zeros(S, 2, N2, device="cuda")
+    st3_ref, st1_ref = ops.stat_unit(C4, "cuda"), ops.stat_unit(N2, "cuda")
     y3 = ops.conv2d_nhwc(y2d, w3d, 1, 1, 1, 0, in_scale=cu(s2), in_shift=cu(h2), relu_in=True, stats=st3_ref)
     a_ref = torch.empty_like(y3)
     y1_ref = ops.conv1x1_residual_in(y3, idd, w1d, cu(s3), cu(h3), cu(si), cu(hi), a_out=a_ref, stats=st1_ref)
     # statistics-only conv3: same sums, nothing stored
-    st3 = torch.zeros(S, 2, C4, device="cuda")
+    st3 = ops.stat_unit(C4, "cuda")
     ops.conv1x1_stats(y2d, w3d, cu(s2), cu(h2), st3)
-    assert_close(st3.double().sum(0).cpu(), st3_ref.double().sum(0).cpu(), 1e-6, what="conv3 statistics without the store")
+    assert_close(ops.stat_totals(st3).cpu(), ops.stat_totals(st3_ref).cpu(), 1e-6, what="conv3 statistics without the store")
     # fused tail
     assert ops.bottleneck_tail_supported(B, H, W, Cb, N2)
-    st1 = torch.zeros(S, 2, N2, device="cuda")
+    st1 = ops.stat_unit(N2, "cuda")
     a, y1 = ops.bottleneck_tail(y2d, (cu(s2), cu(h2)), w3d, (cu(s3), cu(h3)), idd, (cu(si), cu(hi)) if affine2 else None, w1d, stats=st1)
     torch.cuda.synchronize()
     assert torch.equal(a, a_ref), f"block output differs on {(a != a_ref).float().mean().item():.2e} of the elements"
     assert torch.equal(y1, y1_ref), f"conv1 output differs on {(y1 != y1_ref).float().mean().item():.2e} of the elements"
-    assert_close(st1.double().sum(0).cpu(), st1_ref.double().sum(0).cpu(), 1e-6, what="conv1 statistics")
+    assert_close(ops.stat_totals(st1).cpu(), ops.stat_totals(st1_ref).cpu(), 1e-6, what="conv1 statistics")
     # ... and against torch (f64) on the same bf16-rounded operands
     a2 = F.relu(y2.double() * s2.double()[None, :, None, None] + h2.double()[None, :, None, None]).bfloat16().double()
     t = F.conv2d(a2, w3.double()).bfloat16().double()
@@ -535,7 +535,7 @@ def test_gram_statistics_give_the_convolutions_batchnorm_affine(gpu_lib, geom):
     rv_ref = 0.9 * (0.9 * 1.0 + 0.1 * var * P / (P - 1)) + 0.1 * var * P / (P - 1)
     assert_close(rv.cpu(), rv_ref, 1e-4, what="running_var after two steps")
     # the statistics-only launch (bf16-rounded outputs) agrees to the rounding noise of its sums
-    st = torch.zeros(ops.stat_shards(), 2, C4, device="cuda")
+    st = ops.stat_unit(C4, "cuda")
     ops.conv1x1_stats(xd, wd, s2.cuda(), h2.cuda(), st)
     sc2, sh2 = ops.bn_finalize(st, gamma.cuda(), beta.cuda(), None, None, float(P))
     assert_close(sc.cpu(), sc2.cpu(), 2e-3, what="scale vs statistics-only launch")
@@ -556,7 +556,7 @@ def test_stem_with_the_max_pool_inside(gpu_lib, B):
     gamma[::5] = -gamma[::5].abs()                                 # negative scales: window minimum
     gamma[7] = 0.0
     S = ops.stat_shards()
-    st_ref, st = torch.zeros(S, 2, 64, device="cuda"), torch.zeros(S, 2, 64, device="cuda")
+    st_ref, st = ops.stat_unit(64, "cuda"), ops.stat_unit(64, "cuda")
     y = ops.stem_conv7x7s2(x, wd, torch.bfloat16, stats=st_ref)           # [B,128,128,64] raw
     assert ops.stem_pool_supported(B, 256, 256, torch.bfloat16) and not ops.stem_pool_supported(B, 128, 128, torch.bfloat16)
     p = ops.stem_conv7x7s2_pool(x, wd, gamma.cuda(), stats=st)
@@ -566,7 +566,7 @@ def test_stem_with_the_max_pool_inside(gpu_lib, B):
     pmin = -F.max_pool2d(-yn, 3, 2, 1)
     want = torch.where((gamma.cuda() >= 0)[None, :, None, None], pmax, pmin).permute(0, 2, 3, 1).contiguous().bfloat16()
     assert torch.equal(p, want), f"pooled raw output differs on {(p != want).float().mean().item():.2e} of the elements"
-    assert_close(st.double().sum(0).cpu(), st_ref.double().sum(0).cpu(), 1e-6, what="conv1 batch statistics")
+    assert_close(ops.stat_totals(st).cpu(), ops.stat_totals(st_ref).cpu(), 1e-6, what="conv1 batch statistics")
     # ... and the identity the consumers rely on
     sc, sh = gamma.cuda() * 0.7, torch.randn(64, generator=g).cuda()
     a_ref = F.max_pool2d(F.relu(yn * sc[None, :, None, None] + sh[None, :, None, None]), 3, 2, 1)
@@ -603,8 +603,9 @@ def test_conv3_batchnorm_reverse_from_gram_statistics_against_autograd(gpu_lib, 
     _, _, mi = ops.conv1x1_gram_bn(Ax, ones, zeros, wd, gamma.cuda(), beta.cuda(), rm, rv, gbuf, want_mean_invstd=True)
     D = torch.zeros(C4, Cb, device="cuda")
     ops.conv_wgrad(Ax, gx, 1, 1, 1, 0, D)
-    rev = torch.zeros(ops.stat_shards(), 2, C4, device="cuda")
-    rev[3, 0] = g.sum((0, 2, 3)).cuda(); rev[:, 1] = 123.0                              # the second sum is not read
+    revf = torch.zeros(ops.stat_shards(), 2, C4, device="cuda")
+    revf[3, 0] = g.sum((0, 2, 3)).cuda(); revf[:, 1] = 123.0                            # the second sum is not read
+    rev = ops.stat_from_float(revf)
     dgamma, dbeta, dW = torch.zeros(C4, device="cuda"), torch.zeros(C4, device="cuda"), torch.zeros(C4, Cb, device="cuda")
     w_dg, S, c0 = torch.zeros(Cb, C4, device="cuda", dtype=torch.bfloat16), torch.zeros(Cb, Cb, device="cuda", dtype=torch.bfloat16), torch.zeros(Cb, device="cuda")
     ops.conv3_bn_fold(D, wd, gbuf[1], rev, gamma.cuda(), mi, P, dgamma, dbeta, dW, w_dg, S, c0, torch.zeros(2 * C4, device="cuda"))
@@ -631,12 +632,12 @@ def test_conv3_batchnorm_reverse_from_gram_statistics_against_autograd(gpu_lib, 
     assert_close(gAc.float().cpu().permute(0, 3, 1, 2), Ad.grad, 2e-2, what="data gradient, one concatenated launch")
     assert_close(gAc.float().cpu(), gA.float().cpu(), 1e-2, what="concatenated launch vs residual form")     # (the residual form rounds A S to bf16)
     # ... and the same launch with the consumer's BatchNorm-reverse sums (one bn triple) leaves the same tensor
-    st = torch.zeros(ops.stat_shards(), 2, Cb, device="cuda")
+    st = ops.stat_unit(Cb, "cuda")
     mi2 = torch.stack([torch.zeros(Cb), torch.ones(Cb)]).cuda()
     gA2 = ops.conv2d_nhwc(gx, w_dg, 1, 1, 1, 0, residual=t_res, mask=Ax, out_shift=c0, bn=[(Ax, mi2, st)])
     assert torch.equal(gA2, gA)
     # (sum_p of a train-mode BatchNorm's input gradient is zero: the sums are rounding noise - compared on the scale of sum |g|)
-    err = (st.double().sum(0)[0] - gA.double().sum((0, 1, 2))).abs() / gA.double().abs().sum((0, 1, 2))
+    err = (ops.stat_totals(st)[0] - gA.double().sum((0, 1, 2))).abs() / gA.double().abs().sum((0, 1, 2))
     assert float(err.max()) < 4e-3, float(err.max())
 
 
@@ -672,9 +673,9 @@ def test_relu_gate_as_bits_for_the_streaming_data_gradient(gpu_lib):
     S = ops.stat_shards()
     outs = []
     for mb in (None, bits):
-        st0, st1 = torch.zeros(S, 2, C4, device="cuda"), torch.zeros(S, 2, C4, device="cuda")
+        st0, st1 = ops.stat_unit(C4, "cuda"), ops.stat_unit(C4, "cuda")
         o = ops.conv2d_nhwc(gy, wdg, 1, 1, 1, 0, residual=res, mask=a, bn=[(ybn, mi, st0), (a, mi, st1)], mask_bits=mb)
-        outs.append((o, st0.sum(0), st1.sum(0)))
+        outs.append((o, ops.stat_totals(st0), ops.stat_totals(st1)))
     (o0, s00, s01), (o1, s10, s11) = outs
     assert torch.equal(o0, o1)
     assert_close(s10.cpu(), s00.cpu(), 1e-5, what="sums of the consumer with a raw output")
@@ -708,11 +709,11 @@ def test_3x3_kernel_with_the_input_tile_resident_in_lds(gpu_lib, geom, form):
         rnd = lambda *s: torch.randn(*s, generator=g).bfloat16().cuda()
         mask, res, by = rnd(B, H, W, Cout), rnd(B, H, W, Cout), rnd(B, H, W, Cout)
         mi = torch.stack([torch.randn(Cout, generator=g) * 0.1, torch.rand(Cout, generator=g) + 0.5]).cuda().contiguous()
-        st = [torch.zeros(ops.stat_shards(), 2, Cout, device="cuda") for _ in range(2)]
+        st = [ops.stat_unit(Cout, "cuda") for _ in range(2)]
         got = ops.conv3x3_halo(xd, wh, residual=res, mask=mask, bn=(by, mi, st[0]))
         want = ops.conv2d_nhwc(xd, wd, 3, 3, 1, 1, residual=res, mask=mask, bn=[(by, mi, st[1])], tile=2)
         assert_close(got.float().cpu(), want.float().cpu(), 8e-3, what="gated data gradient")
-        a, b = st[0].sum(0).cpu(), st[1].sum(0).cpu()
+        a, b = ops.stat_totals(st[0]).cpu(), ops.stat_totals(st[1]).cpu()
         assert ((a - b).abs() <= 2e-2 * (b.abs().max(1, keepdim=True)[0] + 1.0)).all(), "BatchNorm-reverse sums"
         return
     kw, xin = {}, x
@@ -723,11 +724,11 @@ def test_3x3_kernel_with_the_input_tile_resident_in_lds(gpu_lib, geom, form):
         kw = dict(in_scale=sc.cuda(), in_shift=sh.cuda(), relu_in=True, a_out=a_out)
         xin = torch.relu(x * sc.to(x.device).view(1, -1, 1, 1) + sh.to(x.device).view(1, -1, 1, 1)).bfloat16().float()
     ref = F.conv2d(xin.double() if B <= 16 else xin, w.double() if B <= 16 else w, None, 1, 1)
-    stats = torch.zeros(ops.stat_shards(), 2, Cout, device="cuda")
+    stats = ops.stat_unit(Cout, "cuda")
     y = ops.conv3x3_halo(xd, wh, stats=stats, **kw)
     assert_close(y.float().cpu().permute(0, 3, 1, 2), ref.cpu(), TOL, what="raw conv")
     n = ref.numel() / Cout
-    stt = stats.double().sum(0).cpu()
+    stt = ops.stat_totals(stats).cpu()
     ys = y.double().cpu().permute(0, 3, 1, 2)
     assert_close(stt[0] / n, ys.mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean")
     assert_close(stt[1] / n, (ys ** 2).mean((0, 2, 3)), 1e-5, what="batch E[x^2]")
@@ -767,14 +768,14 @@ def test_3x3_resident_tile_data_gradient_with_batchnorm_reverse_on_its_load(gpu_
     gamma = (torch.rand(Cin, generator=g0) + 0.5).cuda()
     S = ops.stat_shards()
     dg, db = torch.zeros(Cin, device="cuda"), torch.zeros(Cin, device="cuda")
-    sums = torch.zeros(S, 2, Cin, device="cuda")
+    sums = ops.stat_unit(Cin, "cuda")
     coef = ops.bn_backward(g, None, y, mi_in, gamma, sums, dg, db, coef_only=True)
     gy_ref = ops.bn_backward(g, None, y, mi_in, gamma, sums, dg, db, reduced=True)        # (the same sums: the same coefficients to the bit)
-    st = [torch.zeros(S, 2, Cout, device="cuda") for _ in range(2)]
+    st = [ops.stat_unit(Cout, "cuda") for _ in range(2)]
     gy = torch.empty_like(g)
     got = ops.conv3x3_halo_dgrad_bn(g, y, coef, wh, mask, gy_out=gy, bn=(by, mi_out, st[0]))
     want = ops.conv3x3_halo(gy_ref, wh, mask=mask, bn=(by, mi_out, st[1]))
     assert torch.equal(gy, gy_ref), (gy.float() - gy_ref.float()).abs().max().item()
     assert torch.equal(got, want)
-    a, b = st[0].sum(0).cpu(), st[1].sum(0).cpu()
+    a, b = ops.stat_totals(st[0]).cpu(), ops.stat_totals(st[1]).cpu()
     assert ((a - b).abs() <= 1e-3 * (b.abs().max(1, keepdim=True)[0] + 1.0)).all(), "BatchNorm-reverse sums"

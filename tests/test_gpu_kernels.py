@@ -189,12 +189,12 @@ def test_conv_matches_torch(gpu_lib, dtype, cfg):
     ref = torch.nn.functional.conv2d(xt.double(), wt.double(), None, stride, pad)
     xd = ops.nchw_to_nhwc(_dev(x), dtype)
     wd = resnet.pack_conv_weight(torch.as_tensor(w), dtype, xd.shape[-1]).cuda()
-    stats = torch.zeros(ops.stat_shards(), 2, Cout, device="cuda")
+    stats = ops.stat_unit(Cout, "cuda")
     y = ops.conv2d_nhwc(xd, wd, K, K, stride, pad, stats=stats)
     tol = 2e-6 if dtype == torch.float32 else 6e-3        # bf16: output rounding 2^-9
     assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, tol, what="raw conv")
     n = ref.numel() / Cout
-    st = stats.double().sum(0).cpu()
+    st = ops.stat_totals(stats).cpu()
     ys = y.double().cpu().permute(0, 3, 1, 2)           # the statistics are those of the output AS STORED (what the consumer normalises)
     assert_close(st[0] / n, ys.mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean")
     assert_close(st[1] / n, (ys ** 2).mean((0, 2, 3)), 1e-5, what="batch E[x^2]")
@@ -229,12 +229,12 @@ def test_stem_conv_matches_torch(gpu_lib, dtype, B, H, W):
     if dtype == torch.bfloat16:
         xt, wt = xt.bfloat16().float(), wt.bfloat16().float()
     ref = torch.nn.functional.conv2d(xt.double(), wt.double(), None, 2, 3)
-    stats = torch.zeros(ops.stat_shards(), 2, 64, device="cuda")
+    stats = ops.stat_unit(64, "cuda")
     y = ops.stem_conv7x7s2(_dev(x), resnet.pack_stem_weight(torch.as_tensor(w), dtype).cuda(), dtype, stats=stats)
     tol = 2e-6 if dtype == torch.float32 else 6e-3
     assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, tol, what="stem conv")
     n = ref.numel() / 64
-    st = stats.double().sum(0).cpu()
+    st = ops.stat_totals(stats).cpu()
     ys = y.double().cpu().permute(0, 3, 1, 2)           # the statistics are those of the output AS STORED (what the consumer normalises)
     assert_close(st[0] / n, ys.mean((0, 2, 3)), 1e-5, 1e-5, what="batch mean")
     assert_close(st[1] / n, (ys ** 2).mean((0, 2, 3)), 1e-5, what="batch E[x^2]")
@@ -369,7 +369,10 @@ def test_bn_finalize_step_clears_its_accumulators_and_counts_the_batch(gpu_lib):
     from mhentropy_amd import ops
     C_, S = 96, ops.stat_shards()
     rng = np.random.default_rng(3)
-    stats = _dev(rng.random((S, 2, C_)).astype(np.float32) * 10 + np.array([0.0, 400.0], np.float32)[None, :, None])
+    sf = rng.random((S, 2, C_)).astype(np.float32) * 10 + np.array([0.0, 400.0], np.float32)[None, :, None]
+    stats = ops.stat_from_float(_dev(sf))
+    # the unit holds the f32 shard values exactly (two-word fixed point: quantum 2^-56), and its totals are their exact sum
+    assert torch.equal(ops.stat_totals(stats).cpu(), torch.as_tensor(sf).double().sum(0))
     gamma, beta = _dev(rng.normal(1, 0.1, C_).astype(np.float32)), _dev(rng.normal(0, 0.1, C_).astype(np.float32))
     rm, rv = torch.zeros(C_, device="cuda"), torch.ones(C_, device="cuda")
     nbt = torch.tensor(7, dtype=torch.int64, device="cuda")
@@ -378,6 +381,14 @@ def test_bn_finalize_step_clears_its_accumulators_and_counts_the_batch(gpu_lib):
     for a, b in zip(got, ref):
         assert torch.equal(a, b)
     assert int(nbt) == 8 and not stats.any()
+    mean_ref = torch.as_tensor(sf).double().sum(0)[0] / 4096.0
+    assert_close(got[2][0].cpu().double(), mean_ref, 1e-6, what="mean from the fixed-point shards")
+    # a NaN / Inf / out-of-range partial plants a sticky marker: the finalize launch reports NaN for that channel (as the f32 sum did)
+    bad = ops.stat_from_float(_dev(sf))
+    bad[0, 5, 0, 3] = 1 << 62
+    sc, sh = ops.bn_finalize(bad, gamma, beta, None, None, 4096.0)
+    assert torch.isnan(sc[3]) or torch.isnan(sh[3])
+    assert torch.isfinite(sc[:3]).all() and torch.isfinite(sc[4:]).all()
 
 
 def test_linear_with_bf16_copy_and_stochastic_head(gpu_lib):
@@ -418,6 +429,14 @@ def test_basic_enc_returns_the_references_triple(gpu_lib):
     assert torch.isfinite(z2).all() and not torch.equal(z2, z)
     zd, mnd, _ = enc(x, deterministic=True)
     assert torch.equal(zd, mnd)
+    # list-valued latent sizes: mn.shape != sd.shape -> z = mn, sd keeps l2's own shape (hand/network.py:133-136)
+    enc2 = BasicEnc(n_latent=[64, 32], backbone="resnet18", pretrained=False).cuda().eval()
+    z3, mn3, sd3 = enc2(x)
+    assert mn3.shape == (4, 64) and sd3.shape == (4, 32) and torch.equal(z3, mn3)
+    with torch.no_grad():
+        f2 = resnet_ref.forward({k: v.detach().cpu() for k, v in enc2.res.state_dict().items()}, torch.as_tensor(xn), "resnet18", False)
+        sd3_ref = torch.exp(0.5 * torch.nn.functional.linear(f2, enc2.l2[0].weight.cpu(), enc2.l2[0].bias.cpu()))
+    assert_close(sd3.cpu(), sd3_ref, 2e-4, what="sd of the narrower head")
 
 
 def test_pack_transpose_bf16(gpu_lib):

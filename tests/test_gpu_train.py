@@ -178,14 +178,14 @@ def test_stride2_dgrad_parity_classes_gate_and_bn_sums(gpu_lib, tile):
     wd = pack(train.dgrad_operand_index(idx))
     bn_y = torch.randn(B, H, H, Cin, generator=g).to(dt).cuda()
     mi = torch.stack([torch.randn(Cin, generator=g) * 0.1, torch.rand(Cin, generator=g) + 0.5]).cuda().contiguous()
-    st_new, st_old = (torch.zeros(ops.stat_shards(), 2, Cin, device="cuda") for _ in range(2))
+    st_new, st_old = (ops.stat_unit(Cin, "cuda") for _ in range(2))
     mask = _nhwc(x.detach(), dt)
     new = ops.conv3x3s2_dgrad(_nhwc(gy, dt), w_s2, residual=_nhwc(res, dt), mask=mask, bn=[(bn_y, mi, st_new)], tile=tile)
     old = ops.conv2d_nhwc(ops.upsample2(_nhwc(gy, dt), H, H), wd, 3, 3, 1, 1, residual=_nhwc(res, dt), mask=mask, bn=[(bn_y, mi, st_old)])
     want = ((x.grad + res) * (x.detach() > 0)).permute(0, 2, 3, 1)
     assert_close(new.float().cpu(), want, 1.5e-2, what="gated dX + residual")
     assert_close(new.float().cpu(), old.float().cpu(), 8e-3, what="parity classes vs zero-dilated form")      # both round to bf16 once
-    sn, so = st_new.sum(0).cpu(), st_old.sum(0).cpu()
+    sn, so = ops.stat_totals(st_new).cpu(), ops.stat_totals(st_old).cpu()
     gf = new.float().cpu().reshape(-1, Cin)
     xh = (bn_y.float().cpu().reshape(-1, Cin) - mi[0].cpu()) * mi[1].cpu()
     bound = lambda t: 5 * 2.0 ** -9 * t.pow(2).sum(0).sqrt() + 1e-4        # the kernel sums the values before their bf16 rounding
@@ -209,7 +209,7 @@ def test_batchnorm_relu_backward(gpu_lib, C, P, dt):
     a.backward(go)
     mean, var = y.detach().mean(0), y.detach().var(0, unbiased=False)
     mi = torch.stack([mean, 1 / torch.sqrt(var + 1e-5)]).cuda().contiguous()
-    st = torch.zeros(ops.stat_shards(), 2, C, device="cuda")
+    st = ops.stat_unit(C, "cuda")
     dga, dbe = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
     yy = y.detach().to(dt).cuda().view(1, 1, P, C)
     gy, gm = ops.bn_backward(go.to(dt).cuda().view(1, 1, P, C), a.detach().to(dt).cuda().view(1, 1, P, C), yy, mi, gamma.detach().cuda(), st,
@@ -273,7 +273,7 @@ def test_stem_pool_with_batchnorm_folded_in(gpu_lib, dt, H, W):
     assert torch.equal(a, a_ref) and torch.equal(idx, idx_ref)
     gy = torch.randn(a.shape, generator=g).to(dt).cuda()
     mi = torch.stack([mean, invstd]).cuda().contiguous()
-    st = torch.zeros(ops.stat_shards(), 2, C, device="cuda")
+    st = ops.stat_unit(C, "cuda")
     gx = ops.maxpool3x3s2_bwd_bn(gy, idx, y0d, sc, sh, mi, st)
     g_sep = ops.maxpool3x3s2_bwd(gy, idx_ref, H, W)
     assert torch.equal(gx, torch.where(r0 > 0, g_sep, torch.zeros_like(g_sep)))
@@ -281,12 +281,12 @@ def test_stem_pool_with_batchnorm_folded_in(gpu_lib, dt, H, W):
     from mhentropy_amd import _lib
     ops.check(_lib.lib().mhe_bn_bwd_reduce_nhwc(ops._ptr(g_sep), ops._ptr(r0), ops._ptr(y0d), ops._ptr(mi), ops._ptr(st_ref), B * H * W, C,
                                                 ops.dtype_code(dt), ops._stream()), "mhe_bn_bwd_reduce_nhwc")
-    assert_close(st.sum(0).cpu(), st_ref.sum(0).cpu(), 1e-5, what="BatchNorm-reverse sums")
+    assert_close(ops.stat_totals(st).cpu(), ops.stat_totals(st_ref).cpu(), 1e-5, what="BatchNorm-reverse sums")
     # the two-walk form of the train step: sums without the scattered gradient, then the BatchNorm reverse applied where it is formed -
     # to the bit what the apply pass makes of the stored gradient
     st2 = torch.zeros_like(st)
     assert ops.maxpool3x3s2_bwd_bn(gy, idx, y0d, sc, sh, mi, st2, want_gx=False) is None
-    assert_close(st2.sum(0).cpu(), st.sum(0).cpu(), 1e-6, what="sums of the walk that stores nothing")
+    assert_close(ops.stat_totals(st2).cpu(), ops.stat_totals(st).cpu(), 1e-6, what="sums of the walk that stores nothing")
     gamma = (torch.rand(C, generator=g) + 0.5).cuda()
     dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
     coef = ops.bn_bwd_coef(st, gamma, mi, dg, db, B * H * W)
@@ -576,7 +576,9 @@ def test_run_entry_point(gpu_lib, tmp_path, monkeypatch):
     assert len(log) == 2 and all(np.isfinite(r["loss"]) and r["epe3d"] > 0 and r["epe2d"] > 0 for r in log)
     assert log[0]["lr"] == 2e-4 and abs(log[1]["lr"] - 2e-5) < 1e-12
     sd = torch.load(ck)
-    assert set(sd) == {"decoderPose", "encoderRGB"} and "q_z_giv_i.s.0.l.0.weight" in sd["encoderRGB"]
+    assert set(sd) == {"decoderPose", "encoderRGB", "mhe_rng_state"} and "q_z_giv_i.s.0.l.0.weight" in sd["encoderRGB"]
+    # the device generator's words travel with the checkpoint: 8 iterations drew the loss noise + the metrics pass's noise each
+    assert sd["mhe_rng_state"].dtype == torch.int64 and int(sd["mhe_rng_state"][0]) == 0 and int(sd["mhe_rng_state"][1]) > 0
     fresh = harness.build_mhent(backbone="resnet18", h_dims=(64, 64), num_steps=2, tables=synth.mano_tables(0))
     harness.load_model(ck, fresh)
     assert torch.equal(fresh.det_head[0].weight, sd["encoderRGB"]["det_head.0.weight"])
@@ -604,7 +606,8 @@ def test_run_entry_point(gpu_lib, tmp_path, monkeypatch):
     # the batch it saw last and 3,700 / 9,005 on batches 0 / 1, which the resumed run replays; both construction paths and the packs
     # agree to 1e-6.  Adam's moments restart on resume as in the reference, hand/CrossModalHand.py:191-203,589-602.)
     from mhentropy_amd import ops
-    ops.rng_state(torch.device("cuda", torch.cuda.current_device()), seed=0)     # run.main seeds the device generator the same way; its first draw is the loss noise
+    # run.main restores the checkpoint's generator words (the resumed run CONTINUES the base-noise stream); its first draw is the loss noise
+    ops.rng_set_state(torch.device("cuda", torch.cuda.current_device()), sd["mhe_rng_state"])
     noise0 = ops.randn(6 * 8, 45, torch.device("cuda", torch.cuda.current_device()))
     xn, yn = synth.batch(0, 8, image_size=96)
     fresh = fresh.cuda().train()

@@ -62,7 +62,7 @@ def main():
         pad = k // 2
         Ho = (H + 2 * pad - k) // stride + 1
         y = torch.empty(B, Ho, Ho, Cout, device="cuda", dtype=dt)
-        st = None if args.no_stats else torch.zeros(ops.stat_shards(), 2, Cout, device="cuda")
+        st = None if args.no_stats else ops.stat_unit(Cout, "cuda")
         isc = ish = None
         if fused and not args.no_affine:
             isc, ish = torch.rand(Cp, device="cuda") + 0.5, torch.randn(Cp, device="cuda") * 0.1

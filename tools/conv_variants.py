@@ -38,7 +38,7 @@ def main():
         pad = k // 2
         Ho = (H + 2 * pad - k) // stride + 1
         y = torch.empty(B, Ho, Ho, Cout, device="cuda", dtype=torch.bfloat16)
-        st = None if args.no_stats else torch.zeros(ops.stat_shards(), 2, Cout, device="cuda")
+        st = None if args.no_stats else ops.stat_unit(Cout, "cuda")
         flops = 2.0 * B * Ho * Ho * Cout * k * k * Cin
         nbytes = 2.0 * (x.numel() + y.numel() + w.numel())
         if args.tail:

@@ -12,7 +12,7 @@ mask, res = torch.randn(B, H, H, Cout, device="cuda").bfloat16(), torch.randn(B,
 bits = torch.zeros(B, H, H, Cout // 8, device="cuda", dtype=torch.uint8)
 by = torch.randn(B, H, H, Cout, device="cuda").bfloat16()
 for nbn, use_bits in ((1, True), (1, False), (0, True)):
-    bn = [(by, torch.rand(2, Cout, device="cuda") + 0.5, torch.zeros(ops.stat_shards(), 2, Cout, device="cuda"))] if nbn else None
+    bn = [(by, torch.rand(2, Cout, device="cuda") + 0.5, ops.stat_unit(Cout, "cuda"))] if nbn else None
     nbytes = 2.0 * (x.numel() + (2 + nbn) * mask.numel()) + (bits.numel() if use_bits else 2.0 * mask.numel())
     times = {}
     for t in (0, 9, 8, 2, 3):          # launcher's choice, streaming kernel, phase-pipelined 256x256, register-staged 128x128, 256x256

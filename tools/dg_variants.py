@@ -10,7 +10,7 @@ for name, H, Cin, Cout, nbn, k in (("l1 conv1 dgrad", 64, 64, 256, 1, 1), ("l1.1
     x = torch.randn(B, H, H, Cin, device="cuda").bfloat16()
     w = resnet.pack_conv_weight(torch.randn(Cout, Cin, k, k) * 0.05, torch.bfloat16).cuda()
     mask, res = torch.randn(B, H, H, Cout, device="cuda").bfloat16(), torch.randn(B, H, H, Cout, device="cuda").bfloat16()
-    bn = [(torch.randn(B, H, H, Cout, device="cuda").bfloat16(), torch.rand(2, Cout, device="cuda") + 0.5, torch.zeros(ops.stat_shards(), 2, Cout, device="cuda")) for _ in range(nbn)]
+    bn = [(torch.randn(B, H, H, Cout, device="cuda").bfloat16(), torch.rand(2, Cout, device="cuda") + 0.5, ops.stat_unit(Cout, "cuda")) for _ in range(nbn)]
     nbytes = 2.0 * (x.numel() + (3 + nbn) * mask.numel())
     tiles = [8, 9] if k == 1 else [2, 8, 10]          # forced variants: 8 = 256x256 LDS-DMA, 9 / 10 = the streaming kernels, 2 = 128x128
     times = {t: [] for t in tiles}

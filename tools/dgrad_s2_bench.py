@@ -27,7 +27,7 @@ for C, H in ((128, 64), (256, 32), (512, 16)):
     res = torch.randn(B, H, H, C, device="cuda").to(dt)
     bn_y = torch.randn(B, H, H, C, device="cuda").to(dt)
     mi = torch.rand(2, C, device="cuda") + 0.5
-    st = torch.zeros(ops.stat_shards(), 2, C, device="cuda")
+    st = ops.stat_unit(C, "cuda")
     new = t(lambda: ops.conv3x3s2_dgrad(gy, w_s2, residual=res, mask=mask, bn=[(bn_y, mi, st)]))
     old = t(lambda: ops.conv2d_nhwc(ops.upsample2(gy, H, H), wd, 3, 3, 1, 1, residual=res, mask=mask, bn=[(bn_y, mi, st)]))
     print(f"C={C} H={H}: parity classes {new:8.1f} us   zero-dilated {old:8.1f} us", flush=True)

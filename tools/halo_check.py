@@ -41,7 +41,7 @@ for (H, C) in ((32, 128), (16, 256)):
     wh = ops.conv3x3_halo_pack(w)
     sc = (torch.rand(C, device=dev) + 0.5).contiguous(); sh = (torch.randn(C, device=dev) * 0.3).contiguous()
     S = ops.stat_shards()
-    st0 = torch.zeros(S, 2, C, device=dev); st1 = torch.zeros(S, 2, C, device=dev)
+    st0 = ops.stat_unit(C, "cuda"); st1 = ops.stat_unit(C, "cuda")
     # the path it replaces: in-place pass + im2col conv
     a_ref = ops.bn_act(x.clone(), sc, sh, relu=True)
     y_ref = ops.conv2d_nhwc(a_ref, w, 3, 3, 1, 1, stats=st0)

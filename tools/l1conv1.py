@@ -8,7 +8,7 @@ B, H, Cin, Cout = 256, 64, 64, 64
 x = torch.randn(B, H, H, Cin, device="cuda").bfloat16()
 w = resnet.pack_conv_weight(torch.randn(Cout, Cin, 1, 1) * 0.1, torch.bfloat16).cuda()
 sc, sh = torch.rand(Cin, device="cuda") + 0.5, torch.randn(Cin, device="cuda") * 0.1
-st = torch.zeros(ops.stat_shards(), 2, Cout, device="cuda")
+st = ops.stat_unit(Cout, "cuda")
 for bn in (True, False):
     out = {}
     for t in (0, 1, 2, 9):

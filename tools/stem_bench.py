@@ -6,7 +6,7 @@ for dt in (torch.bfloat16, torch.float32):
     B = 256
     x = torch.randn(B, 3, 256, 256, device="cuda")
     w = resnet.pack_stem_weight(torch.randn(64, 3, 7, 7) * 0.1, dt).cuda()
-    st = torch.zeros(ops.stat_shards(), 2, 64, device="cuda")
+    st = ops.stat_unit(64, "cuda")
     for _ in range(2): ops.stem_conv7x7s2(x, w, dt, stats=st)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
