@@ -436,8 +436,14 @@ int mhe_conv_wgrad_batched_nhwc(const mhe_conv_desc *d, int nbatch, const void *
 size_t mhe_conv_wgrad_rect_workspace_floats(const mhe_conv_desc *d, int Ho, int Wo);
 int mhe_conv_wgrad_rect_nhwc(const mhe_conv_desc *d, int stride_w, int pad_w, int Ho, int Wo, const void *x, const void *gy, float *dw,
                              int ldw, float *workspace, size_t workspace_floats, void *stream);
-/* out[c] += sum_r rows[r][c] (bias gradients; caller zeroes out); rows f32 or bf16, sums f32. */
+/* out[c] += sum_r rows[r][c] (bias gradients; caller zeroes out); rows f32 or bf16, sums f32, in a FIXED order (no atomics).
+ * mhe_colsum_f32: one workgroup per 256 columns walks all rows (R <= 4,096).  mhe_colsum_ws_f32: with a workspace of
+ * mhe_colsum_workspace_floats(R, C) floats the rows are cut into slabs (two launches); column c is added to
+ * out[(c / out_group_width) * out_group_stride + c % out_group_width] (out_group_width = 0: out[c]). */
 int mhe_colsum_f32(const void *rows, float *out, long R, int C, int dtype, void *stream);
+size_t mhe_colsum_workspace_floats(long R, int C);
+int mhe_colsum_ws_f32(const void *rows, float *out, long R, int C, int dtype, int out_group_width, long out_group_stride,
+                      float *workspace, size_t workspace_floats, void *stream);
 /* dst[i] = (idx[i] < 0 ? 0 : src[idx[i]]) + (idx2 != NULL && idx2[i] >= 0 ? src[idx2[i]] : 0) ; dst f32 or bf16.  Every weight re-layout of a train step (forward
  * operand packs, transposed / tap-flipped operands of the data-gradient convolutions, un-packing of weight
  * gradients into the flat gradient buffer) is one gather over an index table built once on the host. */
@@ -468,7 +474,7 @@ int mhe_flow_mask_pad_mixed(const float *x, const float *mask, float *xp, void *
  * -> couple_accum compute coupling by coupling (13 launches each), with every intermediate kept on chip.  A workgroup owns one image's 64
  * rows.  Outputs: GO / G2 / G1 [nets][R][64 | 512 | 512] and the masked inputs XP [ncoup][R][64] in bf16 (operands of the grouped weight
  * gradients), Gc [B][cond_stride] (the conditioning table's gradient: column (2 net + layer) * hidden + unit; cond_stride % 4 == 0),
- * db2 (+ net * db_net_stride: l2 bias gradients, ACCUMULATED), z0 [R][dim] (the recovered base sample, optional).  w2F, w1F, w0F =
+ * db2_rows [B][2 ncoup][64] (every image's share of the nets' l2 bias gradients, WRITTEN: their sum over images is a mhe_colsum_ws_f32 away), z0 [R][dim] (the recovered base sample, optional).  w2F, w1F, w0F =
  * net 0's bf16 operands W2^T [512][64], W1^T [512][512], W0^T [64][512] ([out][k]) in FRAGMENT-MAJOR order - element
  * [out][k] at ((out / 16 * (K / 32) + k / 32) * 64 + (k % 32 / 8) * 16 + out % 16) * 8 + k % 8, the order the lanes of
  * v_mfma_f32_16x16x32_bf16 take them, so a fragment is one 1 KiB run; net k at + k * w_net_stride elements. */
@@ -537,7 +543,7 @@ int mhe_flow_couplings_frag_bf16(const float *in, float *out, const float *cond,
 int mhe_flow_reverse_chain_bf16(const float *x_out, const float *g_x, const float *g_logp, float q_weight, const float *mask,
                                 const float *o_pre, const void *sign_bits, const void *w2F, const void *w1F,
                                 const void *w0F, long w_net_stride, void *GO_bf16, void *G2_bf16, void *G1_bf16, void *XP_bf16,
-                                float *Gc, int cond_stride, float *db2, long db_net_stride, float *z0, int R, int B, int dim,
+                                float *Gc, int cond_stride, float *db2_rows, float *z0, int R, int B, int dim,
                                 int hidden, int ncoup, void *stream);
 /* src [R][C] f32 (row pitch src_stride) -> dst [R][C] bf16 (optional) and dstT [C][R] bf16: the conditioning gradient as the two operands
  * its consumers read (the conditioning layer's weight gradient; the split-K product that gives the feature's gradient). */

@@ -44,6 +44,8 @@ SIGNATURES = {
     "mhe_conv_wgrad_rect_workspace_floats": (_sz, [C.POINTER(ConvDesc), _i, _i]),
     "mhe_conv_wgrad_rect_nhwc": (_i, [C.POINTER(ConvDesc), _i, _i, _i, _i, _p, _p, _p, _i, _p, _sz, _p]),
     "mhe_colsum_f32": (_i, [_p, _p, _l, _i, _i, _p]),
+    "mhe_colsum_workspace_floats": (_sz, [_l, _i]),
+    "mhe_colsum_ws_f32": (_i, [_p, _p, _l, _i, _i, _i, _l, _p, _sz, _p]),
     "mhe_gather_f32": (_i, [_p, _p, _p, _p, _sz, _i, _p]),
     "mhe_flow_mask_pad_f32": (_i, [_p, _p, _p, _l, _i, _p]),
     "mhe_flow_cond_lrelu_f32": (_i, [_p, _p, _l, _l, _i, _i, _p]),
@@ -110,7 +112,7 @@ SIGNATURES = {
     "mhe_flow_reverse_chain_supported": (_i, [_i, _i, _i, _i, _i]),
     "mhe_flow_couplings_frag_supported": (_i, [_i, _i, _i, _i, _i]),
     "mhe_flow_couplings_frag_bf16": (_i, [_p, _p, _p, _i, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
-    "mhe_flow_reverse_chain_bf16": (_i, [_p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _i, _p, _l, _p, _i, _i, _i, _i, _i, _p]),
+    "mhe_flow_reverse_chain_bf16": (_i, [_p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mhe_pack_transpose_bf16": (_i, [_p, _l, _p, _p, _i, _i, _p]),
     "mhe_gram_stats_words": (_sz, [_i]),
     "mhe_stat_words": (_sz, [_i]),

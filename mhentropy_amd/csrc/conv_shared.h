@@ -394,7 +394,6 @@ __device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, 
     // stores are whole 16-byte pieces of contiguous channel rows instead of 8-byte row-strided ones.
     constexpr int CPR = BN * (int)sizeof(T) / 16;          // 16-byte chunks per output row
     constexpr int CMASK = (CPR - 1) & 15;
-    constexpr int EPC = 16 / (int)sizeof(T);               // elements per chunk
     static_assert((size_t)BM * BN * sizeof(T) <= sizeof(lds), "output tile must fit the staging buffers");
     if constexpr (sizeof(T) == 2 && !DG) {
         // f32 result from bf16 operands (mhe_conv2d_f32out_nhwc): the accumulator's own layout gives every lane 4 consecutive

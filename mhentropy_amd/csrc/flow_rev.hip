@@ -33,8 +33,7 @@ struct Args {
     const u16 *w2F, *w1F, *w0F;                           // net 0's fragment-major operands; net k lies k * w_stride elements further
     long w_stride;
     u16 *GOb, *G2b, *G1b, *XPb;                           // [nets][R][64], [nets][R][512] x 2, [ncoup][R][64]
-    float *Gc, *db2, *z0;                                 // [B][cstride], net 0's l2 bias gradient (+ k * db_stride), [R][dim]
-    long db_stride;
+    float *Gc, *db2, *z0;                                 // [B][cstride], per-image l2 bias-gradient rows [B][2 ncoup][64] (written), [R][dim]
     int R, B, dim, ncoup, cstride;
     float q_weight;
 };
@@ -153,7 +152,9 @@ __global__ __launch_bounds__(512) void chain_kernel(const Args a) {
             float v = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) v += red[w2][k][d];
-            atomicAdd(a.db2 + (size_t)(2 * ci + w2) * a.db_stride + d, v);
+            // this image's share of net (2 ci + w2)'s l2 bias gradient: a plain store - the sum over images is a fixed-order column sum
+            // afterwards (f32 atomics from the B workgroups up to round 3: order-dependent)
+            a.db2[((size_t)b * (2 * a.ncoup) + 2 * ci + w2) * 64 + d] = v;
         }
 #pragma unroll 1
         for (int n = 0; n < 2; ++n) {
@@ -323,19 +324,19 @@ extern "C" int mhe_flow_reverse_chain_supported(int R, int B, int dim, int hidde
 extern "C" int mhe_flow_reverse_chain_bf16(const float *x_out, const float *g_x, const float *g_logp, float q_weight, const float *mask,
                                            const float *o_pre, const void *sign_bits, const void *w2F, const void *w1F,
                                            const void *w0F, long w_net_stride, void *GO_bf16, void *G2_bf16, void *G1_bf16, void *XP_bf16,
-                                           float *Gc, int cond_stride, float *db2, long db_net_stride, float *z0, int R, int B, int dim,
+                                           float *Gc, int cond_stride, float *db2_rows, float *z0, int R, int B, int dim,
                                            int hidden, int ncoup, void *stream) {
-    MHE_REQUIRE(x_out && g_x && mask && o_pre && sign_bits && w2F && w1F && w0F && GO_bf16 && G2_bf16 && G1_bf16 && XP_bf16 && Gc && db2,
+    MHE_REQUIRE(x_out && g_x && mask && o_pre && sign_bits && w2F && w1F && w0F && GO_bf16 && G2_bf16 && G1_bf16 && XP_bf16 && Gc && db2_rows,
                 "mhe_flow_reverse_chain_bf16: null pointer");
     MHE_REQUIRE(mhe_flow_reverse_chain_supported(R, B, dim, hidden, ncoup), "mhe_flow_reverse_chain_bf16: needs hidden 512 and 64 hypotheses per image (R=%d B=%d)", R, B);
     MHE_REQUIRE((long)R * hidden < (1L << 31), "mhe_flow_reverse_chain_bf16: R x hidden beyond the 32-bit row offsets");
-    MHE_REQUIRE(cond_stride % 4 == 0 && cond_stride >= 4 * ncoup * hidden && w_net_stride > 0 && db_net_stride >= 0, "mhe_flow_reverse_chain_bf16: bad strides");
+    MHE_REQUIRE(cond_stride % 4 == 0 && cond_stride >= 4 * ncoup * hidden && w_net_stride > 0, "mhe_flow_reverse_chain_bf16: bad strides");
     flowrev::Args a;
     a.x_out = x_out; a.g_x = g_x; a.g_logp = g_logp; a.mask = mask; a.oe = o_pre;
     a.hbits = (const uint2 *)sign_bits; a.w2F = (const u16 *)w2F; a.w1F = (const u16 *)w1F; a.w0F = (const u16 *)w0F;
     a.w_stride = w_net_stride;
     a.GOb = (u16 *)GO_bf16; a.G2b = (u16 *)G2_bf16; a.G1b = (u16 *)G1_bf16; a.XPb = (u16 *)XP_bf16;
-    a.Gc = Gc; a.db2 = db2; a.z0 = z0; a.db_stride = db_net_stride;
+    a.Gc = Gc; a.db2 = db2_rows; a.z0 = z0;
     a.R = R; a.B = B; a.dim = dim; a.ncoup = ncoup; a.cstride = cond_stride; a.q_weight = q_weight;
     hipLaunchKernelGGL(flowrev::chain_kernel, dim3(B), dim3(512), 0, (hipStream_t)stream, a);
     return check_launch("flowrev::chain_kernel");

@@ -11,6 +11,7 @@
 // split over gridDim.z and partial tiles are added to dW with f32 atomics (dW zeroed by the caller).
 // Roofline: MFMA f32 (157 TFLOP/s); algorithmic bytes per launch = |x| + |gy| + 4|dW|.
 #include "common.h"
+#include <cstring>
 #include "../../include/mhe.h"
 #include <cstdlib>
 
@@ -485,31 +486,51 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_dma_kernel(const DmaParams
         }
 }
 
-// dW[m][n..n+3] += sum_z ws[z][m][n..n+3]: the reducer of the partial-slab mode (one float4 per thread, slabs read coalesced)
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, int gz, int Mp, int Np,
-                                                          int M, int N, int ldw, long dw_bs) {
+// dW[m][n..n+3] += sum_z ws[z][m][n..n+3]: the reducer of the partial-slab mode (one float4 per thread, slabs read coalesced).
+// ZL slice lanes per float4 (blockDim = 64 * ZL): lane l sums slices l, l + ZL, ... in that order, the lanes are folded through LDS in
+// lane order - a FIXED summation order for a given slice count (the train step's weight gradients are bit-reproducible), and the
+// 100 - 500 slices of the small early-layer gradients (one or two output tiles, pixel range cut 512 ways) are walked 16 abreast
+// instead of serially (those layers added their tiles with f32 atomics up to round 3: order-dependent sums).
+template <int ZL>
+__global__ __launch_bounds__(64 * ZL) void slab_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, int gz, int Mp, int Np,
+                                                              int M, int N, int ldw, long dw_bs) {
+    __shared__ v4f part[ZL > 1 ? 64 * ZL : 1];
     ws += (size_t)blockIdx.y * gz * Mp * Np; dw += (size_t)blockIdx.y * dw_bs;          // (grouped launch: one problem per blockIdx.y)
     const int n4 = N / 4;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)M * n4) return;
-    const int m = (int)(i / n4), n = (int)(i % n4) * 4;
+    const int el = threadIdx.x & 63, zl = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + el;
+    const bool on = i < (long)M * n4;
+    const int m = on ? (int)(i / n4) : 0, n = on ? (int)(i % n4) * 4 : 0;
     v4f a = {0.f, 0.f, 0.f, 0.f};
     const float *src = ws + (size_t)m * Np + n;
+    if (on) {
 #pragma unroll 4
-    for (int z = 0; z < gz; ++z) {
-        const v4f v = *reinterpret_cast<const v4f *>(src + (size_t)z * Mp * Np);
-        a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+        for (int z = zl; z < gz; z += ZL) {
+            const v4f v = *reinterpret_cast<const v4f *>(src + (size_t)z * Mp * Np);
+            a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+        }
     }
+    if constexpr (ZL > 1) {
+        part[threadIdx.x] = a;
+        __syncthreads();
+        if (zl) return;
+#pragma unroll
+        for (int l = 1; l < ZL; ++l) { const v4f v = part[l * 64 + el]; a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3]; }
+    }
+    if (!on) return;
     float *dst = dw + (size_t)m * ldw + n;
     dst[0] += a[0]; dst[1] += a[1]; dst[2] += a[2]; dst[3] += a[3];
 }
 
 // out[c] += sum_r in[r][c]  (bias gradients).  A block owns a slab of rows and ALL of its 256 threads: thread t reads column
-// t % CW of row-lane t / CW (CW = min(C, 256) columns per pass), the row-lanes are folded through LDS and one atomic per
-// column leaves the block - for the 64-wide operands of the flow (C = 64) the one-thread-per-column form idled 3/4 of a block
+// t % CW of row-lane t / CW (CW = min(C, 256) columns per pass), the row-lanes are folded through LDS in lane order - for the 64-wide
+// operands of the flow (C = 64) the one-thread-per-column form idled 3/4 of a block.  A FIXED summation order (f32 atomics from several
+// row slabs into `out` up to round 3: order-dependent): either one block per column group adds its sum to `out`, or every row slab
+// stores its sums as a row of `partial` and a second launch folds those rows.  out column c lands at out[(c / gw) * gs + c % gw]
+// (gw = 0: out[c]).
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ in, float *__restrict__ out, long R, int C,
-                                                     int rows_per_block) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ in, float *__restrict__ out, float *__restrict__ partial, long R, int C,
+                                                     long rows_per_block, int gw, long gs, int) {
     __shared__ float part[256];
     const int CW = C < 256 ? C : 256, NRL = 256 / CW;           // C is a power of two below 256 or a multiple of 256 (checked by the launcher)
     const int cl = threadIdx.x % CW, rl = threadIdx.x / CW;
@@ -517,16 +538,31 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ in, f
     const long r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
     const int c = blockIdx.x * CW + cl;
     float acc = 0.f;
-    if (rl < NRL && c < C)
-        for (long r = r0 + rl; r < r1; r += NRL) {
+    if (rl < NRL && c < C) {
+        long r = r0 + rl;
+        for (; r + 3 * NRL < r1; r += 4 * NRL) {                 // four rows in flight
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if constexpr (sizeof(T) == 4) v[u] = in[(r + u * NRL) * C + c];
+                else v[u] = bf16_to_f32(in[(r + u * NRL) * C + c]);
+            }
+            acc += v[0]; acc += v[1]; acc += v[2]; acc += v[3];
+        }
+        for (; r < r1; r += NRL) {
             if constexpr (sizeof(T) == 4) acc += in[r * C + c];
             else acc += bf16_to_f32(in[r * C + c]);
         }
+    }
     part[threadIdx.x] = acc;
     __syncthreads();
     if (rl == 0 && c < C) {
         for (int k = 1; k < NRL; ++k) acc += part[k * CW + cl];
-        atomicAdd(out + c, acc);
+        if (partial) partial[(size_t)blockIdx.y * C + c] = acc;
+        else {
+            float *dst = out + (gw ? (size_t)(c / gw) * gs + c % gw : (size_t)c);
+            *dst += acc;                                         // the only block of this column
+        }
     }
 }
 
@@ -627,13 +663,25 @@ static WgradPlan plan_wgrad(const mhe_conv_desc *d, int Ho_ = 0, int Wo_ = 0, in
     return w;
 }
 
+// Which launches go through partial slabs + the fixed-order reducer.  MHE_WGRAD_SLABS = "all" (default): every launch whose pixel range is
+// split - the weight gradients do not depend on the order in which workgroups finish; "big": the round-3 policy (<= 64 slices and
+// >= 128K weights; the rest adds its tiles with f32 atomics - order-dependent sums, kept for A/B timing).
+static bool slabs_all() {
+    static const bool all = !(getenv("MHE_WGRAD_SLABS") && !strcmp(getenv("MHE_WGRAD_SLABS"), "big"));
+    return all;
+}
+static bool takes_slabs(const mhe_conv_desc *d, int gz) {
+    if (gz <= 1) return false;
+    if (slabs_all()) return gz <= 4096;
+    return gz <= 64 && (size_t)d->Cout * d->KH * d->KW * d->Cin >= 131072;
+}
+
 extern "C" size_t mhe_conv_wgrad_workspace_floats(const mhe_conv_desc *d) {
     if (!d || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0) return 0;
     const WgradPlan w = plan_wgrad(d);
-    // measured (tools/wgrad_bench.py, SLABS=0/1): slabs win 3-25 % from ~16 output tiles up (<= 64 slices each), and lose below
-    // that (many thin slices of a small dW: the reducer walks them serially) - there the atomics stay
-    if ((size_t)d->Cout * d->KH * d->KW * d->Cin < 131072) return 0;       // small dW: the extra reducer launch costs more than the atomics
-    return (w.gz > 1 && w.gz <= 64) ? (size_t)w.gz * (w.gy * w.BM) * (size_t)(w.gx * w.BN) : 0;
+    // measured in round 2 (tools/wgrad_bench.py, SLABS=0/1) with the serial reducer: slabs win 3-25 % from ~16 output tiles up (<= 64
+    // slices each) and lost below that (many thin slices of a small dW) - the reducer now walks those 16 abreast
+    return takes_slabs(d, w.gz) ? (size_t)w.gz * (w.gy * w.BM) * (size_t)(w.gx * w.BN) : 0;
 }
 
 static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, float *dw, int ldw, float *ws, size_t ws_floats, void *stream,
@@ -646,8 +694,7 @@ static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, fl
 extern "C" size_t mhe_conv_wgrad_batched_workspace_floats(const mhe_conv_desc *d, int nbatch) {
     if (!d || nbatch < 1 || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0) return 0;
     const WgradPlan w = plan_wgrad(d, 0, 0, nbatch);
-    if ((size_t)d->Cout * d->KH * d->KW * d->Cin < 131072) return 0;
-    return (w.gz > 1 && w.gz <= 64) ? (size_t)nbatch * w.gz * (w.gy * w.BM) * (size_t)(w.gx * w.BN) : 0;
+    return takes_slabs(d, w.gz) ? (size_t)nbatch * w.gz * (w.gy * w.BM) * (size_t)(w.gx * w.BN) : 0;
 }
 
 extern "C" int mhe_conv_wgrad_batched_nhwc(const mhe_conv_desc *d, int nbatch, const void *x, long x_batch_stride, const void *gy, long gy_batch_stride,
@@ -672,8 +719,7 @@ extern "C" int mhe_conv_wgrad_ws_nhwc(const mhe_conv_desc *d, const void *x, con
 extern "C" size_t mhe_conv_wgrad_rect_workspace_floats(const mhe_conv_desc *d, int Ho, int Wo) {
     if (!d || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || Ho <= 0 || Wo <= 0) return 0;
     const WgradPlan w = plan_wgrad(d, Ho, Wo);
-    if ((size_t)d->Cout * d->KH * d->KW * d->Cin < 131072) return 0;
-    return (w.gz > 1 && w.gz <= 64) ? (size_t)w.gz * (w.gy * w.BM) * (size_t)(w.gx * w.BN) : 0;
+    return takes_slabs(d, w.gz) ? (size_t)w.gz * (w.gy * w.BM) * (size_t)(w.gx * w.BN) : 0;
 }
 
 extern "C" int mhe_conv_wgrad_rect_nhwc(const mhe_conv_desc *d, int stride_w, int pad_w, int Ho, int Wo, const void *x, const void *gy, float *dw,
@@ -708,7 +754,7 @@ static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, fl
     p.chunk = (int)w.chunk;
     p.Mp = gyy * w.BM; p.Np = gx * w.BN;
     const size_t need = (size_t)nbatch * gz * p.Mp * p.Np;
-    p.ws = (ws && gz > 1 && gz <= 64 && need <= ws_floats && (size_t)d->Cout * p.N >= 131072) ? ws : nullptr;
+    p.ws = (ws && takes_slabs(d, gz) && need <= ws_floats) ? ws : nullptr;
     MHE_REQUIRE(nbatch == 1 || (w.dma && (long)gz * nbatch < 65536), "mhe_conv_wgrad_batched_nhwc: the grouped form runs on the LDS-DMA kernel (bf16, operands below 2 GiB)");
     if (nbatch > 1) { p.gz = gz; p.x_bs = x_bs; p.gy_bs = gy_bs; p.dw_bs = dw_bs; }
     dim3 grid(gx, gyy, gz * nbatch);
@@ -750,23 +796,56 @@ static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, fl
     if (int rc = check_launch("wgrad_kernel")) return rc;
     if (p.ws) {
         const long n = (long)d->Cout * (p.N / 4);
-        hipLaunchKernelGGL(wgrad::slab_reduce_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nbatch), block, 0, s, p.ws, dw, gz, p.Mp, p.Np, d->Cout, p.N, p.ldw, dw_bs);
+        const dim3 rg((unsigned)((n + 63) / 64), (unsigned)nbatch);
+        if (gz > 64) hipLaunchKernelGGL(wgrad::slab_reduce_kernel<16>, rg, dim3(1024), 0, s, p.ws, dw, gz, p.Mp, p.Np, d->Cout, p.N, p.ldw, dw_bs);
+        else if (gz > 8 || n < 65536) hipLaunchKernelGGL(wgrad::slab_reduce_kernel<4>, rg, dim3(256), 0, s, p.ws, dw, gz, p.Mp, p.Np, d->Cout, p.N, p.ldw, dw_bs);
+        else hipLaunchKernelGGL(wgrad::slab_reduce_kernel<1>, rg, dim3(64), 0, s, p.ws, dw, gz, p.Mp, p.Np, d->Cout, p.N, p.ldw, dw_bs);
         return check_launch("slab_reduce_kernel");
     }
     return MHE_OK;
 }
 
-extern "C" int mhe_colsum_f32(const void *rows, float *out, long R, int C, int dtype, void *stream) {
+// Fixed-order column sums (see colsum_kernel).  Without a workspace ONE block walks all rows of its column group (any `out`, up to 4,096
+// rows).  With one, the rows are cut into up to 256 slabs (enough blocks to fill the chip: the [256][24,576] conditioning-gradient sums of
+// config C2 ran on 192 blocks at 0.5 TB/s) whose sums go to the workspace with plain stores, and a second launch folds those rows.
+extern "C" size_t mhe_colsum_workspace_floats(long R, int C) { return R > 16 && C > 0 ? (size_t)256 * (size_t)C : 0; }
+
+template <typename T>
+static void colsum_launch(const T *rows, float *out, float *partial, long R, int C, long rpb, int gw, long gs, hipStream_t s) {
+    const int cw = C < 256 ? C : 256;
+    const dim3 grid((C + cw - 1) / cw, (unsigned)((R + rpb - 1) / rpb));
+    hipLaunchKernelGGL(wgrad::colsum_kernel<T>, grid, dim3(256), 0, s, rows, out, partial, R, C, rpb, gw, gs, 1);
+}
+
+extern "C" int mhe_colsum_ws_f32(const void *rows, float *out, long R, int C, int dtype, int out_group_width, long out_group_stride,
+                                 float *workspace, size_t workspace_floats, void *stream) {
     MHE_REQUIRE(rows && out && R > 0 && C > 0 && (dtype == MHE_F32 || dtype == MHE_BF16), "mhe_colsum_f32: bad arguments");
     const int cw = C < 256 ? C : 256;
     MHE_REQUIRE(256 % cw == 0, "mhe_colsum_f32: C=%d must divide 256 or be at least 256", C);
-    const int rpb = 128;
-    const dim3 grid((C + cw - 1) / cw, (unsigned)((R + rpb - 1) / rpb));
-    if (dtype == MHE_F32)
-        hipLaunchKernelGGL(wgrad::colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)rows, out, R, C, rpb);
-    else
-        hipLaunchKernelGGL(wgrad::colsum_kernel<u16>, grid, dim3(256), 0, (hipStream_t)stream, (const u16 *)rows, out, R, C, rpb);
+    MHE_REQUIRE(out_group_width >= 0 && (out_group_width == 0 || (C % out_group_width == 0 && out_group_stride >= out_group_width)),
+                "mhe_colsum_f32: bad output grouping (width %d, stride %ld)", out_group_width, out_group_stride);
+    hipStream_t s = (hipStream_t)stream;
+    const long ncg = (C + cw - 1) / cw;
+    long nby = 1024 / ncg;
+    if (nby > 256) nby = 256;
+    if (nby > (R + 15) / 16) nby = (R + 15) / 16;
+    if (nby < 1 || !workspace || workspace_floats < (size_t)nby * C) nby = 1;
+    if (nby == 1) {
+        MHE_REQUIRE(R <= 4096, "mhe_colsum_f32: %ld rows need a workspace of mhe_colsum_workspace_floats(R, C) floats (fixed summation order)", R);
+        if (dtype == MHE_F32) colsum_launch((const float *)rows, out, nullptr, R, C, R, out_group_width, out_group_stride, s);
+        else colsum_launch((const u16 *)rows, out, nullptr, R, C, R, out_group_width, out_group_stride, s);
+        return check_launch("colsum_kernel");
+    }
+    const long rpb = (R + nby - 1) / nby, nb = (R + rpb - 1) / rpb;
+    if (dtype == MHE_F32) colsum_launch((const float *)rows, nullptr, workspace, R, C, rpb, 0, 0, s);
+    else colsum_launch((const u16 *)rows, nullptr, workspace, R, C, rpb, 0, 0, s);
+    if (int rc = check_launch("colsum_kernel")) return rc;
+    colsum_launch((const float *)workspace, out, nullptr, nb, C, nb, out_group_width, out_group_stride, s);
     return check_launch("colsum_kernel");
+}
+
+extern "C" int mhe_colsum_f32(const void *rows, float *out, long R, int C, int dtype, void *stream) {
+    return mhe_colsum_ws_f32(rows, out, R, C, dtype, 0, 0, nullptr, 0, stream);
 }
 
 extern "C" int mhe_gather_f32(const float *src, const int *idx, const int *idx2, void *dst, size_t n, int dst_dtype, void *stream) {

@@ -931,12 +931,29 @@ def linear_wgrad(x, gy, dw):
     return conv_wgrad(x.view(R, 1, 1, K), gy.view(R, 1, 1, gy.shape[1]), 1, 1, 1, 0, dw)
 
 
-def colsum(rows, out):
-    """out[c] += sum_r rows[r][c]"""
+_COLSUM_WS = {}
+_COLSUM_WS_RETIRED = []     # (a captured HIP graph may have baked a superseded workspace's address in: keep them alive, as _WGRAD_WS_RETIRED)
+
+
+def colsum(rows, out, group_width=0, group_stride=0):
+    """out[c] += sum_r rows[r][c], summed in a fixed order (mhe_colsum_ws_f32); with group_width g: column c is added to
+    out[(c // g) * group_stride + c % g] (the l2 bias gradients of the flow's nets lie one raw-gradient slot apart)"""
     Cc = rows.shape[-1]
     R = rows.numel() // Cc
-    _chk(rows, rows.dtype, "colsum.rows"); _chk(out, torch.float32, "colsum.out", (Cc,))
-    check(_lib.lib().mhe_colsum_f32(_ptr(rows), _ptr(out), R, Cc, dtype_code(rows.dtype), _stream()), "mhe_colsum_f32")
+    _chk(rows, rows.dtype, "colsum.rows"); _chk(out, torch.float32, "colsum.out")
+    if not group_width and out.numel() < Cc:          # (grouped: `out` is the first group's view into a larger arena)
+        raise _lib.MheError(f"colsum.out: {out.numel()} floats cannot hold {Cc} columns")
+    L = _lib.lib()
+    need = L.mhe_colsum_workspace_floats(R, Cc)
+    ws = None
+    if need:
+        ws = _COLSUM_WS.get(rows.device)
+        if ws is None or ws.numel() < need:
+            if ws is not None:
+                _COLSUM_WS_RETIRED.append(ws)
+            ws = _COLSUM_WS[rows.device] = torch.empty(need, device=rows.device, dtype=torch.float32)
+    check(L.mhe_colsum_ws_f32(_ptr(rows), _ptr(out), R, Cc, dtype_code(rows.dtype), int(group_width), int(group_stride), _ptr(ws),
+                              ws.numel() if ws is not None else 0, _stream()), "mhe_colsum_ws_f32")
     return out
 
 
@@ -1012,9 +1029,15 @@ def flow_couple_bwd(x_out, Os, Ot, mask_row, g_out, g_log_p, q_weight, B, x_in, 
     for t, n, s in ((x_out, "x_out", (R, dim)), (Os, "Os", (R, 64)), (Ot, "Ot", (R, 64)), (g_out, "g_out", (R, dim)),
                     (x_in, "x_in", (R, dim)), (GOs, "GOs", (R, 64)), (GOt, "GOt", (R, 64)), (g_part, "g_part", (R, dim))):
         _chk(t, torch.float32, "couple_bwd." + n, s)
+    # the kernel's own column sums are f32 atomics from every 64-row workgroup: order-dependent beyond one workgroup - there the sums are
+    # taken from the written GOs / GOt rows in a fixed order instead (two more launches on a fallback path)
+    in_kernel = db_s is not None and R <= 64
     check(_lib.lib().mhe_flow_couple_bwd_mixed(_ptr(x_out), _ptr(Os), _ptr(Ot), _ptr(mask_row), _ptr(g_out), _ptr(g_log_p),
                                                float(q_weight), _ptr(x_in), _ptr(GOs), _ptr(GOt), _ptr(g_part), _ptr(GOs_bf16), _ptr(GOt_bf16),
-                                               _ptr(db_s), _ptr(db_t), R, B, dim, _stream()), "mhe_flow_couple_bwd_mixed")
+                                               _ptr(db_s if in_kernel else None), _ptr(db_t if in_kernel else None), R, B, dim, _stream()),
+          "mhe_flow_couple_bwd_mixed")
+    if db_s is not None and not in_kernel:
+        colsum(GOs, db_s); colsum(GOt, db_t)
 
 
 def mfma_fragment_major(t):
@@ -1043,6 +1066,9 @@ def flow_sign_bits(h1, h2, B):
     return torch.stack(out, 2).contiguous()                                    # [net, b, layer, w, lane, 2]
 
 
+_DB2_ROWS = {}
+
+
 def flow_reverse_chain(x_out, g_x, g_logp, q_weight, mask, o_pre, sign_bits, w2F, w1F, w0F, w_net_stride, GOb, G2b, G1b, XPb, Gc, db2,
                        db_net_stride, z0):
     """the RealNVP reverse pass's data-gradient chain over all couplings in one launch (mhe_flow_reverse_chain_bf16; csrc/flow_rev.hip);
@@ -1058,10 +1084,15 @@ def flow_reverse_chain(x_out, g_x, g_logp, q_weight, mask, o_pre, sign_bits, w2F
     _chk(Gc, torch.float32, "rev_chain.Gc"); _chk(z0, torch.float32, "rev_chain.z0", (R, dim))
     if g_logp is not None:
         _chk(g_logp, torch.float32, "rev_chain.g_logp", (B,))
+    rows = _DB2_ROWS.get((x_out.device, B, nets))
+    if rows is None:
+        rows = _DB2_ROWS[(x_out.device, B, nets)] = torch.empty(B, nets * 64, device=x_out.device, dtype=torch.float32)
     check(_lib.lib().mhe_flow_reverse_chain_bf16(_ptr(x_out), _ptr(g_x), _ptr(g_logp), float(q_weight), _ptr(mask), _ptr(o_pre), _ptr(sign_bits), _ptr(w2F),
                                                  _ptr(w1F), _ptr(w0F), int(w_net_stride), _ptr(GOb), _ptr(G2b), _ptr(G1b), _ptr(XPb), _ptr(Gc),
-                                                 Gc.shape[1], _ptr(db2), int(db_net_stride), _ptr(z0), R, B, dim, hidden, nets // 2, _stream()),
+                                                 Gc.shape[1], _ptr(rows), _ptr(z0), R, B, dim, hidden, nets // 2, _stream()),
           "mhe_flow_reverse_chain_bf16")
+    # db2 (+ net * db_net_stride) += the sum over images of the kernel's per-image rows, in a fixed order
+    colsum(rows, db2, group_width=64, group_stride=db_net_stride)
 
 
 def pack_transpose_bf16(src, out=None, outT=None, want_rows=True):

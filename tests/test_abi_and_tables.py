@@ -167,7 +167,7 @@ def test_round3_entries_refuse_what_they_do_not_support():
     null = None
     rc = L.mhe_flow_couplings_frag_bf16(null, null, null, 0, null, null, null, 0, null, null, null, null, null, null, null, null, 192, 3, 45, 512, 12, 0, null)
     assert rc != 0 and b"null pointer" in L.mhe_last_error()
-    rc = L.mhe_flow_reverse_chain_bf16(null, null, null, 0.0, null, null, null, null, null, null, 0, null, null, null, null, null, 0, null, 0, null,
+    rc = L.mhe_flow_reverse_chain_bf16(null, null, null, 0.0, null, null, null, null, null, null, 0, null, null, null, null, null, 0, null, null,
                                        192, 3, 45, 512, 12, null)
     assert rc != 0 and b"null pointer" in L.mhe_last_error()
     rc = L.mhe_conv3_bn_fold(null, null, null, null, null, null, 1024.0, null, null, null, null, 256, null, 64, null, null, 256, 64, null)

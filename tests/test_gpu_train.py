@@ -632,8 +632,10 @@ def test_run_entry_point(gpu_lib, tmp_path, monkeypatch):
 
 def test_graphed_loop_equals_eager_loop(gpu_lib):
     """--graph 1 == --graph 0: a loop that takes GraphedStep's warm-up result for the capture iteration and replays the rest applies
-    exactly one optimizer step per batch - same step count, BatchNorm buffers and (to the f32 atomics' summation order) parameters
-    as the eager loop on the same batches and noise (hand/CrossModalHand.py:455-470: one step per iteration)"""
+    exactly one optimizer step per batch - same step count, BatchNorm buffers and PARAMETERS, bit for bit, as the eager loop on the same
+    batches and noise (hand/CrossModalHand.py:455-470: one step per iteration).  Round 4: every cross-workgroup sum of the step is
+    order-independent (fixed-point statistics, weight gradients through slabs + a fixed-order reducer, fixed-order column sums), so
+    the comparison is exact; up to round 3 the f32 atomics only allowed a statistical bound."""
     from mhentropy_amd import harness
     from mhentropy_amd.train import TrainStep, GraphedStep
     B, N, iters = 4, 4, 4
@@ -659,15 +661,37 @@ def test_graphed_loop_equals_eager_loop(gpu_lib):
         graphed.append(float(-g.replay()["log_p"].mean()))
     assert int(ts0.step_t.item()) == int(ts1.step_t.item()) == iters
     assert int(m0.feat_extractor.res.bn1.num_batches_tracked) == int(m1.feat_extractor.res.bn1.num_batches_tracked) == iters
-    assert abs(graphed[0] - eager[0]) <= 1e-6 * abs(eager[0])          # same model, same batch: the capture iteration IS the first step
-    # later iterations: the f32 atomics' summation order differs between the loops, and Adam turns the sign of a ~0 gradient into a
-    # +-lr parameter difference - measured drift 2e-6 -> 5e-4 over four iterations
-    assert_close(graphed, eager, 3e-3, what="per-iteration loss, graphed vs eager loop")
-    # same kernels, same inputs: the two loops differ by the f32 atomics' summation order only; Adam turns a ~0 gradient whose sign
-    # flips into a +-lr difference, so bound the fraction of such elements instead of the maximum
-    d = (ts1.P - ts0.P).abs()
-    assert float((d > 2e-5).float().mean()) < 5e-3 and float(d.max()) <= 2 * iters * 2e-4, (float((d > 2e-5).float().mean()), float(d.max()))
-    assert torch.allclose(m1.feat_extractor.res.bn1.running_var, m0.feat_extractor.res.bn1.running_var, rtol=1e-5)
+    assert graphed == eager, (graphed, eager)          # same kernels, same inputs, order-independent sums: the same losses ...
+    assert torch.equal(ts1.P, ts0.P), float((ts1.P - ts0.P).abs().max())          # ... and the same parameters after four Adam steps
+    assert torch.equal(ts1.M, ts0.M) and torch.equal(ts1.V, ts0.V)          # Adam's moments too
+    assert torch.equal(m1.feat_extractor.res.bn1.running_var, m0.feat_extractor.res.bn1.running_var)
+
+
+def test_full_size_train_step_is_deterministic(gpu_lib):
+    """BASELINE.json configs[2] shape (B=256, K=64, ResNet-50, h=512, bf16): two reverse passes from the same state give the SAME flat
+    gradient, bit for bit, and two optimizer steps from the same state the same parameters (the reference's CPU step is deterministic,
+    hand/CrossModalHand.py:455-470; the f32 atomics of rounds 1-3 were not)"""
+    from mhentropy_amd import harness
+    from mhentropy_amd.train import TrainStep
+    torch.manual_seed(1)
+    model = harness.build_mhent(backbone="resnet50", tables=synth.mano_tables(0), compute_dtype=torch.bfloat16).cuda().train()
+    xn, yn = synth.batch(2, 256, image_size=256)
+    x, y = torch.as_tensor(xn).cuda(), {k: torch.as_tensor(v).cuda() for k, v in yn.items()}
+    z0 = torch.as_tensor(synth.noise(2, 64 * 256)).cuda()
+    ts = TrainStep(model, lr=0.0)                      # lr 0: the parameters stay put; the BatchNorm buffers are restored by hand
+    bufs = {n: b.clone() for n, b in model.named_buffers()}
+
+    def run():
+        for n, b in model.named_buffers():
+            b.copy_(bufs[n])
+        out = ts.forward_backward(x, y, noise=z0, N=64)
+        return out["log_p"].clone(), ts.G.clone()
+    lp1, g1 = run()
+    lp2, g2 = run()
+    assert torch.isfinite(g1).all() and g1.abs().max() > 0
+    assert torch.equal(lp1, lp2), float((lp1 - lp2).abs().max())
+    bad = (g1 != g2)
+    assert not bad.any(), (int(bad.sum()), float((g1 - g2).abs().max()), [n for n, p in model.named_parameters() if (ts.grad_of(p) != g2[ts.off[id(p)]:ts.off[id(p)] + p.numel()].view(p.shape)).any()][:8])
 
 
 def test_full_size_train_step_properties(gpu_lib):
@@ -842,16 +866,17 @@ def test_shortcut_reverse_on_gram_statistics_equals_the_pass_over_its_output(gpu
     for n in ("layer2.0.downsample.0.weight", "layer1.1.conv1.weight", "layer1.0.conv3.weight"):
         spread = rel(gF2[pre + n], gF[pre + n])
         print(f"upstream {n}: fold vs pass {rel(gF[pre + n], gP[pre + n]):.2e}, fold vs fold {spread:.2e}")
-        assert rel(gF[pre + n], gP[pre + n]) <= 3 * spread + 1e-3, (n, rel(gF[pre + n], gP[pre + n]), spread)
+        assert spread == 0.0 and rel(gF[pre + n], gP[pre + n]) == 0.0, (n, rel(gF[pre + n], gP[pre + n]), spread)      # round 4: bit for bit
     for n, tol in (("layer1.0.downsample.1.bias", 1e-3), ("layer1.0.downsample.0.weight", 5e-3), ("layer1.0.downsample.1.weight", 8e-3)):
         spread = rel(gF2[pre + n], gF[pre + n])
         print(f"shortcut {n}: fold vs pass {rel(gF[pre + n], gP[pre + n]):.2e}, fold vs fold {spread:.2e}")
         assert rel(gF[pre + n], gP[pre + n]) <= tol + 3 * spread, (n, rel(gF[pre + n], gP[pre + n]), spread)
-    # behind it: the stem (through the max pool's reverse) - the band of the other whole-trunk comparisons
-    # (the fold's weights [(k2 W)^T | S] are rounded to bf16 from sums whose split-K atomics change a last bit from run to run: the whole
-    # shortcut gradient moves by a bf16 ulp, and the stem's train-mode BatchNorm on 8 images amplifies that - the fold against itself
-    # spreads as far as the fold against the pass)
-    for n in ("conv1.weight", "bn1.weight", "bn1.bias"):
+    # behind it: the stem (through the max pool's reverse).  The reverse pass is deterministic since round 4 (fold against fold: 0), so
+    # what is left is the fold's own arithmetic: its weights [(k2 W)^T | S] and the per-channel constant c0 are rounded to bf16, i.e. the
+    # shortcut's input gradient carries a ~1e-3 relative error that is COHERENT over a channel's pixels.  conv1's weight gradient does
+    # not see a per-channel constant (bn1's reverse removes it): measured 3.4e-3; bn1's own sums over 32k pixels add the coherent part
+    # up: dgamma 5.9e-2, and dbeta = sum_p g - pure cancellation, |sum g| << sum |g| - 0.5.  Bounds = about twice the measured figures.
+    for n, tol in (("conv1.weight", 8e-3), ("bn1.weight", 1.2e-1), ("bn1.bias", 1.0)):
         spread = rel(gF2[pre + n], gF[pre + n])
         print(f"stem {n}: fold vs pass {rel(gF[pre + n], gP[pre + n]):.2e}, fold vs fold {spread:.2e}")
-        assert rel(gF[pre + n], gP[pre + n]) < max(2e-1, 3 * spread), (n, rel(gF[pre + n], gP[pre + n]), spread)
+        assert spread == 0.0 and rel(gF[pre + n], gP[pre + n]) < tol, (n, rel(gF[pre + n], gP[pre + n]), spread)
