@@ -238,7 +238,8 @@ typedef struct mhe_conv_desc {
                     * (0 128x64, 1 128x128, 2 256x256, 3 256x128, 4 256x64, 5 / 6 the LDS-DMA kernel on 256x256 / 128x128,
                     * 7 the 8-phase 256x256 kernel, 8 the streaming 1x1 kernel for 64 / 128 (/ 256) input channels, 9 the row-streaming 3x3 kernel for 64 -> 64 channels,
                     * 10 the 128 x 256 residual-tail kernel with transfer waves for >= 256 output channels, 11 the resident-slab kernel with transfer
-                    * waves for 256 / 512 -> >= 512 channels, 13 the 8-phase kernel on a 256 x 128 tile): parity tests and tuning runs
+                    * waves for 256 / 512 -> >= 512 channels, 13 the 8-phase kernel on a 256 x 128 tile, 15 the residual-tail kernel of
+                    * variant 10 with every operand brought in by LDS-DMA rings - forward form): parity tests and tuning runs
                     * reach every instantiation in-process */
     int res_half;  /* 1: `residual` is at HALF resolution, [B, ceil(Ho/2), ceil(Wo/2), Cout], and is added at the even output positions
                     * only (the data gradient of a stride-2 1x1 shortcut joining the main branch's gradient without being scattered

@@ -667,6 +667,8 @@ bool fuse_supports(const Params &p, int cb);   // conv_fuse.hip: bottleneck tail
 int launch_fuse(const Params &p, int cb, hipStream_t s);
 bool tail_supports(const Params &p);           // conv_tail.hip: residual tail + conv1 on a 128 x 256 tile with transfer waves (variant 10)
 int launch_tail(const Params &p, hipStream_t s);
+bool tail2_supports(const Params &p);          // conv_tail.hip: the same tile with every operand by LDS-DMA rings (variant 15, forward form)
+int launch_tail2(const Params &p, hipStream_t s);
 
 // tile choice: 0 = 128x64, 1 = 128x128, 2 = 256x256 (FAST only; needs >= ~3/4 of the CUs' worth of tiles)
 static int choose_tile(const Params &p, bool fast, bool bf16) {
@@ -684,6 +686,10 @@ static int choose_tile(const Params &p, bool fast, bool bf16) {
     // one L2 - 62 us against the phase-pipelined kernel's 46 at layer4's conv3)
     if (bf16 && (force == 11 || (force < 0 && env_wide && p.Cin == 256)) && wide_supports(p)) return 11;
     static const int env_tail = getenv("MHE_CONV_TAIL") ? atoi(getenv("MHE_CONV_TAIL")) : 1;
+    // variant 15 (operands by LDS-DMA rings): built, bit-identical, and NOT faster - 117 / 88 / 238 / 162 us against 111 / 74 / 210 / 170 on the
+    // four tail shapes of config C2 (tools/conv_variants.py --tail --tiles 11,16): opt-in (MHE_CONV_TAIL2=1), see profiles/EXPERIMENTS.md
+    static const int env_tail2 = getenv("MHE_CONV_TAIL2") ? atoi(getenv("MHE_CONV_TAIL2")) : 0;
+    if (bf16 && (force == 15 || (force < 0 && env_tail && env_tail2)) && tail2_supports(p)) return 15;
     if (bf16 && (force == 10 || (force < 0 && env_tail)) && tail_supports(p)) return 10;
     if ((force & 15) == 7 && bf16 && p8_supports(p)) return 7;      // (higher bits: ablation builds of tuning runs)
     if (force == 13 && bf16 && p8_supports(p)) return 13;
@@ -723,6 +729,7 @@ static int launch_conv(const Params &p, hipStream_t s) {
         if (t0 == 8) return launch_stream(p, s);
         if (t0 == 9) return launch_stream3(p, s);
         if (t0 == 10) return launch_tail(p, s);
+        if (t0 == 15) return launch_tail2(p, s);
         if (t0 == 11) return launch_wide(p, s);
         if (t0 == 7) return launch_p8(p, s);
         if (t0 == 13) return launch_p8h(p, s);

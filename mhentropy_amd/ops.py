@@ -85,6 +85,8 @@ def _conv_kernel_name(d, dt, mode):
     tile = _lib.lib().mhe_conv_tile_mode(C.byref(d), mode)
     if tile == 11:
         return "mhe::conv::conv_wide_kernel<%s, %s>" % ("128, 4" if d.Cin == 256 else "64, 8", "true" if mode == 1 else "false")
+    if tile == 15:
+        return "mhe::conv::conv_tail2_kernel"
     if tile == 10:
         return "mhe::conv::conv_tail_kernel<false>"
     if tile == 9:
@@ -717,7 +719,10 @@ def conv1x1_residual_in(x, x2, w, in_scale, in_shift, x2_scale=None, x2_shift=No
         ev1.record()
         es = x.element_size()
         nbytes = es * (2 * x.numel() + y.numel() + w.numel() + (a_out.numel() if a_out is not None else 0))
-        KERNEL_TIMES.append((_conv_kernel_name(d, dt, 2), 2.0 * B * H * W * Cout * Cin, ev0, ev1, nbytes))
+        name = _conv_kernel_name(d, dt, 2)
+        if name == "mhe::conv::conv_tail2_kernel" and x2_scale is not None and 4 * Cin > 4096:
+            name = "mhe::conv::conv_tail_kernel<false>"          # (the resident tables of variant 15 hold an identity affine up to 1,024 channels)
+        KERNEL_TIMES.append((name, 2.0 * B * H * W * Cout * Cin, ev0, ev1, nbytes))
     return y
 
 
