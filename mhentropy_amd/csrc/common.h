@@ -94,14 +94,37 @@ __device__ __forceinline__ void add(acc_t *unit, int shard, int stat, int C, int
     add2(unit + ((size_t)shard * 2 + stat) * C + c, plane(C), v);
 }
 __host__ __device__ __forceinline__ double value2(acc_t hi, acc_t lo) { return (double)hi * 0x1p-16 + (double)lo * 0x1p-56; }
-// lane = shard: the unit's total of (stat, c) over the 64 shards, exact (integer wave reduction), NaN if any shard carries the marker.
+// lane = shard: the unit's totals of both statistics of channel c over the 64 shards, exact (integer wave reductions), NaN if any shard
+// carries the marker.  All four words are loaded before anything is reduced (one memory round trip per channel, as the f32 form had);
 // clear: the words are zeroed on the way (self-cleaning arena)
+__device__ __forceinline__ void wave_totals(acc_t *unit, int C, int c, int lane, bool clear, double &t0, double &t1) {
+    acc_t *p0 = unit + ((size_t)lane * 2) * C + c, *p1 = p0 + C;
+    const size_t pl = plane(C);
+    acc_t hi0 = p0[0], hi1 = p1[0], lo0 = p0[pl], lo1 = p1[pl];
+    if (clear) { p0[0] = 0; p1[0] = 0; p0[pl] = 0; p1[pl] = 0; }
+    const bool bad0 = __any(marked(hi0)), bad1 = __any(marked(hi1));
+    if (__any(hi0 >= (1ll << 55) || hi0 <= -(1ll << 55) || hi1 >= (1ll << 55) || hi1 <= -(1ll << 55))) {
+        // (the integer sum of 64 such words could wrap: fixed-order sum of doubles)
+        double d0 = value2(hi0, lo0), d1 = value2(hi1, lo1);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { d0 += __shfl_xor(d0, o, 64); d1 += __shfl_xor(d1, o, 64); }
+        t0 = bad0 ? __builtin_nan("") : d0; t1 = bad1 ? __builtin_nan("") : d1;
+        return;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        hi0 += __shfl_xor(hi0, o, 64); lo0 += __shfl_xor(lo0, o, 64);
+        hi1 += __shfl_xor(hi1, o, 64); lo1 += __shfl_xor(lo1, o, 64);
+    }
+    t0 = bad0 ? __builtin_nan("") : value2(hi0, lo0);
+    t1 = bad1 ? __builtin_nan("") : value2(hi1, lo1);
+}
 __device__ __forceinline__ double wave_total(acc_t *unit, int stat, int C, int c, int lane, bool clear) {
     acc_t *p = unit + ((size_t)lane * 2 + stat) * C + c;
     acc_t hi = p[0], lo = p[plane(C)];
     if (clear) { p[0] = 0; p[plane(C)] = 0; }
     const bool bad = __any(marked(hi));
-    if (__any(hi >= (1ll << 55) || hi <= -(1ll << 55))) {       // (the integer sum of 64 such words could wrap: fixed-order sum of doubles)
+    if (__any(hi >= (1ll << 55) || hi <= -(1ll << 55))) {
         double d = value2(hi, lo);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);

@@ -466,7 +466,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(mhe_stat_t *stats, con
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;      // nn.BatchNorm2d's counter (int64)
     if (c >= C) return;
     // self-cleaning accumulators: the arena is zero again when the next forward starts (no memset launch per step)
-    const double s1 = fx::wave_total(stats, 0, C, c, lane, clear != 0), s2 = fx::wave_total(stats, 1, C, c, lane, clear != 0);
+    double s1, s2;
+    fx::wave_totals(stats, C, c, lane, clear != 0, s1, s2);
     if (lane) return;
     const double dmean = s1 / count;
     const double dvar = fmax(s2 / count - dmean * dmean, 0.0);   // biased, as F.batch_norm normalises with

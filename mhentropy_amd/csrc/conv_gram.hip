@@ -17,6 +17,7 @@
 //   gram_combine    : shards -> f64 totals (and clears the shards: the arena is clean for the next step);
 //   gram_finalize   : one wave per output channel: w^T G w and w . m in f64 -> mean, variance -> scale / shift (+ running statistics).
 #include "conv_shared.h"
+#include <cstdlib>
 
 namespace mhe { namespace conv {
 
@@ -45,18 +46,21 @@ __global__ __launch_bounds__(256) void gram_kernel(const u16 *__restrict__ x, co
     float sc[8], sh[8], cs[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { sc[i] = in_scale ? in_scale[cch * 8 + i] : 1.f; sh[i] = in_shift ? in_shift[cch * 8 + i] : 0.f; cs[i] = 0.f; }
-    uint4 ra[NJ];
-    auto load_tile = [&](int L) __attribute__((always_inline)) {
+    // two tiles in flight in registers (one workgroup per CU: every workgroup's atomics are a full round of Cb^2 integer adds, so fewer,
+    // longer-lived workgroups - with the second tile in flight doing what the second workgroup per CU did for the load latency)
+    struct Regs { uint4 v[NJ]; };
+    Regs ra, rb;
+    auto load_tile = [&](int L, Regs &r) __attribute__((always_inline)) {
         const int Lc = L < ntiles ? L : ntiles - 1;                                // (past the end: a harmless re-read, never stored)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) ra[j] = *reinterpret_cast<const uint4 *>(x + ((size_t)Lc * GPX + r0 + RPP * j) * CB + cch * 8);
+        for (int j = 0; j < NJ; ++j) r.v[j] = *reinterpret_cast<const uint4 *>(x + ((size_t)Lc * GPX + r0 + RPP * j) * CB + cch * 8);
     };
-    auto store_tile = [&](int buf, int L) __attribute__((always_inline)) {
+    auto store_tile = [&](int buf, int L, const Regs &r) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int row = r0 + RPP * j;
             float f[8];
-            Chunk<u16>::unpack(ra[j], f);
+            Chunk<u16>::unpack(r.v[j], f);
             if (in_scale) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { f[i] = fmaf(f[i], sc[i], sh[i]); if (relu) f[i] = fmaxf(f[i], 0.f); }
@@ -89,13 +93,8 @@ __global__ __launch_bounds__(256) void gram_kernel(const u16 *__restrict__ x, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tile(blockIdx.x);
-    int it = 0;
-    for (int L = blockIdx.x; L < ntiles; L += (int)gridDim.x, ++it) {
-        const int buf = it & 1;
-        store_tile(buf, L);
-        load_tile(L + (int)gridDim.x);                           // in flight during this tile's products
-        __syncthreads();                                         // (also: every wave is done reading the buffer written two tiles ago)
+    const int G = (int)gridDim.x;
+    auto products = [&](int buf) __attribute__((always_inline)) {
         const char *base = tile[buf];
 #pragma unroll
         for (int kk = 0; kk < GPX; kk += 16) {
@@ -114,6 +113,20 @@ __global__ __launch_bounds__(256) void gram_kernel(const u16 *__restrict__ x, co
 #pragma unroll
                 for (int j = 0; j < TW; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8g, fa[i]), __builtin_bit_cast(bf8g, fb[j]), acc[i][j], 0, 0, 0);
+        }
+    };
+    load_tile(blockIdx.x, ra);
+    load_tile(blockIdx.x + G, rb);
+    for (int L = blockIdx.x; L < ntiles; L += 2 * G) {
+        store_tile(0, L, ra);
+        load_tile(L + 2 * G, ra);                                // in flight during two tiles' products
+        __syncthreads();                                         // (also: every wave is done reading the buffer written two tiles ago)
+        products(0);
+        if (L + G < ntiles) {                                    // (uniform over the workgroup)
+            store_tile(1, L + G, rb);
+            load_tile(L + 3 * G, rb);
+            __syncthreads();
+            products(1);
         }
     }
     fx::acc_t *dst = gram + (size_t)((int)blockIdx.x % GSH) * GE;
@@ -208,8 +221,12 @@ extern "C" int mhe_conv1x1_gram_store_nhwc(const void *x, const float *in_scale,
                 "mhe_conv1x1_gram_nhwc: bf16 rows of 64 / 128 channels, pixel count a multiple of %d (pixels=%ld Cb=%d)", conv::GPX, pixels, Cb);
     MHE_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "mhe_conv1x1_gram_nhwc: in_scale/in_shift must come together");
     const int ntiles = (int)(pixels / conv::GPX);
-    const int per_cu = Cb == 64 ? 3 : 2;                         // 40 / 72 KiB of LDS per workgroup
-    const dim3 grid((unsigned)(ntiles < 256 * per_cu ? ntiles : 256 * per_cu));
+    // one workgroup per CU (MHE_GRAM_PER_CU: 3 / 2 up to round 3, when the shard adds were f32): a workgroup ends with Cb^2 + Cb 64-bit integer
+    // atomics whatever it has summed, and with two tiles in flight per workgroup the second resident workgroup no longer hides anything
+    static const int wgs64 = getenv("MHE_GRAM_WGS_64") ? atoi(getenv("MHE_GRAM_WGS_64")) : 512;
+    static const int wgs128 = getenv("MHE_GRAM_WGS_128") ? atoi(getenv("MHE_GRAM_WGS_128")) : 192;
+    const int want = Cb == 64 ? wgs64 : wgs128;
+    const dim3 grid((unsigned)(ntiles < want ? ntiles : want));
     if (Cb == 64) hipLaunchKernelGGL(conv::gram_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, (const u16 *)x, in_scale, in_shift, gram, (int)pixels, relu_in, (u16 *)a_out);
     else hipLaunchKernelGGL(conv::gram_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, (const u16 *)x, in_scale, in_shift, gram, (int)pixels, relu_in, (u16 *)a_out);
     return check_launch("gram_kernel");

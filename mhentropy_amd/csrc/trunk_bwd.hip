@@ -92,8 +92,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const mhe_stat_t *
     static_assert(NSH == 64, "one lane per statistic shard");
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
-    const double s1 = fx::wave_total(const_cast<mhe_stat_t *>(stats), 0, C, c, lane, false);
-    const double s2 = fx::wave_total(const_cast<mhe_stat_t *>(stats), 1, C, c, lane, false);
+    double s1, s2;
+    fx::wave_totals(const_cast<mhe_stat_t *>(stats), C, c, lane, false, s1, s2);
     if (lane) return;
     const float db = (float)s1, dg = (float)s2;
     dbeta[c] = db;
@@ -134,8 +134,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
 __global__ __launch_bounds__(256) void bn_mean_invstd_kernel(const mhe_stat_t *__restrict__ stats, float *__restrict__ mean_invstd, int C, double count, float eps) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
-    const double s1 = fx::wave_total(const_cast<mhe_stat_t *>(stats), 0, C, c, lane, false);
-    const double s2 = fx::wave_total(const_cast<mhe_stat_t *>(stats), 1, C, c, lane, false);
+    double s1, s2;
+    fx::wave_totals(const_cast<mhe_stat_t *>(stats), C, c, lane, false, s1, s2);
     if (lane) return;
     const double dmean = s1 / (double)count;
     const double dvar = fmax(s2 / (double)count - dmean * dmean, 0.0);
