@@ -80,6 +80,12 @@ int mhe_linear_f32_bf16copy(const float *X, const float *W, const float *bias, f
  * {seed, next counter, 0}: the launch advances the counter itself, so a captured HIP graph draws fresh noise on every replay.
  * A device generator cannot reproduce the reference's CPU stream: parity runs supply the noise instead. */
 int mhe_randn_f32(float *out, long n, unsigned long long *state, float scale, void *stream);
+/* train-mode dropout of the ConditionalGlow's residual blocks (hand/network.py:343-344, `dropout_probability=0.2`; nflows ResidualBlock:
+ * activation -> linear -> activation -> dropout -> linear): x <- x * keep / (1 - p_drop) in place, keep ~ Bernoulli(1 - p_drop).
+ * draw != 0: the mask is drawn from `state` (the device generator of mhe_randn_f32, advanced by the launch) and its bits - bit k of byte i =
+ * element 8 i + k kept - are written to `bits` (optional); draw == 0: the given bits are applied (the reverse pass applies them to the
+ * gradient; parity tests feed the oracle the same mask).  n % 8 == 0; dtype MHE_F32 / MHE_BF16. */
+int mhe_dropout(void *x, int dtype, unsigned char *bits, long n, float p_drop, unsigned long long *state, int draw, void *stream);
 /* BasicEnc's stochastic head (hand/network.py:121-138): sd = exp(l2/2) (sigmoid_act: sigmoid(l2)), z = mn + sd*eps (deterministic:
  * z = mn; eps may then be NULL).  Dead for MHEnt, which keeps only mn (:779,862); built so BasicEnc returns the reference's (z, mn, sd). */
 int mhe_reparam_f32(const float *mn, const float *l2, const float *eps, float *sd, float *z, long n, int sigmoid_act,
@@ -377,6 +383,11 @@ int mhe_maxpool3x3s2_nhwc(const void *x, const float *scale, const float *shift,
 
 /* global average pool NHWC [B,HW,C] -> f32 [B,C]. */
 int mhe_avgpool_nhwc(const void *x, float *y, int B, int HW, int C, int dtype, void *stream);
+/* mhe_bn_act_nhwc followed by mhe_avgpool_nhwc in one pass - the last residual block's tail and the encoder's average pool
+ * (torchvision ResNet.forward: layer4 -> avgpool, hand/network.py:54-61,110): y[b][c] = mean_p round(relu?(x*scale+shift (+ res*rscale+rshift | + res))),
+ * rounded to `dtype` before the sum and summed in mhe_avgpool_nhwc's order: the same bits as the two launches.  C % 4 == 0. */
+int mhe_bn_act_avgpool_nhwc(const void *x, const float *scale, const float *shift, const void *res, const float *rscale,
+                            const float *rshift, float *y, int B, int HW, int C, int relu, int dtype, void *stream);
 
 /* NCHW f32 image -> NHWC (dtype), stem input layout change. */
 int mhe_nchw_to_nhwc(const float *x, void *y, int B, int C, int H, int W, int dtype, void *stream);
@@ -434,6 +445,9 @@ int mhe_conv_wgrad_batched_nhwc(const mhe_conv_desc *d, int nbatch, const void *
  * (reference: torchvision ResNet.conv1 under hand/CrossModalHand.py:455-470's backward) read as a 7 x 4 / stride (2, 1) / pad (3, 2)
  * convolution over PIXEL PAIRS - x [B, H, W/2, 8] = two neighbouring pixels x (3 channels padded to 4), Ho x Wo = H/2 x W/2 - so that
  * dW' [Cout][7][4][8] has 224 columns instead of the 392 of 3 channels padded to 8; dW'[co][kh][kw'][4 par + c] = dW[co][c][kh][2 kw' + par - 1]. */
+/* the kernel instantiation a weight-gradient launch of this geometry takes (Ho / Wo = 0: derived; nbatch = 1: not grouped): BM * 1000 + BN,
+ * + 1,000,000 on the LDS-DMA kernel, + 2,000,000 on the register-staged bf16 kernel; -1 for a bad descriptor.  (bench.py names what it times.) */
+int mhe_conv_wgrad_variant(const mhe_conv_desc *d, int Ho, int Wo, int nbatch);
 size_t mhe_conv_wgrad_rect_workspace_floats(const mhe_conv_desc *d, int Ho, int Wo);
 int mhe_conv_wgrad_rect_nhwc(const mhe_conv_desc *d, int stride_w, int pad_w, int Ho, int Wo, const void *x, const void *gy, float *dw,
                              int ldw, float *workspace, size_t workspace_floats, void *stream);

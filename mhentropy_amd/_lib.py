@@ -24,6 +24,7 @@ SIGNATURES = {
     "mhe_linear_skinny_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mhe_linear_f32_bf16copy": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mhe_randn_f32": (_i, [_p, _l, _p, _f, _p]),
+    "mhe_dropout": (_i, [_p, _i, _p, _l, _f, _p, _i, _p]),
     "mhe_reparam_f32": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _p]),
     "mhe_flow_packed_floats_per_net": (_sz, [_i, _i]),
     "mhe_flow_pack_net_host": (_i, [_p, _p, _p, _i, _i, _p]),
@@ -40,6 +41,7 @@ SIGNATURES = {
     "mhe_sum_over_hypotheses_f32": (_i, [_p, _p, _i, _i, _i, _i, _l, _p]),
     "mhe_conv_wgrad_nhwc": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _i, _p]),
     "mhe_conv_wgrad_workspace_floats": (_sz, [C.POINTER(ConvDesc)]),
+    "mhe_conv_wgrad_variant": (_i, [_p, _i, _i, _i]),
     "mhe_conv_wgrad_ws_nhwc": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _i, _p, _sz, _p]),
     "mhe_conv_wgrad_rect_workspace_floats": (_sz, [C.POINTER(ConvDesc), _i, _i]),
     "mhe_conv_wgrad_rect_nhwc": (_i, [C.POINTER(ConvDesc), _i, _i, _i, _i, _p, _p, _p, _i, _p, _sz, _p]),
@@ -129,6 +131,7 @@ SIGNATURES = {
     "mhe_bn_act_nhwc": (_i, [_p] * 7 + [_l, _i, _i, _i, _p]),
     "mhe_maxpool3x3s2_nhwc": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mhe_avgpool_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "mhe_bn_act_avgpool_nhwc": (_i, [_p] * 7 + [_i, _i, _i, _i, _i, _p]),
     "mhe_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "mhe_nchw_to_nhwc_pad": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mhe_rot6d_to_rotmat_f32": (_i, [_p, _p, _l, _i, _p]),

@@ -607,6 +607,47 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const T *__restrict__ x, f
     if (g == 0 && c < C) y[(size_t)b * C + c] = (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) / (float)HW;
 }
 
+// the last block's tail and the global average pool in one pass (round 4; the forward ended with a 42 us bn_act pass writing the
+// 8 x 8 x 2048 block output that only the 24 us pool read): y[b][c] = mean_p round_T(relu(x * scale + shift + (res * rscale + rshift | res))).
+// Rounded to the storage type before it is summed and summed in avgpool_kernel's order (four pixel groups p = g, g + 4, ...; then
+// (s0 + s1 + s2 + s3) / HW): the pooled feature equals the two launches' bit for bit.  Thread = 4 channels of one pixel group.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_avgpool_kernel(const T *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift,
+                                                             const T *__restrict__ res, const float *__restrict__ rscale, const float *__restrict__ rshift,
+                                                             float *__restrict__ y, int HW, int C, int relu) {
+    __shared__ float part[4][256];
+    const int b = blockIdx.y, l = threadIdx.x & 63, g = threadIdx.x >> 6, c = blockIdx.x * 256 + l * 4;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        const float4 s = *reinterpret_cast<const float4 *>(scale + c), t = *reinterpret_cast<const float4 *>(shift + c);
+        float4 rs = make_float4(1.f, 1.f, 1.f, 1.f), rt = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rscale) { rs = *reinterpret_cast<const float4 *>(rscale + c); rt = *reinterpret_cast<const float4 *>(rshift + c); }
+        for (int p = g; p < HW; p += 4) {
+            const size_t e = ((size_t)b * HW + p) * C + c;
+            float v[4], r[4];
+            load4<T>(x + e, v);
+            v[0] = fmaf(v[0], s.x, t.x); v[1] = fmaf(v[1], s.y, t.y); v[2] = fmaf(v[2], s.z, t.z); v[3] = fmaf(v[3], s.w, t.w);
+            if (res) {
+                load4<T>(res + e, r);
+                if (rscale) { r[0] = fmaf(r[0], rs.x, rt.x); r[1] = fmaf(r[1], rs.y, rt.y); r[2] = fmaf(r[2], rs.z, rt.z); r[3] = fmaf(r[3], rs.w, rt.w); }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] += r[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (relu) v[k] = fmaxf(v[k], 0.f);
+                if constexpr (sizeof(T) == 2) v[k] = bf16_to_f32(f32_to_bf16(v[k]));      // what bn_act_kernel would have stored
+                a[k] += v[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) part[g][l * 4 + k] = a[k];
+    __syncthreads();
+    const int cc = blockIdx.x * 256 + threadIdx.x;
+    if (cc < C) y[(size_t)b * C + cc] = (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) / (float)HW;
+}
+
 // NCHW f32 -> NHWC with the channel dimension zero-padded to Cp
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const float *__restrict__ x, T *__restrict__ y, int B, int C, int HW, int Cp) {
@@ -1108,6 +1149,21 @@ extern "C" int mhe_avgpool_nhwc(const void *x, float *y, int B, int HW, int C, i
     else
         hipLaunchKernelGGL(conv::avgpool_kernel<u16>, grid, dim3(256), 0, (hipStream_t)stream, (const u16 *)x, y, HW, C);
     return check_launch("avgpool_kernel");
+}
+
+extern "C" int mhe_bn_act_avgpool_nhwc(const void *x, const float *scale, const float *shift, const void *res, const float *rscale,
+                                       const float *rshift, float *y, int B, int HW, int C, int relu, int dtype, void *stream) {
+    MHE_REQUIRE(x && scale && shift && y && B > 0 && HW > 0 && C > 0 && C % 4 == 0, "mhe_bn_act_avgpool_nhwc: bad arguments (C=%d must be a multiple of 4)", C);
+    MHE_REQUIRE((rscale == nullptr) == (rshift == nullptr) && (res || !rscale), "mhe_bn_act_avgpool_nhwc: the residual's affine needs both tables and the residual");
+    MHE_REQUIRE(dtype == MHE_F32 || dtype == MHE_BF16, "mhe_bn_act_avgpool_nhwc: dtype=%d", dtype);
+    const dim3 grid((C + 255) / 256, B);
+    if (dtype == MHE_F32)
+        hipLaunchKernelGGL(conv::bn_act_avgpool_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)x, scale, shift, (const float *)res,
+                           rscale, rshift, y, HW, C, relu);
+    else
+        hipLaunchKernelGGL(conv::bn_act_avgpool_kernel<u16>, grid, dim3(256), 0, (hipStream_t)stream, (const u16 *)x, scale, shift, (const u16 *)res,
+                           rscale, rshift, y, HW, C, relu);
+    return check_launch("bn_act_avgpool_kernel");
 }
 
 extern "C" int mhe_nchw_to_nhwc(const float *x, void *y, int B, int C, int H, int W, int dtype, void *stream) {

@@ -70,6 +70,64 @@ extern "C" int mhe_randn_f32(float *out, long n, unsigned long long *state, floa
     return check_launch("randn_kernel");
 }
 
+// ---- dropout of the ConditionalGlow's residual blocks in train mode (reference hand/network.py:343-344: `dropout_probability=0.2`, and the
+// comment at :781 "Since uses Dropout"; nflows ResidualBlock: activation -> linear -> activation -> DROPOUT -> linear).  x <- x * keep / (1 - p)
+// in place with keep ~ Bernoulli(1 - p) drawn from the same device-resident Philox state as the base noise (so a captured graph draws a fresh
+// mask on every replay); one mask BIT per element goes to `bits` for the reverse pass, which applies the same launch with draw = 0 to the
+// gradient.  Thread = 8 elements = one byte of bits = one Philox call (eight 16-bit uniforms; P(drop) = round(p * 65536) / 65536).
+namespace mhe { namespace rng {
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(T *__restrict__ x, unsigned char *__restrict__ bits, long n8, unsigned long long *__restrict__ state,
+                                                      unsigned thr, float scale, int draw) {
+    const unsigned long long key = draw ? state[0] : 0ull, base = draw ? state[1] : 0ull;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        unsigned m;
+        if (draw) {
+            unsigned r[4];
+            philox4x32_10(base + (unsigned long long)i, key, r);
+            m = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m |= (unsigned)(((r[k >> 1] >> (16 * (k & 1))) & 0xffffu) >= thr) << k;
+            if (bits) bits[i] = (unsigned char)m;
+        } else m = bits[i];
+        float v[8];
+        load4<T>(x + 8 * i, v); load4<T>(x + 8 * i + 4, v + 4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (m >> k) & 1u ? v[k] * scale : 0.f;
+        store4<T>(x + 8 * i, v); store4<T>(x + 8 * i + 4, v + 4);
+    }
+    if (!draw) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned long long done = atomicAdd(&state[2], 1ull);
+        if (done == (unsigned long long)gridDim.x - 1ull) {
+            state[2] = 0ull;
+            state[1] = base + (unsigned long long)n8;
+            __threadfence();
+        }
+    }
+}
+}}  // namespace mhe::rng
+
+extern "C" int mhe_dropout(void *x, int dtype, unsigned char *bits, long n, float p_drop, unsigned long long *state, int draw, void *stream) {
+    using namespace mhe;
+    MHE_REQUIRE(x && n > 0 && n % 8 == 0 && (dtype == MHE_F32 || dtype == MHE_BF16), "mhe_dropout: n=%ld must be a multiple of 8, dtype f32 / bf16", n);
+    MHE_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "mhe_dropout: p=%f", (double)p_drop);
+    MHE_REQUIRE(draw ? state != nullptr : bits != nullptr, "mhe_dropout: drawing needs the generator state, applying needs the mask bits");
+    MHE_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "mhe_dropout: x must be 16-byte aligned");
+    const long n8 = n / 8;
+    long blocks = (n8 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    const unsigned thr = (unsigned)(p_drop * 65536.f + 0.5f);
+    const float scale = 1.f / (1.f - p_drop);
+    if (dtype == MHE_F32)
+        hipLaunchKernelGGL(rng::dropout_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float *)x, bits, n8, state, thr, scale, draw);
+    else
+        hipLaunchKernelGGL(rng::dropout_kernel<u16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (u16 *)x, bits, n8, state, thr, scale, draw);
+    return check_launch("dropout_kernel");
+}
+
 // ---- BasicEnc's stochastic head (reference hand/network.py:121-138): sd = exp(l2 / 2) | sigmoid(l2), z = mn + sd * eps.
 // Dead for MHEnt (it keeps only mn, :779,862) - built so that the exported class returns the reference's (z, mn, sd).
 namespace mhe { namespace rng {

@@ -676,6 +676,14 @@ static bool takes_slabs(const mhe_conv_desc *d, int gz) {
     return gz <= 64 && (size_t)d->Cout * d->KH * d->KW * d->Cin >= 131072;
 }
 
+// which instantiation a launch takes (bench.py names the kernel it times as rocprofv3 prints it): BM * 1000 + BN, + 1,000,000 for the
+// LDS-DMA kernel, + 2,000,000 for the register-staged bf16 kernel (0 + ... : the f32 / generic kernel)
+extern "C" int mhe_conv_wgrad_variant(const mhe_conv_desc *d, int Ho, int Wo, int nbatch) {
+    if (!d || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || nbatch < 1) return -1;
+    const WgradPlan w = plan_wgrad(d, Ho, Wo, nbatch);
+    return w.BM * 1000 + w.BN + (w.bf16k && w.dma ? 1000000 : w.bf16k ? 2000000 : 0);
+}
+
 extern "C" size_t mhe_conv_wgrad_workspace_floats(const mhe_conv_desc *d) {
     if (!d || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0) return 0;
     const WgradPlan w = plan_wgrad(d);

@@ -8,8 +8,9 @@
 nor installed; no reference test or fixture covers it.  This module follows the published nflows algorithm as
 restated in oracle/glow_ref.py (per layer ActNorm -> LULinear -> AffineCouplingTransform whose scale/shift come
 from a context-conditioned ResidualNet with GLU gating; alternating +-1 mask; StandardNormal base) and keeps
-nflows' module tree so that its state_dict keys (`_transform._transforms.{i}...`) line up.  Dropout is evaluated
-in eval mode (the reference's train-mode dropout draws from torch's RNG and cannot be reproduced);
+nflows' module tree so that its state_dict keys (`_transform._transforms.{i}...`) line up.  Dropout (p = 0.2 in the reference's
+constructor call) is active in train mode as in the reference - masks drawn on the device (mhe_dropout; the reference's draws come from
+torch's generator and cannot be reproduced, so parity tests record the masks and hand them to the oracle) - and the identity in eval mode;
 batch norm inside the nets is off (nflows' default).
 
 MI355X shape of the computation: ActNorm and the LU product collapse into one 45x45 affine map per layer (and its
@@ -124,6 +125,12 @@ class ConditionalGlow(nn.Module):
         self._distribution = _StandardNormal([features])
         self._embedding_net = nn.Identity()
         self._pack = None
+        # train-mode dropout of the residual blocks (nflows ResidualBlock: after the second activation; hand/network.py:343-344 builds the
+        # flow with dropout_probability=0.2 and trains it that way, :781 "Since uses Dropout"): masks drawn on the device (ops.dropout_).
+        # mask_feed: a list of mask-bit tensors consumed in call order instead of drawing (parity tests); record_masks: the bits of every
+        # dropout of a pass are appended to last_masks (handed to the oracle, which cannot draw the same stream)
+        self.p_drop = float(dropout_probability)
+        self.mask_feed, self.record_masks, self.last_masks = None, False, []
         # operand dtype of the four hidden x hidden products per layer (95 % of the flow's FLOP): float32 (parity mode) or
         # bfloat16 with f32 accumulate (performance mode; forward / loss / sample only - the train step's pass stays f32)
         self.compute_dtype = torch.float32
@@ -174,6 +181,16 @@ class ConditionalGlow(nn.Module):
         self._pack = (ver, pk)
         return pk
 
+    def dropout_(self, t):
+        """the residual block's dropout on its second activation `t`, in place (train mode only); returns the mask bits or None"""
+        if not (self.training and self.p_drop > 0.0):
+            return None
+        given = self.mask_feed.pop(0) if self.mask_feed else None
+        bits = ops.dropout_(t, self.p_drop, bits=given)
+        if self.record_masks:
+            self.last_masks.append(bits)
+        return bits
+
     # ---- the two directions ------------------------------------------------------------------------------
     def _net(self, d, v, ctab, slot, R, row_div, n_img, bufs):
         """coupling parameters [R,64] of layer `d` from the (padded) variable v whose identity columns are current"""
@@ -191,10 +208,12 @@ class ConditionalGlow(nn.Module):
                 w0b, w1b = d["blocks_bf16"][b]
                 ops.check(L.mhe_relu_copy_f32(ops._ptr(h), ops._ptr(tb), h.numel(), ops.BF16, s()), "mhe_relu_copy_f32")
                 ops.conv2d_nhwc(tb, w0b, 1, 1, 1, 0, out_shift=b0, relu_out=True, out=t2b)
+                self.dropout_(t2b)
                 t = ops.conv2d_nhwc(t2b, w1b, 1, 1, 1, 0, out_shift=b1, out=tb).view(R, H)
             else:
                 ops.check(L.mhe_relu_copy_f32(ops._ptr(h), ops._ptr(t), h.numel(), ops.dtype_code(t.dtype), s()), "mhe_relu_copy_f32")
                 ops.linear(t, w0, b0, relu=True, out=t2)
+                self.dropout_(t2)
                 ops.linear(t2, w1, b1, out=t)
             ops.check(L.mhe_glow_glu_residual_f32(ops._ptr(h), ops._ptr(t), ops.dtype_code(t.dtype), C.c_void_p(ctab[:, (slot + 1 + b) * H:].data_ptr()), cs, R, H, row_div,
                                                   n_img, s()), "mhe_glow_glu_residual_f32")

@@ -174,6 +174,28 @@ def randn(rows, cols, device, scale=1.0, state=None):
     return out
 
 
+def dropout_(x, p, bits=None, state=None):
+    """x <- x * keep / (1 - p) in place (mhe_dropout).  bits=None: the mask is drawn on the device (the generator state of randn advances) and
+    its bits are returned (uint8 [x.numel() / 8], bit k of byte i = element 8 i + k kept); bits given: that mask is applied."""
+    if x.dtype not in (torch.float32, torch.bfloat16) or not x.is_cuda or not x.is_contiguous() or x.numel() % 8:
+        raise _lib.MheError("dropout_: contiguous f32 / bf16 device tensor with a multiple of 8 elements expected")
+    draw = bits is None
+    if draw:
+        bits = torch.empty(x.numel() // 8, device=x.device, dtype=torch.uint8)
+        st = state if state is not None else rng_state(x.device)
+    else:
+        _chk(bits, torch.uint8, "dropout.bits", (x.numel() // 8,))
+        st = None
+    check(_lib.lib().mhe_dropout(_ptr(x), dtype_code(x.dtype), _ptr(bits), x.numel(), float(p), _ptr(st), int(draw), _stream()), "mhe_dropout")
+    return bits
+
+
+def dropout_mask(bits, shape, p):
+    """the float mask (0 or 1 / (1 - p)) that dropout_ applied, from its bits (tests: the oracle is fed the same mask)"""
+    m = ((bits.view(-1, 1).int() >> torch.arange(8, device=bits.device, dtype=torch.int32)) & 1).float().reshape(shape)
+    return m / (1.0 - p)
+
+
 def reparam(mn, l2, eps=None, sigmoid_act=False, deterministic=False):
     """(sd, z) of BasicEnc's stochastic head (mhe_reparam_f32)"""
     _chk(mn, torch.float32, "reparam.mn"); _chk(l2, torch.float32, "reparam.l2", mn.shape)
@@ -842,6 +864,20 @@ def avgpool(x):
     return y
 
 
+def bn_act_avgpool(x, scale, shift, res=None, rscale=None, rshift=None, relu=True):
+    """avgpool(bn_act(x, scale, shift, res, rscale, rshift, relu)) in one pass (mhe_bn_act_avgpool_nhwc): the same bits, no block-wide store"""
+    B, H, W, Cn = x.shape
+    _chk(x, x.dtype, "bn_act_avgpool.x"); _chk(scale, torch.float32, "bn_act_avgpool.scale", (Cn,)); _chk(shift, torch.float32, "bn_act_avgpool.shift", (Cn,))
+    if res is not None:
+        _chk(res, x.dtype, "bn_act_avgpool.res", x.shape)
+    if rscale is not None:
+        _chk(rscale, torch.float32, "bn_act_avgpool.rscale", (Cn,)); _chk(rshift, torch.float32, "bn_act_avgpool.rshift", (Cn,))
+    y = torch.empty(B, Cn, device=x.device, dtype=torch.float32)
+    check(_lib.lib().mhe_bn_act_avgpool_nhwc(_ptr(x), _ptr(scale), _ptr(shift), _ptr(res), _ptr(rscale), _ptr(rshift), _ptr(y), B, H * W, Cn, int(relu),
+                                             dtype_code(x.dtype), _stream()), "mhe_bn_act_avgpool_nhwc")
+    return y
+
+
 def nchw_to_nhwc(x, dtype=torch.float32, cpad=None):
     """NCHW f32 -> NHWC `dtype`, channels zero-padded to a 16-byte chunk (or to cpad: mhe_nchw_to_nhwc_pad)"""
     B, Cn, H, W = x.shape
@@ -871,6 +907,40 @@ def _wgrad_ws(device, need):
 WGRAD_SLABS = True      # False: f32 atomics into dw (the form without a workspace)
 
 
+_WG_WAVES = {(256, 256): "4, 2", (128, 128): "2, 2", (64, 128): "1, 4", (128, 64): "4, 1", (64, 64): "2, 2"}
+
+
+def _wgrad_kernel_name(d, Ho=0, Wo=0, nbatch=1):
+    """the weight-gradient instantiation the launcher will pick, spelled as rocprofv3 prints it"""
+    v = _lib.lib().mhe_conv_wgrad_variant(C.byref(d), Ho, Wo, nbatch)
+    kind, bm, bn = v // 1000000, (v % 1000000) // 1000, v % 1000
+    if kind == 1:
+        return "mhe::wgrad::wgrad_dma_kernel<%d, %d, %s>" % (bm, bn, _WG_WAVES.get((bm, bn), "?"))
+    if kind == 2:
+        return "mhe::wgrad::wgrad_bf16_kernel<%d, %d, %s>" % (bm, bn, _WG_WAVES.get((bm, bn), "?"))
+    return "mhe::wgrad::wgrad_kernel<%s, %d, %d>" % ("float" if d.dtype == F32 else "unsigned short", bm, bn)
+
+
+class _Timed:
+    """HIP events on the launch stream around one launch, appended to KERNEL_TIMES while TIMING is on (bench.py's live roofline pass)"""
+    def __init__(self, name_fn, flops, nbytes):
+        self.on = TIMING
+        if self.on:
+            self.name, self.flops, self.nbytes = name_fn(), flops, nbytes
+            self.ev0, self.ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        if self.on:
+            self.ev0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ev1.record()
+            KERNEL_TIMES.append((self.name, self.flops, self.ev0, self.ev1, self.nbytes))
+        return False
+
+
 def conv_wgrad(x, gy, KH, KW, stride, pad, dw, ldw=0):
     """dw[Cout, KH*KW*Cin] (f32, pre-zeroed or accumulating) += gy^T (*) x ; x [B,H,W,Cin], gy [B,Ho,Wo,Cout]."""
     B, H, W, Cin = x.shape
@@ -883,11 +953,13 @@ def conv_wgrad(x, gy, KH, KW, stride, pad, dw, ldw=0):
     d = ConvDesc(B, H, W, Cin, Cout, KH, KW, stride, pad, dtype_code(dt), 0, 0)
     L = _lib.lib()
     need = L.mhe_conv_wgrad_workspace_floats(C.byref(d)) if WGRAD_SLABS else 0
-    if need:
-        ws = _wgrad_ws(x.device, need)
-        check(L.mhe_conv_wgrad_ws_nhwc(C.byref(d), _ptr(x), _ptr(gy), _ptr(dw), int(ldw), _ptr(ws), ws.numel(), _stream()), "mhe_conv_wgrad_ws_nhwc")
-    else:
-        check(L.mhe_conv_wgrad_nhwc(C.byref(d), _ptr(x), _ptr(gy), _ptr(dw), int(ldw), _stream()), "mhe_conv_wgrad_nhwc")
+    # (timed: the kernel + its slab reducer; algorithmic bytes: both operands once + the gradient)
+    with _Timed(lambda: _wgrad_kernel_name(d), 2.0 * B * Ho * Wo * Cout * KH * KW * Cin, x.element_size() * (x.numel() + gy.numel()) + 4 * Cout * KH * KW * Cin):
+        if need:
+            ws = _wgrad_ws(x.device, need)
+            check(L.mhe_conv_wgrad_ws_nhwc(C.byref(d), _ptr(x), _ptr(gy), _ptr(dw), int(ldw), _ptr(ws), ws.numel(), _stream()), "mhe_conv_wgrad_ws_nhwc")
+        else:
+            check(L.mhe_conv_wgrad_nhwc(C.byref(d), _ptr(x), _ptr(gy), _ptr(dw), int(ldw), _stream()), "mhe_conv_wgrad_nhwc")
     return dw
 
 
@@ -905,8 +977,9 @@ def conv_wgrad_batched(x, gy, dw, dw_batch_stride, nbatch, x_batch_stride=None, 
     L = _lib.lib()
     need = L.mhe_conv_wgrad_batched_workspace_floats(C.byref(d), nbatch) if WGRAD_SLABS else 0
     ws = _wgrad_ws(x.device, need) if need else None
-    check(L.mhe_conv_wgrad_batched_nhwc(C.byref(d), nbatch, _ptr(x), xs, _ptr(gy), gs, _ptr(dw), int(dw_batch_stride), 0, _ptr(ws),
-                                        ws.numel() if ws is not None else 0, _stream()), "mhe_conv_wgrad_batched_nhwc")
+    with _Timed(lambda: _wgrad_kernel_name(d, 0, 0, nbatch), 2.0 * nbatch * R * N * K, nbatch * (2 * R * (K + N) + 4 * N * K)):
+        check(L.mhe_conv_wgrad_batched_nhwc(C.byref(d), nbatch, _ptr(x), xs, _ptr(gy), gs, _ptr(dw), int(dw_batch_stride), 0, _ptr(ws),
+                                            ws.numel() if ws is not None else 0, _stream()), "mhe_conv_wgrad_batched_nhwc")
     return dw
 
 
@@ -925,8 +998,9 @@ def conv_wgrad_rect(x, gy, KH, KW, stride_h, stride_w, pad_h, pad_w, dw):
     ws = None
     if need:
         ws = _wgrad_ws(x.device, need)
-    check(L.mhe_conv_wgrad_rect_nhwc(C.byref(d), stride_w, pad_w, Ho, Wo, _ptr(x), _ptr(gy), _ptr(dw), 0, _ptr(ws), ws.numel() if ws is not None else 0,
-                                     _stream()), "mhe_conv_wgrad_rect_nhwc")
+    with _Timed(lambda: _wgrad_kernel_name(d, Ho, Wo), 2.0 * B * Ho * Wo * Cout * KH * KW * Cin, x.element_size() * (x.numel() + gy.numel()) + 4 * Cout * KH * KW * Cin):
+        check(L.mhe_conv_wgrad_rect_nhwc(C.byref(d), stride_w, pad_w, Ho, Wo, _ptr(x), _ptr(gy), _ptr(dw), 0, _ptr(ws), ws.numel() if ws is not None else 0,
+                                         _stream()), "mhe_conv_wgrad_rect_nhwc")
     return dw
 
 

@@ -110,6 +110,8 @@ class ResNetTrunk(nn.Module):
         # the stem's max pool taken inside the conv1 kernel on the raw output (bf16, 256x256 images; csrc/stem_pool.hip): the
         # full-resolution conv1 output is never written, layer1.0's conv1 / shortcut apply bn1 + ReLU on their operand load
         self.stem_pool_fused = os.environ.get("MHE_STEM_POOL", "1") == "1"
+        # the last block's relu(bn(y) + identity) evaluated inside the global average pool (csrc/conv.hip: bn_act_avgpool_kernel)
+        self.fuse_pool = os.environ.get("MHE_FUSE_POOL", "1") == "1"
 
     # -- packed-weight cache keyed on the parameter's version counter
     def _w(self, conv, cin_pad=None, stem=False):
@@ -247,6 +249,11 @@ class ResNetTrunk(nn.Module):
                 pending = ("re", y2, a2, w3, al, idt, idaff)
             elif self.fuse_tail and nxt is not None and nxt.kind == "bottleneck":
                 pending = (yl, al, idt, idaff)
+            elif nxt is None and self.fuse_pool and yl.shape[-1] % 4 == 0:
+                # the last block's tail inside the average pool (same bits; no block-wide store: MHE_FUSE_POOL=0 keeps the two launches)
+                if pool is not None:
+                    pool.done()
+                return self.fc(ops.bn_act_avgpool(yl, al[0], al[1], idt, None if idaff is None else idaff[0], None if idaff is None else idaff[1]))
             elif idaff is not None:
                 a = ops.bn_act(yl, al[0], al[1], idt, idaff[0], idaff[1], relu=True)
             else:

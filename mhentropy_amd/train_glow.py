@@ -10,7 +10,8 @@ Per layer (sampling order L-1 .. 0, reverse pass 0 .. L-1):
 with (A, c) the ActNorm + LU affine map.  Dense products: mhe_linear_f32 / mhe_conv_wgrad_nhwc; elementwise stages: csrc/glow.hip.
 The gradients of the 45x45 re-parameterisation (log_scale, shift, LU entries, softplus diagonal, bias from dAinv, dcinv and the
 log-det constant) are a few 45x45 products per layer, done in float64 on the host - bookkeeping of the same kind as weight
-packing, not part of the per-hypothesis path.  Dropout is taken in eval mode (see glow.py).
+packing, not part of the per-hypothesis path.  Dropout (train mode, p = 0.2: hand/network.py:343-344,781) is applied to the second activation
+of every residual block in the sampling pass (mask bits kept on the tape) and to its gradient in the reverse pass (glow.py, mhe_dropout).
 """
 import ctypes as C
 
@@ -171,18 +172,20 @@ class GlowPart:
             slot = l * self.per
             h = ops.linear(v, d["wx"])
             ops.check(L_.mhe_glow_add_image_rows_f32(ops._ptr(h), C.c_void_p(ctab[:, slot * H:].data_ptr()), cs, R, H, 1, B, s()), "mhe_glow_add_image_rows_f32")
-            hs, t2s, t3s = [h], [], []
+            hs, t2s, t3s, drops = [h], [], [], []
             for b, (w0, b0, w1, b1) in enumerate(d["blocks"]):
                 if self.mixed:
                     w0b, w1b = d["blocks_b"][b][:2]
                     t = torch.empty(R, 1, 1, H, device=dev, dtype=torch.bfloat16)
                     ops.check(L_.mhe_relu_copy_f32(ops._ptr(hs[-1]), ops._ptr(t), t.numel(), ops.BF16, s()), "mhe_relu_copy_f32")
                     t2 = ops.conv2d_nhwc(t, w0b, 1, 1, 1, 0, out_shift=b0, relu_out=True)
+                    drops.append(g.dropout_(t2))
                     t3 = ops.conv2d_nhwc(t2, w1b, 1, 1, 1, 0, out_shift=b1)
                 else:
                     t = torch.empty_like(h)
                     ops.check(L_.mhe_relu_copy_f32(ops._ptr(hs[-1]), ops._ptr(t), t.numel(), 0, s()), "mhe_relu_copy_f32")
                     t2 = ops.linear(t, w0, b0, relu=True)
+                    drops.append(g.dropout_(t2))
                     t3 = ops.linear(t2, w1, b1)
                 hn = hs[-1].clone()
                 ops.check(L_.mhe_glow_glu_residual_f32(ops._ptr(hn), ops._ptr(t3), ops.dtype_code(t3.dtype), C.c_void_p(ctab[:, (slot + 1 + b) * H:].data_ptr()), cs, R, H, 1, B, s()),
@@ -192,7 +195,7 @@ class GlowPart:
             y = torch.empty(R, 64, device=dev)
             ops.check(L_.mhe_glow_coupling_f32(ops._ptr(v), ops._ptr(prm), ops._ptr(y), ops._ptr(logdet), R, D, d["first"], d["T"], 1, s()),
                       "mhe_glow_coupling_f32")
-            tape[l] = {"v": v, "hs": hs, "t2": t2s, "t3": t3s, "prm": prm, "y": y}
+            tape[l] = {"v": v, "hs": hs, "t2": t2s, "t3": t3s, "prm": prm, "y": y, "drop": drops}
             v = ops.linear(y, self.aff["Ainv"][l], self.aff["cinv"][l])
         x = torch.empty(R, D, device=dev)
         logq = torch.empty(R, device=dev)
@@ -239,6 +242,8 @@ class GlowPart:
                     _, _, w0Tb, w1Tb = d["blocks_b"][b]
                     ops.conv_wgrad(t2b, gt3, 1, 1, 1, 0, raw(rb["w1"], (H, H))); ops.colsum(gt3, raw(rb["b1"], (H,)))
                     gt2 = ops.conv2d_nhwc(gt3, w1Tb, 1, 1, 1, 0)
+                    if t["drop"][b] is not None:          # dropout's reverse: the same mask and scale on the gradient
+                        ops.dropout_(gt2, g.p_drop, bits=t["drop"][b])
                     ops.flow_lrelu_bwd_mixed(gt2.view(R, H), t2b.view(R, H), out_bf16=gt2.view(R, H), slope=0.0)
                     tt = torch.empty(R, 1, 1, H, device=dev, dtype=torch.bfloat16)
                     ops.check(L_.mhe_relu_copy_f32(ops._ptr(t["hs"][b]), ops._ptr(tt), tt.numel(), ops.BF16, s()), "mhe_relu_copy_f32")
@@ -248,6 +253,8 @@ class GlowPart:
                     continue
                 ops.linear_wgrad(t2b, gt3, raw(rb["w1"], (H, H))); ops.colsum(gt3, raw(rb["b1"], (H,)))
                 gt2 = ops.linear(gt3, w1T)
+                if t["drop"][b] is not None:
+                    ops.dropout_(gt2, g.p_drop, bits=t["drop"][b])
                 ops.flow_lrelu_bwd(gt2, t2b, slope=0.0)
                 tt = torch.empty(R, H, device=dev)
                 ops.check(L_.mhe_relu_copy_f32(ops._ptr(t["hs"][b]), ops._ptr(tt), tt.numel(), 0, s()), "mhe_relu_copy_f32")

@@ -13,8 +13,9 @@ against the reference: this file restates the PUBLISHED nflows algorithm the for
 `nn.nets.ResidualNet` with GLU context gating, `distributions.StandardNormal`, `flows.Flow`), composed the way
 Glow / ProHMR describe: per layer ActNorm -> LU-decomposed invertible linear -> affine coupling whose
 scale/shift come from a context-conditioned residual MLP, with an alternating +-1 feature mask.
-State-dict keys follow nflows' module tree (`_transform._transforms.{3l+0,1,2}...`).  Dropout is taken in
-eval mode (identity); `use_batch_norm=False`.  Until the fork is reachable the HIP path is tested against THIS
+State-dict keys follow nflows' module tree (`_transform._transforms.{3l+0,1,2}...`).  Dropout: the identity (eval mode) unless
+the caller supplies the masks of a train-mode pass (`masks=`, one [R, H] tensor per residual block in call order);
+`use_batch_norm=False`.  Until the fork is reachable the HIP path is tested against THIS
 restatement plus the flow's own identities (inverse(forward(x)) == x, log-det consistency).
 """
 import math
@@ -57,14 +58,18 @@ def masks(features, num_layers):
     return out
 
 
-def residual_net(sd, p, inputs, context, num_blocks):
-    """nflows nn.nets.ResidualNet with context (eval mode, no batch norm)"""
+def residual_net(sd, p, inputs, context, num_blocks, masks=None):
+    """nflows nn.nets.ResidualNet with context (no batch norm).  masks: None = eval mode (dropout is the identity); an iterator of [R, H]
+    tensors holding 0 or 1 / (1 - p) = train mode with THESE dropout masks, one per residual block in call order (nn.Dropout's own
+    draws cannot be matched across generators: the tests hand over the masks the device drew)"""
     t = F.linear(torch.cat([inputs, context], 1), sd[p + "initial_layer.weight"], sd[p + "initial_layer.bias"])
     for b in range(num_blocks):
         q = p + f"blocks.{b}."
         u = F.relu(t)
         u = F.linear(u, sd[q + "linear_layers.0.weight"], sd[q + "linear_layers.0.bias"])
         u = F.relu(u)
+        if masks is not None:
+            u = u * next(masks)                       # nflows ResidualBlock: activation -> dropout -> linear_layers[1]
         u = F.linear(u, sd[q + "linear_layers.1.weight"], sd[q + "linear_layers.1.bias"])
         g = F.linear(context, sd[q + "context_layer.weight"], sd[q + "context_layer.bias"])
         t = t + u * torch.sigmoid(g)                  # F.glu(cat(u, g)) = u * sigmoid(g)
@@ -76,7 +81,7 @@ def _scale_shift(params, T):
     return torch.sigmoid(params[:, T:] + 2.0) + 1e-3, params[:, :T]
 
 
-def transform_forward(sd, x, context, num_layers, num_blocks):
+def transform_forward(sd, x, context, num_layers, num_blocks, drop=None):
     """data -> noise, with log|det|"""
     D = x.shape[1]
     logdet = x.new_zeros(x.shape[0])
@@ -89,7 +94,7 @@ def transform_forward(sd, x, context, num_layers, num_blocks):
         x = F.linear(x, W, sd[p + "bias"])
         logdet = logdet + torch.log(diag).sum()
         p = layer_prefix(l, 2)
-        params = residual_net(sd, p + "transform_net.", x[:, idf], context, num_blocks)
+        params = residual_net(sd, p + "transform_net.", x[:, idf], context, num_blocks, drop)
         scale, shift = _scale_shift(params, trf.numel())
         y = x.clone()
         y[:, trf] = x[:, trf] * scale + shift
@@ -98,7 +103,7 @@ def transform_forward(sd, x, context, num_layers, num_blocks):
     return x, logdet
 
 
-def transform_inverse(sd, z, context, num_layers, num_blocks):
+def transform_inverse(sd, z, context, num_layers, num_blocks, drop=None):
     """noise -> data, with log|det| of the inverse"""
     D = z.shape[1]
     logdet = z.new_zeros(z.shape[0])
@@ -106,7 +111,7 @@ def transform_inverse(sd, z, context, num_layers, num_blocks):
     for l in reversed(range(num_layers)):
         idf, trf = ms[l]
         p = layer_prefix(l, 2)
-        params = residual_net(sd, p + "transform_net.", z[:, idf], context, num_blocks)
+        params = residual_net(sd, p + "transform_net.", z[:, idf], context, num_blocks, drop)
         scale, shift = _scale_shift(params, trf.numel())
         y = z.clone()
         y[:, trf] = (z[:, trf] - shift) / scale
@@ -125,18 +130,18 @@ def std_normal_log_prob(z):
     return -0.5 * (z * z).sum(1) - 0.5 * z.shape[1] * math.log(2 * math.pi)
 
 
-def log_prob(sd, x, context, num_layers=4, num_blocks=2):
+def log_prob(sd, x, context, num_layers=4, num_blocks=2, masks=None):
     """Flow.log_prob as the fork returns it: (log_prob (R,), noise (R,D))"""
-    z, logdet = transform_forward(sd, x, context, num_layers, num_blocks)
+    z, logdet = transform_forward(sd, x, context, num_layers, num_blocks, None if masks is None else iter(masks))
     return std_normal_log_prob(z) + logdet, z
 
 
-def sample_and_log_prob(sd, noise, context, num_layers=4, num_blocks=2):
+def sample_and_log_prob(sd, noise, context, num_layers=4, num_blocks=2, masks=None):
     """noise (B,N,D), context (B,F) -> samples (B,N,D), log_prob (B,N), noise: rows are batch-major
     (nflows repeats each context row N times, `torchutils.repeat_rows`)."""
     B, N, D = noise.shape
     z = noise.reshape(B * N, D)
     ctx = context.repeat_interleave(N, 0)
-    x, logdet = transform_inverse(sd, z, ctx, num_layers, num_blocks)
+    x, logdet = transform_inverse(sd, z, ctx, num_layers, num_blocks, None if masks is None else iter(masks))
     lp = std_normal_log_prob(z) - logdet
     return x.reshape(B, N, D), lp.reshape(B, N), noise

@@ -50,7 +50,7 @@ def test_glow_matches_the_nflows_restatement(gpu_lib, hidden, B, N, D, F):
 
 def test_mhent_glow_branch(gpu_lib):
     """MHEnt with q_z_giv_i_model='glow' (hand/network.py:342-344,736-742,781-799): loss dict from the sampling pass's own log-prob"""
-    from mhentropy_amd import harness
+    from mhentropy_amd import harness, ops
     from mhentropy_amd.network import MHEnt
     from oracle import glow_ref, network_ref, mano_ref
     special, common = harness.mhent_cfgs(backbone="resnet18", tables=synth.mano_tables(0))
@@ -67,10 +67,19 @@ def test_mhent_glow_branch(gpu_lib):
     feat = torch.as_tensor(np.random.default_rng(6).normal(0, 0.5, (B, 512)).astype(np.float32))
     model.feat_extractor.forward = lambda x: (feat.cuda(), feat.cuda(), None)
     noise = torch.as_tensor(np.random.default_rng(7).normal(0, 1, (B, N, 45)).astype(np.float32))
+    # train mode: the residual blocks' dropout (p = 0.2, hand/network.py:343-344,781) is active; its masks are drawn on the device -
+    # recorded here and handed to the oracle, which cannot draw the same stream
+    flow = model.q_z_giv_i
+    flow.record_masks, flow.last_masks = True, []
     out = model.get_loss(None, {k: v.cuda() for k, v in y.items()}, mods=["uv"], N=N, noise=noise.cuda())
+    assert len(flow.last_masks) == 4 * 2
+    masks = [ops.dropout_mask(b, (B * N, 512), flow.p_drop).cpu() for b in flow.last_masks]
+    kept = float(torch.stack(masks).gt(0).float().mean())
+    assert abs(kept - 0.8) < 0.01, kept
+    flow.record_masks = False
     # oracle composition of the same lines
     tb = mano_ref.tables_from_numpy(synth.mano_tables(0))
-    x, lp, _ = glow_ref.sample_and_log_prob(gsd, noise, feat)
+    x, lp, _ = glow_ref.sample_and_log_prob(gsd, noise, feat, masks=masks)
     th45 = x.permute(1, 0, 2).flatten(0, 1)
     log_q = lp.transpose(0, 1).flatten()
     z = network_ref.combine_z(network_ref.det_head(hsd, feat).repeat(N, 1), th45)
@@ -87,7 +96,7 @@ def test_mhent_glow_branch(gpu_lib):
 def test_glow_train_step_gradients(gpu_lib, hidden):
     """reverse pass of the Glow branch (sampling pass + entropy from its own log-prob, reference README.md:36-42,
     hand/network.py:736-742,781-799) against torch autograd on the nflows restatement; from the trunk feature on"""
-    from mhentropy_amd import harness
+    from mhentropy_amd import harness, ops
     from mhentropy_amd.glow import ConditionalGlow
     from mhentropy_amd.network import MHEnt
     from mhentropy_amd.train import TrainStep
@@ -108,20 +117,27 @@ def test_glow_train_step_gradients(gpu_lib, hidden):
     y = {k: torch.as_tensor(v) for k, v in yn.items()}
     f = torch.as_tensor(np.random.default_rng(6).normal(0, 0.5, (B, 512)).astype(np.float32))
     noise = torch.as_tensor(np.random.default_rng(7).normal(0, 1, (B, N, 45)).astype(np.float32))
+    # the HIP pass first: its train-mode dropout masks (drawn on the device, kept as bits on the tape) are handed to the oracle
+    ts = TrainStep(model)
+    flow = model.q_z_giv_i
+    flow.record_masks, flow.last_masks = True, []
+    out = ts.forward_backward(None, {k: v.cuda() for k, v in y.items()}, noise=noise.cuda(), N=N, trunk_out=f.cuda())
+    flow.record_masks = False
+    assert len(flow.last_masks) == 4 * 2
+    # the train pass lays its rows out sample-major (r = n B + b), nflows batch-major (r = b N + n)
+    masks = [ops.dropout_mask(b_, (N, B, hidden), flow.p_drop).permute(1, 0, 2).reshape(B * N, hidden).cpu() for b_ in flow.last_masks]
     # oracle: same lines, autograd
     tb = mano_ref.tables_from_numpy(synth.mano_tables(0))
     P = {("q_z_giv_i." + k): v.clone().requires_grad_(True) for k, v in gsd.items()}
     P.update({k: v.clone().requires_grad_(True) for k, v in hsd.items()})
     g_sd = {k[len("q_z_giv_i."):]: v for k, v in P.items() if k.startswith("q_z_giv_i.")}
     feat = F.linear(f, P["feat_extractor.l1.0.weight"], P["feat_extractor.l1.0.bias"])
-    x, lp, _ = glow_ref.sample_and_log_prob(g_sd, noise, feat)
+    x, lp, _ = glow_ref.sample_and_log_prob(g_sd, noise, feat, masks=masks)
     th45, log_q = x.permute(1, 0, 2).flatten(0, 1), lp.transpose(0, 1).flatten()
     z = network_ref.combine_z(network_ref.det_head(P, feat).repeat(N, 1), th45)
     q = network_ref.forward_log_p(tb, z, y, N)["log_p"].reshape(N, -1).mean(0)
     log_p = q + (-log_q).reshape(N, -1).mean(0)
     (-log_p).mean().backward()
-    ts = TrainStep(model)
-    out = ts.forward_backward(None, {k: v.cuda() for k, v in y.items()}, noise=noise.cuda(), N=N, trunk_out=f.cuda())
     assert_close(out["log_p"].cpu(), log_p.detach(), 1e-4, what="log_p")
     rows = []
     for name, p in model.named_parameters():
@@ -179,8 +195,44 @@ def test_glow_train_step_bf16_products(gpu_lib):
         noise = torch.as_tensor(np.random.default_rng(7).normal(0, 1, (N * B, 45)).astype(np.float32)).cuda()
         ts = TrainStep(model)
         assert ts.glow.mixed == (dt == torch.bfloat16)
+        flow = model.q_z_giv_i
+        if "masks" in res:                                    # the second mode replays the first one's dropout masks
+            flow.mask_feed = [m.clone() for m in res["masks"]]
+        else:
+            flow.record_masks, flow.last_masks = True, []
         out = ts.forward_backward(None, y, noise=noise, N=N, trunk_out=f)
+        if "masks" not in res:
+            res["masks"] = list(flow.last_masks)
+            assert len(res["masks"]) == 8
         res[dt] = (out["log_p"].cpu(), {n: ts.grad_of(p).cpu().double().clone() for n, p in model.named_parameters() if n.startswith("q_z_giv_i")})
     assert_close(res[torch.bfloat16][0], res[torch.float32][0], 2e-2, what="log_p")
     errs = sorted(((res[torch.bfloat16][1][n] - g).norm() / (g.norm() + 1e-30)).item() for n, g in res[torch.float32][1].items() if g.norm() > 0)
     assert errs[-1] < 0.15 and errs[len(errs) // 2] < 3e-2, (errs[-3:], errs[len(errs) // 2])
+
+
+def test_dropout_kernel_draws_keeps_and_reapplies_its_mask(gpu_lib):
+    """mhe_dropout (csrc/rng.hip): x <- x * keep / (1 - p) with keep ~ Bernoulli(1 - p) from the device generator; the returned bits
+    reproduce the launch (reverse pass, oracle masks); two draws differ (the launch advances the counter, also under graph replay)"""
+    from mhentropy_amd import ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ops.rng_state(dev, seed=123)
+    for dt in (torch.float32, torch.bfloat16):
+        x0 = torch.randn(640, 512, device="cuda").to(dt)
+        x = x0.clone()
+        bits = ops.dropout_(x, 0.2)
+        m = ops.dropout_mask(bits, x.shape, 0.2)
+        assert abs(float(m.gt(0).float().mean()) - 0.8) < 5e-3
+        assert torch.equal(x, (x0.float() * m).to(dt))
+        x2 = x0.clone()
+        ops.dropout_(x2, 0.2, bits=bits)                      # applying the stored bits = the same launch
+        assert torch.equal(x2, x)
+        x3 = x0.clone()
+        bits3 = ops.dropout_(x3, 0.2)
+        assert not torch.equal(bits3, bits)                  # a fresh mask
+    # per-column keep rates are flat (no structure from the 8-elements-per-Philox-call layout)
+    big = torch.ones(4096, 512, device="cuda")
+    mb = ops.dropout_mask(ops.dropout_(big, 0.2), big.shape, 0.2).gt(0).float()
+    assert float((mb.mean(0) - 0.8).abs().max()) < 0.04 and float((mb.mean(1) - 0.8).abs().max()) < 0.09
+    # eval mode: the module applies no dropout
+    g, _ = _glow(1, 64)
+    assert g.dropout_(torch.ones(8, 64, device="cuda")) is None

@@ -441,7 +441,8 @@ def test_trunk_with_conv3_reevaluated_equals_the_stored_form(gpu_lib, training, 
 def test_trunk_with_the_pool_inside_the_stem_equals_the_two_kernel_stem(gpu_lib, training):
     """MHE_STEM_POOL (csrc/stem_pool.hip; bf16, 256x256 images): layer1.0's conv1 / shortcut read the pooled RAW conv1 output with bn1 + ReLU
     on their operand load - the same values as stem -> bn1 -> relu -> maxpool (hand/network.py:54-61,110), so eval mode agrees to the last
-    bit of the feature and train mode to the noise of the statistics' atomics (see the recompute test above for its amplification)"""
+    bit of the feature and train mode to the summation order of the statistics (the fused kernel sums conv1's outputs per strip, the
+    two-kernel stem per tile: another f32 grouping, amplified like the recompute test's above)"""
     from mhentropy_amd import resnet
     sd = {k: torch.as_tensor(v) for k, v in synth.resnet_state(8, "resnet50").items()}
     sd["bn1.weight"] = sd["bn1.weight"].clone()
@@ -460,3 +461,22 @@ def test_trunk_with_the_pool_inside_the_stem_equals_the_two_kernel_stem(gpu_lib,
     assert d < (2e-1 if training else 1e-6), d
     assert_close(rv1, rv0, 1e-5, what="bn1 running_var")
     assert_close(rm1, rm0, 1e-4, 1e-6, what="layer1.0.bn1 running_mean (first consumer of the pooled output)")
+
+
+@pytest.mark.parametrize("arch,dt,S", [("resnet50", torch.bfloat16, 128), ("resnet50", torch.float32, 96), ("resnet18", torch.bfloat16, 96)])
+@pytest.mark.parametrize("training", [True, False])
+def test_trunk_with_the_last_tail_inside_the_average_pool_equals_the_two_launches(gpu_lib, arch, dt, S, training):
+    """MHE_FUSE_POOL (csrc/conv.hip, bn_act_avgpool_kernel): the last block's relu(bn(y) + identity) evaluated inside the global average pool
+    (torchvision ResNet.forward: layer4 -> avgpool; hand/network.py:54-61,110) - rounded to the storage type before it is summed, summed in
+    the pool kernel's order: the encoder feature equals the two launches' BIT FOR BIT, in both modes and both storage types"""
+    from mhentropy_amd import resnet
+    sd = {k: torch.as_tensor(v) for k, v in synth.resnet_state(12, arch).items()}
+    x = torch.as_tensor(synth.batch(12, 6, image_size=S)[0]).cuda()
+    outs = []
+    for fused in (True, False):
+        trunk = resnet.ResNetTrunk(arch, compute_dtype=dt)
+        trunk.load_state_dict(sd)
+        trunk = trunk.cuda().train(training)
+        trunk.fuse_pool = fused
+        outs.append(trunk(x))
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
