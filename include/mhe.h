@@ -504,6 +504,17 @@ int mhe_bottleneck_tail_bits_nhwc(const mhe_conv_desc *d, int Cb, const void *y2
                                   const void *w3, const float *bn3_scale, const float *bn3_shift, const void *identity,
                                   const float *id_scale, const float *id_shift, const void *w1, void *a_out, void *a_bits, void *y1,
                                   mhe_stat_t *stats, void *stream);
+/* The bottleneck tail with conv3 re-evaluated at 256 bottleneck channels (layer3 of ResNet-50 at config C2; csrc/conv_fuse256.hip): as
+ * mhe_bottleneck_tail_nhwc with Cb = 256, block width d->Cin = 1024, d->Cout = 256 outputs, pixels % 128 == 0.  The two weight operands
+ * come PRE-PACKED as the bank-swizzled LDS images of the kernel's 32-channel stages, 32 stages of 16 KiB each:
+ *   w3_stages: stage t, K tile kt, row r, piece sp = bf16 W3[32 t + r][64 kt + 8 (sp ^ ((r >> 1) & 7)) .. + 7]   at piece kt * 256 + r * 8 + sp
+ *   w1_stages: stage t, row n, piece sp        = bf16 W1[n][32 t + 8 (sp ^ (-(n >> 2) & 3)) .. + 7]               at piece n * 4 + sp
+ * (mhentropy_amd/ops.py:bottleneck_tail256_pack).  bn3's statistics: mhe_conv1x1_stats_nhwc (256 input channels: the statistics-only launch
+ * of the resident-slab kernel).  Block output = the unfused path's bit for bit. */
+int mhe_bottleneck_tail256_supported(const mhe_conv_desc *d);
+int mhe_bottleneck_tail256_nhwc(const mhe_conv_desc *d, const void *y2, const float *bn2_scale, const float *bn2_shift, const void *w3_stages,
+                                const float *bn3_scale, const float *bn3_shift, const void *identity, const float *id_scale,
+                                const float *id_shift, const void *w1_stages, void *a_out, void *y1, mhe_stat_t *stats, void *stream);
 /* mhe_conv2d_masked_nhwc with a per-channel constant: y = (conv(x, w) + bias + residual) * [mask > 0] (+ the BatchNorm-reverse sums of one
  * consumer).  Register-staged 128-row tiles only.  xcat (optional, bf16 1x1 stride-1 launches): the operand's K range continues on a second
  * tensor - y = [x | xcat] w^T with w [Cout][Cin + cin2] and xcat [pixels][cin2]. */

@@ -971,8 +971,8 @@ static int conv_entry(const mhe_conv_desc *d, const void *x, const void *w, void
 extern "C" int mhe_conv1x1_stats_nhwc(const mhe_conv_desc *d, const void *x, const void *w, const float *in_scale, const float *in_shift,
                                       mhe_stat_t *stats, void *stream) {
     MHE_REQUIRE(d && x && w && stats, "mhe_conv1x1_stats_nhwc: null pointer");
-    MHE_REQUIRE(d->dtype == MHE_BF16 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && (d->Cin == 64 || d->Cin == 128) && d->Cout % 256 == 0,
-                "mhe_conv1x1_stats_nhwc: bf16 1x1 stride-1 with 64 / 128 input channels and a multiple of 256 output channels");
+    MHE_REQUIRE(d->dtype == MHE_BF16 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && (d->Cin == 64 || d->Cin == 128 || d->Cin == 256) && d->Cout % 256 == 0,
+                "mhe_conv1x1_stats_nhwc: bf16 1x1 stride-1 with 64 / 128 / 256 input channels and a multiple of 256 output channels");
     MHE_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "mhe_conv1x1_stats_nhwc: in_scale/in_shift must come together");
     conv::Params p{};
     p.x = x; p.w = w; p.y = nullptr; p.in_scale = in_scale; p.in_shift = in_shift; p.stats = stats;
@@ -980,6 +980,11 @@ extern "C" int mhe_conv1x1_stats_nhwc(const mhe_conv_desc *d, const void *x, con
     const long long M = (long long)d->B * d->H * d->W;
     MHE_REQUIRE(M > 0 && M < (1ll << 31), "mhe_conv1x1_stats_nhwc: bad pixel count");
     p.M = (int)M; p.Kpad = d->Cin; p.relu_in = d->relu_in; p.force = 8; p.stats_only = 1;
+    if (d->Cin == 256) {       // the resident-slab kernel with its stores dropped (conv_wide.hip): the sums of the products as they would be stored
+        p.force = 11;
+        MHE_REQUIRE(conv::wide_supports(p), "mhe_conv1x1_stats_nhwc: geometry not taken by the resident-slab kernel (M=%lld Cout=%d)", M, d->Cout);
+        return conv::launch_wide(p, (hipStream_t)stream);
+    }
     MHE_REQUIRE(conv::stream_supports(p), "mhe_conv1x1_stats_nhwc: geometry not taken by the streaming kernel");
     return conv::launch_stream(p, (hipStream_t)stream);
 }

@@ -127,7 +127,9 @@ __global__ __launch_bounds__(512) void conv_wide_kernel(const Params p, int nsla
     } else {
         struct Set { uint4 a[4]; };
         Set st[WNSET];
-        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.M * p.Cout * 2), 0x00020000);
+        // (statistics-only launch, p.y == NULL: a descriptor of zero records - every store is dropped by the hardware, the staged tile still
+        // feeds the sums of the values that WOULD have been stored)
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y ? p.y : const_cast<void *>(p.x), 0, p.y ? (int)((size_t)p.M * p.Cout * 2) : 0, 0x00020000);
         // flat tick u = (pixel tile j, K tile kt): this thread's chunk s of rows rbase + 32 i; j clamped (past the end: loaded, never used)
         auto load_tick = [&](int j, int kt, Set &S) __attribute__((always_inline)) {
             const size_t m0 = (size_t)tile_m0(j < tiles_per_wg ? j : tiles_per_wg - 1);

@@ -480,3 +480,33 @@ def test_trunk_with_the_last_tail_inside_the_average_pool_equals_the_two_launche
         trunk.fuse_pool = fused
         outs.append(trunk(x))
     assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_trunk_with_layer3_conv3_reevaluated_equals_the_stored_form(gpu_lib, training):
+    """MHE_FUSE_RECOMPUTE256 (csrc/conv_fuse256.hip, round 4): layer3's blocks without conv3's raw output - bn3's statistics from the
+    statistics-only launch of the resident-slab kernel (the same sums as the storing launch), conv3 evaluated again inside the tail kernel.
+    Same products in the same order, order-independent statistics: the encoder feature and the BatchNorm buffers equal the stored form's
+    BIT FOR BIT (hand/network.py:54-61,110).  B = 64 at 256 x 256: layer3 has 16,384 pixels, the smallest count the resident-slab kernel takes."""
+    from mhentropy_amd import resnet
+    sd = {k: torch.as_tensor(v) for k, v in synth.resnet_state(13, "resnet50").items()}
+    x = torch.as_tensor(synth.batch(13, 8, image_size=256)[0]).cuda().repeat(8, 1, 1, 1)
+    x = x + 0.01 * torch.randn(x.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(2))
+    outs, used = [], []
+    for fused in (True, False):
+        trunk = resnet.ResNetTrunk("resnet50", compute_dtype=torch.bfloat16)
+        trunk.load_state_dict(sd)
+        trunk = trunk.cuda().train(training)
+        trunk.fuse_recompute256 = fused
+        calls = []
+        orig = resnet.ops.bottleneck_tail256
+        resnet.ops.bottleneck_tail256 = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            f = trunk(x)
+        finally:
+            resnet.ops.bottleneck_tail256 = orig
+        used.append(len(calls))
+        outs.append((f, trunk.layer3[2].bn3.running_var.clone(), trunk.layer3[5].bn1.running_mean.clone()))
+    assert used == [5, 0], used                  # the five tails inside layer3 (the one into layer4 has 512 outputs)
+    for u, v in zip(outs[0], outs[1]):
+        assert torch.isfinite(u).all() and torch.equal(u, v), float((u.float() - v.float()).abs().max())
