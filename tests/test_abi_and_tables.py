@@ -1,8 +1,10 @@
 """CPU: the C-ABI library loads and exports every symbol include/mhe.h declares;
 host-side packing/layout constants agree with the kernels; the index tables baked
 into the kernels equal the reference's gathers (bit-exact integer work)."""
+import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -179,3 +181,19 @@ def test_round3_entries_refuse_what_they_do_not_support():
     assert L.mhe_conv3x3_halo_supported(256, 32, 32, 128, 128) == 1 and L.mhe_conv3x3_halo_supported(256, 8, 8, 512, 512) == 0
     rc = L.mhe_pack_transpose_bf16(null, 0, null, null, 4, 4, null)
     assert rc != 0 and b"bad arguments" in L.mhe_last_error()
+
+
+def test_committed_counter_summaries_describe_the_committed_kernels():
+    """bench.py's `roofline.traffic` comes from profiles/<round>_pmc_traffic.json and is reported only while the summary's
+    `source_sha1` equals the sha1 of csrc/*.hip + csrc/*.h; a kernel edit after the counter passes would silently turn the field into
+    null (VERDICT r3 #10).  This test makes that a failure instead: re-run tools/refresh_profiles_r04.sh after touching a kernel."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from tools.pmc_traffic import kernel_sources_sha1
+    sha = kernel_sources_sha1()
+    for name in (bench.PMC_TRAFFIC, bench.PMC_TRAFFIC_TRAIN):
+        path = os.path.join(ROOT, "profiles", name)
+        assert os.path.exists(path), path
+        d = json.load(open(path))
+        assert d["source_sha1"] == sha, f"{name} was collected on other kernel sources ({d['source_sha1'][:10]} vs {sha[:10]}): refresh it"
+        assert d["kernels"] and all(v["hbm_bytes_per_launch"] >= 0 for v in d["kernels"].values())

@@ -486,8 +486,11 @@ def test_trunk_with_the_last_tail_inside_the_average_pool_equals_the_two_launche
 def test_trunk_with_layer3_conv3_reevaluated_equals_the_stored_form(gpu_lib, training):
     """MHE_FUSE_RECOMPUTE256 (csrc/conv_fuse256.hip, round 4): layer3's blocks without conv3's raw output - bn3's statistics from the
     statistics-only launch of the resident-slab kernel (the same sums as the storing launch), conv3 evaluated again inside the tail kernel.
-    Same products in the same order, order-independent statistics: the encoder feature and the BatchNorm buffers equal the stored form's
-    BIT FOR BIT (hand/network.py:54-61,110).  B = 64 at 256 x 256: layer3 has 16,384 pixels, the smallest count the resident-slab kernel takes."""
+    Same products in the same order: with the running statistics (eval) the encoder feature equals the stored form's BIT FOR BIT; with batch
+    statistics the block outputs are still the same products, but the next conv1's statistics are summed over other per-thread groupings
+    than the residual-tail kernel's (f32 partial sums: a last bit of a scale, then a bf16 rounding, then 30 train-mode BatchNorms - the
+    amplification the other recompute tests document), so train mode is held to their band (hand/network.py:54-61,110).  B = 64 at
+    256 x 256: layer3 has 16,384 pixels, the smallest count the resident-slab kernel takes."""
     from mhentropy_amd import resnet
     sd = {k: torch.as_tensor(v) for k, v in synth.resnet_state(13, "resnet50").items()}
     x = torch.as_tensor(synth.batch(13, 8, image_size=256)[0]).cuda().repeat(8, 1, 1, 1)
@@ -509,4 +512,9 @@ def test_trunk_with_layer3_conv3_reevaluated_equals_the_stored_form(gpu_lib, tra
         outs.append((f, trunk.layer3[2].bn3.running_var.clone(), trunk.layer3[5].bn1.running_mean.clone()))
     assert used == [5, 0], used                  # the five tails inside layer3 (the one into layer4 has 512 outputs)
     for u, v in zip(outs[0], outs[1]):
-        assert torch.isfinite(u).all() and torch.equal(u, v), float((u.float() - v.float()).abs().max())
+        assert torch.isfinite(u).all()
+        if not training:
+            assert torch.equal(u, v), float((u.float() - v.float()).abs().max())
+        else:
+            d = ((u.float() - v.float()).abs().mean() / v.float().abs().mean()).item()
+            assert d < 2e-2, d
