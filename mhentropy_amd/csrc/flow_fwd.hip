@@ -38,7 +38,7 @@ struct Args {
 
 __device__ __forceinline__ float leaky(float v) { return fmaxf(v, 0.01f * v); }
 
-template <bool EMIT>
+template <bool EMIT, int SETS>
 __global__ __launch_bounds__(512) void couplings_frag_kernel(const Args a) {
     __shared__ uint4 act[KT * ROWS * 8];                  // 64 KiB: H1, then H2, as eight [64 rows][64 units] k-tiles (16-byte chunks swizzled)
     __shared__ uint4 xb[ROWS * 8];                        // the masked flow variable as a [64 rows][64 dims] bf16 operand tile
@@ -166,14 +166,15 @@ __global__ __launch_bounds__(512) void couplings_frag_kernel(const Args a) {
             float4 c1[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) c1[nt] = __builtin_bit_cast(float4, bld(condr, cq, (unsigned)((2 * net + 1) * H + nt * 16) * 4u));
-            uint4 fA[2][4], fB[2][4];
+            uint4 fS[SETS][2][4];                         // SETS - 1 k-tiles of W1 fragments in flight beside the one being multiplied
             auto fetch_w = [&](uint4 (&f)[2][4], int kt) __attribute__((always_inline)) {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) f[kk][nt] = frag(w1, lane16, 4 * wave + nt, 16, 2 * kt + kk);
             };
-            fetch_w(fA, 0);
+#pragma unroll
+            for (int k0 = 0; k0 < SETS - 1; ++k0) fetch_w(fS[k0], k0);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();                              // (B0) every wave is through the layer 2 before: act is free
             finish(c0, a.h1e, 0);
@@ -196,14 +197,10 @@ __global__ __launch_bounds__(512) void couplings_frag_kernel(const Args a) {
                 }
             };
 #pragma unroll
-            for (int p = 0; p < KT / 2; ++p) {
-                fetch_w(fB, 2 * p + 1);
+            for (int kt = 0; kt < KT; ++kt) {
+                if (kt + SETS - 1 < KT) fetch_w(fS[(kt + SETS - 1) % SETS], kt + SETS - 1);
                 __builtin_amdgcn_sched_barrier(0);
-                ktile(fA, 2 * p);
-                __builtin_amdgcn_sched_barrier(0);
-                if (p + 1 < KT / 2) fetch_w(fA, 2 * p + 2);
-                __builtin_amdgcn_sched_barrier(0);
-                ktile(fB, 2 * p + 1);
+                ktile(fS[kt % SETS], kt);
                 __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();                              // (B2) every wave has read H1: act is free for H2
@@ -304,7 +301,12 @@ extern "C" int mhe_flow_couplings_frag_bf16(const float *in, float *out, const f
     a.w0F = (const u16 *)w0F; a.w1F = (const u16 *)w1F; a.w2F = (const u16 *)w2F; a.w_stride = w_net_stride;
     a.h1e = (u16 *)h1; a.h2e = (u16 *)h2; a.oe = o; a.hbits = (uint2 *)sign_bits;
     a.R = R; a.B = B; a.dim = dim; a.ncoup = ncoup; a.cstride = cond_stride; a.inverse = direction == MHE_FLOW_INVERSE;
-    if (emit) hipLaunchKernelGGL(flowfwd::couplings_frag_kernel<true>, dim3(R / 64), dim3(512), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(flowfwd::couplings_frag_kernel<false>, dim3(R / 64), dim3(512), 0, (hipStream_t)stream, a);
+    // W1 register sets of the forward-only form: 3 = two k-tiles in flight (4 VGPRs spilled).  Measured at C2: 313.7 us (2) against 312.1 us (3) -
+    // the layer-1 stream is not latency-bound: 64 KiB per CU and k-tile at 75-90 GB/s per CU IS the L2 -> CU rate of this chip
+    // (MI355X_MICROARCH.md "Indexed rows": 66-73 GB/s per CU for rows served by the XCD's L2); the default stays 2
+    static const int sets = getenv("MHE_FLOW_W1_SETS") ? atoi(getenv("MHE_FLOW_W1_SETS")) : 2;
+    if (emit) hipLaunchKernelGGL((flowfwd::couplings_frag_kernel<true, 2>), dim3(R / 64), dim3(512), 0, (hipStream_t)stream, a);
+    else if (sets == 3) hipLaunchKernelGGL((flowfwd::couplings_frag_kernel<false, 3>), dim3(R / 64), dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((flowfwd::couplings_frag_kernel<false, 2>), dim3(R / 64), dim3(512), 0, (hipStream_t)stream, a);
     return check_launch("flowfwd::couplings_frag_kernel");
 }

@@ -880,3 +880,65 @@ def test_shortcut_reverse_on_gram_statistics_equals_the_pass_over_its_output(gpu
         spread = rel(gF2[pre + n], gF[pre + n])
         print(f"stem {n}: fold vs pass {rel(gF[pre + n], gP[pre + n]):.2e}, fold vs fold {spread:.2e}")
         assert spread == 0.0 and rel(gF[pre + n], gP[pre + n]) < tol, (n, rel(gF[pre + n], gP[pre + n]), spread)
+
+
+def test_resident_tile_3x3_kernel_in_the_train_step_equals_the_im2col_kernels(gpu_lib):
+    """layer2 / layer3's stride-1 3x3 units in the bf16 train step run on the resident-tile kernel (csrc/conv_halo.hip): forward with the
+    producer's BatchNorm + ReLU on its load (the normalised tensor written on the way for the weight gradient), data gradient in the
+    same kernel.  Against the im2col kernels + separate BatchNorm pass (conv_halo / conv_halo_dg = False) on the same inputs:
+      forward  whole steps of two trainers: the launch counts prove which path ran; the loss agrees to 5e-3 (1.7e-3 seen: the two forms sum a
+               tap's products in different orders and round y2 to bf16 from different f32 sums; B = 4 under 53 train-mode BatchNorms).  The
+               GRADIENTS of two different forwards are not comparable at this batch size (ReLU gates flip: 0.7 norm-wise in layer1) - the
+               forward kernel itself is compared layer by layer in test_gpu_modules.py;
+      reverse  two reverse passes over ONE forward tape, data gradients on the resident-tile kernel / on the im2col kernels: nothing
+               upstream of the first such unit changes at all, everything else at the bf16 level norm-wise."""
+    from mhentropy_amd import harness, ops
+    from mhentropy_amd.train import TrainStep
+    B, N = 4, 4
+    xn, yn = synth.batch(21, B, image_size=256)                     # layer2 at 32 x 32, layer3 at 16 x 16: the two widths the kernel takes
+    x, y = _dev(xn), {k: _dev(v) for k, v in yn.items()}
+    z0 = _dev(synth.noise(21, N * B))
+    calls = {"fwd": 0, "dg": 0}
+    f0 = ops.conv3x3_halo
+    def spy(*a, **k):                                                # (the data gradient is the same entry with the ReLU gate's tensor as mask=)
+        calls["dg" if k.get("mask") is not None else "fwd"] += 1
+        return f0(*a, **k)
+    ops.conv3x3_halo = spy
+    try:
+        res = {}
+        for mode, on in (("halo", True), ("im2col", False), ("halo again", True)):
+            torch.manual_seed(5)
+            model = harness.build_mhent(backbone="resnet50", h_dims=(64, 64), num_steps=1, tables=synth.mano_tables(0), compute_dtype=torch.bfloat16).cuda().train()
+            ts = TrainStep(model, lr=0.0)
+            ts.conv_halo = ts.conv_halo_dg = on
+            calls["fwd"] = calls["dg"] = 0
+            out = ts.forward_backward(x, y, noise=z0, N=N)
+            res[mode] = (float(out["total"]), {n: ts.grad_of(p).clone() for n, p in model.named_parameters()}, dict(calls))
+        # 3 + 5 stride-1 units of layer2 / layer3 (the first block of a stage has the stride-2 unit)
+        assert res["halo"][2] == {"fwd": 8, "dg": 8} and res["im2col"][2] == {"fwd": 0, "dg": 0}, (res["halo"][2], res["im2col"][2])
+        assert res["halo again"][0] == res["halo"][0] and all(torch.equal(res["halo again"][1][n], g) for n, g in res["halo"][1].items())
+        assert abs(res["halo"][0] - res["im2col"][0]) <= 5e-3 * abs(res["im2col"][0]), (res["halo"][0], res["im2col"][0])
+        # ---- reverse: one tape (the last trainer's: resident-tile forward), two reverse passes
+        ts.forward(x, y, noise=z0, N=N)
+        rev = {}
+        for mode, on in (("halo", True), ("im2col", False)):
+            ts.conv_halo_dg = on
+            calls["dg"] = 0
+            ts.backward()
+            rev[mode] = ({n: ts.grad_of(p).clone() for n, p in model.named_parameters()}, calls["dg"])
+    finally:
+        ops.conv3x3_halo = f0
+    assert rev["halo"][1] == 8 and rev["im2col"][1] == 0, (rev["halo"][1], rev["im2col"][1])
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+    gH, gI = rev["halo"][0], rev["im2col"][0]
+    pre = "feat_extractor.res."
+    for n in ("layer4.0.conv1.weight", "layer4.2.conv3.weight", "layer3.5.conv3.weight", "layer3.5.bn3.weight", "layer3.5.conv2.weight"):
+        assert torch.equal(gH[pre + n], gI[pre + n]), n              # upstream of (and at: its weight gradient reads the same gy) the first such unit
+    names = [n for n in gI if n.startswith(pre) and gI[n].abs().max() > 0]
+    errs = sorted((rel(gH[n], gI[n]), n) for n in names)
+    layers = [e for e in errs if ".layer" in e[1]]
+    assert layers[-1][0] < 8e-2 and layers[len(layers) // 2][0] < 2e-2, (layers[-3:], layers[len(layers) // 2])
+    # the stem's BatchNorm sits behind the max pool's reverse: its bias gradient is a nearly cancelling sum of 4 M gated elements (0.5 seen, the
+    # same figure as in the shortcut test above), its weight gradient 6.5e-2
+    stem = [e for e in errs if ".layer" not in e[1]]
+    assert all(e[0] < (1.0 if e[1].endswith("res.bn1.bias") else 1.5e-1) for e in stem), stem
