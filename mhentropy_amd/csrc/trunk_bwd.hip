@@ -6,6 +6,7 @@
 //
 // All of these are HBM-bound elementwise / reduction passes; algorithmic bytes are the tensors they name.
 #include "common.h"
+#include <cstdlib>
 
 namespace mhe { namespace tb {
 constexpr int NSH = fx::NSH;  // statistic shards, as the forward's (conv.hip)
@@ -235,6 +236,37 @@ template <> struct Lane<u16> {
     static __device__ __forceinline__ float stored(float v) { return __uint_as_float((unsigned)f32_to_bf16(v) << 16); }     // the value a bf16 tensor would hold
 };
 
+// bn_bwd_apply_kernel on 16-byte lanes (bf16: eight elements per thread; the four-element form moved 8 bytes per lane - the 8-byte
+// accesses run at 0.54-0.70 of the 16-byte rate on this chip, MI355X_MICROARCH.md - and took a 64-bit modulo per element group): the channel
+// chunk of a thread does not change along its walk (the grid's stride is a multiple of 2048 elements >= C, C a power of two or a divisor of
+// the stride: checked by the launcher), so the three coefficient rows are read once.  Same arithmetic, same results.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_wide_kernel(const T *__restrict__ g, const T *__restrict__ a, const T *__restrict__ y,
+                                                                const float *__restrict__ coef, T *__restrict__ gy, T *__restrict__ g_masked, size_t nl, int C) {
+    constexpr int E = Lane<T>::E;
+    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)((i0 * E) % (size_t)C);
+    float k2[E], k1[E], k0[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) { k2[k] = coef[c + k]; k1[k] = coef[C + c + k]; k0[k] = coef[2 * C + c + k]; }
+    for (size_t i = i0; i < nl; i += (size_t)gridDim.x * 256) {
+        const size_t e = i * E;
+        float gv[E], yv[E], o[E];
+        Lane<T>::get(g + e, gv);
+        Lane<T>::get(y + e, yv);
+        if (a) {
+            float av[E];
+            Lane<T>::get(a + e, av);
+#pragma unroll
+            for (int k = 0; k < E; ++k) gv[k] = av[k] > 0.f ? gv[k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < E; ++k) o[k] = fmaf(k2[k], gv[k], fmaf(k1[k], yv[k], k0[k]));
+        Lane<T>::put(gy + e, o);
+        if (g_masked) Lane<T>::put(g_masked + e, gv);
+    }
+}
+
 // y = maxpool3x3s2(relu(x * scale + shift)) and the winning tap; the comparison runs on the values as a stored activation would hold them
 // (bf16-rounded for T = u16), first maximum in scan order - the same winners as maxpool_idx_kernel on the materialised activation
 template <typename T>
@@ -309,40 +341,45 @@ __global__ __launch_bounds__(256) void maxpool_bwd_bn_kernel(const T *__restrict
     float k2[E], k1[E], k0[E];
 #pragma unroll
     for (int k = 0; k < E; ++k) { k2[k] = coef ? coef[c + k] : 0.f; k1[k] = coef ? coef[C + c + k] : 0.f; k0[k] = coef ? coef[2 * C + c + k] : 0.f; }
+    // (power-of-two maps - the stem's 128 x 128 - take shifts instead of three integer divisions per element group; the second window row
+    // exists for odd h only, which is uniform over a wave: 8 threads share a pixel and a wave's 8 / 16 pixels lie in one row)
+    const bool p2 = !(W & (W - 1)) && !(H & (H - 1)) && !(cpp & (cpp - 1));
+    const int cs = __ffs(cpp) - 1, wsh = __ffs(W) - 1, hsh = __ffs(H) - 1;
     for (unsigned i = blockIdx.x * blockDim.x + tid; i < n; i += gridDim.x * blockDim.x) {
-        unsigned t = i / cpp;
-        const int w = (int)(t % W); t /= W;
-        const int h = (int)(t % H);
-        const int b = (int)(t / H);
+        int w, h, b;
+        if (p2) { const unsigned t = i >> cs; w = (int)(t & (unsigned)(W - 1)); h = (int)((t >> wsh) & (unsigned)(H - 1)); b = (int)(t >> (wsh + hsh)); }
+        else { unsigned t = i / cpp; w = (int)(t % W); t /= W; h = (int)(t % H); b = (int)(t / H); }
         // windows (ho, wo) containing (h, w): ho in {h / 2, (h + 1) / 2}, the second one only for odd h (and inside the pooled grid)
-        float g[4][E];
-        unsigned a0[4], a1[4], tap[4];
-        bool ok[4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                const int ho = (h + u) / 2, wo = (w + v) / 2;
-                const int j = 2 * u + v;
-                ok[j] = (u == 0 || (h & 1)) && (v == 0 || (w & 1)) && ho < Ho && wo < Wo;
-                tap[j] = (unsigned)((h - (2 * ho - 1)) * 3 + (w - (2 * wo - 1)));
-                const size_t o = (((size_t)b * Ho + (ho < Ho ? ho : Ho - 1)) * Wo + (wo < Wo ? wo : Wo - 1)) * C + c;
-                Lane<T>::get(gy + o, g[j]);
-                if constexpr (E == 8) { const uint2 r = *reinterpret_cast<const uint2 *>(idx + o); a0[j] = r.x; a1[j] = r.y; }
-                else { a0[j] = *reinterpret_cast<const unsigned *>(idx + o); a1[j] = 0; }
-            }
         const size_t e = (size_t)i * E;
         float yv[E], acc[E];
         Lane<T>::get(y + e, yv);
 #pragma unroll
         for (int k = 0; k < E; ++k) acc[k] = 0.f;
+        // the windows of one row, in the order (u, 0), (u, 1): loads first, then the adds (the order the sums have always had)
+        auto window_row = [&](int u) __attribute__((always_inline)) {
+            float g[2][E];
+            unsigned a0[2], a1[2], tap[2];
+            bool ok[2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int k = 0; k < E; ++k) {
-                const unsigned am = ((k < 4 ? a0[j] : a1[j]) >> (8 * (k & 3))) & 0xffu;
-                acc[k] += (ok[j] && am == tap[j]) ? g[j][k] : 0.f;
+            for (int v = 0; v < 2; ++v) {
+                const int ho = (h + u) / 2, wo = (w + v) / 2;
+                ok[v] = (v == 0 || (w & 1)) && ho < Ho && wo < Wo;
+                tap[v] = (unsigned)((h - (2 * ho - 1)) * 3 + (w - (2 * wo - 1)));
+                const size_t o = (((size_t)b * Ho + (ho < Ho ? ho : Ho - 1)) * Wo + (wo < Wo ? wo : Wo - 1)) * C + c;
+                Lane<T>::get(gy + o, g[v]);
+                if constexpr (E == 8) { const uint2 r = *reinterpret_cast<const uint2 *>(idx + o); a0[v] = r.x; a1[v] = r.y; }
+                else { a0[v] = *reinterpret_cast<const unsigned *>(idx + o); a1[v] = 0; }
             }
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+                for (int k = 0; k < E; ++k) {
+                    const unsigned am = ((k < 4 ? a0[v] : a1[v]) >> (8 * (k & 3))) & 0xffu;
+                    acc[k] += (ok[v] && am == tap[v]) ? g[v][k] : 0.f;
+                }
+        };
+        window_row(0);
+        if (h & 1) window_row(1);
 #pragma unroll
         for (int k = 0; k < E; ++k) {
             const bool on = Lane<T>::stored(fmaxf(fmaf(yv[k], sc[k], sf[k]), 0.f)) > 0.f;
@@ -509,6 +546,20 @@ extern "C" int mhe_bn_bwd_apply_nhwc(const void *g, const void *a, const void *y
                                      long P, int C, int dtype, void *stream) {
     MHE_REQUIRE(g && y && coef && gy && P > 0 && C > 0 && C % 4 == 0, "mhe_bn_bwd_apply_nhwc: bad arguments");
     const size_t n4 = (size_t)P * C / 4;
+    // 16-byte lanes where a thread's channel chunk is the same at every step of its walk (stride = blocks * 256 lanes, a multiple of C / E)
+    const int E = dtype == MHE_F32 ? 4 : 8;
+    const size_t nl = (size_t)P * C / E;
+    static const int wide_env = getenv("MHE_BN_BWD_APPLY_WIDE") ? atoi(getenv("MHE_BN_BWD_APPLY_WIDE")) : 1;
+    if (wide_env && C % E == 0 && ((size_t)ewg(nl) * 256) % (size_t)(C / E) == 0 &&
+        ((uintptr_t)g | (uintptr_t)a | (uintptr_t)y | (uintptr_t)gy | (uintptr_t)g_masked) % 16 == 0) {
+        if (dtype == MHE_F32)
+            hipLaunchKernelGGL(tb::bn_bwd_apply_wide_kernel<float>, dim3(ewg(nl)), dim3(256), 0, (hipStream_t)stream, (const float *)g, (const float *)a,
+                               (const float *)y, coef, (float *)gy, (float *)g_masked, nl, C);
+        else
+            hipLaunchKernelGGL(tb::bn_bwd_apply_wide_kernel<u16>, dim3(ewg(nl)), dim3(256), 0, (hipStream_t)stream, (const u16 *)g, (const u16 *)a,
+                               (const u16 *)y, coef, (u16 *)gy, (u16 *)g_masked, nl, C);
+        return check_launch("bn_bwd_apply_wide_kernel");
+    }
     if (dtype == MHE_F32)
         hipLaunchKernelGGL(tb::bn_bwd_apply_kernel<float>, dim3(ewg(n4)), dim3(256), 0, (hipStream_t)stream, (const float *)g,
                            (const float *)a, (const float *)y, coef, (float *)gy, (float *)g_masked, n4, C);
