@@ -1120,8 +1120,9 @@ extern "C" int mhe_bn_act_nhwc(const void *x, const float *scale, const float *s
                                int dtype, void *stream) {
     MHE_REQUIRE(x && scale && shift && y && P > 0 && C > 0 && C % 4 == 0, "mhe_bn_act_nhwc: bad arguments");
     const size_t n4 = (size_t)P * C / 4;
-    // (a 16-byte-lane form with the scale / shift rows read once per thread was built in round 4 and measured SLOWER in the train step:
-    // 25.57 -> 25.77 ms over its 18 launches, twice; the same change to bn_bwd_apply_kernel gave -0.04 ms - profiles/EXPERIMENTS.md)
+    // (16-byte-lane forms with the scale / shift rows read once per thread were built in round 4 and measured SLOWER: one piece per thread
+    // 25.57 -> 25.77 ms in the train step over its 18 launches, twice; four pieces per thread in flight on the small tensors 27 us against
+    // 15 us for 67 MB - while the same two changes took bn_bwd_apply_kernel from 39 to 21-26 us per 100 MB: profiles/EXPERIMENTS.md)
     if (dtype == MHE_F32)
         hipLaunchKernelGGL(conv::bn_act_kernel<float>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream,
                            (const float *)x, scale, shift, (const float *)res, res_scale, res_shift, (float *)y, n4, C, relu);

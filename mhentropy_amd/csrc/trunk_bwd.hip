@@ -217,16 +217,17 @@ template <> struct Lane<float> {
     static constexpr int E = 4;
     static __device__ __forceinline__ void get(const float *p, float *v) { const float4 r = *reinterpret_cast<const float4 *>(p); v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w; }
     static __device__ __forceinline__ void put(float *p, const float *v) { *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+    static __device__ __forceinline__ void unpack(uint4 r, float *v) { v[0] = __uint_as_float(r.x); v[1] = __uint_as_float(r.y); v[2] = __uint_as_float(r.z); v[3] = __uint_as_float(r.w); }
     static __device__ __forceinline__ float stored(float v) { return v; }
 };
 template <> struct Lane<u16> {
     static constexpr int E = 8;
-    static __device__ __forceinline__ void get(const u16 *p, float *v) {
-        const uint4 r = *reinterpret_cast<const uint4 *>(p);
+    static __device__ __forceinline__ void unpack(uint4 r, float *v) {
         const unsigned in[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(in[i] << 16); v[2 * i + 1] = __uint_as_float(in[i] & 0xffff0000u); }
     }
+    static __device__ __forceinline__ void get(const u16 *p, float *v) { unpack(*reinterpret_cast<const uint4 *>(p), v); }
     static __device__ __forceinline__ void put(u16 *p, const float *v) {
         unsigned o[4];
 #pragma unroll
@@ -240,7 +241,7 @@ template <> struct Lane<u16> {
 // accesses run at 0.54-0.70 of the 16-byte rate on this chip, MI355X_MICROARCH.md - and took a 64-bit modulo per element group): the channel
 // chunk of a thread does not change along its walk (the grid's stride is a multiple of 2048 elements >= C, C a power of two or a divisor of
 // the stride: checked by the launcher), so the three coefficient rows are read once.  Same arithmetic, same results.
-template <typename T>
+template <typename T, int U>
 __global__ __launch_bounds__(256) void bn_bwd_apply_wide_kernel(const T *__restrict__ g, const T *__restrict__ a, const T *__restrict__ y,
                                                                 const float *__restrict__ coef, T *__restrict__ gy, T *__restrict__ g_masked, size_t nl, int C) {
     constexpr int E = Lane<T>::E;
@@ -249,21 +250,37 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_wide_kernel(const T *__restr
     float k2[E], k1[E], k0[E];
 #pragma unroll
     for (int k = 0; k < E; ++k) { k2[k] = coef[c + k]; k1[k] = coef[C + c + k]; k0[k] = coef[2 * C + c + k]; }
-    for (size_t i = i0; i < nl; i += (size_t)gridDim.x * 256) {
-        const size_t e = i * E;
-        float gv[E], yv[E], o[E];
-        Lane<T>::get(g + e, gv);
-        Lane<T>::get(y + e, yv);
-        if (a) {
-            float av[E];
-            Lane<T>::get(a + e, av);
+    // U 16-byte pieces per thread and tensor in flight.  U = 4 for the 33 / 17 MB tensors of layer3 / layer4: with one piece per thread a launch
+    // was four dependent load -> store rounds of workgroups per CU (100 MB in 39 us = 2.6 TB/s; 21-26 us with four).  U = 1 for the large
+    // tensors (eight waves per SIMD carry the latency there: 5.6-6.3 TB/s, 5-10 % slower with U = 4 at half the occupancy)
+    const size_t S = (size_t)gridDim.x * 256;
+    for (size_t i = i0; i < nl; i += U * S) {
+        uint4 rg[U], ry[U], ra[U];
 #pragma unroll
-            for (int k = 0; k < E; ++k) gv[k] = av[k] > 0.f ? gv[k] : 0.f;
+        for (int u = 0; u < U; ++u) {
+            const size_t j = i + u * S < nl ? i + u * S : i;                               // (past the end: a harmless re-read, never stored)
+            rg[u] = reinterpret_cast<const uint4 *>(g)[j];
+            ry[u] = reinterpret_cast<const uint4 *>(y)[j];
+            if (a) ra[u] = reinterpret_cast<const uint4 *>(a)[j];
         }
 #pragma unroll
-        for (int k = 0; k < E; ++k) o[k] = fmaf(k2[k], gv[k], fmaf(k1[k], yv[k], k0[k]));
-        Lane<T>::put(gy + e, o);
-        if (g_masked) Lane<T>::put(g_masked + e, gv);
+        for (int u = 0; u < U; ++u) {
+            if (i + u * S >= nl) break;
+            float gv[E], yv[E], o[E];
+            Lane<T>::unpack(rg[u], gv);
+            Lane<T>::unpack(ry[u], yv);
+            if (a) {
+                float av[E];
+                Lane<T>::unpack(ra[u], av);
+#pragma unroll
+                for (int k = 0; k < E; ++k) gv[k] = av[k] > 0.f ? gv[k] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < E; ++k) o[k] = fmaf(k2[k], gv[k], fmaf(k1[k], yv[k], k0[k]));
+            const size_t e = (i + u * S) * E;
+            Lane<T>::put(gy + e, o);
+            if (g_masked) Lane<T>::put(g_masked + e, gv);
+        }
     }
 }
 
@@ -550,14 +567,15 @@ extern "C" int mhe_bn_bwd_apply_nhwc(const void *g, const void *a, const void *y
     const int E = dtype == MHE_F32 ? 4 : 8;
     const size_t nl = (size_t)P * C / E;
     static const int wide_env = getenv("MHE_BN_BWD_APPLY_WIDE") ? atoi(getenv("MHE_BN_BWD_APPLY_WIDE")) : 1;
-    if (wide_env && C % E == 0 && ((size_t)ewg(nl) * 256) % (size_t)(C / E) == 0 &&
+    const bool deep = nl * 16 <= ((size_t)80 << 20);                  // up to 80 MB per tensor: four 16-byte pieces per thread and tensor in flight
+    const unsigned wblocks = ewg(deep ? (nl + 3) / 4 : nl);
+    if (wide_env && C % E == 0 && ((size_t)wblocks * 256) % (size_t)(C / E) == 0 &&
         ((uintptr_t)g | (uintptr_t)a | (uintptr_t)y | (uintptr_t)gy | (uintptr_t)g_masked) % 16 == 0) {
-        if (dtype == MHE_F32)
-            hipLaunchKernelGGL(tb::bn_bwd_apply_wide_kernel<float>, dim3(ewg(nl)), dim3(256), 0, (hipStream_t)stream, (const float *)g, (const float *)a,
-                               (const float *)y, coef, (float *)gy, (float *)g_masked, nl, C);
-        else
-            hipLaunchKernelGGL(tb::bn_bwd_apply_wide_kernel<u16>, dim3(ewg(nl)), dim3(256), 0, (hipStream_t)stream, (const u16 *)g, (const u16 *)a,
-                               (const u16 *)y, coef, (u16 *)gy, (u16 *)g_masked, nl, C);
+#define MHE_APPLY_WIDE(T, U) hipLaunchKernelGGL((tb::bn_bwd_apply_wide_kernel<T, U>), dim3(wblocks), dim3(256), 0, (hipStream_t)stream, (const T *)g, (const T *)a, \
+                                                (const T *)y, coef, (T *)gy, (T *)g_masked, nl, C)
+        if (dtype == MHE_F32) { if (deep) MHE_APPLY_WIDE(float, 4); else MHE_APPLY_WIDE(float, 1); }
+        else { if (deep) MHE_APPLY_WIDE(u16, 4); else MHE_APPLY_WIDE(u16, 1); }
+#undef MHE_APPLY_WIDE
         return check_launch("bn_bwd_apply_wide_kernel");
     }
     if (dtype == MHE_F32)

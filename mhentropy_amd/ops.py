@@ -884,8 +884,9 @@ def bn_act(x, scale, shift, res=None, res_scale=None, res_shift=None, relu=True,
     Cn = x.shape[-1]
     P = x.numel() // Cn
     y = out if out is not None else torch.empty_like(x)
-    check(_lib.lib().mhe_bn_act_nhwc(_ptr(x), _ptr(scale), _ptr(shift), _ptr(res), _ptr(res_scale), _ptr(res_shift),
-                                     _ptr(y), P, Cn, int(relu), dtype_code(x.dtype), _stream()), "mhe_bn_act_nhwc")
+    with _Timed(lambda: "mhe::conv::bn_act_kernel<%s>" % ("float" if x.dtype == torch.float32 else "unsigned short"), 0.0, x.element_size() * x.numel() * (2 + (res is not None))):
+        check(_lib.lib().mhe_bn_act_nhwc(_ptr(x), _ptr(scale), _ptr(shift), _ptr(res), _ptr(res_scale), _ptr(res_shift),
+                                         _ptr(y), P, Cn, int(relu), dtype_code(x.dtype), _stream()), "mhe_bn_act_nhwc")
     return y
 
 
@@ -1265,7 +1266,8 @@ def bn_backward(g, a, y, mean_invstd, gamma, stats, dgamma, dbeta, want_masked=F
         return coef
     gy = out if out is not None else torch.empty_like(y)
     gm = torch.empty_like(y) if want_masked else None
-    check(L.mhe_bn_bwd_apply_nhwc(_ptr(g), _ptr(a), _ptr(y), _ptr(coef), _ptr(gy), _ptr(gm), P, Cc, dtype_code(dt), _stream()), "mhe_bn_bwd_apply_nhwc")
+    with _Timed(lambda: "mhe::tb::bn_bwd_apply_wide_kernel<%s, %d>" % ("float" if dt == torch.float32 else "unsigned short", 4 if y.numel() * y.element_size() <= (80 << 20) else 1), 0.0, y.element_size() * y.numel() * (3 + (a is not None) + (gm is not None))):
+        check(L.mhe_bn_bwd_apply_nhwc(_ptr(g), _ptr(a), _ptr(y), _ptr(coef), _ptr(gy), _ptr(gm), P, Cc, dtype_code(dt), _stream()), "mhe_bn_bwd_apply_nhwc")
     return (gy, gm) if want_masked else gy
 
 
