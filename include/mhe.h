@@ -259,10 +259,12 @@ int mhe_conv1x1_stats_nhwc(const mhe_conv_desc *d, const void *x, const void *w,
                            mhe_stat_t *stats, void *stream);
 /* ... and cheaper still: the same batch statistics from the moments of the convolution's INPUT.  For y = W a:  sum_p y_c = w_c . m,
  * sum_p y_c^2 = w_c^T G w_c  with m = sum_p a_p and G = sum_p a_p a_p^T (Cb x Cb) - 8x / 4x fewer multiply-adds than the product and no
- * per-output-element work.  mhe_conv1x1_gram_nhwc accumulates G and m of a = relu?(x * in_scale + in_shift) (rounded to bf16, the operand
- * conv3 multiplies) into `gram`, mhe_gram_stats_words(Cb) fixed-point words (one-word form, quantum 2^-20) (sharded; zeroed by the caller once - mhe_gram_bn_finalize clears what it
- * read); mhe_gram_bn_finalize turns them into bn's affine like mhe_bn_finalize_step (w = the packed [C][Cb] bf16 weights; workspace =
- * mhe_gram_stats_workspace_bytes(Cb) bytes).  Statistics of the f32 products (not of bf16-rounded outputs). */
+ * per-output-element work.  mhe_conv1x1_gram_nhwc WRITES G and m of a = relu?(x * in_scale + in_shift) (rounded to bf16, the operand
+ * conv3 multiplies) into `gram`, a workspace of mhe_gram_stats_words(Cb) 8-byte words: a count word, then one f32 partial slab per workgroup
+ * of the launch (plain stores - nothing to zero, nothing to clear; ONE launch per finalize); mhe_gram_bn_finalize sums the slabs in slab
+ * order in f64 (the totals do not depend on the order the workgroups finish in) and turns them into bn's affine like mhe_bn_finalize_step
+ * (w = the packed [C][Cb] bf16 weights; workspace = mhe_gram_stats_workspace_bytes(Cb) bytes, left holding the f64 totals [Cb][Cb] | [Cb]).
+ * Statistics of the f32 products (not of bf16-rounded outputs). */
 size_t mhe_gram_stats_words(int Cb);
 size_t mhe_gram_stats_workspace_bytes(int Cb);
 int mhe_conv1x1_gram_nhwc(const void *x, const float *in_scale, const float *in_shift, int relu_in, mhe_stat_t *gram, long pixels, int Cb,

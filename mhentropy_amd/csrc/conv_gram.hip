@@ -12,9 +12,11 @@
 // reference's f32 arithmetic, different from the unfused path by the rounding noise of the sums (~1e-4 of the variance).
 //   gram_kernel     : persistent workgroups, 128-pixel tiles register-staged into a double-buffered LDS image ([pixel][channel] rows, 64-byte
 //                     segments XOR-swizzled as in wgrad.hip), G accumulated on v_mfma_f32_32x32x16_bf16 from transposing reads
-//                     (ds_read_b64_tr_b16) over the workgroup's whole life, one round of fixed-point integer atomics (common.h, fx::add1: the totals
-//                     do not depend on the order the workgroups arrive in) into a shard at the end;
-//   gram_combine    : shards -> f64 totals (and clears the shards: the arena is clean for the next step);
+//                     (ds_read_b64_tr_b16) over the workgroup's whole life; at the end the workgroup STORES its partial G and m (f32) as slab
+//                     blockIdx of the workspace - no atomics (up to round 3: f32 atomics into 16 shards, order-dependent; round 4 first:
+//                     one round of Cb^2 64-bit fixed-point atomics per workgroup, 10-20 us of a 35-50 us launch);
+//   gram_combine    : slabs -> f64 totals, summed in slab order: the totals do not depend on the order the workgroups finish in, and
+//                     nothing has to be zeroed or cleared (a launch overwrites its slabs and records how many it wrote);
 //   gram_finalize   : one wave per output channel: w^T G w and w . m in f64 -> mean, variance -> scale / shift (+ running statistics).
 #include "conv_shared.h"
 #include <cstdlib>
@@ -26,17 +28,17 @@ typedef short v4s __attribute__((ext_vector_type(4)));
 typedef short v8s __attribute__((ext_vector_type(8)));
 typedef __attribute__((ext_vector_type(8))) __bf16 bf8g;
 typedef __attribute__((address_space(3))) v4s lds_v4s;
-constexpr int GSH = 16;                   // Gram accumulator shards (workgroup b adds into shard b % GSH)
+constexpr int GMAXWG = 512;               // most workgroups (= partial slabs) of a launch
 constexpr int GPX = 128;                  // pixels per tile
 __device__ __forceinline__ int gseg_swz(int pitch, int row) { return pitch >= 256 ? (row & 3) : ((row >> 1) & 1); }
 }
 
 template <int CB>
 __global__ __launch_bounds__(256) void gram_kernel(const u16 *__restrict__ x, const float *__restrict__ in_scale, const float *__restrict__ in_shift,
-                                                   fx::acc_t *__restrict__ gram, int M, int relu, u16 *__restrict__ a_out) {
+                                                   float *__restrict__ gram, int M, int relu, u16 *__restrict__ a_out) {
     constexpr int PA = CB * 2, CPR = CB / 8, RPP = 256 / CPR, NJ = GPX / RPP;      // row pitch (bytes), 16-byte chunks per row, rows per pass, passes
     constexpr int TW = CB / 64;                                                    // 32 x 32 tiles per wave and dimension (waves 2 x 2)
-    constexpr int GE = CB * CB + CB;                                               // floats per shard: G then m
+    constexpr int GE = CB * CB + CB;                                               // floats per slab: G then m
     __shared__ __attribute__((aligned(1024))) char tile[2][GPX * PA];
     __shared__ float red[256 * 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -129,7 +131,8 @@ __global__ __launch_bounds__(256) void gram_kernel(const u16 *__restrict__ x, co
             products(1);
         }
     }
-    fx::acc_t *dst = gram + (size_t)((int)blockIdx.x % GSH) * GE;
+    if (blockIdx.x == 0 && tid == 0) reinterpret_cast<int *>(gram)[0] = (int)gridDim.x;      // slabs written by this launch (gram_combine)
+    float *dst = gram + 2 + (size_t)blockIdx.x * GE;
 #pragma unroll
     for (int i = 0; i < TW; ++i)
 #pragma unroll
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const u16 *__restrict__ x, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = (wm * TW + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                fx::add1(dst + m * CB + n, acc[i][j][r]);
+                dst[m * CB + n] = acc[i][j][r];
             }
         }
     // column sums: RPP threads share a channel chunk
@@ -150,19 +153,24 @@ __global__ __launch_bounds__(256) void gram_kernel(const u16 *__restrict__ x, co
         const int c8 = tid >> 3, e = tid & 7;
         float a = 0.f;
         for (int k = 0; k < RPP; ++k) a += red[(c8 + CPR * k) * 8 + e];
-        fx::add1(dst + CB * CB + tid, a);
+        dst[CB * CB + tid] = a;
     }
 }
 
-// totals in f64; the shards are cleared on the way (self-cleaning accumulators)
-__global__ __launch_bounds__(256) void gram_combine_kernel(fx::acc_t *__restrict__ gram, double *__restrict__ tot, int ge) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= ge) return;
-    fx::acc_t a = 0;
-    bool bad = false;
-#pragma unroll
-    for (int s = 0; s < GSH; ++s) { const fx::acc_t w = gram[(size_t)s * ge + e]; bad |= fx::marked(w); a += w; gram[(size_t)s * ge + e] = 0; }
-    tot[e] = bad ? __builtin_nan("") : fx::value1(a);
+// totals in f64: entry e = sum over the launch's slabs in slab order (four slab lanes per entry, folded in lane order: a fixed order)
+__global__ __launch_bounds__(256) void gram_combine_kernel(const float *__restrict__ gram, double *__restrict__ tot, int ge) {
+    __shared__ double part[256];
+    const int el = threadIdx.x & 63, zl = threadIdx.x >> 6, e = blockIdx.x * 64 + el;
+    const int n = reinterpret_cast<const int *>(gram)[0];
+    double a = 0.0;
+    if (e < ge) {
+        const float *src = gram + 2 + e;
+#pragma unroll 8
+        for (int b = zl; b < n; b += 4) a += (double)src[(size_t)b * ge];
+    }
+    part[threadIdx.x] = a;
+    __syncthreads();
+    if (zl == 0 && e < ge) tot[e] = ((part[el] + part[64 + el]) + part[128 + el]) + part[192 + el];
 }
 
 // one wave per output channel c: q = w^T G w, s = w . m in f64 -> the BatchNorm affine (torch semantics, as bn_finalize_kernel)
@@ -207,7 +215,8 @@ __global__ __launch_bounds__(256) void gram_finalize_kernel(const double *__rest
 
 using namespace mhe;
 
-extern "C" size_t mhe_gram_stats_words(int Cb) { return (Cb == 64 || Cb == 128) ? (size_t)conv::GSH * ((size_t)Cb * Cb + Cb) : 0; }
+// 8-byte words of the partial-slab workspace: a count word, then GMAXWG slabs of Cb^2 + Cb floats
+extern "C" size_t mhe_gram_stats_words(int Cb) { return (Cb == 64 || Cb == 128) ? 1 + ((size_t)conv::GMAXWG * ((size_t)Cb * Cb + Cb) + 1) / 2 : 0; }
 extern "C" size_t mhe_gram_stats_workspace_bytes(int Cb) { return (Cb == 64 || Cb == 128) ? ((size_t)Cb * Cb + Cb) * sizeof(double) : 0; }
 
 extern "C" int mhe_conv1x1_gram_nhwc(const void *x, const float *in_scale, const float *in_shift, int relu_in, mhe_stat_t *gram, long pixels, int Cb,
@@ -221,14 +230,15 @@ extern "C" int mhe_conv1x1_gram_store_nhwc(const void *x, const float *in_scale,
                 "mhe_conv1x1_gram_nhwc: bf16 rows of 64 / 128 channels, pixel count a multiple of %d (pixels=%ld Cb=%d)", conv::GPX, pixels, Cb);
     MHE_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "mhe_conv1x1_gram_nhwc: in_scale/in_shift must come together");
     const int ntiles = (int)(pixels / conv::GPX);
-    // one workgroup per CU (MHE_GRAM_PER_CU: 3 / 2 up to round 3, when the shard adds were f32): a workgroup ends with Cb^2 + Cb 64-bit integer
-    // atomics whatever it has summed, and with two tiles in flight per workgroup the second resident workgroup no longer hides anything
+    // workgroups = partial slabs (a workgroup ends with Cb^2 + Cb plain stores whatever it has summed)
     static const int wgs64 = getenv("MHE_GRAM_WGS_64") ? atoi(getenv("MHE_GRAM_WGS_64")) : 512;
-    static const int wgs128 = getenv("MHE_GRAM_WGS_128") ? atoi(getenv("MHE_GRAM_WGS_128")) : 192;
-    const int want = Cb == 64 ? wgs64 : wgs128;
+    static const int wgs128 = getenv("MHE_GRAM_WGS_128") ? atoi(getenv("MHE_GRAM_WGS_128")) : 256;
+    int want = Cb == 64 ? wgs64 : wgs128;
+    if (want < 1) want = 1;
+    if (want > conv::GMAXWG) want = conv::GMAXWG;
     const dim3 grid((unsigned)(ntiles < want ? ntiles : want));
-    if (Cb == 64) hipLaunchKernelGGL(conv::gram_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, (const u16 *)x, in_scale, in_shift, gram, (int)pixels, relu_in, (u16 *)a_out);
-    else hipLaunchKernelGGL(conv::gram_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, (const u16 *)x, in_scale, in_shift, gram, (int)pixels, relu_in, (u16 *)a_out);
+    if (Cb == 64) hipLaunchKernelGGL(conv::gram_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, (const u16 *)x, in_scale, in_shift, (float *)gram, (int)pixels, relu_in, (u16 *)a_out);
+    else hipLaunchKernelGGL(conv::gram_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, (const u16 *)x, in_scale, in_shift, (float *)gram, (int)pixels, relu_in, (u16 *)a_out);
     return check_launch("gram_kernel");
 }
 
@@ -238,7 +248,7 @@ extern "C" int mhe_gram_bn_finalize(mhe_stat_t *gram, void *workspace, const voi
     MHE_REQUIRE(gram && workspace && w && gamma && beta && scale && shift && C > 0 && (Cb == 64 || Cb == 128) && count > 1.f,
                 "mhe_gram_bn_finalize: bad arguments");
     const int ge = Cb * Cb + Cb;
-    hipLaunchKernelGGL(conv::gram_combine_kernel, dim3((ge + 255) / 256), dim3(256), 0, (hipStream_t)stream, gram, (double *)workspace, ge);
+    hipLaunchKernelGGL(conv::gram_combine_kernel, dim3((ge + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const float *)gram, (double *)workspace, ge);
     if (int rc = check_launch("gram_combine_kernel")) return rc;
     if (Cb == 64)
         hipLaunchKernelGGL(conv::gram_finalize_kernel<64>, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const double *)workspace, (const u16 *)w, gamma,

@@ -515,7 +515,8 @@ def conv1x1_stats(x, w, in_scale, in_shift, stats):
 
 
 def gram_buffers(Cb, device):
-    """(zeroed shard accumulators, f64 workspace) for conv1x1_gram_bn; the accumulators clean themselves (gram_bn_finalize)"""
+    """(partial-slab workspace, f64 totals) for conv1x1_gram_bn: every workgroup of the Gram launch stores its partial sums as a slab, the
+    finalize sums the slabs in slab order (csrc/conv_gram.hip) - nothing to clear between steps"""
     L = _lib.lib()
     return (torch.zeros(L.mhe_gram_stats_words(Cb), device=device, dtype=STAT_DTYPE),
             torch.empty(L.mhe_gram_stats_workspace_bytes(Cb) // 8, device=device, dtype=torch.float64))

@@ -577,10 +577,13 @@ def test_gram_statistics_give_the_convolutions_batchnorm_affine(gpu_lib, geom):
     rm, rv = torch.zeros(C4, device="cuda"), torch.ones(C4, device="cuda")
     nbt = torch.tensor(0, dtype=torch.int64, device="cuda")
     bufs = ops.gram_buffers(Cb, torch.device("cuda"))
-    for rep in range(2):                                   # twice: the accumulators clean themselves
+    outs = []
+    for rep in range(2):                                   # twice: a launch overwrites its partial slabs, nothing is carried over
         sc, sh, mi = ops.conv1x1_gram_bn(xd, s2.cuda(), h2.cuda(), wd, gamma.cuda(), beta.cuda(), rm, rv, bufs, num_batches_tracked=nbt,
                                          want_mean_invstd=True)
-    assert int(nbt) == 2 and not bufs[0].any()
+        outs.append((sc.clone(), sh.clone(), mi.clone()))
+    assert int(nbt) == 2
+    assert all(torch.equal(a, b) for a, b in zip(*outs))    # slab-order sums: bit-reproducible
     a = F.relu(x.double() * s2.double()[None, :, None, None] + h2.double()[None, :, None, None]).bfloat16().double()
     y = F.conv2d(a, w.double())
     mean, var = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)

@@ -1,4 +1,4 @@
-"""Every timed launch of ONE eager train step at the bench workload (C2), in issue order, with its algorithmic work: where the
+"""Every timed launch of ONE eager train step (or, --forward, forward + loss step) at the bench workload (C2), in issue order, with its algorithmic work: where the
 weight-gradient and forward-convolution lines of the step stand against the two rooflines.  python tools/train_lines.py [--min-us 20]"""
 import argparse
 import os
@@ -14,6 +14,7 @@ from mhentropy_amd.train import TrainStep
 ap = argparse.ArgumentParser()
 ap.add_argument("--min-us", type=float, default=0.0)
 ap.add_argument("--only", default="")
+ap.add_argument("--forward", action="store_true", help="the forward + loss step (MHEnt.get_loss) instead of the train step")
 a = ap.parse_args()
 cfg = bench.WORKLOADS["c2"]
 B, K = cfg["B"], cfg["K"]
@@ -24,13 +25,17 @@ x, yn = synth.batch(0, B, image_size=256)
 x = torch.as_tensor(x).to(dev)
 y = {k: torch.as_tensor(v).to(dev) for k, v in yn.items()}
 ops.rng_state(dev, seed=0)
-ts = TrainStep(model)
+if a.forward:
+    step = lambda: model.get_loss(x, y, mods=["uv"], N=K)
+else:
+    ts = TrainStep(model)
+    step = lambda: ts.step(x, y, N=K)
 for _ in range(2):
-    ts.step(x, y, N=K)
+    step()
 torch.cuda.synchronize()
 ops.KERNEL_TIMES.clear()
 ops.TIMING = True
-ts.step(x, y, N=K)
+step()
 torch.cuda.synchronize()
 ops.TIMING = False
 tot = {}
