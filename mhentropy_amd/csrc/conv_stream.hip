@@ -23,9 +23,10 @@ void conv1x1_stream_kernel(const Params p, int nchunks, int ntiles_n) {
     using T = u16;
     constexpr int NTH = 256, CPR = ST_BN * 2 / 16;                // sixteen-byte chunks per output row
     constexpr int NTW = ST_BN / 64, NJ = ST_PIX * CPR / NTH;      // 16-channel tiles per wave; staged chunks per thread
+    constexpr int SWM = CPR < 16 ? CPR - 1 : 15;                  // staging rows: 16-byte chunks XOR-swizzled by the row within the row's own width
     __shared__ uint4 Wl[ST_BN * 8 * KT];                          // weights: 256 rows x (KT x 128 B), XOR-swizzled like the tiled kernels
     __shared__ uint4 Al[2][ST_PIX * 8 * KT];                      // activations of a chunk, double-buffered
-    __shared__ uint4 Ol[ST_PIX * CPR > NTH ? ST_PIX * CPR : NTH];    // output staging; statistic partials at the end (256 threads x 16 floats)
+    __shared__ uint4 Ol[ST_PIX * CPR > NTH * 4 ? ST_PIX * CPR : NTH * 4];    // output staging; statistic partials at the end (256 threads x 16 floats)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, l15 = lane & 15;
     const int nt_id = blockIdx.x % ntiles_n, wg = blockIdx.x / ntiles_n, nwg = gridDim.x / ntiles_n;
     const int n0 = nt_id * ST_BN;
@@ -145,7 +146,7 @@ void conv1x1_stream_kernel(const Params p, int nchunks, int ntiles_n) {
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     const int row = mt * 16 + l15, boff = (wave * (ST_BN / 4) + nt * 16 + 4 * q) * 2;
-                    const int chunk = (boff >> 4) ^ (row & 15);
+                    const int chunk = (boff >> 4) ^ (row & SWM);
                     const v4f v = acc[nt][mt];
                     uint2 o;
                     o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
@@ -181,7 +182,7 @@ void conv1x1_stream_kernel(const Params p, int nchunks, int ntiles_n) {
                         }
                         if (y0g && !y0sum) ya[g] = *reinterpret_cast<const uint4 *>(y0g + off[g]);
                         if (y1g && !y1sum) yb[g] = *reinterpret_cast<const uint4 *>(y1g + off[g]);
-                        raw[g] = *reinterpret_cast<const uint4 *>(ot + ((size_t)row * CPR + (cc ^ (row & 15))) * 16);
+                        raw[g] = *reinterpret_cast<const uint4 *>(ot + ((size_t)row * CPR + (cc ^ (row & SWM))) * 16);
                     }
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -226,7 +227,7 @@ void conv1x1_stream_kernel(const Params p, int nchunks, int ntiles_n) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int id = tid + NTH * j, row = id / CPR, cc = id % CPR;
-                raw[j] = *reinterpret_cast<const uint4 *>(ot + ((size_t)row * CPR + (cc ^ (row & 15))) * 16);
+                raw[j] = *reinterpret_cast<const uint4 *>(ot + ((size_t)row * CPR + (cc ^ (row & SWM))) * 16);
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -591,7 +592,9 @@ int launch_stream3(const Params &p, hipStream_t s) {
 
 // (measured, tools/conv_variants.py / dg_variants.py: at K = 128 the plain / on-load forms run 85 / 95 us on the 256 tile against 96 / 105 us
 // on the 128 tile, the data-gradient form 254 against 227 us)
-static int stream_bn(const Params &p) { return p.Cin == 64 ? 256 : (p.Cin == 128 && !p.mask ? 256 : 128); }
+// (round 4: 64 -> 64 channels, forward forms - layer1.0's conv1 on the pooled stem output, 1 M pixels at config C2: 268 MB in 107 us on the
+// 128 x 64 register-staged tile; a 64-wide weight tile here, four workgroups per CU)
+static int stream_bn(const Params &p) { return p.Cin == 64 ? (p.Cout == 64 && !p.mask ? 64 : 256) : (p.Cin == 128 && !p.mask ? 256 : 128); }
 
 bool stream_supports(const Params &p) {
     if (!(p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && (p.Cin == 64 || p.Cin == 128 || p.Cin == 256) && p.Kpad == p.Cin &&
@@ -606,7 +609,10 @@ bool stream_supports(const Params &p) {
 template <int KT, int NB>
 static void launch_stream_t(const Params &p, hipStream_t s, dim3 grid, int nchunks, int ntn) {
     const dim3 block(256);
-    if (p.mask) hipLaunchKernelGGL((conv1x1_stream_kernel<KT, NB, false, true>), grid, block, 0, s, p, nchunks, ntn);
+    if constexpr (NB == 64) {                      // forward forms only (stream_bn)
+        if (p.in_scale) hipLaunchKernelGGL((conv1x1_stream_kernel<KT, NB, true>), grid, block, 0, s, p, nchunks, ntn);
+        else hipLaunchKernelGGL((conv1x1_stream_kernel<KT, NB, false>), grid, block, 0, s, p, nchunks, ntn);
+    } else if (p.mask) hipLaunchKernelGGL((conv1x1_stream_kernel<KT, NB, false, true>), grid, block, 0, s, p, nchunks, ntn);
     else if constexpr (KT <= 2) {
         if (p.in_scale) hipLaunchKernelGGL((conv1x1_stream_kernel<KT, NB, true>), grid, block, 0, s, p, nchunks, ntn);
         else hipLaunchKernelGGL((conv1x1_stream_kernel<KT, NB, false>), grid, block, 0, s, p, nchunks, ntn);
@@ -616,12 +622,13 @@ static void launch_stream_t(const Params &p, hipStream_t s, dim3 grid, int nchun
 int launch_stream(const Params &p, hipStream_t s) {
     const int nb = stream_bn(p);
     const int nchunks = (p.M + ST_PIX - 1) / ST_PIX, ntn = p.Cout / nb;
-    const int per_cu = (p.Cin == 256 || (p.Cin == 128 && nb == 256)) ? 1 : 2;
+    const int per_cu = nb == 64 ? 4 : (p.Cin == 256 || (p.Cin == 128 && nb == 256)) ? 1 : 2;
     int nwg = 256 * per_cu / ntn;                                  // resident workgroups: pixel groups x N tiles
     if (nwg < 1) nwg = 1;
     if (nwg > nchunks) nwg = nchunks;
     const dim3 grid((unsigned)(nwg * ntn));
-    if (p.Cin == 64) launch_stream_t<1, 256>(p, s, grid, nchunks, ntn);
+    if (p.Cin == 64 && nb == 64) launch_stream_t<1, 64>(p, s, grid, nchunks, ntn);
+    else if (p.Cin == 64) launch_stream_t<1, 256>(p, s, grid, nchunks, ntn);
     else if (p.Cin == 128 && nb == 256) launch_stream_t<2, 256>(p, s, grid, nchunks, ntn);
     else if (p.Cin == 128) launch_stream_t<2, 128>(p, s, grid, nchunks, ntn);
     else launch_stream_t<4, 128>(p, s, grid, nchunks, ntn);

@@ -92,7 +92,7 @@ def _conv_kernel_name(d, dt, mode):
     if tile == 9:
         return "mhe::conv::conv3x3_c64_stream_kernel<%s, false>" % ("true" if mode == 1 else "false")
     if tile == 8:
-        return "mhe::conv::conv1x1_stream_kernel<%d, %d, %s, false>" % (d.Cin // 64, 256 if d.Cin <= 128 else 128, "true" if mode == 1 else "false")
+        return "mhe::conv::conv1x1_stream_kernel<%d, %d, %s, false>" % (d.Cin // 64, 64 if (d.Cin == 64 and d.Cout == 64) else 256 if d.Cin <= 128 else 128, "true" if mode == 1 else "false")
     if tile == 13:
         return "mhe::conv::conv_p8_kernel<false, %s, 0, 1>" % ("false" if d.KH == 1 and d.KW == 1 and d.pad == 0 else "true")
     if tile == 7:

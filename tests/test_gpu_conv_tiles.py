@@ -345,7 +345,8 @@ def test_half_resolution_residual(gpu_lib, tile, masked):
 
 
 @pytest.mark.parametrize("bn_load", [False, True], ids=["plain", "bn-on-load"])
-@pytest.mark.parametrize("shape", [(16, 64, 64, 64, 256), (18, 61, 60, 64, 256), (64, 32, 32, 128, 512), (17, 64, 61, 128, 256), (17, 64, 61, 256, 384)],
+@pytest.mark.parametrize("shape", [(16, 64, 64, 64, 256), (18, 61, 60, 64, 256), (64, 32, 32, 128, 512), (17, 64, 61, 128, 256), (17, 64, 61, 256, 384),
+                                   (16, 64, 64, 64, 64), (18, 61, 60, 64, 64)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_streaming_1x1_kernel(gpu_lib, shape, bn_load):
     """conv1x1_stream_kernel (variant 8: K = 64 / 128 input channels, weights resident in LDS, 64-pixel chunks): the launcher picks it
