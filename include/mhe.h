@@ -328,7 +328,8 @@ int mhe_conv3x3s2_dgrad_nhwc(int B, int Ho, int Wo, int Cout, int Cin, int dtype
                              const float *bn_mean_invstd0, mhe_stat_t *bn_stats0, const void *bn_y1,
                              const float *bn_mean_invstd1, mhe_stat_t *bn_stats1, int tile /* mhe_conv_desc.tile */, void *stream);
 int mhe_conv_tile(const mhe_conv_desc *d);
-/* the same for an operand-load form: mode 1 = producer BatchNorm on load, 2 = residual-block tail, 0 = plain operands */
+/* the same for an operand-load form: mode 1 = producer BatchNorm on load, 2 = residual-block tail, 0 = plain operands, 3 = plain operands
+ * with a residual added in the epilogue (the streaming kernels' forward forms do not take one) */
 int mhe_conv_tile_mode(const mhe_conv_desc *d, int mode);
 
 /* 1x1 stride-1 convolution whose operand is the TAIL of the previous residual block evaluated while

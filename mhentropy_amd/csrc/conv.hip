@@ -1049,7 +1049,7 @@ extern "C" int mhe_conv_tile(const mhe_conv_desc *d) {
 // the same for an operand-load form: 1 = producer BatchNorm on load (mhe_conv2d_nhwc with in_scale), 2 = residual-block tail
 // (mhe_conv1x1_residual_in_nhwc); 0 = plain (mhe_conv_tile)
 extern "C" int mhe_conv_tile_mode(const mhe_conv_desc *d, int mode) {
-    if (!d || mode < 0 || mode > 2) return -1;
+    if (!d || mode < 0 || mode > 3) return -1;
     static const float dummy = 0.f;
     conv::Params p{};
     p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
@@ -1058,8 +1058,9 @@ extern "C" int mhe_conv_tile_mode(const mhe_conv_desc *d, int mode) {
     p.force = d->tile - 1;
     const int bke = d->dtype == MHE_F32 ? 32 : 64;
     p.Kpad = (d->KH * d->KW * d->Cin + bke - 1) / bke * bke;
-    if (mode >= 1) p.in_scale = &dummy;
+    if (mode == 1 || mode == 2) p.in_scale = &dummy;
     if (mode == 2) p.x2 = &dummy;
+    if (mode == 3) p.residual = &dummy;            // forward form with a residual operand (the streaming kernels do not take it)
     return conv::choose_tile(p, d->Cin % bke == 0, d->dtype == MHE_BF16);
 }
 

@@ -83,6 +83,7 @@ def _conv_kernel_name(d, dt, mode):
     """the template instantiation the launcher will pick, spelled as rocprofv3 prints it"""
     bke = 32 if dt == torch.float32 else 64
     tile = _lib.lib().mhe_conv_tile_mode(C.byref(d), mode)
+    mode = 0 if mode == 3 else mode          # (3 = plain operand load + a residual in the epilogue: the kernel's MODE is 0)
     if tile == 11:
         return "mhe::conv::conv_wide_kernel<%s, %s>" % ("128, 4" if d.Cin == 256 else "64, 8", "true" if mode == 1 else "false")
     if tile == 15:
@@ -490,7 +491,7 @@ def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in
         ev1.record()
         es = x.element_size()      # algorithmic HBM bytes: input once, output once, weights once (+ residual)
         nbytes = es * (x.numel() + y.numel() + w.numel() + (residual.numel() if residual is not None else 0))
-        KERNEL_TIMES.append((_conv_kernel_name(d, dt, 1 if in_scale is not None else 0),
+        KERNEL_TIMES.append((_conv_kernel_name(d, dt, 1 if in_scale is not None else 3 if residual is not None else 0),
                              2.0 * B * Ho * Wo * Cout * KH * KW * Cin, ev0, ev1, nbytes))
     return y
 
