@@ -109,12 +109,43 @@ void conv1x1_stream_kernel(const Params p, int nchunks, int ntiles_n) {
             }
     }
 
+    // data-gradient form: the epilogue's operands of a group of four rows (gate, residual, the consumers' raw tensors) do not depend on the
+    // product - group 0 of a chunk is requested BEFORE the chunk's product and staging, so that its latency runs under them (round 4: the
+    // store phase used to start with these loads: a chunk iteration took 5.5 us for 80 KB)
+    uint4 gm[DG ? 4 : 1], rr[DG ? 4 : 1], ya[DG ? 4 : 1], yb[DG ? 4 : 1];
+    unsigned gmb[DG ? 4 : 1];
+    size_t off[DG ? 4 : 1];
+    bool okr[DG ? 4 : 1];
+    auto dg_load = [&](int j0, int c) __attribute__((always_inline)) {
+        if constexpr (DG) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int id = tid + NTH * (j0 + g), row = id / CPR;
+                const long m = (long)c * ST_PIX + row;
+                okr[g] = m < p.M && ccol < p.Cout;
+                const long mc = okr[g] ? m : 0;
+                off[g] = (size_t)mc * p.Cout + ccol;
+                if (mkb) gmb[g] = mkb[(size_t)mc * (p.Cout / 8) + (ccol >> 3)];
+                else gm[g] = *reinterpret_cast<const uint4 *>(mk + off[g]);
+                rr[g] = make_uint4(0u, 0u, 0u, 0u);
+                if (rg) {
+                    if (p.res_s2) {
+                        const long hr = res_half_row(p, mc);
+                        if (hr >= 0) rr[g] = *reinterpret_cast<const uint4 *>(rg + (size_t)hr * p.Cout + ccol);
+                    } else rr[g] = *reinterpret_cast<const uint4 *>(rg + off[g]);
+                }
+                if (y0g && !y0sum) ya[g] = *reinterpret_cast<const uint4 *>(y0g + off[g]);
+                if (y1g && !y1sum) yb[g] = *reinterpret_cast<const uint4 *>(y1g + off[g]);
+            }
+        }
+    };
     load_chunk(wg);
     int it = 0;
     for (int c = wg; c < nchunks; c += nwg, ++it) {
         const int buf = it & 1;
         store_chunk(buf, c);
         load_chunk(c + nwg);                                     // in flight during this chunk's product and stores
+        if constexpr (ST_BN <= 128) dg_load(0, c);               // (the 256-wide tile has no registers for it: 20 VGPRs spilled)
         __syncthreads();
         v4f acc[NTW][4];                                         // [channel tile of this wave's ST_BN / 4][pixel tile]
 #pragma unroll
@@ -160,28 +191,11 @@ void conv1x1_stream_kernel(const Params p, int nchunks, int ntiles_n) {
             if constexpr (DG) {
 #pragma unroll 1
                 for (int j0 = 0; j0 < NJ; j0 += 4) {                 // 4 rows at a time: their operand loads are issued together
-                    uint4 raw[4], gm[4], rr[4], ya[4], yb[4];
-                    unsigned gmb[4];
-                    size_t off[4];
-                    bool okr[4];
+                    if (j0 || ST_BN > 128) dg_load(j0, c);           // (128-wide tile: group 0 was requested before this chunk's product, see the loop head)
+                    uint4 raw[4];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int id = tid + NTH * (j0 + g), row = id / CPR, cc = id % CPR;
-                        const long m = (long)c * ST_PIX + row;
-                        okr[g] = m < p.M && ccol < p.Cout;
-                        const long mc = okr[g] ? m : 0;
-                        off[g] = (size_t)mc * p.Cout + ccol;
-                        if (mkb) gmb[g] = mkb[(size_t)mc * (p.Cout / 8) + (ccol >> 3)];
-                        else gm[g] = *reinterpret_cast<const uint4 *>(mk + off[g]);
-                        rr[g] = make_uint4(0u, 0u, 0u, 0u);
-                        if (rg) {
-                            if (p.res_s2) {
-                                const long hr = res_half_row(p, mc);
-                                if (hr >= 0) rr[g] = *reinterpret_cast<const uint4 *>(rg + (size_t)hr * p.Cout + ccol);
-                            } else rr[g] = *reinterpret_cast<const uint4 *>(rg + off[g]);
-                        }
-                        if (y0g && !y0sum) ya[g] = *reinterpret_cast<const uint4 *>(y0g + off[g]);
-                        if (y1g && !y1sum) yb[g] = *reinterpret_cast<const uint4 *>(y1g + off[g]);
                         raw[g] = *reinterpret_cast<const uint4 *>(ot + ((size_t)row * CPR + (cc ^ (row & SWM))) * 16);
                     }
 #pragma unroll

@@ -18,6 +18,7 @@ FLOW_FORWARD, FLOW_INVERSE = 0, 1
 # bench.py instrumentation: when TIMING is set every conv launch is bracketed by
 # HIP events on the launch stream and logged as (kernel name, algorithmic flops, ev0, ev1)
 TIMING = False
+TIMING_DG = False        # tools/train_lines.py: also the data-gradient launches, under descriptive names (not rocprofv3's: bench.py leaves it off)
 KERNEL_TIMES = []
 
 
@@ -450,8 +451,9 @@ def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in
                 _chk(xcat, dt, "conv.xcat", (B, H, W, cin2))
                 if tuple(w.shape) != (Cout, Cin + cin2):
                     raise ValueError(f"conv2d_nhwc: xcat= needs w [{Cout}, {Cin + cin2}], got {tuple(w.shape)}")
-            check(_lib.lib().mhe_conv2d_masked_bias_nhwc(C.byref(d), _ptr(x), _ptr(xcat), int(cin2), _ptr(w), _ptr(y), _ptr(residual), _ptr(mask),
-                                                         _ptr(out_shift), _ptr(by), _ptr(bmi), _ptr(bst), _stream()), "mhe_conv2d_masked_bias_nhwc")
+            with _dg_timed(d, x, y, w, residual, mask, None, [by], "cat" if xcat is not None else "bias", xcat):
+                check(_lib.lib().mhe_conv2d_masked_bias_nhwc(C.byref(d), _ptr(x), _ptr(xcat), int(cin2), _ptr(w), _ptr(y), _ptr(residual), _ptr(mask),
+                                                             _ptr(out_shift), _ptr(by), _ptr(bmi), _ptr(bst), _stream()), "mhe_conv2d_masked_bias_nhwc")
             return y
         if xcat is not None:
             raise ValueError("conv2d_nhwc: xcat= comes with mask= and out_shift=")
@@ -463,11 +465,13 @@ def conv2d_nhwc(x, w, KH, KW, stride, pad, in_scale=None, in_shift=None, relu_in
             ext += [_ptr(by), _ptr(bmi), _ptr(bst)]
         if mask_bits is not None:        # the gate also as bits [pixel][Cout / 8] (bottleneck_tail want_bits=): read instead of `mask` where the kernel can
             _chk(mask_bits, torch.uint8, "conv.mask_bits", (B, Ho, Wo, Cout // 8))
-            check(_lib.lib().mhe_conv2d_masked_bits_nhwc(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _ptr(residual), _ptr(mask), _ptr(mask_bits), *ext, _stream()),
-                  "mhe_conv2d_masked_bits_nhwc")
+            with _dg_timed(d, x, y, w, residual, mask, mask_bits, [b[0] for b in (bn or [])], "bits"):
+                check(_lib.lib().mhe_conv2d_masked_bits_nhwc(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _ptr(residual), _ptr(mask), _ptr(mask_bits), *ext, _stream()),
+                      "mhe_conv2d_masked_bits_nhwc")
             return y
-        check(_lib.lib().mhe_conv2d_masked_nhwc(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _ptr(residual), _ptr(mask), *ext, _stream()),
-              "mhe_conv2d_masked_nhwc")
+        with _dg_timed(d, x, y, w, residual, mask, None, [b[0] for b in (bn or [])], ""):
+            check(_lib.lib().mhe_conv2d_masked_nhwc(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _ptr(residual), _ptr(mask), *ext, _stream()),
+                  "mhe_conv2d_masked_nhwc")
         return y
     if bn:
         raise ValueError("conv2d_nhwc: bn= needs mask= (data-gradient form)")
@@ -968,7 +972,7 @@ def _wgrad_kernel_name(d, Ho=0, Wo=0, nbatch=1):
 class _Timed:
     """HIP events on the launch stream around one launch, appended to KERNEL_TIMES while TIMING is on (bench.py's live roofline pass)"""
     def __init__(self, name_fn, flops, nbytes):
-        self.on = TIMING
+        self.on = TIMING and name_fn is not None
         if self.on:
             self.name, self.flops, self.nbytes = name_fn(), flops, nbytes
             self.ev0, self.ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -983,6 +987,21 @@ class _Timed:
             self.ev1.record()
             KERNEL_TIMES.append((self.name, self.flops, self.ev0, self.ev1, self.nbytes))
         return False
+
+
+def _dg_timed(d, x, y, w, residual, mask, mask_bits, bn_ys, tag, xcat=None):
+    """tools/train_lines.py: a data-gradient launch under a descriptive name with the bytes it has to move (operand, result, weights,
+    residual, the gate - as bits where the kernel reads bits - and the raw tensors of the BatchNorm-reverse sums that are not the gate)"""
+    if not (TIMING and TIMING_DG):
+        return _Timed(None, 0.0, 0)
+    es = x.element_size()
+    nb = es * (x.numel() + y.numel() + w.numel() + (residual.numel() if residual is not None else 0) + (xcat.numel() if xcat is not None else 0))
+    nb += mask_bits.numel() if mask_bits is not None else es * mask.numel()
+    nb += sum(es * b.numel() for b in bn_ys if b is not None and b.data_ptr() != mask.data_ptr())
+    name = "dgrad %dx%d s%d %d->%d @%dx%d%s%s bn%d %s" % (d.KH, d.KW, d.stride, d.Cin, d.Cout, y.shape[1], y.shape[2], " +res" if residual is not None else "",
+                                                      " half" if d.res_half else "", sum(b is not None for b in bn_ys), tag)
+    t = _Timed(lambda: name, 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * d.Cout * d.KH * d.KW * (d.Cin + (xcat.shape[-1] if xcat is not None else 0)), nb)
+    return t
 
 
 def conv_wgrad(x, gy, KH, KW, stride, pad, dw, ldw=0):

@@ -34,7 +34,7 @@ for _ in range(2):
     step()
 torch.cuda.synchronize()
 ops.KERNEL_TIMES.clear()
-ops.TIMING = True
+ops.TIMING = ops.TIMING_DG = True
 step()
 torch.cuda.synchronize()
 ops.TIMING = False
