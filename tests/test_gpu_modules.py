@@ -360,6 +360,50 @@ def test_c1_shape_bf16_mode_deviation_from_the_f32_oracle(gpu_lib):
     assert dev["q_log_p_z_giv_y"] < 1e-2 and dev["log_p"] < 1e-2 and loss_rel < 1e-3, (dev, loss_rel)
 
 
+def test_c2_full_size_vs_oracle(gpu_lib):
+    """config C2 WHOLE - the workload the headline is timed on (BASELINE.json configs[2]: ResNet-50, shipped 12-coupling h = 512 RealNVP,
+    B = 256 images x K = 64 hypotheses, 256x256) - against the CPU restatement on the same seeded inputs (one oracle pass: ~15 s on the
+    box's 16 cores, the pass bench.py times as cpu_baseline):
+      f32 mode   every `get_loss` entry at 3e-4 (the bound of the C1 test: 53 train-mode BatchNorm layers of round-off in front of the
+                 1e-4 path),
+      bf16 mode  (the timed product path) the deviation from the f32 reference value, printed and bounded at the C1 figures."""
+    from mhentropy_amd import harness
+    from oracle import network_ref, mano_ref
+    B, N = 256, 64
+    sdn = {"q_z_giv_i." + k: v for k, v in synth.flow_state(43, 45, 512, (512, 512), 6).items()}
+    sdn.update(synth.head_state(43, 2048, 512, 16))
+    sdn.update({"feat_extractor.res." + k: v for k, v in synth.resnet_state(43, "resnet50").items()})
+    x, yn = synth.batch(43, B, image_size=256)
+    z0 = synth.noise(43, N * B)
+    sd = {k: torch.as_tensor(v) for k, v in sdn.items()}
+    tb = mano_ref.tables_from_numpy(synth.mano_tables(0))
+    with torch.no_grad():
+        ref = network_ref.get_loss(sd, tb, torch.as_tensor(x), _t(yn, "cpu"), torch.as_tensor(z0), N, "resnet50", True)
+    keys = ("th_norm", "bt_norm", "q_log_p_z_giv_y", "h_q_z_giv_i", "log_p")
+    xg, yg, zg = torch.as_tensor(x).cuda(), _t(yn), torch.as_tensor(z0).cuda()
+    for dt in (torch.float32, torch.bfloat16):
+        model = harness.build_mhent(backbone="resnet50", h_dims=(512, 512), num_steps=6, tables=synth.mano_tables(0), compute_dtype=dt)
+        model.load_state_dict({k: torch.as_tensor(v) for k, v in sdn.items()}, strict=False)
+        model = model.cuda().train()
+        out = {k: v.clone() for k, v in model.get_loss(xg, yg, mods=["uv"], N=N, noise=zg).items() if k in keys}
+        del model
+        torch.cuda.empty_cache()
+        if dt == torch.float32:
+            for k in keys:
+                assert out[k].shape == ref[k].shape
+                assert_close(out[k].cpu(), ref[k], 3e-4, what="C2 f32 " + k)
+            continue
+        dev = {}
+        for k in keys:
+            a, b = out[k].cpu().double(), ref[k].double()
+            assert a.shape == b.shape and torch.isfinite(a).all(), k
+            dev[k] = ((a - b).abs().mean() / b.abs().mean()).item()
+        loss_rel = abs(float(out["log_p"].mean()) - float(ref["log_p"].mean())) / abs(float(ref["log_p"].mean()))
+        print("C2 bf16 mode vs f32 oracle, mean|a-b|/mean|b|: " + ", ".join(f"{k} {v:.2e}" for k, v in dev.items()) + f"; loss value {loss_rel:.2e}")
+        assert dev["h_q_z_giv_i"] < 5e-3 and dev["th_norm"] < 2e-2 and dev["bt_norm"] < 5e-2, dev
+        assert dev["q_log_p_z_giv_y"] < 1e-2 and dev["log_p"] < 1e-2 and loss_rel < 1e-3, (dev, loss_rel)
+
+
 def test_c2_size_bf16_graph_replay_equals_eager(gpu_lib):
     """config C2's forward + loss (B = 256, K = 64, bf16) is DETERMINISTIC like the reference's CPU `get_loss` (hand/network.py:838-844):
     two eager runs and the HIP-graph replay the bench times return the same bits.  (Rounds 1-3 summed the BatchNorm / Gram statistics with
