@@ -632,6 +632,15 @@ int mhe_maxpool3x3s2_bwd_nhwc(const void *gy, const unsigned char *idx, void *gx
  * BatchNorm-reverse sums of gx into stats[shard][2][C] (as mhe_bn_bwd_reduce_nhwc would add them) in one pass; C / (16 bytes of dtype) must divide 256. */
 int mhe_maxpool3x3s2_idx_affine_nhwc(const void *x, const float *scale, const float *shift, void *y, unsigned char *idx, int B, int H, int W,
                                      int C, int dtype, void *stream);
+/* ... that also keeps the RAW input at every winner (xwin [B,Ho,Wo,C]), and the BatchNorm-reverse sums taken from the pooled tensors alone
+ * (round 4): sum g' = sum g [pooled > 0], sum g' xhat = sum g [pooled > 0] (xwin - mean) invstd over the P = B Ho Wo pooled pixels - the
+ * scattered gradient is non-zero only at the winners, so the full-resolution tensor is not walked for the sums (a quarter of the
+ * elements, no window gathers).  Differs from mhe_maxpool3x3s2_bwd_bn_nhwc's sums in the last bf16 bit where two windows picked one pixel
+ * (that walk rounds the sum of their gradients to `dtype` first). */
+int mhe_maxpool3x3s2_idx_affine_win_nhwc(const void *x, const float *scale, const float *shift, void *y, unsigned char *idx, void *xwin, int B,
+                                         int H, int W, int C, int dtype, void *stream);
+int mhe_pooled_bn_sums_nhwc(const void *g, const void *pooled, const void *xwin, const float *mean_invstd, mhe_stat_t *stats, long P, int C,
+                            int dtype, void *stream);
 int mhe_maxpool3x3s2_bwd_bn_nhwc(const void *gy, const unsigned char *idx, const void *y, const float *scale, const float *shift,
                                  const float *mean_invstd, mhe_stat_t *stats, void *gx, int B, int H, int W, int C, int dtype, void *stream);
 /* (gx may be NULL: the sums only.)  The same walk with the finished BatchNorm-reverse coefficients coef = k2 | k1 | k0 [3][C] (mhe_bn_bwd_finalize):

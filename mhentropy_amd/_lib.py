@@ -67,6 +67,8 @@ SIGNATURES = {
     "mhe_maxpool3x3s2_idx_nhwc": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mhe_maxpool3x3s2_bwd_nhwc": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mhe_maxpool3x3s2_idx_affine_nhwc": (_i, [_p] * 5 + [_i] * 5 + [_p]),
+    "mhe_maxpool3x3s2_idx_affine_win_nhwc": (_i, [_p] * 6 + [_i] * 5 + [_p]),
+    "mhe_pooled_bn_sums_nhwc": (_i, [_p] * 5 + [_l, _i, _i, _p]),
     "mhe_maxpool3x3s2_bwd_bn_nhwc": (_i, [_p] * 8 + [_i] * 5 + [_p]),
     "mhe_maxpool3x3s2_bwd_bn_apply_nhwc": (_i, [_p] * 8 + [_i] * 5 + [_p]),
     "mhe_avgpool_bwd_nhwc": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),

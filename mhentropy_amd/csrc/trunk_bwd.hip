@@ -288,7 +288,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_wide_kernel(const T *__restr
 // (bf16-rounded for T = u16), first maximum in scan order - the same winners as maxpool_idx_kernel on the materialised activation
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_idx_affine_kernel(const T *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift,
-                                                                 T *__restrict__ y, unsigned char *__restrict__ idx, int B, int H, int W, int C, int Ho, int Wo) {
+                                                                 T *__restrict__ y, unsigned char *__restrict__ idx, int B, int H, int W, int C, int Ho, int Wo,
+                                                                 T *__restrict__ xwin = nullptr) {
     constexpr int E = Lane<T>::E;
     const int cpp = C / E;                                   // chunks per pixel
     const unsigned n = (unsigned)B * Ho * Wo * cpp;
@@ -309,10 +310,10 @@ __global__ __launch_bounds__(256) void maxpool_idx_affine_kernel(const T *__rest
                 const int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi), wc = wi < 0 ? 0 : (wi >= W ? W - 1 : wi);
                 Lane<T>::get(x + (((size_t)b * H + hc) * W + wc) * C + c, v[dh * 3 + dw]);
             }
-        float sc[E], sf[E], m[E];
+        float sc[E], sf[E], m[E], xw[E];
         unsigned am[E];
 #pragma unroll
-        for (int k = 0; k < E; ++k) { sc[k] = scale[c + k]; sf[k] = shift[c + k]; m[k] = -3.0e38f; am[k] = 0; }
+        for (int k = 0; k < E; ++k) { sc[k] = scale[c + k]; sf[k] = shift[c + k]; m[k] = -3.0e38f; am[k] = 0; xw[k] = 0.f; }
 #pragma unroll
         for (int j = 0; j < 9; ++j)
 #pragma unroll
@@ -321,9 +322,11 @@ __global__ __launch_bounds__(256) void maxpool_idx_affine_kernel(const T *__rest
                 const bool win = ok[j] && a > m[k];
                 m[k] = win ? a : m[k];
                 am[k] = win ? (unsigned)j : am[k];
+                xw[k] = win ? v[j][k] : xw[k];               // the RAW input at the winner (what the reverse pass normalises again)
             }
         const size_t e = (size_t)i * E;
         Lane<T>::put(y + e, m);
+        if (xwin) Lane<T>::put(xwin + e, xw);
         unsigned w0 = 0, w1 = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) w0 |= am[k] << (8 * k);
@@ -332,6 +335,59 @@ __global__ __launch_bounds__(256) void maxpool_idx_affine_kernel(const T *__rest
             for (int k = 0; k < 4; ++k) w1 |= am[4 + k] << (8 * k);
             *reinterpret_cast<uint2 *>(idx + e) = make_uint2(w0, w1);
         } else *reinterpret_cast<unsigned *>(idx + e) = w0;
+    }
+}
+
+// The BatchNorm-reverse sums of the stem WITHOUT a walk over its full-resolution output (round 4).  The gradient that reaches the stem's
+// output through the max pool is non-zero only at the pool's winners, and the forward pass can keep what the sums need of them: per POOLED
+// element its gradient g, the pooled value a = relu(bn(y_win)) (the gate: a > 0) and the raw winner y_win (maxpool_idx_affine_kernel's
+// xwin):  sum g' = sum_pooled g [a > 0],  sum g' xhat = sum_pooled g [a > 0] (y_win - mean) invstd.  A quarter of the elements of
+// maxpool_bwd_bn_kernel's first walk and no window gathers.  One difference to that walk, in the last bf16 bit: where two windows picked
+// the same pixel, the walk rounds the SUM of their gradients to the storage type before adding it up (as the apply walk stores it), here
+// each term enters exactly.
+template <typename T>
+__global__ __launch_bounds__(256) void pooled_bn_sums_kernel(const T *__restrict__ g, const T *__restrict__ a, const T *__restrict__ ywin,
+                                                             const float *__restrict__ mean_invstd, mhe_stat_t *__restrict__ stats, size_t nl, int C) {
+    constexpr int E = Lane<T>::E;
+    __shared__ float red[256 * 2 * E];
+    const int tid = threadIdx.x, cpp = C / E;
+    const size_t i0 = (size_t)blockIdx.x * 256 + tid, S = (size_t)gridDim.x * 256;
+    const int c = (int)((i0 * E) % (size_t)C);
+    float mu[E], iv[E], s1[E], s2[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) { mu[k] = mean_invstd[c + k]; iv[k] = mean_invstd[C + c + k]; s1[k] = s2[k] = 0.f; }
+    for (size_t i = i0; i < nl; i += 2 * S) {
+        uint4 rg[2], ra[2], ry[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const size_t j = i + u * S < nl ? i + u * S : i;
+            rg[u] = reinterpret_cast<const uint4 *>(g)[j]; ra[u] = reinterpret_cast<const uint4 *>(a)[j]; ry[u] = reinterpret_cast<const uint4 *>(ywin)[j];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (i + u * S >= nl) break;
+            float gv[E], av[E], yv[E];
+            Lane<T>::unpack(rg[u], gv); Lane<T>::unpack(ra[u], av); Lane<T>::unpack(ry[u], yv);
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                const float t = av[k] > 0.f ? gv[k] : 0.f;
+                s1[k] += t;
+                s2[k] = fmaf(t, (yv[k] - mu[k]) * iv[k], s2[k]);
+            }
+        }
+    }
+    // threads tid, tid + cpp, ... of a block share a channel chunk (the launcher keeps the grid's stride a multiple of cpp)
+#pragma unroll
+    for (int k = 0; k < E; ++k) { red[tid * 2 * E + k] = s1[k]; red[tid * 2 * E + E + k] = s2[k]; }
+    __syncthreads();
+    if (tid < cpp) {
+        const int shard = (int)(blockIdx.x % NSH);
+        for (int k = 0; k < E; ++k) {
+            float x1 = 0.f, x2 = 0.f;
+            for (int o = tid; o < 256; o += cpp) { x1 += red[o * 2 * E + k]; x2 += red[o * 2 * E + E + k]; }
+            fx::add(stats, shard, 0, C, c + k, x1);
+            fx::add(stats, shard, 1, C, c + k, x2);
+        }
     }
 }
 
@@ -622,6 +678,39 @@ extern "C" int mhe_maxpool3x3s2_idx_affine_nhwc(const void *x, const float *scal
     else
         hipLaunchKernelGGL(tb::maxpool_idx_affine_kernel<u16>, dim3(ewg(n)), dim3(256), 0, (hipStream_t)stream, (const u16 *)x, scale, shift, (u16 *)y, idx, B, H, W, C, Ho, Wo);
     return check_launch("maxpool_idx_affine_kernel");
+}
+
+extern "C" int mhe_maxpool3x3s2_idx_affine_win_nhwc(const void *x, const float *scale, const float *shift, void *y, unsigned char *idx, void *xwin, int B,
+                                                    int H, int W, int C, int dtype, void *stream) {
+    MHE_REQUIRE(x && scale && shift && y && idx && xwin && B > 0 && H > 0 && W > 0, "mhe_maxpool3x3s2_idx_affine_win_nhwc: bad arguments");
+    MHE_REQUIRE(dtype == MHE_F32 || dtype == MHE_BF16, "mhe_maxpool3x3s2_idx_affine_win_nhwc: dtype=%d", dtype);
+    const int E = dtype == MHE_F32 ? 4 : 8;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    MHE_REQUIRE(C > 0 && C % E == 0 && (size_t)B * Ho * Wo * (C / E) < (1ull << 31), "mhe_maxpool3x3s2_idx_affine_win_nhwc: C=%d must be a multiple of %d (and < 2^31 lanes)", C, E);
+    const size_t n = (size_t)B * Ho * Wo * (C / E);
+    if (dtype == MHE_F32)
+        hipLaunchKernelGGL(tb::maxpool_idx_affine_kernel<float>, dim3(ewg(n)), dim3(256), 0, (hipStream_t)stream, (const float *)x, scale, shift, (float *)y, idx, B, H, W, C, Ho, Wo, (float *)xwin);
+    else
+        hipLaunchKernelGGL(tb::maxpool_idx_affine_kernel<u16>, dim3(ewg(n)), dim3(256), 0, (hipStream_t)stream, (const u16 *)x, scale, shift, (u16 *)y, idx, B, H, W, C, Ho, Wo, (u16 *)xwin);
+    return check_launch("maxpool_idx_affine_kernel");
+}
+
+extern "C" int mhe_pooled_bn_sums_nhwc(const void *g, const void *pooled, const void *xwin, const float *mean_invstd, mhe_stat_t *stats, long P, int C,
+                                       int dtype, void *stream) {
+    MHE_REQUIRE(g && pooled && xwin && mean_invstd && stats && P > 0, "mhe_pooled_bn_sums_nhwc: bad arguments");
+    MHE_REQUIRE(dtype == MHE_F32 || dtype == MHE_BF16, "mhe_pooled_bn_sums_nhwc: dtype=%d", dtype);
+    const int E = dtype == MHE_F32 ? 4 : 8;
+    MHE_REQUIRE(C > 0 && C % E == 0 && 256 % (C / E) == 0, "mhe_pooled_bn_sums_nhwc: C=%d: C / %d must divide 256 (a thread keeps one channel chunk)", C, E);
+    MHE_REQUIRE(((uintptr_t)g | (uintptr_t)pooled | (uintptr_t)xwin) % 16 == 0, "mhe_pooled_bn_sums_nhwc: 16-byte aligned tensors");
+    const size_t nl = (size_t)P * C / E;
+    const unsigned blocks = ewg((nl + 1) / 2);
+    if (dtype == MHE_F32)
+        hipLaunchKernelGGL(tb::pooled_bn_sums_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)g, (const float *)pooled, (const float *)xwin,
+                           mean_invstd, stats, nl, C);
+    else
+        hipLaunchKernelGGL(tb::pooled_bn_sums_kernel<u16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16 *)g, (const u16 *)pooled, (const u16 *)xwin,
+                           mean_invstd, stats, nl, C);
+    return check_launch("pooled_bn_sums_kernel");
 }
 
 extern "C" int mhe_maxpool3x3s2_bwd_bn_nhwc(const void *gy, const unsigned char *idx, const void *y, const float *scale, const float *shift,

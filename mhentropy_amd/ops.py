@@ -1303,6 +1303,32 @@ def bn_bwd_coef(stats, gamma, mean_invstd, dgamma, dbeta, count):
     return coef
 
 
+def maxpool3x3s2_idx_win(x, scale, shift):
+    """maxpool3x3s2_idx(x, scale, shift) that also returns the RAW input at every winner (mhe_maxpool3x3s2_idx_affine_win_nhwc): what
+    pooled_bn_sums needs of the full-resolution tensor"""
+    B, H, W, Cc = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(B, Ho, Wo, Cc, device=x.device, dtype=x.dtype)
+    xwin = torch.empty_like(y)
+    idx = torch.empty(B, Ho, Wo, Cc, device=x.device, dtype=torch.uint8)
+    _chk(x, x.dtype, "maxpool_idx.x"); _chk(scale, torch.float32, "maxpool_idx.scale", (Cc,)); _chk(shift, torch.float32, "maxpool_idx.shift", (Cc,))
+    check(_lib.lib().mhe_maxpool3x3s2_idx_affine_win_nhwc(_ptr(x), _ptr(scale), _ptr(shift), _ptr(y), _ptr(idx), _ptr(xwin), B, H, W, Cc, dtype_code(x.dtype),
+                                                          _stream()), "mhe_maxpool3x3s2_idx_affine_win_nhwc")
+    return y, idx, xwin
+
+
+def pooled_bn_sums(g, pooled, xwin, mean_invstd, stats):
+    """the stem's BatchNorm-reverse sums from the pooled tensors alone (mhe_pooled_bn_sums_nhwc): g = the gradient of the pooled output,
+    pooled = maxpool(relu(bn(y))) (its gate), xwin = the raw y at the winners; adds sum g', sum g' xhat per channel to `stats`"""
+    Cc = g.shape[-1]
+    dt = g.dtype
+    _chk(g, dt, "pooled_bn_sums.g"); _chk(pooled, dt, "pooled_bn_sums.pooled", g.shape); _chk(xwin, dt, "pooled_bn_sums.xwin", g.shape)
+    _chk(mean_invstd, torch.float32, "pooled_bn_sums.mean_invstd", (2, Cc)); _chk_stats(stats, "pooled_bn_sums.stats", Cc)
+    check(_lib.lib().mhe_pooled_bn_sums_nhwc(_ptr(g), _ptr(pooled), _ptr(xwin), _ptr(mean_invstd), _ptr(stats), g.numel() // Cc, Cc, dtype_code(dt), _stream()),
+          "mhe_pooled_bn_sums_nhwc")
+    return stats
+
+
 def maxpool3x3s2_idx(x, scale=None, shift=None):
     """(pooled, winning taps) of a 3x3 / stride-2 / pad-1 max pool; with scale / shift: of relu(x * scale + shift), evaluated on the load
     (mhe_maxpool3x3s2_idx_affine_nhwc: the normalised activation is never materialised)"""

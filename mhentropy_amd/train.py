@@ -164,6 +164,9 @@ class TrainStep:
         self.halo_bn_on_load = os.environ.get("MHE_HALO_BN_ON_LOAD", "0") == "1"
         # the stem's BatchNorm + ReLU folded into its max pool, forward and reverse (ops.maxpool3x3s2_idx / maxpool3x3s2_bwd_bn)
         self.stem_pool_fused = os.environ.get("MHE_STEM_POOL_FUSED", "1") == "1"
+        # the stem's BatchNorm-reverse sums from the pooled tensors (+ the raw winners kept by the forward's pool) instead of a first walk over
+        # its full-resolution output: MHE_STEM_POOLED_SUMS=0 restores the walk
+        self.stem_pooled_sums = os.environ.get("MHE_STEM_POOLED_SUMS", "1") == "1"
         self.bn_on_load_wide = os.environ.get("MHE_BN_BWD_ON_LOAD_WIDE", "1") == "1"
         self._bucket_bounds = self._gradient_buckets()
         self._works = []
@@ -539,7 +542,11 @@ class TrainStep:
         self._bn_tape(u, self.x_nhwc, y0, st)
         if self.stem_pool_fused:
             # pool straight from the raw stem output, BatchNorm + ReLU on the load: the normalised full-resolution copy is never written
-            a, self.pool_idx = ops.maxpool3x3s2_idx(y0, u.scale, u.shift)
+            if self.stem_pooled_sums:       # ... and keep the raw winners: the reverse pass takes the BatchNorm-reverse sums from the pooled tensors
+                a, self.pool_idx, self.pool_win = ops.maxpool3x3s2_idx_win(y0, u.scale, u.shift)
+                self.pool_out = a
+            else:
+                a, self.pool_idx = ops.maxpool3x3s2_idx(y0, u.scale, u.shift)
             self.r0 = None
         else:
             self.r0 = ops.bn_act(y0, u.scale, u.shift, relu=True)
@@ -869,7 +876,10 @@ class TrainStep:
             if self.stem_bwd_two_pass:
                 # the same walk twice - sums, then the BatchNorm reverse applied where the scattered gradient is formed: that gradient (as
                 # large as the stem's output: 0.54 GB at C2) is never written or read back (MHE_STEM_BWD_TWO_PASS=0: one walk + an apply pass)
-                ops.maxpool3x3s2_bwd_bn(g, self.pool_idx, u.y, u.scale, u.shift, u.mi, st, want_gx=False)
+                if self.stem_pooled_sums:   # the sums from the pooled tensors (the gradient is non-zero at the pool's winners only): no first walk
+                    ops.pooled_bn_sums(g, self.pool_out, self.pool_win, u.mi, st)
+                else:
+                    ops.maxpool3x3s2_bwd_bn(g, self.pool_idx, u.y, u.scale, u.shift, u.mi, st, want_gx=False)
                 coef = ops.bn_bwd_coef(st, u.bn.weight.data, u.mi, u.dgamma, u.dbeta, u.y.numel() // u.cout)
                 gy0 = ops.maxpool3x3s2_bwd_bn_apply(g, self.pool_idx, u.y, u.scale, u.shift, u.mi, coef)
             else:

@@ -287,6 +287,21 @@ def test_stem_pool_with_batchnorm_folded_in(gpu_lib, dt, H, W):
     st2 = torch.zeros_like(st)
     assert ops.maxpool3x3s2_bwd_bn(gy, idx, y0d, sc, sh, mi, st2, want_gx=False) is None
     assert_close(ops.stat_totals(st2).cpu(), ops.stat_totals(st).cpu(), 1e-6, what="sums of the walk that stores nothing")
+    # round 4: the same sums from the POOLED tensors alone (the gradient is non-zero at the winners only): the pool also keeps the raw
+    # input at every winner.  f32: equal to summation order; bf16: where two windows picked one pixel the walk rounds the sum of their
+    # gradients to bf16 first (as the apply walk stores it), here the terms enter exactly - a last-bit difference on those pixels
+    a3, idx3, win = ops.maxpool3x3s2_idx_win(y0d, sc, sh)
+    assert torch.equal(a3, a) and torch.equal(idx3, idx)
+    ho, wo = torch.meshgrid(torch.arange(a.shape[1]), torch.arange(a.shape[2]), indexing="ij")
+    hi = (2 * ho.view(1, -1, a.shape[2], 1) - 1 + idx.cpu().long() // 3).clamp(0, H - 1)
+    wi = (2 * wo.view(1, a.shape[1], -1, 1) - 1 + idx.cpu().long() % 3).clamp(0, W - 1)
+    bi = torch.arange(B).view(-1, 1, 1, 1).expand_as(hi)
+    ci = torch.arange(C).view(1, 1, 1, -1).expand_as(hi)
+    assert torch.equal(win.cpu(), y0d.cpu()[bi, hi, wi, ci])
+    st3 = torch.zeros_like(st)
+    ops.pooled_bn_sums(gy, a, win, mi, st3)
+    t3, t1 = ops.stat_totals(st3).cpu(), ops.stat_totals(st).cpu()
+    assert_close(t3, t1, 1e-5 if dt == torch.float32 else 2e-3, what="sums from the pooled tensors")
     gamma = (torch.rand(C, generator=g) + 0.5).cuda()
     dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
     coef = ops.bn_bwd_coef(st, gamma, mi, dg, db, B * H * W)
