@@ -427,7 +427,8 @@ int mhe_sum_over_hypotheses_f32(const float *rows, float *out, int N, int B, int
 
 /* dW[Cout][KH*KW*Cin] += gy^T (*) x : weight gradient of mhe_conv2d_nhwc (x [B,H,W,Cin], gy [B,Ho,Wo,Cout]
  * of d->dtype storage, dW f32 with row pitch ldw >= KH*KW*Cin, 0 = dense).  The caller zeroes dW; partial sums of the
- * pixel-range split are added with f32 atomics.  With H = W = KH = KW = 1 it is the weight gradient of a dense
+ * pixel-range split are added with f32 atomics HERE (order-dependent in the last bits) - mhe_conv_wgrad_ws_nhwc below takes a workspace
+ * and sums them in a fixed order (what the train step uses).  With H = W = KH = KW = 1 it is the weight gradient of a dense
  * layer, dW[N][K] += gy[R,N]^T x[R,K] (torch.nn.Linear layout).  Cin, Cout multiples of 4. */
 int mhe_conv_wgrad_nhwc(const mhe_conv_desc *d, const void *x, const void *gy, float *dw, int ldw, void *stream);
 /* The same with a workspace of >= mhe_conv_wgrad_workspace_floats(d) floats: every pixel-range slice stores its partial tile

@@ -389,7 +389,7 @@ __device__ __forceinline__ void epilogue(const Params &p, AccT &acc, LdsT &lds, 
     const int wr = wave / WN, wc = wave % WN;
     // ---- epilogue.  The accumulator holds y^T: lane (l15, q) owns channels 4q..4q+3 of tile nt
     // for pixel 16mt + l15.  (1) batch statistics: per-thread partials -> LDS -> one thread per
-    // (statistic, channel) -> ONE coalesced f32 atomic per thread into this block's shard.
+    // (statistic, channel) -> one order-independent fixed-point add (fx::add: two 64-bit integer atomics) per thread into this block's shard.
     // (2) the tile is transposed through LDS (16-byte chunks XOR-swizzled by row) so that global
     // stores are whole 16-byte pieces of contiguous channel rows instead of 8-byte row-strided ones.
     constexpr int CPR = BN * (int)sizeof(T) / 16;          // 16-byte chunks per output row

@@ -8,7 +8,8 @@
 // contiguous, 8/16-byte loads); a stage of BK = 16 pixels is staged in LDS as f32 [pixel][channel] rows,
 // which IS the [k][m] / [k][n] image v_mfma_f32_16x16x4_f32 wants (lane = 16*k + m reads one dword,
 // conflict-free with a 16-dword row pad).  f32 accumulate of f32 or bf16 operands; the pixel range is
-// split over gridDim.z and partial tiles are added to dW with f32 atomics (dW zeroed by the caller).
+// split over gridDim.z; the partial tiles go through workspace slabs + a fixed-order reducer (mhe_conv_wgrad_ws_nhwc: what the train step
+// uses - bit-reproducible sums) or, without a workspace, are added to dW with f32 atomics (dW zeroed by the caller).
 // Roofline: MFMA f32 (157 TFLOP/s); algorithmic bytes per launch = |x| + |gy| + 4|dW|.
 #include "common.h"
 #include <cstring>

@@ -466,7 +466,7 @@ def test_row_streaming_3x3_kernel(gpu_lib, B, H, form):
 def test_bottleneck_tail_with_conv3_reevaluated(gpu_lib, geom, affine2):
     """variant 12 (csrc/conv_fuse.hip): statistics-only conv3 + the fused tail that evaluates conv3 again, against the path it replaces -
     conv3 written out (mhe_conv2d_nhwc, BatchNorm on load) then read back by mhe_conv1x1_residual_in_nhwc.  Same products in the same
-    order: block output, next conv1 output bit-identical; statistics to the f32 atomics' order.  And against torch in f64 (bf16 tolerance).
+    order: block output, next conv1 output bit-identical; statistics to the summation order of the per-thread partials.  And against torch in f64 (bf16 tolerance).
     The last two geometries give every workgroup several tiles (persistent loop, cross-tile prefetch)."""
     from mhentropy_amd import ops, resnet
     B, H, W, Cb, N2 = geom
@@ -687,7 +687,7 @@ def test_conv3_batchnorm_reverse_from_gram_statistics_against_autograd(gpu_lib, 
     w_cat, c0b = torch.zeros(Cb, C4 + Cb, device="cuda", dtype=torch.bfloat16), torch.zeros(Cb, device="cuda")
     ops.conv3_bn_fold(D2, wd, gbuf[1], rev, gamma.cuda(), mi, P, torch.zeros(C4, device="cuda"), torch.zeros(C4, device="cuda"),
                       torch.zeros(C4, Cb, device="cuda"), w_cat, None, c0b, torch.zeros(2 * C4, device="cuda"))
-    # (D comes out of a split-K launch with f32 atomics: a second evaluation may differ in the last bit, and so a bf16 rounding of S)
+    # (up to round 3 D came out of a split-K launch with f32 atomics and a second evaluation could differ in the last bit; slabs + a fixed-order reducer now)
     assert_close(w_cat[:, :C4].float().cpu(), w_dg.float().cpu(), 4e-3, what="(k2 W)^T in the concatenated weights")
     assert_close(w_cat[:, C4:].float().cpu(), S.float().cpu(), 4e-3, what="S in the concatenated weights")
     assert_close(c0b.cpu(), c0.cpu(), 1e-4, what="c0")

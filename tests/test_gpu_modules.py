@@ -451,7 +451,7 @@ def test_c2_size_bf16_graph_replay_equals_eager(gpu_lib):
 def test_trunk_with_conv3_reevaluated_equals_the_stored_form(gpu_lib, training, stats):
     """MHE_FUSE_RECOMPUTE (layer1 / layer2 of ResNet-50 in bf16: conv3's raw output never written, csrc/conv_fuse.hip) against the same
     trunk writing and re-reading it.  stats = "stream": bn3's statistics from the statistics-only launch - same products in the same
-    order, the pooled feature and the BatchNorm buffers agree to the summation order of the f32 atomics.  stats = "gram" (the default):
+    order, the pooled feature and the BatchNorm buffers agree to the grouping of the statistics' partial sums.  stats = "gram" (the default):
     statistics of the f32 products from the input's Gram matrix (csrc/conv_gram.hip) instead of the bf16-rounded outputs - bn3's batch
     statistics agree to ~1e-4; downstream a changed bf16 rounding is amplified by the later train-mode BatchNorms over this test's 128
     samples per channel, so the pooled feature is only held to the band by which bf16 storage itself moves it (measured 7e-2)."""
@@ -471,7 +471,7 @@ def test_trunk_with_conv3_reevaluated_equals_the_stored_form(gpu_lib, training, 
     (f1, rv1, rm1, n1), (f0, rv0, rm0, n0) = outs
     d = ((f1 - f0).abs().mean() / f0.abs().mean()).item()
     print(f"trunk feature, conv3 re-evaluated vs stored (training={training}, statistics={stats}): mean-rel {d:.2e}")
-    # training: even the summation order of the statistics' f32 atomics (stats = "stream": otherwise identical arithmetic) can flip a bf16
+    # training: even another grouping of the statistics' partial sums (stats = "stream": otherwise identical arithmetic) can flip a bf16
     # rounding that the later BatchNorms over 128 samples amplify to ~5e-2 of the pooled feature (measured) - the tight check is on the
     # first bn3's buffers below; eval (running statistics): bit-level agreement
     assert d < (1e-6 if not training else 2e-1), d

@@ -503,7 +503,7 @@ def test_autograd_bridge_runs_the_references_loop_unchanged(gpu_lib):
             for (n, p), (_, q) in zip(models[1].named_parameters(), models[0].named_parameters()):
                 if p.grad is None:
                     continue
-                # two separate runs of the same arithmetic: the f32 atomics' order differs, and a ReLU / max-pool decision that
+                # two separate runs of the same arithmetic (rounds 1-3: the f32 atomics' order differed), and a ReLU / max-pool decision that
                 # flips under that round-off moves single elements by O(1 %) (tools/debug_bridge.py: 6e-7 when the launch
                 # histories match, up to 2e-4 .. 1e-2 otherwise) - so a norm-wise bound
                 a, b = p.grad.double().cpu(), fused.grad_of(q).double().cpu()
@@ -838,7 +838,7 @@ def test_conv3_reverse_on_gram_statistics_equals_the_pass_that_reads_y3(gpu_lib)
                    ("layer2.3.conv1.weight", 2e-2)):
         assert rel(gC[pre + n], gB[pre + n]) <= tol, (n, rel(gC[pre + n], gB[pre + n]))
     # through the six further folds the difference stays at the bf16 level in the residual layers (it grows by ~1.5e-3 per block here), and
-    # so does the run-to-run spread of C itself (the f32 atomics of D's split-K change a last bit of the bf16-rounded S / k2 W); the stem's
+    # so did the run-to-run spread of C itself up to round 3 (f32 atomics of D's split-K; C2 == C exactly since round 4); the stem's
     # own few parameters sit behind the max pool's reverse and see up to 1e-1 (the band of the other whole-trunk comparisons: 2e-1)
     layers = [n for n in trunk if ".layer" in n]
     worst = max((rel(gC[n], gB[n]), n) for n in layers)
@@ -876,8 +876,8 @@ def test_shortcut_reverse_on_gram_statistics_equals_the_pass_over_its_output(gpu
     rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
     gP, gF, gF2 = res["pass"][0], res["fold"][0], res["fold again"][0]
     pre = "feat_extractor.res."
-    # upstream of the shortcut nothing changes but the run-to-run spread of the reverse pass itself (f32 atomics of the small weight gradients,
-    # amplified by the train-mode BatchNorm layers in between: measured below as fold against fold)
+    # upstream of the shortcut nothing changes (up to round 3: nothing but the run-to-run spread of the reverse pass itself - f32 atomics of the
+    # small weight gradients, amplified by the train-mode BatchNorm layers in between; measured below as fold against fold: 0 now)
     for n in ("layer2.0.downsample.0.weight", "layer1.1.conv1.weight", "layer1.0.conv3.weight"):
         spread = rel(gF2[pre + n], gF[pre + n])
         print(f"upstream {n}: fold vs pass {rel(gF[pre + n], gP[pre + n]):.2e}, fold vs fold {spread:.2e}")
