@@ -111,13 +111,22 @@ __device__ __forceinline__ void wave_totals(acc_t *unit, int C, int c, int lane,
         t0 = bad0 ? __builtin_nan("") : d0; t1 = bad1 ? __builtin_nan("") : d1;
         return;
     }
+    // Four words per lane, 64 lanes -> four totals with 7 cross-lane exchanges of a 64-bit word instead of the 24 of four butterflies (the
+    // exchanges - ds_bpermute pairs - were most of this kernel's time above its launch floor): at xor 32 a lane hands over the statistic its
+    // half does not keep, at xor 16 the word its quarter does not keep; four butterfly steps finish one word per lane.  Integer sums:
+    // the same totals whatever the order.
+    const bool up = (lane & 32) != 0, lw = (lane & 16) != 0;
+    acc_t kh = up ? hi1 : hi0, kl = up ? lo1 : lo0;
+    kh += __shfl_xor(up ? hi0 : hi1, 32, 64);
+    kl += __shfl_xor(up ? lo0 : lo1, 32, 64);
+    acc_t k = lw ? kl : kh;
+    k += __shfl_xor(lw ? kh : kl, 16, 64);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        hi0 += __shfl_xor(hi0, o, 64); lo0 += __shfl_xor(lo0, o, 64);
-        hi1 += __shfl_xor(hi1, o, 64); lo1 += __shfl_xor(lo1, o, 64);
-    }
-    t0 = bad0 ? __builtin_nan("") : value2(hi0, lo0);
-    t1 = bad1 ? __builtin_nan("") : value2(hi1, lo1);
+    for (int o = 8; o > 0; o >>= 1) k += __shfl_xor(k, o, 64);
+    // lane 0: hi of statistic 0, lane 16: its lo; lanes 32 / 48: statistic 1
+    const acc_t H0 = __shfl(k, 0, 64), L0 = __shfl(k, 16, 64), H1 = __shfl(k, 32, 64), L1 = __shfl(k, 48, 64);
+    t0 = bad0 ? __builtin_nan("") : value2(H0, L0);
+    t1 = bad1 ? __builtin_nan("") : value2(H1, L1);
 }
 __device__ __forceinline__ double wave_total(acc_t *unit, int stat, int C, int c, int lane, bool clear) {
     acc_t *p = unit + ((size_t)lane * 2 + stat) * C + c;
@@ -130,9 +139,14 @@ __device__ __forceinline__ double wave_total(acc_t *unit, int stat, int C, int c
         for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
         return bad ? __builtin_nan("") : d;
     }
+    // (as above: the upper half keeps the low word, the lower half the high word - 6 exchanges instead of 12)
+    const bool up = (lane & 32) != 0;
+    acc_t k = up ? lo : hi;
+    k += __shfl_xor(up ? hi : lo, 32, 64);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { hi += __shfl_xor(hi, o, 64); lo += __shfl_xor(lo, o, 64); }
-    return bad ? __builtin_nan("") : value2(hi, lo);
+    for (int o = 16; o > 0; o >>= 1) k += __shfl_xor(k, o, 64);
+    const acc_t Hs = __shfl(k, 0, 64), Ls = __shfl(k, 32, 64);
+    return bad ? __builtin_nan("") : value2(Hs, Ls);
 }
 }  // namespace fx
 
