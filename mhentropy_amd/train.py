@@ -136,13 +136,21 @@ class TrainStep:
         if self.dev.type != "cuda":
             raise RuntimeError("TrainStep needs the model on a HIP device (there is no CPU path)")
         self._flatten_params()
+        import os
         # derived operand layouts: two arenas (f32 / bf16), each refreshed by ONE gather per step over one concatenated index
         # table (a gather per tensor was ~340 launches of ~5 us)
+        # ... and a second pair for the operand layouts only the FALLBACK paths of the flow read (coupling-by-coupling reverse pass, the
+        # second-generation coupling kernel for hypothesis counts that are not a multiple of 64 per image): refreshed lazily, when such a path
+        # runs (`_need_fallback`) - with the one-launch forward and reverse kernels they were gathered every step to be read by nobody
+        # (33 M of the 118 M+ gathered elements at the shipped flow's size)
         self._arena = {dt: {"buf": torch.zeros(4 * self.n_params, device=self.dev, dtype=dt), "used": 0, "idx": [], "idx2": []}
                        for dt in (torch.float32, torch.bfloat16)}
+        self._arena_fb = {dt: {"buf": None, "used": 0, "idx": [], "idx2": []} for dt in (torch.float32, torch.bfloat16)}
+        self._fb_lazy = os.environ.get("MHE_LAZY_FALLBACK_TABLES", "1") == "1"
+        self._fb_keep = not self._fb_lazy     # True: every repack refreshes them (as soon as a step has needed them once)
+        self._fb_stale = False
         self._raw_n = 0
         self._unpack = torch.full((self.n_params,), -1, dtype=torch.int64)
-        import os
         self.cond_bwd_bf16 = os.environ.get("MHE_COND_BWD_BF16", "1") == "1"      # (read by _build_flow)
         self._build_trunk()
         self._build_heads()
@@ -174,8 +182,10 @@ class TrainStep:
         for u in self._raw_views:
             u()
         self._unpack_idx = self._unpack.to(torch.int32).to(self.dev)
-        for a in self._arena.values():
+        for a in list(self._arena.values()) + list(self._arena_fb.values()):
             n = a["used"]
+            if a["buf"] is None:
+                a["buf"] = torch.zeros(0, device=self.dev, dtype=torch.float32)
             a["view"] = a["buf"][:n]
             a["idx"] = (torch.cat(a["idx"]) if a["idx"] else torch.zeros(0, dtype=torch.int64)).to(torch.int32).to(self.dev).contiguous()
             i2 = torch.cat(a["idx2"]) if a["idx2"] else torch.zeros(0, dtype=torch.int64)
@@ -192,7 +202,7 @@ class TrainStep:
             fragp = ((f0["f0F"], f0["f1F"], f0["f2F"], (self.fnets[1]["f1F"].data_ptr() - f0["f1F"].data_ptr()) // 2)
                      if "f1F" in f0 and len(self.fnets) > 1 else None)
             self.flow._external_pack = (self.f_stream, self.f_b2, self.f_wc, self.f_bc, self.f_wcb, fragp)
-            self.flow._external_sync = self.sync
+            self.flow._external_sync = self.sync_all
         self.trunk._external_w = {id(u.conv.weight): u.w_fwd for u in self.units}
         self.trunk._external_sync = self.sync
         self._G_averaged = False
@@ -260,11 +270,14 @@ class TrainStep:
         o = self.off[id(p)]
         return self.G[o:o + p.numel()].view(p.shape)
 
-    def _derived(self, idx, dtype, idx2=None):
-        """a tensor refreshed every step as P[idx] (+ P[idx2]); idx int64 with -1 = 0"""
-        a = self._arena[dtype]
+    def _derived(self, idx, dtype, idx2=None, fallback=False):
+        """a tensor refreshed every step as P[idx] (+ P[idx2]); idx int64 with -1 = 0.  fallback=True: a layout only the flow's fallback
+        paths read - refreshed when one of them runs (`_need_fallback`)"""
+        a = (self._arena_fb if fallback else self._arena)[dtype]
         n = idx.numel()
         room = _ceil(n, 8)                                    # 16-byte aligned views
+        if a["buf"] is None:
+            a["buf"] = torch.zeros(2 * self.n_params, device=self.dev, dtype=dtype)
         if a["used"] + room > a["buf"].numel():
             raise RuntimeError("TrainStep: derived-operand arena exhausted")
         dst = a["buf"][a["used"]:a["used"] + n].view(idx.shape)
@@ -417,6 +430,8 @@ class TrainStep:
         dim, h, ncoup = fl.dim, fl.hidden, len(fl.mask)
         bf16 = fl.compute_dtype == torch.bfloat16 and h % 128 == 0
         self.flow_bf16 = bf16
+        # the one-launch forward / reverse kernels (hidden 512) read fragment-major layouts of their own: everything else is a fallback layout
+        self.flow_fused_tables = bool(bf16 and h == 512 and self._fb_lazy)
         loc = torch.from_numpy(flow_stream_table(fl.dim, fl.hidden, bf16))
         n0, n1 = h * dim, h * h
         streams, b2, wc, bc1, bc2, nets = [], [], [], [], [], []
@@ -437,15 +452,16 @@ class TrainStep:
                 w0i = torch.full((h, 64), -1, dtype=torch.int64); w0i[:, :dim] = self._pidx(net.l[0].weight)
                 w2i = torch.full((64, h), -1, dtype=torch.int64); w2i[:dim] = self._pidx(net.l[2].weight)
                 b2i = torch.full((64,), -1, dtype=torch.int64); b2i[:dim] = self._pidx(net.l[2].bias)
-                d["w0"], d["w0T"] = self._derived(w0i, torch.float32), self._derived(w0i.t().contiguous(), torch.float32)
-                d["w1"], d["w1T"] = net.l[1].weight.data, self._derived(self._pidx(net.l[1].weight).t().contiguous(), torch.float32)
+                fb = self.flow_fused_tables        # (the f32 / plain bf16 layouts below are the fallback paths' when the fragment-major ones exist)
+                d["w0"], d["w0T"] = self._derived(w0i, torch.float32, fallback=fb), self._derived(w0i.t().contiguous(), torch.float32, fallback=fb)
+                d["w1"], d["w1T"] = net.l[1].weight.data, self._derived(self._pidx(net.l[1].weight).t().contiguous(), torch.float32, fallback=fb)
                 if bf16:        # bf16 operand copies for the products that run on bf16 MFMA (all but the two 64-wide f32 ones)
-                    d["w1b"] = self._derived(self._pidx(net.l[1].weight), torch.bfloat16)
-                    d["w1Tb"] = self._derived(self._pidx(net.l[1].weight).t().contiguous(), torch.bfloat16)
-                    d["w0b"] = self._derived(w0i, torch.bfloat16)                           # [h, 64]: XP W0^T
-                    d["w2Tb"] = self._derived(w2i.t().contiguous(), torch.bfloat16)         # [h, 64]: GO W2
-                    d["w2b"] = self._derived(w2i, torch.bfloat16)                           # [64, h]: H1 W2^T (f32 result)
-                    d["w0Tb"] = self._derived(w0i.t().contiguous(), torch.bfloat16)         # [64, h]: G1 W0 (f32 result)
+                    d["w1b"] = self._derived(self._pidx(net.l[1].weight), torch.bfloat16, fallback=fb)
+                    d["w1Tb"] = self._derived(self._pidx(net.l[1].weight).t().contiguous(), torch.bfloat16, fallback=fb)
+                    d["w0b"] = self._derived(w0i, torch.bfloat16, fallback=fb)                           # [h, 64]: XP W0^T
+                    d["w2Tb"] = self._derived(w2i.t().contiguous(), torch.bfloat16, fallback=fb)         # [h, 64]: GO W2
+                    d["w2b"] = self._derived(w2i, torch.bfloat16, fallback=fb)                           # [64, h]: H1 W2^T (f32 result)
+                    d["w0Tb"] = self._derived(w0i.t().contiguous(), torch.bfloat16, fallback=fb)         # [64, h]: G1 W0 (f32 result)
                     # the three [out][k] operands again in MFMA fragment order: what the one-launch reverse chain reads (csrc/flow_rev.hip)
                     d["w1Fb"] = self._derived(ops.mfma_fragment_major(self._pidx(net.l[1].weight).t()), torch.bfloat16)
                     d["w2Fb"] = self._derived(ops.mfma_fragment_major(w2i.t()), torch.bfloat16)
@@ -454,15 +470,15 @@ class TrainStep:
                     d["f1F"] = self._derived(ops.mfma_fragment_major(self._pidx(net.l[1].weight)), torch.bfloat16)
                     d["f0F"] = self._derived(ops.mfma_fragment_major(w0i), torch.bfloat16)
                     d["f2F"] = self._derived(ops.mfma_fragment_major(w2i), torch.bfloat16)
-                d["w2"], d["w2T"] = self._derived(w2i, torch.float32), self._derived(w2i.t().contiguous(), torch.float32)
-                d["b2"] = self._derived(b2i, torch.float32)
+                d["w2"], d["w2T"] = self._derived(w2i, torch.float32, fallback=fb), self._derived(w2i.t().contiguous(), torch.float32, fallback=fb)
+                d["b2"] = self._derived(b2i, torch.float32, fallback=fb)
                 d["r0"], d["r1"], d["r2"], d["rb2"] = (self._raw_slot(s) for s in ((h, 64), (h, h), (64, h), (64,)))
                 self._map_grad(net.l[0].weight, (torch.arange(h * 64, dtype=torch.int64).view(h, 64) + d["r0"])[:, :dim])
                 self._map_grad(net.l[1].weight, torch.arange(h * h, dtype=torch.int64).view(h, h) + d["r1"])
                 self._map_grad(net.l[2].weight, (torch.arange(64 * h, dtype=torch.int64).view(64, h) + d["r2"])[:dim])
                 self._map_grad(net.l[2].bias, torch.arange(dim, dtype=torch.int64) + d["rb2"])
                 self.fnets.append(d)
-        self.f_stream = self._derived(torch.cat(streams), torch.bfloat16 if bf16 else torch.float32)
+        self.f_stream = self._derived(torch.cat(streams), torch.bfloat16 if bf16 else torch.float32, fallback=self.flow_fused_tables)
         self.f_b2 = self._derived(torch.stack(b2), torch.float32)
         # bf16 mode with the conditioning products in bf16 (forward table, dWc, g_feat): the two f32 copies (2 x 12.6 M elements at C2) would
         # only be gathered every step to be read by nobody
@@ -494,6 +510,29 @@ class TrainStep:
         for a in self._arena.values():
             if a["idx"].numel():
                 ops.gather(self.P, a["idx"], a["view"], a["idx2"])
+        if self._fb_keep:
+            self._repack_fallback()
+        else:
+            self._fb_stale = True
+
+    def _repack_fallback(self):
+        for a in self._arena_fb.values():
+            if a["idx"].numel():
+                ops.gather(self.P, a["idx"], a["view"], a["idx2"])
+        self._fb_stale = False
+
+    def _need_fallback(self):
+        """called by every path that reads a fallback layout (this class's coupling-by-coupling passes, the modules' own forward / sample
+        paths through sync_all): brings the layouts up to the current parameters if the last repack skipped them, and keeps them fresh from
+        now on (this process evidently runs such steps)"""
+        if self._fb_stale:
+            self._repack_fallback()
+        self._fb_keep = True
+
+    def sync_all(self):
+        """sync() for the modules' own paths, which may read any layout (RealNVP._packed: the second-generation kernel's stream)"""
+        self.sync()
+        self._need_fallback()
 
     def sync(self):
         """refresh every derived operand layout if someone else (torch.optim through the attach() bridge, load_state_dict)
@@ -963,6 +1002,8 @@ class TrainStep:
                 # reverse - the rows and their transpose - come from one pack launch instead of a scattered second layout + two casts)
                 self._Gc_packed = ops.pack_transpose_bf16(Gc, out=self._buf("Gcond_b", (B, cstride), bf), outT=self._buf("GcondT_b", (cstride, B), bf))
                 x_cur = z0r
+            if not fused:
+                self._need_fallback()                  # the coupling-by-coupling pass reads the plain operand layouts
             for i in range(ncoup - 1, -1, -1) if not fused else ():
                 m = fl.mask[i]
                 if grouped:
@@ -1105,9 +1146,11 @@ class TrainStep:
                                                              ops.FLOW_FORWARD, emit=kept, sign_bits=sg)
                     self._flow_sign = sg
                 else:
+                    self._need_fallback()              # the second-generation kernel's stream
                     th45, _, log_q = ops.flow_couplings_emit(z0, cond, self.f_stream, self.f_b2, fl.mask, B, h, ops.FLOW_FORWARD, *kept)
                 self._flow_kept = kept
             else:
+                self._need_fallback()
                 th45, _, log_q = ops.flow_couplings(z0, cond, self.f_stream, self.f_b2, fl.mask, B, h, ops.FLOW_FORWARD)
         blob = m.mano_dec.table_blob()
         cu, vis = y["crop_uv"].contiguous(), y["vis"].contiguous()
@@ -1304,6 +1347,7 @@ class GraphedStep:
             self.graphs.append(self._cur)
         cur.wait_stream(side)
         torch.cuda.synchronize()
+        self._fb_in_graph = ts._fb_keep        # does the captured end-of-step repack refresh the flow's fallback layouts? (replay())
 
     def cut(self, action):
         self._cur.capture_end()
@@ -1314,6 +1358,8 @@ class GraphedStep:
 
     def replay(self):
         ts = self.ts
+        if not self._fb_in_graph:              # the captured repack did not refresh the fallback layouts: they no longer follow the parameters
+            ts._fb_stale = True
         for k, g in enumerate(self.graphs):
             g.replay()
             if k < len(self.actions):

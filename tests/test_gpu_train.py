@@ -957,3 +957,60 @@ def test_resident_tile_3x3_kernel_in_the_train_step_equals_the_im2col_kernels(gp
     # same figure as in the shortcut test above), its weight gradient 6.5e-2
     stem = [e for e in errs if ".layer" not in e[1]]
     assert all(e[0] < (1.0 if e[1].endswith("res.bn1.bias") else 1.5e-1) for e in stem), stem
+
+
+def test_fallback_operand_layouts_are_refreshed_when_a_fallback_path_runs(gpu_lib):
+    """The flow's plain operand layouts (the second-generation coupling kernel's stream, the coupling-by-coupling reverse pass's matrices)
+    are not re-gathered after every optimizer step while only the one-launch kernels run (hidden 512, 64 hypotheses per image): a path
+    that reads them - here the modules' own `sample` with 3 hypotheses per image, and a train step with 16 hypotheses per image - must
+    find them at the CURRENT parameters, after eager steps and after HIP-graph replays alike (compared with a fresh model built from
+    the state_dict, which packs its operands from scratch)."""
+    from mhentropy_amd.train import TrainStep, GraphedStep
+    B = 2
+    xn, yn = synth.batch(7, B, image_size=96)
+    x, y = torch.as_tensor(xn).cuda(), {k: torch.as_tensor(v).cuda() for k, v in yn.items()}
+    z64, z3 = torch.as_tensor(synth.noise(7, 64 * B)).cuda(), torch.as_tensor(synth.noise(8, 3 * B)).cuda()
+    z16 = torch.as_tensor(synth.noise(9, 16 * B)).cuda()
+
+    def sample_of(m):
+        m.eval()
+        with torch.no_grad():
+            o = m.sample(x, N=[3, 3], temp=0.8, mods={"uv"}, y=y, noise=z3)
+        m.train()
+        assert torch.isfinite(o["uv"]).all()
+        return o["uv"].float().cpu()
+
+    def fresh_like(model):
+        f, _ = _model_and_state("resnet18", 512, 2, dtype=torch.bfloat16)
+        f.load_state_dict(model.state_dict())
+        return f
+
+    model, _ = _model_and_state("resnet18", 512, 2, dtype=torch.bfloat16)
+    ts = TrainStep(model, lr=1e-3)                          # steps large enough that stale layouts would be visible (1e-2 diverges in two steps)
+    assert ts.flow_fused_tables and not ts._fb_keep
+    for _ in range(2):
+        ts.step(x, y, noise=z64, N=64)                      # the one-launch kernels only: the fallback layouts are left behind
+    assert ts._fb_stale and not ts._fb_keep
+    assert_close(sample_of(model), sample_of(fresh_like(model)), 1e-5, what="sample after eager steps on the one-launch kernels")
+    assert ts._fb_keep and not ts._fb_stale                 # ... refreshed on demand, and kept fresh from now on
+    ts.step(x, y, noise=z64, N=64)
+    assert not ts._fb_stale
+    assert_close(sample_of(model), sample_of(fresh_like(model)), 1e-5, what="sample after a further step")
+    # graph replays: the captured repack of a trainer that never needed the layouts does not refresh them
+    model2, _ = _model_and_state("resnet18", 512, 2, dtype=torch.bfloat16)
+    ts2 = TrainStep(model2, lr=1e-3)
+    gs = GraphedStep(ts2, x, y, noise=z64, N=64)
+    assert not gs._fb_in_graph
+    gs.replay(); gs.replay()
+    torch.cuda.synchronize()
+    assert ts2._fb_stale
+    assert_close(sample_of(model2), sample_of(fresh_like(model2)), 1e-5, what="sample after graph replays")
+    gs.replay()
+    torch.cuda.synchronize()
+    assert ts2._fb_stale                                    # (the replay cannot refresh them: stale again, refreshed again on demand)
+    assert_close(sample_of(model2), sample_of(fresh_like(model2)), 1e-5, what="sample after a further replay")
+    # a train step that takes the coupling-by-coupling passes itself (16 hypotheses per image) equals the same step of a fresh trainer
+    out = ts2.forward_backward(x, y, noise=z16, N=16)
+    ts3 = TrainStep(fresh_like(model2), lr=1e-3)
+    ref = ts3.forward_backward(x, y, noise=z16, N=16)
+    assert torch.equal(out["log_p"], ref["log_p"]) and torch.equal(ts2.G, ts3.G)
