@@ -530,8 +530,16 @@ __global__ void upsample2_kernel(const T *__restrict__ g, const T *__restrict__ 
 constexpr int SQ_BLOCKS = 1024;
 __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float *__restrict__ g, size_t n, float *__restrict__ partial) {
     __shared__ float red[4];
+    // 16-byte loads, two in flight per thread (4-byte lanes read the 184 MB gradient of config C2 at 2.4 TB/s); a fixed order all the same
     float acc = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)SQ_BLOCKS * 256) acc = fmaf(g[i], g[i], acc);
+    const size_t n4 = n / 4, S = (size_t)SQ_BLOCKS * 256;
+    const float4 *g4 = reinterpret_cast<const float4 *>(g);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += 2 * S) {
+        const float4 a = g4[i], b = i + S < n4 ? g4[i + S] : make_float4(0.f, 0.f, 0.f, 0.f);
+        acc = fmaf(a.x, a.x, acc); acc = fmaf(a.y, a.y, acc); acc = fmaf(a.z, a.z, acc); acc = fmaf(a.w, a.w, acc);
+        acc = fmaf(b.x, b.x, acc); acc = fmaf(b.y, b.y, acc); acc = fmaf(b.z, b.z, acc); acc = fmaf(b.w, b.w, acc);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - 4 * n4)) { const float t = g[4 * n4 + threadIdx.x]; acc = fmaf(t, t, acc); }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -774,7 +782,7 @@ extern "C" int mhe_upsample2_nhwc(const void *g, const void *base, void *out, in
 extern "C" size_t mhe_sqnorm_workspace_floats(void) { return tb::SQ_BLOCKS; }
 
 extern "C" int mhe_sqnorm_f32(const float *g, size_t n, float *workspace, float *out, void *stream) {
-    MHE_REQUIRE(g && workspace && out && n > 0, "mhe_sqnorm_f32: bad arguments");
+    MHE_REQUIRE(g && workspace && out && n > 0 && (uintptr_t)g % 16 == 0, "mhe_sqnorm_f32: bad arguments (g 16-byte aligned)");
     hipLaunchKernelGGL(tb::sqnorm_partial_kernel, dim3(tb::SQ_BLOCKS), dim3(256), 0, (hipStream_t)stream, g, n, workspace);
     hipLaunchKernelGGL(tb::sqnorm_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, out);
     return check_launch("sqnorm_kernel");
