@@ -711,7 +711,10 @@ extern "C" int mhe_pooled_bn_sums_nhwc(const void *g, const void *pooled, const 
     MHE_REQUIRE(C > 0 && C % E == 0 && 256 % (C / E) == 0, "mhe_pooled_bn_sums_nhwc: C=%d: C / %d must divide 256 (a thread keeps one channel chunk)", C, E);
     MHE_REQUIRE(((uintptr_t)g | (uintptr_t)pooled | (uintptr_t)xwin) % 16 == 0, "mhe_pooled_bn_sums_nhwc: 16-byte aligned tensors");
     const size_t nl = (size_t)P * C / E;
-    const unsigned blocks = ewg((nl + 1) / 2);
+    // few, long-lived workgroups: every workgroup ends with an LDS fold and 4 x C / 8 fixed-point adds by eight of its threads (8,192
+    // one-or-two-iteration workgroups took 143 us for 0.4 GB)
+    unsigned blocks = ewg((nl + 1) / 2);
+    if (blocks > 2048) blocks = 2048;
     if (dtype == MHE_F32)
         hipLaunchKernelGGL(tb::pooled_bn_sums_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)g, (const float *)pooled, (const float *)xwin,
                            mean_invstd, stats, nl, C);
