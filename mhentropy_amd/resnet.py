@@ -110,11 +110,6 @@ class ResNetTrunk(nn.Module):
         # the stem's max pool taken inside the conv1 kernel on the raw output (bf16, 256x256 images; csrc/stem_pool.hip): the
         # full-resolution conv1 output is never written, layer1.0's conv1 / shortcut apply bn1 + ReLU on their operand load
         self.stem_pool_fused = os.environ.get("MHE_STEM_POOL", "1") == "1"
-        # ... and at 256 bottleneck channels (layer3): bn3's statistics from the statistics-only launch of the resident-slab kernel (the same
-        # bf16-rounded products, nothing stored), conv3 evaluated again inside the tail kernel (csrc/conv_fuse256.hip)
-        # Built, bit-identical to the stored form, and NOT faster at config C2 (tail 120-136 us + statistics launch 67 against 102 + 68:
-        # profiles/EXPERIMENTS.md): opt-in
-        self.fuse_recompute256 = os.environ.get("MHE_FUSE_RECOMPUTE256", "0") == "1"
         # the last block's relu(bn(y) + identity) evaluated inside the global average pool (csrc/conv.hip: bn_act_avgpool_kernel)
         self.fuse_pool = os.environ.get("MHE_FUSE_POOL", "1") == "1"
 
@@ -141,17 +136,6 @@ class ResNetTrunk(nn.Module):
         if hit is None or hit[0] != key:
             hit = (key, ops.conv3x3_halo_pack(self._w(conv)))
             self._wcache[("halo", id(p))] = hit
-        return hit[1]
-
-    def _w_tail256(self, conv3, conv1):
-        """(W3, W1) as the stage images of csrc/conv_fuse256.hip (cached like _w; None while a trainer owns the packs)"""
-        if getattr(self, "_external_w", None) is not None:
-            return None
-        key = (id(conv3.weight), conv3.weight._version, id(conv1.weight), conv1.weight._version, conv3.weight.device)
-        hit = self._wcache.get(("t256", id(conv3.weight)))
-        if hit is None or hit[0] != key:
-            hit = (key, ops.bottleneck_tail256_pack(self._w(conv3), self._w(conv1)))
-            self._wcache[("t256", id(conv3.weight))] = hit
         return hit[1]
 
     def _bn_affine(self, y, bn, st, count=None):
@@ -199,10 +183,7 @@ class ResNetTrunk(nn.Module):
                     # ... with the previous block's conv3 evaluated again inside the same kernel (its raw output was never written)
                     kind_p, y2_p, a2_p, w3_p, al_p, idt_p, idaff_p = pending
                     st = pool.take(blk.conv1.out_channels) if self.training else None
-                    if kind_p == "re256":
-                        a, y1 = ops.bottleneck_tail256(y2_p, a2_p, w3_p[0], al_p, idt_p, idaff_p, w3_p[1], stats=st)
-                    else:
-                        a, y1 = ops.bottleneck_tail(y2_p, a2_p, w3_p, al_p, idt_p, idaff_p, self._w(blk.conv1), stats=st)
+                    a, y1 = ops.bottleneck_tail(y2_p, a2_p, w3_p, al_p, idt_p, idaff_p, self._w(blk.conv1), stats=st)
                     a1 = self._bn_affine(y1, blk.bn1, st)
                     pending = None
                 elif pending is not None:
@@ -240,19 +221,7 @@ class ResNetTrunk(nn.Module):
                 recompute = (self.fuse_recompute and self.fuse_tail and nxt is not None and nxt.kind == "bottleneck" and y2.dtype == torch.bfloat16
                              and nxt.conv1.kernel_size == (1, 1) and nxt.conv1.stride == (1, 1)
                              and ops.bottleneck_tail_supported(y2.shape[0], y2.shape[1], y2.shape[2], y2.shape[3], nxt.conv1.out_channels))
-                recompute256 = None
-                if (not recompute and self.fuse_recompute256 and self.fuse_tail and nxt is not None and nxt.kind == "bottleneck" and y2.dtype == torch.bfloat16
-                        and nxt.conv1.kernel_size == (1, 1) and nxt.conv1.stride == (1, 1) and blk.conv3.in_channels == 256
-                        and ops.bottleneck_tail256_supported(y2.shape[0], y2.shape[1], y2.shape[2], 256, nxt.conv1.out_channels)
-                        and ops.conv_tile_choice(y2.shape[0], y2.shape[1], y2.shape[2], 256, blk.conv3.out_channels, 1, 1, 0, y2.dtype, 1) == 11):
-                    recompute256 = self._w_tail256(blk.conv3, nxt.conv1)
-                if recompute256 is not None:
-                    st3 = None
-                    if self.training:        # bn3's batch statistics from the products as they would be stored - nothing is stored
-                        st3 = pool.take(blk.conv3.out_channels)
-                        ops.conv1x1_stats(y2, self._w(blk.conv3), a2[0], a2[1], st3)
-                    yl, al = None, self._bn_affine(None, blk.bn3, st3, count=y2.numel() // y2.shape[-1])
-                elif recompute:
+                if recompute:
                     w3 = self._w(blk.conv3)
                     st3 = None
                     if self.training and self.recompute_stats == "gram":

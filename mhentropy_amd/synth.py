@@ -168,6 +168,29 @@ def batch(seed=0, B=2, image_size=256, with_image=True):
     return x, y
 
 
+def structured_images(seed=0, B=2, image_size=256):
+    """Images with image-to-image structure (a smooth random field per image: random 4x4 / 16x16 colour patterns bilinearly enlarged, a
+    per-image gain and offset, a little pixel noise), in [-1,1].  batch()'s default images are i.i.d. white noise: after global average pooling
+    every image of a batch has almost the same feature, so the part of the gradient that survives train-mode BatchNorm is a small residual
+    of a large batch-constant term - a badly conditioned problem for ANY reduced-precision forward (tools/bf16_grad_sensitivity.py).  The
+    gradient-parity tests of the bf16 mode use these images for a well-conditioned case next to the bench's own workload."""
+    rng = np.random.default_rng(seed + 3500)
+
+    def up(a, S):                                   # bilinear enlargement of (B,3,h,h) to (B,3,S,S), align_corners=False
+        h = a.shape[-1]
+        c = (np.arange(S) + 0.5) * h / S - 0.5
+        i0 = np.clip(np.floor(c).astype(np.int64), 0, h - 1)
+        i1 = np.clip(i0 + 1, 0, h - 1)
+        w = np.clip(c - i0, 0.0, 1.0).astype(np.float32)
+        rows = a[:, :, i0, :] * (1 - w)[None, None, :, None] + a[:, :, i1, :] * w[None, None, :, None]
+        return rows[:, :, :, i0] * (1 - w) + rows[:, :, :, i1] * w
+    S = image_size
+    x = 0.9 * up(rng.normal(0, 1, (B, 3, 4, 4)).astype(np.float32), S) + 0.5 * up(rng.normal(0, 1, (B, 3, 16, 16)).astype(np.float32), S)
+    x = x * rng.uniform(0.3, 1.0, (B, 1, 1, 1)).astype(np.float32) + rng.normal(0, 0.3, (B, 3, 1, 1)).astype(np.float32)
+    x = x + rng.normal(0, 0.05, x.shape).astype(np.float32)
+    return np.clip(x, -1, 1).astype(np.float32)
+
+
 def noise(seed, rows, dim=45):
     """Host-generated base noise z0 ~ N(0, I) (parity runs
     must feed captured noise, GPU and CPU generators differ)."""

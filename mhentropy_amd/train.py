@@ -1290,7 +1290,9 @@ class TrainStep:
         means = [u.mi[0] for u in units]
         var = torch._foreach_pow([u.mi[1] for u in units], -2.0)            # 1/invstd^2 = biased var + eps
         torch._foreach_sub_(var, BN_EPS)
-        torch._foreach_mul_(var, [float(u.y.numel() // u.cout) / max(float(u.y.numel() // u.cout) - 1.0, 1.0) for u in units])
+        # pixels per channel of the unit's output (a folded conv3 - 1x1, stride 1 - never wrote it: its input has the same pixels)
+        npix = [float(u.y.numel() // u.cout) if u.y is not None else float(u.x.numel() // u.cin) for u in units]
+        torch._foreach_mul_(var, [n / max(n - 1.0, 1.0) for n in npix])
         torch._foreach_lerp_([u.bn.running_mean for u in units], means, BN_MOMENTUM)
         torch._foreach_lerp_([u.bn.running_var for u in units], var, BN_MOMENTUM)
         torch._foreach_add_([u.bn.num_batches_tracked for u in units], 1)
@@ -1319,10 +1321,21 @@ class GraphedStep:
     (RCCL, async_op: it runs on the communicator's stream under the next graph's kernels), the next graph starts; the last
     graph (norm, clip, Adam, operand re-pack) is launched after the waits.  Six graphs and four collectives per step."""
 
-    def __init__(self, ts, x, y, noise=None, N=None):
+    def __init__(self, ts, x, y, noise=None, N=None, test_samples=0, criterion=None):
+        """test_samples / criterion: the reference's whole iteration (hand/CrossModalHand.py:349-361,452-470) in the graph - the
+        metrics pass sample(N=[n,n], temp=0.8) from this forward's feature and `criterion(out, y)` (MHEntLoss: 14 metrics);
+        self.out then carries 'criterion' = (total, losses, metrics)"""
         if ts.shard_hypotheses:
             raise NotImplementedError("GraphedStep: the hypothesis-sharded forward has collectives inside the forward pass")
         self.ts, self.graphs, self.actions = ts, [], []
+        _step = ts.step
+
+        def step(x, y, noise=None, N=None):
+            out = _step(x, y, noise=noise, N=N, test_samples=test_samples)
+            if criterion is not None:
+                with torch.no_grad():
+                    out["criterion"] = criterion(dict(out), y)
+            return out
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
@@ -1331,7 +1344,7 @@ class GraphedStep:
             # batch held by x / y: `warm_out` is that iteration's result, and a training loop must not replay() the same batch
             # again (mhentropy_amd/run.py takes warm_out for the capture iteration; the reference steps once per iteration,
             # hand/CrossModalHand.py:455-470)
-            self.warm_out = ts.step(x, y, noise=noise, N=N)
+            self.warm_out = step(x, y, noise=noise, N=N)
         cur.wait_stream(side)
         torch.cuda.synchronize()
         self._mode = "thread_local" if ts.comm else "global"           # the communicator's watchdog thread may touch the device
@@ -1340,7 +1353,7 @@ class GraphedStep:
             self._cur.capture_begin(capture_error_mode=self._mode)
             ts._capture = self
             try:
-                self.out = ts.step(x, y, noise=noise, N=N)
+                self.out = step(x, y, noise=noise, N=N)
             finally:
                 ts._capture = None
                 self._cur.capture_end()

@@ -23,10 +23,14 @@ def sub(sd, prefix):
     return {k[n:]: v for k, v in sd.items() if k.startswith(prefix)}
 
 
-def encoder(sd, x, arch="resnet50", training=True):
+def encoder(sd, x, arch="resnet50", training=True, bf16_storage=False):
     """BasicEnc.forward, network.py:96-140: trunk, then mn = l1(feat).  The caller keeps
-    only mn (network.py:779); l2/exp/epsilon are dead for MHEnt and not restated."""
-    trunk = resnet_ref.forward(sub(sd, "feat_extractor.res."), x, arch=arch, training=training)
+    only mn (network.py:779); l2/exp/epsilon are dead for MHEnt and not restated.
+    bf16_storage=True: the trunk with the bf16 performance mode's rounding points (resnet_ref.forward_bf16_storage: every stored
+    tensor rounded to bf16 - and, under autograd, every gradient passing a storage point -, all arithmetic f32): the yardstick for what
+    bf16 STORAGE alone does to a result, with exact arithmetic everywhere else."""
+    fwd = resnet_ref.forward_bf16_storage if bf16_storage else resnet_ref.forward
+    trunk = fwd(sub(sd, "feat_extractor.res."), x, arch=arch, training=training)
     return F.linear(trunk, sd["feat_extractor.l1.0.weight"], sd["feat_extractor.l1.0.bias"])
 
 
@@ -105,9 +109,9 @@ def reverse_kld(sd, tb, feat, y, z0, N):
     return out
 
 
-def get_loss(sd, tb, x, y, z0, N, arch="resnet50", training=True):
+def get_loss(sd, tb, x, y, z0, N, arch="resnet50", training=True, bf16_storage=False):
     """MHEnt.get_loss, network.py:838-844."""
-    feat = encoder(sd, x, arch, training)
+    feat = encoder(sd, x, arch, training, bf16_storage)
     return reverse_kld(sd, tb, feat, y, z0, N)
 
 

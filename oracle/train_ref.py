@@ -15,10 +15,11 @@ def _is_param(k):
     return not (k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked") or k.endswith("mask"))
 
 
-def loss_and_grads(sd, tb, x, y, z0, N, arch="resnet50"):
-    """sd: flat state dict of float tensors (reference key names).  Returns (get_loss dict, total, {name: grad})."""
+def loss_and_grads(sd, tb, x, y, z0, N, arch="resnet50", bf16_storage=False):
+    """sd: flat state dict of float tensors (reference key names).  Returns (get_loss dict, total, {name: grad}).
+    bf16_storage: the trunk's stored tensors (and the gradients passing them) rounded to bf16, network_ref.encoder."""
     p = {k: (v.clone().requires_grad_(True) if _is_param(k) and v.is_floating_point() else v.clone()) for k, v in sd.items()}
-    out = network_ref.get_loss(p, tb, x, y, z0, N, arch=arch, training=True)
+    out = network_ref.get_loss(p, tb, x, y, z0, N, arch=arch, training=True, bf16_storage=bf16_storage)
     total = (-out["log_p"]).mean()
     total.backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in p.items() if isinstance(v, torch.Tensor) and v.requires_grad}

@@ -509,58 +509,6 @@ def test_bottleneck_tail_with_conv3_reevaluated(gpu_lib, geom, affine2):
     assert_close(y1.float().cpu().permute(0, 3, 1, 2), F.conv2d(aa.bfloat16().double(), w1.double()), 2 * TOL, what="conv1 vs torch")
 
 
-# (B, H, W): 128 pixels (one tile), 384 tiles (some workgroups take two: cross-tile prefetch), config C2's layer3 (512 tiles)
-@pytest.mark.parametrize("geom", [(2, 8, 8), (192, 16, 16), (256, 16, 16)], ids=lambda g: "x".join(map(str, g)))
-@pytest.mark.parametrize("affine2", [False, True], ids=["identity", "downsample-bn"])
-def test_bottleneck_tail_with_conv3_reevaluated_at_256_channels(gpu_lib, geom, affine2):
-    """csrc/conv_fuse256.hip (round 4): layer3's bottleneck tail with conv3 (256 -> 1024) evaluated again + the next conv1 (1024 -> 256),
-    against the path it replaces - conv3 written out (the resident-slab kernel, BatchNorm on load) then read back by the residual-tail
-    kernel.  Same products in the same order: block output and next conv1 output bit-identical.  bn3's statistics come from the
-    statistics-only launch of the resident-slab kernel (stores dropped): the same sums as the storing launch.  And against torch in f64."""
-    from mhentropy_amd import ops, resnet
-    B, H, W = geom
-    Cb, N2, C4 = 256, 256, 1024
-    g = torch.Generator().manual_seed(B + H)
-    y2 = torch.randn(B, Cb, H, W, generator=g).bfloat16().float()
-    idt = torch.randn(B, C4, H, W, generator=g).bfloat16().float()
-    w3 = (torch.randn(C4, Cb, 1, 1, generator=g) * (2.0 / Cb) ** 0.5).bfloat16().float()
-    w1 = (torch.randn(N2, C4, 1, 1, generator=g) * (2.0 / C4) ** 0.5).bfloat16().float()
-    s2, h2 = torch.rand(Cb, generator=g) + 0.5, torch.randn(Cb, generator=g) * 0.3
-    s3, h3 = torch.rand(C4, generator=g) + 0.5, torch.randn(C4, generator=g) * 0.3
-    si, hi = (torch.rand(C4, generator=g) + 0.5, torch.randn(C4, generator=g) * 0.3) if affine2 else (None, None)
-    cu = lambda t: None if t is None else t.cuda()
-    y2d, idd = _nhwc(y2), _nhwc(idt)
-    w3d, w1d = resnet.pack_conv_weight(w3, torch.bfloat16).cuda(), resnet.pack_conv_weight(w1, torch.bfloat16).cuda()
-    # the unfused path: conv3 with bn2 + relu on the operand load (+ statistics), then the residual-tail kernel
-    st3_ref, st1_ref = ops.stat_unit(C4, "cuda"), ops.stat_unit(N2, "cuda")
-    y3 = ops.conv2d_nhwc(y2d, w3d, 1, 1, 1, 0, in_scale=cu(s2), in_shift=cu(h2), relu_in=True, stats=st3_ref)
-    a_ref = torch.empty_like(y3)
-    y1_ref = ops.conv1x1_residual_in(y3, idd, w1d, cu(s3), cu(h3), cu(si), cu(hi), a_out=a_ref, stats=st1_ref)
-    if ops.conv_tile_choice(B, H, W, Cb, C4, 1, 1, 0, torch.bfloat16, 1) == 11:
-        # statistics-only launch of the resident-slab kernel: the sums of the values it would have stored - the SAME partial sums, bit for bit
-        st3 = ops.stat_unit(C4, "cuda")
-        ops.conv1x1_stats(y2d, w3d, cu(s2), cu(h2), st3)
-        assert torch.equal(ops.stat_totals(st3), ops.stat_totals(st3_ref)), "conv3 statistics without the store"
-    assert ops.bottleneck_tail256_supported(B, H, W, Cb, N2) and not ops.bottleneck_tail256_supported(B, H, W, Cb, 512)
-    w3s, w1s = ops.bottleneck_tail256_pack(w3d, w1d)
-    st1 = ops.stat_unit(N2, "cuda")
-    a, y1 = ops.bottleneck_tail256(y2d, (cu(s2), cu(h2)), w3s, (cu(s3), cu(h3)), idd, (cu(si), cu(hi)) if affine2 else None, w1s, stats=st1)
-    torch.cuda.synchronize()
-    assert torch.equal(a, a_ref), f"block output differs on {(a != a_ref).float().mean().item():.2e} of the elements"
-    assert torch.equal(y1, y1_ref), f"conv1 output differs on {(y1 != y1_ref).float().mean().item():.2e} of the elements"
-    assert_close(ops.stat_totals(st1).cpu(), ops.stat_totals(st1_ref).cpu(), 1e-6, what="conv1 statistics")
-    # ... and against torch (f64) on the same bf16-rounded operands
-    a2 = F.relu(y2.double() * s2.double()[None, :, None, None] + h2.double()[None, :, None, None]).bfloat16().double()
-    t = F.conv2d(a2, w3.double()).bfloat16().double()
-    ident = idt.double() * si.double()[None, :, None, None] + hi.double()[None, :, None, None] if affine2 else idt.double()
-    aa = F.relu(t * s3.double()[None, :, None, None] + h3.double()[None, :, None, None] + ident)
-    assert_close(a.float().cpu().permute(0, 3, 1, 2), aa, TOL, what="block output vs torch")
-    assert_close(y1.float().cpu().permute(0, 3, 1, 2), F.conv2d(aa.bfloat16().double(), w1.double()), 2 * TOL, what="conv1 vs torch")
-    # without statistics
-    a2_, y1_ = ops.bottleneck_tail256(y2d, (cu(s2), cu(h2)), w3s, (cu(s3), cu(h3)), idd, (cu(si), cu(hi)) if affine2 else None, w1s)
-    assert torch.equal(a2_, a) and torch.equal(y1_, y1)
-
-
 @pytest.mark.parametrize("geom", [(4, 16, 16, 64, 256), (2, 8, 8, 128, 512), (96, 32, 32, 64, 256), (40, 32, 32, 128, 512)], ids=lambda g: "x".join(map(str, g)))
 def test_gram_statistics_give_the_convolutions_batchnorm_affine(gpu_lib, geom):
     """csrc/conv_gram.hip: train-mode BatchNorm (scale, shift, running statistics) of conv1x1(relu(bn(x)), w) from the Gram matrix of the

@@ -295,9 +295,22 @@ def test_c1_full_size_f32_vs_oracle_and_properties(gpu_lib):
     tb = mano_ref.tables_from_numpy(synth.mano_tables(0))
     with torch.no_grad():
         ref = network_ref.get_loss(sd, tb, torch.as_tensor(x), _t(yn, "cpu"), torch.as_tensor(z0), N, "resnet50", True)
+        # the arbiter: the same oracle in float64.  north_star's bar is 1e-4 of the reference's fp32 CPU path; that path is itself
+        # 53 train-mode BatchNorm layers of fp32 round-off away from the exact arithmetic, so the claim made (and asserted) here is
+        # |HIP - f64| <= max(1e-4 scale, 2 |f32 oracle - f64|) per entry, with the measured figures printed
+        D = torch.float64
+        sd64 = {k: (v.to(D) if v.is_floating_point() else v) for k, v in sd.items()}
+        y64 = {k: (v.to(D) if v.is_floating_point() else v) for k, v in _t(yn, "cpu").items()}
+        ref64 = network_ref.get_loss(sd64, mano_ref.tables_from_numpy(synth.mano_tables(0), dtype=D), torch.as_tensor(x).to(D), y64,
+                                     torch.as_tensor(z0).to(D), N, "resnet50", True)
     for k in keys:
         assert out[k].shape == ref[k].shape
-        assert_close(out[k].cpu(), ref[k], 3e-4, what="C1 " + k)   # 53 train-mode BN layers of round-off in front of the 1e-4 path
+        a, r32, r64 = out[k].cpu().double(), ref[k].double(), ref64[k].double()
+        scale = float(r64.abs().max())
+        e_hip, e_f32, e_pair = float((a - r64).abs().max()) / scale, float((r32 - r64).abs().max()) / scale, float((a - r32).abs().max()) / scale
+        print(f"C1 f32 {k}: |HIP-f64| {e_hip:.2e}  |f32 oracle-f64| {e_f32:.2e}  |HIP-f32 oracle| {e_pair:.2e}  (max-norm, relative to max|f64|)")
+        assert e_hip <= max(1e-4, 2.0 * e_f32), (k, e_hip, e_f32)
+        assert_close(out[k].cpu(), ref[k], 3e-4, what="C1 " + k)   # two f32 evaluations, each up to e_f32 from f64: at most their sum apart
     # (i) hypothesis order within an image is irrelevant (rows are sample-major: r = n*B + b)
     perm = torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(b)) for b in range(B)], 1).cuda()      # (N, B)
     zp = zg.view(N, B, -1).gather(0, perm[:, :, None].expand(-1, -1, zg.shape[-1])).reshape(N * B, -1).contiguous()
@@ -524,41 +537,3 @@ def test_trunk_with_the_last_tail_inside_the_average_pool_equals_the_two_launche
         trunk.fuse_pool = fused
         outs.append(trunk(x))
     assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
-
-
-@pytest.mark.parametrize("training", [True, False])
-def test_trunk_with_layer3_conv3_reevaluated_equals_the_stored_form(gpu_lib, training):
-    """MHE_FUSE_RECOMPUTE256 (csrc/conv_fuse256.hip, round 4): layer3's blocks without conv3's raw output - bn3's statistics from the
-    statistics-only launch of the resident-slab kernel (the same sums as the storing launch), conv3 evaluated again inside the tail kernel.
-    Same products in the same order: with the running statistics (eval) the encoder feature equals the stored form's BIT FOR BIT; with batch
-    statistics the block outputs are still the same products, but the next conv1's statistics are summed over other per-thread groupings
-    than the residual-tail kernel's (f32 partial sums: a last bit of a scale, then a bf16 rounding, then 30 train-mode BatchNorms - the
-    amplification the other recompute tests document), so train mode is held to their band (hand/network.py:54-61,110).  B = 64 at
-    256 x 256: layer3 has 16,384 pixels, the smallest count the resident-slab kernel takes."""
-    from mhentropy_amd import resnet
-    sd = {k: torch.as_tensor(v) for k, v in synth.resnet_state(13, "resnet50").items()}
-    x = torch.as_tensor(synth.batch(13, 8, image_size=256)[0]).cuda().repeat(8, 1, 1, 1)
-    x = x + 0.01 * torch.randn(x.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(2))
-    outs, used = [], []
-    for fused in (True, False):
-        trunk = resnet.ResNetTrunk("resnet50", compute_dtype=torch.bfloat16)
-        trunk.load_state_dict(sd)
-        trunk = trunk.cuda().train(training)
-        trunk.fuse_recompute256 = fused
-        calls = []
-        orig = resnet.ops.bottleneck_tail256
-        resnet.ops.bottleneck_tail256 = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
-        try:
-            f = trunk(x)
-        finally:
-            resnet.ops.bottleneck_tail256 = orig
-        used.append(len(calls))
-        outs.append((f, trunk.layer3[2].bn3.running_var.clone(), trunk.layer3[5].bn1.running_mean.clone()))
-    assert used == [5, 0], used                  # the five tails inside layer3 (the one into layer4 has 512 outputs)
-    for u, v in zip(outs[0], outs[1]):
-        assert torch.isfinite(u).all()
-        if not training:
-            assert torch.equal(u, v), float((u.float() - v.float()).abs().max())
-        else:
-            d = ((u.float() - v.float()).abs().mean() / v.float().abs().mean()).item()
-            assert d < 2e-2, d
