@@ -438,6 +438,7 @@ def main():
                        "base_noise": "resident tensor" if args.resident_noise else "drawn on the device inside the step (Philox4x32-10, mhe_randn_f32)",
                        "img_per_s": round(world * B * args.steps / dt, 1),
                        "timing": f"median of {max(1, args.windows)} windows of {args.steps} steps, each bracketed by barrier + synchronize",
+                       "switches_set": __import__("mhentropy_amd.switches", fromlist=["x"]).non_default(),     # {} = the product path (mhentropy_amd/switches.py)
                        "ranks": world, "rccl_ranks": (world if (dist is not None and dist.get_backend() == "nccl") else 0),
                        "backend": (None if dist is None else "rccl (torch backend 'nccl')" if dist.get_backend() == "nccl" else dist.get_backend()),
                        "glow_variant": glow_variant},

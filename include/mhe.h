@@ -241,11 +241,11 @@ typedef struct mhe_conv_desc {
     int relu_in;   /* apply relu after in_scale/in_shift */
     int relu_out;
     int tile;      /* 0 = the launcher chooses the kernel variant; k > 0 forces variant k-1 where the geometry admits it
-                    * (0 128x64, 1 128x128, 2 256x256, 3 256x128, 4 256x64, 5 / 6 the LDS-DMA kernel on 256x256 / 128x128,
+                    * (0 128x64, 1 128x128, 2 256x256, 3 256x128, 4 256x64,
                     * 7 the 8-phase 256x256 kernel, 8 the streaming 1x1 kernel for 64 / 128 (/ 256) input channels, 9 the row-streaming 3x3 kernel for 64 -> 64 channels,
                     * 10 the 128 x 256 residual-tail kernel with transfer waves for >= 256 output channels, 11 the resident-slab kernel with transfer
-                    * waves for 256 / 512 -> >= 512 channels, 13 the 8-phase kernel on a 256 x 128 tile, 15 the residual-tail kernel of
-                    * variant 10 with every operand brought in by LDS-DMA rings - forward form): parity tests and tuning runs
+                    * waves for 256 / 512 -> >= 512 channels, 13 the 8-phase kernel on a 256 x 128 tile; 5, 6 and 15 - the round-1 LDS-DMA kernels and the
+                    * DMA-ring residual tail, measured no faster - left the build in round 5): parity tests and tuning runs
                     * reach every instantiation in-process */
     int res_half;  /* 1: `residual` is at HALF resolution, [B, ceil(Ho/2), ceil(Wo/2), Cout], and is added at the even output positions
                     * only (the data gradient of a stride-2 1x1 shortcut joining the main branch's gradient without being scattered
@@ -508,17 +508,6 @@ int mhe_bottleneck_tail_bits_nhwc(const mhe_conv_desc *d, int Cb, const void *y2
                                   const void *w3, const float *bn3_scale, const float *bn3_shift, const void *identity,
                                   const float *id_scale, const float *id_shift, const void *w1, void *a_out, void *a_bits, void *y1,
                                   mhe_stat_t *stats, void *stream);
-/* The bottleneck tail with conv3 re-evaluated at 256 bottleneck channels (layer3 of ResNet-50 at config C2; csrc/conv_fuse256.hip): as
- * mhe_bottleneck_tail_nhwc with Cb = 256, block width d->Cin = 1024, d->Cout = 256 outputs, pixels % 128 == 0.  The two weight operands
- * come PRE-PACKED as the bank-swizzled LDS images of the kernel's 32-channel stages, 32 stages of 16 KiB each:
- *   w3_stages: stage t, K tile kt, row r, piece sp = bf16 W3[32 t + r][64 kt + 8 (sp ^ ((r >> 1) & 7)) .. + 7]   at piece kt * 256 + r * 8 + sp
- *   w1_stages: stage t, row n, piece sp        = bf16 W1[n][32 t + 8 (sp ^ (-(n >> 2) & 3)) .. + 7]               at piece n * 4 + sp
- * (mhentropy_amd/ops.py:bottleneck_tail256_pack).  bn3's statistics: mhe_conv1x1_stats_nhwc (256 input channels: the statistics-only launch
- * of the resident-slab kernel).  Block output = the unfused path's bit for bit. */
-int mhe_bottleneck_tail256_supported(const mhe_conv_desc *d);
-int mhe_bottleneck_tail256_nhwc(const mhe_conv_desc *d, const void *y2, const float *bn2_scale, const float *bn2_shift, const void *w3_stages,
-                                const float *bn3_scale, const float *bn3_shift, const void *identity, const float *id_scale,
-                                const float *id_shift, const void *w1_stages, void *a_out, void *y1, mhe_stat_t *stats, void *stream);
 /* mhe_conv2d_masked_nhwc with a per-channel constant: y = (conv(x, w) + bias + residual) * [mask > 0] (+ the BatchNorm-reverse sums of one
  * consumer).  Register-staged 128-row tiles only.  xcat (optional, bf16 1x1 stride-1 launches): the operand's K range continues on a second
  * tensor - y = [x | xcat] w^T with w [Cout][Cin + cin2] and xcat [pixels][cin2]. */

@@ -125,8 +125,6 @@ SIGNATURES = {
     "mhe_conv1x1_gram_store_nhwc": (_i, [_p, _p, _p, _i, _p, _p, _l, _i, _p]),
     "mhe_gram_bn_finalize": (_i, [_p] * 10 + [_i, _i, _d, _f, _f, _p, _p]),
     "mhe_bottleneck_tail_supported": (_i, [_p, _i]),
-    "mhe_bottleneck_tail256_supported": (_i, [_p]),
-    "mhe_bottleneck_tail256_nhwc": (_i, [_p] * 14 + [_p]),
     "mhe_bottleneck_tail_nhwc": (_i, [_p, _i] + [_p] * 14),
     "mhe_stem_pool_supported": (_i, [_i, _i, _i, _i]),
     "mhe_stem_conv7x7s2_pool": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),

@@ -181,162 +181,6 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_kerne
 }
 
 // ---------------------------------------------------------------------------
-// LDS-DMA variant of the plain (MODE 0) bf16 convolution: operands go HBM/L2 -> LDS with
-// global_load_lds_dwordx4 (no VGPR staging, no ds_write pass) into a 4-slot ring of 32-deep K stages,
-// three stages in flight behind a counted vmcnt, one raw s_barrier per stage.  The register-staged
-// kernel above keeps ONE stage in flight and measures latency/L2-fill bound at ~35 % of the MFMA rate.
-//   * rows are 64 bytes (4 chunks of 8 bf16); the DMA writes LDS linearly (lane -> row lane>>2, physical
-//     chunk lane&3), so the bank-conflict swizzle is applied to the SOURCE: physical chunk p of tile row r
-//     holds logical chunk p ^ ((-(r>>2)) & 3); with it every ds_read_b128 lane group of a fragment read
-//     touches 16 distinct 16-byte slots;
-//   * padding taps / rows outside the problem read a 64-byte zero page instead of being predicated
-//     (a masked lane would leave stale LDS bytes);
-//   * fragment reads are inline asm (hipcc fences every LDS read after an LDS-DMA with vmcnt(0)).
-// Measured (l3 3x3 256->256, B=256, ablation builds): everything 89 us; without the DMA 62; without the
-// fragment reads 74; MFMA + barriers + epilogue alone 49 (the MFMAs themselves ~40 = peak at the clock the
-// chip holds); DMA + barriers alone 55.  DMA time and MFMA time ADD instead of overlapping: per stage the CU's
-// LDS carries 96 KB of fragment reads (the 16 KB A tile is read by 4 waves, the B tile by 2) plus 32 KB of
-// DMA writes, i.e. it is busy for most of the 1024 MFMA cycles - deeper prefetch (this kernel) therefore
-// buys only 0-5 % over the register-staged one; the next step is fewer LDS bytes per MAC.  A K order with the
-// taps innermost (re-reads of an input line back to back, served by L2) was also tried: no gain, reverted.
-__device__ __attribute__((aligned(64))) uint4 g_zero_page[4];
-
-template <int BM, int BN, int WM, int WN, int ABL = 0>     // ABL: ablation switches of tuning builds (1 no DMA, 2 no fragment reads, 4 no MFMA; 0 in production)
-__global__ __launch_bounds__(64 * WM * WN) void conv_dma_kernel(const Params p) {
-    using T = u16;
-    constexpr int NW = WM * WN;
-    constexpr int BKE = 32, ROWS = BM + BN, STAGE_BYTES = ROWS * 64;
-    constexpr int NBUF = 4, DEPTH = 3;
-    constexpr int GROUPS = ROWS / 16, GPW = GROUPS / NW;
-    static_assert(GROUPS % NW == 0 && GPW == 4, "4 DMA pieces per wave per stage (the counted wait below)");
-    constexpr int MTW = BM / WM / 16, NTW = BN / WN / 16;
-    static_assert(MTW == 8 || MTW == 4, "fragment asm blocks are written for 8 or 4 row tiles");
-    static_assert(NTW == 4, "and 4 column tiles");
-    __shared__ uint4 lds[NBUF * STAGE_BYTES / 16];
-    static_assert(sizeof(lds) >= (size_t)BM * BN * 2, "epilogue staging");
-
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int q = lane >> 4, l15 = lane & 15;
-    const int wr = wave / WN, wc = wave % WN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const T *xg = reinterpret_cast<const T *>(p.x);
-    const T *wg = reinterpret_cast<const T *>(p.w);
-    const unsigned char *zp = reinterpret_cast<const unsigned char *>(g_zero_page) + (lane & 3) * 16;
-
-    // ---- DMA role of this lane: row lane>>2 of each of the wave's GPW 16-row pieces, physical chunk lane&3
-    const int r16 = lane >> 2, pc = lane & 3, lq = pc ^ ((-(r16 >> 2)) & 3);
-    int hi0[GPW], wi0[GPW];
-    size_t base[GPW];            // A piece: pixel index of image start; B piece: element offset of the weight row
-    bool rv[GPW], isA[GPW];
-#pragma unroll
-    for (int j = 0; j < GPW; ++j) {
-        const int row = 16 * (wave * GPW + j) + r16;
-        isA[j] = row < BM;
-        if (isA[j]) {
-            const int m = m0 + row;
-            rv[j] = m < p.M;
-            const int mm = rv[j] ? m : 0;
-            const int wo = mm % p.Wo, t = mm / p.Wo, ho = t % p.Ho, b = t / p.Ho;
-            hi0[j] = ho * p.stride - p.pad;
-            wi0[j] = wo * p.stride - p.pad;
-            base[j] = (size_t)b * p.H * p.W;
-        } else {
-            const int n = n0 + row - BM;
-            rv[j] = n < p.Cout;
-            hi0[j] = wi0[j] = 0;
-            base[j] = (size_t)(rv[j] ? n : 0) * p.Kpad;
-        }
-    }
-    const int nk = p.Kpad / BKE;
-    const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char *)lds);
-    auto issue_piece = [&](int ks, int j) {      // DMA piece j (0..GPW-1) of stage ks
-        if constexpr (ABL & 1) return;
-        const int ksc = ks < nk ? ks : nk - 1;             // past the end: harmless re-fetch into a free slot
-        const int k0 = ksc * BKE;                         // position in the packed weight rows
-        const int tap = k0 / p.Cin, c = k0 - tap * p.Cin + lq * 8;                   // K order [tap][Cin]
-        const int kh = tap / p.KW, kw = tap - kh * p.KW;
-        unsigned char *dst = reinterpret_cast<unsigned char *>(lds) + (ks % NBUF) * STAGE_BYTES + (wave * GPW + j) * 1024;
-        const unsigned char *src = zp;
-        if (isA[j]) {
-            const int hi = hi0[j] + kh, wi = wi0[j] + kw;
-            if (rv[j] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-                src = reinterpret_cast<const unsigned char *>(xg + ((base[j] + (size_t)hi * p.W + wi) * p.Cin + c));
-        } else if (rv[j]) {
-            src = reinterpret_cast<const unsigned char *>(wg + base[j] + k0 + lq * 8);
-        }
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-    };
-    auto issue = [&](int ks) {
-#pragma unroll
-        for (int j = 0; j < GPW; ++j) issue_piece(ks, j);
-    };
-
-    v4f acc[NTW][MTW];
-#pragma unroll
-    for (int a = 0; a < NTW; ++a)
-#pragma unroll
-        for (int b = 0; b < MTW; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
-
-    // fragment addresses: tile row l15 -> physical chunk q ^ ((-(l15>>2)) & 3)  (tiles start at multiples of 16 rows)
-    const unsigned fpc = (unsigned)(q ^ ((-(l15 >> 2)) & 3));
-    const unsigned a_off = (unsigned)(wr * (BM / WM) + l15) * 64 + fpc * 16;
-    const unsigned b_off = (unsigned)(BM + wc * (BN / WN) + l15) * 64 + fpc * 16;
-    typedef unsigned u4 __attribute__((ext_vector_type(4)));
-    typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
-
-#pragma unroll
-    for (int s0 = 0; s0 < DEPTH; ++s0) issue(s0);
-    for (int ks = 0; ks < nk; ++ks) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // GPW * (DEPTH - 1): stage ks has landed
-        __builtin_amdgcn_s_barrier();
-        issue(ks + DEPTH);                                          // slot (ks+3)%4 was last read in iteration ks-1
-        const unsigned sb = lds_base + (ks % NBUF) * STAGE_BYTES;
-        const unsigned aa = sb + a_off, ba = sb + b_off;
-        u4 fa[MTW], fb[NTW];
-        if constexpr (ABL & 2) {
-#pragma unroll
-            for (int i = 0; i < MTW; ++i) fa[i] = u4{(unsigned)ks, 1u, 2u, 3u};
-#pragma unroll
-            for (int i = 0; i < NTW; ++i) fb[i] = u4{(unsigned)ks, 1u, 2u, 3u};
-        } else if constexpr (MTW == 8) {
-            asm volatile("ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:1024\n\tds_read_b128 %2, %12 offset:2048\n\t"
-                         "ds_read_b128 %3, %12 offset:3072\n\tds_read_b128 %4, %12 offset:4096\n\tds_read_b128 %5, %12 offset:5120\n\t"
-                         "ds_read_b128 %6, %12 offset:6144\n\tds_read_b128 %7, %12 offset:7168\n\t"
-                         "ds_read_b128 %8, %13\n\tds_read_b128 %9, %13 offset:1024\n\tds_read_b128 %10, %13 offset:2048\n\t"
-                         "ds_read_b128 %11, %13 offset:3072\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(fa[0]), "=&v"(fa[1]), "=&v"(fa[2]), "=&v"(fa[3]), "=&v"(fa[4]), "=&v"(fa[5]), "=&v"(fa[6]),
-                           "=&v"(fa[7]), "=&v"(fb[0]), "=&v"(fb[1]), "=&v"(fb[2]), "=&v"(fb[3])
-                         : "v"(aa), "v"(ba) : "memory");
-        } else {
-            asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:1024\n\tds_read_b128 %2, %8 offset:2048\n\t"
-                         "ds_read_b128 %3, %8 offset:3072\n\t"
-                         "ds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:1024\n\tds_read_b128 %6, %9 offset:2048\n\t"
-                         "ds_read_b128 %7, %9 offset:3072\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(fa[0]), "=&v"(fa[1]), "=&v"(fa[2]), "=&v"(fa[3]), "=&v"(fb[0]), "=&v"(fb[1]), "=&v"(fb[2]),
-                           "=&v"(fb[3])
-                         : "v"(aa), "v"(ba) : "memory");
-        }
-        if constexpr (ABL & 4) {
-#pragma unroll
-            for (int i = 0; i < MTW; ++i) asm volatile("" :: "v"(fa[i]));
-#pragma unroll
-            for (int i = 0; i < NTW; ++i) asm volatile("" :: "v"(fb[i]));
-        } else {
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < MTW; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, fb[nt]), __builtin_bit_cast(bf8, fa[mt]),
-                                                                          acc[nt][mt], 0, 0, 0);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the tail re-fetches must not land on the epilogue's staging
-    __syncthreads();
-    epilogue<T, BM, BN, WM, WN, false>(p, acc, lds, (int)(blockIdx.x % NSH), n0, [&](int row) { const int m = m0 + row; return m < p.M ? (long)m : -1l; });
-}
-
-// ---------------------------------------------------------------------------
 // Stem: 7x7 stride-2 pad-3 convolution 3 -> 64 read straight from the NCHW f32 image (no layout-change
 // pass, no channel padding, every input element fetched from HBM once per 8x16 output tile).
 // K is ordered (kh, kw, c) with every kh row padded from 21 to 24: k = 24*kh + 3*kw + c.  With the input
@@ -709,8 +553,6 @@ bool fuse_supports(const Params &p, int cb);   // conv_fuse.hip: bottleneck tail
 int launch_fuse(const Params &p, int cb, hipStream_t s);
 bool tail_supports(const Params &p);           // conv_tail.hip: residual tail + conv1 on a 128 x 256 tile with transfer waves (variant 10)
 int launch_tail(const Params &p, hipStream_t s);
-bool tail2_supports(const Params &p);          // conv_tail.hip: the same tile with every operand by LDS-DMA rings (variant 15, forward form)
-int launch_tail2(const Params &p, hipStream_t s);
 
 // tile choice: 0 = 128x64, 1 = 128x128, 2 = 256x256 (FAST only; needs >= ~3/4 of the CUs' worth of tiles)
 static int choose_tile(const Params &p, bool fast, bool bf16) {
@@ -728,10 +570,6 @@ static int choose_tile(const Params &p, bool fast, bool bf16) {
     // one L2 - 62 us against the phase-pipelined kernel's 46 at layer4's conv3)
     if (bf16 && (force == 11 || (force < 0 && env_wide && p.Cin == 256)) && wide_supports(p)) return 11;
     static const int env_tail = getenv("MHE_CONV_TAIL") ? atoi(getenv("MHE_CONV_TAIL")) : 1;
-    // variant 15 (operands by LDS-DMA rings): built, bit-identical, and NOT faster - 117 / 88 / 238 / 162 us against 111 / 74 / 210 / 170 on the
-    // four tail shapes of config C2 (tools/conv_variants.py --tail --tiles 11,16): opt-in (MHE_CONV_TAIL2=1), see profiles/EXPERIMENTS.md
-    static const int env_tail2 = getenv("MHE_CONV_TAIL2") ? atoi(getenv("MHE_CONV_TAIL2")) : 0;
-    if (bf16 && (force == 15 || (force < 0 && env_tail && env_tail2)) && tail2_supports(p)) return 15;
     if (bf16 && (force == 10 || (force < 0 && env_tail)) && tail_supports(p)) return 10;
     if ((force & 15) == 7 && bf16 && p8_supports(p)) return 7;      // (higher bits: ablation builds of tuning runs)
     if (force == 13 && bf16 && p8_supports(p)) return 13;
@@ -771,31 +609,11 @@ static int launch_conv(const Params &p, hipStream_t s) {
         if (t0 == 8) return launch_stream(p, s);
         if (t0 == 9) return launch_stream3(p, s);
         if (t0 == 10) return launch_tail(p, s);
-        if (t0 == 15) return launch_tail2(p, s);
         if (t0 == 11) return launch_wide(p, s);
         if (t0 == 7) return launch_p8(p, s);
         if (t0 == 13) return launch_p8h(p, s);
     }
     if (p.x2 && !fast) { set_error("residual-tail prologue needs Cin %% %d == 0", BKE); return MHE_ERR_ARG; }
-    // the LDS-DMA kernel measures equal to the register-staged one (see its header): opt-in, bit 0 = 256x256, bit 1 = 128x128
-    static const int env_dma = getenv("MHE_CONV_DMA") ? atoi(getenv("MHE_CONV_DMA")) : 0;
-    const int use_dma = p.force == 5 ? 1 : p.force == 6 ? 3 : p.force >= 0 ? 0 : env_dma;      // variants 5 / 6: the LDS-DMA kernel on the 256x256 / 128x128 tile
-    if constexpr (sizeof(T) == 2) {
-        // plain bf16 operands (no producer BatchNorm, no residual tail) can be DMA'd straight into LDS
-        if (use_dma && fast && !p.in_scale && !p.x2 && !p.mask) {
-            const int tile = p.force == 5 ? 2 : p.force == 6 ? 1 : choose_tile(p, fast, true);
-            if (tile == 2) {
-                const dim3 grid((p.M + 255) / 256, (p.Cout + 255) / 256);
-                hipLaunchKernelGGL((conv_dma_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, p);
-                return check_launch("conv_dma_kernel");
-            }
-            if (tile == 1 && (use_dma & 2)) {
-                const dim3 grid((p.M + 127) / 128, (p.Cout + 127) / 128);
-                hipLaunchKernelGGL((conv_dma_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, p);
-                return check_launch("conv_dma_kernel");
-            }
-        }
-    }
     switch (choose_tile(p, fast, sizeof(T) == 2)) {
         case 0: if (fast) launch_mode<T, 128, 64, 2, 2, true>(p, s); else launch_mode<T, 128, 64, 2, 2, false>(p, s); break;
         case 2: if constexpr (sizeof(T) == 2) launch_mode<T, 256, 256, 2, 4, true>(p, s); break;

@@ -87,8 +87,6 @@ def _conv_kernel_name(d, dt, mode):
     mode = 0 if mode == 3 else mode          # (3 = plain operand load + a residual in the epilogue: the kernel's MODE is 0)
     if tile == 11:
         return "mhe::conv::conv_wide_kernel<%s, %s>" % ("128, 4" if d.Cin == 256 else "64, 8", "true" if mode == 1 else "false")
-    if tile == 15:
-        return "mhe::conv::conv_tail2_kernel"
     if tile == 10:
         return "mhe::conv::conv_tail_kernel<false>"
     if tile == 9:
@@ -683,47 +681,6 @@ def bottleneck_tail(y2, bn2, w3, bn3, identity, id_aff, w1, stats=None, want_bit
     return (a, y1, bits) if want_bits else (a, y1)
 
 
-def bottleneck_tail256_supported(B, H, W, Cb, Cout):
-    if Cb != 256:
-        return False
-    d = ConvDesc(B, H, W, 4 * Cb, Cout, 1, 1, 1, 0, BF16, 1, 0, 0, 0)
-    return bool(_lib.lib().mhe_bottleneck_tail256_supported(C.byref(d)))
-
-
-def bottleneck_tail256_pack(w3, w1):
-    """the two weight operands of mhe_bottleneck_tail256_nhwc as the bank-swizzled LDS images of its 32 stages (include/mhe.h):
-    w3 [1024, 256], w1 [256, 1024] bf16 (torch Linear / 1x1-conv layout) -> ([32, 8192], [32, 8192]) bf16"""
-    _chk(w3, torch.bfloat16, "tail256_pack.w3", (1024, 256)); _chk(w1, torch.bfloat16, "tail256_pack.w1", (256, 1024))
-    dev = w3.device
-    ar = lambda n: torch.arange(n, device=dev)
-    t, kt, r, sp, e = torch.meshgrid(ar(32), ar(4), ar(32), ar(8), ar(8), indexing="ij")
-    w3s = w3[32 * t + r, 64 * kt + 8 * (sp ^ ((r >> 1) & 7)) + e].reshape(32, 8192).contiguous()
-    t, n, sp, e = torch.meshgrid(ar(32), ar(256), ar(4), ar(8), indexing="ij")
-    w1s = w1[n, 32 * t + 8 * (sp ^ ((-(n >> 2)) & 3)) + e].reshape(32, 8192).contiguous()
-    return w3s, w1s
-
-
-def bottleneck_tail256(y2, bn2, w3s, bn3, identity, id_aff, w1s, stats=None):
-    """(a, y1) of mhe_bottleneck_tail256_nhwc (bottleneck 256 / block width 1024 / 256 outputs; w3s, w1s = bottleneck_tail256_pack)"""
-    B, H, W, Cb = y2.shape
-    Cw, Cout = 4 * Cb, 256
-    _chk(y2, torch.bfloat16, "tail256.y2", (B, H, W, 256)); _chk(w3s, torch.bfloat16, "tail256.w3", (32, 8192)); _chk(w1s, torch.bfloat16, "tail256.w1", (32, 8192))
-    _chk(identity, torch.bfloat16, "tail256.identity", (B, H, W, Cw))
-    for (sc, sh), n, c in ((bn2, "bn2", Cb), (bn3, "bn3", Cw)) + (((id_aff, "id", Cw),) if id_aff is not None else ()):
-        _chk(sc, torch.float32, f"tail256.{n}_scale", (c,)); _chk(sh, torch.float32, f"tail256.{n}_shift", (c,))
-    if stats is not None:
-        _chk_stats(stats, "tail256.stats", Cout)
-    a = torch.empty(B, H, W, Cw, device=y2.device, dtype=torch.bfloat16)
-    y1 = torch.empty(B, H, W, Cout, device=y2.device, dtype=torch.bfloat16)
-    d = ConvDesc(B, H, W, Cw, Cout, 1, 1, 1, 0, BF16, 1, 0, 0, 0)
-    with _Timed(lambda: "mhe::conv::bottleneck_tail256_kernel<%s>" % ("true" if id_aff is not None else "false"), 2.0 * B * H * W * Cw * (Cb + Cout),
-                2 * (y2.numel() + identity.numel() + a.numel() + y1.numel() + w3s.numel() + w1s.numel())):
-        check(_lib.lib().mhe_bottleneck_tail256_nhwc(C.byref(d), _ptr(y2), _ptr(bn2[0]), _ptr(bn2[1]), _ptr(w3s), _ptr(bn3[0]), _ptr(bn3[1]), _ptr(identity),
-                                                     _ptr(id_aff[0] if id_aff is not None else None), _ptr(id_aff[1] if id_aff is not None else None),
-                                                     _ptr(w1s), _ptr(a), _ptr(y1), _ptr(stats), _stream()), "mhe_bottleneck_tail256_nhwc")
-    return a, y1
-
-
 def linear_bf16_f32out(x, w, bias=None, out=None):
     """out[R,N] (f32) = x[R,K] (bf16) w[N,K]^T (bf16) + bias, f32 accumulation (mhe_conv2d_f32out_nhwc); K % 64 == 0, N % 4 == 0"""
     R, K = x.shape
@@ -789,8 +746,6 @@ def conv1x1_residual_in(x, x2, w, in_scale, in_shift, x2_scale=None, x2_shift=No
         es = x.element_size()
         nbytes = es * (2 * x.numel() + y.numel() + w.numel() + (a_out.numel() if a_out is not None else 0))
         name = _conv_kernel_name(d, dt, 2)
-        if name == "mhe::conv::conv_tail2_kernel" and x2_scale is not None and 4 * Cin > 4096:
-            name = "mhe::conv::conv_tail_kernel<false>"          # (the resident tables of variant 15 hold an identity affine up to 1,024 channels)
         KERNEL_TIMES.append((name, 2.0 * B * H * W * Cout * Cin, ev0, ev1, nbytes))
     return y
 

@@ -181,7 +181,7 @@ class ResNetTrunk(nn.Module):
             if blk.kind == "bottleneck":
                 if pending is not None and isinstance(pending[0], str):
                     # ... with the previous block's conv3 evaluated again inside the same kernel (its raw output was never written)
-                    kind_p, y2_p, a2_p, w3_p, al_p, idt_p, idaff_p = pending
+                    _, y2_p, a2_p, w3_p, al_p, idt_p, idaff_p = pending
                     st = pool.take(blk.conv1.out_channels) if self.training else None
                     a, y1 = ops.bottleneck_tail(y2_p, a2_p, w3_p, al_p, idt_p, idaff_p, self._w(blk.conv1), stats=st)
                     a1 = self._bn_affine(y1, blk.bn1, st)
@@ -245,9 +245,7 @@ class ResNetTrunk(nn.Module):
             else:
                 idt, idaff = a, None
             nxt = blocks[bi + 1] if bi + 1 < len(blocks) else None
-            if blk.kind == "bottleneck" and recompute256 is not None:
-                pending = ("re256", y2, a2, recompute256, al, idt, idaff)
-            elif recompute:
+            if recompute:
                 pending = ("re", y2, a2, w3, al, idt, idaff)
             elif self.fuse_tail and nxt is not None and nxt.kind == "bottleneck":
                 pending = (yl, al, idt, idaff)

@@ -197,3 +197,32 @@ def test_committed_counter_summaries_describe_the_committed_kernels():
         d = json.load(open(path))
         assert d["source_sha1"] == sha, f"{name} was collected on other kernel sources ({d['source_sha1'][:10]} vs {sha[:10]}): refresh it"
         assert d["kernels"] and all(v["hbm_bytes_per_launch"] >= 0 for v in d["kernels"].values())
+
+
+def test_switch_table_matches_the_source():
+    """mhentropy_amd/switches.py is the ONE table of run-time switches: every MHE_* environment variable the host code or the kernels'
+    launchers read is listed there with the default the source uses (so "no MHE_* set" IS the benched product path), and the table lists
+    nothing the source does not read"""
+    import glob
+    import re
+    from mhentropy_amd import switches
+    found = {}
+    pats = [re.compile(r'environ\.get\("(MHE_[A-Z0-9_]+)"(?:,\s*"([^"]*)")?\)'), re.compile(r'getenv\("(MHE_[A-Z0-9_]+)"\)')]
+    files = glob.glob(os.path.join(ROOT, "mhentropy_amd", "*.py")) + glob.glob(os.path.join(ROOT, "mhentropy_amd", "csrc", "*.hip")) + \
+        glob.glob(os.path.join(ROOT, "mhentropy_amd", "csrc", "*.h")) + [os.path.join(ROOT, "bench.py")]
+    for f in files:
+        if f.endswith("switches.py") or f.endswith("build.py"):
+            continue
+        src = open(f).read()
+        for pat in pats:
+            for m in pat.finditer(src):
+                found.setdefault(m.group(1), set())
+                if pat is pats[0] and m.group(2) is not None:
+                    found[m.group(1)].add(m.group(2))
+        # C side: `getenv("X") ? atoi(getenv("X")) : D`
+        for m in re.finditer(r'getenv\("(MHE_[A-Z0-9_]+)"\)\s*\?\s*ato[il]\(getenv\("MHE_[A-Z0-9_]+"\)\)\s*:\s*(-?\d+)', src):
+            found[m.group(1)].add(m.group(2))
+    assert set(found) == set(switches.SWITCHES), (sorted(set(found) - set(switches.SWITCHES)), sorted(set(switches.SWITCHES) - set(found)))
+    for k, defaults in found.items():
+        assert all(d == switches.SWITCHES[k][0] for d in defaults), (k, defaults, switches.SWITCHES[k][0])
+    assert switches.non_default({}) == {} and switches.non_default({"MHE_CONV_HALO": "1"}) == {} and switches.non_default({"MHE_CONV_HALO": "0"}) == {"MHE_CONV_HALO": "0"}
