@@ -60,10 +60,14 @@ __device__ __forceinline__ u16 f32_to_bf16(float f) {
 // on the order in which workgroups arrive - two runs of one launch, eager or replayed from a HIP graph, give the same bits (the f32
 // atomics of rounds 1-3 did not: one flipped bf16 rounding after 53 train-mode BatchNorm layers moved the C2 loss by 3e-3 ... 2e-2).
 //   two-word form (BatchNorm sums):  v = W0 * 2^-16 + W1 * 2^-56, W0 = rint(v 2^16), W1 = rint((v 2^16 - W0) 2^40): an f32 partial whose
-//       lowest bit is >= 2^-56 is represented EXACTLY (|v| >= 2^-32 for a full 24-bit mantissa); |partial| < 2^32, |shard total| < 2^39;
+//       lowest bit is >= 2^-56 is represented EXACTLY (|v| >= 2^-32 for a full 24-bit mantissa);
 //   one-word form (Gram matrices of normalised activations): quantum 2^-20.
-// A partial that is NaN / Inf / out of range plants a sticky marker (atomicMax to 2^62; legitimate shard totals stay below 2^55, so the
-// marker survives later adds): the finalize kernels turn it into NaN, as the f32 sum would have become.
+// RANGE (round 5): a partial sum is accepted up to |v| < 2^38 (two-word form; 2^34 in the one-word form) - a 1,024-pixel sum
+// of y^2 at an RMS |y| of 1.6e4, where the f32 atomics these replace would already have lost every contribution below 2^14.  (Round 4
+// drew the line at 2^32: un-normalised 0..255 images or a run about to diverge could reach that.)  A shard total at or beyond 2^55
+// quanta takes the finalize kernels' double-precision path (wave_totals); |shard total| must stay below 2^61 quanta = 2^45 in value.
+// A partial that is NaN / Inf / beyond the range plants a sticky marker (atomicMax to 2^62, above every legitimate total, so it survives
+// later adds): the finalize kernels turn it into NaN - an explicit, detectable error, as the f32 sum would have become Inf / NaN.
 namespace fx {
 typedef long long acc_t;
 constexpr int NSH = 64;                                   // shards per unit: workgroup b adds into shard b % NSH
@@ -74,7 +78,7 @@ __device__ __forceinline__ void add_word(acc_t *p, float x) {
 // one-word form, quantum 2^-20
 __device__ __forceinline__ void add1(acc_t *p, float v) {
     const float s = v * 0x1p20f;
-    if (fabsf(s) < 0x1p48f) add_word(p, rintf(s));
+    if (fabsf(s) < 0x1p54f) add_word(p, rintf(s));
     else atomicMax(p, MARK);
 }
 __device__ __forceinline__ bool marked(acc_t w) { return w >= LIMIT || w <= -LIMIT; }
@@ -83,7 +87,7 @@ __host__ __device__ __forceinline__ double value1(acc_t w) { return (double)w * 
 __device__ __forceinline__ size_t plane(int C) { return (size_t)NSH * 2 * C; }
 __device__ __forceinline__ void add2(acc_t *p, size_t lo_off, float v) {
     const float s = v * 0x1p16f;
-    if (fabsf(s) < 0x1p48f) {
+    if (fabsf(s) < 0x1p54f) {
         const float h = rintf(s);
         add_word(p, h);
         add_word(p + lo_off, rintf((s - h) * 0x1p40f));

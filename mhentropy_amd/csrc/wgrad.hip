@@ -763,7 +763,11 @@ static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, fl
     p.chunk = (int)w.chunk;
     p.Mp = gyy * w.BM; p.Np = gx * w.BN;
     const size_t need = (size_t)nbatch * gz * p.Mp * p.Np;
-    p.ws = (ws && takes_slabs(d, gz) && need <= ws_floats) ? ws : nullptr;
+    // a workspace was passed for a launch that takes slabs, but it is too small: fail (round 4 fell back to order-dependent f32 atomics without
+    // a word - the bit-reproducibility the train step asserts would have been gone silently)
+    MHE_REQUIRE(!(ws && takes_slabs(d, gz) && need > ws_floats), "mhe_conv_wgrad_ws_nhwc: workspace of %zu floats, this launch needs %zu (mhe_conv_wgrad_workspace_floats)",
+                ws_floats, need);
+    p.ws = (ws && takes_slabs(d, gz)) ? ws : nullptr;
     MHE_REQUIRE(nbatch == 1 || (w.dma && (long)gz * nbatch < 65536), "mhe_conv_wgrad_batched_nhwc: the grouped form runs on the LDS-DMA kernel (bf16, operands below 2 GiB)");
     if (nbatch > 1) { p.gz = gz; p.x_bs = x_bs; p.gy_bs = gy_bs; p.dw_bs = dw_bs; }
     dim3 grid(gx, gyy, gz * nbatch);

@@ -308,6 +308,7 @@ class _StatsPool:
             self.off = 0
         v = self.buf[self.off:self.off + n].view(2, self.S, 2, C)
         self.off += n
+        self.high = max(getattr(self, "high", 0), self.off)          # (high-water mark: what a pass has touched)
         return v
 
 

@@ -56,6 +56,7 @@ SWITCHES = {
     "MHE_FLOW_REV_FUSED": ("1", "train.py", "0: the flow's reverse chain coupling by coupling"),
     "MHE_FLOW_RECOMPUTE": ("0", "train.py", "1: the reverse pass re-evaluates the flow nets instead of reading emitted activations"),
     "MHE_LAZY_FALLBACK_TABLES": ("1", "train.py", "0: the fallback operand layouts refreshed every step"),
+    "MHE_POISON_STALE_TABLES": ("0", "train.py", "1 (debug): fallback operand layouts a repack leaves behind are filled with NaN"),
     "MHE_WGRAD_DMA": ("1", "csrc/wgrad.hip", "0: register-staged bf16 weight-gradient kernel"),
     "MHE_WGRAD_BIG": ("1", "csrc/wgrad.hip", "0: no 256x256 weight-gradient tile"),
     "MHE_WGRAD_XCD": ("1", "csrc/wgrad.hip", "0: weight-gradient tiles in grid order"),

@@ -149,6 +149,7 @@ class TrainStep:
         self._fb_lazy = os.environ.get("MHE_LAZY_FALLBACK_TABLES", "1") == "1"
         self._fb_keep = not self._fb_lazy     # True: every repack refreshes them (as soon as a step has needed them once)
         self._fb_stale = False
+        self._poison_stale = os.environ.get("MHE_POISON_STALE_TABLES", "0") == "1"
         self._raw_n = 0
         self._unpack = torch.full((self.n_params,), -1, dtype=torch.int64)
         self.cond_bwd_bf16 = os.environ.get("MHE_COND_BWD_BF16", "1") == "1"      # (read by _build_flow)
@@ -514,6 +515,15 @@ class TrainStep:
             self._repack_fallback()
         else:
             self._fb_stale = True
+            self._poison_fallback()
+
+    def _poison_fallback(self):
+        """debug mode (MHE_POISON_STALE_TABLES=1, tests): a fallback layout left behind by a repack is filled with NaN, so a reader that
+        did not go through _need_fallback() fails loudly instead of computing with an earlier step's weights"""
+        if self._poison_stale:
+            for a in self._arena_fb.values():
+                if a["idx"].numel():
+                    a["view"].fill_(float("nan"))
 
     def _repack_fallback(self):
         for a in self._arena_fb.values():
@@ -780,7 +790,15 @@ class TrainStep:
                           w_s2=getattr(u, "w_s2", None), res_half=res_half, coarse=coarse, mask_bits=mask_bits)
 
     def _trunk_backward(self, g_f):
-        pool = resnet._StatsPool(self.dev, channels=65536)
+        # the reverse pass's BatchNorm sums: ONE arena kept across steps; a pass zeroes the slice the previous pass used (ResNet-50 takes
+        # ~27k channels = 55 MB of fixed-point words; round 4 allocated and zeroed a fresh 134 MB arena every step - and every graph replay)
+        pool = getattr(self, "_rev_pool", None)
+        if pool is None:
+            pool = self._rev_pool = resnet._StatsPool(self.dev, channels=65536, persistent=True)
+            pool.high = 0
+        else:
+            pool.buf[:pool.high].zero_()
+        pool.off = 0
         self.n_fold = 0                 # blocks whose conv3 + bn3 were reversed on the Gram statistics in this pass
         self.n_fold_ds = 0              # ... and shortcuts
         B, Hh, Ww, Cc = self.a_last.shape
@@ -1373,6 +1391,7 @@ class GraphedStep:
         ts = self.ts
         if not self._fb_in_graph:              # the captured repack did not refresh the fallback layouts: they no longer follow the parameters
             ts._fb_stale = True
+            ts._poison_fallback()
         for k, g in enumerate(self.graphs):
             g.replay()
             if k < len(self.actions):

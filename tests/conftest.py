@@ -14,6 +14,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through the C-ABI HIP library)")
 
 
+def free_port():
+    """a TCP port that is free right now on 127.0.0.1 (bind to port 0, read it back): a fixed rendezvous port fails with EADDRINUSE when a
+    concurrent session or a socket in TIME_WAIT holds it - and looks like a GPU / RCCL failure"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
 

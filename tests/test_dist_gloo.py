@@ -4,7 +4,7 @@ import os
 import subprocess
 import sys
 
-from conftest import ROOT
+from conftest import ROOT, free_port
 from mhentropy_amd import dist as mdist
 
 WORKER = r'''
@@ -46,7 +46,7 @@ def test_two_ranks_over_gloo(tmp_path):
     script.write_text(WORKER)
     env = dict(os.environ, MHE_ROOT=ROOT, MHE_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29611", str(script)]
+           "--master-port", str(free_port()), str(script)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
     recs = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
@@ -112,7 +112,7 @@ def test_hypothesis_sharded_exchange_equals_the_unsharded_loss_and_gradient(tmp_
     script.write_text(X2_WORKER)
     env = dict(os.environ, MHE_ROOT=ROOT, MHE_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29617", str(script)]
+           "--master-port", str(free_port()), str(script)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
     recs = [json.load(open(tmp_path / f"x2_rank{r}.json")) for r in range(2)]

@@ -8,7 +8,7 @@ import sys
 
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, free_port
 
 pytestmark = pytest.mark.gpu
 
@@ -61,7 +61,7 @@ def test_two_ranks_average_their_gradients(gpu_lib, tmp_path):
     script.write_text(WORKER)
     env = dict(os.environ, MHE_ROOT=ROOT, MHE_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29633", str(script)]
+           "--master-port", str(free_port()), str(script)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
     assert out.returncode == 0, out.stderr[-3000:]
     recs = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
@@ -110,7 +110,7 @@ def test_hypothesis_sharded_train_step_equals_the_image_sharded_one(gpu_lib, tmp
     script.write_text(X2_WORKER)
     env = dict(os.environ, MHE_ROOT=ROOT, MHE_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29635", str(script)]
+           "--master-port", str(free_port()), str(script)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
     assert out.returncode == 0, out.stderr[-3000:]
     for r in range(2):
@@ -160,7 +160,7 @@ def test_graphed_step_cut_at_the_gradient_buckets(gpu_lib, tmp_path):
     script.write_text(GRAPH_WORKER)
     env = dict(os.environ, MHE_ROOT=ROOT, MHE_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29637", str(script)]
+           "--master-port", str(free_port()), str(script)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
     assert out.returncode == 0, out.stderr[-3000:]
     recs = [json.load(open(tmp_path / f"graph_rank{r}.json")) for r in range(2)]

@@ -180,3 +180,41 @@ def test_full_size_properties(gpu_lib):
     q, hh, lp = ops.elbo_reduce(o["log_p"], lq, N, B)
     assert_close(q.cpu(), o["log_p"].view(N, B).mean(0).cpu(), 1e-5, what="mean over hypotheses")
     assert_close(lp.cpu(), (o["log_p"].view(N, B).mean(0) - lq.view(N, B).mean(0)).cpu(), 1e-5, what="ELBO")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_batch_statistics_of_large_magnitude_activations_stay_finite(gpu_lib, dt):
+    """The fixed-point statistic accumulators (csrc/common.h, namespace fx) accept per-workgroup partial sums up to 2^38 (round 4: 2^32 -
+    un-normalised 0..255 images or a diverging run could plant the NaN marker where the reference's BatchNorm, hand/network.py:54-61, goes
+    on): activations of RMS ~3e3 give 256-pixel sums of y^2 of ~2^31 ... 2^35 - finite statistics equal to torch's in f64; beyond the
+    range the finalize returns NaN (an explicit, detectable error), never a silently wrong number."""
+    from mhentropy_amd import ops, resnet
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(3)
+    B, H, W, Cin, Cout = 4, 32, 32, 64, 128
+    x = (torch.randn(B, Cin, H, W, generator=g) * 400.0).to(dt).float()
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) * (2.0 / Cin) ** 0.5 * 6.0).to(dt).float()
+    y_ref = F.conv2d(x.double(), w.double())
+    assert float(y_ref.pow(2).mean().sqrt()) > 2.5e3
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dt).cuda()
+    wd = resnet.pack_conv_weight(w, dt).cuda()
+    st = ops.stat_unit(Cout, "cuda")
+    y = ops.conv2d_nhwc(xd, wd, 1, 1, 1, 0, stats=st)
+    tot = ops.stat_totals(st).cpu().double()
+    assert torch.isfinite(tot).all()
+    ys = y.double().cpu().permute(0, 3, 1, 2)            # the statistics are those of the output as stored
+    n = B * H * W
+    assert float(ys.pow(2).sum((0, 2, 3)).max()) > 2.0 ** 33          # the round-4 range (2^32 per partial) is crossed for whole channels
+    assert_close(tot[0] / n, ys.mean((0, 2, 3)), 1e-5, 1e-3, what="batch mean at large magnitude")
+    assert_close(tot[1] / n, ys.pow(2).mean((0, 2, 3)), 1e-5, what="batch E[y^2] at large magnitude")
+    # ... and past the range: NaN, not garbage
+    st2 = ops.stat_unit(Cout, "cuda")
+    big = (xd.float() * 3.0e4).to(dt)
+    ops.conv2d_nhwc(big, wd, 1, 1, 1, 0, stats=st2)
+    ones, zeros = torch.ones(Cout, device="cuda"), torch.zeros(Cout, device="cuda")
+    scale, _, mi = ops.bn_finalize(st2, ones, zeros, zeros.clone(), ones.clone(), n, want_mean_invstd=True)
+    assert torch.isnan(mi[1]).all(), "sums of y^2 of ~1e19 per 256 pixels are beyond the accumulator's range: the finalize must return NaN"
+    # (the in-range unit finalizes to torch's BatchNorm affine)
+    scale1, shift1, mi1 = ops.bn_finalize(st, ones, zeros, zeros.clone(), ones.clone(), n, want_mean_invstd=True)
+    var = ys.var((0, 2, 3), unbiased=False)
+    assert_close(mi1[1].cpu(), 1.0 / torch.sqrt(var + 1e-5), 1e-4, what="invstd at large magnitude")

@@ -12,7 +12,7 @@ import sys
 
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, free_port
 
 pytestmark = pytest.mark.gpu
 
@@ -83,7 +83,7 @@ def test_one_rank_rccl_group_runs_every_collective_of_the_train_step(gpu_lib, tm
     # it is a separate process with its own context either way, like test_gpu_ddp.py's ranks)
     script = tmp_path / "rccl_worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MHE_ROOT=ROOT, MHE_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", RANK="0", LOCAL_RANK="0",
+    env = dict(os.environ, MHE_ROOT=ROOT, MHE_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", LOCAL_RANK="0",
                WORLD_SIZE="1", MHE_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
     out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])

@@ -1005,6 +1005,7 @@ def test_fallback_operand_layouts_are_refreshed_when_a_fallback_path_runs(gpu_li
 
     model, _ = _model_and_state("resnet18", 512, 2, dtype=torch.bfloat16)
     ts = TrainStep(model, lr=1e-3)                          # steps large enough that stale layouts would be visible (1e-2 diverges in two steps)
+    ts._poison_stale = True                                 # ... and a reader that skipped _need_fallback() would meet NaN (MHE_POISON_STALE_TABLES)
     assert ts.flow_fused_tables and not ts._fb_keep
     for _ in range(2):
         ts.step(x, y, noise=z64, N=64)                      # the one-launch kernels only: the fallback layouts are left behind
@@ -1017,6 +1018,7 @@ def test_fallback_operand_layouts_are_refreshed_when_a_fallback_path_runs(gpu_li
     # graph replays: the captured repack of a trainer that never needed the layouts does not refresh them
     model2, _ = _model_and_state("resnet18", 512, 2, dtype=torch.bfloat16)
     ts2 = TrainStep(model2, lr=1e-3)
+    ts2._poison_stale = True
     gs = GraphedStep(ts2, x, y, noise=z64, N=64)
     assert not gs._fb_in_graph
     gs.replay(); gs.replay()
