@@ -397,23 +397,57 @@ def main():
             gstep = lambda: gmodel.get_loss(x, y, mods=["uv"], N=K, noise=noise)
             for _ in range(2):
                 gstep()
-            dtg = mdist.timed_region(gstep, args.steps, None, dev)
+            torch.cuda.synchronize()
+            glaunch = "eager"
+            if args.graph:          # round 5: nothing on the Glow path depends on a host value any more (ActNorm / LU algebra on the device)
+                try:
+                    gs2 = torch.cuda.Stream()
+                    gs2.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(gs2):
+                        gstep()
+                    torch.cuda.current_stream().wait_stream(gs2)
+                    ggraph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(ggraph):
+                        gout = gstep()
+                    ggraph.replay()
+                    torch.cuda.synchronize()
+                    assert torch.isfinite(gout["log_p"]).all()
+                    gstep, glaunch = ggraph.replay, "hip-graph replay"
+                except Exception as e:
+                    log(f"glow variant graph capture unavailable ({type(e).__name__}: {e}); eager")
+                    torch.cuda.synchronize()
+            dtg, gwin = timed_windows(gstep, args.steps, args.windows, None, dev)
             glow_variant = {"flow": "4-layer ConditionalGlow h=512, %s, train-mode dropout p=0.2 drawn on the device (parity unpinned: third-party class absent "
                                     "from the reference)" % ("bf16 hidden products, f32 elsewhere" if args.dtype == "bf16" else "f32"),
                             "value": round(B * K * args.steps / dtg, 1), "unit": "hypotheses/s", "ms_per_step": round(dtg / args.steps * 1e3, 3),
-                            "launch": "eager"}
-            log(f"glow variant: {glow_variant['ms_per_step']} ms/step")
+                            "windows_ms": gwin, "launch": glaunch}
+            log(f"glow variant: {glow_variant['ms_per_step']} ms/step ({glaunch})")
             if args.train_steps > 0:
-                # ... and its full train step (eager: the 45x45 ActNorm / LU re-parameterisation gradients are float64 host bookkeeping)
-                from mhentropy_amd.train import TrainStep
+                # ... and its full train step (the 45x45 ActNorm / LU re-parameterisation and its gradients run on the device: one HIP graph)
+                from mhentropy_amd.train import TrainStep, GraphedStep
+                if args.graph:
+                    del ggraph
                 gts = TrainStep(gmodel)
                 gtstep = lambda: gts.step(x, y, noise=noise, N=K)
                 for _ in range(2):
                     gtstep()
-                dtt = mdist.timed_region(gtstep, args.train_steps, None, dev)
+                torch.cuda.synchronize()
+                gtl = "eager"
+                if args.graph:
+                    try:
+                        gg = GraphedStep(gts, x, y, noise=noise, N=K)
+                        gg.replay()
+                        torch.cuda.synchronize()
+                        assert torch.isfinite(gg.out["log_p"]).all()
+                        gtstep, gtl = gg.replay, "hip-graph replay"
+                    except Exception as e:
+                        log(f"glow variant train-step graph capture unavailable ({type(e).__name__}: {e}); eager")
+                        torch.cuda.synchronize()
+                        gts._capture = None
+                dtt, gtw = timed_windows(gtstep, args.train_steps, args.windows, None, dev)
                 glow_variant["train_step"] = {"ms_per_step": round(dtt / args.train_steps * 1e3, 3), "img_per_s": round(B * args.train_steps / dtt, 1),
-                                              "steps": args.train_steps, "launch": "eager"}
-                log(f"glow variant train step: {glow_variant['train_step']['ms_per_step']} ms/step")
+                                              "windows_ms": gtw, "steps": args.train_steps, "launch": gtl}
+                log(f"glow variant train step: {glow_variant['train_step']['ms_per_step']} ms/step ({gtl})")
         except Exception as e:
             log(f"glow variant skipped: {type(e).__name__}: {e}")
 

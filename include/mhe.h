@@ -41,9 +41,10 @@ enum { MHE_FLOW_FORWARD = 0, MHE_FLOW_INVERSE = 1 };
 /* library ---------------------------------------------------------------- */
 /* MHE_ABI_VERSION changes whenever a struct layout or an existing signature changes (new entry points alone do not bump it).
  *   1: round 1.   2: mhe_conv_desc gained `tile` and `res_half` (every convolution entry reads them), mhe_conv_wgrad_nhwc
- *   takes the descriptor.   3: statistic accumulators are fixed-point mhe_stat_t words (below) instead of f32; pixel counts are double.  A caller compiled against another version must not call in: check
+ *   takes the descriptor.   3: statistic accumulators are fixed-point mhe_stat_t words (below) instead of f32; pixel counts are double.
+ *   4 (round 5): mhe_bottleneck_tail256_* and the forced convolution variants 5 / 6 / 15 are gone (negative results, pruned).  A caller compiled against another version must not call in: check
  *   mhe_abi_version() == MHE_ABI_VERSION once after loading the library. */
-#define MHE_ABI_VERSION 3
+#define MHE_ABI_VERSION 4
 int         mhe_abi_version(void);
 
 /* Sharded per-channel accumulators (BatchNorm batch statistics, BatchNorm-reverse sums): 64-bit FIXED-POINT words added with integer
@@ -677,6 +678,24 @@ int mhe_relu_bwd_add_f32(float *acc, const void *g, const float *h, long n, int 
 /* log_prob[r] = log N(z_r; 0, I) + sign * (logdet[r] + logdet_const); optionally un-pads v_padded into v_out [R,dim]. */
 int mhe_glow_finish_f32(const float *z_padded, const float *v_padded, const float *logdet, float *v_out, float *log_prob,
                         long R, int dim, float sign, float logdet_const, void *stream);
+/* ... with the log-determinant constant read from the device: log_prob = base(z) + sign * logdet[r] + sum(const_parts[0 .. n_parts)) - a captured
+ * HIP graph then follows the parameters from step to step */
+int mhe_glow_finish_dev_f32(const float *z_padded, const float *v_padded, const float *logdet, float *v_out, float *log_prob,
+                            long R, int dim, float sign, const float *const_parts, int n_parts, void *stream);
+/* The ActNorm + LU re-parameterisation on the device (csrc/glow_affine.hip; nflows transforms.ActNorm / LULinear, oracle/glow_ref.py): one
+ * workgroup per layer, float64.  param_ptrs: [layers][6] device pointers (log_scale, shift, lower_entries, upper_entries,
+ * unconstrained_upper_diag, bias: f32 tensors of `features`, features (features - 1) / 2 entries in numpy's tril_indices(-1) / triu_indices(1)
+ * order).  Outputs, f32 zero-padded to 64: A = L U diag(exp(log_scale)) [layers][64][64], c = L U shift + bias [layers][64], A^-1, its
+ * transpose, c^-1 = -A^-1 c; const_parts [layers] = sum(log_scale) + sum(log diag U); workspace (mhe_glow_affine_workspace_doubles doubles)
+ * keeps the float64 factors for mhe_glow_reparam_bwd_f64. */
+size_t mhe_glow_affine_workspace_doubles(int layers, int features);
+int mhe_glow_affine_f64(const void *param_ptrs, int layers, int features, float eps, float *A, float *c, float *Ainv, float *AinvT,
+                        float *cinv, float *const_parts, double *workspace, void *stream);
+/* Gradients of the six small parameter tensors of every layer from dL/dA^-1 (g_ainv_ptrs[l]: f32 [64][64]), dL/dc^-1 (g_cinv_ptrs[l]: f32 [64])
+ * and S = q_sign * sum(g_log_p[0 .. n_log_p)) = sum_r dL/dlog q[r] (g_log_p may be NULL); written through grad_ptrs ([layers][6] device pointers,
+ * the order of param_ptrs).  Formulas: csrc/glow_affine.hip. */
+int mhe_glow_reparam_bwd_f64(const void *g_ainv_ptrs, const void *g_cinv_ptrs, const float *g_log_p, int n_log_p, float q_sign, int layers,
+                             int features, const double *workspace, const void *grad_ptrs, void *stream);
 
 #ifdef __cplusplus
 }

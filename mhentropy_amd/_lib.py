@@ -86,6 +86,10 @@ SIGNATURES = {
     "mhe_glow_glu_bwd_f32": (_i, [_p, _p, _p, _l, _p, _p, _l, _i, _i, _i, _i, _p]),
     "mhe_relu_bwd_add_f32": (_i, [_p, _p, _p, _l, _i, _p]),
     "mhe_glow_finish_f32": (_i, [_p, _p, _p, _p, _p, _l, _i, _f, _f, _p]),
+    "mhe_glow_finish_dev_f32": (_i, [_p, _p, _p, _p, _p, _l, _i, _f, _p, _i, _p]),
+    "mhe_glow_affine_workspace_doubles": (_sz, [_i, _i]),
+    "mhe_glow_affine_f64": (_i, [_p, _i, _i, _f] + [_p] * 7 + [_p]),
+    "mhe_glow_reparam_bwd_f64": (_i, [_p, _p, _p, _i, _f, _i, _i, _p, _p, _p]),
     "mhe_mano_regress_joints_f32": (_i, [_p, _p, _p, _i, _p]),
     "mhe_elbo_reduce_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
     "mhe_conv2d_nhwc": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
@@ -146,7 +150,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 3          # MHE_ABI_VERSION of include/mhe.h
+ABI_VERSION = 4          # MHE_ABI_VERSION of include/mhe.h
 
 
 class MheError(RuntimeError):

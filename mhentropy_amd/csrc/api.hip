@@ -14,5 +14,5 @@ void set_error(const char *fmt, ...) {
 
 // 2: mhe_conv_desc grew `tile` and `res_half` (read by every convolution entry) and mhe_conv_wgrad_nhwc takes the descriptor
 // 3: statistic accumulators are fixed-point mhe_stat_t words (order-independent integer atomics); pixel counts are double
-extern "C" int mhe_abi_version(void) { return 3; }
+extern "C" int mhe_abi_version(void) { return 4; }
 extern "C" const char *mhe_last_error(void) { return mhe::g_err; }

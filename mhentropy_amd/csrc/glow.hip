@@ -157,10 +157,13 @@ __global__ __launch_bounds__(256) void pad64_kernel(const float *__restrict__ x,
 
 __global__ __launch_bounds__(256) void finish_kernel(const float *__restrict__ zp, const float *__restrict__ vp, const float *__restrict__ logdet,
                                                      float *__restrict__ v_out, float *__restrict__ logp, long R, int dim, float sign,
-                                                     float logdet_const, int ld) {
+                                                     float logdet_const, int ld, const float *__restrict__ const_parts, int n_parts) {
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
+    // the per-layer constants sum(log_scale) + sum(log diag U) as mhe_glow_affine_f64 left them on the device: + in the density direction,
+    // - in the sampling direction, i.e. sign * sum inside the bracket below
+    for (int i = 0; i < n_parts; ++i) logdet_const += sign * const_parts[i];
     float sq = 0.f;
     for (int c = lane; c < dim; c += 64) {
         const float z = zp[r * ld + c];
@@ -226,7 +229,18 @@ extern "C" int mhe_glow_finish_f32(const float *z_padded, const float *v_padded,
                                    long R, int dim, float sign, float logdet_const, void *stream) {
     MHE_REQUIRE(z_padded && logdet && log_prob && (!v_out || v_padded) && R > 0 && dim > 0 && dim <= 256, "mhe_glow_finish_f32: bad arguments");
     hipLaunchKernelGGL(glow::finish_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z_padded, v_padded, logdet, v_out,
-                       log_prob, R, dim, sign, logdet_const, pad_cols(dim));
+                       log_prob, R, dim, sign, logdet_const, pad_cols(dim), (const float *)nullptr, 0);
+    return check_launch("finish_kernel");
+}
+
+// ... with the log-determinant constant read from the device: sum of const_parts[0 .. n_parts) (mhe_glow_affine_f64) - a captured HIP graph
+// then follows the parameters from step to step (a host scalar would be baked into the graph)
+extern "C" int mhe_glow_finish_dev_f32(const float *z_padded, const float *v_padded, const float *logdet, float *v_out, float *log_prob,
+                                       long R, int dim, float sign, const float *const_parts, int n_parts, void *stream) {
+    MHE_REQUIRE(z_padded && logdet && log_prob && (!v_out || v_padded) && R > 0 && dim > 0 && dim <= 256 && const_parts && n_parts > 0 && n_parts <= 64,
+                "mhe_glow_finish_dev_f32: bad arguments");
+    hipLaunchKernelGGL(glow::finish_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z_padded, v_padded, logdet, v_out,
+                       log_prob, R, dim, sign, 0.f, pad_cols(dim), const_parts, n_parts);
     return check_launch("finish_kernel");
 }
 

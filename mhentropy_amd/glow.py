@@ -47,7 +47,9 @@ class _LULinear(nn.Module):
         self.unconstrained_upper_diag = nn.Parameter(torch.full((features,), math.log(math.exp(1 - eps) - 1)))   # identity init
         self.bias = nn.Parameter(torch.zeros(features))
 
+
     def weight_and_diag(self):
+        """W = L U and U's diagonal in float64 on the host (the wide body flow, features > 64; the hand flow builds them on the device)"""
         D = self.features
         lower = torch.zeros(D, D, dtype=torch.float64)
         li = np.tril_indices(D, k=-1)
@@ -136,29 +138,54 @@ class ConditionalGlow(nn.Module):
         self.compute_dtype = torch.float32
 
     # ---- derived device operands, rebuilt when a parameter changes --------------------------------------
+    def small_param_table(self):
+        """int64 [layers, 6] device tensor: addresses of log_scale, shift, lower_entries, upper_entries, unconstrained_upper_diag, bias of
+        every layer (the operand of ops.glow_affine); rebuilt when a parameter's storage moves"""
+        T = self._transform._transforms
+        rows = [[p.data_ptr() for p in (T[3 * l].log_scale, T[3 * l].shift, T[3 * l + 1].lower_entries, T[3 * l + 1].upper_entries,
+                                        T[3 * l + 1].unconstrained_upper_diag, T[3 * l + 1].bias)] for l in range(self.num_layers)]
+        key = tuple(map(tuple, rows))
+        if getattr(self, "_ptab", None) is None or self._ptab[0] != key:
+            self._ptab = (key, torch.tensor(rows, dtype=torch.int64, device=next(self.parameters()).device))
+        return self._ptab[1]
+
     def _packed(self):
+        ext = getattr(self, "_external_pack", None)
+        if ext is not None:          # a train.TrainStep owns the parameters: its device-resident operand layouts, refreshed every step
+            return ext()
         dev = next(self.parameters()).device
         ver = tuple(p._version for p in self.parameters()) + (str(dev),)
         if self._pack is not None and self._pack[0] == ver:
             return self._pack[1]
         D, H, Fc, T = self.features, self.hidden, self.context_features, self._transform._transforms
-        pk = {"layers": [], "const": 0.0}
+        if D <= 64:
+            # ActNorm + LU of every layer as one 45x45 affine map and its inverse: one launch, float64 on the device (no host round trip)
+            aff = ops.glow_affine(self.small_param_table(), self.num_layers, D, T[1].eps)
+            pk = {"layers": [], "const_parts": aff["const_parts"], "aff": aff}
+        else:
+            # the wide body flow (144-D pose, padded to 192 columns): float64 on the host, once per parameter version
+            pk = {"layers": [], "aff": None}
+            parts = []
         wctx, bctx = [], []
         for l in range(self.num_layers):
-            an, lu, cp = T[3 * l], T[3 * l + 1], T[3 * l + 2]
-            W, diag = lu.weight_and_diag()
-            s = torch.exp(an.log_scale.detach().double().cpu())
-            A = W * s[None, :]                                           # x -> W (s*x + shift) + b
-            c = W @ an.shift.detach().double().cpu() + lu.bias.detach().double().cpu()
-            Ainv = torch.linalg.inv(A)
-            Dp = self.Dp
-            pad = lambda M, v: (F.pad(M, (0, Dp - D, 0, Dp - D)).float().to(dev).contiguous(), F.pad(v, (0, Dp - D)).float().to(dev).contiguous())
-            d = {}
-            d["A"], d["c"] = pad(A, c)
-            d["Ainv"], d["cinv"] = pad(Ainv, -(Ainv @ c))
-            pk["const"] += float(an.log_scale.detach().double().sum().cpu() + torch.log(diag).sum())
+            cp = T[3 * l + 2]
+            if D <= 64:
+                d = {"A": aff["A"][l], "c": aff["c"][l], "Ainv": aff["Ainv"][l], "cinv": aff["cinv"][l]}
+            else:
+                an, lu = T[3 * l], T[3 * l + 1]
+                W, diag = lu.weight_and_diag()
+                sc = torch.exp(an.log_scale.detach().double().cpu())
+                A = W * sc[None, :]                                          # x -> W (s*x + shift) + b
+                c = W @ an.shift.detach().double().cpu() + lu.bias.detach().double().cpu()
+                Ainv = torch.linalg.inv(A)
+                Dp = self.Dp
+                pad = lambda M, v: (F.pad(M, (0, Dp - D, 0, Dp - D)).float().to(dev).contiguous(), F.pad(v, (0, Dp - D)).float().to(dev).contiguous())
+                d = {}
+                d["A"], d["c"] = pad(A, c)
+                d["Ainv"], d["cinv"] = pad(Ainv, -(Ainv @ c))
+                parts.append(float(an.log_scale.detach().double().sum().cpu() + torch.log(diag).sum()))
             net = cp.transform_net
-            idf = cp.identity_features.cpu()
+            idf = cp.identity_features
             w0 = net.initial_layer.weight.detach()
             wx = torch.zeros(H, self.Dp, device=dev)
             wx[:, idf.to(dev)] = w0[:, :idf.numel()]
@@ -175,8 +202,10 @@ class ConditionalGlow(nn.Module):
             Pp = (2 * nt + 63) // 64 * 64
             wf = torch.zeros(Pp, H, device=dev); wf[:2 * nt] = net.final_layer.weight.detach()
             bf = torch.zeros(Pp, device=dev); bf[:2 * nt] = net.final_layer.bias.detach()
-            d["wf"], d["bf"], d["T"], d["first"] = wf.contiguous(), bf.contiguous(), nt, int(cp.transform_features[0])
+            d["wf"], d["bf"], d["T"], d["first"] = wf.contiguous(), bf.contiguous(), nt, 1 - (l % 2)      # (the alternating mask: odd columns first)
             pk["layers"].append(d)
+        if D > 64:
+            pk["const_parts"] = torch.tensor(parts, dtype=torch.float32, device=dev)
         pk["wctx"], pk["bctx"] = torch.cat(wctx).contiguous(), torch.cat(bctx).contiguous()
         self._pack = (ver, pk)
         return pk
@@ -243,12 +272,8 @@ class ConditionalGlow(nn.Module):
             ops.check(L.mhe_glow_coupling_f32(ops._ptr(v), ops._ptr(prm), ops._ptr(y), ops._ptr(logdet), R, D, d["first"], d["T"], int(inverse), s()),
                       "mhe_glow_coupling_f32")
             v = ops.linear(y, d["Ainv"], d["cinv"]) if inverse else y
-        out = torch.empty(R, D, device=dev)
-        logp = torch.empty(R, device=dev)
         z = z_in if inverse else v                                               # the base-density argument
-        ops.check(L.mhe_glow_finish_f32(ops._ptr(z), ops._ptr(v), ops._ptr(logdet), ops._ptr(out), ops._ptr(logp), R, D,
-                                        -1.0 if inverse else 1.0, -pk["const"] if inverse else pk["const"], s()), "mhe_glow_finish_f32")
-        return out, logp
+        return ops.glow_finish(z, v, logdet, R, D, inverse, pk["const_parts"])
 
     # ---- reference call surface ----------------------------------------------------------------------------
     def log_prob(self, inputs, context=None, rows_per_context=None):

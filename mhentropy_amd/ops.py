@@ -1410,3 +1410,33 @@ def flow_lrelu_bwd_mixed(g, h, out_f32=None, out_bf16=None, slope=0.01):
     _chk(g, g.dtype, "lrelu_bwd_mixed.g"); _chk(h, h.dtype, "lrelu_bwd_mixed.h", g.shape)
     check(_lib.lib().mhe_flow_lrelu_bwd_mixed(_ptr(g), dtype_code(g.dtype), _ptr(h), dtype_code(h.dtype), _ptr(out_f32), _ptr(out_bf16),
                                               g.numel(), float(slope), _stream()), "mhe_flow_lrelu_bwd_mixed")
+
+
+# ---- conditional Glow: the ActNorm + LU re-parameterisation on the device (csrc/glow_affine.hip) ---------------------------------------
+def glow_affine(ptr_table, layers, features, eps, out=None):
+    """ptr_table: int64 [layers, 6] device tensor of parameter addresses (log_scale, shift, lower, upper, unconstrained diag, bias).
+    Returns / refreshes dict(A, Ainv, AinvT [L,64,64], c, cinv [L,64], const_parts [L], ws float64): mhe_glow_affine_f64"""
+    dev = ptr_table.device
+    if out is None:
+        out = {k: torch.zeros(layers, 64, 64, device=dev) for k in ("A", "Ainv", "AinvT")}
+        out.update({k: torch.zeros(layers, 64, device=dev) for k in ("c", "cinv")})
+        out["const_parts"] = torch.zeros(layers, device=dev)
+        out["ws"] = torch.zeros(int(_lib.lib().mhe_glow_affine_workspace_doubles(layers, features)), device=dev, dtype=torch.float64)
+    check(_lib.lib().mhe_glow_affine_f64(_ptr(ptr_table), layers, features, float(eps), _ptr(out["A"]), _ptr(out["c"]), _ptr(out["Ainv"]),
+                                         _ptr(out["AinvT"]), _ptr(out["cinv"]), _ptr(out["const_parts"]), _ptr(out["ws"]), _stream()), "mhe_glow_affine_f64")
+    return out
+
+
+def glow_reparam_bwd(g_ainv_ptrs, g_cinv_ptrs, g_logp, layers, features, ws, grad_ptrs, q_sign=-1.0):
+    """gradients of every layer's six small tensors, written through grad_ptrs (int64 [layers, 6] addresses): mhe_glow_reparam_bwd_f64"""
+    check(_lib.lib().mhe_glow_reparam_bwd_f64(_ptr(g_ainv_ptrs), _ptr(g_cinv_ptrs), _ptr(g_logp), 0 if g_logp is None else g_logp.numel(), float(q_sign),
+                                              layers, features, _ptr(ws), _ptr(grad_ptrs), _stream()), "mhe_glow_reparam_bwd_f64")
+
+
+def glow_finish(z_padded, v_padded, logdet, R, dim, inverse, const_parts, want_out=True):
+    """(out [R,dim] | None, log_prob [R]) with the log-determinant constant summed from the device-resident per-layer parts"""
+    out = torch.empty(R, dim, device=z_padded.device) if want_out else None
+    logp = torch.empty(R, device=z_padded.device)
+    check(_lib.lib().mhe_glow_finish_dev_f32(_ptr(z_padded), _ptr(v_padded), _ptr(logdet), _ptr(out), _ptr(logp), R, dim, -1.0 if inverse else 1.0,
+                                             _ptr(const_parts), const_parts.numel(), _stream()), "mhe_glow_finish_dev_f32")
+    return out, logp

@@ -8,9 +8,9 @@ PARITY UNPINNED like the forward (mhentropy_amd/glow.py): checked against torch 
 Per layer (sampling order L-1 .. 0, reverse pass 0 .. L-1):
     params = ResidualNet(v[identity columns], context);  y = (v - shift) / scale on the transform columns;  v' = Ainv y + cinv
 with (A, c) the ActNorm + LU affine map.  Dense products: mhe_linear_f32 / mhe_conv_wgrad_nhwc; elementwise stages: csrc/glow.hip.
-The gradients of the 45x45 re-parameterisation (log_scale, shift, LU entries, softplus diagonal, bias from dAinv, dcinv and the
-log-det constant) are a few 45x45 products per layer, done in float64 on the host - bookkeeping of the same kind as weight
-packing, not part of the per-hypothesis path.  Dropout (train mode, p = 0.2: hand/network.py:343-344,781) is applied to the second activation
+The 45x45 re-parameterisation - A, A^-1, the log-det constant from (log_scale, shift, LU entries, softplus diagonal, bias), and their
+gradients from dAinv, dcinv and the constant - runs in float64 ON THE DEVICE since round 5 (csrc/glow_affine.hip: one workgroup per layer;
+rounds 2-4 did it in numpy on the host, a queue drain per step that kept this branch out of HIP graphs).  Dropout (train mode, p = 0.2: hand/network.py:343-344,781) is applied to the second activation
 of every residual block in the sampling pass (mask bits kept on the tape) and to its gradient in the reverse pass (glow.py, mhe_dropout).
 """
 import ctypes as C
@@ -90,75 +90,49 @@ class GlowPart:
             wctx_idx.append(ts._pidx(net.initial_layer.weight)[:, nid:]); bctx_idx.append(ts._pidx(net.initial_layer.bias))
             for blk in net.blocks:
                 wctx_idx.append(ts._pidx(blk.context_layer.weight)); bctx_idx.append(ts._pidx(blk.context_layer.bias))
-            # the layer's small parameters sit next to each other in the flat buffer: one device->host copy per layer
-            small = [an.log_scale, an.shift, lu.lower_entries, lu.upper_entries, lu.unconstrained_upper_diag, lu.bias]
-            lo = min(ts.off[id(p)] for p in small)
-            hi = max(ts.off[id(p)] + p.numel() for p in small)
-            d["small"] = (lo, hi, [(ts.off[id(p)] - lo, p.numel()) for p in small])
             self.layers.append(d)
         self.wctx = ts._derived(torch.cat(wctx_idx), torch.float32)
         self.bctx = ts._derived(torch.cat(bctx_idx), torch.float32)
         self.wctxT = ts._derived(torch.cat(wctx_idx).t().contiguous(), torch.float32)
-        dev = ts.dev
-        self.aff = {k: torch.zeros(L, 64, 64, device=dev) for k in ("A", "Ainv", "AinvT")}
-        self.aff.update({k: torch.zeros(L, 64, device=dev) for k in ("c", "cinv")})
-        self.const = 0.0
-        self._host = None
+        # the six small tensors of every layer (in the flat parameter buffer) -> A, A^-1, c, c^-1, constant parts: one launch per refresh
+        self._ptab = torch.tensor([[p.data_ptr() for p in (d["an"].log_scale, d["an"].shift, d["lu"].lower_entries, d["lu"].upper_entries,
+                                                           d["lu"].unconstrained_upper_diag, d["lu"].bias)] for d in self.layers],
+                                  dtype=torch.int64, device=ts.dev)
+        self.aff = ops.glow_affine(self._ptab, L, D, self.layers[0]["lu"].eps)
+        self._gtabs = None
         self._tp = None
-        li, ui = np.tril_indices(D, k=-1), np.triu_indices(D, k=1)
-        self._li, self._ui = li, ui
+        glow._external_pack = self.module_pack
 
-    # ------------------------------------------------------------------ the 45x45 affine maps (host float64, tiny)
-    def _small_params(self):
-        """log_scale, shift, lower, upper, unconstrained diag, bias of every layer as float64 numpy (one small D2H per layer)"""
-        out = []
-        for d in self.layers:
-            lo, hi, parts = d["small"]
-            seg = self.ts.P[lo:hi].cpu().numpy().astype(np.float64)
-            out.append([seg[o:o + n] for o, n in parts])
-        return out
-
-    def _lu(self, lower_e, upper_e, udiag):
-        D = self.g.features
-        Lm, U = np.eye(D), np.zeros((D, D))
-        Lm[self._li] = lower_e
-        U[self._ui] = upper_e
-        diag = np.logaddexp(0.0, udiag) + self.layers[0]["lu"].eps        # softplus + eps (nflows LULinear)
-        U[np.arange(D), np.arange(D)] = diag
-        return Lm, U, diag
-
+    # ------------------------------------------------------------------ the 45x45 affine maps (float64 on the device, tiny)
     def refresh_affine(self):
-        """A = W diag(exp(log_scale)), c = W shift + b and their inverse, padded to 64, from the current parameters"""
-        D = self.g.features
-        host = {k: np.zeros(v.shape, np.float32) for k, v in self.aff.items()}
-        const, keep = 0.0, []
-        for l, (ls, sh, lo_e, up_e, ud, bias) in enumerate(self._small_params()):
-            Lm, U, diag = self._lu(lo_e, up_e, ud)
-            W, sc = Lm @ U, np.exp(ls)
-            A, c = W * sc[None, :], W @ sh + bias
-            Ainv = np.linalg.inv(A)
-            host["A"][l, :D, :D], host["Ainv"][l, :D, :D], host["AinvT"][l, :D, :D] = A, Ainv, Ainv.T
-            host["c"][l, :D], host["cinv"][l, :D] = c, -(Ainv @ c)
-            const += ls.sum() + np.log(diag).sum()
-            keep.append((Lm, U, diag, W, sc, sh, ud, A, c, Ainv))
-        for k, v in self.aff.items():
-            v.copy_(torch.from_numpy(host[k]))
-        self.const, self._host = float(const), keep
-
-    def _pack(self):
-        if self._host is None:
-            self.refresh_affine()
-        return self
+        """A = W diag(exp(log_scale)), c = W shift + b, their inverse (padded to 64) and the per-layer log-det constants from the CURRENT
+        parameters: mhe_glow_affine_f64 into the same tensors (graph-capturable: no host value depends on the parameters)"""
+        ops.glow_affine(self._ptab, self.g.num_layers, self.g.features, self.layers[0]["lu"].eps, out=self.aff)
 
     def invalidate(self):
-        self._host = None
-        self.g._pack = None          # the module's own (inference) operand cache follows the new parameters too
+        pass             # (nothing host-side follows the parameters any more; the operand layouts are refreshed by the trainer's gather)
+
+    def module_pack(self):
+        """the operand dict ConditionalGlow._run reads (glow.py:_packed), on the trainer's device-resident layouts: the modules' own forward /
+        sample / log_prob paths follow the optimizer without any host-side re-packing"""
+        self.ts.sync()
+        self.refresh_affine()
+        pk = {"layers": [], "const_parts": self.aff["const_parts"], "aff": self.aff, "wctx": self.wctx, "bctx": self.bctx}
+        for l, d in enumerate(self.layers):
+            e = {"A": self.aff["A"][l], "c": self.aff["c"][l], "Ainv": self.aff["Ainv"][l], "cinv": self.aff["cinv"][l], "wx": d["wx"],
+                 "blocks": d["blocks"], "wf": d["wf"], "bf": d["bf"], "T": d["T"], "first": d["first"]}
+            if self.mixed:
+                e["blocks_bf16"] = [bb[:2] for bb in d["blocks_b"]]
+            else:
+                e["blocks_bf16"] = [(w0.to(torch.bfloat16), w1.to(torch.bfloat16)) for (w0, _, w1, _) in d["blocks"]] if self.g.compute_dtype == torch.bfloat16 else None
+            pk["layers"].append(e)
+        return pk
 
     # ------------------------------------------------------------------ sampling pass with tape
     def forward(self, z0, feat):
         ts, g = self.ts, self.g
         L_, D, H, B, R = _lib.lib(), g.features, g.hidden, feat.shape[0], z0.shape[0]
-        self._pack()
+        self.refresh_affine()
         s, dev = ops._stream, z0.device
         ctab = ops.linear(feat, self.wctx, self.bctx)
         cs = ctab.shape[1]
@@ -197,10 +171,7 @@ class GlowPart:
                       "mhe_glow_coupling_f32")
             tape[l] = {"v": v, "hs": hs, "t2": t2s, "t3": t3s, "prm": prm, "y": y, "drop": drops}
             v = ops.linear(y, self.aff["Ainv"][l], self.aff["cinv"][l])
-        x = torch.empty(R, D, device=dev)
-        logq = torch.empty(R, device=dev)
-        ops.check(L_.mhe_glow_finish_f32(ops._ptr(zp), ops._ptr(v), ops._ptr(logdet), ops._ptr(x), ops._ptr(logq), R, D, -1.0, -self.const, s()),
-                  "mhe_glow_finish_f32")
+        x, logq = ops.glow_finish(zp, v, logdet, R, D, True, self.aff["const_parts"])
         self._tp = {"tape": tape, "ctab": ctab, "feat": feat}
         return x, logq
 
@@ -210,7 +181,6 @@ class GlowPart:
         parameter's gradient into the trainer's raw arena and returns dL/d feat (B, F) through the context terms."""
         ts, g = self.ts, self.g
         L_, D, H, R = _lib.lib(), g.features, g.hidden, g_x.shape[0]
-        self._pack()
         tp = self._tp
         s, dev = ops._stream, g_x.device
         raw = lambda o, shape: ts._raw(o, shape)
@@ -270,22 +240,15 @@ class GlowPart:
         return g_feat
 
     def _reparam_backward(self, g_logp):
-        """ActNorm / LU parameter gradients from dAinv, dcinv and the log-det constant (float64 numpy on the host:
-        one device->host copy of the 4 x (64x64 + 64) sums, a few 45x45 products per layer, one host->device copy back)."""
-        ts, D = self.ts, self.g.features
-        S = 0.0 if g_logp is None else -float(g_logp.double().sum())        # sum_r dL/dlog q[r]
-        for rs, (Lm, U, diag, W, sc, sh, ud, A, c, Ainv) in zip(self.layers, self._host):
-            G = ts._raw(rs["r_ainv"], (64, 64))[:D, :D].cpu().numpy().astype(np.float64)
-            gc = ts._raw(rs["r_cinv"], (64,))[:D].cpu().numpy().astype(np.float64)
-            G = G - np.outer(gc, c)                              # cinv = -Ainv c
-            dc = -Ainv.T @ gc
-            dA = -Ainv.T @ G @ Ainv.T
-            dW = dA * sc[None, :] + np.outer(dc, sh)
-            d_log_scale = (dA * W).sum(0) * sc + S
-            d_shift = W.T @ dc
-            dL, dU = dW @ U.T, Lm.T @ dW                          # W = L U
-            d_udiag = (np.diagonal(dU) + S / diag) / (1.0 + np.exp(-ud))
-            an, lu = rs["an"], rs["lu"]
-            for key, val, p in (("r_log_scale", d_log_scale, an.log_scale), ("r_shift", d_shift, an.shift), ("r_lower", dL[self._li], lu.lower_entries),
-                                ("r_upper", dU[self._ui], lu.upper_entries), ("r_udiag", d_udiag, lu.unconstrained_upper_diag), ("r_bias", dc, lu.bias)):
-                ts._raw(rs[key], p.shape).copy_(torch.from_numpy(np.ascontiguousarray(val, dtype=np.float32)).reshape(p.shape))
+        """ActNorm / LU parameter gradients from dAinv, dcinv (in the raw arena) and the log-det constant: mhe_glow_reparam_bwd_f64, one
+        workgroup per layer, float64, written straight into the six raw-gradient slots of every layer"""
+        ts = self.ts
+        if self._gtabs is None or self._gtabs[0] != ts.raw.data_ptr():
+            base = ts.raw.data_ptr()
+            at = lambda o: base + 4 * o
+            mk = lambda rows: torch.tensor(rows, dtype=torch.int64, device=ts.dev)
+            self._gtabs = (base, mk([at(d["r_ainv"]) for d in self.layers]), mk([at(d["r_cinv"]) for d in self.layers]),
+                           mk([[at(d["r_" + k]) for k in ("log_scale", "shift", "lower", "upper", "udiag", "bias")] for d in self.layers]))
+        _, ga, gc, gp = self._gtabs
+        # sum_r dL/dlog q[r] = -sum_b g_logp[b] (the entropy term: each image's K rows carry g_logp[b] * (-1 / K))
+        ops.glow_reparam_bwd(ga, gc, g_logp, self.g.num_layers, self.g.features, self.aff["ws"], gp, q_sign=-1.0)

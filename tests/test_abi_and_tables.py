@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, s), f"{s} declared in include/mhe.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
     assert set(_lib.SIGNATURES) == set(syms)
-    assert L.mhe_abi_version() == 3
+    assert L.mhe_abi_version() == 4
 
 
 def test_layout_constants_agree():
