@@ -682,6 +682,28 @@ int mhe_glow_finish_f32(const float *z_padded, const float *v_padded, const floa
  * HIP graph then follows the parameters from step to step */
 int mhe_glow_finish_dev_f32(const float *z_padded, const float *v_padded, const float *logdet, float *v_out, float *log_prob,
                             long R, int dim, float sign, const float *const_parts, int n_parts, void *stream);
+/* relu'(h) reverse with h (or relu(h): same sign) stored as f32 or bf16: acc += g * [h > 0] */
+int mhe_relu_bwd_add_mixed(float *acc, const void *g, const void *h, long n, int g_dtype, int h_dtype, void *stream);
+/* Dropout mask bits alone (n elements, n % 8 == 0; byte i = keep bits of elements 8 i .. 8 i + 7, as mhe_dropout writes them), drawn from the
+ * device-resident Philox state, which advances. */
+int mhe_dropout_bits(unsigned char *bits, long n, float p_drop, unsigned long long *state, void *stream);
+/* The conditional Glow's sampling direction, ALL layers in one launch (csrc/glow_fwd.hip; hidden 512, 2 residual blocks per layer, dim <= 48;
+ * reference call site hand/network.py:736-742, algorithm oracle/glow_ref.py - parity unpinned).  N hypotheses for each of B images; hypothesis n of
+ * image b is row n * row_n + b * row_b of every [R = N B] tensor ((B, 1) sample-major or (1, N) batch-major).
+ *   noise [R][dim] f32 -> out [R][dim], log_q [R];   ctab [B][ctab_stride] f32: slot l * 3 = initial-layer context term + bias, slots l * 3 + 1, + 2 =
+ *   the blocks' GLU gate pre-activations;   weights bf16 in MFMA fragment order ([rows / 16][K / 32][4][16][8], ops.mfma_fragment_major):
+ *   wxF [L][512][64] (initial layer on the 64-padded variable), w0F / w1F [L][2][512][512], wsF / wuF [L][64][512] = the final layer's shift /
+ *   unconstrained-scale rows placed at the flow variable's own column (row c = parameter of transform column c, other rows zero), bs / bu [L][64]
+ *   their biases likewise;   b0 / b1 [L][2][512];   ainvT [L][64][64], cinv [L][64], const_parts [L] from mhe_glow_affine_f64;
+ *   drop_bits [L][2][R * 64] bytes (mhe_dropout_bits' format over [R][512]) or NULL = no dropout.
+ * Tape (all NULL, or all given for the train step): v_e, y_e, prm_e f32 [L][R][64] (layer input, coupling output, [shift (T) | us (T) | 0]),
+ * tb_e, t2_e, t3_e bf16 [L][2][R][512] (relu(h), dropped second activation, W1 t2 + b1), hf_e bf16 [L][R][512] (the final layer's operand). */
+int mhe_glow_layers_supported(int N, int B, int dim, int hidden, int layers, int blocks);
+int mhe_glow_layers_bf16(const float *noise, const float *ctab, int ctab_stride, const void *wxF, const void *w0F, const void *w1F, const void *wsF,
+                         const void *wuF, const float *b0, const float *b1, const float *bs, const float *bu, const float *ainvT,
+                         const float *cinv, const float *const_parts, const unsigned char *drop_bits, float p_drop, float *out, float *log_q,
+                         float *v_e, float *y_e, float *prm_e, void *tb_e, void *t2_e, void *t3_e, void *hf_e, int N, int B, int dim,
+                         int hidden, int layers, int blocks, long row_n, long row_b, void *stream);
 /* The ActNorm + LU re-parameterisation on the device (csrc/glow_affine.hip; nflows transforms.ActNorm / LULinear, oracle/glow_ref.py): one
  * workgroup per layer, float64.  param_ptrs: [layers][6] device pointers (log_scale, shift, lower_entries, upper_entries,
  * unconstrained_upper_diag, bias: f32 tensors of `features`, features (features - 1) / 2 entries in numpy's tril_indices(-1) / triu_indices(1)

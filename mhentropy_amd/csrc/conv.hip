@@ -314,7 +314,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(mhe_stat_t *stats, con
     fx::wave_totals(stats, C, c, lane, clear != 0, s1, s2);
     if (lane) return;
     const double dmean = s1 / count;
-    const double dvar = fmax(s2 / count - dmean * dmean, 0.0);   // biased, as F.batch_norm normalises with
+    // biased, as F.batch_norm normalises with; a NaN total (the accumulators' out-of-range / non-finite marker) must stay NaN: fmax(NaN, 0) is 0,
+    // which made an overflowed sum of squares a silent variance of ZERO up to round 4
+    const double dvar0 = s2 / count - dmean * dmean, dvar = dvar0 != dvar0 ? dvar0 : fmax(dvar0, 0.0);
     const float mean = (float)dmean, var = (float)dvar;
     const float sc = gamma[c] / sqrtf(var + eps);
     scale[c] = sc;

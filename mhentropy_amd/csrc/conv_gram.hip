@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void gram_finalize_kernel(const double *__rest
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { qv += __shfl_xor(qv, o, 64); sv += __shfl_xor(sv, o, 64); }
     if (lane) return;
-    const double dmean = sv / count, dvar = fmax(qv / count - dmean * dmean, 0.0);
+    const double dmean = sv / count, dvar0 = qv / count - dmean * dmean, dvar = dvar0 != dvar0 ? dvar0 : fmax(dvar0, 0.0);      // (NaN stays NaN)
     const float mean = (float)dmean, var = (float)dvar;
     const float scv = gamma[c] / sqrtf(var + eps);
     scale[c] = scv;

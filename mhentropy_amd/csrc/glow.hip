@@ -134,13 +134,13 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float *__restrict__ 
 }
 
 // acc += g * [h > 0]   (reverse of t = relu(h) feeding a layer, accumulated onto the residual path's gradient)
-template <typename TG>
-__global__ __launch_bounds__(256) void relu_bwd_add_kernel(float *__restrict__ acc, const TG *__restrict__ g, const float *__restrict__ h, long n4) {
+template <typename TG, typename TH = float>
+__global__ __launch_bounds__(256) void relu_bwd_add_kernel(float *__restrict__ acc, const TG *__restrict__ g, const TH *__restrict__ h, long n4) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         v4f a = *reinterpret_cast<v4f *>(acc + i * 4);
-        float gg[4];
+        float gg[4], hh[4];
         load4<TG>(g + i * 4, gg);
-        const v4f hh = *reinterpret_cast<const v4f *>(h + i * 4);
+        load4<TH>(h + i * 4, hh);
 #pragma unroll
         for (int e = 0; e < 4; ++e) a[e] += hh[e] > 0.f ? gg[e] : 0.f;
         *reinterpret_cast<v4f *>(acc + i * 4) = a;
@@ -273,5 +273,17 @@ extern "C" int mhe_relu_bwd_add_f32(float *acc, const void *g, const float *h, l
         hipLaunchKernelGGL(glow::relu_bwd_add_kernel<float>, dim3(gg(n / 4)), dim3(256), 0, (hipStream_t)stream, acc, (const float *)g, h, n / 4);
     else
         hipLaunchKernelGGL(glow::relu_bwd_add_kernel<u16>, dim3(gg(n / 4)), dim3(256), 0, (hipStream_t)stream, acc, (const u16 *)g, h, n / 4);
+    return check_launch("relu_bwd_add_kernel");
+}
+
+// ... with the ReLU's argument (or its output: same sign) kept in bf16 - the fused Glow kernel's tape (csrc/glow_fwd.hip) holds relu(h) as bf16
+extern "C" int mhe_relu_bwd_add_mixed(float *acc, const void *g, const void *h, long n, int g_dtype, int h_dtype, void *stream) {
+    MHE_REQUIRE(acc && g && h && n > 0 && n % 4 == 0 && (g_dtype == MHE_F32 || g_dtype == MHE_BF16) && (h_dtype == MHE_F32 || h_dtype == MHE_BF16),
+                "mhe_relu_bwd_add_mixed: bad arguments");
+    if (h_dtype == MHE_F32) return mhe_relu_bwd_add_f32(acc, g, (const float *)h, n, g_dtype, stream);
+    if (g_dtype == MHE_F32)
+        hipLaunchKernelGGL((glow::relu_bwd_add_kernel<float, u16>), dim3(gg(n / 4)), dim3(256), 0, (hipStream_t)stream, acc, (const float *)g, (const u16 *)h, n / 4);
+    else
+        hipLaunchKernelGGL((glow::relu_bwd_add_kernel<u16, u16>), dim3(gg(n / 4)), dim3(256), 0, (hipStream_t)stream, acc, (const u16 *)g, (const u16 *)h, n / 4);
     return check_launch("relu_bwd_add_kernel");
 }

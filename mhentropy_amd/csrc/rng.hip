@@ -128,6 +128,42 @@ extern "C" int mhe_dropout(void *x, int dtype, unsigned char *bits, long n, floa
     return check_launch("dropout_kernel");
 }
 
+// ... the mask bits alone (no tensor touched): all dropouts of the fused Glow kernel (csrc/glow_fwd.hip) are drawn by ONE launch; byte i holds
+// the keep bits of elements 8 i .. 8 i + 7, the format mhe_dropout writes and applies
+namespace mhe { namespace rng {
+__global__ __launch_bounds__(256) void dropout_bits_kernel(unsigned char *__restrict__ bits, long n8, unsigned long long *__restrict__ state, unsigned thr) {
+    const unsigned long long key = state[0], base = state[1];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        unsigned r[4];
+        philox4x32_10(base + (unsigned long long)i, key, r);
+        unsigned m = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m |= (unsigned)(((r[k >> 1] >> (16 * (k & 1))) & 0xffffu) >= thr) << k;
+        bits[i] = (unsigned char)m;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned long long done = atomicAdd(&state[2], 1ull);
+        if (done == (unsigned long long)gridDim.x - 1ull) {
+            state[2] = 0ull;
+            state[1] = base + (unsigned long long)n8;
+            __threadfence();
+        }
+    }
+}
+}}  // namespace mhe::rng
+
+extern "C" int mhe_dropout_bits(unsigned char *bits, long n, float p_drop, unsigned long long *state, void *stream) {
+    using namespace mhe;
+    MHE_REQUIRE(bits && state && n > 0 && n % 8 == 0 && p_drop >= 0.f && p_drop < 1.f, "mhe_dropout_bits: bad arguments (n=%ld, p=%f)", n, (double)p_drop);
+    const long n8 = n / 8;
+    long blocks = (n8 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(rng::dropout_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, bits, n8, state, (unsigned)(p_drop * 65536.f + 0.5f));
+    return check_launch("dropout_bits_kernel");
+}
+
 // ---- BasicEnc's stochastic head (reference hand/network.py:121-138): sd = exp(l2 / 2) | sigmoid(l2), z = mn + sd * eps.
 // Dead for MHEnt (it keeps only mn, :779,862) - built so that the exported class returns the reference's (z, mn, sd).
 namespace mhe { namespace rng {

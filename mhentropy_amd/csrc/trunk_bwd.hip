@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void bn_mean_invstd_kernel(const mhe_stat_t *_
     fx::wave_totals(const_cast<mhe_stat_t *>(stats), C, c, lane, false, s1, s2);
     if (lane) return;
     const double dmean = s1 / (double)count;
-    const double dvar = fmax(s2 / (double)count - dmean * dmean, 0.0);
+    const double dvar0 = s2 / (double)count - dmean * dmean, dvar = dvar0 != dvar0 ? dvar0 : fmax(dvar0, 0.0);      // (NaN stays NaN)
     mean_invstd[c] = (float)dmean;
     mean_invstd[C + c] = 1.f / sqrtf((float)dvar + eps);
 }

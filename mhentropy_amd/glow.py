@@ -20,6 +20,7 @@ gates of every block of every layer) is ONE GEMM per image, indexed per hypothes
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -207,8 +208,36 @@ class ConditionalGlow(nn.Module):
         if D > 64:
             pk["const_parts"] = torch.tensor(parts, dtype=torch.float32, device=dev)
         pk["wctx"], pk["bctx"] = torch.cat(wctx).contiguous(), torch.cat(bctx).contiguous()
+        if H == 512 and self.num_blocks == 2 and D <= 48:
+            # the one-launch kernel's operands (csrc/glow_fwd.hip): bf16 copies in MFMA fragment order, the final layer's rows at the flow
+            # variable's own columns
+            nets = [T[3 * l + 2].transform_net for l in range(self.num_layers)]
+            st = lambda f: torch.stack([f(n) for n in nets])
+            fp = ops.glow_fused_layout(torch.stack([d["wx"] for d in pk["layers"]]),
+                                       st(lambda n: torch.stack([b.linear_layers[0].weight.detach() for b in n.blocks])),
+                                       st(lambda n: torch.stack([b.linear_layers[1].weight.detach() for b in n.blocks])),
+                                       torch.stack([d["wf"] for d in pk["layers"]]), torch.stack([d["bf"] for d in pk["layers"]]),
+                                       st(lambda n: torch.stack([b.linear_layers[0].bias.detach() for b in n.blocks])),
+                                       st(lambda n: torch.stack([b.linear_layers[1].bias.detach() for b in n.blocks])), D)
+            pk["fused"] = {k: (v.to(torch.bfloat16) if k.endswith("F") else v.float()).contiguous() for k, v in fp.items()}
         self._pack = (ver, pk)
         return pk
+
+    def _drop_bits(self, R):
+        """the dropout masks of one sampling pass of the one-launch kernel: uint8 [L, 2, R * 64] (layer, block; ops.dropout_'s bit format over
+        [R, hidden]) or None (eval mode / p = 0).  mask_feed / record_masks speak the layer-by-layer path's CALL ORDER - layers L-1 .. 0, blocks
+        0 .. 1 - so that tests written against it feed and read the same lists"""
+        if not (self.training and self.p_drop > 0.0):
+            return None
+        L, NB = self.num_layers, self.num_blocks
+        if self.mask_feed:
+            fed = [self.mask_feed.pop(0) for _ in range(L * NB)]
+            bits = torch.stack([torch.stack([fed[(L - 1 - l) * NB + b].reshape(-1) for b in range(NB)]) for l in range(L)]).contiguous()
+        else:
+            bits = ops.dropout_bits(L * NB * R * self.hidden, self.p_drop, next(self.parameters()).device).view(L, NB, R * self.hidden // 8)
+        if self.record_masks:
+            self.last_masks += [bits[L - 1 - k // NB, k % NB] for k in range(L * NB)]
+        return bits
 
     def dropout_(self, t):
         """the residual block's dropout on its second activation `t`, in place (train mode only); returns the mask bits or None"""
@@ -256,6 +285,13 @@ class ConditionalGlow(nn.Module):
         dev = v_in.device
         s = ops._stream
         ctab = ops.linear(context, pk["wctx"], pk["bctx"])                       # every context-only term, once per image
+        N = R // n_img
+        if (inverse and self.compute_dtype == torch.bfloat16 and pk.get("fused") is not None and row_div in (1, N)
+                and os.environ.get("MHE_GLOW_FUSED", "1") == "1" and ops.glow_layers_supported(N, n_img, D, H, self.num_layers, self.num_blocks)):
+            # the sampling direction of all layers in ONE launch (csrc/glow_fwd.hip; bf16 operands on the products, f32 residual stream,
+            # flow variable, coupling and affine map)
+            rn, rb = (n_img, 1) if row_div == 1 else (1, N)
+            return ops.glow_layers(v_in, ctab, pk["fused"], pk["aff"], self._drop_bits(R), self.p_drop, N, n_img, D, rn, rb)
         v = torch.empty(R, self.Dp, device=dev)
         ops.check(L.mhe_pad64_f32(ops._ptr(v_in), ops._ptr(v), R, D, s()), "mhe_pad64_f32")
         z_in = v

@@ -1440,3 +1440,70 @@ def glow_finish(z_padded, v_padded, logdet, R, dim, inverse, const_parts, want_o
     check(_lib.lib().mhe_glow_finish_dev_f32(_ptr(z_padded), _ptr(v_padded), _ptr(logdet), _ptr(out), _ptr(logp), R, dim, -1.0 if inverse else 1.0,
                                              _ptr(const_parts), const_parts.numel(), _stream()), "mhe_glow_finish_dev_f32")
     return out, logp
+
+
+# ---- conditional Glow: the sampling direction of all layers in one launch (csrc/glow_fwd.hip) -------------------------------------------
+def dropout_bits(n, p, device, state=None):
+    """keep bits of n elements (uint8 [n / 8], the format dropout_ writes / applies), drawn on the device: mhe_dropout_bits"""
+    bits = torch.empty(n // 8, device=device, dtype=torch.uint8)
+    st = state if state is not None else rng_state(device)
+    check(_lib.lib().mhe_dropout_bits(_ptr(bits), n, float(p), _ptr(st), _stream()), "mhe_dropout_bits")
+    return bits
+
+
+def glow_layers_supported(N, B, dim, hidden, layers, blocks):
+    return bool(_lib.lib().mhe_glow_layers_supported(N, B, dim, hidden, layers, blocks))
+
+
+def glow_fused_layout(wx, w0, w1, wf, bf, b0, b1, dim):
+    """the weight operands of mhe_glow_layers_bf16 from per-layer stacks - wx [L, 512, 64] (initial layer on the padded variable), w0 / w1
+    [L, 2, 512, 512], wf [L, >= 2 T, 512] / bf [L, >= 2 T] (final layer, rows [shift (T) | unconstrained scale (T)]), b0 / b1 [L, 2, 512] - as
+    VALUES (float tensors: zero fill) or as INDEX tensors into a flat parameter buffer (integer tensors: -1 fill; the trainer's gather tables).
+    The final layer's rows move to the flow variable's own columns: row c of wsF / wuF = the shift / scale row of transform column c."""
+    L = wx.shape[0]
+    idx = not wx.is_floating_point()
+    fill = -1 if idx else 0
+    ws, wu = (torch.full((L, 64, 512), fill, dtype=wf.dtype, device=wf.device) for _ in range(2))
+    bs, bu = (torch.full((L, 64), fill, dtype=bf.dtype, device=bf.device) for _ in range(2))
+    for l in range(L):
+        first = 1 - (l & 1)
+        T = dim // 2 if first else (dim + 1) // 2
+        cols = torch.arange(first, dim, 2, device=wf.device)
+        ws[l, cols], wu[l, cols] = wf[l, :T], wf[l, T:2 * T]
+        bs[l, cols], bu[l, cols] = bf[l, :T], bf[l, T:2 * T]
+    fr = mfma_fragment_major
+    return {"wxF": torch.stack([fr(wx[l]) for l in range(L)]), "w0F": torch.stack([torch.stack([fr(w0[l, b]) for b in range(2)]) for l in range(L)]),
+            "w1F": torch.stack([torch.stack([fr(w1[l, b]) for b in range(2)]) for l in range(L)]),
+            "wsF": torch.stack([fr(ws[l]) for l in range(L)]), "wuF": torch.stack([fr(wu[l]) for l in range(L)]),
+            "bs": bs, "bu": bu, "b0": b0.contiguous(), "b1": b1.contiguous()}
+
+
+def glow_layers(noise, ctab, fp, aff, drop_bits, p_drop, N, B, dim, row_n, row_b, tape=None):
+    """(sample [R, dim], log q [R]) of the conditional Glow's sampling direction, all layers in one launch (mhe_glow_layers_bf16).
+    fp: glow_fused_layout's dict as bf16 (weights) / f32 (biases) device tensors; aff: glow_affine's dict; drop_bits: uint8 [L, 2, R * 64] | None;
+    tape: dict(v, y, prm f32 [L, R, 64]; tb, t2, t3 bf16 [L, 2, R, 512]; hf bf16 [L, R, 512]) | None"""
+    R = N * B
+    _chk(noise, torch.float32, "glow_layers.noise", (R, dim)); _chk(ctab, torch.float32, "glow_layers.ctab")
+    L = fp["wxF"].shape[0]
+    for k, dt in (("wxF", torch.bfloat16), ("w0F", torch.bfloat16), ("w1F", torch.bfloat16), ("wsF", torch.bfloat16), ("wuF", torch.bfloat16),
+                  ("b0", torch.float32), ("b1", torch.float32), ("bs", torch.float32), ("bu", torch.float32)):
+        _chk(fp[k], dt, "glow_layers." + k)
+    if fp["w0F"].numel() != L * 2 * 512 * 512 or fp["wxF"].numel() != L * 512 * 64 or fp["wsF"].numel() != L * 64 * 512:
+        raise _lib.MheError("glow_layers: weight operands do not match hidden 512 / 2 blocks per layer")
+    if drop_bits is not None:
+        _chk(drop_bits, torch.uint8, "glow_layers.drop_bits")
+        if drop_bits.numel() != L * 2 * R * 64:
+            raise _lib.MheError(f"glow_layers.drop_bits: {L * 2 * R * 64} bytes expected, got {drop_bits.numel()}")
+    out, logq = torch.empty(R, dim, device=noise.device), torch.empty(R, device=noise.device)
+    t = tape or {}
+    if tape is not None:
+        for k, dt, shp in (("v", torch.float32, (L, R, 64)), ("y", torch.float32, (L, R, 64)), ("prm", torch.float32, (L, R, 64)),
+                           ("tb", torch.bfloat16, (L, 2, R, 512)), ("t2", torch.bfloat16, (L, 2, R, 512)), ("t3", torch.bfloat16, (L, 2, R, 512)),
+                           ("hf", torch.bfloat16, (L, R, 512))):
+            _chk(tape[k], dt, "glow_layers.tape." + k, shp)
+    check(_lib.lib().mhe_glow_layers_bf16(_ptr(noise), _ptr(ctab), ctab.shape[1], _ptr(fp["wxF"]), _ptr(fp["w0F"]), _ptr(fp["w1F"]), _ptr(fp["wsF"]),
+                                          _ptr(fp["wuF"]), _ptr(fp["b0"]), _ptr(fp["b1"]), _ptr(fp["bs"]), _ptr(fp["bu"]), _ptr(aff["AinvT"]),
+                                          _ptr(aff["cinv"]), _ptr(aff["const_parts"]), _ptr(drop_bits), float(p_drop), _ptr(out), _ptr(logq),
+                                          _ptr(t.get("v")), _ptr(t.get("y")), _ptr(t.get("prm")), _ptr(t.get("tb")), _ptr(t.get("t2")), _ptr(t.get("t3")),
+                                          _ptr(t.get("hf")), N, B, dim, 512, L, 2, row_n, row_b, _stream()), "mhe_glow_layers_bf16")
+    return out, logq

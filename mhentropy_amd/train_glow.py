@@ -75,6 +75,7 @@ class GlowPart:
             bfi = torch.full((64,), -1, dtype=torch.int64)
             bfi[:2 * nt] = ts._pidx(net.final_layer.bias)
             f32 = torch.float32
+            d["wxi"], d["wfi"], d["bfi"] = wxi, wfi, bfi
             d["wx"], d["wxT"] = ts._derived(wxi, f32), ts._derived(wxi.t().contiguous(), f32)
             d["wf"], d["wfT"], d["bf"] = ts._derived(wfi, f32), ts._derived(wfi.t().contiguous(), f32), ts._derived(bfi, f32)
             d["blocks"] = [(blk.linear_layers[0].weight.data, blk.linear_layers[0].bias.data, blk.linear_layers[1].weight.data,
@@ -101,6 +102,19 @@ class GlowPart:
         self.aff = ops.glow_affine(self._ptab, L, D, self.layers[0]["lu"].eps)
         self._gtabs = None
         self._tp = None
+        # operands of the one-launch sampling kernel (csrc/glow_fwd.hip): gather tables like every other derived layout
+        self.fused = None
+        if self.mixed and H == 512 and NB == 2 and D <= 48:
+            nets = [d["cp"].transform_net for d in self.layers]
+            st = lambda f: torch.stack([f(n) for n in nets])
+            pi = ts._pidx
+            fp = ops.glow_fused_layout(torch.stack([d["wxi"] for d in self.layers]),
+                                       st(lambda n: torch.stack([pi(b.linear_layers[0].weight) for b in n.blocks])),
+                                       st(lambda n: torch.stack([pi(b.linear_layers[1].weight) for b in n.blocks])),
+                                       torch.stack([d["wfi"] for d in self.layers]), torch.stack([d["bfi"] for d in self.layers]),
+                                       st(lambda n: torch.stack([pi(b.linear_layers[0].bias) for b in n.blocks])),
+                                       st(lambda n: torch.stack([pi(b.linear_layers[1].bias) for b in n.blocks])), D)
+            self.fused = {k: ts._derived(v.contiguous(), torch.bfloat16 if k.endswith("F") else torch.float32) for k, v in fp.items()}
         glow._external_pack = self.module_pack
 
     # ------------------------------------------------------------------ the 45x45 affine maps (float64 on the device, tiny)
@@ -117,7 +131,7 @@ class GlowPart:
         sample / log_prob paths follow the optimizer without any host-side re-packing"""
         self.ts.sync()
         self.refresh_affine()
-        pk = {"layers": [], "const_parts": self.aff["const_parts"], "aff": self.aff, "wctx": self.wctx, "bctx": self.bctx}
+        pk = {"layers": [], "const_parts": self.aff["const_parts"], "aff": self.aff, "wctx": self.wctx, "bctx": self.bctx, "fused": self.fused}
         for l, d in enumerate(self.layers):
             e = {"A": self.aff["A"][l], "c": self.aff["c"][l], "Ainv": self.aff["Ainv"][l], "cinv": self.aff["cinv"][l], "wx": d["wx"],
                  "blocks": d["blocks"], "wf": d["wf"], "bf": d["bf"], "T": d["T"], "first": d["first"]}
@@ -129,9 +143,28 @@ class GlowPart:
         return pk
 
     # ------------------------------------------------------------------ sampling pass with tape
+    def _forward_fused(self, z0, feat):
+        """the sampling pass with its tape from ONE launch (mhe_glow_layers_bf16): the reverse pass below reads the kernel's tape tensors"""
+        ts, g = self.ts, self.g
+        D, H, B, R, L, NB = g.features, g.hidden, feat.shape[0], z0.shape[0], g.num_layers, g.num_blocks
+        self.refresh_affine()
+        ctab = ops.linear(feat, self.wctx, self.bctx)
+        bits = g._drop_bits(R)
+        bf = torch.bfloat16
+        tape = {"v": ts._buf("glow_v", (L, R, 64)), "y": ts._buf("glow_y", (L, R, 64)), "prm": ts._buf("glow_prm", (L, R, 64)),
+                "tb": ts._buf("glow_tb", (L, NB, R, H), bf), "t2": ts._buf("glow_t2", (L, NB, R, H), bf), "t3": ts._buf("glow_t3", (L, NB, R, H), bf),
+                "hf": ts._buf("glow_hf", (L, R, H), bf)}
+        x, logq = ops.glow_layers(z0, ctab, self.fused, self.aff, bits, g.p_drop, R // B, B, D, B, 1, tape=tape)
+        self._tp = {"fused": tape, "bits": bits, "ctab": ctab, "feat": feat}
+        return x, logq
+
     def forward(self, z0, feat):
         ts, g = self.ts, self.g
         L_, D, H, B, R = _lib.lib(), g.features, g.hidden, feat.shape[0], z0.shape[0]
+        import os
+        if (self.fused is not None and os.environ.get("MHE_GLOW_FUSED", "1") == "1" and R % B == 0
+                and ops.glow_layers_supported(R // B, B, D, H, g.num_layers, g.num_blocks)):
+            return self._forward_fused(z0, feat)
         self.refresh_affine()
         s, dev = ops._stream, z0.device
         ctab = ops.linear(feat, self.wctx, self.bctx)
@@ -188,16 +221,29 @@ class GlowPart:
         gv = torch.empty(R, 64, device=dev)
         ops.check(L_.mhe_pad64_f32(ops._ptr(g_x), ops._ptr(gv), R, D, s()), "mhe_pad64_f32")
         Gct = torch.zeros(B, cs, device=dev)
+        fused = tp.get("fused")
         for l in range(g.num_layers):
             d = rs = self.layers[l]
-            t = tp["tape"][l]
+            if fused is not None:       # the one-launch kernel's tape: relu(h) of every block and the final layer's operand as bf16
+                bits = tp["bits"]
+                t = {"y": fused["y"][l], "v": fused["v"][l], "prm": fused["prm"][l], "hf": fused["hf"][l],
+                     "tb": [fused["tb"][l, b_].view(R, 1, 1, H) for b_ in range(g.num_blocks)],
+                     "t2": [fused["t2"][l, b_].view(R, 1, 1, H) for b_ in range(g.num_blocks)],
+                     "t3": [fused["t3"][l, b_].view(R, 1, 1, H) for b_ in range(g.num_blocks)],
+                     "drop": [None if bits is None else bits[l, b_] for b_ in range(g.num_blocks)]}
+            else:
+                t = tp["tape"][l]
             slot = l * self.per
             ops.linear_wgrad(t["y"], gv, raw(rs["r_ainv"], (64, 64))); ops.colsum(gv, raw(rs["r_cinv"], (64,)))
             gy = ops.linear(gv, self.aff["AinvT"][l])
             gvc, gprm = torch.empty(R, 64, device=dev), torch.empty(R, 64, device=dev)
             ops.check(L_.mhe_glow_coupling_inv_bwd_f32(ops._ptr(t["v"]), ops._ptr(t["prm"]), ops._ptr(gy), ops._ptr(g_logp), -1.0 / N,
                                                        ops._ptr(gvc), ops._ptr(gprm), R, B, D, d["first"], d["T"], s()), "mhe_glow_coupling_inv_bwd_f32")
-            ops.linear_wgrad(t["hs"][-1], gprm, raw(rs["r_wf"], (64, H))); ops.colsum(gprm, raw(rs["r_bf"], (64,)))
+            if fused is not None:       # the final layer's operand was kept as bf16: its weight gradient on bf16 operands, f32 accumulation
+                ops.conv_wgrad(t["hf"].view(R, 1, 1, H), gprm.to(torch.bfloat16).view(R, 1, 1, 64), 1, 1, 1, 0, raw(rs["r_wf"], (64, H)))
+            else:
+                ops.linear_wgrad(t["hs"][-1], gprm, raw(rs["r_wf"], (64, H)))
+            ops.colsum(gprm, raw(rs["r_bf"], (64,)))
             gh = ops.linear(gprm, d["wfT"])
             for b in range(g.num_blocks - 1, -1, -1):
                 rb = rs["r_blocks"][b]
@@ -215,11 +261,17 @@ class GlowPart:
                     if t["drop"][b] is not None:          # dropout's reverse: the same mask and scale on the gradient
                         ops.dropout_(gt2, g.p_drop, bits=t["drop"][b])
                     ops.flow_lrelu_bwd_mixed(gt2.view(R, H), t2b.view(R, H), out_bf16=gt2.view(R, H), slope=0.0)
-                    tt = torch.empty(R, 1, 1, H, device=dev, dtype=torch.bfloat16)
-                    ops.check(L_.mhe_relu_copy_f32(ops._ptr(t["hs"][b]), ops._ptr(tt), tt.numel(), ops.BF16, s()), "mhe_relu_copy_f32")
+                    if fused is not None:
+                        tt = t["tb"][b]
+                    else:
+                        tt = torch.empty(R, 1, 1, H, device=dev, dtype=torch.bfloat16)
+                        ops.check(L_.mhe_relu_copy_f32(ops._ptr(t["hs"][b]), ops._ptr(tt), tt.numel(), ops.BF16, s()), "mhe_relu_copy_f32")
                     ops.conv_wgrad(tt, gt2, 1, 1, 1, 0, raw(rb["w0"], (H, H))); ops.colsum(gt2, raw(rb["b0"], (H,)))
                     gt = ops.conv2d_nhwc(gt2, w0Tb, 1, 1, 1, 0)
-                    ops.check(L_.mhe_relu_bwd_add_f32(ops._ptr(gh), ops._ptr(gt), ops._ptr(t["hs"][b]), gh.numel(), ops.BF16, s()), "mhe_relu_bwd_add_f32")
+                    if fused is not None:       # relu(h) > 0  <=>  h > 0: the gate from the kept bf16 activation
+                        ops.check(L_.mhe_relu_bwd_add_mixed(ops._ptr(gh), ops._ptr(gt), ops._ptr(tt), gh.numel(), ops.BF16, ops.BF16, s()), "mhe_relu_bwd_add_mixed")
+                    else:
+                        ops.check(L_.mhe_relu_bwd_add_f32(ops._ptr(gh), ops._ptr(gt), ops._ptr(t["hs"][b]), gh.numel(), ops.BF16, s()), "mhe_relu_bwd_add_f32")
                     continue
                 ops.linear_wgrad(t2b, gt3, raw(rb["w1"], (H, H))); ops.colsum(gt3, raw(rb["b1"], (H,)))
                 gt2 = ops.linear(gt3, w1T)

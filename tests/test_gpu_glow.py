@@ -244,3 +244,55 @@ def test_dropout_kernel_draws_keeps_and_reapplies_its_mask(gpu_lib):
     # eval mode: the module applies no dropout
     g, _ = _glow(1, 64)
     assert g.dropout_(torch.ones(8, 64, device="cuda")) is None
+
+
+@pytest.mark.parametrize("B,N,layout", [(3, 64, "sample-major"), (2, 70, "sample-major"), (4, 16, "batch-major"), (5, 128, "sample-major")])
+@pytest.mark.parametrize("train", [False, True], ids=["eval", "train-dropout"])
+def test_glow_one_launch_sampling_kernel(gpu_lib, B, N, layout, train, monkeypatch):
+    """csrc/glow_fwd.hip (round 5): the sampling direction of all four layers in one launch (bf16 operands on every product, f32 residual
+    stream / flow variable / coupling / inverse affine map) against (i) the nflows restatement in f32 (oracle/glow_ref.py - parity unpinned,
+    reference call site hand/network.py:736-742) at the bf16-products bound of test_glow_bf16_products_stay_close_to_fp32 and (ii) the
+    layer-by-layer bf16 path it replaces (MHE_GLOW_FUSED=0) on the same dropout masks.  Hypothesis counts that are not a multiple of 64
+    (surplus rows computed, never stored), both row layouts, dropout masks in ops.dropout_'s bit format."""
+    from oracle import glow_ref
+    from mhentropy_amd import ops
+    g, sd = _glow(1, 512)
+    g.compute_dtype = torch.bfloat16
+    g.train(train)
+    rng = np.random.default_rng(B * 100 + N)
+    noise = torch.as_tensor(rng.normal(0, 0.8, (B, N, 45)).astype(np.float32))
+    ctx = torch.as_tensor(rng.normal(0, 0.5, (B, 512)).astype(np.float32))
+    ops.rng_state(torch.device("cuda", torch.cuda.current_device()), seed=21)
+
+    def run(fused, feed=None):
+        monkeypatch.setenv("MHE_GLOW_FUSED", "1" if fused else "0")
+        g.mask_feed = None if feed is None else [m.clone() for m in feed]
+        g.record_masks, g.last_masks = True, []
+        if layout == "batch-major":
+            x, lp, _ = g.sample_and_log_prob(N, noise=noise.cuda(), context=ctx.cuda())
+            x, lp = x.permute(1, 0, 2).reshape(N * B, 45), lp.t().reshape(-1)
+        else:
+            x, lp = g._run(noise.permute(1, 0, 2).reshape(N * B, 45).contiguous().cuda(), ctx.cuda(), True, 1, B)
+        return x.cpu(), lp.cpu(), list(g.last_masks)
+    x1, lp1, masks = run(True)
+    assert torch.isfinite(x1).all() and torch.isfinite(lp1).all()
+    assert len(masks) == (8 if train else 0)
+    x0, lp0, masks0 = run(False, masks if train else None)
+    if train:
+        assert all(torch.equal(a, b) for a, b in zip(masks, masks0))
+        keep = float(np.mean([float(ops.dropout_mask(m, (N * B, 512), 0.2).gt(0).float().mean()) for m in masks]))
+        assert abs(keep - 0.8) < 0.01, keep
+    # the oracle: batch-major rows (nflows' repeat_rows); masks per call in its row order
+    fmask = None
+    if train:
+        R = N * B
+        to_bm = lambda m: ops.dropout_mask(m, (R, 512), 0.2).view(N, B, 512).permute(1, 0, 2).reshape(R, 512).cpu() if layout == "sample-major" else ops.dropout_mask(m, (R, 512), 0.2).cpu()
+        fmask = [to_bm(m) for m in masks]
+    x_ref, lp_ref, _ = glow_ref.sample_and_log_prob(sd, noise, ctx, masks=fmask)
+    x_ref, lp_ref = x_ref.permute(1, 0, 2).reshape(N * B, 45), lp_ref.t().reshape(-1)
+    e_x, e_lp = float((x1 - x_ref).abs().max() / x_ref.abs().max()), float((lp1 - lp_ref).abs().max() / lp_ref.abs().max())
+    d_x, d_lp = float((x1 - x0).abs().max() / x0.abs().max()), float((lp1 - lp0).abs().max() / lp0.abs().max())
+    u_x = float((x0 - x_ref).abs().max() / x_ref.abs().max())
+    print(f"one-launch Glow vs f32 oracle: x {e_x:.2e} lp {e_lp:.2e}; vs the layer-by-layer bf16 path: x {d_x:.2e} lp {d_lp:.2e} (that path vs oracle: x {u_x:.2e})")
+    assert_close(x1, x_ref, 2e-2, what="samples vs oracle"); assert_close(lp1, lp_ref, 2e-2, what="log q vs oracle")
+    assert_close(x1, x0, 1e-2, what="samples vs the layer-by-layer bf16 path"); assert_close(lp1, lp0, 1e-2, what="log q vs the layer-by-layer bf16 path")
