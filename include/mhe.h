@@ -682,6 +682,13 @@ int mhe_glow_finish_f32(const float *z_padded, const float *v_padded, const floa
  * HIP graph then follows the parameters from step to step */
 int mhe_glow_finish_dev_f32(const float *z_padded, const float *v_padded, const float *logdet, float *v_out, float *log_prob,
                             long R, int dim, float sign, const float *const_parts, int n_parts, void *stream);
+/* Per-image reverse stages of the one-launch Glow kernel's tape (csrc/glow.hip; sample-major rows r = n B + b, C columns, bf16 tensors [N B][C]):
+ *   glu_bwd_sum:     g_t3 = g_h sigmoid(gate[b]) (bf16);  gct[b][c] = s (1 - s) sum_n g_h t3;  bsum[b][c] = s sum_n g_h    (rows of pitch *_stride)
+ *   mask_scale_sum:  g <- g * scale * [t2 > 0] in place;  bsum[b][c] = sum_n g (of the stored values)
+ * - the gate's gradient, the dropout + ReLU reverse and the per-image rows of the bias gradients without a second pass over [R][C]. */
+int mhe_glow_glu_bwd_sum(const float *g_h, const void *t3, const float *gate, long gate_stride, void *g_t3, float *gct, long gct_stride,
+                         float *bsum, long bsum_stride, int N, int B, int C, void *stream);
+int mhe_glow_mask_scale_sum(void *g, const void *t2, float scale, float *bsum, long bsum_stride, int N, int B, int C, void *stream);
 /* relu'(h) reverse with h (or relu(h): same sign) stored as f32 or bf16: acc += g * [h > 0] */
 int mhe_relu_bwd_add_mixed(float *acc, const void *g, const void *h, long n, int g_dtype, int h_dtype, void *stream);
 /* Dropout mask bits alone (n elements, n % 8 == 0; byte i = keep bits of elements 8 i .. 8 i + 7, as mhe_dropout writes them), drawn from the

@@ -86,6 +86,8 @@ SIGNATURES = {
     "mhe_glow_glu_bwd_f32": (_i, [_p, _p, _p, _l, _p, _p, _l, _i, _i, _i, _i, _p]),
     "mhe_relu_bwd_add_f32": (_i, [_p, _p, _p, _l, _i, _p]),
     "mhe_glow_finish_f32": (_i, [_p, _p, _p, _p, _p, _l, _i, _f, _f, _p]),
+    "mhe_glow_glu_bwd_sum": (_i, [_p, _p, _p, _l, _p, _p, _l, _p, _l, _i, _i, _i, _p]),
+    "mhe_glow_mask_scale_sum": (_i, [_p, _p, _f, _p, _l, _i, _i, _i, _p]),
     "mhe_relu_bwd_add_mixed": (_i, [_p, _p, _p, _l, _i, _i, _p]),
     "mhe_dropout_bits": (_i, [_p, _l, _f, _p, _p]),
     "mhe_glow_layers_supported": (_i, [_i] * 6),

@@ -173,6 +173,71 @@ __global__ __launch_bounds__(256) void finish_kernel(const float *__restrict__ z
     sq = wave_sum(sq);
     if (lane == 0) logp[r] = -0.5f * sq - 0.5f * dim * 1.8378770664093453f + sign * (logdet[r] + logdet_const);
 }
+// ---- reverse stages of the one-launch kernel's tape (round 5): a workgroup owns ONE IMAGE = its N sample-major rows r = n B + b, so the sums
+// over an image's hypotheses (gate gradients, per-image bias-gradient rows) fall out of the same pass that writes the gradient - the
+// glu_bwd + sum_over_hypotheses + colsum (and dropout + relu-mask + colsum) chains were 6 launches and 5 passes over [R, 512] per block.
+//   glu_bwd_sum:     g_t3 = g_h s (bf16),  gct[b] = s (1 - s) sum_n g_h t3,  bsum[b] = s sum_n g_h          (s = sigmoid(gate[b]))
+//   mask_scale_sum:  g <- g scale [t2 > 0] in place (t2 = dropout(relu(.)): zero where dropped or inactive),  bsum[b] = sum_n g
+// 512 threads: column quad c = t % (C / 4), row lane t / (C / 4); four rows per lane in flight; lanes folded through LDS in lane order.
+template <bool GLU>
+__global__ __launch_bounds__(512) void image_rows_bwd_kernel(const float *__restrict__ g_h, u16 *__restrict__ g_io, const u16 *__restrict__ act,
+                                                             const float *__restrict__ gate, long gate_stride, float scale, float *__restrict__ gct,
+                                                             long gct_stride, float *__restrict__ bsum, long bsum_stride, int N, int B, int C) {
+    __shared__ float part[2][512][4];
+    const int b = blockIdx.x, quads = C / 4, nl = 512 / quads, c = (threadIdx.x % quads) * 4, l0 = threadIdx.x / quads;
+    float s[4] = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (GLU) {
+        const v4f gt = *reinterpret_cast<const v4f *>(gate + (size_t)b * gate_stride + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] = 1.f / (1.f + expf(-gt[e]));
+    }
+    float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int n0 = l0; n0 < N; n0 += 4 * nl) {
+        float gh[4][4], tv[4][4];
+        bool on[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int n = n0 + u * nl;
+            on[u] = n < N;
+            const size_t o = ((size_t)(on[u] ? n : 0) * B + b) * C + c;
+            if constexpr (GLU) load4<float>(g_h + o, gh[u]); else load4<u16>(g_io + o, gh[u]);
+            load4<u16>(act + o, tv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!on[u]) continue;
+            const size_t o = ((size_t)(n0 + u * nl) * B + b) * C + c;
+            float out[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (GLU) { out[e] = gh[u][e] * s[e]; ag[e] = fmaf(gh[u][e], tv[u][e], ag[e]); ab[e] += gh[u][e]; }
+                else { out[e] = tv[u][e] > 0.f ? gh[u][e] * scale : 0.f; }
+            }
+            store4<u16>(g_io + o, out);
+            if constexpr (!GLU) {               // the bias gradient sums the values AS STORED (bf16): what the weight gradient multiplies
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ab[e] += bf16_to_f32(f32_to_bf16(out[e]));
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { part[0][threadIdx.x][e] = ag[e]; part[1][threadIdx.x][e] = ab[e]; }
+    __syncthreads();
+    if (l0) return;
+#pragma unroll 1
+    for (int l = 1; l < nl; ++l)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ag[e] += part[0][l * quads + threadIdx.x][e]; ab[e] += part[1][l * quads + threadIdx.x][e]; }
+    if constexpr (GLU) {
+        v4f og, ob;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { og[e] = s[e] * (1.f - s[e]) * ag[e]; ob[e] = s[e] * ab[e]; }
+        *reinterpret_cast<v4f *>(gct + (size_t)b * gct_stride + c) = og;
+        *reinterpret_cast<v4f *>(bsum + (size_t)b * bsum_stride + c) = ob;
+    } else {
+        *reinterpret_cast<v4f *>(bsum + (size_t)b * bsum_stride + c) = v4f{ab[0], ab[1], ab[2], ab[3]};
+    }
+}
 }}  // namespace mhe::glow
 
 using namespace mhe;
@@ -286,4 +351,22 @@ extern "C" int mhe_relu_bwd_add_mixed(float *acc, const void *g, const void *h, 
     else
         hipLaunchKernelGGL((glow::relu_bwd_add_kernel<u16, u16>), dim3(gg(n / 4)), dim3(256), 0, (hipStream_t)stream, acc, (const u16 *)g, (const u16 *)h, n / 4);
     return check_launch("relu_bwd_add_kernel");
+}
+
+// the two per-image reverse stages of the one-launch kernel's tape (sample-major rows r = n B + b; C in {64 .. 2048}, 512 % (C / 4) == 0)
+extern "C" int mhe_glow_glu_bwd_sum(const float *g_h, const void *t3, const float *gate, long gate_stride, void *g_t3, float *gct, long gct_stride,
+                                    float *bsum, long bsum_stride, int N, int B, int C, void *stream) {
+    MHE_REQUIRE(g_h && t3 && gate && g_t3 && gct && bsum && N > 0 && B > 0 && C >= 4 && C % 4 == 0 && C / 4 <= 512 && 512 % (C / 4) == 0 &&
+                    gate_stride % 4 == 0 && gct_stride % 4 == 0 && bsum_stride % 4 == 0, "mhe_glow_glu_bwd_sum: bad arguments");
+    hipLaunchKernelGGL(glow::image_rows_bwd_kernel<true>, dim3(B), dim3(512), 0, (hipStream_t)stream, g_h, (u16 *)g_t3, (const u16 *)t3, gate, gate_stride,
+                       1.f, gct, gct_stride, bsum, bsum_stride, N, B, C);
+    return check_launch("image_rows_bwd_kernel<glu>");
+}
+
+extern "C" int mhe_glow_mask_scale_sum(void *g, const void *t2, float scale, float *bsum, long bsum_stride, int N, int B, int C, void *stream) {
+    MHE_REQUIRE(g && t2 && bsum && N > 0 && B > 0 && C >= 4 && C % 4 == 0 && C / 4 <= 512 && 512 % (C / 4) == 0 && bsum_stride % 4 == 0,
+                "mhe_glow_mask_scale_sum: bad arguments");
+    hipLaunchKernelGGL(glow::image_rows_bwd_kernel<false>, dim3(B), dim3(512), 0, (hipStream_t)stream, (const float *)nullptr, (u16 *)g, (const u16 *)t2,
+                       (const float *)nullptr, 0L, scale, (float *)nullptr, 0L, bsum, bsum_stride, N, B, C);
+    return check_launch("image_rows_bwd_kernel<mask>");
 }

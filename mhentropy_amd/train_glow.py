@@ -37,6 +37,9 @@ class GlowPart:
         self.layers = []
         wctx_idx, bctx_idx = [], []
         ar = lambda n: torch.arange(n, dtype=torch.int64)
+        # the residual blocks' gradients in (layer, block) order, one pitch apart: what the grouped weight-gradient launches and the single
+        # bias column sum of the fused reverse pass write ([L NB][H][H] x 2; [L NB][b0 | b1][H])
+        self.raw_w0, self.raw_w1, self.raw_bias = ts._raw_slot((L * NB * H * H,)), ts._raw_slot((L * NB * H * H,)), ts._raw_slot((L * NB * 2 * H,))
         for l in range(L):
             an, lu, cp = T[3 * l], T[3 * l + 1], T[3 * l + 2]
             net = cp.transform_net
@@ -60,7 +63,8 @@ class GlowPart:
             ts._map_grad(net.final_layer.bias, ar(2 * nt) + d["r_bf"])
             d["r_blocks"] = []
             for b, blk in enumerate(net.blocks):
-                rb = {k: ts._raw_slot(s) for k, s in (("w0", (H, H)), ("b0", (H,)), ("w1", (H, H)), ("b1", (H,)))}
+                kb = l * NB + b
+                rb = {"w0": self.raw_w0 + kb * H * H, "w1": self.raw_w1 + kb * H * H, "b0": self.raw_bias + (2 * kb) * H, "b1": self.raw_bias + (2 * kb + 1) * H}
                 for j in range(2):
                     ts._map_grad(blk.linear_layers[j].weight, ar(H * H).view(H, H) + rb[f"w{j}"])
                     ts._map_grad(blk.linear_layers[j].bias, ar(H) + rb[f"b{j}"])
@@ -209,9 +213,68 @@ class GlowPart:
         return x, logq
 
     # ------------------------------------------------------------------ reverse pass
+    def _backward_fused(self, g_x, g_logp, N, B):
+        """the reverse pass over the one-launch kernel's tape: per layer the small stages as before, per residual block two products on bf16
+        MFMA and three per-image kernels (gate / dropout + ReLU reverse with the per-image sums inside, csrc/glow.hip); the 16 hidden x hidden
+        weight gradients as TWO grouped launches after the chain (x = the tape's [L, 2, R, 512] tensors as they lie), all 16 bias gradients
+        as ONE column sum of the per-image rows"""
+        ts, g = self.ts, self.g
+        L_, D, H, R, L, NB = _lib.lib(), g.features, g.hidden, g_x.shape[0], g.num_layers, g.num_blocks
+        tp = self._tp
+        ft, bits, ctab = tp["fused"], tp["bits"], tp["ctab"]
+        s, dev, raw, cs, bf = ops._stream, g_x.device, ts._raw, ctab.shape[1], torch.bfloat16
+        gv = torch.empty(R, 64, device=dev)
+        ops.check(L_.mhe_pad64_f32(ops._ptr(g_x), ops._ptr(gv), R, D, s()), "mhe_pad64_f32")
+        Gct = ts._buf("glow_Gct", (B, cs)); Gct.zero_()
+        gt3_all, gt2_all = ts._buf("glow_gt3", (L, NB, R, H), bf), ts._buf("glow_gt2", (L, NB, R, H), bf)
+        bs_w = L * NB * 2 * H
+        bsum = ts._buf("glow_bsum", (B, bs_w))                  # per-image rows of all 16 bias gradients: every slice is written below
+        dscale = 1.0 / (1.0 - g.p_drop) if bits is not None else 1.0
+        for l in range(L):
+            d = rs = self.layers[l]
+            slot = l * self.per
+            y, v, prm, hf = ft["y"][l], ft["v"][l], ft["prm"][l], ft["hf"][l]
+            ops.linear_wgrad(y, gv, raw(rs["r_ainv"], (64, 64))); ops.colsum(gv, raw(rs["r_cinv"], (64,)))
+            gy = ops.linear(gv, self.aff["AinvT"][l])
+            gvc, gprm = torch.empty(R, 64, device=dev), torch.empty(R, 64, device=dev)
+            ops.check(L_.mhe_glow_coupling_inv_bwd_f32(ops._ptr(v), ops._ptr(prm), ops._ptr(gy), ops._ptr(g_logp), -1.0 / N,
+                                                       ops._ptr(gvc), ops._ptr(gprm), R, B, D, d["first"], d["T"], s()), "mhe_glow_coupling_inv_bwd_f32")
+            # the final layer's operand was kept as bf16: its weight gradient on bf16 operands, f32 accumulation
+            ops.conv_wgrad(hf.view(R, 1, 1, H), gprm.to(bf).view(R, 1, 1, 64), 1, 1, 1, 0, raw(rs["r_wf"], (64, H)))
+            ops.colsum(gprm, raw(rs["r_bf"], (64,)))
+            gh = ops.linear(gprm, d["wfT"])
+            for b in range(NB - 1, -1, -1):
+                kb = l * NB + b
+                _, _, w0Tb, w1Tb = d["blocks_b"][b]
+                gt3, gt2 = gt3_all[l, b].view(R, 1, 1, H), gt2_all[l, b].view(R, 1, 1, H)
+                gate = C.c_void_p(ctab[:, (slot + 1 + b) * H:].data_ptr())
+                ops.check(L_.mhe_glow_glu_bwd_sum(ops._ptr(gh), ops._ptr(ft["t3"][l, b]), gate, cs, ops._ptr(gt3),
+                                                  C.c_void_p(Gct[:, (slot + 1 + b) * H:].data_ptr()), cs,
+                                                  C.c_void_p(bsum[:, (2 * kb + 1) * H:].data_ptr()), bs_w, N, B, H, s()), "mhe_glow_glu_bwd_sum")
+                ops.conv2d_nhwc(gt3, w1Tb, 1, 1, 1, 0, out=gt2)
+                # dropout's and the ReLU's reverse in one pass: t2 = dropout(relu(.)) is zero exactly where either gate is closed
+                ops.check(L_.mhe_glow_mask_scale_sum(ops._ptr(gt2), ops._ptr(ft["t2"][l, b]), dscale, C.c_void_p(bsum[:, (2 * kb) * H:].data_ptr()),
+                                                     bs_w, N, B, H, s()), "mhe_glow_mask_scale_sum")
+                gt = ops.conv2d_nhwc(gt2, w0Tb, 1, 1, 1, 0)
+                ops.check(L_.mhe_relu_bwd_add_mixed(ops._ptr(gh), ops._ptr(gt), ops._ptr(ft["tb"][l, b]), gh.numel(), ops.BF16, ops.BF16, s()),
+                          "mhe_relu_bwd_add_mixed")
+            ops.linear_wgrad(v, gh, raw(rs["r_wx"], (H, 64)))
+            ops.sum_over_hypotheses(gh, N, B, out=Gct[:, slot * H:], out_stride=cs)
+            gv = ops.add(gvc, ops.linear(gh, d["wxT"]))
+        # dW1[l, b] = gt3^T t2, dW0[l, b] = gt2^T relu(h): two grouped launches over the tape tensors as they lie
+        ops.conv_wgrad_batched(ft["t2"].view(L * NB, R, H), gt3_all.view(L * NB, R, H), raw(self.raw_w1, (H, H)), H * H, L * NB)
+        ops.conv_wgrad_batched(ft["tb"].view(L * NB, R, H), gt2_all.view(L * NB, R, H), raw(self.raw_w0, (H, H)), H * H, L * NB)
+        ops.colsum(bsum, raw(self.raw_bias, (bs_w,)))
+        ops.linear_wgrad(tp["feat"], Gct, raw(self.raw_wctx, (cs, g.context_features))); ops.colsum(Gct, raw(self.raw_bctx, (cs,)))
+        g_feat = ops.linear(Gct, self.wctxT)
+        self._reparam_backward(g_logp)
+        return g_feat
+
     def backward(self, g_x, g_logp, N, B):
         """g_x (R,45) = dL/d sample, g_logp (B,) = dL/d log_p per image (None: no entropy term).  Writes every Glow
         parameter's gradient into the trainer's raw arena and returns dL/d feat (B, F) through the context terms."""
+        if self._tp.get("fused") is not None and self.mixed:
+            return self._backward_fused(g_x, g_logp, N, B)
         ts, g = self.ts, self.g
         L_, D, H, R = _lib.lib(), g.features, g.hidden, g_x.shape[0]
         tp = self._tp
