@@ -445,6 +445,20 @@ int mhe_conv_wgrad_ws_nhwc(const mhe_conv_desc *d, const void *x, const void *gy
 size_t mhe_conv_wgrad_batched_workspace_floats(const mhe_conv_desc *d, int nbatch);
 int mhe_conv_wgrad_batched_nhwc(const mhe_conv_desc *d, int nbatch, const void *x, long x_batch_stride, const void *gy, long gy_batch_stride,
                                 float *dw, long dw_batch_stride, int ldw, float *workspace, size_t workspace_floats, void *stream);
+/* SEVERAL independent weight gradients in one call (round 5; csrc/wgrad.hip: wgrad_dma_multi_kernel): the problems that share a tile shape of the
+ * LDS-DMA kernel are launched together (16 per launch), the chip is filled by the tiles of ALL of them and every problem's pixel range is cut
+ * only as far as a common slice length asks - the partial-slab traffic of the one-problem-per-launch form (workgroups x tile bytes) falls by the
+ * number of problems that share the chip.  Unsplit problems add their tiles to dW with plain stores, split ones through slabs and ONE fixed-order
+ * reducer launch per batch: sums do not depend on the order in which workgroups finish.  Problems the LDS-DMA kernel does not take run as their
+ * own launches.  dW += as in mhe_conv_wgrad_nhwc; workspace: mhe_conv_wgrad_multi_workspace_floats(items, n) floats. */
+typedef struct mhe_wgrad_item {
+    mhe_conv_desc d;
+    const void *x, *gy;
+    float *dw;
+    int ldw;        /* row pitch of dW in floats, 0 = KH * KW * Cin */
+} mhe_wgrad_item;
+size_t mhe_conv_wgrad_multi_workspace_floats(const mhe_wgrad_item *items, int n);
+int mhe_conv_wgrad_multi_nhwc(const mhe_wgrad_item *items, int n, float *workspace, size_t workspace_floats, void *stream);
 /* Weight gradient of a convolution whose WIDTH direction has its own stride and left padding and whose output size is given instead of
  * derived (d->stride / d->pad describe the height direction; d->KH x d->KW taps).  Use: the stem's 7x7 / stride-2 / pad-3 convolution
  * (reference: torchvision ResNet.conv1 under hand/CrossModalHand.py:455-470's backward) read as a 7 x 4 / stride (2, 1) / pad (3, 2)

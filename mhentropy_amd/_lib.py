@@ -16,6 +16,11 @@ class ConvDesc(C.Structure):
                 ("B", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad", "dtype", "relu_in", "relu_out", "tile", "res_half")]
 
 
+class WgradItem(C.Structure):
+    """mhe_wgrad_item of include/mhe.h: one problem of mhe_conv_wgrad_multi_nhwc"""
+    _fields_ = [("d", ConvDesc), ("x", C.c_void_p), ("gy", C.c_void_p), ("dw", C.c_void_p), ("ldw", C.c_int)]
+
+
 # name -> (restype, argtypes); must list every symbol of include/mhe.h
 SIGNATURES = {
     "mhe_abi_version": (_i, []),
@@ -86,6 +91,8 @@ SIGNATURES = {
     "mhe_glow_glu_bwd_f32": (_i, [_p, _p, _p, _l, _p, _p, _l, _i, _i, _i, _i, _p]),
     "mhe_relu_bwd_add_f32": (_i, [_p, _p, _p, _l, _i, _p]),
     "mhe_glow_finish_f32": (_i, [_p, _p, _p, _p, _p, _l, _i, _f, _f, _p]),
+    "mhe_conv_wgrad_multi_workspace_floats": (_sz, [_p, _i]),
+    "mhe_conv_wgrad_multi_nhwc": (_i, [_p, _i, _p, _sz, _p]),
     "mhe_glow_glu_bwd_sum": (_i, [_p, _p, _p, _l, _p, _p, _l, _p, _l, _i, _i, _i, _p]),
     "mhe_glow_mask_scale_sum": (_i, [_p, _p, _f, _p, _l, _i, _i, _i, _p]),
     "mhe_relu_bwd_add_mixed": (_i, [_p, _p, _p, _l, _i, _i, _p]),

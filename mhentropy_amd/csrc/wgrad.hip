@@ -32,6 +32,8 @@ struct Params {
     // ~1000 slices of 64 KiB that was 10-35 % of a launch)
     float *ws;
     int Mp, Np;
+    int direct;          // no workspace and ONE pixel slice: the tile is added to dW with plain read-modify-write stores (every element has exactly one
+                         // writer - no atomics, no slab; the multi-problem launch's unsplit problems)
     // grouped launch (mhe_conv_wgrad_batched_nhwc, LDS-DMA kernel only): gridDim.z = nbatch * gz; problem b = blockIdx.z / gz reads
     // x + b * x_bs, gy + b * gy_bs (elements) and adds into dw + b * dw_bs (floats); slabs lie [b][slice][Mp][Np].  gz = 0: not grouped
     int gz;
@@ -327,8 +329,15 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 // per 4 MFMAs - every staged byte twice, 128 B/clk/CU of transposing reads at the full MFMA rate, which the LDS does not deliver next to
 // the DMA writes (PMC: MFMA utilisation 0.20, 44 % issue-stalled); 64 x 128 per wave reads (2 + 4) per 8: 96 B/clk.  One workgroup per CU
 // (128 KiB ring), two waves per SIMD as before.
+template <int BM, int BN, int WM, int WN> struct DmaTile {
+    static constexpr int BKB = 32, NBUF = 4, DEPTH = 3, NW = WM * WN;
+    static constexpr int PA = BM * 2, PB = BN * 2;                // row pitches in bytes (128, 256 or 512)
+    static constexpr int STAGE = BKB * (PA + PB);
+};
+
+// the workgroup's work: output tile (bx, by) of pixel slice bzl of the problem dp; ring = NBUF * STAGE bytes of LDS, 1 KiB aligned
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void wgrad_dma_kernel(const DmaParams dp) {
+__device__ __forceinline__ void wgrad_dma_body(const DmaParams &dp, const int bx, const int by, const int bzl, char *const ring) {
     const Params &p = dp.p;
     constexpr int BKB = 32, NBUF = 4, DEPTH = 3, NW = WM * WN;
     constexpr int PA = BM * 2, PB = BN * 2;                       // row pitches in bytes (128, 256 or 512)
@@ -337,16 +346,8 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_dma_kernel(const DmaParams
     constexpr int RA = 1024 / PA, RB = 1024 / PB;                 // rows per DMA wave-instruction
     constexpr int IA = BKB / RA / NW, IB = BKB / RB / NW;         // DMA instructions per wave per stage
     static_assert((NW == 4 || NW == 8) && (PA == 128 || PA == 256 || PA == 512) && (PB == 128 || PB == 256 || PB == 512) && IA >= 1 && IB >= 1, "tile");
-    __shared__ __attribute__((aligned(1024))) char ring[NBUF * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    int bx = blockIdx.x, by = blockIdx.y, bzl = blockIdx.z;
-    if (dp.xcd) {
-        const int S = gridDim.x * gridDim.y, L = bx + gridDim.x * (by + gridDim.y * bzl), j = L >> 3;
-        const int sl = j / S, t = j - sl * S;
-        bzl = sl * 8 + (L & 7); bx = t % (int)gridDim.x; by = t / (int)gridDim.x;
-        if (bzl >= dp.nzt) return;
-    }
     const int m0 = by * BM, n0 = bx * BN;
     const int bz = p.gz ? bzl / p.gz : 0, zs = p.gz ? bzl - bz * p.gz : bzl;      // problem of a grouped launch, slice
     const long k_begin = (long)zs * p.chunk;
@@ -482,9 +483,93 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_dma_kernel(const DmaParams
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (p.ws) p.ws[((size_t)bzl * p.Mp + m) * p.Np + n] = acc[i][j][r];
-                else if (m < p.Cout && n < p.N) atomicAdd(p.dw + (size_t)bz * p.dw_bs + (size_t)m * p.ldw + n, acc[i][j][r]);
+                else if (m < p.Cout && n < p.N) {
+                    float *dst = p.dw + (size_t)bz * p.dw_bs + (size_t)m * p.ldw + n;
+                    if (p.direct) *dst += acc[i][j][r];
+                    else atomicAdd(dst, acc[i][j][r]);
+                }
             }
         }
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void wgrad_dma_kernel(const DmaParams dp) {
+    __shared__ __attribute__((aligned(1024))) char ring[DmaTile<BM, BN, WM, WN>::NBUF * DmaTile<BM, BN, WM, WN>::STAGE];
+    int bx = blockIdx.x, by = blockIdx.y, bzl = blockIdx.z;
+    if (dp.xcd) {
+        const int S = gridDim.x * gridDim.y, L = bx + gridDim.x * (by + gridDim.y * bzl), j = L >> 3;
+        const int sl = j / S, t = j - sl * S;
+        bzl = sl * 8 + (L & 7); bx = t % (int)gridDim.x; by = t / (int)gridDim.x;
+        if (bzl >= dp.nzt) return;
+    }
+    wgrad_dma_body<BM, BN, WM, WN>(dp, bx, by, bzl, ring);
+}
+
+// ---------------------------------------------------------------------------
+// SEVERAL weight gradients of one tile shape in ONE launch (round 5).  A single layer's launch must cut its pixel range into as many slices as
+// it takes to fill 256 CUs with ITS tiles - 28 to 64 slices for the 4 - 9 tiles of a layer3 layer - and every slice writes a full output tile
+// of partial sums: slab bytes = workgroups x tile bytes, whatever the tile (PMC: 383 MB moved per launch for 208 MB of operands and gradient).
+// The weight gradients of a gradient bucket do not depend on one another, so the train step queues them and launches them together: the
+// chip is filled by the tiles of ALL queued layers, each layer's pixel range is cut only as far as a common slice length asks (layer4: not at
+// all; layer3: 4 - 8 slices), and the slab traffic falls by that factor.  The problems ride in the kernel argument (up to 16 x 176 bytes; a
+// captured HIP graph keeps them), workgroup L belongs to the problem whose range [first[i], first[i + 1]) holds it and takes that problem's
+// tile / slice in the XCD-aware order of the single launch (every range is a multiple of 8 long and starts at a multiple of 8).
+constexpr int MAXMULTI = 16;
+struct MultiParams {
+    DmaParams p[MAXMULTI];
+    int first[MAXMULTI + 1];          // first workgroup of problem i (first[n] = grid size)
+    int tx[MAXMULTI];                 // column tiles of problem i (tiles per slice = tx * ty; ty is not needed: the tile index is decoded with tx)
+    int ts[MAXMULTI];                 // tiles per slice
+    int n;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void wgrad_dma_multi_kernel(const MultiParams mp) {
+    __shared__ __attribute__((aligned(1024))) char ring[DmaTile<BM, BN, WM, WN>::NBUF * DmaTile<BM, BN, WM, WN>::STAGE];
+    const int L = blockIdx.x;
+    int i = 0;
+    while (i + 1 < mp.n && mp.first[i + 1] <= L) ++i;
+    i = __builtin_amdgcn_readfirstlane(i);
+    const int loc = L - mp.first[i], S = mp.ts[i];
+    int bzl, t;
+    if (mp.p[i].xcd) { const int j = loc >> 3, sl = j / S; t = j - sl * S; bzl = sl * 8 + (loc & 7); }
+    else { bzl = loc / S; t = loc - bzl * S; }
+    if (bzl >= mp.p[i].nzt) return;
+    wgrad_dma_body<BM, BN, WM, WN>(mp.p[i], t % mp.tx[i], t / mp.tx[i], bzl, ring);
+}
+
+// the slab reducers of a multi-problem launch in one launch: dW[m][n .. n + 3] += sum_z ws[z][m][n .. n + 3] in slice order (fixed order: reproducible)
+struct MultiReduce {
+    const float *ws[MAXMULTI];
+    float *dw[MAXMULTI];
+    int gz[MAXMULTI], Mp[MAXMULTI], Np[MAXMULTI], M[MAXMULTI], N[MAXMULTI], ldw[MAXMULTI];
+    int first[MAXMULTI + 1];          // first block of problem i
+    int n;
+};
+__global__ __launch_bounds__(256) void slab_reduce_multi_kernel(const MultiReduce mr) {
+    __shared__ v4f part[256];
+    int i = 0;
+    while (i + 1 < mr.n && mr.first[i + 1] <= (int)blockIdx.x) ++i;
+    i = __builtin_amdgcn_readfirstlane(i);
+    const int gz = mr.gz[i], Mp = mr.Mp[i], Np = mr.Np[i], n4 = mr.N[i] / 4;
+    const int el = threadIdx.x & 63, zl = threadIdx.x >> 6;      // four slice lanes per float4, folded in lane order
+    const long e = (long)(blockIdx.x - mr.first[i]) * 64 + el;
+    const bool on = e < (long)mr.M[i] * n4;
+    const int m = on ? (int)(e / n4) : 0, n = on ? (int)(e % n4) * 4 : 0;
+    v4f a = {0.f, 0.f, 0.f, 0.f};
+    const float *src = mr.ws[i] + (size_t)m * Np + n;
+    if (on)
+        for (int z = zl; z < gz; z += 4) {
+            const v4f v = *reinterpret_cast<const v4f *>(src + (size_t)z * Mp * Np);
+            a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+        }
+    part[threadIdx.x] = a;
+    __syncthreads();
+    if (zl || !on) return;
+#pragma unroll
+    for (int l = 1; l < 4; ++l) { const v4f v = part[l * 64 + el]; a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3]; }
+    float *dst = mr.dw[i] + (size_t)m * mr.ldw[i] + n;
+    dst[0] += a[0]; dst[1] += a[1]; dst[2] += a[2]; dst[3] += a[3];
 }
 
 // dW[m][n..n+3] += sum_z ws[z][m][n..n+3]: the reducer of the partial-slab mode (one float4 per thread, slabs read coalesced).
@@ -814,6 +899,151 @@ static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, fl
         else if (gz > 8 || n < 65536) hipLaunchKernelGGL(wgrad::slab_reduce_kernel<4>, rg, dim3(256), 0, s, p.ws, dw, gz, p.Mp, p.Np, d->Cout, p.N, p.ldw, dw_bs);
         else hipLaunchKernelGGL(wgrad::slab_reduce_kernel<1>, rg, dim3(64), 0, s, p.ws, dw, gz, p.Mp, p.Np, d->Cout, p.N, p.ldw, dw_bs);
         return check_launch("slab_reduce_kernel");
+    }
+    return MHE_OK;
+}
+
+// ---- several weight gradients in one launch (see wgrad_dma_multi_kernel) ---------------------------------------------------------------
+namespace {
+struct MultiItemPlan { WgradPlan w; long P; int Ho, Wo, tiles; };
+static long multi_target(bool big) {
+    static const long tb = getenv("MHE_WGRAD_MULTI_WGS_BIG") ? atol(getenv("MHE_WGRAD_MULTI_WGS_BIG")) : 512;     // 256 x 256 tile: one workgroup per CU
+    static const long ts = getenv("MHE_WGRAD_MULTI_WGS") ? atol(getenv("MHE_WGRAD_MULTI_WGS")) : 1024;            // the 4-wave tiles: two per CU
+    return big ? tb : ts;
+}
+// common slice length of a batch: the shortest (multiple of 32, >= 512 pixels) at which the batch's workgroups - tiles x slices - fit the target
+static long common_chunk(const MultiItemPlan *it, const int *idx, int n, long target) {
+    long lo = 512, hi = 512;
+    for (int k = 0; k < n; ++k) if (it[idx[k]].P > hi) hi = it[idx[k]].P;
+    hi = (hi + 31) / 32 * 32;
+    auto total = [&](long c) { long t = 0; for (int k = 0; k < n; ++k) t += (long)it[idx[k]].tiles * ((it[idx[k]].P + c - 1) / c); return t; };
+    if (total(lo) <= target) return lo;
+    while (lo + 32 < hi) {
+        const long mid = (lo + hi) / 2 / 32 * 32;
+        if (total(mid) <= target) hi = mid; else lo = mid;
+    }
+    return hi;
+}
+struct MultiLayout { int gz[wgrad::MAXMULTI]; long chunk[wgrad::MAXMULTI]; size_t ws_off[wgrad::MAXMULTI]; size_t ws_total; };
+static void layout_batch(const mhe_wgrad_item *items, const MultiItemPlan *it, const int *idx, int n, bool big, MultiLayout &lo) {
+    const long c = common_chunk(it, idx, n, multi_target(big));
+    lo.ws_total = 0;
+    for (int k = 0; k < n; ++k) {
+        const MultiItemPlan &q = it[idx[k]];
+        int gz = (int)((q.P + c - 1) / c);
+        long chunk = ((q.P + gz - 1) / gz + 31) / 32 * 32;          // balanced slices of this problem
+        gz = (int)((q.P + chunk - 1) / chunk);
+        lo.gz[k] = gz; lo.chunk[k] = chunk; lo.ws_off[k] = lo.ws_total;
+        if (gz > 1) lo.ws_total += (size_t)gz * (q.w.gy * q.w.BM) * (size_t)(q.w.gx * q.w.BN);
+    }
+}
+static bool multi_plan(const mhe_wgrad_item *items, int n, MultiItemPlan *it) {
+    for (int i = 0; i < n; ++i) {
+        const mhe_conv_desc *d = &items[i].d;
+        if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->pad < 0) return false;
+        it[i].w = plan_wgrad(d);
+        it[i].Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1; it[i].Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+        it[i].P = (long)d->B * it[i].Ho * it[i].Wo;
+        it[i].tiles = it[i].w.gx * it[i].w.gy;
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" size_t mhe_conv_wgrad_multi_workspace_floats(const mhe_wgrad_item *items, int n) {
+    if (!items || n <= 0 || n > 256) return 0;
+    MultiItemPlan it[256];
+    if (!multi_plan(items, n, it)) return 0;
+    size_t need = 0;
+    bool used[256] = {false};
+    for (int i = 0; i < n; ++i) {
+        if (used[i]) continue;
+        if (!(it[i].w.bf16k && it[i].w.dma)) { used[i] = true; const size_t w = mhe_conv_wgrad_workspace_floats(&items[i].d); if (w > need) need = w; continue; }
+        int idx[wgrad::MAXMULTI], m = 0;
+        for (int j = i; j < n && m < wgrad::MAXMULTI; ++j)
+            if (!used[j] && it[j].w.bf16k && it[j].w.dma && it[j].w.BM == it[i].w.BM && it[j].w.BN == it[i].w.BN) { idx[m++] = j; used[j] = true; }
+        MultiLayout lo;
+        layout_batch(items, it, idx, m, it[i].w.big, lo);
+        if (lo.ws_total > need) need = lo.ws_total;
+    }
+    return need;
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_multi(const wgrad::MultiParams &mp, hipStream_t s) {
+    hipLaunchKernelGGL((wgrad::wgrad_dma_multi_kernel<BM, BN, WM, WN>), dim3((unsigned)mp.first[mp.n]), dim3(64 * WM * WN), 0, s, mp);
+}
+
+extern "C" int mhe_conv_wgrad_multi_nhwc(const mhe_wgrad_item *items, int n, float *workspace, size_t workspace_floats, void *stream) {
+    MHE_REQUIRE(items && n > 0 && n <= 256, "mhe_conv_wgrad_multi_nhwc: 1 .. 256 problems");
+    MultiItemPlan it[256];
+    MHE_REQUIRE(multi_plan(items, n, it), "mhe_conv_wgrad_multi_nhwc: bad geometry");
+    for (int i = 0; i < n; ++i) MHE_REQUIRE(items[i].x && items[i].gy && items[i].dw, "mhe_conv_wgrad_multi_nhwc: null pointer (problem %d)", i);
+    hipStream_t s = (hipStream_t)stream;
+    bool used[256] = {false};
+    for (int i = 0; i < n; ++i) {
+        if (used[i]) continue;
+        if (!(it[i].w.bf16k && it[i].w.dma)) {          // not a shape of the LDS-DMA kernel (f32 operands, odd channel counts): its own launch
+            used[i] = true;
+            if (int rc = wgrad_entry(&items[i].d, items[i].x, items[i].gy, items[i].dw, items[i].ldw, workspace, workspace_floats, stream)) return rc;
+            continue;
+        }
+        int idx[wgrad::MAXMULTI], m = 0;
+        for (int j = i; j < n && m < wgrad::MAXMULTI; ++j)
+            if (!used[j] && it[j].w.bf16k && it[j].w.dma && it[j].w.BM == it[i].w.BM && it[j].w.BN == it[i].w.BN) { idx[m++] = j; used[j] = true; }
+        MultiLayout lo;
+        layout_batch(items, it, idx, m, it[i].w.big, lo);
+        MHE_REQUIRE(lo.ws_total == 0 || (workspace && lo.ws_total <= workspace_floats), "mhe_conv_wgrad_multi_nhwc: workspace of %zu floats, this batch needs %zu",
+                    workspace_floats, lo.ws_total);
+        wgrad::MultiParams mp;
+        wgrad::MultiReduce mr;
+        memset(&mp, 0, sizeof(mp)); memset(&mr, 0, sizeof(mr));
+        mp.n = m; mr.n = 0;
+        int first = 0, rfirst = 0;
+        for (int k = 0; k < m; ++k) {
+            const mhe_wgrad_item &q = items[idx[k]];
+            const MultiItemPlan &pl = it[idx[k]];
+            const mhe_conv_desc *d = &q.d;
+            wgrad::DmaParams &dp = mp.p[k];
+            wgrad::Params &p = dp.p;
+            p.x = q.x; p.gy = q.gy; p.dw = q.dw;
+            p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
+            p.stride_w = d->stride; p.pad_w = d->pad; p.Ho = pl.Ho; p.Wo = pl.Wo;
+            p.N = d->KH * d->KW * d->Cin; p.ldw = q.ldw > 0 ? q.ldw : p.N;
+            MHE_REQUIRE(p.ldw >= p.N, "mhe_conv_wgrad_multi_nhwc: ldw=%d < KH*KW*Cin=%d (problem %d)", q.ldw, p.N, idx[k]);
+            p.P = pl.P; p.chunk = (int)lo.chunk[k];
+            p.Mp = pl.w.gy * pl.w.BM; p.Np = pl.w.gx * pl.w.BN;
+            const int gz = lo.gz[k];
+            p.ws = gz > 1 ? workspace + lo.ws_off[k] : nullptr;
+            p.direct = gz == 1;
+            dp.rcp_wo = (unsigned)((0x100000000ull + p.Wo - 1) / p.Wo); dp.rcp_ho = (unsigned)((0x100000000ull + p.Ho - 1) / p.Ho);
+            dp.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->Cin * 2); dp.gy_bytes = (unsigned)((size_t)p.P * d->Cout * 2);
+            dp.plain = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0;
+            dp.nzt = gz;
+            // a problem cut at least 8 ways takes the single launch's XCD-aware order (8 slices side by side, one per XCD, their tiles next to each
+            // other in time: slot = 8 * (tile + tiles * (slice / 8)) + slice % 8); fewer slices: tile-major within the slice
+            dp.xcd = gz >= 8;
+            mp.tx[k] = pl.w.gx; mp.ts[k] = pl.tiles;
+            mp.first[k] = first;
+            const int wgs = dp.xcd ? 8 * pl.tiles * ((gz + 7) / 8) : (pl.tiles * gz + 7) / 8 * 8;
+            first += wgs;
+            if (gz > 1) {
+                const int r = mr.n++;
+                mr.ws[r] = p.ws; mr.dw[r] = q.dw; mr.gz[r] = gz; mr.Mp[r] = p.Mp; mr.Np[r] = p.Np; mr.M[r] = d->Cout; mr.N[r] = p.N; mr.ldw[r] = p.ldw;
+                mr.first[r] = rfirst;
+                rfirst += (int)(((long)d->Cout * (p.N / 4) + 63) / 64);
+            }
+        }
+        mp.first[m] = first; mr.first[mr.n] = rfirst;
+        const WgradPlan &w = it[i].w;
+        if (w.big) launch_multi<256, 256, 4, 2>(mp, s);
+        else if (w.narrow) { if (w.small) launch_multi<64, 64, 2, 2>(mp, s); else launch_multi<128, 64, 4, 1>(mp, s); }
+        else { if (w.small) launch_multi<64, 128, 1, 4>(mp, s); else launch_multi<128, 128, 2, 2>(mp, s); }
+        if (int rc = check_launch("wgrad_dma_multi_kernel")) return rc;
+        if (mr.n) {
+            hipLaunchKernelGGL(wgrad::slab_reduce_multi_kernel, dim3((unsigned)rfirst), dim3(256), 0, s, mr);
+            if (int rc = check_launch("slab_reduce_multi_kernel")) return rc;
+        }
     }
     return MHE_OK;
 }

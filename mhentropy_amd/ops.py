@@ -981,6 +981,34 @@ def conv_wgrad(x, gy, KH, KW, stride, pad, dw, ldw=0):
     return dw
 
 
+def conv_wgrad_multi(items):
+    """several independent weight gradients in one call (mhe_conv_wgrad_multi_nhwc): items = [(x, gy, KH, KW, stride, pad, dw), ...] as for
+    conv_wgrad.  Problems of one tile shape share launches: the chip is filled by the tiles of all of them, each pixel range is cut only as far
+    as a common slice length asks (the partial-slab traffic of one launch per layer falls by the number of layers that share the chip).
+    Fixed summation order; dW += as in conv_wgrad."""
+    if not items:
+        return
+    n = len(items)
+    arr = (_lib.WgradItem * n)()
+    flops = nbytes = 0.0
+    for i, (x, gy, KH, KW, stride, pad, dw) in enumerate(items):
+        B, H, W, Cin = x.shape
+        Cout = gy.shape[-1]
+        Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+        _chk(x, x.dtype, "wgrad_multi.x"); _chk(gy, x.dtype, "wgrad_multi.gy", (B, Ho, Wo, Cout)); _chk(dw, torch.float32, "wgrad_multi.dw")
+        if dw.numel() < Cout * KH * KW * Cin:
+            raise ValueError(f"wgrad_multi.dw[{i}]: {dw.numel()} floats cannot hold [{Cout}, {KH * KW * Cin}]")
+        arr[i].d = ConvDesc(B, H, W, Cin, Cout, KH, KW, stride, pad, dtype_code(x.dtype), 0, 0)
+        arr[i].x, arr[i].gy, arr[i].dw, arr[i].ldw = x.data_ptr(), gy.data_ptr(), dw.data_ptr(), 0
+        flops += 2.0 * B * Ho * Wo * Cout * KH * KW * Cin
+        nbytes += x.element_size() * (x.numel() + gy.numel()) + 4 * Cout * KH * KW * Cin
+    L = _lib.lib()
+    need = L.mhe_conv_wgrad_multi_workspace_floats(C.byref(arr), n)
+    ws = _wgrad_ws(items[0][0].device, need) if need else None
+    with _Timed(lambda: "mhe::wgrad::wgrad_dma_multi_kernel (a bucket's weight gradients, %d problems)" % n, flops, nbytes):
+        check(L.mhe_conv_wgrad_multi_nhwc(C.byref(arr), n, _ptr(ws), ws.numel() if ws is not None else 0, _stream()), "mhe_conv_wgrad_multi_nhwc")
+
+
 def conv_wgrad_batched(x, gy, dw, dw_batch_stride, nbatch, x_batch_stride=None, gy_batch_stride=None):
     """nbatch dense weight gradients dw_b [N, K] += gy_b [R, N]^T x_b [R, K] in one grouped launch (mhe_conv_wgrad_batched_nhwc).  x / gy: bf16
     tensors whose storage holds the problems at the given element strides (default: x [nbatch, R, K], gy [nbatch, R, N] contiguous); dw: the

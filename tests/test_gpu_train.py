@@ -1034,3 +1034,44 @@ def test_fallback_operand_layouts_are_refreshed_when_a_fallback_path_runs(gpu_li
     ts3 = TrainStep(fresh_like(model2), lr=1e-3)
     ref = ts3.forward_backward(x, y, noise=z16, N=16)
     assert torch.equal(out["log_p"], ref["log_p"]) and torch.equal(ts2.G, ts3.G)
+
+
+def test_multi_problem_weight_gradient_launch(gpu_lib):
+    """mhe_conv_wgrad_multi_nhwc (round 5): the weight gradients of several layers in one call - problems of one tile shape share a launch, the
+    pixel range of each is cut only as far as a common slice length asks (fewer partial slabs), unsplit problems add their tiles with plain
+    stores.  Against one launch per layer (same bf16 products, f32 sums in another order) and against torch autograd; `dW +=` semantics;
+    two calls give the same bits (fixed summation order).  Shapes: layer3's three convolutions (256 x 256 and 128 x 128 tile classes, split),
+    layer1's 64-channel shapes (64 x 128 / 128 x 64 classes), a stride-2 3x3, an f32 problem (its own launch), and a batch with more tiles
+    than the chip takes (unsplit: the plain-store form)."""
+    from mhentropy_amd import ops
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(11)
+    bf = torch.bfloat16
+    # (Cin, Cout, k, stride, pad, H, B, dtype)
+    cases = [(256, 256, 3, 1, 1, 16, 24, bf), (256, 1024, 1, 1, 0, 16, 24, bf), (1024, 256, 1, 1, 0, 16, 24, bf), (512, 256, 1, 1, 0, 16, 24, bf),
+             (64, 64, 3, 1, 1, 32, 6, bf), (64, 256, 1, 1, 0, 32, 6, bf), (256, 64, 1, 1, 0, 32, 6, bf), (128, 128, 3, 2, 1, 32, 6, bf),
+             (64, 128, 1, 1, 0, 16, 4, torch.float32),
+             (1152, 1024, 1, 1, 0, 8, 8, bf), (1024, 1152, 1, 1, 0, 8, 8, bf), (1152, 1152, 1, 1, 0, 8, 8, bf), (1024, 1024, 3, 1, 1, 8, 8, bf)]
+    items, refs, singles = [], [], []
+    for (Cin, Cout, k, stride, pad, H, B, dt) in cases:
+        x = torch.randn(B, Cin, H, H, generator=g).to(dt).float().requires_grad_(False)
+        w = torch.zeros(Cout, Cin, k, k, requires_grad=True)
+        y = F.conv2d(x, w, stride=stride, padding=pad)
+        gy = torch.randn(y.shape, generator=g).to(dt).float()
+        y.backward(gy)
+        refs.append(w.grad.permute(0, 2, 3, 1).reshape(Cout, -1))
+        xd, gyd = _nhwc(x, dt), _nhwc(gy, dt)
+        dw = torch.ones(Cout, k * k * Cin, device="cuda")
+        items.append((xd, gyd, k, k, stride, pad, dw))
+        singles.append(ops.conv_wgrad(xd, gyd, k, k, stride, pad, torch.ones(Cout, k * k * Cin, device="cuda")))
+    ops.conv_wgrad_multi(items)
+    torch.cuda.synchronize()
+    first = [it[6].clone() for it in items]
+    for it, ref, one, c in zip(items, refs, singles, cases):
+        assert_close(it[6].cpu() - 1.0, ref, 2e-5, what=f"multi-problem dW vs autograd {c}")            # dW += : the ones survive
+        assert_close(it[6].cpu(), one.cpu(), 2e-5, what=f"multi-problem dW vs its own launch {c}")
+    for it in items:
+        it[6].fill_(1.0)
+    ops.conv_wgrad_multi(items)
+    torch.cuda.synchronize()
+    assert all(torch.equal(it[6], f) for it, f in zip(items, first)), "two multi-problem calls differ: the summation order is not fixed"
