@@ -907,8 +907,10 @@ static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, fl
 namespace {
 struct MultiItemPlan { WgradPlan w; long P; int Ho, Wo, tiles; };
 static long multi_target(bool big) {
-    static const long tb = getenv("MHE_WGRAD_MULTI_WGS_BIG") ? atol(getenv("MHE_WGRAD_MULTI_WGS_BIG")) : 512;     // 256 x 256 tile: one workgroup per CU
-    static const long ts = getenv("MHE_WGRAD_MULTI_WGS") ? atol(getenv("MHE_WGRAD_MULTI_WGS")) : 1024;            // the 4-wave tiles: two per CU
+    // measured at config C2 on one box (gpurun_out/r5, profiles/EXPERIMENTS.md "Round 5"): 512 / 1024 -> 25.85 ms per train step, 768 / 1024 -> 25.60,
+    // 512 / 2048 -> 25.62, 768 / 2048 -> 25.30 (896 / 2048 -> 26.0: a fourth partial round of the one-workgroup-per-CU tile); one launch per layer: 26.0
+    static const long tb = getenv("MHE_WGRAD_MULTI_WGS_BIG") ? atol(getenv("MHE_WGRAD_MULTI_WGS_BIG")) : 768;     // 256 x 256 tile: one workgroup per CU, three rounds
+    static const long ts = getenv("MHE_WGRAD_MULTI_WGS") ? atol(getenv("MHE_WGRAD_MULTI_WGS")) : 2048;            // the 4-wave tiles: two per CU, four rounds
     return big ? tb : ts;
 }
 // common slice length of a batch: the shortest (multiple of 32, >= 512 pixels) at which the batch's workgroups - tiles x slices - fit the target
@@ -962,6 +964,7 @@ extern "C" size_t mhe_conv_wgrad_multi_workspace_floats(const mhe_wgrad_item *it
         int idx[wgrad::MAXMULTI], m = 0;
         for (int j = i; j < n && m < wgrad::MAXMULTI; ++j)
             if (!used[j] && it[j].w.bf16k && it[j].w.dma && it[j].w.BM == it[i].w.BM && it[j].w.BN == it[i].w.BN) { idx[m++] = j; used[j] = true; }
+        if (m == 1) { const size_t w = mhe_conv_wgrad_workspace_floats(&items[i].d); if (w > need) need = w; continue; }
         MultiLayout lo;
         layout_batch(items, it, idx, m, it[i].w.big, lo);
         if (lo.ws_total > need) need = lo.ws_total;
@@ -991,6 +994,10 @@ extern "C" int mhe_conv_wgrad_multi_nhwc(const mhe_wgrad_item *items, int n, flo
         int idx[wgrad::MAXMULTI], m = 0;
         for (int j = i; j < n && m < wgrad::MAXMULTI; ++j)
             if (!used[j] && it[j].w.bf16k && it[j].w.dma && it[j].w.BM == it[i].w.BM && it[j].w.BN == it[i].w.BN) { idx[m++] = j; used[j] = true; }
+        if (m == 1) {            // alone in its tile class: the single launch's own plan (one resident round of workgroups, its reducer) is the better one
+            if (int rc = wgrad_entry(&items[i].d, items[i].x, items[i].gy, items[i].dw, items[i].ldw, workspace, workspace_floats, stream)) return rc;
+            continue;
+        }
         MultiLayout lo;
         layout_batch(items, it, idx, m, it[i].w.big, lo);
         MHE_REQUIRE(lo.ws_total == 0 || (workspace && lo.ws_total <= workspace_floats), "mhe_conv_wgrad_multi_nhwc: workspace of %zu floats, this batch needs %zu",

@@ -177,6 +177,9 @@ class TrainStep:
         # its full-resolution output: MHE_STEM_POOLED_SUMS=0 restores the walk
         self.stem_pooled_sums = os.environ.get("MHE_STEM_POOLED_SUMS", "1") == "1"
         self.bn_on_load_wide = os.environ.get("MHE_BN_BWD_ON_LOAD_WIDE", "1") == "1"
+        # the trunk's weight gradients queued per gradient bucket and launched together (MHE_WGRAD_MULTI=0: one launch per layer)
+        self.wgrad_multi = os.environ.get("MHE_WGRAD_MULTI", "1") == "1"
+        self._wq = []
         self._bucket_bounds = self._gradient_buckets()
         self._works = []
         self.raw = torch.zeros(self._raw_n, device=self.dev, dtype=torch.float32)
@@ -240,6 +243,7 @@ class TrainStep:
 
     def _grad_ready(self, i):
         lo, hi = self._bucket_bounds[i]
+        self._wgrad_flush()              # the bucket's queued weight gradients, one multi-problem launch per tile shape
         ops.gather(self.raw, self._unpack_idx[lo:hi], self.G[lo:hi])
         if self.comm:
             cap = getattr(self, "_capture", None)
@@ -766,7 +770,20 @@ class TrainStep:
         return u.y
 
     def _wgrad(self, u, gy):
-        ops.conv_wgrad(u.x, gy, u.k, u.k, u.stride, u.pad, u.dw)
+        """dW of a trunk unit.  bf16 trunk: QUEUED - a gradient bucket's weight gradients do not depend on one another, so they are launched
+        together when the bucket completes (ops.conv_wgrad_multi: the layers share the chip, every pixel range is cut 4 - 8 ways instead of
+        28 - 64, layer4 not at all - the partial-slab traffic of one launch per layer, 5.4 GB of the step's 98 GB, falls accordingly).  The
+        queue holds x and gy alive; nothing in the reverse pass writes into either after this point (gy is this unit's own tensor, x a
+        forward activation)."""
+        if self.wgrad_multi and gy.dtype == torch.bfloat16:
+            self._wq.append((u.x, gy, u.k, u.k, u.stride, u.pad, u.dw))
+        else:
+            ops.conv_wgrad(u.x, gy, u.k, u.k, u.stride, u.pad, u.dw)
+
+    def _wgrad_flush(self):
+        if self._wq:
+            ops.conv_wgrad_multi(self._wq)
+            self._wq = []
 
     def _dgrad(self, u, gy, residual=None, gate=True, consumers=(), pool=None, res_half=False, coarse=False, mask_bits=None):
         """gradient w.r.t. the pre-activation of the unit's input (+ residual): every unit input in the trunk is a post-ReLU

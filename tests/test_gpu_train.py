@@ -1075,3 +1075,40 @@ def test_multi_problem_weight_gradient_launch(gpu_lib):
     ops.conv_wgrad_multi(items)
     torch.cuda.synchronize()
     assert all(torch.equal(it[6], f) for it, f in zip(items, first)), "two multi-problem calls differ: the summation order is not fixed"
+
+
+def test_queued_multi_problem_weight_gradients_equal_one_launch_per_layer(gpu_lib):
+    """TrainStep queues the trunk's weight gradients per gradient bucket and launches them together (MHE_WGRAD_MULTI, ops.conv_wgrad_multi).
+    Two reverse passes over ONE forward pass's tape - queued vs one launch per layer: the same bf16 operands and products, f32 sums in another
+    order, so every parameter gradient agrees to 2e-5 of its scale; the queued form twice: equal bit for bit (fixed summation order).
+    ResNet-50 in the bf16 mode at 128 x 128 (all four tile classes, split and unsplit problems)."""
+    from mhentropy_amd import harness
+    from mhentropy_amd.train import TrainStep
+    torch.manual_seed(6)
+    model = harness.build_mhent(backbone="resnet50", h_dims=(64, 64), num_steps=1, tables=synth.mano_tables(0), compute_dtype=torch.bfloat16).cuda().train()
+    B, N = 16, 4
+    xn, yn = synth.batch(10, B, image_size=128)
+    x, y = _dev(xn), {k: _dev(v) for k, v in yn.items()}
+    z0 = _dev(synth.noise(10, N * B))
+    ts = TrainStep(model)
+    assert ts.wgrad_multi
+    ts.forward(x, y, noise=z0, N=N)
+    grads = {}
+    for mode in (True, False, True):
+        ts.wgrad_multi = mode
+        ts.backward()
+        g = {n: ts.grad_of(p).clone() for n, p in model.named_parameters()}
+        if mode and True in grads:
+            bad = [n for n in g if not torch.equal(g[n], grads[True][n])]
+            assert not bad, bad[:6]
+        grads[mode] = g
+    worst = (0.0, "")
+    for n, a in grads[True].items():
+        b_ = grads[False][n]
+        if b_.abs().max() == 0:
+            assert a.abs().max() == 0, n
+            continue
+        e = float((a - b_).abs().max() / b_.abs().max())
+        worst = max(worst, (e, n))
+    print("queued vs per-layer weight gradients, worst max-abs relative difference:", worst)
+    assert worst[0] < 2e-5, worst
