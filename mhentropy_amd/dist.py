@@ -88,6 +88,84 @@ def allreduce_gradients(flat, dist=None, bucket_elems=16 << 20):
     return flat
 
 
+class GradExchange:
+    """The train step's ONE exchange, bucket by bucket: `start(flat_slice)` hands a completed range of the flat f32
+    gradient buffer to the communicator while the reverse pass goes on, `finish()` makes the compute stream wait for all of them.
+
+    * EVENT-SCOPED: each bucket's collective depends on ONE event - recorded on the compute stream right after the bucket's gather - and runs
+      on a communication stream of its own (backend "nccl" = RCCL).  Whatever the reverse pass queues afterwards on the compute stream is
+      not in the collective's way, and the collective is not in the way of the compute stream until finish().
+    * mode "f32" (default): all_reduce(SUM) of the f32 range, in place.
+    * mode "bf16" (MHE_GRAD_EXCHANGE=bf16; absent in the reference, which has no distributed path at all): half the bytes on the wire WITH f32
+      accumulation - an all-to-all of bf16 chunks (rank r receives chunk r of every rank: a direct reduce-scatter in which all seven xGMI
+      links of a GPU carry 1/8 of the message at once), the chunks summed locally in f32 in rank order (a fixed order:
+      every rank computes the same sums), the reduced chunk rounded to bf16 and all-gathered.  Every rank ends with the SAME bits, so
+      replicas stay identical; the gradient carries one bf16 rounding per element and rank before the sum and one after it.
+    The mean over ranks (DDP semantics) is taken by the optimizer kernel's grad_scale = 1 / world in both modes."""
+
+    def __init__(self, dist, mode=None, device=None):
+        self.dist, self.mode = dist, (mode or os.environ.get("MHE_GRAD_EXCHANGE", "f32"))
+        if self.mode not in ("f32", "bf16"):
+            raise ValueError(f"gradient exchange mode {self.mode!r}: 'f32' or 'bf16'")
+        self.world = dist.get_world_size()
+        self.side = torch.cuda.Stream(device=device) if (device is not None and torch.device(device).type == "cuda" and dist.get_backend() == "nccl") else None
+        self._pending, self._bufs = [], {}
+
+    def _buf(self, key, n, dtype, device):
+        b = self._bufs.get(key)
+        if b is None or b.numel() < n or b.dtype != dtype:
+            b = self._bufs[key] = torch.empty(n, dtype=dtype, device=device)
+        return b[:n]
+
+    def _exchange(self, g, key):
+        """the collective(s) of one bucket, issued on the current stream context; returns the work handle(s) to wait on"""
+        d = self.dist
+        if self.mode == "f32":
+            return [d.all_reduce(g, op=d.ReduceOp.SUM, async_op=True)]
+        W, n = self.world, g.numel()
+        c = -(-n // (8 * W)) * 8                                    # chunk length: a multiple of 8 elements (16-byte bf16 pieces)
+        send = self._buf((key, "send"), W * c, torch.bfloat16, g.device)
+        send[:n].copy_(g)
+        if W * c > n:
+            send[n:].zero_()
+        recv = self._buf((key, "recv"), W * c, torch.bfloat16, g.device)
+        w1 = d.all_to_all_single(recv, send, async_op=True)
+        w1.wait()                                                   # (stream-ordered on the device: the host does not block on nccl; gloo: it does)
+        red = recv.view(W, c).float().sum(0).to(torch.bfloat16)     # f32 accumulation, rank order
+        out = self._buf((key, "out"), W * c, torch.bfloat16, g.device)
+        w2 = d.all_gather_into_tensor(out, red, async_op=True)
+        w2.wait()
+        g.copy_(out[:n])
+        return []
+
+    def start(self, g, key=0):
+        if self.side is None:                                       # gloo (CPU tests, one-GPU rehearsals): the backend's own ordering
+            self._pending += self._exchange(g, key)
+            return
+        ev = torch.cuda.Event()
+        ev.record()                                                 # the bucket's gather has been queued on the compute stream: depend on exactly that
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            works = self._exchange(g, key)
+            for w in works:
+                w.wait()                                            # the side stream waits for the communicator's stream (no host block)
+            done = torch.cuda.Event()
+            done.record()
+        g.record_stream(self.side)
+        self._pending.append(done)
+
+    def in_flight(self):
+        return len(self._pending)
+
+    def finish(self):
+        for p in self._pending:
+            if isinstance(p, torch.cuda.Event):
+                torch.cuda.current_stream().wait_event(p)
+            else:
+                p.wait()
+        self._pending = []
+
+
 class HypothesisShards:
     """Hypothesis-sharded exchange around the image-sharded encoder (SURVEY.md section 8e, "optional hypothesis sharding";
     config C4).  Given the conditioning feature, an image's K hypotheses are independent, so once the encoder has run on each

@@ -69,6 +69,7 @@ SWITCHES = {
     "MHE_WGRAD_SLABS": ("all", "csrc/wgrad.hip", "big: small layers add their tiles with f32 atomics (order-dependent sums)"),
     "MHE_WGRAD_F32MFMA": ("", "csrc/wgrad.hip", "set: bf16 operands through the f32 MFMA kernel"),
     # ---- processes
+    "MHE_GRAD_EXCHANGE": ("f32", "dist.py", "bf16: gradient buckets exchanged as bf16 (all-to-all + all-gather, f32 accumulation) instead of an f32 all-reduce"),
     "MHE_DIST_FORCE": ("0", "dist.py", "1: issue every collective in a group of ONE rank (one-GPU rehearsal of the RCCL path)"),
     "MHE_BENCH_REHEARSE": ("0", "bench.py", "1: all ranks share cuda:0 and talk over gloo (development only)"),
 }

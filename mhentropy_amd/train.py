@@ -181,7 +181,7 @@ class TrainStep:
         self.wgrad_multi = os.environ.get("MHE_WGRAD_MULTI", "1") == "1"
         self._wq = []
         self._bucket_bounds = self._gradient_buckets()
-        self._works = []
+        self._xchg = None
         self.raw = torch.zeros(self._raw_n, device=self.dev, dtype=torch.float32)
         for u in self._raw_views:
             u()
@@ -253,18 +253,26 @@ class TrainStep:
                 self._all_reduce_bucket(i)
 
     def _all_reduce_bucket(self, i):
+        """hand bucket i of the flat gradient to the communicator (dist.GradExchange: event-scoped, on its own stream; f32 all-reduce or the
+        bf16 all-to-all + all-gather exchange with f32 accumulation)"""
         lo, hi = self._bucket_bounds[i]
-        self._works.append(self.dist.all_reduce(self.G[lo:hi], op=self.dist.ReduceOp.SUM, async_op=True))
+        if self._xchg is None:
+            from .dist import GradExchange
+            self._xchg = GradExchange(self.dist, device=self.dev)
+        self._xchg.start(self.G[lo:hi], key=i)
+
+    @property
+    def _works(self):           # (tests: how many bucket exchanges are in flight)
+        return [None] * (self._xchg.in_flight() if self._xchg is not None else 0)
 
     def finish_allreduce(self):
-        """wait for the gradient buckets' all-reduces (sum over ranks; the mean is taken by grad_scale = 1/world)"""
+        """wait for the gradient buckets' exchanges (sum over ranks; the mean is taken by grad_scale = 1/world)"""
         cap = getattr(self, "_capture", None)
         if cap is not None and self.comm:
             cap.cut(("wait",))
             return
-        for w in self._works:
-            w.wait()
-        self._works = []
+        if self._xchg is not None:
+            self._xchg.finish()
 
     def _pidx(self, p):
         """int64 index tensor shaped like p holding each element's position in the flat buffer"""
@@ -1415,10 +1423,8 @@ class GraphedStep:
                 a = self.actions[k]
                 if a[0] == "allreduce":
                     ts._all_reduce_bucket(a[1])
-                else:
-                    for w in ts._works:
-                        w.wait()
-                    ts._works = []
+                elif ts._xchg is not None:
+                    ts._xchg.finish()
         return self.out
 
 

@@ -206,3 +206,45 @@ def test_scalar_log_uses_the_reference_tags(tmp_path):
     tags = {r["tag"]: r for r in recs}
     assert tags["loss_it/neg_log_p"]["value"] == 2.0 and tags["param/theta_norm"]["value"] == 2.0
     assert tags["loss_avg/loss_total"]["step"] == 4 and abs(tags["metric_train/eval_3d_rgb"]["value"] - 12.0) < 1e-9
+
+
+XCHG_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["MHE_ROOT"])
+import torch
+from mhentropy_amd import dist as mdist
+rank, _, world, dist = mdist.init("gloo")
+n = 1003                                       # not a multiple of 8 * world: the chunks are padded
+gs = [torch.randn(n, generator=torch.Generator().manual_seed(100 + r)) * (1.0 + r) for r in range(world)]
+rec = {}
+for mode in ("f32", "bf16"):
+    x = mdist.GradExchange(dist, mode=mode)
+    g = gs[rank].clone()
+    x.start(g, key=0)
+    x.finish()
+    if mode == "f32":
+        want = sum(gs)
+    else:                                      # bf16 on the wire, f32 accumulation in rank order, one bf16 rounding of the sum
+        want = sum(t.bfloat16().float() for t in gs).bfloat16().float()
+    rec[mode] = {"equal": bool(torch.equal(g, want)), "err": float((g - want).abs().max()), "sum": float(g.double().sum())}
+json.dump(rec, open(os.path.join(os.environ["MHE_OUT"], f"xchg{rank}.json"), "w"))
+dist.destroy_process_group()
+'''
+
+
+def test_gradient_exchange_modes_over_gloo(tmp_path):
+    """dist.GradExchange on two ranks: the f32 all-reduce, and the bf16 exchange (all-to-all of bf16 chunks, local f32 sum in rank order, bf16
+    all-gather: half the bytes of the f32 ring with f32 accumulation) - every rank ends with the same bits, equal to the value computed
+    locally from both ranks' gradients"""
+    import json
+    script = tmp_path / "xchg.py"
+    script.write_text(XCHG_WORKER)
+    env = dict(os.environ, MHE_ROOT=ROOT, MHE_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    recs = [json.load(open(tmp_path / f"xchg{r}.json")) for r in range(2)]
+    for mode in ("f32", "bf16"):
+        assert recs[0][mode]["equal"] and recs[1][mode]["equal"], (mode, recs)
+        assert recs[0][mode]["sum"] == recs[1][mode]["sum"]                 # replicas hold the same bits

@@ -71,6 +71,22 @@ ta.step(x, y, noise=z0, N=N); tb.step(x, y, noise=z0, N=N)
 torch.cuda.synchronize()
 rec["params_equal"] = bool(torch.equal(ta.P, tb.P))
 rec["params_err"] = float((ta.P - tb.P).abs().max())
+# the bf16 exchange (all_to_all_single + all_gather_into_tensor over RCCL, f32 accumulation): over one rank the gradient comes back
+# rounded to bf16 once - exactly G0.bfloat16() - through the eager step and through the six-graph replay
+from mhentropy_amd.dist import GradExchange
+m5, _ = _model_and_state("resnet18", 64, 2)
+t5 = TrainStep(m5, dist=dist, lr=0.0)
+t5._xchg = GradExchange(dist, mode="bf16", device=t5.dev)
+t5.forward_backward(x, y, noise=z0, N=N)
+t5.finish_allreduce()
+torch.cuda.synchronize()
+want = G0.bfloat16().float()
+rec["bf16_exchange_equal"] = bool(torch.equal(t5.G, want))
+rec["bf16_exchange_err"] = float((t5.G - want).abs().max() / G0.abs().max())
+gs5 = GraphedStep(t5, x, y, noise=z0, N=N)
+gs5.replay(); torch.cuda.synchronize()
+rec["bf16_exchange_graph_equal"] = bool(torch.equal(t5.G, want))
+rec["exchange_stream_is_separate"] = bool(t5._xchg.side is not None and t5._xchg.side != torch.cuda.current_stream())
 with open(os.path.join(os.environ["MHE_OUT"], "rccl.json"), "w") as fh:
     json.dump(rec, fh)
 dist.barrier()
@@ -97,3 +113,6 @@ def test_one_rank_rccl_group_runs_every_collective_of_the_train_step(gpu_lib, tm
     assert abs(rec["eager_loss"][0] - rec["eager_loss"][1]) <= 1e-6 * abs(rec["eager_loss"][1]), rec
     assert abs(rec["graph_loss"] - rec["eager_loss"][1]) <= 1e-6 * abs(rec["eager_loss"][1]), rec
     assert rec["params_equal"], rec
+    # round 5: the bucket exchanges run on a communication stream of their own behind one event each (dist.GradExchange); the optional bf16
+    # exchange returns the once-rounded gradient
+    assert rec["exchange_stream_is_separate"] and rec["bf16_exchange_equal"] and rec["bf16_exchange_graph_equal"], rec
