@@ -30,8 +30,8 @@ WORKLOADS = {
     # BASELINE.json configs[0] (CPU-runnable plumbing case)
     "c0": dict(B=2, K=4, backbone="resnet18", h=64, steps=2),
 }
-PMC_TRAFFIC = "r04_pmc_traffic.json"
-PMC_TRAFFIC_TRAIN = "r04_train_pmc_traffic.json"
+PMC_TRAFFIC = "r05_pmc_traffic.json"
+PMC_TRAFFIC_TRAIN = "r05_train_pmc_traffic.json"
 HBM_PEAK = 8.0e12               # MI355X_MICROARCH.md (spec); hand-written copy / read kernels reach 5.4-6.0 / 6.3e12 here (tools/probes/hbm_probe.hip)
 PEAK = {"f32": 157.3e12, "bf16": 2.5e15}      # dense MFMA peaks, MI355X_MICROARCH.md "Chip-level parameters"
 _T0 = time.time()

@@ -186,7 +186,7 @@ def test_round3_entries_refuse_what_they_do_not_support():
 def test_committed_counter_summaries_describe_the_committed_kernels():
     """bench.py's `roofline.traffic` comes from profiles/<round>_pmc_traffic.json and is reported only while the summary's
     `source_sha1` equals the sha1 of csrc/*.hip + csrc/*.h; a kernel edit after the counter passes would silently turn the field into
-    null (VERDICT r3 #10).  This test makes that a failure instead: re-run tools/refresh_profiles_r04.sh after touching a kernel."""
+    null (VERDICT r3 #10).  This test makes that a failure instead: re-run tools/refresh_profiles_r05.sh after touching a kernel."""
     sys.path.insert(0, ROOT)
     import bench
     from tools.pmc_traffic import kernel_sources_sha1

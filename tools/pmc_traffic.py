@@ -45,8 +45,9 @@ def main():
         res[k] = {"launches_profiled": nf, "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
                   "hbm_bytes_per_launch": round(rd + wr)}
     sha = kernel_sources_sha1()
-    json.dump({"source_sha1": sha, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py "
-                         "--steps 2 --warmup 1 --dtype bf16 --no-cpu-baseline --graph 0 --train-steps 0 --no-glow-variant",
+    cmd = sys.argv[4] if len(sys.argv) > 4 else ("python3 bench.py --steps 2 --warmup 1 --dtype bf16 --no-cpu-baseline --graph 0 --train-steps 0 "
+                                                 "--no-glow-variant")        # the command the two passes profiled (the caller says which)
+    json.dump({"source_sha1": sha, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- " + cmd,
                "correction": "FETCH_SIZE x2 (gfx950 wide coalesced reads), counters in KiB", "kernels": res},
               open(dst, "w"), indent=1, sort_keys=True)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_profiled"])[:8]:
