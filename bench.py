@@ -127,7 +127,8 @@ def roofline_of(times, dtype, steps_timed, step_seconds, pmc_file, n_next=3):
              "algorithmic_flop_per_launch": int(fl / cnt), "algorithmic_bytes_per_launch": int(nby / cnt),
              "tflops": round(fl / sec / 1e12, 1), "share_of_step": round(sec / steps_timed / step_seconds, 3)}
         if "wgrad" in name:         # one C-ABI entry launches both: rocprofv3's average for the kernel alone is ~8-13 us below avg_launch_us
-            e["timed_interval"] = "the weight-gradient kernel + its slab_reduce_kernel launch (fixed-order sum of the pixel-range partials)"
+            e["timed_interval"] = ("the weight-gradient kernel + its slab reducer launch (fixed-order sum of the pixel-range partials)" +
+                                   ("; a multi-problem launch = up to 16 layers of a gradient bucket that share this tile shape" if "multi" in name else ""))
         return e
     order = sorted(agg, key=lambda k: -agg[k][1])
     roof = entry(order[0])

@@ -988,6 +988,18 @@ def conv_wgrad_multi(items):
     Fixed summation order; dW += as in conv_wgrad."""
     if not items:
         return
+    if TIMING and len(items) > 1:
+        # bench.py's live roofline pass: one call per tile class, so that every timed interval is ONE kernel instantiation (+ its reducer) under
+        # the name rocprofv3 prints - the product path makes one call for the whole bucket
+        groups = {}
+        for it in items:
+            x, gy, KH, KW, stride, pad, dw = it
+            d = ConvDesc(x.shape[0], x.shape[1], x.shape[2], x.shape[3], gy.shape[-1], KH, KW, stride, pad, dtype_code(x.dtype), 0, 0)
+            groups.setdefault(_lib.lib().mhe_conv_wgrad_variant(C.byref(d), 0, 0, 1), []).append(it)
+        if len(groups) > 1:
+            for g in groups.values():
+                conv_wgrad_multi(g)
+            return
     n = len(items)
     arr = (_lib.WgradItem * n)()
     flops = nbytes = 0.0
@@ -1005,7 +1017,10 @@ def conv_wgrad_multi(items):
     L = _lib.lib()
     need = L.mhe_conv_wgrad_multi_workspace_floats(C.byref(arr), n)
     ws = _wgrad_ws(items[0][0].device, need) if need else None
-    with _Timed(lambda: "mhe::wgrad::wgrad_dma_multi_kernel (a bucket's weight gradients, %d problems)" % n, flops, nbytes):
+    def name():
+        k = _wgrad_kernel_name(arr[0].d)
+        return k.replace("wgrad_dma_kernel", "wgrad_dma_multi_kernel") if n > 1 else k
+    with _Timed(name, flops, nbytes):
         check(L.mhe_conv_wgrad_multi_nhwc(C.byref(arr), n, _ptr(ws), ws.numel() if ws is not None else 0, _stream()), "mhe_conv_wgrad_multi_nhwc")
 
 

@@ -310,7 +310,9 @@ def test_c1_full_size_f32_vs_oracle_and_properties(gpu_lib):
         e_hip, e_f32, e_pair = float((a - r64).abs().max()) / scale, float((r32 - r64).abs().max()) / scale, float((a - r32).abs().max()) / scale
         print(f"C1 f32 {k}: |HIP-f64| {e_hip:.2e}  |f32 oracle-f64| {e_f32:.2e}  |HIP-f32 oracle| {e_pair:.2e}  (max-norm, relative to max|f64|)")
         assert e_hip <= max(1e-4, 2.0 * e_f32), (k, e_hip, e_f32)
-        assert_close(out[k].cpu(), ref[k], 3e-4, what="C1 " + k)   # two f32 evaluations, each up to e_f32 from f64: at most their sum apart
+        # north_star's bar itself: 1e-4 of the reference's fp32 CPU path (measured on MI355X, round 5: th_norm 4.4e-6, bt_norm 1.1e-5, q_log_p
+        # 2.2e-6, h 1.3e-6, log_p 2.2e-6 - rounds 3-4 asserted 3e-4 without having measured)
+        assert_close(out[k].cpu(), ref[k], 1e-4, what="C1 " + k)
     # (i) hypothesis order within an image is irrelevant (rows are sample-major: r = n*B + b)
     perm = torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(b)) for b in range(B)], 1).cuda()      # (N, B)
     zp = zg.view(N, B, -1).gather(0, perm[:, :, None].expand(-1, -1, zg.shape[-1])).reshape(N * B, -1).contiguous()
@@ -377,8 +379,7 @@ def test_c2_full_size_vs_oracle(gpu_lib):
     """config C2 WHOLE - the workload the headline is timed on (BASELINE.json configs[2]: ResNet-50, shipped 12-coupling h = 512 RealNVP,
     B = 256 images x K = 64 hypotheses, 256x256) - against the CPU restatement on the same seeded inputs (one oracle pass: ~15 s on the
     box's 16 cores, the pass bench.py times as cpu_baseline):
-      f32 mode   every `get_loss` entry at 3e-4 (the bound of the C1 test: 53 train-mode BatchNorm layers of round-off in front of the
-                 1e-4 path),
+      f32 mode   every `get_loss` entry at north_star's 1e-4 (measured figures printed),
       bf16 mode  (the timed product path) the deviation from the f32 reference value, printed and bounded at the C1 figures."""
     from mhentropy_amd import harness
     from oracle import network_ref, mano_ref
@@ -404,7 +405,9 @@ def test_c2_full_size_vs_oracle(gpu_lib):
         if dt == torch.float32:
             for k in keys:
                 assert out[k].shape == ref[k].shape
-                assert_close(out[k].cpu(), ref[k], 3e-4, what="C2 f32 " + k)
+                e = float((out[k].cpu().double() - ref[k].double()).abs().max() / ref[k].double().abs().max())
+                print(f"C2 f32 {k}: |HIP - f32 oracle| {e:.2e} (max-norm, relative to max|oracle|)")
+                assert_close(out[k].cpu(), ref[k], 1e-4, what="C2 f32 " + k)          # north_star's 1e-4 (3e-4 up to round 4)
             continue
         dev = {}
         for k in keys:
