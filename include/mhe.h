@@ -718,13 +718,30 @@ int mhe_dropout_bits(unsigned char *bits, long n, float p_drop, unsigned long lo
  *   their biases likewise;   b0 / b1 [L][2][512];   ainvT [L][64][64], cinv [L][64], const_parts [L] from mhe_glow_affine_f64;
  *   drop_bits [L][2][R * 64] bytes (mhe_dropout_bits' format over [R][512]) or NULL = no dropout.
  * Tape (all NULL, or all given for the train step): v_e, y_e, prm_e f32 [L][R][64] (layer input, coupling output, [shift (T) | us (T) | 0]),
- * tb_e, t2_e, t3_e bf16 [L][2][R][512] (relu(h), dropped second activation, W1 t2 + b1), hf_e bf16 [L][R][512] (the final layer's operand). */
+ * tb_e, t2_e, t3_e bf16 [L][2][R][512] (relu(h), dropped second activation, W1 t2 + b1), hf_e bf16 [L][R][512] (the final layer's operand).
+ * For mhe_glow_reverse_chain_bf16 (all NULL or all given, N % 64 == 0): prmc_e f32 [L][R][128] = [shift | unconstrained scale] in the flow
+ * variable's column order, vb_e bf16 [L][R][64] = the layer input as multiplied, bits_e [L][2][2][R / 64][512] x 8 bytes = [stored value != 0] of
+ * relu(h) / t2 in the accumulator layout. */
 int mhe_glow_layers_supported(int N, int B, int dim, int hidden, int layers, int blocks);
 int mhe_glow_layers_bf16(const float *noise, const float *ctab, int ctab_stride, const void *wxF, const void *w0F, const void *w1F, const void *wsF,
                          const void *wuF, const float *b0, const float *b1, const float *bs, const float *bu, const float *ainvT,
                          const float *cinv, const float *const_parts, const unsigned char *drop_bits, float p_drop, float *out, float *log_q,
-                         float *v_e, float *y_e, float *prm_e, void *tb_e, void *t2_e, void *t3_e, void *hf_e, int N, int B, int dim,
-                         int hidden, int layers, int blocks, long row_n, long row_b, void *stream);
+                         float *v_e, float *y_e, float *prm_e, void *tb_e, void *t2_e, void *t3_e, void *hf_e, float *prmc_e, void *vb_e,
+                         void *bits_e, int N, int B, int dim, int hidden, int layers, int blocks, long row_n, long row_b, void *stream);
+/* The reverse of mhe_glow_layers_bf16: the data-gradient chain of all layers in one launch (csrc/glow_rev.hip; 64 hypotheses per image,
+ * sample-major rows r = n B + b, hidden 512, 2 blocks per layer).  In: g_x [R][dim] = dL / d sample, g_log_p [B] | NULL with q_weight = -1 / K
+ * (dL / d log q[r] = g_log_p[r % B] q_weight), the tape (v_e, prmc_e, t3_e, bits_e of mhe_glow_layers_bf16), ctab (the gates), the weights as bf16
+ * fragment-major TRANSPOSES (wsT / wuT [L][512][64]: row u, k = flow-variable column; w1T / w0T [L][2][512][512] = W^T; wxT [L][64][512] = Wx^T), ainv
+ * [L][64][64] = A^-1.  Out (all written): gv_e f32 [L][R][64] (dL / d layer output: for dA^-1 = gv^T y and dc^-1), gpc_e bf16 [L][R][128] =
+ * [g_shift | g_us] in the flow variable's column order, gt3_e / gt2_e bf16 [L][2][R][512], gh0_e bf16 [L][R][512] (operands of the grouped weight-
+ * gradient launches), and per-image rows: gct [B][ctab_stride] (gradient of ctab: gates and initial-layer context terms), bsum [B][L * 2 * 2 * 512]
+ * (rows of the block bias gradients: [l][blk][b0 | b1]), bfsum [B][L * 128] (rows of the final layer's bias gradient, column order). */
+int mhe_glow_reverse_chain_supported(int R, int B, int dim, int hidden, int layers, int blocks);
+int mhe_glow_reverse_chain_bf16(const float *g_x, const float *g_log_p, float q_weight, const float *v_e, const float *prmc_e, const void *t3_e,
+                                const void *bits_e, const float *ctab, int ctab_stride, const void *wsT, const void *wuT, const void *w1T,
+                                const void *w0T, const void *wxT, const float *ainv, float p_drop, float *gv_e, void *gpc_e, void *gt3_e,
+                                void *gt2_e, void *gh0_e, float *gct, float *bsum, float *bfsum, int R, int B, int dim, int hidden, int layers,
+                                int blocks, void *stream);
 /* The ActNorm + LU re-parameterisation on the device (csrc/glow_affine.hip; nflows transforms.ActNorm / LULinear, oracle/glow_ref.py): one
  * workgroup per layer, float64.  param_ptrs: [layers][6] device pointers (log_scale, shift, lower_entries, upper_entries,
  * unconstrained_upper_diag, bias: f32 tensors of `features`, features (features - 1) / 2 entries in numpy's tril_indices(-1) / triu_indices(1)

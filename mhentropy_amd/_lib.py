@@ -98,7 +98,9 @@ SIGNATURES = {
     "mhe_relu_bwd_add_mixed": (_i, [_p, _p, _p, _l, _i, _i, _p]),
     "mhe_dropout_bits": (_i, [_p, _l, _f, _p, _p]),
     "mhe_glow_layers_supported": (_i, [_i] * 6),
-    "mhe_glow_layers_bf16": (_i, [_p, _p, _i] + [_p] * 13 + [_f] + [_p] * 9 + [_i] * 6 + [_l, _l, _p]),
+    "mhe_glow_layers_bf16": (_i, [_p, _p, _i] + [_p] * 13 + [_f] + [_p] * 12 + [_i] * 6 + [_l, _l, _p]),
+    "mhe_glow_reverse_chain_supported": (_i, [_i] * 6),
+    "mhe_glow_reverse_chain_bf16": (_i, [_p, _p, _f, _p, _p, _p, _p, _p, _i] + [_p] * 6 + [_f] + [_p] * 8 + [_i] * 6 + [_p]),
     "mhe_glow_finish_dev_f32": (_i, [_p, _p, _p, _p, _p, _l, _i, _f, _p, _i, _p]),
     "mhe_glow_affine_workspace_doubles": (_sz, [_i, _i]),
     "mhe_glow_affine_f64": (_i, [_p, _i, _i, _f] + [_p] * 7 + [_p]),

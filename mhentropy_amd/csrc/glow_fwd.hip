@@ -45,6 +45,13 @@ struct Args {
     float *out, *logp;                                    // [R][dim], [R]
     float *v_e, *y_e, *prm_e;                             // EMIT: [L][R][64]
     u16 *tb_e, *t2_e, *t3_e, *hf_e;                       // EMIT: [L][NBLK][R][512] x 3, [L][R][512]
+    // EMIT, for the one-launch reverse chain (csrc/glow_rev.hip; all three or none): the coupling parameters in the flow variable's column order
+    // ([shift' (64) | us' (64)] f32 [L][R][128]), the layer input as the bf16 operand it was multiplied as ([L][R][64]), and the gates of the two
+    // ReLUs of every block as bits in the accumulator layout ([L][NBLK][2: relu(h) > 0 | t2 != 0][R / 64][8 waves][64 lanes] x 64 bits, bit
+    // (unit tile nt * 4 + row tile mt) * 4 + e - the layout flow_fwd.hip / flow_rev.hip use)
+    float *prmc_e;
+    u16 *vb_e;
+    uint2 *bits_e;
     int R, B, N, dim, L, cstride, row_n, row_b;
 };
 
@@ -131,7 +138,15 @@ __global__ __launch_bounds__(512) void layers_kernel(const Args a) {
         if constexpr (EMIT) {
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
-                if (ok[mi]) *reinterpret_cast<v4f *>(a.v_e + ((size_t)l * R + grow[mi]) * 64 + d0) = x[mi];
+                if (ok[mi]) {
+                    *reinterpret_cast<v4f *>(a.v_e + ((size_t)l * R + grow[mi]) * 64 + d0) = x[mi];
+                    if (a.vb_e) {
+                        uint2 o;
+                        o.x = (unsigned)f32_to_bf16(x[mi][0]) | ((unsigned)f32_to_bf16(x[mi][1]) << 16);
+                        o.y = (unsigned)f32_to_bf16(x[mi][2]) | ((unsigned)f32_to_bf16(x[mi][3]) << 16);
+                        *reinterpret_cast<uint2 *>(a.vb_e + ((size_t)l * R + grow[mi]) * 64 + d0) = o;
+                    }
+                }
         }
         v4f acc[4][4], h[4][4];
         // ================= initial layer (K = 64): h = Wx v + ctab[image][slot0]
@@ -212,6 +227,13 @@ __global__ __launch_bounds__(512) void layers_kernel(const Args a) {
                 if (n < a.N) m = *reinterpret_cast<const unsigned long long *>(a.drop + (lb * R + ((size_t)n * rn + (size_t)b * rb)) * 64 + (tid & 7) * 8);
                 mk[tid] = m;
             }
+            uint2 sg = make_uint2(0u, 0u);                // EMIT: [stored value != 0] of this lane's 64 elements
+            auto note = [&](uint2 o, int nt, int mt) __attribute__((always_inline)) {
+                const unsigned b4 = (unsigned)((o.x & 0x7fffu) != 0) | ((unsigned)((o.x & 0x7fff0000u) != 0) << 1) |
+                                    ((unsigned)((o.y & 0x7fffu) != 0) << 2) | ((unsigned)((o.y & 0x7fff0000u) != 0) << 3);
+                if (nt * 4 + mt < 8) sg.x |= b4 << ((nt * 4 + mt) * 4);
+                else sg.y |= b4 << (((nt * 4 + mt) & 7) * 4);
+            };
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -221,8 +243,13 @@ __global__ __launch_bounds__(512) void layers_kernel(const Args a) {
                     o.x = (unsigned)f32_to_bf16(fmaxf(g[0], 0.f)) | ((unsigned)f32_to_bf16(fmaxf(g[1], 0.f)) << 16);
                     o.y = (unsigned)f32_to_bf16(fmaxf(g[2], 0.f)) | ((unsigned)f32_to_bf16(fmaxf(g[3], 0.f)) << 16);
                     *reinterpret_cast<uint2 *>(tile + ac_off[nt] + 2048 * mt) = o;
+                    if constexpr (EMIT) note(o, nt, mt);
                 }
-            if constexpr (EMIT) emit_tile(a.tb_e, lb);
+            if constexpr (EMIT) {
+                emit_tile(a.tb_e, lb);
+                if (a.bits_e) a.bits_e[((lb * 2 + 0) * gridDim.x + blockIdx.x) * 512 + wave * 64 + lane] = sg;
+                sg = make_uint2(0u, 0u);
+            }
             product(a.w0F + lb * H * H);
             // ---- t2 = dropout(relu(acc + b0)) -> the wave's k-tile
             {
@@ -245,10 +272,14 @@ __global__ __launch_bounds__(512) void layers_kernel(const Args a) {
                         o.x = (unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16);
                         o.y = (unsigned)f32_to_bf16(v2) | ((unsigned)f32_to_bf16(v3) << 16);
                         *reinterpret_cast<uint2 *>(tile + ac_off[nt] + 2048 * mt) = o;
+                        if constexpr (EMIT) note(o, nt, mt);
                     }
                 }
             }
-            if constexpr (EMIT) emit_tile(a.t2_e, lb);
+            if constexpr (EMIT) {
+                emit_tile(a.t2_e, lb);
+                if (a.bits_e) a.bits_e[((lb * 2 + 1) * gridDim.x + blockIdx.x) * 512 + wave * 64 + lane] = sg;
+            }
             product(a.w1F + lb * H * H);
             // ---- h += (acc + b1) sigmoid(gate[image])
             {
@@ -345,6 +376,13 @@ __global__ __launch_bounds__(512) void layers_kernel(const Args a) {
                     }
                 }
                 *reinterpret_cast<v4f *>(yb + ((mt3 + mi) * 16 + l15) * YP + d0) = y;
+                if constexpr (EMIT) {
+                    if (a.prmc_e && ok[mi]) {
+                        float *pc = a.prmc_e + ((size_t)l * R + grow[mi]) * 128 + d0;
+                        *reinterpret_cast<v4f *>(pc) = v4f{os[mi][0] + bsa[0], os[mi][1] + bsa[1], os[mi][2] + bsa[2], os[mi][3] + bsa[3]};
+                        *reinterpret_cast<v4f *>(pc + 64) = v4f{ou[mi][0] + bua[0], ou[mi][1] + bua[1], ou[mi][2] + bua[2], ou[mi][3] + bua[3]};
+                    }
+                }
             }
         }
         __syncthreads();                                  // y complete; every wave is through the final layer's reads of the image
@@ -405,8 +443,8 @@ extern "C" int mhe_glow_layers_supported(int N, int B, int dim, int hidden, int 
 extern "C" int mhe_glow_layers_bf16(const float *noise, const float *ctab, int ctab_stride, const void *wxF, const void *w0F, const void *w1F, const void *wsF,
                                     const void *wuF, const float *b0, const float *b1, const float *bs, const float *bu, const float *ainvT,
                                     const float *cinv, const float *const_parts, const unsigned char *drop_bits, float p_drop, float *out, float *log_q,
-                                    float *v_e, float *y_e, float *prm_e, void *tb_e, void *t2_e, void *t3_e, void *hf_e, int N, int B, int dim,
-                                    int hidden, int layers, int blocks, long row_n, long row_b, void *stream) {
+                                    float *v_e, float *y_e, float *prm_e, void *tb_e, void *t2_e, void *t3_e, void *hf_e, float *prmc_e, void *vb_e,
+                                    void *bits_e, int N, int B, int dim, int hidden, int layers, int blocks, long row_n, long row_b, void *stream) {
     MHE_REQUIRE(noise && ctab && wxF && w0F && w1F && wsF && wuF && b0 && b1 && bs && bu && ainvT && cinv && const_parts && out && log_q,
                 "mhe_glow_layers_bf16: null pointer");
     MHE_REQUIRE(mhe_glow_layers_supported(N, B, dim, hidden, layers, blocks),
@@ -418,11 +456,14 @@ extern "C" int mhe_glow_layers_bf16(const float *noise, const float *ctab, int c
     MHE_REQUIRE(R * hidden < (1L << 30), "mhe_glow_layers_bf16: R x hidden beyond the 32-bit byte offsets of the tape rows");
     const bool emit = v_e || y_e || prm_e || tb_e || t2_e || t3_e || hf_e;
     MHE_REQUIRE(!emit || (v_e && y_e && prm_e && tb_e && t2_e && t3_e && hf_e), "mhe_glow_layers_bf16: the tape tensors come together");
+    MHE_REQUIRE((!prmc_e && !vb_e && !bits_e) || (emit && prmc_e && vb_e && bits_e && N % 64 == 0),
+                "mhe_glow_layers_bf16: prmc_e, vb_e and bits_e come together, with the tape, for N %% 64 == 0");
     glowf::Args a;
     a.in = noise; a.ctab = ctab; a.wxF = (const u16 *)wxF; a.w0F = (const u16 *)w0F; a.w1F = (const u16 *)w1F; a.wsF = (const u16 *)wsF; a.wuF = (const u16 *)wuF;
     a.b0 = b0; a.b1 = b1; a.bs = bs; a.bu = bu; a.ainvT = ainvT; a.cinv = cinv; a.const_parts = const_parts;
     a.drop = drop_bits; a.drop_scale = 1.f / (1.f - p_drop); a.out = out; a.logp = log_q;
     a.v_e = v_e; a.y_e = y_e; a.prm_e = prm_e; a.tb_e = (u16 *)tb_e; a.t2_e = (u16 *)t2_e; a.t3_e = (u16 *)t3_e; a.hf_e = (u16 *)hf_e;
+    a.prmc_e = prmc_e; a.vb_e = (u16 *)vb_e; a.bits_e = (uint2 *)bits_e;
     a.R = (int)R; a.B = B; a.N = N; a.dim = dim; a.L = layers; a.cstride = ctab_stride; a.row_n = (int)row_n; a.row_b = (int)row_b;
     const dim3 grid((unsigned)(((N + 63) / 64) * B));
     if (emit) hipLaunchKernelGGL(glowf::layers_kernel<true>, grid, dim3(512), 0, (hipStream_t)stream, a);

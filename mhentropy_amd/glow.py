@@ -219,7 +219,7 @@ class ConditionalGlow(nn.Module):
                                        torch.stack([d["wf"] for d in pk["layers"]]), torch.stack([d["bf"] for d in pk["layers"]]),
                                        st(lambda n: torch.stack([b.linear_layers[0].bias.detach() for b in n.blocks])),
                                        st(lambda n: torch.stack([b.linear_layers[1].bias.detach() for b in n.blocks])), D)
-            pk["fused"] = {k: (v.to(torch.bfloat16) if k.endswith("F") else v.float()).contiguous() for k, v in fp.items()}
+            pk["fused"] = {k: (v.to(torch.bfloat16) if k.endswith("F") else v.float()).contiguous() for k, v in fp.items() if not k.endswith("T")}
         self._pack = (ver, pk)
         return pk
 

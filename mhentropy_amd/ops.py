@@ -1515,7 +1515,12 @@ def glow_fused_layout(wx, w0, w1, wf, bf, b0, b1, dim):
         ws[l, cols], wu[l, cols] = wf[l, :T], wf[l, T:2 * T]
         bs[l, cols], bu[l, cols] = bf[l, :T], bf[l, T:2 * T]
     fr = mfma_fragment_major
-    return {"wxF": torch.stack([fr(wx[l]) for l in range(L)]), "w0F": torch.stack([torch.stack([fr(w0[l, b]) for b in range(2)]) for l in range(L)]),
+    tr = lambda m: m.t().contiguous()
+    rev = {"wsT": torch.stack([fr(tr(ws[l])) for l in range(L)]), "wuT": torch.stack([fr(tr(wu[l])) for l in range(L)]),
+           "w0T": torch.stack([torch.stack([fr(tr(w0[l, b])) for b in range(2)]) for l in range(L)]),
+           "w1T": torch.stack([torch.stack([fr(tr(w1[l, b])) for b in range(2)]) for l in range(L)]),
+           "wxT": torch.stack([fr(tr(wx[l])) for l in range(L)])}                       # operands of the reverse chain (mhe_glow_reverse_chain_bf16)
+    return {**rev, "wxF": torch.stack([fr(wx[l]) for l in range(L)]), "w0F": torch.stack([torch.stack([fr(w0[l, b]) for b in range(2)]) for l in range(L)]),
             "w1F": torch.stack([torch.stack([fr(w1[l, b]) for b in range(2)]) for l in range(L)]),
             "wsF": torch.stack([fr(ws[l]) for l in range(L)]), "wuF": torch.stack([fr(wu[l]) for l in range(L)]),
             "bs": bs, "bu": bu, "b0": b0.contiguous(), "b1": b1.contiguous()}
@@ -1548,5 +1553,34 @@ def glow_layers(noise, ctab, fp, aff, drop_bits, p_drop, N, B, dim, row_n, row_b
                                           _ptr(fp["wuF"]), _ptr(fp["b0"]), _ptr(fp["b1"]), _ptr(fp["bs"]), _ptr(fp["bu"]), _ptr(aff["AinvT"]),
                                           _ptr(aff["cinv"]), _ptr(aff["const_parts"]), _ptr(drop_bits), float(p_drop), _ptr(out), _ptr(logq),
                                           _ptr(t.get("v")), _ptr(t.get("y")), _ptr(t.get("prm")), _ptr(t.get("tb")), _ptr(t.get("t2")), _ptr(t.get("t3")),
-                                          _ptr(t.get("hf")), N, B, dim, 512, L, 2, row_n, row_b, _stream()), "mhe_glow_layers_bf16")
+                                          _ptr(t.get("hf")), _ptr(t.get("prmc")), _ptr(t.get("vb")), _ptr(t.get("bits")), N, B, dim, 512, L, 2, row_n, row_b,
+                                          _stream()), "mhe_glow_layers_bf16")
     return out, logq
+
+
+def glow_reverse_chain_supported(R, B, dim, hidden, layers, blocks):
+    return bool(_lib.lib().mhe_glow_reverse_chain_supported(R, B, dim, hidden, layers, blocks))
+
+
+def glow_reverse_chain(g_x, g_logp, q_weight, tape, ctab, fp, aff, p_drop, out, B, dim):
+    """the data-gradient chain of the conditional Glow's sampling direction in one launch (mhe_glow_reverse_chain_bf16) over the tape of
+    glow_layers (v, prmc, t3, bits).  out: dict(gv f32 [L,R,64]; gpc bf16 [L,R,128]; gt3, gt2 bf16 [L,2,R,512]; gh0 bf16 [L,R,512];
+    gct f32 [B,cs]; bsum f32 [B, L*2*2*512]; bfsum f32 [B, L*128]) - all written"""
+    R = g_x.shape[0]
+    L = tape["v"].shape[0]
+    _chk(g_x, torch.float32, "glow_reverse_chain.g_x", (R, dim))
+    for k, dt, shp in (("v", torch.float32, (L, R, 64)), ("prmc", torch.float32, (L, R, 128)), ("t3", torch.bfloat16, (L, 2, R, 512))):
+        _chk(tape[k], dt, "glow_reverse_chain.tape." + k, shp)
+    _chk(tape["bits"], torch.int32, "glow_reverse_chain.tape.bits", (L, 2, 2, B, 512, 2))
+    for k, dt, shp in (("gv", torch.float32, (L, R, 64)), ("gpc", torch.bfloat16, (L, R, 128)), ("gt3", torch.bfloat16, (L, 2, R, 512)),
+                       ("gt2", torch.bfloat16, (L, 2, R, 512)), ("gh0", torch.bfloat16, (L, R, 512)), ("gct", torch.float32, (B, ctab.shape[1])),
+                       ("bsum", torch.float32, (B, L * 2 * 2 * 512)), ("bfsum", torch.float32, (B, L * 128))):
+        _chk(out[k], dt, "glow_reverse_chain.out." + k, shp)
+    for k in ("wsT", "wuT", "w1T", "w0T", "wxT"):
+        _chk(fp[k], torch.bfloat16, "glow_reverse_chain." + k)
+    check(_lib.lib().mhe_glow_reverse_chain_bf16(_ptr(g_x), _ptr(g_logp), float(q_weight), _ptr(tape["v"]), _ptr(tape["prmc"]), _ptr(tape["t3"]),
+                                                 _ptr(tape["bits"]), _ptr(ctab), ctab.shape[1], _ptr(fp["wsT"]), _ptr(fp["wuT"]), _ptr(fp["w1T"]),
+                                                 _ptr(fp["w0T"]), _ptr(fp["wxT"]), _ptr(aff["Ainv"]), float(p_drop), _ptr(out["gv"]), _ptr(out["gpc"]),
+                                                 _ptr(out["gt3"]), _ptr(out["gt2"]), _ptr(out["gh0"]), _ptr(out["gct"]), _ptr(out["bsum"]),
+                                                 _ptr(out["bfsum"]), R, B, dim, 512, L, 2, _stream()), "mhe_glow_reverse_chain_bf16")
+    return out

@@ -34,6 +34,7 @@ SWITCHES = {
     "MHE_FLOW_FRAG": ("1", "flows.py, train.py", "0: second-generation coupling-stack kernel (flow_ns.hip) instead of the fragment-streaming one"),
     "MHE_FLOW_W1_SETS": ("2", "csrc/flow_fwd.hip", "3: a third register set of layer-1 weight fragments (measured equal)"),
     "MHE_GLOW_FUSED": ("1", "glow.py, train_glow.py", "0: the Glow branch's sampling pass layer by layer (~60 launches) instead of the one-launch kernel"),
+    "MHE_GLOW_REV_FUSED": ("1", "train_glow.py", "0: the Glow branch's reverse pass over the tape stage by stage instead of the one-launch chain (csrc/glow_rev.hip)"),
     "MHE_MANO_FOUR": ("1", "csrc/mano.hip", "0: one hypothesis per wavefront"),
     # ---- train step (train.py / csrc/wgrad.hip, trunk_bwd.hip)
     "MHE_TRAIN_RECOMPUTE": ("1", "train.py", "0: conv3 of layer1 / layer2 written by the train step's forward pass"),

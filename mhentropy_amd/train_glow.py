@@ -40,6 +40,8 @@ class GlowPart:
         # the residual blocks' gradients in (layer, block) order, one pitch apart: what the grouped weight-gradient launches and the single
         # bias column sum of the fused reverse pass write ([L NB][H][H] x 2; [L NB][b0 | b1][H])
         self.raw_w0, self.raw_w1, self.raw_bias = ts._raw_slot((L * NB * H * H,)), ts._raw_slot((L * NB * H * H,)), ts._raw_slot((L * NB * 2 * H,))
+        # ... and the initial / final layers' ([L][H][64], [L][64][H], [L][64]): the one-launch reverse chain's grouped launches write [L]-strided
+        self.raw_wx, self.raw_wf, self.raw_bf = ts._raw_slot((L * H * 64,)), ts._raw_slot((L * 64 * H,)), ts._raw_slot((L * 64,))
         for l in range(L):
             an, lu, cp = T[3 * l], T[3 * l + 1], T[3 * l + 2]
             net = cp.transform_net
@@ -52,7 +54,7 @@ class GlowPart:
                 d["r_" + name] = ts._raw_slot(p.shape)
                 ts._map_grad(p, ar(p.numel()).view(p.shape) + d["r_" + name])
             d["r_ainv"], d["r_cinv"] = ts._raw_slot((64, 64)), ts._raw_slot((64,))
-            d["r_wx"], d["r_wf"], d["r_bf"] = ts._raw_slot((H, 64)), ts._raw_slot((64, H)), ts._raw_slot((64,))
+            d["r_wx"], d["r_wf"], d["r_bf"] = self.raw_wx + l * H * 64, self.raw_wf + l * 64 * H, self.raw_bf + l * 64
             s0 = l * self.per
             wi = torch.empty(H, nid + Fc, dtype=torch.int64)
             wi[:, :nid] = (ar(H * 64).view(H, 64) + d["r_wx"])[:, idf]
@@ -118,7 +120,17 @@ class GlowPart:
                                        torch.stack([d["wfi"] for d in self.layers]), torch.stack([d["bfi"] for d in self.layers]),
                                        st(lambda n: torch.stack([pi(b.linear_layers[0].bias) for b in n.blocks])),
                                        st(lambda n: torch.stack([pi(b.linear_layers[1].bias) for b in n.blocks])), D)
-            self.fused = {k: ts._derived(v.contiguous(), torch.bfloat16 if k.endswith("F") else torch.float32) for k, v in fp.items()}
+            self.fused = {k: ts._derived(v.contiguous(), torch.bfloat16 if (k.endswith("F") or k.endswith("T")) else torch.float32) for k, v in fp.items()}
+            # the final layer's rows move to the flow variable's columns in the chain's [g_shift | g_us] gradient: row c of the first / second half
+            # is the shift / scale row of transform column c -> back to nflows' [shift (T) | scale (T)] rows by one index_select per step
+            perm = torch.zeros(L, 64, dtype=torch.int64)
+            for l in range(L):
+                first = 1 - (l & 1)
+                T_ = D // 2 if first else (D + 1) // 2
+                cols = torch.arange(first, D, 2)
+                perm[l, :T_], perm[l, T_:2 * T_] = cols, 64 + cols
+                perm[l, 2 * T_:] = 63                          # (a zero row of the first half: columns >= dim are never transform columns)
+            self._wf_perm = (perm + 128 * torch.arange(L)[:, None]).reshape(-1).to(ts.dev)
         glow._external_pack = self.module_pack
 
     # ------------------------------------------------------------------ the 45x45 affine maps (float64 on the device, tiny)
@@ -158,8 +170,13 @@ class GlowPart:
         tape = {"v": ts._buf("glow_v", (L, R, 64)), "y": ts._buf("glow_y", (L, R, 64)), "prm": ts._buf("glow_prm", (L, R, 64)),
                 "tb": ts._buf("glow_tb", (L, NB, R, H), bf), "t2": ts._buf("glow_t2", (L, NB, R, H), bf), "t3": ts._buf("glow_t3", (L, NB, R, H), bf),
                 "hf": ts._buf("glow_hf", (L, R, H), bf)}
+        import os
+        chain = (os.environ.get("MHE_GLOW_REV_FUSED", "1") == "1" and ops.glow_reverse_chain_supported(R, B, D, H, L, NB))
+        if chain:           # what the one-launch reverse chain reads besides t3: parameters in column order, the bf16 layer input, the ReLU gates as bits
+            tape.update({"prmc": ts._buf("glow_prmc", (L, R, 128)), "vb": ts._buf("glow_vb", (L, R, 64), bf),
+                         "bits": ts._buf("glow_bits", (L, NB, 2, B, 512, 2), torch.int32)})
         x, logq = ops.glow_layers(z0, ctab, self.fused, self.aff, bits, g.p_drop, R // B, B, D, B, 1, tape=tape)
-        self._tp = {"fused": tape, "bits": bits, "ctab": ctab, "feat": feat}
+        self._tp = {"fused": tape, "bits": bits, "ctab": ctab, "feat": feat, "chain": chain}
         return x, logq
 
     def forward(self, z0, feat):
@@ -213,6 +230,38 @@ class GlowPart:
         return x, logq
 
     # ------------------------------------------------------------------ reverse pass
+    def _backward_chain(self, g_x, g_logp, N, B):
+        """the reverse pass with the data-gradient chain of all layers in ONE launch (mhe_glow_reverse_chain_bf16, csrc/glow_rev.hip): what is
+        left around it are the weight gradients - grouped launches over the tape and the chain's outputs as they lie ([L]- / [L, 2]-strided) -,
+        the 45 x 45 products for dA^-1, the column sums of the per-image rows and the float64 re-parameterisation kernel"""
+        ts, g = self.ts, self.g
+        D, H, R, L, NB = g.features, g.hidden, g_x.shape[0], g.num_layers, g.num_blocks
+        tp = self._tp
+        ft, ctab = tp["fused"], tp["ctab"]
+        raw, cs, bf = ts._raw, ctab.shape[1], torch.bfloat16
+        out = {"gv": ts._buf("glow_gv", (L, R, 64)), "gpc": ts._buf("glow_gpc", (L, R, 128), bf), "gt3": ts._buf("glow_gt3", (L, NB, R, H), bf),
+               "gt2": ts._buf("glow_gt2", (L, NB, R, H), bf), "gh0": ts._buf("glow_gh0", (L, R, H), bf), "gct": ts._buf("glow_Gct", (B, cs)),
+               "bsum": ts._buf("glow_bsum", (B, L * NB * 2 * H)), "bfsum": ts._buf("glow_bfsum", (B, L * 128))}
+        ops.glow_reverse_chain(g_x, g_logp, -1.0 / N, ft, ctab, self.fused, self.aff, g.p_drop if tp["bits"] is not None else 0.0, out, B, D)
+        for l in range(L):          # dA^-1 = gv^T y, dc^-1 = sum gv (f32: they feed the float64 re-parameterisation)
+            rs = self.layers[l]
+            ops.linear_wgrad(ft["y"][l], out["gv"][l], raw(rs["r_ainv"], (64, 64))); ops.colsum(out["gv"][l], raw(rs["r_cinv"], (64,)))
+        ops.conv_wgrad_batched(ft["t2"].view(L * NB, R, H), out["gt3"].view(L * NB, R, H), raw(self.raw_w1, (H, H)), H * H, L * NB)
+        ops.conv_wgrad_batched(ft["tb"].view(L * NB, R, H), out["gt2"].view(L * NB, R, H), raw(self.raw_w0, (H, H)), H * H, L * NB)
+        ops.conv_wgrad_batched(ft["vb"], out["gh0"], raw(self.raw_wx, (H, 64)), H * 64, L)                      # dWx[l] = gh0^T v   [H, 64]
+        wfp = ts._buf("glow_wfp", (L * 128, H)); wfp.zero_()
+        ops.conv_wgrad_batched(ft["hf"], out["gpc"], wfp[:128], 128 * H, L)                                     # [g_shift | g_us]^T h  [128, H] per layer
+        torch.index_select(wfp, 0, self._wf_perm, out=raw(self.raw_wf, (L * 64, H)))                            # -> nflows' [shift | scale] rows
+        bfp = ts._buf("glow_bfp", (L * 128,)); bfp.zero_()
+        ops.colsum(out["bfsum"], bfp)
+        torch.index_select(bfp, 0, self._wf_perm, out=raw(self.raw_bf, (L * 64,)))
+        ops.colsum(out["bsum"], raw(self.raw_bias, (L * NB * 2 * H,)))
+        Gct = out["gct"]
+        ops.linear_wgrad(tp["feat"], Gct, raw(self.raw_wctx, (cs, g.context_features))); ops.colsum(Gct, raw(self.raw_bctx, (cs,)))
+        g_feat = ops.linear(Gct, self.wctxT)
+        self._reparam_backward(g_logp)
+        return g_feat
+
     def _backward_fused(self, g_x, g_logp, N, B):
         """the reverse pass over the one-launch kernel's tape: per layer the small stages as before, per residual block two products on bf16
         MFMA and three per-image kernels (gate / dropout + ReLU reverse with the per-image sums inside, csrc/glow.hip); the 16 hidden x hidden
@@ -274,6 +323,8 @@ class GlowPart:
         """g_x (R,45) = dL/d sample, g_logp (B,) = dL/d log_p per image (None: no entropy term).  Writes every Glow
         parameter's gradient into the trainer's raw arena and returns dL/d feat (B, F) through the context terms."""
         if self._tp.get("fused") is not None and self.mixed:
+            if self._tp.get("chain"):
+                return self._backward_chain(g_x, g_logp, N, B)
             return self._backward_fused(g_x, g_logp, N, B)
         ts, g = self.ts, self.g
         L_, D, H, R = _lib.lib(), g.features, g.hidden, g_x.shape[0]

@@ -306,3 +306,51 @@ def test_glow_one_launch_sampling_kernel(gpu_lib, B, N, layout, train, monkeypat
     print(f"one-launch Glow vs f32 oracle: x {e_x:.2e} lp {e_lp:.2e}; vs the layer-by-layer bf16 path: x {d_x:.2e} lp {d_lp:.2e} (that path vs oracle: x {u_x:.2e})")
     assert_close(x1, x_ref, 2e-2, what="samples vs oracle"); assert_close(lp1, lp_ref, 2e-2, what="log q vs oracle")
     assert_close(x1, x0, 1e-2, what="samples vs the layer-by-layer bf16 path"); assert_close(lp1, lp0, 1e-2, what="log q vs the layer-by-layer bf16 path")
+
+
+def test_glow_one_launch_reverse_chain_equals_the_staged_reverse(gpu_lib, monkeypatch):
+    """csrc/glow_rev.hip (round 5): the data-gradient chain of all four layers in one launch (64 hypotheses per image, bf16 mode) against the
+    stage-by-stage reverse over the same tape (MHE_GLOW_REV_FUSED=0: per-image kernels + conv2d products, f32 on the 45 / 64-wide layers):
+    the same dropout masks, the same forward values, every Glow parameter gradient and dL / d feat to bf16 rounding of the 64-wide products
+    (norm-wise per tensor); and the train step through it moves the parameters."""
+    from mhentropy_amd import harness, ops
+    from mhentropy_amd.network import MHEnt
+    from mhentropy_amd.train import TrainStep
+    B, N = 6, 64
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MHE_GLOW_REV_FUSED", mode)
+        special, common = harness.mhent_cfgs(backbone="resnet18", tables=synth.mano_tables(0))
+        special["q_z_giv_i_model"] = "glow"
+        model = MHEnt(special, **common)
+        model.q_z_giv_i.load_state_dict({k: torch.as_tensor(v) for k, v in synth.glow_state(3).items()}, strict=False)
+        model.load_state_dict({k: torch.as_tensor(v) for k, v in synth.head_state(4, 512).items()}, strict=False)
+        model.q_z_giv_i.compute_dtype = torch.bfloat16
+        model = model.cuda().train()
+        _, yn = synth.batch(5, B, with_image=False)
+        y = {k: torch.as_tensor(v).cuda() for k, v in yn.items()}
+        f = torch.as_tensor(np.random.default_rng(6).normal(0, 0.5, (B, 512)).astype(np.float32)).cuda()
+        noise = torch.as_tensor(np.random.default_rng(7).normal(0, 1, (N * B, 45)).astype(np.float32)).cuda()
+        ts = TrainStep(model)
+        flow = model.q_z_giv_i
+        if "masks" in res:
+            flow.mask_feed = [m.clone() for m in res["masks"]]
+        else:
+            ops.rng_state(torch.device("cuda", torch.cuda.current_device()), seed=17)
+            flow.record_masks, flow.last_masks = True, []
+        out = ts.forward_backward(None, y, noise=noise, N=N, trunk_out=f)
+        assert bool(ts.glow._tp.get("chain")) == (mode == "1")
+        if "masks" not in res:
+            res["masks"] = list(flow.last_masks)
+        res[mode] = (out["log_p"].cpu(), {n: ts.grad_of(p).cpu().double().clone() for n, p in model.named_parameters()}, ts.tape["g_feat"].cpu().double())
+        if mode == "1":
+            p0 = ts.P.clone()
+            ts.optimizer_step()
+            assert torch.isfinite(ts.P).all() and (ts.P - p0).abs().max() > 1e-5
+    assert torch.equal(res["1"][0], res["0"][0])                       # the same forward
+    rel = lambda a, b_: float((a - b_).norm() / (b_.norm() + 1e-30))
+    assert rel(res["1"][2], res["0"][2]) < 1e-2, rel(res["1"][2], res["0"][2])
+    rows = sorted(((rel(g, res["0"][1][n]), n) for n, g in res["1"][1].items() if n.startswith("q_z_giv_i") and res["0"][1][n].norm() > 0), reverse=True)
+    print("one-launch reverse chain vs staged reverse, worst per-tensor relative L2:", rows[:4], "median", rows[len(rows) // 2])
+    assert len(rows) >= 4 * (6 + 2 + 2 * 6 + 2)
+    assert rows[0][0] < 3e-2 and rows[len(rows) // 2][0] < 1e-2, rows[:6]
