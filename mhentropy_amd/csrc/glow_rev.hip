@@ -86,14 +86,11 @@ __global__ __launch_bounds__(512) void chain_kernel(const Args a) {
     };
     // sum over the image's 64 rows of the wave's [4 unit tiles][4 row tiles] x 4 values: in-lane over the row tiles, DPP over the 16 rows of a tile;
     // the lanes l15 == 0 store unit 64 wave + 16 nt + 4 q + e
-    auto store_colsum = [&](float *dst, const float (&sv)[4][4]) __attribute__((always_inline)) {
+    auto store_colsum = [&](float *dst, int nt, const float (&sv)[4]) __attribute__((always_inline)) {
+        v4f o;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            v4f o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = row16_sum(sv[nt][e]);
-            if (l15 == 0) *reinterpret_cast<v4f *>(dst + 64 * wave + 16 * nt + 4 * q) = o;
-        }
+        for (int e = 0; e < 4; ++e) o[e] = row16_sum(sv[e]);
+        if (l15 == 0) *reinterpret_cast<v4f *>(dst + 64 * wave + 16 * nt + 4 * q) = o;
     };
 
     for (int l = 0; l < a.L; ++l) {
@@ -239,7 +236,6 @@ __global__ __launch_bounds__(512) void chain_kernel(const Args a) {
 #pragma unroll 1
         for (int blk = NBLK - 1; blk >= 0; --blk) {
             const size_t lb = (size_t)l * NBLK + blk;
-            const uint2 bt_h = a.bits_e[((lb * 2 + 0) * B + b) * 512 + wave * 64 + lane], bt_2 = a.bits_e[((lb * 2 + 1) * B + b) * 512 + wave * 64 + lane];
             // t3 of this block: whole rows into the wave's k-tile, then read back in the accumulator layout
             {
                 const rsrc_t tr = rsrc_of(a.t3_e + lb * (size_t)R * H, hbytes);
@@ -254,14 +250,12 @@ __global__ __launch_bounds__(512) void chain_kernel(const Args a) {
                 sg[nt].x = 1.f / (1.f + expf(-sg[nt].x)); sg[nt].y = 1.f / (1.f + expf(-sg[nt].y));
                 sg[nt].z = 1.f / (1.f + expf(-sg[nt].z)); sg[nt].w = 1.f / (1.f + expf(-sg[nt].w));
             }
-            float sgate[4][4], sbias[4][4];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sgate[nt][e] = sbias[nt][e] = 0.f;
+            float *const gct_row = a.gct + (size_t)b * a.cstride + (size_t)(slot0 + 1 + blk) * H;
+            float *const bs_row = a.bsum + (size_t)b * (a.L * NBLK * 2 * H) + 2 * lb * H;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const float sv[4] = {sg[nt].x, sg[nt].y, sg[nt].z, sg[nt].w};
+                float sgate[4] = {0.f, 0.f, 0.f, 0.f}, sbias[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     const uint2 tq = *reinterpret_cast<const uint2 *>(tile + ac_off[nt] + 2048 * mt);
@@ -270,8 +264,8 @@ __global__ __launch_bounds__(512) void chain_kernel(const Args a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float g = gh[nt][mt][e];
-                        sgate[nt][e] = fmaf(g, t3[e], sgate[nt][e]);
-                        sbias[nt][e] += g;
+                        sgate[e] = fmaf(g, t3[e], sgate[e]);
+                        sbias[e] += g;
                         g3[e] = g * sv[e];
                     }
                     uint2 o;
@@ -280,19 +274,17 @@ __global__ __launch_bounds__(512) void chain_kernel(const Args a) {
                     *reinterpret_cast<uint2 *>(tile + ac_off[nt] + 2048 * mt) = o;      // (same lane reads and writes this 8-byte slot)
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { sgate[nt][e] *= sv[e] * (1.f - sv[e]); sbias[nt][e] *= sv[e]; }
+                for (int e = 0; e < 4; ++e) { sgate[e] *= sv[e] * (1.f - sv[e]); sbias[e] *= sv[e]; }
+                store_colsum(gct_row, nt, sgate);
+                store_colsum(bs_row + H, nt, sbias);
             }
-            store_colsum(a.gct + (size_t)b * a.cstride + (size_t)(slot0 + 1 + blk) * H, sgate);
-            store_colsum(a.bsum + (size_t)b * (a.L * NBLK * 2 * H) + (2 * lb + 1) * H, sbias);
             emit_tile(a.gt3_e, lb);
             product(a.w1T + lb * H * H);
             // g_t2 = (g_t3 W1) [t2 != 0] / (1 - p)
+            const uint2 bt_2 = a.bits_e[((lb * 2 + 1) * B + b) * 512 + wave * 64 + lane];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sbias[nt][e] = 0.f;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < 4; ++nt) {
+                float sbias[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     const int idx = (nt * 4 + mt) * 4;
@@ -304,13 +296,15 @@ __global__ __launch_bounds__(512) void chain_kernel(const Args a) {
                     o.x = (unsigned)f32_to_bf16(g2[0]) | ((unsigned)f32_to_bf16(g2[1]) << 16);
                     o.y = (unsigned)f32_to_bf16(g2[2]) | ((unsigned)f32_to_bf16(g2[3]) << 16);
                     *reinterpret_cast<uint2 *>(tile + ac_off[nt] + 2048 * mt) = o;
-                    sbias[nt][0] += __uint_as_float(o.x << 16); sbias[nt][1] += __uint_as_float(o.x & 0xffff0000u);
-                    sbias[nt][2] += __uint_as_float(o.y << 16); sbias[nt][3] += __uint_as_float(o.y & 0xffff0000u);
+                    sbias[0] += __uint_as_float(o.x << 16); sbias[1] += __uint_as_float(o.x & 0xffff0000u);
+                    sbias[2] += __uint_as_float(o.y << 16); sbias[3] += __uint_as_float(o.y & 0xffff0000u);
                 }
-            store_colsum(a.bsum + (size_t)b * (a.L * NBLK * 2 * H) + (2 * lb) * H, sbias);
+                store_colsum(bs_row, nt, sbias);
+            }
             emit_tile(a.gt2_e, lb);
             product(a.w0T + lb * H * H);
             // gh += (g_t2 W0) [relu(h) > 0]
+            const uint2 bt_h = a.bits_e[((lb * 2 + 0) * B + b) * 512 + wave * 64 + lane];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -323,13 +317,9 @@ __global__ __launch_bounds__(512) void chain_kernel(const Args a) {
         }
         // ---- (6) gh at the initial layer: its per-image sums (the context term's gradient), bf16 -> image + out
         {
-            float sv[4][4];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sv[nt][e] = 0.f;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < 4; ++nt) {
+                float sv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     const v4f g = gh[nt][mt];
@@ -337,9 +327,10 @@ __global__ __launch_bounds__(512) void chain_kernel(const Args a) {
                     o.x = (unsigned)f32_to_bf16(g[0]) | ((unsigned)f32_to_bf16(g[1]) << 16);
                     o.y = (unsigned)f32_to_bf16(g[2]) | ((unsigned)f32_to_bf16(g[3]) << 16);
                     *reinterpret_cast<uint2 *>(tile + ac_off[nt] + 2048 * mt) = o;
-                    sv[nt][0] += g[0]; sv[nt][1] += g[1]; sv[nt][2] += g[2]; sv[nt][3] += g[3];
+                    sv[0] += g[0]; sv[1] += g[1]; sv[2] += g[2]; sv[3] += g[3];
                 }
-            store_colsum(a.gct + (size_t)b * a.cstride + (size_t)slot0 * H, sv);
+                store_colsum(a.gct + (size_t)b * a.cstride + (size_t)slot0 * H, nt, sv);
+            }
             emit_tile(a.gh0_e, (size_t)l);
         }
         // ---- (7) gv' = g_v(coupling) + gh Wx (K = 512 -> 64)
