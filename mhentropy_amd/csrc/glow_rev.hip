@@ -200,14 +200,15 @@ __global__ __launch_bounds__(512) void chain_kernel(const Args a) {
         }
         auto product = [&](const u16 *wbase) __attribute__((always_inline)) {
             const rsrc_t w1 = rsrc_of(wbase, (size_t)H * H * 2);
-            uint4 fS[2][2][4];
-            auto fetch_w = [&](uint4 (&f)[2][4], int kt) __attribute__((always_inline)) {
+            // the residual gradient gh (64 VGPRs) stays live across this product: the weight fragments are fetched ONE 32-deep k step ahead in
+            // three rotating sets of 4 (48 VGPRs, two steps in flight) instead of flow_fwd.hip's two sets of 8 (64 VGPRs)
+            uint4 fS[3][4];
+            auto fetch_w = [&](uint4 (&f)[4], int ks) __attribute__((always_inline)) {
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) f[kk][nt] = frag(w1, lane16, 4 * wave + nt, 16, 2 * kt + kk);
+                for (int nt = 0; nt < 4; ++nt) f[nt] = frag(w1, lane16, 4 * wave + nt, 16, ks);
             };
             fetch_w(fS[0], 0);
+            fetch_w(fS[1], 1);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -215,19 +216,16 @@ __global__ __launch_bounds__(512) void chain_kernel(const Args a) {
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();                              // the operand image is complete
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                if (kt + 1 < KT) fetch_w(fS[(kt + 1) & 1], kt + 1);
+            for (int ks = 0; ks < 2 * KT; ++ks) {
+                if (ks + 2 < 2 * KT) fetch_w(fS[(ks + 2) % 3], ks + 2);
                 __builtin_amdgcn_sched_barrier(0);
+                uint4 fa[4];
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    uint4 fa[4];
+                for (int mt = 0; mt < 4; ++mt) fa[mt] = *reinterpret_cast<const uint4 *>(actb + fa_off[ks & 1] + (8192 * (ks >> 1) + 2048 * mt));
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) fa[mt] = *reinterpret_cast<const uint4 *>(actb + fa_off[kk] + (8192 * kt + 2048 * mt));
+                for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mfma(fS[kt & 1][kk][nt], fa[mt], acc[nt][mt]);
-                }
+                    for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mfma(fS[ks % 3][nt], fa[mt], acc[nt][mt]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();                              // every wave has read the image
