@@ -1220,6 +1220,7 @@ class TrainStep:
         m, t = self.model, self.tape
         N, B, f, feat, hd, det, cond, th45 = t["N"], t["B"], t["f"], t["feat"], t["hd"], t["det"], t["cond"], t["th45"]
         hs, B_own, N_all = t.get("hs"), t.get("B_own", B), t.get("N_all", N)
+        self._wq = []                   # (a reverse pass that raised half way must not leave its queued weight gradients to the next one)
         self.raw.zero_()
         g_logp = self._buf("g_logp", (B,))
         if g_log_p is None:
