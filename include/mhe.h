@@ -562,8 +562,9 @@ int mhe_conv3x3_halo_dgrad_bn_nhwc(int B, int H, int W, int Cin, int Cout, const
                                    void *gx, void *gy_out, const void *residual, const void *mask, const void *bn_y0,
                                    const float *bn_mean_invstd0, mhe_stat_t *bn_stats0, void *stream);
 int mhe_flow_reverse_chain_supported(int R, int B, int dim, int hidden, int ncoup);
-/* mhe_flow_couplings_bf16 / _emit on the fragment-streaming skeleton (csrc/flow_fwd.hip): hidden 512, a multiple of 64 hypotheses per
- * image (R % (64 B) == 0; a workgroup = 64 rows of one image), at most 32 couplings.  Same results as mhe_flow_couplings_bf16 up to the
+/* mhe_flow_couplings_bf16 / _emit on the fragment-streaming skeleton (csrc/flow_fwd.hip): hidden 512, R % B == 0 (a workgroup = 64 rows
+ * of one image; a last chunk of fewer rows computes on zeros and stores nothing for them - the metrics pass' N = 200; the form WITH h1, h2, o
+ * needs R % (64 B) == 0), at most 32 couplings.  Same results as mhe_flow_couplings_bf16 up to the
  * order of the f32 accumulation.  w0F, w1F, w2F = net 0's W0 [512][64 (dim zero-padded)], W1 [512][512], W2 [64 (padded)][512] as bf16 in
  * FRAGMENT-MAJOR order (see mhe_flow_reverse_chain_bf16), net k at + k * w_net_stride elements; cond [B][cond_stride] with column
  * (2 net + layer) * 512 + unit; bias2 [nets][64].  h1, h2, o: all three or none - the activations the reverse pass reads

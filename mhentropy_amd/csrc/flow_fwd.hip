@@ -65,9 +65,17 @@ __global__ __launch_bounds__(512) void couplings_frag_kernel(const Args a) {
     const unsigned co = (unsigned)((((64 * chunk + r8) * B + b) * H + 64 * wave + c8 * 8) * 2);       // EMIT: 16-byte row pieces (bytes)
     const unsigned cstep = (unsigned)(8 * B * H) * 2u;
     const size_t hbytes = (size_t)R * H * 2;
+    // hypotheses per image need not be a multiple of 64 in the forward-only form (round 5: the metrics pass draws N = 200): the last chunk's
+    // surplus rows are computed on zeros and never stored (csrc/glow_fwd.hip does the same)
+    const int Nh = R / B;
     int grow[2];                                          // global rows of this lane's two flow-variable rows
+    bool ok[2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) grow[mi] = (64 * chunk + (mt3 + mi) * 16 + l15) * B + b;
+    for (int mi = 0; mi < 2; ++mi) {
+        const int n = 64 * chunk + (mt3 + mi) * 16 + l15;
+        ok[mi] = n < Nh;
+        grow[mi] = ok[mi] ? n * B + b : b;
+    }
 
     for (int i = tid; i < a.ncoup * 64; i += 512) mk[i] = (i & 63) < dim ? a.mask[(i >> 6) * dim + (i & 63)] : 1.f;
     v4f x[2];
@@ -76,7 +84,7 @@ __global__ __launch_bounds__(512) void couplings_frag_kernel(const Args a) {
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            x[mi][e] = d0 + e < dim ? a.in[(size_t)grow[mi] * dim + d0 + e] : 0.f;
+            x[mi][e] = (ok[mi] && d0 + e < dim) ? a.in[(size_t)grow[mi] * dim + d0 + e] : 0.f;
             sq_in[mi] = fmaf(x[mi][e], x[mi][e], sq_in[mi]);
         }
     __syncthreads();                                      // masks staged
@@ -256,7 +264,7 @@ __global__ __launch_bounds__(512) void couplings_frag_kernel(const Args a) {
         float so = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if (d0 + e < dim) a.out[(size_t)grow[mi] * dim + d0 + e] = x[mi][e];
+            if (ok[mi] && d0 + e < dim) a.out[(size_t)grow[mi] * dim + d0 + e] = x[mi][e];
             so = fmaf(x[mi][e], x[mi][e], so);
         }
         sq[mi] = a.inverse ? so : sq_in[mi];
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(512) void couplings_frag_kernel(const Args a) {
         if (q == 0) { red[0][nt3][(mt3 + mi) * 16 + l15] = sq[mi]; red[1][nt3][(mt3 + mi) * 16 + l15] = sum_s[mi]; }
     }
     __syncthreads();
-    if (tid < ROWS) {
+    if (tid < ROWS && 64 * chunk + tid < Nh) {
         const int r = (64 * chunk + tid) * B + b;
         const float s2 = red[0][0][tid] + red[0][1][tid] + red[0][2][tid] + red[0][3][tid];
         const float ss = red[1][0][tid] + red[1][1][tid] + red[1][2][tid] + red[1][3][tid];
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(512) void couplings_frag_kernel(const Args a) {
 using namespace mhe;
 
 extern "C" int mhe_flow_couplings_frag_supported(int R, int B, int dim, int hidden, int ncoup) {
-    return R > 0 && B > 0 && R % (64 * B) == 0 && dim > 0 && dim <= 64 && hidden == 512 && ncoup > 0 && ncoup <= flowfwd::MAXC;
+    return R > 0 && B > 0 && R % B == 0 && dim > 0 && dim <= 64 && hidden == 512 && ncoup > 0 && ncoup <= flowfwd::MAXC;
 }
 
 extern "C" int mhe_flow_couplings_frag_bf16(const float *in, float *out, const float *cond, int cond_stride, const void *w0F, const void *w1F,
@@ -289,13 +297,14 @@ extern "C" int mhe_flow_couplings_frag_bf16(const float *in, float *out, const f
                                             int ncoup, int direction, void *stream) {
     MHE_REQUIRE(in && out && cond && w0F && w1F && w2F && bias2 && mask, "mhe_flow_couplings_frag_bf16: null pointer");
     MHE_REQUIRE(mhe_flow_couplings_frag_supported(R, B, dim, hidden, ncoup),
-                "mhe_flow_couplings_frag_bf16: needs hidden 512, a multiple of 64 hypotheses per image, at most %d couplings (R=%d B=%d)", flowfwd::MAXC, R, B);
+                "mhe_flow_couplings_frag_bf16: needs hidden 512, R a multiple of B, at most %d couplings (R=%d B=%d)", flowfwd::MAXC, R, B);
     MHE_REQUIRE(direction == MHE_FLOW_FORWARD || direction == MHE_FLOW_INVERSE, "mhe_flow_couplings_frag_bf16: direction=%d", direction);
     MHE_REQUIRE(cond_stride % 4 == 0 && cond_stride >= 4 * ncoup * hidden && w_net_stride > 0, "mhe_flow_couplings_frag_bf16: bad strides");
     MHE_REQUIRE((long)R * hidden < (1L << 31), "mhe_flow_couplings_frag_bf16: R x hidden beyond the 32-bit row offsets");
     const bool emit = h1 || h2 || o;
     MHE_REQUIRE(!emit || (h1 && h2 && o), "mhe_flow_couplings_frag_bf16: h1, h2 and o come together");
     MHE_REQUIRE(!sign_bits || emit, "mhe_flow_couplings_frag_bf16: sign_bits come with h1, h2 and o");
+    MHE_REQUIRE(!emit || R % (64 * B) == 0, "mhe_flow_couplings_frag_bf16: the train step's form (h1, h2, o) needs a multiple of 64 hypotheses per image");
     flowfwd::Args a;
     a.in = in; a.cond = cond; a.bias2 = bias2; a.mask = mask; a.out = out; a.sum_s = sum_s; a.logp = log_prob;
     a.w0F = (const u16 *)w0F; a.w1F = (const u16 *)w1F; a.w2F = (const u16 *)w2F; a.w_stride = w_net_stride;
@@ -305,8 +314,9 @@ extern "C" int mhe_flow_couplings_frag_bf16(const float *in, float *out, const f
     // the layer-1 stream is not latency-bound: 64 KiB per CU and k-tile at 75-90 GB/s per CU IS the L2 -> CU rate of this chip
     // (MI355X_MICROARCH.md "Indexed rows": 66-73 GB/s per CU for rows served by the XCD's L2); the default stays 2
     static const int sets = getenv("MHE_FLOW_W1_SETS") ? atoi(getenv("MHE_FLOW_W1_SETS")) : 2;
-    if (emit) hipLaunchKernelGGL((flowfwd::couplings_frag_kernel<true, 2>), dim3(R / 64), dim3(512), 0, (hipStream_t)stream, a);
-    else if (sets == 3) hipLaunchKernelGGL((flowfwd::couplings_frag_kernel<false, 3>), dim3(R / 64), dim3(512), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((flowfwd::couplings_frag_kernel<false, 2>), dim3(R / 64), dim3(512), 0, (hipStream_t)stream, a);
+    const dim3 grid((unsigned)(((R / B + 63) / 64) * B));
+    if (emit) hipLaunchKernelGGL((flowfwd::couplings_frag_kernel<true, 2>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    else if (sets == 3) hipLaunchKernelGGL((flowfwd::couplings_frag_kernel<false, 3>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((flowfwd::couplings_frag_kernel<false, 2>), grid, dim3(512), 0, (hipStream_t)stream, a);
     return check_launch("flowfwd::couplings_frag_kernel");
 }

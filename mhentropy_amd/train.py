@@ -1182,7 +1182,8 @@ class TrainStep:
                 kept = (self._buf("fl_h1", (2 * ncoup, Rr, h), torch.bfloat16), self._buf("fl_h2", (2 * ncoup, Rr, h), torch.bfloat16),
                         self._buf("fl_o", (2 * ncoup, Rr, 64)))
                 f0 = self.fnets[0]
-                if (os.environ.get("MHE_FLOW_FRAG", "1") == "1" and "f1F" in f0 and ops.flow_couplings_frag_supported(Rr, B, z0.shape[1], h, ncoup)):
+                if (os.environ.get("MHE_FLOW_FRAG", "1") == "1" and "f1F" in f0 and N % 64 == 0          # (the tape form needs whole 64-row chunks)
+                        and ops.flow_couplings_frag_supported(Rr, B, z0.shape[1], h, ncoup)):
                     wst = (self.fnets[1]["f1F"].data_ptr() - f0["f1F"].data_ptr()) // 2
                     sg = self._buf("fl_sign", (2 * ncoup, Rr // 64, 2, 8, 64, 2), torch.int32)
                     th45, _, log_q = ops.flow_couplings_frag(z0, cond, f0["f0F"], f0["f1F"], f0["f2F"], wst, self.f_b2, fl.mask, B, h,
