@@ -346,7 +346,6 @@ __global__ __launch_bounds__(256) void mano_joints16_kernel(
 //      tables (vertex-fastest, coalesced) are fetched once per workgroup and reused from registers across
 //      the HB hypotheses (1.5 MB / HB of L2 traffic per hypothesis).  No LDS at all in this kernel: the first
 //      version kept the per-hypothesis values in LDS and was LDS-issue bound (1536 broadcast reads per vertex).
-constexpr int WS_PM = 0, WS_BT = 135, WS_GR = 145, WS_NRM = 337, WS_STRIDE = 352;
 
 __global__ __launch_bounds__(256) void mano_pose_kernel(const float *__restrict__ z_g, const float *__restrict__ tables,
                                                         float *__restrict__ ws, int R) {
@@ -514,7 +513,11 @@ extern "C" int mhe_mano_joints_f32(const float *th45, const float *det, const fl
     return check_launch("mano_joints_kernel");
 }
 
-extern "C" size_t mhe_mano_verts_workspace_floats(int R) { return R > 0 ? (size_t)R * mano::WS_STRIDE : 0; }
+size_t mhe_mano_skin_split_floats();
+int mhe_mano_skin_mfma(const float *ws_rows, const float *tables, float *split, float *verts, int R, int mm_mode, hipStream_t stream);      // mano_skin.hip
+
+// [bf16 pieces of the vertex tables (mano_skin.hip) | 352 floats per hypothesis]
+extern "C" size_t mhe_mano_verts_workspace_floats(int R) { return R > 0 ? mhe_mano_skin_split_floats() + (size_t)R * mano::WS_STRIDE : 0; }
 
 extern "C" int mhe_mano_verts_f32(const float *z, const float *tables, float *verts, float *workspace, int R, int mm_mode,
                                   void *stream) {
@@ -523,10 +526,14 @@ extern "C" int mhe_mano_verts_f32(const float *z, const float *tables, float *ve
     constexpr int HB = 16;
     const size_t lds = (mano::JOINT_FLOATS + 4 * mano::SCRATCH) * sizeof(float);
     const int pb = (R + 3) / 4 < 2048 ? (R + 3) / 4 : 2048;
-    hipLaunchKernelGGL(mano::mano_pose_kernel, dim3(pb), dim3(256), lds, (hipStream_t)stream, z, tables, workspace, R);
+    float *rows = workspace + mhe_mano_skin_split_floats();
+    hipLaunchKernelGGL(mano::mano_pose_kernel, dim3(pb), dim3(256), lds, (hipStream_t)stream, z, tables, rows, R);
     if (int rc = check_launch("mano_pose_kernel")) return rc;
+    // 1 (default): both products on the matrix cores from bf16 pieces (mano_skin.hip); 0: the round-1 kernel, one thread per vertex (A/B runs)
+    static const int mfma = getenv("MHE_MANO_SKIN_MFMA") ? atoi(getenv("MHE_MANO_SKIN_MFMA")) : 1;
+    if (mfma) return mhe_mano_skin_mfma(rows, tables, workspace, verts, R, mm_mode, (hipStream_t)stream);
     hipLaunchKernelGGL(mano::mano_skin_kernel<HB>, dim3((mano::VP + 255) / 256, (R + HB - 1) / HB), dim3(256), 0,
-                       (hipStream_t)stream, workspace, tables, verts, R, mm_mode);
+                       (hipStream_t)stream, rows, tables, verts, R, mm_mode);
     return check_launch("mano_skin_kernel");
 }
 

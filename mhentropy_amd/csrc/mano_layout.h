@@ -24,4 +24,7 @@ constexpr int V_PD = V_SD + 30 * VP;       // [135][3][VP]
 constexpr int V_W = V_PD + 405 * VP;       // [16][VP]
 constexpr int V_JR = V_W + 16 * VP;         // [16][VP]   J_regressor (wrapper re-regression, ManoLayer.py:141-148)
 constexpr int TOTAL_FLOATS = V_JR + 16 * VP;
+// ---- per-hypothesis workspace row of the full-mesh pass (mano_pose_kernel -> the skinning kernels) --------
+// pose map (135), beta (10), the 16 skinning transforms [j][12] (192), centre / root / bone (7)
+constexpr int WS_PM = 0, WS_BT = 135, WS_GR = 145, WS_NRM = 337, WS_STRIDE = 352;
 }}  // namespace

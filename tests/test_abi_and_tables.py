@@ -161,9 +161,9 @@ def test_round3_entries_refuse_what_they_do_not_support():
     """argument checks of the round-3 C entries run before anything touches the GPU: unsupported geometries and null operands come back
     as MHE_ERR_ARG with a message, never as a launch"""
     L = _lib.lib()
-    # hidden 512, a multiple of 64 hypotheses per image
-    assert L.mhe_flow_couplings_frag_supported(64 * 3, 3, 45, 512, 12) == 1
-    assert L.mhe_flow_couplings_frag_supported(40 * 3, 3, 45, 512, 12) == 0 and L.mhe_flow_couplings_frag_supported(64 * 3, 3, 45, 256, 12) == 0
+    # hidden 512, whole images (round 5: any hypothesis count per image in the forward-only form)
+    assert L.mhe_flow_couplings_frag_supported(64 * 3, 3, 45, 512, 12) == 1 and L.mhe_flow_couplings_frag_supported(40 * 3, 3, 45, 512, 12) == 1
+    assert L.mhe_flow_couplings_frag_supported(40 * 3 + 1, 3, 45, 512, 12) == 0 and L.mhe_flow_couplings_frag_supported(64 * 3, 3, 45, 256, 12) == 0
     assert L.mhe_flow_couplings_frag_supported(64 * 3, 3, 45, 512, 40) == 0
     assert L.mhe_flow_reverse_chain_supported(64 * 3, 3, 45, 512, 12) == 1 and L.mhe_flow_reverse_chain_supported(128 * 3, 3, 45, 512, 12) == 0
     null = None

@@ -135,6 +135,35 @@ def test_mano_joints_and_verts_match_reference_vectors(gpu_lib):
     assert_close(verts.cpu(), (torch.as_tensor(g["mesh"]) - tj[:, 12:13]) / bone[:, None, None], RTOL, what="verts")
 
 
+@pytest.mark.parametrize("R,scale", [(1, 1.0), (33, 1.0), (70, 1.0), (200, 3.0)])
+def test_full_mesh_on_the_matrix_cores_keeps_f32_accuracy(gpu_lib, R, scale):
+    """mhe_mano_verts_f32 (round 5: csrc/mano_skin.hip - blend shapes and per-vertex transforms as GEMMs on v_mfma_f32_32x32x16_bf16, every
+    f32 operand split into bf16 pieces) against the f64 oracle (hand/manopth/manolayer.py:181-273, hand/network.py:466-483): the bound is the
+    one an f32 evaluation meets (the f32 oracle's own distance from f64, with a floor of 2e-6 of the mesh's extent), far inside the 1e-4 of
+    north_star.  Ragged hypothesis counts (a workgroup = 32), large poses (scale 3: |theta| up to ~6 rad), both output modes."""
+    from mhentropy_amd import ops
+    from oracle import network_ref, mano_ref
+    rng = np.random.default_rng(R)
+    t = synth.mano_tables(0)
+    blob = _mano_blob(0)
+    z = np.zeros((R, 61), np.float32)
+    z[:, :48] = rng.normal(0, 0.6 * scale, (R, 48)); z[:, 48:58] = rng.normal(0, 1.0, (R, 10)); z[:, 58:] = rng.normal(0, 0.1, (R, 3))
+    verts = ops.mano_verts(_dev(z), blob)
+    assert torch.equal(verts, ops.mano_verts(_dev(z), blob))
+    with torch.no_grad():
+        ref64 = network_ref.decode(mano_ref.tables_from_numpy(t, torch.float64), torch.as_tensor(z).double())["verts"]
+        ref32 = network_ref.decode(mano_ref.tables_from_numpy(t), torch.as_tensor(z))["verts"]
+    ext = float(ref64.abs().max())
+    e_gpu, e_f32 = float((verts.cpu().double() - ref64).abs().max()) / ext, float((ref32.double() - ref64).abs().max()) / ext
+    print(f"full mesh R={R}: max error / extent  HIP {e_gpu:.2e}   f32 oracle {e_f32:.2e}")
+    assert e_gpu <= max(3 * e_f32, 2e-6), (e_gpu, e_f32)
+    # millimetre mode (ManoLayer's own output, manolayer.py:262-273): the same vertices before the root / bone normalisation
+    mm = ops.mano_verts(_dev(z), blob, mm=True)
+    with torch.no_grad():
+        out = mano_ref.wrapper_forward(mano_ref.tables_from_numpy(t, torch.float64), torch.as_tensor(z[:, :48]).double(), torch.as_tensor(z[:, 48:58]).double())
+    assert_close(mm.cpu(), out["mesh"], 1e-5, what="mesh (mm)")
+
+
 @pytest.mark.parametrize("tag", ["small", "shipped"])
 def test_loss_rows_match_reference_vectors(gpu_lib, tag):
     from mhentropy_amd import ops
@@ -248,6 +277,30 @@ def test_metrics_match_reference_vectors(gpu_lib):
                           _dev(g["y_crop_uv"]), _dev(g["y_vis"]))
         for i, k in enumerate(criteria.METRIC_KEYS):
             assert_close(out[i].cpu(), g["metric_" + k], RTOL, what=k)
+
+
+@pytest.mark.parametrize("B,N", [(5, 200), (3, 300), (2, 1), (70, 7), (4, 256), (2, 513)])
+def test_metrics_kernel_vs_oracle_at_the_iterations_hypothesis_counts(gpu_lib, B, N):
+    """mhe_metrics_f32 (round 5: one workgroup per image, hypotheses staged through LDS in chunks of 256) against the criterion oracle
+    (hand/criteria.py:91-168) at the per-iteration pass' N = 200 (hand/CrossModalHand.py:357-361), at counts of more than one chunk, at
+    N = 1 (spread := 0), and with images that have no visible / no invisible joint (criteria.py:128-131 renormalisation)"""
+    from mhentropy_amd import ops, criteria
+    from oracle import criteria_ref
+    rng = np.random.default_rng(B * 1000 + N)
+    y = {"pose3d": rng.normal(0, 1, (B, 63)).astype(np.float32), "scale": rng.uniform(0.5, 1.5, B).astype(np.float32),
+         "crop_uv": rng.uniform(-1, 1, (B, 42)).astype(np.float32), "vis": (rng.random((B, 21)) < 0.7).astype(np.float32)}
+    y["vis"][0] = 1.0
+    if B > 1:
+        y["vis"][1] = 0.0
+    xyz = (y["pose3d"][None] + rng.normal(0, 0.3, (N, B, 63))).astype(np.float32)
+    uv = ((y["crop_uv"][None] + 1) * 128 + rng.normal(0, 9, (N, B, 42))).astype(np.float32)
+    out = ops.metrics(_dev(xyz), _dev(uv), _dev(y["pose3d"]), _dev(y["scale"]), _dev(y["crop_uv"]), _dev(y["vis"]))
+    again = ops.metrics(_dev(xyz), _dev(uv), _dev(y["pose3d"]), _dev(y["scale"]), _dev(y["crop_uv"]), _dev(y["vis"]))
+    assert torch.equal(out, again)
+    _, _, ref = criteria_ref.mhent_loss({"log_p": torch.zeros(B), "xyz": torch.as_tensor(xyz), "uv": torch.as_tensor(uv)},
+                                        {k: torch.as_tensor(v) for k, v in y.items()})
+    for i, k in enumerate(criteria.METRIC_KEYS):
+        assert_close(out[i].cpu(), ref[k], RTOL, what=f"{k} (B={B}, N={N})")
 
 
 @pytest.mark.parametrize("B,N", [(3, 64), (2, 40)])
