@@ -208,6 +208,14 @@ int mhe_mano_joints_f32(const float *th45, const float *det, const float *crop_u
 size_t mhe_mano_verts_workspace_floats(int R);
 int mhe_mano_verts_f32(const float *z, const float *tables, float *verts, float *workspace, int R, int mm_mode,
                        void *stream);
+/* mhe_mano_joints_f32 + mhe_mano_verts_f32 of the same hypotheses (MHEnt.sample with mods = {uv, xyz, verts}: the reference iteration's
+ * metrics pass, hand/CrossModalHand.py:357-361, hand/network.py:541-558): the joint pass leaves every hypothesis' skinning operands in the
+ * workspace (same size as for mhe_mano_verts_f32), the skinning launch (csrc/mano_skin.hip: both products on the matrix cores from bf16
+ * pieces of the f32 operands, f32-class accuracy) follows.  Arguments as in the two entries; verts as there. */
+int mhe_mano_decode_f32(const float *th45, const float *det, const float *crop_uv, const float *vis, const float *tables,
+                        float *z, float *xyz, float *uv, float *terms, float *log_p, float *norms, float *joints_mm,
+                        float *verts, float *workspace, int R, int B, float laplace_b, float th45_alpha, int inv_norm,
+                        float image_size, int mm_mode, void *stream);
 
 /* ManoLayer.xyz_from_vertice (hand/ManoLayer.py:108-148) + RHD reorder (:54-56):
  * verts [R,778,3] -> joints [R,21,3] (the wrapper's 'joints' output, unused by MHEnt). */

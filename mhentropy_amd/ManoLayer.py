@@ -94,8 +94,8 @@ class ManoLayer(nn.Module):
         det = torch.zeros(R, 16, device=beta.device, dtype=torch.float32)
         det[:, :3], det[:, 3:13] = theta[:, :3], beta
         blob = self.table_blob()
-        o = ops.mano_joints(theta[:, 3:].contiguous(), det, blob, want=("z", "joints_mm"))
-        mesh = ops.mano_verts(o["z"], blob, mm=True)
+        o = ops.mano_joints(theta[:, 3:].contiguous(), det, blob, want=("joints_mm", "mesh_mm"))
+        mesh = o["mesh_mm"]
         return {"beta": beta, "theta": theta, "mesh": mesh, "joints": ops.mano_regress_joints(mesh, blob),
                 "mano_joints": o["joints_mm"].view(R, 21, 3)}
 

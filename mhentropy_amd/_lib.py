@@ -42,6 +42,7 @@ SIGNATURES = {
     "mhe_mano_joints_f32": (_i, [_p] * 12 + [_i, _i, _f, _f, _i, _f, _p]),
     "mhe_mano_verts_workspace_floats": (_sz, [_i]),
     "mhe_mano_verts_f32": (_i, [_p, _p, _p, _p, _i, _i, _p]),
+    "mhe_mano_decode_f32": (_i, [_p] * 14 + [_i, _i, _f, _f, _i, _f, _i, _p]),
     "mhe_mano_joints_bwd_f32": (_i, [_p] * 8 + [_i, _i, _f, _f, _f, _p]),
     "mhe_sum_over_hypotheses_f32": (_i, [_p, _p, _i, _i, _i, _i, _l, _p]),
     "mhe_conv_wgrad_nhwc": (_i, [C.POINTER(ConvDesc), _p, _p, _p, _i, _p]),

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void mano_joints16_kernel(
     const float *__restrict__ th45_g, const float *__restrict__ det_g, const float *__restrict__ crop_uv,
     const float *__restrict__ vis, const float *__restrict__ tables,
     float *__restrict__ z_o, float *__restrict__ xyz_o, float *__restrict__ uv_o, float *__restrict__ terms_o,
-    float *__restrict__ logp_o, float *__restrict__ norms_o, float *__restrict__ jmm_o,
+    float *__restrict__ logp_o, float *__restrict__ norms_o, float *__restrict__ jmm_o, float *__restrict__ ws_o,
     int R, int B, float lap_b, float th45_alpha, int inv_norm, float image_size) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *tb = smem;
@@ -274,6 +274,19 @@ __global__ __launch_bounds__(256) void mano_joints16_kernel(
                 if (live && xyz_o) xyz_o[(size_t)r * 63 + e] = xv;
                 if (live && jmm_o) jmm_o[(size_t)r * 63 + e] = J;
             }
+        }
+        // -- what the full-mesh skinning needs of this hypothesis (mhe_mano_decode_f32; the row mano_pose_kernel writes for mhe_mano_verts_f32)
+        if (live && ws_o) {
+            float *w = ws_o + (size_t)r * WS_STRIDE;
+            for (int k = sub; k < 135; k += 16) {
+                const int e = k % 9;
+                w[WS_PM + k] = sc[S_ROT + 9 + k] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+            }
+            if (sub < 10) w[WS_BT + sub] = sc[S16_DET + 3 + sub];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) w[WS_GR + sub + 16 * k] = sc[S_GR + sub + 16 * k];
+            if (sub < 3) { w[WS_NRM + sub] = sc[S_PRE + 3 * kCenterPre + sub]; w[WS_NRM + 3 + sub] = sc[S_J21 + 3 * kRootIdx + sub]; }
+            if (sub == 0) w[WS_NRM + 6] = bone;
         }
         wave_sync();
         // -- orthographic projection (hand/network.py:497-514, ManoLayer.py:150-165) + visibility-masked Laplace (hand/network.py:255-257)
@@ -488,10 +501,10 @@ using namespace mhe;
 
 extern "C" size_t mhe_mano_table_floats(void) { return mano::TOTAL_FLOATS; }
 
-extern "C" int mhe_mano_joints_f32(const float *th45, const float *det, const float *crop_uv, const float *vis,
-                                   const float *tables, float *z, float *xyz, float *uv, float *terms, float *log_p,
-                                   float *norms, float *joints_mm, int R, int B, float laplace_b, float th45_alpha,
-                                   int inv_norm, float image_size, void *stream) {
+static int joints_launch(const float *th45, const float *det, const float *crop_uv, const float *vis,
+                         const float *tables, float *z, float *xyz, float *uv, float *terms, float *log_p,
+                         float *norms, float *joints_mm, float *ws_rows, int R, int B, float laplace_b, float th45_alpha,
+                         int inv_norm, float image_size, void *stream) {
     MHE_REQUIRE(th45 && det && tables, "mhe_mano_joints_f32: null input");
     MHE_REQUIRE(R > 0 && B > 0 && R % B == 0, "mhe_mano_joints_f32: R=%d must be a positive multiple of B=%d", R, B);
     MHE_REQUIRE(!(terms || log_p) || (crop_uv && vis), "mhe_mano_joints_f32: likelihood outputs need crop_uv and vis");
@@ -502,9 +515,10 @@ extern "C" int mhe_mano_joints_f32(const float *th45, const float *det, const fl
         const int blocks = wgs < 512 ? wgs : 512;            // two workgroups per CU (67 KiB of LDS each), every wave walks its share of the row quads
         const size_t lds = (mano::JOINT_FLOATS + 16 * mano::SCRATCH16) * sizeof(float);
         hipLaunchKernelGGL(mano::mano_joints16_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, th45, det, crop_uv,
-                           vis, tables, z, xyz, uv, terms, log_p, norms, joints_mm, R, B, laplace_b, th45_alpha, inv_norm, image_size);
+                           vis, tables, z, xyz, uv, terms, log_p, norms, joints_mm, ws_rows, R, B, laplace_b, th45_alpha, inv_norm, image_size);
         return check_launch("mano_joints16_kernel");
     }
+    MHE_REQUIRE(!ws_rows, "mhe_mano_decode_f32 runs on the four-hypotheses-per-wave kernel (MHE_MANO_FOUR=1)");
     const int blocks = (R + 3) / 4 < 2048 ? (R + 3) / 4 : 2048;
     const size_t lds = (mano::JOINT_FLOATS + 4 * mano::SCRATCH) * sizeof(float);
     hipLaunchKernelGGL(mano::mano_joints_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, th45, det, crop_uv,
@@ -517,6 +531,14 @@ size_t mhe_mano_skin_split_floats();
 int mhe_mano_skin_mfma(const float *ws_rows, const float *tables, float *split, float *verts, int R, int mm_mode, hipStream_t stream);      // mano_skin.hip
 
 // [bf16 pieces of the vertex tables (mano_skin.hip) | 352 floats per hypothesis]
+extern "C" int mhe_mano_joints_f32(const float *th45, const float *det, const float *crop_uv, const float *vis,
+                                   const float *tables, float *z, float *xyz, float *uv, float *terms, float *log_p,
+                                   float *norms, float *joints_mm, int R, int B, float laplace_b, float th45_alpha,
+                                   int inv_norm, float image_size, void *stream) {
+    return joints_launch(th45, det, crop_uv, vis, tables, z, xyz, uv, terms, log_p, norms, joints_mm, nullptr, R, B, laplace_b, th45_alpha,
+                         inv_norm, image_size, stream);
+}
+
 extern "C" size_t mhe_mano_verts_workspace_floats(int R) { return R > 0 ? mhe_mano_skin_split_floats() + (size_t)R * mano::WS_STRIDE : 0; }
 
 extern "C" int mhe_mano_verts_f32(const float *z, const float *tables, float *verts, float *workspace, int R, int mm_mode,
@@ -535,6 +557,20 @@ extern "C" int mhe_mano_verts_f32(const float *z, const float *tables, float *ve
     hipLaunchKernelGGL(mano::mano_skin_kernel<HB>, dim3((mano::VP + 255) / 256, (R + HB - 1) / HB), dim3(256), 0,
                        (hipStream_t)stream, rows, tables, verts, R, mm_mode);
     return check_launch("mano_skin_kernel");
+}
+
+// joints + full mesh of the same hypotheses in two launches: the joint pass leaves the skinning operands of every hypothesis in the workspace
+// (what mano_pose_kernel recomputes from z for mhe_mano_verts_f32: 135 us at 51,200 hypotheses), the matrix-core skinning follows
+extern "C" int mhe_mano_decode_f32(const float *th45, const float *det, const float *crop_uv, const float *vis,
+                                   const float *tables, float *z, float *xyz, float *uv, float *terms, float *log_p,
+                                   float *norms, float *joints_mm, float *verts, float *workspace, int R, int B, float laplace_b,
+                                   float th45_alpha, int inv_norm, float image_size, int mm_mode, void *stream) {
+    MHE_REQUIRE(verts && workspace, "mhe_mano_decode_f32: null pointer");
+    float *rows = workspace + mhe_mano_skin_split_floats();
+    if (int rc = joints_launch(th45, det, crop_uv, vis, tables, z, xyz, uv, terms, log_p, norms, joints_mm, rows, R, B, laplace_b, th45_alpha,
+                               inv_norm, image_size, stream))
+        return rc;
+    return mhe_mano_skin_mfma(rows, tables, workspace, verts, R, mm_mode, (hipStream_t)stream);
 }
 
 extern "C" int mhe_mano_regress_joints_f32(const float *verts, const float *tables, float *joints, int R, void *stream) {

@@ -36,9 +36,10 @@ __global__ __launch_bounds__(256) void randn_kernel(float *__restrict__ out, lon
         for (int h = 0; h < 2; ++h) {
             // u1 in (0, 1], u2 in [0, 1): 24 mantissa bits each
             const float u1 = ((float)(r[2 * h] >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(r[2 * h + 1] >> 8) * (1.0f / 16777216.0f);
-            const float rad = sqrtf(-2.0f * logf(u1));
-            float sn, cs;
-            sincospif(2.0f * u2, &sn, &cs);
+            // hardware transcendentals (v_log_f32, v_sqrt_f32, v_sin_f32 / v_cos_f32 take revolutions): ~1e-6 of the value - noise, not parity
+            // data; the library forms (logf, sincospif with full range reduction) made this launch 61 us for 2.3 M values
+            const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+            const float sn = __builtin_amdgcn_sinf(u2), cs = __builtin_amdgcn_cosf(u2);
             v[2 * h] = rad * cs * scale; v[2 * h + 1] = rad * sn * scale;
         }
         if (4 * i + 3 < n) *reinterpret_cast<float4 *>(out + 4 * i) = make_float4(v[0], v[1], v[2], v[3]);
@@ -65,7 +66,9 @@ extern "C" int mhe_randn_f32(float *out, long n, unsigned long long *state, floa
     MHE_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "mhe_randn_f32: out must be 16-byte aligned");
     const long n4 = (n + 3) / 4;
     long blocks = (n4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    // one workgroup per CU: every workgroup ends with an atomic on ONE counter word, and same-address atomics retire one per ~28 ns - with 2,048
+    // workgroups that tail WAS the launch (61 us for 2.3 M values; 20 us at the train step's 0.74 M)
+    if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(rng::randn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, n, state, scale);
     return check_launch("randn_kernel");
 }
@@ -118,7 +121,7 @@ extern "C" int mhe_dropout(void *x, int dtype, unsigned char *bits, long n, floa
     MHE_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "mhe_dropout: x must be 16-byte aligned");
     const long n8 = n / 8;
     long blocks = (n8 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 512) blocks = 512;
     const unsigned thr = (unsigned)(p_drop * 65536.f + 0.5f);
     const float scale = 1.f / (1.f - p_drop);
     if (dtype == MHE_F32)
@@ -159,7 +162,7 @@ extern "C" int mhe_dropout_bits(unsigned char *bits, long n, float p_drop, unsig
     MHE_REQUIRE(bits && state && n > 0 && n % 8 == 0 && p_drop >= 0.f && p_drop < 1.f, "mhe_dropout_bits: bad arguments (n=%ld, p=%f)", n, (double)p_drop);
     const long n8 = n / 8;
     long blocks = (n8 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 256) blocks = 256;            // the counter word's atomic tail: see mhe_randn_f32 (58 us at 2,048 workgroups for the Glow train step's 4.2 M bytes of bits)
     hipLaunchKernelGGL(rng::dropout_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, bits, n8, state, (unsigned)(p_drop * 65536.f + 0.5f));
     return check_launch("dropout_bits_kernel");
 }

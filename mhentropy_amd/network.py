@@ -213,11 +213,11 @@ class MHEnt(nn.Module):
         mods = {"xyz", "uv", "verts"} if mods is None else set(mods)
         blob = self.mano_dec.table_blob()
         o = ops.mano_joints(th45, self._det(feat), blob, inv_norm=True, image_size=float(self.image_size),
-                            want=("z", "xyz", "uv"))
+                            want=("z", "xyz", "uv") + (("verts",) if "verts" in mods else ()))      # the mesh from the joint pass' operands
         z = o["z"].view(N, B, 61)
         out["th_bt"], out["logs_t"] = z[..., :58], z[..., -3:]
         if "verts" in mods:
-            out["verts"] = ops.mano_verts(o["z"], blob).view(N, B, -1)
+            out["verts"] = o["verts"].view(N, B, -1)
             out["faces"] = self.mano_dec.mano_faces
         if "xyz" in mods:
             out["xyz"] = o["xyz"].view(N, B, -1)

@@ -317,7 +317,8 @@ def flow_couplings_frag(x_in, cond, w0F, w1F, w2F, w_net_stride, bias2, mask, B,
 
 def mano_joints(th45, det, tables, crop_uv=None, vis=None, laplace_b=0.03, th45_alpha=50.0, inv_norm=False,
                 image_size=256.0, want=("z", "xyz", "uv", "terms", "log_p", "norms")):
-    """want may also include "joints_mm"."""
+    """want may also include "joints_mm", and "verts" (the full mesh, normalised like xyz) or "mesh_mm" (ManoLayer's mesh in mm): the mesh
+    of the same hypotheses through mhe_mano_decode_f32 - the joint pass leaves the skinning operands, no second pose pass."""
     R, B = th45.shape[0], det.shape[0]
     dev = th45.device
     _chk(th45, torch.float32, "mano.th45", (R, 45)); _chk(det, torch.float32, "mano.det", (B, 16))
@@ -327,6 +328,18 @@ def mano_joints(th45, det, tables, crop_uv=None, vis=None, laplace_b=0.03, th45_
     shapes = {"z": (R, 61), "xyz": (R, 63), "uv": (R, 42), "terms": (R, 4), "log_p": (R,), "norms": (R, 2),
               "joints_mm": (R, 63)}
     o = {k: (torch.empty(shapes[k], device=dev, dtype=torch.float32) if k in want else None) for k in shapes}
+    if "verts" in want or "mesh_mm" in want:
+        if "verts" in want and "mesh_mm" in want:
+            raise ValueError("mano_joints: 'verts' or 'mesh_mm', one mesh per call")
+        key = "verts" if "verts" in want else "mesh_mm"
+        o[key] = torch.empty(R, 778, 3, device=dev, dtype=torch.float32)
+        ws = torch.empty(_lib.lib().mhe_mano_verts_workspace_floats(R), device=dev, dtype=torch.float32)
+        check(_lib.lib().mhe_mano_decode_f32(_ptr(th45), _ptr(det), _ptr(crop_uv), _ptr(vis), _ptr(tables),
+                                             _ptr(o["z"]), _ptr(o["xyz"]), _ptr(o["uv"]), _ptr(o["terms"]), _ptr(o["log_p"]),
+                                             _ptr(o["norms"]), _ptr(o["joints_mm"]), _ptr(o[key]), _ptr(ws), R, B, float(laplace_b),
+                                             float(th45_alpha), int(inv_norm), float(image_size), int(key == "mesh_mm"), _stream()),
+              "mhe_mano_decode_f32")
+        return o
     check(_lib.lib().mhe_mano_joints_f32(_ptr(th45), _ptr(det), _ptr(crop_uv), _ptr(vis), _ptr(tables),
                                          _ptr(o["z"]), _ptr(o["xyz"]), _ptr(o["uv"]), _ptr(o["terms"]), _ptr(o["log_p"]),
                                          _ptr(o["norms"]), _ptr(o["joints_mm"]), R, B, float(laplace_b), float(th45_alpha), int(inv_norm),

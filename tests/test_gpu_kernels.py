@@ -157,6 +157,24 @@ def test_full_mesh_on_the_matrix_cores_keeps_f32_accuracy(gpu_lib, R, scale):
     e_gpu, e_f32 = float((verts.cpu().double() - ref64).abs().max()) / ext, float((ref32.double() - ref64).abs().max()) / ext
     print(f"full mesh R={R}: max error / extent  HIP {e_gpu:.2e}   f32 oracle {e_f32:.2e}")
     assert e_gpu <= max(3 * e_f32, 2e-6), (e_gpu, e_f32)
+    # rows past R of the last workgroup's 32 hypotheses are not stored (the kernel relies on the buffer resource's range check for them):
+    # the floats behind the R-th row keep their sentinel
+    from mhentropy_amd import _lib
+    import ctypes as C
+    big = torch.full((R + 40, 778, 3), -7.0, device="cuda")
+    wsb = torch.empty(_lib.lib().mhe_mano_verts_workspace_floats(R), device="cuda")
+    zd = _dev(z)
+    assert _lib.lib().mhe_mano_verts_f32(C.c_void_p(zd.data_ptr()), C.c_void_p(blob.data_ptr()), C.c_void_p(big.data_ptr()), C.c_void_p(wsb.data_ptr()),
+                                         R, 0, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    assert torch.equal(big[:R], verts) and bool((big[R:] == -7.0).all())
+    # the same mesh from the joint pass' own operands (mhe_mano_decode_f32: no second pose pass), with the joint outputs unchanged
+    det = np.zeros((R, 16), np.float32)
+    det[:, :3], det[:, 3:] = z[:, :3], z[:, 48:61]
+    o = ops.mano_joints(_dev(z[:, 3:48]), _dev(det), blob, want=("z", "xyz", "uv", "verts"))
+    o0 = ops.mano_joints(_dev(z[:, 3:48]), _dev(det), blob, want=("z", "xyz", "uv"))
+    assert all(torch.equal(o[k], o0[k]) for k in ("z", "xyz", "uv"))
+    e_dec = float((o["verts"].cpu().double() - ref64).abs().max()) / ext
+    assert e_dec <= max(3 * e_f32, 2e-6), (e_dec, e_f32)
     # millimetre mode (ManoLayer's own output, manolayer.py:262-273): the same vertices before the root / bone normalisation
     mm = ops.mano_verts(_dev(z), blob, mm=True)
     with torch.no_grad():
