@@ -329,6 +329,10 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 // per 4 MFMAs - every staged byte twice, 128 B/clk/CU of transposing reads at the full MFMA rate, which the LDS does not deliver next to
 // the DMA writes (PMC: MFMA utilisation 0.20, 44 % issue-stalled); 64 x 128 per wave reads (2 + 4) per 8: 96 B/clk.  One workgroup per CU
 // (128 KiB ring), two waves per SIMD as before.
+// <256, 256, 4, 4> (round 5, the default for this tile): SIXTEEN waves of 64 x 64 (TM = TN = 2: 4 fragment reads per 4 MFMAs again), four per SIMD,
+// 108 registers.  More LDS read traffic, and faster: train step 24.69 -> 24.35 ms (two A/B pairs), while FOUR waves of 128 x 128 (a third less
+// read traffic, one wave per SIMD) lost 1.3 ms: what the loop lacks is something to issue while a wave sits at the stage's barrier or waits
+// for its fragments, not LDS bandwidth (profiles/EXPERIMENTS.md "Round 5").  MHE_WGRAD_W16=0: the eight-wave form.
 template <int BM, int BN, int WM, int WN> struct DmaTile {
     static constexpr int BKB = 32, NBUF = 4, DEPTH = 3, NW = WM * WN;
     static constexpr int PA = BM * 2, PB = BN * 2;                // row pitches in bytes (128, 256 or 512)
@@ -345,7 +349,7 @@ __device__ __forceinline__ void wgrad_dma_body(const DmaParams &dp, const int bx
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int RA = 1024 / PA, RB = 1024 / PB;                 // rows per DMA wave-instruction
     constexpr int IA = BKB / RA / NW, IB = BKB / RB / NW;         // DMA instructions per wave per stage
-    static_assert((NW == 4 || NW == 8) && (PA == 128 || PA == 256 || PA == 512) && (PB == 128 || PB == 256 || PB == 512) && IA >= 1 && IB >= 1, "tile");
+    static_assert((NW == 4 || NW == 8 || NW == 16) && (PA == 128 || PA == 256 || PA == 512) && (PB == 128 || PB == 256 || PB == 512) && IA >= 1 && IB >= 1, "tile");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = by * BM, n0 = bx * BN;
@@ -873,7 +877,9 @@ static int wgrad_entry(const mhe_conv_desc *d, const void *x, const void *gy, fl
         dp.nzt = gz * nbatch;
         dp.xcd = xcd_env && w.xcd && dp.nzt >= 8;
         if (dp.xcd) grid.z = (unsigned)((dp.nzt + 7) / 8 * 8);
-        if (w.big) hipLaunchKernelGGL((wgrad::wgrad_dma_kernel<256, 256, 4, 2>), grid, dim3(512), 0, s, dp);
+        static const int w16 = getenv("MHE_WGRAD_W16") ? atoi(getenv("MHE_WGRAD_W16")) : 1;
+        if (w.big && w16) hipLaunchKernelGGL((wgrad::wgrad_dma_kernel<256, 256, 4, 4>), grid, dim3(1024), 0, s, dp);
+        else if (w.big) hipLaunchKernelGGL((wgrad::wgrad_dma_kernel<256, 256, 4, 2>), grid, dim3(512), 0, s, dp);
         else if (narrow) {
             if (small) hipLaunchKernelGGL((wgrad::wgrad_dma_kernel<64, 64, 2, 2>), grid, block, 0, s, dp);
             else hipLaunchKernelGGL((wgrad::wgrad_dma_kernel<128, 64, 4, 1>), grid, block, 0, s, dp);
@@ -1043,7 +1049,9 @@ extern "C" int mhe_conv_wgrad_multi_nhwc(const mhe_wgrad_item *items, int n, flo
         }
         mp.first[m] = first; mr.first[mr.n] = rfirst;
         const WgradPlan &w = it[i].w;
-        if (w.big) launch_multi<256, 256, 4, 2>(mp, s);
+        static const int w16 = getenv("MHE_WGRAD_W16") ? atoi(getenv("MHE_WGRAD_W16")) : 1;
+        if (w.big && w16) launch_multi<256, 256, 4, 4>(mp, s);
+        else if (w.big) launch_multi<256, 256, 4, 2>(mp, s);
         else if (w.narrow) { if (w.small) launch_multi<64, 64, 2, 2>(mp, s); else launch_multi<128, 64, 4, 1>(mp, s); }
         else { if (w.small) launch_multi<64, 128, 1, 4>(mp, s); else launch_multi<128, 128, 2, 2>(mp, s); }
         if (int rc = check_launch("wgrad_dma_multi_kernel")) return rc;

@@ -5,6 +5,7 @@ produced by the hand-written kernels in csrc/.  All functions require CUDA (HIP)
 tensors and raise on anything else - there is no CPU path in the product.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -923,7 +924,8 @@ def _wgrad_ws(device, need):
 WGRAD_SLABS = True      # False: f32 atomics into dw (the form without a workspace)
 
 
-_WG_WAVES = {(256, 256): "4, 2", (128, 128): "2, 2", (64, 128): "1, 4", (128, 64): "4, 1", (64, 64): "2, 2"}
+_WG_WAVES = {(256, 256): "4, 4" if os.environ.get("MHE_WGRAD_W16", "1") != "0" else "4, 2", (128, 128): "2, 2", (64, 128): "1, 4", (128, 64): "4, 1",
+             (64, 64): "2, 2"}
 
 
 def _wgrad_kernel_name(d, Ho=0, Wo=0, nbatch=1):

@@ -63,6 +63,7 @@ SWITCHES = {
     "MHE_WGRAD_MULTI": ("1", "train.py", "0: one weight-gradient launch per trunk layer instead of one multi-problem launch per gradient bucket and tile shape"),
     "MHE_WGRAD_MULTI_WGS": ("2048", "csrc/wgrad.hip", "workgroups a multi-problem launch of the 4-wave tiles aims at"),
     "MHE_WGRAD_MULTI_WGS_BIG": ("768", "csrc/wgrad.hip", "workgroups a multi-problem launch of the 256 x 256 tile aims at"),
+    "MHE_WGRAD_W16": ("1", "csrc/wgrad.hip", "0: the 256 x 256 weight-gradient tile on eight waves of 64 x 128 instead of sixteen of 64 x 64"),
     "MHE_WGRAD_DMA": ("1", "csrc/wgrad.hip", "0: register-staged bf16 weight-gradient kernel"),
     "MHE_WGRAD_BIG": ("1", "csrc/wgrad.hip", "0: no 256x256 weight-gradient tile"),
     "MHE_WGRAD_XCD": ("1", "csrc/wgrad.hip", "0: weight-gradient tiles in grid order"),
