@@ -41,3 +41,9 @@ cd /tmp
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/glow -o glow -- python3 $R/tools/glow_train_prof.py > $R/$O/glow.log 2>&1 || true
 cd $R
 cp $O/glow/glow_kernel_stats.csv profiles/r05_glow_head_train_kernel_stats.csv 2>/dev/null || true
+# the metrics pass of the reference's iteration (sample(N=[200,200]) + MHEntLoss from the conditioning feature on) per kernel
+cd /tmp
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/sample -o s -- python3 $R/tools/sample_bench.py > $R/$O/sample.log 2>&1 || true
+cd $R
+cp $O/sample/s_kernel_stats.csv profiles/r05_metrics_pass_kernel_stats.csv 2>/dev/null || true
+tail -1 $O/sample.log || true
