@@ -490,6 +490,10 @@ int mhe_colsum_ws_f32(const void *rows, float *out, long R, int C, int dtype, in
  * operand packs, transposed / tap-flipped operands of the data-gradient convolutions, un-packing of weight
  * gradients into the flat gradient buffer) is one gather over an index table built once on the host. */
 int mhe_gather_f32(const float *src, const int *idx, const int *idx2, void *dst, size_t n, int dst_dtype, void *stream);
+/* dst[8 g + k] = bf16(src[base_g + k * stride_g]) for the k whose bit is set in mask[g], else 0 - mhe_gather_f32's bf16 form for operand layouts
+ * whose groups of eight destination elements are affine in the source (permuted / padded weight tensors: the train step's operand re-pack,
+ * hand/CrossModalHand.py:455-470 has no counterpart - torch keeps one layout).  base_stride: int32 pairs [n / 8][2], mask: bytes [n / 8]. */
+int mhe_gather_affine8_bf16(const float *src, const int *base_stride, const unsigned char *mask, void *dst, size_t n, void *stream);
 
 /* Elementwise stages of the RealNVP reverse pass (hand/flows.py:97-122,210-217), f32, flow variable padded
  * to 64 columns where it is a GEMM operand; see csrc/flow_bwd.hip for the formulas. */

@@ -55,6 +55,7 @@ SIGNATURES = {
     "mhe_colsum_workspace_floats": (_sz, [_l, _i]),
     "mhe_colsum_ws_f32": (_i, [_p, _p, _l, _i, _i, _i, _l, _p, _sz, _p]),
     "mhe_gather_f32": (_i, [_p, _p, _p, _p, _sz, _i, _p]),
+    "mhe_gather_affine8_bf16": (_i, [_p, _p, _p, _p, _sz, _p]),
     "mhe_flow_mask_pad_f32": (_i, [_p, _p, _p, _l, _i, _p]),
     "mhe_flow_cond_lrelu_f32": (_i, [_p, _p, _l, _l, _i, _i, _p]),
     "mhe_flow_lrelu_bwd_f32": (_i, [_p, _p, _l, _f, _p]),

@@ -688,6 +688,29 @@ __global__ __launch_bounds__(256) void gather8_bf16_kernel(const float *__restri
         reinterpret_cast<uint4 *>(dst)[i] = o;
     }
 }
+// ... the same eight destinations from ONE (base, stride) pair and a validity byte (round 5): the operand layouts are permutations of weight
+// tensors with zero padding, so eight consecutive destination elements are almost always eight steps along one source dimension -
+// src[base + k * stride] - and the 32 bytes of indices per group (472 MB per step for the 118 M bf16 elements, more than the 236 MB they
+// produce) shrink to 9.  The host encodes an arena this way only if EVERY group of it is affine (mhentropy_amd/train.py: _affine8).
+__global__ __launch_bounds__(256) void gather8_affine_bf16_kernel(const float *__restrict__ src, const int2 *__restrict__ bs, const unsigned char *__restrict__ mask,
+                                                                  u16 *__restrict__ dst, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const int2 g = bs[i];
+        const unsigned m = mask[i];
+        float v[8];
+        if (m == 0xffu && g.y == 1 && (g.x & 3) == 0) {
+            const float4 a = *reinterpret_cast<const float4 *>(src + g.x), b = *reinterpret_cast<const float4 *>(src + g.x + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (m >> k) & 1u ? src[(long)g.x + (long)k * g.y] : 0.f;
+        }
+        uint4 o;
+        o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16); o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        o.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16); o.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+        reinterpret_cast<uint4 *>(dst)[i] = o;
+    }
+}
 // ... and four f32 destinations per thread (the f32 arena: 11 M elements, a second index for a handful of them)
 __global__ __launch_bounds__(256) void gather4_f32_kernel(const float *__restrict__ src, const int *__restrict__ idx, const int *__restrict__ idx2,
                                                           float *__restrict__ dst, size_t n4) {
@@ -1104,6 +1127,16 @@ extern "C" int mhe_colsum_ws_f32(const void *rows, float *out, long R, int C, in
 
 extern "C" int mhe_colsum_f32(const void *rows, float *out, long R, int C, int dtype, void *stream) {
     return mhe_colsum_ws_f32(rows, out, R, C, dtype, 0, 0, nullptr, 0, stream);
+}
+
+extern "C" int mhe_gather_affine8_bf16(const float *src, const int *base_stride, const unsigned char *mask, void *dst, size_t n, void *stream) {
+    MHE_REQUIRE(src && base_stride && mask && dst && n > 0 && n % 8 == 0, "mhe_gather_affine8_bf16: bad arguments (n = %zu must be a multiple of 8)", n);
+    MHE_REQUIRE(((size_t)base_stride & 7) == 0 && ((size_t)dst & 15) == 0, "mhe_gather_affine8_bf16: alignment");
+    size_t b8 = (n / 8 + 255) / 256;
+    if (b8 > 16384) b8 = 16384;
+    hipLaunchKernelGGL(wgrad::gather8_affine_bf16_kernel, dim3((unsigned)b8), dim3(256), 0, (hipStream_t)stream, src,
+                       reinterpret_cast<const int2 *>(base_stride), mask, (u16 *)dst, n / 8);
+    return check_launch("gather8_affine_bf16_kernel");
 }
 
 extern "C" int mhe_gather_f32(const float *src, const int *idx, const int *idx2, void *dst, size_t n, int dst_dtype, void *stream) {

@@ -1123,6 +1123,44 @@ def gather(src, idx, dst, idx2=None):
     return dst
 
 
+def affine8(idx, with_bad=False):
+    """host side of gather_affine8: int64 index vector (numel a multiple of 8, -1 = zero) -> (base_stride int32 [n/8, 2], mask uint8 [n/8]) if
+    every group of eight is src[base + k * stride] on its valid positions, else None.  with_bad: always the pair plus a bool vector of the
+    groups that are NOT affine (their entries are meaningless: the caller gathers those groups by index)"""
+    I = idx.reshape(-1, 8).to(torch.int64)
+    valid = I >= 0
+    k = torch.arange(8, dtype=torch.int64)
+    nv = valid.sum(1)
+    first = torch.where(valid, k, torch.full_like(k, 8)).min(1).values.clamp(max=7)                 # first valid position
+    second = torch.where(valid & (k > first[:, None]), k, torch.full_like(k, 8)).min(1).values      # next valid position (8: none)
+    rows = torch.arange(I.shape[0])
+    v0 = I[rows, first]
+    has2 = second < 8
+    v1 = I[rows, second.clamp(max=7)]
+    num = v1 - v0
+    den = (second - first).clamp(min=1)
+    stride = torch.where(has2, torch.div(num, den, rounding_mode="floor"), torch.zeros_like(num))
+    base = torch.where(nv > 0, v0 - first * stride, torch.zeros_like(v0))
+    pred = base[:, None] + k[None, :] * stride[:, None]
+    bad = ~(((pred == I) | ~valid).all(1)) | (stride.abs() >= 2 ** 31) | (base < -2 ** 31) | (base >= 2 ** 31)
+    if not with_bad and bool(bad.any()):
+        return None
+    base, stride = torch.where(bad, torch.zeros_like(base), base), torch.where(bad, torch.zeros_like(stride), stride)
+    mask = torch.where(bad, torch.zeros_like(nv), (valid.to(torch.int64) << k[None, :]).sum(1)).to(torch.uint8)
+    enc = torch.stack([base, stride], 1).to(torch.int32).contiguous(), mask.contiguous()
+    return enc + (bad,) if with_bad else enc
+
+
+def gather_affine8(src, base_stride, mask, dst):
+    """dst[8 g + k] = bf16(src[base_g + k stride_g]) where bit k of mask[g] is set, else 0 (mhe_gather_affine8_bf16)"""
+    n8 = mask.numel()
+    _chk(src, torch.float32, "gather.src"); _chk(base_stride, torch.int32, "gather.base_stride", (n8, 2)); _chk(mask, torch.uint8, "gather.mask", (n8,))
+    if dst.numel() != 8 * n8 or dst.dtype != torch.bfloat16 or not dst.is_contiguous():
+        raise ValueError("gather_affine8.dst: contiguous bf16 tensor of 8 x mask.numel() elements expected")
+    check(_lib.lib().mhe_gather_affine8_bf16(_ptr(src), _ptr(base_stride), _ptr(mask), _ptr(dst), 8 * n8, _stream()), "mhe_gather_affine8_bf16")
+    return dst
+
+
 def flow_mask_pad(x, mask_row, out):
     R, dim = x.shape
     _chk(x, torch.float32, "mask_pad.x"); _chk(mask_row, torch.float32, "mask_pad.mask", (dim,)); _chk(out, torch.float32, "mask_pad.out", (R, 64))

@@ -60,6 +60,7 @@ SWITCHES = {
     "MHE_FLOW_RECOMPUTE": ("0", "train.py", "1: the reverse pass re-evaluates the flow nets instead of reading emitted activations"),
     "MHE_LAZY_FALLBACK_TABLES": ("1", "train.py", "0: the fallback operand layouts refreshed every step"),
     "MHE_POISON_STALE_TABLES": ("0", "train.py", "1 (debug): fallback operand layouts a repack leaves behind are filled with NaN"),
+    "MHE_GATHER_AFFINE": ("1", "train.py", "0: the bf16 operand re-pack from one index per element instead of (base, stride, validity) per eight"),
     "MHE_WGRAD_MULTI": ("1", "train.py", "0: one weight-gradient launch per trunk layer instead of one multi-problem launch per gradient bucket and tile shape"),
     "MHE_WGRAD_MULTI_WGS": ("2048", "csrc/wgrad.hip", "workgroups a multi-problem launch of the 4-wave tiles aims at"),
     "MHE_WGRAD_MULTI_WGS_BIG": ("768", "csrc/wgrad.hip", "workgroups a multi-problem launch of the 256 x 256 tile aims at"),

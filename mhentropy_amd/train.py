@@ -191,9 +191,33 @@ class TrainStep:
             if a["buf"] is None:
                 a["buf"] = torch.zeros(0, device=self.dev, dtype=torch.float32)
             a["view"] = a["buf"][:n]
-            a["idx"] = (torch.cat(a["idx"]) if a["idx"] else torch.zeros(0, dtype=torch.int64)).to(torch.int32).to(self.dev).contiguous()
+            i1 = torch.cat(a["idx"]) if a["idx"] else torch.zeros(0, dtype=torch.int64)
+            a["idx"] = i1.to(torch.int32).to(self.dev).contiguous()
             i2 = torch.cat(a["idx2"]) if a["idx2"] else torch.zeros(0, dtype=torch.int64)
             a["idx2"] = i2.to(torch.int32).to(self.dev).contiguous() if bool((i2 >= 0).any()) else None
+            # the bf16 operand layouts as (base, stride, validity) per eight elements instead of eight indices (472 -> 133 MB of index reads per
+            # step at C2) - when every group of the arena is affine in the parameter vector (permuted / padded weight tensors are)
+            a["aff"] = None
+            if (a["buf"].dtype == torch.bfloat16 and a["idx2"] is None and i1.numel() and i1.numel() % 8 == 0
+                    and os.environ.get("MHE_GATHER_AFFINE", "1") == "1"):
+                bs, msk, bad = ops.affine8(i1, with_bad=True)
+                # groups that are not affine (the stem's 7 x 7 x 3 taps: 1.3 k of 10.6 M groups at ResNet-50) stay on the indexed form: a few
+                # ranges of groups, merged when less than 4,096 groups apart
+                ranges = []
+                for g in bad.nonzero().flatten().tolist():
+                    if ranges and g - ranges[-1][1] < 4096:
+                        ranges[-1][1] = g + 1
+                    else:
+                        ranges.append([g, g + 1])
+                if len(ranges) <= 4 and sum(r[1] - r[0] for r in ranges) * 50 < bad.numel():
+                    segs, at = [], 0
+                    for lo, hi in ranges + [[bad.numel(), bad.numel()]]:
+                        if lo > at:
+                            segs.append(("aff", at, lo))
+                        if hi > lo:
+                            segs.append(("idx", lo, hi))
+                        at = hi
+                    a["aff"] = (bs.to(self.dev), msk.to(self.dev), segs)
         self.step_t = torch.zeros(1, device=self.dev, dtype=torch.int32)
         self._zeros_c = torch.zeros(4096, device=self.dev, dtype=torch.float32)
         self.sq = torch.zeros(1, device=self.dev, dtype=torch.float32)
@@ -519,10 +543,21 @@ class TrainStep:
         self._raw_views.append(views)
 
     # ------------------------------------------------------------------ per-step plumbing
+    def _gather(self, a):
+        if a.get("aff") is not None:
+            bs, msk, segs = a["aff"]
+            for kind, lo, hi in segs:
+                if kind == "aff":
+                    ops.gather_affine8(self.P, bs[lo:hi], msk[lo:hi], a["view"][8 * lo:8 * hi])
+                else:
+                    ops.gather(self.P, a["idx"][8 * lo:8 * hi], a["view"][8 * lo:8 * hi])
+        else:
+            ops.gather(self.P, a["idx"], a["view"], a["idx2"])
+
     def repack(self):
         for a in self._arena.values():
             if a["idx"].numel():
-                ops.gather(self.P, a["idx"], a["view"], a["idx2"])
+                self._gather(a)
         if self._fb_keep:
             self._repack_fallback()
         else:
@@ -540,7 +575,7 @@ class TrainStep:
     def _repack_fallback(self):
         for a in self._arena_fb.values():
             if a["idx"].numel():
-                ops.gather(self.P, a["idx"], a["view"], a["idx2"])
+                self._gather(a)
         self._fb_stale = False
 
     def _need_fallback(self):

@@ -671,6 +671,29 @@ def test_flow_fragment_streaming_kernel_vs_bf16_rounding_oracle(gpu_lib, steps, 
     assert float(e1[2][:, :, 45:].abs().max()) == 0
 
 
+def test_affine_operand_gather_equals_the_indexed_one(gpu_lib):
+    """mhe_gather_affine8_bf16 (round 5: the train step's bf16 operand re-pack from (base, stride, validity) per eight elements) against
+    mhe_gather_f32 on the layouts the trainer derives from a weight tensor - padded, transposed, MFMA fragment order of both - and on
+    groups with holes, negative strides and a single element"""
+    from mhentropy_amd import ops
+    g = torch.Generator().manual_seed(7)
+    src = torch.randn(60000, generator=g).cuda()
+    W = torch.arange(512 * 45).view(512, 45) + 1000
+    pad = torch.full((512, 64), -1, dtype=torch.int64); pad[:, :45] = W
+    odd = torch.tensor([7, -1, 9, -1, 11, -1, -1, 14,   50, 40, 30, 20, 10, 0, -1, -1,   -1, -1, -1, 5, -1, -1, -1, -1,   3, 3, 3, 3, 3, 3, 3, 3,
+                        -1] * 1 + [-1] * 7, dtype=torch.int64)
+    for I in (pad.reshape(-1), pad.t().contiguous().reshape(-1), ops.mfma_fragment_major(pad).reshape(-1), ops.mfma_fragment_major(pad.t()).reshape(-1),
+              torch.arange(4096, dtype=torch.int64) + 16, torch.arange(4096, dtype=torch.int64) + 13, odd):
+        enc = ops.affine8(I)
+        assert enc is not None
+        a = torch.empty(I.numel(), device="cuda", dtype=torch.bfloat16)
+        b = torch.empty_like(a)
+        ops.gather_affine8(src, enc[0].cuda(), enc[1].cuda(), a)
+        ops.gather(src, I.to(torch.int32).cuda(), b)
+        assert torch.equal(a, b)
+    assert ops.affine8(torch.tensor([0, 1, 2, 4, 5, 6, 7, 8], dtype=torch.int64)) is None            # not affine: the indexed form stays
+
+
 @pytest.mark.parametrize("n", [8 * 1000, 8 * 1000 + 3, 1 << 20])
 def test_operand_gather_matches_torch_indexing(gpu_lib, n):
     """mhe_gather_f32: dst[i] = src[idx[i]] (0 where idx < 0) (+ src[idx2[i]]), f32 and bf16 destinations - the scalar kernel and the

@@ -1077,6 +1077,34 @@ def test_multi_problem_weight_gradient_launch(gpu_lib):
     assert all(torch.equal(it[6], f) for it, f in zip(items, first)), "two multi-problem calls differ: the summation order is not fixed"
 
 
+def test_operand_repack_from_affine_groups_equals_the_indexed_repack(gpu_lib):
+    """TrainStep.repack (round 5): the bf16 operand layouts (convolution weights in every tile order, the flow's fragment-major and fallback
+    layouts) come from (base, stride, validity) per eight elements.  Every group of the ResNet-50 + RealNVP arena is affine, and the
+    operands are the bits the one-index-per-element gather produces."""
+    from mhentropy_amd import harness, ops
+    from mhentropy_amd.train import TrainStep
+    torch.manual_seed(2)
+    model = harness.build_mhent(backbone="resnet50", tables=synth.mano_tables(0), compute_dtype=torch.bfloat16).cuda().train()
+    ts = TrainStep(model)
+    a = ts._arena[torch.bfloat16]
+    assert a["aff"] is not None and a["idx"].numel() > 5e7, "the bf16 arena is expected to be affine in groups of eight"
+    segs = a["aff"][2]
+    assert sum(hi - lo for kind, lo, hi in segs if kind == "idx") < 1e-3 * a["idx"].numel() / 8, segs      # (the stem's taps stay on indices)
+    with torch.no_grad():
+        ts.P.add_(torch.randn_like(ts.P) * 1e-3)          # operands of other parameters than the ones packed at construction
+    ts.repack()
+    got = a["view"].clone()
+    ops.gather(ts.P, a["idx"], a["view"], a["idx2"])
+    assert torch.equal(got, a["view"])
+    # (the fallback layouts - gathered only when a fallback path runs - go through the same choice: affine where every range qualifies)
+    ts._repack_fallback()
+    fb = ts._arena_fb[torch.bfloat16]
+    if fb["idx"].numel():
+        got = fb["view"].clone()
+        ops.gather(ts.P, fb["idx"], fb["view"], fb["idx2"])
+        assert torch.equal(got, fb["view"])
+
+
 def test_queued_multi_problem_weight_gradients_equal_one_launch_per_layer(gpu_lib):
     """TrainStep queues the trunk's weight gradients per gradient bucket and launches them together (MHE_WGRAD_MULTI, ops.conv_wgrad_multi).
     Two reverse passes over ONE forward pass's tape - queued vs one launch per layer: the same bf16 operands and products, f32 sums in another
