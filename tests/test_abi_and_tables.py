@@ -225,4 +225,7 @@ def test_switch_table_matches_the_source():
     assert set(found) == set(switches.SWITCHES), (sorted(set(found) - set(switches.SWITCHES)), sorted(set(switches.SWITCHES) - set(found)))
     for k, defaults in found.items():
         assert all(d == switches.SWITCHES[k][0] for d in defaults), (k, defaults, switches.SWITCHES[k][0])
+    # DESIGN.md prints this very table
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    assert switches.markdown_table().strip() in design, "DESIGN.md's switch table is not mhentropy_amd.switches.markdown_table()"
     assert switches.non_default({}) == {} and switches.non_default({"MHE_CONV_HALO": "1"}) == {} and switches.non_default({"MHE_CONV_HALO": "0"}) == {"MHE_CONV_HALO": "0"}
