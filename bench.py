@@ -219,7 +219,7 @@ def time_iteration_with_metrics(ts, x, y, noise, B, K, args, dist, world, dev):
         out = it()
         torch.cuda.synchronize()
         run = it
-        if args.graph and world == 1:
+        if args.graph:        # (data parallel: the same cut graphs as the train-step leg - a bucket's exchange between two graph launches)
             try:
                 from mhentropy_amd.train import GraphedStep
                 g = GraphedStep(ts, x, y, noise=noise, N=K, test_samples=n, criterion=crit)
