@@ -626,6 +626,16 @@ int mhe_lbs_pose_f32(const float *rotmats, const float *betas, const float *j_te
                      const int *parents, float *workspace, float *joints, int R, int J, int nb, void *stream);
 int mhe_lbs_skin_f32(const float *workspace, const float *v_template, const float *v_shapedirs, const float *v_posedirs,
                      const float *v_weights, float *verts, int R, int J, int nb, int NV, int VP, float scale, void *stream);
+/* mhe_lbs_skin_f32 on the matrix cores (csrc/lbs_skin.hip: the scheme of csrc/mano_skin.hip at runtime sizes - both products as GEMMs on bf16
+ * pieces of the f32 operands, f32-class accuracy).  The table pieces are made once per model: `split` = mhe_lbs_split_floats(J, nb, VP) floats,
+ * filled by mhe_lbs_split_tables_f32 from the same four vertex tables (VP a multiple of 32); the skinning launch then takes the workspace rows of
+ * mhe_lbs_pose_f32 and `split`.  mhe_lbs_skin_mfma_supported: J <= 32, the hypotheses' pieces within the LDS, the output within 4 GiB. */
+size_t mhe_lbs_split_floats(int J, int nb, int VP);
+int mhe_lbs_split_tables_f32(const float *v_template, const float *v_shapedirs, const float *v_posedirs, const float *v_weights,
+                             float *split, int J, int nb, int VP, void *stream);
+int mhe_lbs_skin_mfma_supported(int R, int J, int nb, int NV, int VP);
+int mhe_lbs_skin_mfma_f32(const float *workspace, const float *split, float *verts, int R, int J, int nb, int NV, int VP, float scale,
+                          void *stream);
 
 /* Train-mode BatchNorm(+ReLU) reverse over NHWC activations of storage `dtype` (F.batch_norm backward):
  *   g' = g [a > 0] (a = the unit's post-activation output, NULL = no ReLU);  xhat = (y - mean) invstd

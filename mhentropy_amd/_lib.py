@@ -162,6 +162,10 @@ SIGNATURES = {
     "mhe_lbs_workspace_floats": (_sz, [_i, _i, _i]),
     "mhe_lbs_pose_f32": (_i, [_p] * 7 + [_i, _i, _i, _p]),
     "mhe_lbs_skin_f32": (_i, [_p] * 6 + [_i, _i, _i, _i, _i, _f, _p]),
+    "mhe_lbs_split_floats": (_sz, [_i, _i, _i]),
+    "mhe_lbs_split_tables_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "mhe_lbs_skin_mfma_supported": (_i, [_i, _i, _i, _i, _i]),
+    "mhe_lbs_skin_mfma_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "mhe_topk_gather_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mhe_metrics_f32": (_i, [_p] * 7 + [_i, _i, _p]),
 }

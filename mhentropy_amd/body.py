@@ -12,6 +12,8 @@ Hypotheses are independent given the conditioning feature, so `forward` takes an
 hypothesis-sharded form is `dist.HypothesisShards` around this layer."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -83,6 +85,17 @@ class BodyLayer(nn.Module):
         self.register_buffer("_vpd", f(vp(t["posedirs"].transpose(2, 1, 0))), persistent=False)                             # [9(J-1)][3][VP]
         self.register_buffer("_vw", f(vp(t["weights"].T)), persistent=False)                                                # [J][VP]
 
+    def _split_tables(self, dev):
+        """the vertex tables as bf16 pieces in MFMA operand order (19 MB for SMPL), made on first use per device; the tables are fixed buffers"""
+        key = (dev.type, dev.index, self._vt.data_ptr())
+        if getattr(self, "_split_key", None) != key:
+            L = _lib.lib()
+            sp = torch.empty(L.mhe_lbs_split_floats(self.J, self.nb, self.VP), device=dev, dtype=torch.float32)
+            ops.check(L.mhe_lbs_split_tables_f32(ops._ptr(self._vt), ops._ptr(self._vsd), ops._ptr(self._vpd), ops._ptr(self._vw), ops._ptr(sp),
+                                                 self.J, self.nb, self.VP, ops._stream()), "mhe_lbs_split_tables_f32")
+            self._split, self._split_key = sp, key
+        return self._split
+
     def forward(self, betas, rotmats=None, pose6d=None, scale=1.0, want_verts=True):
         """betas (R,nb); rotmats (R,J,3,3) or pose6d (R,6J) -> {'vertices' (R,NV,3), 'joints' (R,J,3), 'rotmats'}"""
         if rotmats is None:
@@ -98,6 +111,12 @@ class BodyLayer(nn.Module):
         out = {"joints": joints, "rotmats": rotmats}
         if want_verts:
             verts = torch.empty(R, self.NV, 3, device=dev, dtype=torch.float32)
+            if os.environ.get("MHE_LBS_MFMA", "1") == "1" and self.VP % 32 == 0 and L.mhe_lbs_skin_mfma_supported(R, self.J, self.nb, self.NV, self.VP):
+                # both products on the matrix cores from bf16 pieces of the f32 operands (csrc/lbs_skin.hip); the table pieces are made once
+                ops.check(L.mhe_lbs_skin_mfma_f32(ops._ptr(ws), ops._ptr(self._split_tables(dev)), ops._ptr(verts), R, self.J, self.nb, self.NV, self.VP,
+                                                  float(scale), ops._stream()), "mhe_lbs_skin_mfma_f32")
+                out["vertices"] = verts
+                return out
             ops.check(L.mhe_lbs_skin_f32(ops._ptr(ws), ops._ptr(self._vt), ops._ptr(self._vsd), ops._ptr(self._vpd), ops._ptr(self._vw), ops._ptr(verts),
                                          R, self.J, self.nb, self.NV, self.VP, float(scale), ops._stream()), "mhe_lbs_skin_f32")
             out["vertices"] = verts

@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libmhe_hip.so")
-SOURCES = ["api.hip", "rng.hip", "mano.hip", "mano_skin.hip", "mano_bwd.hip", "flow.hip", "flow_bf16.hip", "flow_ns.hip", "conv.hip", "conv_p8.hip", "conv_stream.hip", "conv_tail.hip", "conv_fuse.hip", "conv_gram.hip", "conv_fold.hip", "conv_halo.hip", "stem_pool.hip", "conv_wide.hip", "wgrad.hip", "flow_bwd.hip", "flow_rev.hip", "flow_fwd.hip", "trunk_bwd.hip", "glow.hip", "glow_affine.hip", "glow_fwd.hip", "glow_rev.hip", "metrics.hip", "body.hip", "ho3d.hip"]
+SOURCES = ["api.hip", "rng.hip", "mano.hip", "mano_skin.hip", "mano_bwd.hip", "flow.hip", "flow_bf16.hip", "flow_ns.hip", "conv.hip", "conv_p8.hip", "conv_stream.hip", "conv_tail.hip", "conv_fuse.hip", "conv_gram.hip", "conv_fold.hip", "conv_halo.hip", "stem_pool.hip", "conv_wide.hip", "wgrad.hip", "flow_bwd.hip", "flow_rev.hip", "flow_fwd.hip", "trunk_bwd.hip", "glow.hip", "glow_affine.hip", "glow_fwd.hip", "glow_rev.hip", "metrics.hip", "body.hip", "lbs_skin.hip", "ho3d.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"] + os.environ.get("MHE_EXTRA_FLAGS", "").split()
 

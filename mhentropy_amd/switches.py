@@ -36,6 +36,7 @@ SWITCHES = {
     "MHE_GLOW_FUSED": ("1", "glow.py, train_glow.py", "0: the Glow branch's sampling pass layer by layer (~60 launches) instead of the one-launch kernel"),
     "MHE_GLOW_REV_FUSED": ("1", "train_glow.py", "0: the Glow branch's reverse pass over the tape stage by stage instead of the one-launch chain (csrc/glow_rev.hip)"),
     "MHE_MANO_FOUR": ("1", "csrc/mano.hip", "0: one hypothesis per wavefront"),
+    "MHE_LBS_MFMA": ("1", "body.py", "0: the body model's skinning with one thread per vertex (csrc/body.hip) instead of the matrix-core kernel (csrc/lbs_skin.hip)"),
     "MHE_MANO_SKIN_MFMA": ("1", "csrc/mano.hip", "0: full-mesh skinning with one thread per vertex (round 1) instead of the matrix-core kernel on bf16 pieces (csrc/mano_skin.hip)"),
     # ---- train step (train.py / csrc/wgrad.hip, trunk_bwd.hip)
     "MHE_TRAIN_RECOMPUTE": ("1", "train.py", "0: conv3 of layer1 / layer2 written by the train step's forward pass"),

@@ -42,7 +42,7 @@ def test_generic_lbs_at_mano_size_matches_reference_mesh(gpu_lib):
     assert_close(((out["vertices"] - centre) * 1000).cpu(), g["mesh"], 1e-4, what="mesh (mm, centred on joint 9)")
 
 
-@pytest.mark.parametrize("R", [1, 5, 19])
+@pytest.mark.parametrize("R", [1, 5, 19, 70])
 def test_generic_lbs_at_smpl_size_matches_oracle(gpu_lib, R):
     from mhentropy_amd import body
     from oracle import body_ref, rot6d_ref
@@ -59,6 +59,27 @@ def test_generic_lbs_at_smpl_size_matches_oracle(gpu_lib, R):
     assert_close(out["rotmats"].cpu(), rm, 1e-6, what="rotation matrices")
     assert_close(out["joints"].cpu(), joints, 1e-4, what="posed joints")
     assert_close(out["vertices"].cpu(), verts, 1e-4, what="vertices")
+    # round 5: the skinning runs on the matrix cores from bf16 pieces of the f32 operands (csrc/lbs_skin.hip) - against the f64 oracle it stays
+    # within three times the f32 oracle's own distance (floor 2e-6 of the mesh's extent)
+    tb64 = {k: (torch.as_tensor(v).double() if np.asarray(v).dtype.kind == "f" else torch.as_tensor(v)) for k, v in t.items()}
+    v64, _ = body_ref.lbs(tb64, rm.double(), betas.double())
+    ext = float(v64.abs().max())
+    e_gpu, e_f32 = float((out["vertices"].cpu().double() - v64).abs().max()) / ext, float((verts.double() - v64).abs().max()) / ext
+    print(f"SMPL-size mesh R={R}: max error / extent  HIP {e_gpu:.2e}   f32 oracle {e_f32:.2e}")
+    assert e_gpu <= max(3 * e_f32, 2e-6), (e_gpu, e_f32)
+    big = torch.full((R + 40, 6890, 3), -7.0, device="cuda")          # rows past R are not stored
+    from mhentropy_amd import _lib, ops
+    L = _lib.lib()
+    if L.mhe_lbs_skin_mfma_supported(R, 24, 10, 6890, layer.VP):
+        ws = torch.empty(L.mhe_lbs_workspace_floats(R, 24, 10), device="cuda")
+        jt = torch.empty(R, 24, 3, device="cuda")
+        rmd, bd = out["rotmats"].contiguous(), betas.cuda().contiguous()
+        ops.check(L.mhe_lbs_pose_f32(ops._ptr(rmd), ops._ptr(bd), ops._ptr(layer._jt), ops._ptr(layer._jsd), ops._ptr(layer.parents), ops._ptr(ws), ops._ptr(jt),
+                                     R, 24, 10, ops._stream()), "pose")
+        ops.check(L.mhe_lbs_skin_mfma_f32(ops._ptr(ws), ops._ptr(layer._split_tables(torch.device("cuda", 0))), ops._ptr(big), R, 24, 10, 6890, layer.VP, 1.0,
+                                          ops._stream()), "skin")
+        assert_close(big[:R].cpu(), out["vertices"].cpu(), 1e-5, what="direct call")          # (bit-equal unless MHE_LBS_MFMA=0 chose the other kernel above)
+        assert bool((big[R:] == -7.0).all())
 
 
 def test_body_flow_head_and_hypothesis_slices(gpu_lib):
